@@ -1,0 +1,514 @@
+"""Seeded, backend-agnostic test cases for the ABI.
+
+Every case is a callable `run(be) -> dict[str, np.ndarray | int | ...]` that builds its inputs
+with `be`'s own allocator, calls the ABI, and returns the observable outputs.  Two backends are
+at parity on a case when the returned dicts are equal (see `assert_same`).  Inputs avoid what is
+undefined behaviour in the reference itself (integer division by zero, INT_MIN / -1,
+out-of-range float->int conversions), as the reference's HOST and DEVICE builds already
+disagree there.
+"""
+import ctypes as C
+
+import numpy as np
+
+import harness as H
+from aresdb_amd import abi
+
+INT_TYPES = [abi.Int8, abi.Uint8, abi.Int16, abi.Uint16, abi.Int32, abi.Uint32]
+COL_TYPES = [abi.Bool] + INT_TYPES + [abi.Float32]
+UNARY_INT = [abi.Negate, abi.Not, abi.BitwiseNot, abi.IsNull, abi.IsNotNull, abi.Noop,
+             abi.GetWeekStart, abi.GetMonthStart, abi.GetQuarterStart, abi.GetYearStart,
+             abi.GetDayOfMonth, abi.GetDayOfYear, abi.GetMonthOfYear, abi.GetQuarterOfYear]
+UNARY_FLOAT = [abi.Negate, abi.Not, abi.IsNull, abi.IsNotNull, abi.Noop, abi.GetMonthStart]
+BINARY_ALL = list(range(abi.And, abi.Floor + 1))
+BINARY_FLOAT_OK = list(range(abi.And, abi.Divide + 1)) + [abi.Mod, abi.Floor]  # last two: "return lhs"
+
+
+def _rand_values(rng, dtype, n, small=False, nonzero=False, nonneg=False):
+    if dtype == abi.Bool:
+        return rng.integers(0, 2, n).astype(bool)
+    if dtype == abi.Float32:
+        v = (rng.random(n) * (90 if small else 1000) + (1 if nonzero else 0)).astype(np.float32)
+        if not nonneg:
+            v = v * rng.choice([-1, 1], n).astype(np.float32)
+        v = np.round(v * 4) / 4  # exactly representable quarters
+        return v.astype(np.float32)
+    info = np.iinfo(H._NP_OF[dtype])
+    lo, hi = int(info.min), int(info.max)
+    if small:
+        lo, hi = max(lo, -100), min(hi, 100)
+    else:
+        lo, hi = max(lo, -(1 << 30)), min(hi, (1 << 30))
+    if nonneg:
+        lo = max(lo, 0)
+    v = rng.integers(lo, hi + 1, n)
+    if nonzero:
+        v[v == 0] = 1
+    return v.astype(H._NP_OF[dtype])
+
+
+class ColSpec:
+    """Logical description of a column; materialised per backend."""
+
+    def __init__(self, rng, dtype, mode, rows, **kw):
+        self.dtype, self.mode, self.rows = dtype, mode, rows
+        self.starting_index = int(rng.integers(0, 8)) if mode in (2, 3) or dtype == abi.Bool else 0
+        if mode == 1 and dtype != abi.Bool:
+            self.starting_index = 0
+        self.default = None
+        self.values = self.valid = self.counts = None
+        if mode == 0:
+            if rng.random() < 0.8:
+                self.default = _rand_values(rng, dtype, 1, **kw)[0]
+                if dtype != abi.Bool and dtype != abi.Float32:
+                    self.default = int(self.default)
+        elif mode in (1, 2):
+            self.values = _rand_values(rng, dtype, rows, **kw)
+            if mode == 2:
+                self.valid = rng.random(rows) > 0.25
+        else:  # run-length compressed: `runs` runs covering `rows` logical rows
+            runs = max(1, int(rng.integers(1, max(2, rows // 2 + 1))))
+            cuts = np.sort(rng.choice(np.arange(1, rows), size=min(runs - 1, rows - 1), replace=False)) \
+                if rows > 1 else np.array([], np.int64)
+            self.counts = np.concatenate([[0], cuts, [rows]]).astype(np.uint32)
+            nruns = len(self.counts) - 1
+            self.values = _rand_values(rng, dtype, nruns, **kw)
+            self.valid = rng.random(nruns) > 0.25
+
+    def build(self, be):
+        if self.mode == 0:
+            return H.Column(be, self.dtype, default=self.default)
+        return H.Column(be, self.dtype, self.values, valid=self.valid, counts=self.counts,
+                        starting_index=self.starting_index)
+
+
+class OperandSpec:
+    KINDS = ("col", "scratch", "cint", "cfloat")
+
+    def __init__(self, rng, kind, rows, n, dtype=None, mode=None, **kw):
+        self.kind, self.n = kind, n
+        if kind == "col":
+            self.col = ColSpec(rng, dtype if dtype is not None else rng.choice(COL_TYPES),
+                               mode if mode is not None else int(rng.integers(0, 4)), rows, **kw)
+        elif kind == "scratch":
+            self.dtype = dtype if dtype in (abi.Int32, abi.Uint32, abi.Float32) else \
+                [abi.Int32, abi.Uint32, abi.Float32][int(rng.integers(0, 3))]
+            self.values = _rand_values(rng, self.dtype, n, **kw)
+            self.valid = rng.random(n) > 0.25
+        elif kind == "cint":
+            self.value = int(_rand_values(rng, abi.Int32, 1, **kw)[0])
+            self.valid = bool(rng.random() > 0.1)
+        else:
+            self.value = float(_rand_values(rng, abi.Float32, 1, **kw)[0])
+            self.valid = bool(rng.random() > 0.1)
+
+    def is_float(self):
+        if self.kind == "col":
+            return self.col.dtype == abi.Float32
+        if self.kind == "scratch":
+            return self.dtype == abi.Float32
+        return self.kind == "cfloat"
+
+    def uses_rle(self):
+        return self.kind == "col" and self.col.mode == 3
+
+    def build(self, be, keep):
+        if self.kind == "col":
+            c = self.col.build(be)
+            keep.append(c)
+            return c.input()
+        if self.kind == "scratch":
+            s = H.Scratch(be, self.n, self.dtype, self.values, self.valid)
+            keep.append(s)
+            return s.input()
+        if self.kind == "cint":
+            return H.const_int(self.value, self.valid)
+        return H.const_float(self.value, self.valid)
+
+
+class OutSpec:
+    def __init__(self, kind, dtype, agg=None):
+        self.kind, self.dtype, self.agg = kind, dtype, agg
+
+    def build(self, be, n, keep):
+        if self.kind == "scratch":
+            s = H.Scratch(be, n, self.dtype)
+            keep.append(s)
+            return s.output(), lambda: {"values": s.buf.read(np.uint8, 4 * n), "valid": s.valid()}
+        w = abi.DATA_TYPE_BYTES[self.dtype]
+        if self.kind == "dim":
+            vb = H.Buf(be, nbytes=w * n + 8)
+            nb = H.Buf(be, nbytes=n + 8)
+            keep.extend([vb, nb])
+            return H.dimension_output(vb.ptr, nb.ptr, self.dtype), \
+                lambda: {"values": vb.read(np.uint8, w * n), "valid": nb.read(np.uint8, n)}
+        vb = H.Buf(be, nbytes=w * n + 8)
+        keep.append(vb)
+        return H.measure_output(vb.ptr, self.dtype, self.agg), \
+            lambda: {"values": vb.read(np.uint8, w * n)}
+
+
+def make_index(rng, rows, style):
+    """Index vectors as the filters leave them (sorted subsets) plus a permuted one."""
+    if style == "identity":
+        return np.arange(rows, dtype=np.uint32)
+    if style == "subset":
+        keep = rng.random(rows) > 0.4
+        idx = np.nonzero(keep)[0].astype(np.uint32)
+        return idx if len(idx) else np.array([0], np.uint32)
+    return rng.permutation(rows).astype(np.uint32)
+
+
+class TransformCase:
+    """Unary/BinaryTransform and Unary/BinaryFilter."""
+
+    def __init__(self, seed, arity, as_filter, rows=None, index_style=None):
+        rng = np.random.default_rng(seed)
+        self.seed, self.arity, self.as_filter = seed, arity, as_filter
+        self.rows = rows if rows is not None else int(rng.integers(1, 300))
+        style = index_style or ["identity", "subset", "perm"][int(rng.integers(0, 3))]
+        if as_filter and style == "perm":
+            style = "subset"
+        self.index = make_index(rng, self.rows, style)
+        self.n = len(self.index)
+        n = self.n
+        self.base_counts = None
+        self.start_count = 0
+        if arity == 1:
+            kind = ["col", "col", "col", "scratch", "cint"][int(rng.integers(0, 5))]
+            a = OperandSpec(rng, kind, self.rows, n, small=True, nonneg=True)
+            self.ops = [a]
+            self.functor = int(rng.choice(UNARY_FLOAT if a.is_float() else UNARY_INT))
+            if kind == "col" and a.col.dtype not in (abi.Float32, abi.Bool) and \
+                    self.functor >= abi.GetWeekStart:
+                # calendar functors: realistic epoch seconds
+                a.col.values = None if a.col.mode == 0 else \
+                    rng.integers(0, 1 << 31, len(a.col.values)).astype(H._NP_OF[a.col.dtype]) \
+                    if a.col.dtype in (abi.Int32, abi.Uint32) else a.col.values
+        else:
+            ka = ["col", "col", "scratch", "cint", "cfloat"][int(rng.integers(0, 5))]
+            kb = ["col", "scratch", "cint", "cfloat"][int(rng.integers(0, 4))]
+            if ka in ("cint", "cfloat") and kb in ("cint", "cfloat"):
+                kb = "col"
+            a = OperandSpec(rng, ka, self.rows, n, small=True)
+            b = OperandSpec(rng, kb, self.rows, n, small=True, nonzero=True)
+            if b.kind == "col" and b.col.dtype == abi.Bool:  # bool divisors may be 0
+                b = OperandSpec(rng, "col", self.rows, n, dtype=abi.Int16, small=True, nonzero=True)
+            self.ops = [a, b]
+            anyf = a.is_float() or b.is_float()
+            self.functor = int(rng.choice(BINARY_FLOAT_OK if anyf else BINARY_ALL))
+        if any(o.uses_rle() for o in self.ops):
+            # logical row r of the batch maps to compressed position via baseCounts/startCount
+            if rng.random() < 0.5:
+                self.start_count = 0
+            else:
+                # identity baseCounts vector (uncompressed base column)
+                self.base_counts = np.arange(self.rows + 1, dtype=np.uint32)
+        anyf = any(o.is_float() for o in self.ops)
+        if as_filter:
+            self.out = None
+            self.num_foreign = int(rng.integers(0, 3))
+            self.rids = [np.stack([rng.integers(1, 5, n), rng.integers(0, 1000, n)], 1).astype(np.uint32)
+                         for _ in range(self.num_foreign)]
+        else:
+            choice = int(rng.integers(0, 3))
+            if choice == 0:
+                dt = [abi.Int32, abi.Uint32, abi.Float32][int(rng.integers(0, 3))]
+                self.out = OutSpec("scratch", dt)
+            elif choice == 1:
+                dts = [abi.Bool, abi.Int8, abi.Uint8, abi.Int16, abi.Uint16, abi.Int32, abi.Uint32, abi.Float32]
+                self.out = OutSpec("dim", dts[int(rng.integers(0, len(dts)))])
+            else:
+                dts = [abi.Int32, abi.Uint32, abi.Float32, abi.Int64, abi.Float64]
+                aggs = [abi.AGGR_SUM_UNSIGNED, abi.AGGR_SUM_SIGNED, abi.AGGR_SUM_FLOAT,
+                        abi.AGGR_MIN_UNSIGNED, abi.AGGR_MIN_SIGNED, abi.AGGR_MAX_UNSIGNED,
+                        abi.AGGR_MAX_SIGNED, abi.AGGR_AVG_FLOAT]
+                agg = aggs[int(rng.integers(0, len(aggs)))]
+                dt = dts[int(rng.integers(0, len(dts)))]
+                if agg == abi.AGGR_AVG_FLOAT:
+                    dt = abi.Float64
+                self.out = OutSpec("measure", dt, agg)
+                if self.base_counts is None and rng.random() < 0.5 and not any(o.uses_rle() for o in self.ops):
+                    # compressed base column: run lengths multiply SUM/AVG
+                    lens = rng.integers(1, 5, self.rows)
+                    self.base_counts = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
+            # out-of-range float -> integer conversions are UB in the reference (negative ->
+            # unsigned, |x| >= 2^(bits-1)): floats only meet 32/64-bit signed or float sinks
+            if anyf and self.out.dtype in (abi.Int8, abi.Uint8, abi.Int16, abi.Uint16, abi.Uint32):
+                self.out.dtype = abi.Int32
+
+    def __repr__(self):
+        return f"TransformCase(seed={self.seed}, arity={self.arity}, filter={self.as_filter})"
+
+    def run(self, be):
+        keep = []
+        ins = [o.build(be, keep) for o in self.ops]
+        idx = H.Buf(be, self.index)
+        bc = H.Buf(be, self.base_counts) if self.base_counts is not None else None
+        bcp = bc.ptr if bc else None
+        n = self.n
+        res = {}
+        if self.as_filter:
+            pred = H.Buf(be, nbytes=n + 8)
+            rbufs = [H.Buf(be, r) for r in self.rids]
+            vecs = (C.c_void_p * max(1, len(rbufs)))(*[b.ptr for b in rbufs])
+            name = "UnaryFilter" if self.arity == 1 else "BinaryFilter"
+            cnt = be.call(name, *ins, idx.ptr, pred.ptr, n, C.addressof(vecs) if rbufs else None,
+                          len(rbufs), bcp, self.start_count, self.functor, None, 0)
+            res["count"] = cnt
+            res["pred"] = pred.read(np.uint8, n)
+            res["index"] = idx.read(np.uint32, cnt)
+            for i, b in enumerate(rbufs):
+                res[f"rid{i}"] = b.read(np.uint32, 2 * cnt)
+            keep.extend([pred] + rbufs)
+        else:
+            ov, reader = self.out.build(be, n, keep)
+            name = "UnaryTransform" if self.arity == 1 else "BinaryTransform"
+            res["ret"] = be.call(name, *ins, ov, idx.ptr, n, bcp, self.start_count, self.functor,
+                                 None, 0)
+            res.update(reader())
+        for k in keep + [idx] + ([bc] if bc else []):
+            k.free()
+        return res
+
+
+# ---- cuckoo index builder (layout of memstore/cuckoo_index.go; see oracle HashLookup) ----------
+def _murmur3_32(key: bytes, seed: int) -> int:
+    h = seed & 0xFFFFFFFF
+    nb = len(key) // 4
+    for i in range(nb):
+        k = int.from_bytes(key[4 * i:4 * i + 4], "little")
+        k = (k * 0xcc9e2d51) & 0xFFFFFFFF
+        k = ((k << 15) | (k >> 17)) & 0xFFFFFFFF
+        k = (k * 0x1b873593) & 0xFFFFFFFF
+        h ^= k
+        h = ((h << 13) | (h >> 19)) & 0xFFFFFFFF
+        h = (h * 5 + 0xe6546b64) & 0xFFFFFFFF
+    tail = key[4 * nb:]
+    k = 0
+    if len(tail) >= 3:
+        k ^= tail[2] << 16
+    if len(tail) >= 2:
+        k ^= tail[1] << 8
+    if len(tail) >= 1:
+        k ^= tail[0]
+        k = (k * 0xcc9e2d51) & 0xFFFFFFFF
+        k = ((k << 15) | (k >> 17)) & 0xFFFFFFFF
+        k = (k * 0x1b873593) & 0xFFFFFFFF
+        h ^= k
+    h ^= len(key)
+    h ^= h >> 16
+    h = (h * 0x85ebca6b) & 0xFFFFFFFF
+    h ^= h >> 13
+    h = (h * 0xc2b2ae35) & 0xFFFFFFFF
+    h ^= h >> 16
+    return h
+
+
+def build_cuckoo(keys, key_bytes, num_buckets, seeds, rng, record_of=None):
+    """Places each key in the first free slot among its 4 candidate buckets, else the stash.
+    (Insertion policy does not matter to the probe; only the layout does.)"""
+    bucket_bytes = 8 * (8 + 1 + key_bytes)
+    table = np.zeros((num_buckets + 1) * bucket_bytes, np.uint8)
+    placed = {}
+    for ki, key in enumerate(keys):
+        rec = record_of(ki) if record_of else (1 + ki // 1000, ki % 1000)
+        done = False
+        order = list(range(len(seeds)))
+        rng.shuffle(order)
+        for h in order:
+            hv = _murmur3_32(key, seeds[h])
+            b = hv % num_buckets
+            sig = max(1, hv >> 24)
+            base = b * bucket_bytes
+            for j in range(8):
+                if table[base + 64 + j] == 0:
+                    table[base + 8 * j: base + 8 * j + 8] = np.array(rec, np.uint32).view(np.uint8)
+                    table[base + 64 + j] = sig
+                    table[base + 72 + j * key_bytes: base + 72 + (j + 1) * key_bytes] = \
+                        np.frombuffer(key, np.uint8)
+                    done = True
+                    break
+            if done:
+                break
+        if not done:
+            base = num_buckets * bucket_bytes
+            for j in range(4):
+                if table[base + 64 + j] == 0:
+                    table[base + 8 * j: base + 8 * j + 8] = np.array(rec, np.uint32).view(np.uint8)
+                    table[base + 64 + j] = 1
+                    table[base + 72 + j * key_bytes: base + 72 + (j + 1) * key_bytes] = \
+                        np.frombuffer(key, np.uint8)
+                    done = True
+                    break
+        if done:
+            placed[key] = rec
+    return table, placed
+
+
+class HashLookupCase:
+    def __init__(self, seed, n=None, nkeys=None):
+        rng = np.random.default_rng(seed)
+        self.seed = seed
+        self.dtype = [abi.Uint32, abi.Int32, abi.Uint16, abi.Uint8, abi.Int64, abi.UUID][int(rng.integers(0, 6))]
+        self.key_bytes = {abi.Uint32: 4, abi.Int32: 4, abi.Uint16: 2, abi.Uint8: 1, abi.Int64: 8,
+                          abi.UUID: 16}[self.dtype]
+        nkeys = nkeys or int(rng.integers(1, 200))
+        if self.key_bytes == 1:
+            nkeys = min(nkeys, 100)
+        space = min(1 << (8 * min(self.key_bytes, 4)), 1 << 20)
+        raw = rng.choice(space, size=min(nkeys, space // 2), replace=False)
+        self.keys = [int(k).to_bytes(self.key_bytes, "little") for k in raw]
+        self.num_buckets = max(1, len(self.keys) // 5)  # dense enough to exercise the stash
+        self.seeds = [int(x) for x in rng.integers(0, 1 << 32, 4)]
+        self.table, self.placed = build_cuckoo(self.keys, self.key_bytes, self.num_buckets,
+                                               self.seeds, rng)
+        self.rows = n or int(rng.integers(1, 400))
+        probe = rng.choice(space, size=self.rows)  # hits and misses
+        hit = rng.random(self.rows) < 0.6
+        probe[hit] = rng.choice(raw, size=int(hit.sum()))
+        self.probe = probe
+        self.valid = rng.random(self.rows) > 0.1
+        self.index = make_index(rng, self.rows, "subset")
+
+    def run(self, be):
+        if self.dtype in (abi.Int64, abi.UUID):
+            w = abi.DATA_TYPE_BYTES[self.dtype]
+            rawv = b"".join(int(p).to_bytes(w, "little") for p in self.probe)
+            col = H.Column(be, self.dtype, raw_values=rawv, valid=self.valid)
+        else:
+            col = H.Column(be, self.dtype, self.probe.astype(np.int64).astype(H._NP_OF[self.dtype]),
+                           valid=self.valid)
+        tb = H.Buf(be, self.table)
+        hi = abi.CuckooHashIndex()
+        hi.buckets = tb.ptr
+        for i, s in enumerate(self.seeds):
+            hi.seeds[i] = s
+        hi.keyBytes, hi.numHashes, hi.numBuckets = self.key_bytes, 4, self.num_buckets
+        idx = H.Buf(be, self.index)
+        n = len(self.index)
+        out = H.Buf(be, np.full(2 * n, 0xAAAAAAAA, np.uint32))
+        be.call("HashLookup", col.input(), out.ptr, idx.ptr, n, None, 0, hi, None, 0)
+        res = {"rids": out.read(np.uint32, 2 * n)}
+        for b in (col, tb, idx, out):
+            b.free()
+        return res
+
+
+class GroupByCase:
+    """Dimension vector + measures -> Sort/Reduce and HashReduce."""
+
+    def __init__(self, seed, length=None, groups=None, ndw=None, agg=None, value_bytes=None,
+                 capacity_slack=None):
+        rng = np.random.default_rng(seed)
+        self.seed = seed
+        self.ndw = ndw or tuple(int(x) for x in rng.integers(0, 3, 5))
+        if sum(self.ndw) == 0:
+            self.ndw = (0, 0, 1, 0, 0)
+        while sum(w * c for w, c in zip(H.DIM_WIDTHS, self.ndw)) + sum(self.ndw) > 32:
+            self.ndw = tuple(max(0, c - 1) if i < 2 else c for i, c in enumerate(self.ndw))
+        self.length = length if length is not None else int(rng.integers(1, 2000))
+        self.capacity = self.length + (capacity_slack if capacity_slack is not None else int(rng.integers(0, 50)))
+        ngroups = groups or max(1, int(rng.integers(1, max(2, self.length // 3 + 1))))
+        # distinct group rows
+        self.offsets = []
+        value_bytes_total = sum(w * c for w, c in zip(H.DIM_WIDTHS, self.ndw))
+        ndims = sum(self.ndw)
+        protos = []
+        for _ in range(ngroups):
+            vals = [rng.integers(0, 256, w, dtype=np.uint8) if rng.random() < 0.9 else
+                    np.zeros(w, np.uint8) for w, c in zip(H.DIM_WIDTHS, self.ndw) for _ in range(c)]
+            valid = (rng.random(ndims) > 0.1).astype(np.uint8)
+            protos.append((vals, valid))
+        pick = rng.integers(0, ngroups, self.length)
+        blob = np.zeros((value_bytes_total + ndims) * self.capacity, np.uint8)
+        off, d = 0, 0
+        for w, c in zip(H.DIM_WIDTHS, self.ndw):
+            for _ in range(c):
+                col = np.stack([protos[g][0][d] for g in pick]).reshape(-1)
+                blob[off:off + w * self.length] = col
+                noff = value_bytes_total * self.capacity + d * self.capacity
+                blob[noff:noff + self.length] = [protos[g][1][d] for g in pick]
+                off += w * self.capacity
+                d += 1
+        self.blob = blob
+        aggs = [abi.AGGR_SUM_UNSIGNED, abi.AGGR_SUM_SIGNED, abi.AGGR_SUM_FLOAT, abi.AGGR_MIN_UNSIGNED,
+                abi.AGGR_MIN_SIGNED, abi.AGGR_MIN_FLOAT, abi.AGGR_MAX_UNSIGNED, abi.AGGR_MAX_SIGNED,
+                abi.AGGR_MAX_FLOAT, abi.AGGR_AVG_FLOAT]
+        self.agg = agg if agg is not None else aggs[int(rng.integers(0, len(aggs)))]
+        is_sum = self.agg in (abi.AGGR_SUM_UNSIGNED, abi.AGGR_SUM_SIGNED, abi.AGGR_SUM_FLOAT)
+        self.value_bytes = value_bytes or (int(rng.choice([4, 8])) if is_sum else
+                                           (8 if self.agg == abi.AGGR_AVG_FLOAT else 4))
+        n = self.length
+        if self.agg == abi.AGGR_AVG_FLOAT:
+            v = np.zeros(2 * n, np.uint32)
+            v[0::2] = (rng.integers(0, 400, n) / 4).astype(np.float32).view(np.uint32)
+            v[1::2] = rng.integers(1, 4, n)
+            self.values = v.view(np.uint8)
+        elif self.agg in (abi.AGGR_SUM_FLOAT, abi.AGGR_MIN_FLOAT, abi.AGGR_MAX_FLOAT):
+            f = (rng.integers(-4000, 4000, n) / 8)
+            self.values = (f.astype(np.float64) if self.value_bytes == 8 else f.astype(np.float32)).view(np.uint8)
+        elif self.agg in (abi.AGGR_SUM_SIGNED, abi.AGGR_MIN_SIGNED, abi.AGGR_MAX_SIGNED):
+            i = rng.integers(-100000, 100000, n)
+            self.values = (i.astype(np.int64) if self.value_bytes == 8 else i.astype(np.int32)).view(np.uint8)
+        else:
+            i = rng.integers(0, 100000, n)
+            self.values = (i.astype(np.uint64) if self.value_bytes == 8 else i.astype(np.uint32)).view(np.uint8)
+        self.vb = 8 if self.value_bytes == 8 else 4
+
+    def _dims(self, be, with_sort):
+        din = H.DimVector(be, self.capacity, self.ndw, with_hash=with_sort, with_index=with_sort,
+                          init=self.blob)
+        dout = H.DimVector(be, self.capacity, self.ndw, with_hash=with_sort, with_index=with_sort)
+        return din, dout
+
+    def run_sort_reduce(self, be):
+        din, dout = self._dims(be, True)
+        vin = H.Buf(be, self.values)
+        vout = H.Buf(be, nbytes=self.vb * self.capacity + 8)
+        be.call("InitIndexVector", din.index.ptr, 0, self.length, None, 0)
+        be.call("Sort", din.struct(), self.length, None, 0)
+        res = {"sorted_hash": din.hash.read(np.uint64, self.length),
+               "sorted_index": din.index.read(np.uint32, self.length)}
+        g = be.call("Reduce", din.struct(), vin.ptr, dout.struct(), vout.ptr, self.value_bytes,
+                    self.length, self.agg, None, 0)
+        res["groups"] = g
+        res["out_index"] = dout.index.read(np.uint32, g)
+        res["out_values"] = vout.read(np.uint8, self.vb * g)
+        res["out_dims"] = dout.rows(g)
+        for b in (din, dout, vin, vout):
+            b.free()
+        return res
+
+    def run_hash_reduce(self, be):
+        din, dout = self._dims(be, False)
+        vin = H.Buf(be, self.values)
+        vout = H.Buf(be, nbytes=self.vb * self.capacity + 8)
+        g = be.call("HashReduce", din.struct(), vin.ptr, dout.struct(), vout.ptr, self.value_bytes,
+                    self.length, self.agg, None, 0)
+        vals = vout.read(np.uint8, self.vb * g).reshape(g, self.vb)
+        rows = dout.rows(g)
+        res = {"groups": g, "map": {r: bytes(v) for r, v in zip(rows, vals)}}
+        for b in (din, dout, vin, vout):
+            b.free()
+        return res
+
+    def value_dtype(self):
+        if self.agg == abi.AGGR_AVG_FLOAT:
+            return "avg"
+        if self.agg in (abi.AGGR_SUM_FLOAT, abi.AGGR_MIN_FLOAT, abi.AGGR_MAX_FLOAT):
+            return np.float64 if self.vb == 8 else np.float32
+        if self.agg in (abi.AGGR_SUM_SIGNED, abi.AGGR_MIN_SIGNED, abi.AGGR_MAX_SIGNED):
+            return np.int64 if self.vb == 8 else np.int32
+        return np.uint64 if self.vb == 8 else np.uint32
+
+
+def assert_same(a, b, what=""):
+    assert a.keys() == b.keys(), what
+    for k in a:
+        x, y = a[k], b[k]
+        if isinstance(x, np.ndarray):
+            assert x.shape == y.shape and np.array_equal(x, y), \
+                f"{what}: field {k!r} differs\n{x[:32]}\n{y[:32]}"
+        else:
+            assert x == y, f"{what}: field {k!r} differs: {x!r} != {y!r}"

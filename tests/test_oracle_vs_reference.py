@@ -1,0 +1,55 @@
+"""Differential pinning of the C oracle against the reference's own HOST build.
+
+oracle/_ref/libalgorithm.so is compiled from the UNMODIFIED reference sources by
+oracle/Makefile.ref; on hundreds of seeded cases the plain-C restatement must produce
+bit-identical buffers.  Skipped when oracle/_ref has not been built.
+"""
+import numpy as np
+import pytest
+
+import cases
+import harness as H
+
+pytestmark = pytest.mark.skipif(not H.have_ref(), reason="oracle/_ref not built")
+
+
+@pytest.mark.parametrize("arity", [1, 2])
+@pytest.mark.parametrize("as_filter", [False, True])
+@pytest.mark.parametrize("block", range(8))
+def test_transform_and_filter(arity, as_filter, block):
+    o, r = H.oracle_backend(), H.ref_backend()
+    for seed in range(block * 40, block * 40 + 40):
+        c = cases.TransformCase(seed * 4 + arity * 2 + int(as_filter), arity, as_filter)
+        cases.assert_same(c.run(o), c.run(r), repr(c))
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_hash_lookup(seed):
+    c = cases.HashLookupCase(seed)
+    cases.assert_same(c.run(H.oracle_backend()), c.run(H.ref_backend()), f"HashLookupCase({seed})")
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_sort_reduce(seed):
+    c = cases.GroupByCase(seed)
+    cases.assert_same(c.run_sort_reduce(H.oracle_backend()), c.run_sort_reduce(H.ref_backend()),
+                      f"GroupByCase({seed}) sort/reduce")
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_hash_reduce(seed):
+    c = cases.GroupByCase(1000 + seed)
+    cases.assert_same(c.run_hash_reduce(H.oracle_backend()), c.run_hash_reduce(H.ref_backend()),
+                      f"GroupByCase({1000 + seed}) hash reduce")
+
+
+def test_murmur_known_answers():
+    """Row hashes recorded from the reference build: row = {value, validity=1}."""
+    import ctypes as C
+    lib = C.CDLL(H.ORACLE_SO)
+    lib.oracle_murmur3_128.argtypes = [C.c_char_p, C.c_int, C.c_uint32, C.POINTER(C.c_uint64)]
+    out = (C.c_uint64 * 2)()
+    exp = {2: 0x60e187b4814392c4, 0: 0x7cb3f5c58dab264c, 3: 0xb73e42bb654cee53, 1: 0xca410abc0a9d4c6b}
+    for v, h in exp.items():
+        lib.oracle_murmur3_128(bytes([v, 1]), 2, 0, out)
+        assert out[0] == h

@@ -1,0 +1,87 @@
+// Host-side plumbing shared by every entry point of libalgorithm.so (MI355X / gfx950).
+//
+// Mirrors the reference's ABI wrapper pattern (query/filter.cu:141-165, query/utils.cu:44-59):
+// select the device, run, convert any C++ exception into a strdup()'ed message — an exception
+// never crosses the C boundary.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+#include "ares_algorithm.h"
+
+namespace ares {
+
+class AlgorithmError : public std::runtime_error {
+ public:
+  explicit AlgorithmError(const std::string &m) : std::runtime_error(m) {}
+};
+
+inline void hip_check(hipError_t e, const char *what) {
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    throw AlgorithmError(std::string("ERROR: ") + what + ": " + hipGetErrorString(e));
+  }
+}
+
+// Checks the launch that was just enqueued (reference CheckCUDAError, utils.cu:44-59).
+inline void check_launch(const char *what) { hip_check(hipGetLastError(), what); }
+
+#define ARES_ABI_BEGIN(device)                         \
+  CGoCallResHandle resHandle = {nullptr, nullptr};     \
+  try {                                                \
+    ares::hip_check(hipSetDevice(device), "hipSetDevice");
+
+#define ARES_ABI_END(name)                                            \
+  }                                                                   \
+  catch (std::exception & e) {                                        \
+    fprintf(stderr, "Exception happened when doing %s: %s\n", name, e.what()); \
+    resHandle.pStrErr = strdup(e.what());                             \
+  }                                                                   \
+  return resHandle;
+
+inline void *int_result(int64_t v) { return reinterpret_cast<void *>(static_cast<intptr_t>(v)); }
+
+// Stream-ordered temporary device memory (tile descriptors, hash tables, radix-sort ping-pong
+// buffers).  Comes from the device's default pool, so after warm-up it costs no driver call.
+class StreamBuffer {
+ public:
+  StreamBuffer(size_t bytes, hipStream_t stream) : stream_(stream) {
+    if (bytes == 0) bytes = 16;
+    hip_check(hipMallocAsync(&ptr_, bytes, stream), "hipMallocAsync");
+  }
+  ~StreamBuffer() {
+    if (ptr_) (void)hipFreeAsync(ptr_, stream_);
+  }
+  StreamBuffer(const StreamBuffer &) = delete;
+  StreamBuffer &operator=(const StreamBuffer &) = delete;
+  template <typename T>
+  T *as() const { return static_cast<T *>(ptr_); }
+  void *get() const { return ptr_; }
+
+ private:
+  void *ptr_ = nullptr;
+  hipStream_t stream_;
+};
+
+// A few pinned host words per calling thread: where count-returning entry points receive their
+// result (D2H of 4-16 bytes + stream sync).  ABI calls arrive on arbitrary goroutine threads.
+uint64_t *pinned_words();
+
+// Reads `count` 32-bit words written by a kernel at `dev` back to the host; synchronises stream.
+void read_back_u32(const uint32_t *dev, uint32_t *host, int count, hipStream_t stream);
+
+// Grid size helper: enough blocks to cover `tiles`, capped so that huge inputs are processed by
+// a few waves of blocks per CU (256 CUs x 8 blocks) with a grid-stride / ticket loop.
+inline int capped_grid(int64_t tiles, int cap = 256 * 8) {
+  if (tiles < 1) tiles = 1;
+  return static_cast<int>(tiles < cap ? tiles : cap);
+}
+
+}  // namespace ares

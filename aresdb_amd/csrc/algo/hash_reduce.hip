@@ -1,0 +1,118 @@
+// HashReduce for MI355X (gfx950): group-by aggregation through an open-addressed hash table.
+//
+// Reference: query/hash_reduction.cu:183-391 (+ cudf concurrent_unordered_map on the device,
+// std::unordered_map on the host, query/concurrent_unordered_map.hpp).  Observable contract:
+//   * group identity = murmur3_x86_32(seed 0) of the packed dim row — equality on the 32-bit hash
+//     only (hash_reduction.cu:216-243);
+//   * the representative row of a group is the FIRST row carrying the hash; the reference's
+//     device build leaves "first" to the CAS race, its host build means input order.  We pin it
+//     to input order deterministically: the slot key (hash << 32 | row) is lowered with a 64-bit
+//     atomicMin, so the smallest row index always wins, whatever the scheduling;
+//   * output rows [0, groups) in unspecified order; res = groups.
+// The table has 2 * length slots rounded up to a power of two (reference load factor 2); keys and
+// values live in two separate arrays so the probe sequence touches 8-byte keys only.
+#include <hip/hip_runtime.h>
+
+#include "aggregate.hpp"
+#include "common.hpp"
+#include "device_model.hpp"
+#include "dim_layout.hpp"
+
+namespace ares {
+
+constexpr int kBlock = 256;
+constexpr uint64_t kEmptyKey = ~0ull;
+
+__global__ __launch_bounds__(kBlock) void hash_table_init_kernel(uint64_t *keys, uint8_t *values, uint64_t capacity,
+                                                                 AggSpec a) {
+  for (uint64_t s = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; s < capacity;
+       s += static_cast<uint64_t>(gridDim.x) * kBlock) {
+    keys[s] = kEmptyKey;
+    if (a.width == 8) reinterpret_cast<uint64_t *>(values)[s] = a.identity;
+    else reinterpret_cast<uint32_t *>(values)[s] = static_cast<uint32_t>(a.identity);
+  }
+}
+
+// Finds (or claims) the slot of hash h and lowers its key to min(key, h<<32|row).
+__device__ __forceinline__ uint64_t find_or_claim(uint64_t *keys, uint64_t mask, uint32_t h, uint32_t row) {
+  const uint64_t mine = (static_cast<uint64_t>(h) << 32) | row;
+  uint64_t slot = h & mask;
+  for (;;) {
+    uint64_t cur = __hip_atomic_load(keys + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cur == kEmptyKey) {
+      const uint64_t prev = atomicCAS(reinterpret_cast<unsigned long long *>(keys + slot), kEmptyKey, mine);
+      if (prev == kEmptyKey) return slot;
+      cur = prev;
+    }
+    if (static_cast<uint32_t>(cur >> 32) == h) {
+      if (mine < cur) atomicMin(reinterpret_cast<unsigned long long *>(keys + slot), mine);
+      return slot;
+    }
+    slot = (slot + 1) & mask;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void hash_insert_kernel(const uint8_t *dimValues, DimLayoutD L, size_t capacity,
+                                                             const uint8_t *inputValues, AggSpec a, uint64_t *keys,
+                                                             uint8_t *values, uint64_t mask, int length) {
+  for (int64_t i64 = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i64 < length;
+       i64 += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const uint32_t row = static_cast<uint32_t>(i64);
+    Murmur32Stream ms(0);
+    hash_dim_row(ms, dimValues, L, capacity, row);
+    const uint32_t h = ms.finish();
+    const uint64_t slot = find_or_claim(keys, mask, h, row);
+    aggregate_slot(values + slot * a.width, inputValues + static_cast<size_t>(a.width) * row, a);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void hash_extract_kernel(const uint64_t *keys, const uint8_t *values,
+                                                              uint64_t tableSize, const uint8_t *dimIn, uint8_t *dimOut,
+                                                              DimLayoutD L, size_t capacity, uint8_t *outputValues,
+                                                              AggSpec a, uint32_t *counter) {
+  for (uint64_t s = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; s < tableSize;
+       s += static_cast<uint64_t>(gridDim.x) * kBlock) {
+    const uint64_t k = keys[s];
+    if (k == kEmptyKey) continue;
+    const uint32_t dst = atomicAdd(counter, 1u);  // compiler aggregates per wavefront
+    copy_dim_row(dimIn, capacity, dimOut, capacity, L, static_cast<uint32_t>(k), dst);
+    if (a.width == 8) reinterpret_cast<uint64_t *>(outputValues)[dst] = reinterpret_cast<const uint64_t *>(values)[s];
+    else reinterpret_cast<uint32_t *>(outputValues)[dst] = reinterpret_cast<const uint32_t *>(values)[s];
+  }
+}
+
+}  // namespace ares
+
+using namespace ares;
+
+extern "C" CGoCallResHandle HashReduce(DimensionVector inputKeys, uint8_t *inputValues, DimensionVector outputKeys,
+                                       uint8_t *outputValues, int valueBytes, int length,
+                                       enum AggregateFunction aggFunc, void *cudaStream, int device) {
+  ARES_ABI_BEGIN(device)
+  hipStream_t stream = reinterpret_cast<hipStream_t>(cudaStream);
+  const AggSpec a = make_agg_spec(aggFunc, valueBytes);
+  if (length > 0) {
+    const DimLayoutD L = make_dim_layout(inputKeys.NumDimsPerDimWidth);
+    uint64_t tableSize = 1024;
+    while (tableSize < 2ull * static_cast<uint64_t>(length)) tableSize <<= 1;
+    StreamBuffer keyBuf(tableSize * 8, stream), valBuf(tableSize * a.width, stream), counter(16, stream);
+    hip_check(hipMemsetAsync(counter.get(), 0, 16, stream), "hipMemsetAsync");
+    const int initGrid = capped_grid(static_cast<int64_t>((tableSize + kBlock - 1) / kBlock), 256 * 16);
+    hipLaunchKernelGGL(hash_table_init_kernel, dim3(initGrid), dim3(kBlock), 0, stream, keyBuf.as<uint64_t>(),
+                       valBuf.as<uint8_t>(), tableSize, a);
+    check_launch("HashReduce init");
+    const int grid = capped_grid((static_cast<int64_t>(length) + kBlock - 1) / kBlock, 256 * 16);
+    hipLaunchKernelGGL(hash_insert_kernel, dim3(grid), dim3(kBlock), 0, stream, inputKeys.DimValues, L,
+                       static_cast<size_t>(inputKeys.VectorCapacity), inputValues, a, keyBuf.as<uint64_t>(),
+                       valBuf.as<uint8_t>(), tableSize - 1, length);
+    check_launch("HashReduce insert");
+    hipLaunchKernelGGL(hash_extract_kernel, dim3(initGrid), dim3(kBlock), 0, stream, keyBuf.as<uint64_t>(),
+                       valBuf.as<uint8_t>(), tableSize, inputKeys.DimValues, outputKeys.DimValues, L,
+                       static_cast<size_t>(inputKeys.VectorCapacity), outputValues, a, counter.as<uint32_t>());
+    check_launch("HashReduce extract");
+    uint32_t groups = 0;
+    read_back_u32(counter.as<uint32_t>(), &groups, 1, stream);
+    resHandle.res = int_result(groups);
+  }
+  ARES_ABI_END("HashReduce")
+}

@@ -1,0 +1,566 @@
+// Sort, Reduce and Expand for MI355X (gfx950): the sort-based group-by path.
+//
+// Reference: query/sort_reduce.cu:118-133 (hash rows + thrust::stable_sort_by_key),
+// :135-249 (thrust::reduce_by_key + permuted dim gather), :252-314 (Expand).
+//
+// Sort   = one fused "hash rows + all eight digit histograms" pass, then eight passes of a
+//          single-pass LSD radix sort ("onesweep"): each tile ranks its keys with wavefront
+//          ballot matching (stable), publishes its 256-bin histogram through the chained-scan
+//          protocol of lookback.hpp and scatters through LDS so that global writes are runs of
+//          consecutive addresses.  64-bit keys are sorted on all 64 bits: the order of the output
+//          is observable (Reduce emits groups in ascending hash order).
+// Reduce = one pass: head flags from neighbouring hashes, chained scan of the head counts for the
+//          group numbering, in-register folds per lane, a wavefront segmented scan for runs that
+//          span lanes, atomics only for runs that span wavefronts.
+#include <hip/hip_runtime.h>
+
+#include "aggregate.hpp"
+#include "common.hpp"
+#include "device_model.hpp"
+#include "dim_layout.hpp"
+#include "lookback.hpp"
+
+namespace ares {
+
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / 64;
+
+// ---------------------------------------------------------------------------------------------
+// Sort step 1: hashes + global digit histograms
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void sort_hash_hist_kernel(const uint8_t *dimValues, DimLayoutD L, size_t capacity,
+                                                                const uint32_t *indexVector, uint64_t *hashes, int n,
+                                                                uint32_t *globalHist /* [8][256] */) {
+  __shared__ uint32_t sHist[8 * 256];
+  for (int i = threadIdx.x; i < 8 * 256; i += kBlock) sHist[i] = 0;
+  __syncthreads();
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * kBlock) {
+    Murmur128Stream ms(0);
+    hash_dim_row(ms, dimValues, L, capacity, indexVector[i]);
+    const uint64_t h = ms.finish();
+    hashes[i] = h;
+#pragma unroll
+    for (int p = 0; p < 8; p++) atomicAdd(&sHist[p * 256 + ((h >> (8 * p)) & 255)], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 8 * 256; i += kBlock) {
+    const uint32_t c = sHist[i];
+    if (c) atomicAdd(&globalHist[i], c);
+  }
+}
+
+// exclusive scan of each pass's 256 bins: digitStart[p][d] = number of keys with a smaller digit
+__global__ __launch_bounds__(256) void digit_start_kernel(uint32_t *hist /* in: counts, out: starts */) {
+  __shared__ uint32_t s[256];
+  uint32_t *h = hist + blockIdx.x * 256;
+  const uint32_t c = h[threadIdx.x];
+  s[threadIdx.x] = c;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    const uint32_t t = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+    __syncthreads();
+    s[threadIdx.x] += t;
+    __syncthreads();
+  }
+  h[threadIdx.x] = s[threadIdx.x] - c;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sort step 2: one LSD pass (8-bit digit), stable, single pass over the data
+// ---------------------------------------------------------------------------------------------
+constexpr int kSortKPT = 16;                    // keys per lane
+constexpr int kSortTile = kBlock * kSortKPT;    // 4096 keys per tile
+constexpr int kSortWaveChunk = 64 * kSortKPT;   // contiguous keys owned by one wavefront
+constexpr uint32_t kFlagAgg32 = 1u << 30, kFlagInc32 = 2u << 30, kFlagMask32 = 3u << 30;
+
+__device__ __forceinline__ uint32_t ld_status32(const uint32_t *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_status32(uint32_t *p, uint32_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(kBlock) void radix_pass_kernel(const uint64_t *keysIn, const uint32_t *valsIn,
+                                                            uint64_t *keysOut, uint32_t *valsOut, int n, int shift,
+                                                            const uint32_t *digitStart, unsigned int *ticket,
+                                                            uint32_t *status /* [numTiles][256] */, int numTiles) {
+  __shared__ uint64_t sKeys[kSortTile];
+  __shared__ uint32_t sVals[kSortTile];
+  __shared__ uint32_t sHist[kWaves][256];  // per-wave digit counts -> per-wave bases inside the tile
+  __shared__ uint32_t sTileStart[256];     // first tile-local slot of each digit
+  __shared__ uint32_t sBase[256];          // global position = sBase[digit] + tile-local slot
+  __shared__ uint32_t sWaveTotals[kWaves];
+  __shared__ int sTile;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint64_t ltMask = (1ull << lane) - 1;
+  for (;;) {
+    if (threadIdx.x == 0) sTile = static_cast<int>(atomicAdd(ticket, 1u));
+    for (int i = threadIdx.x; i < kWaves * 256; i += kBlock) (&sHist[0][0])[i] = 0;
+    __syncthreads();
+    const int tile = sTile;
+    if (tile >= numTiles) break;
+    const int64_t tileBase = static_cast<int64_t>(tile) * kSortTile;
+    const int tileCount = static_cast<int>(n - tileBase < kSortTile ? n - tileBase : kSortTile);
+
+    uint64_t key[kSortKPT];
+    uint32_t val[kSortKPT];
+    uint16_t rank[kSortKPT];
+#pragma unroll
+    for (int r = 0; r < kSortKPT; r++) {
+      const int local = wave * kSortWaveChunk + r * 64 + lane;
+      if (local < tileCount) {
+        key[r] = keysIn[tileBase + local];
+        val[r] = valsIn[tileBase + local];
+      } else {
+        key[r] = ~0ull;
+        val[r] = 0;
+      }
+    }
+    // stable ranking inside the wavefront's chunk: lanes holding the same digit find each other
+    // with 8 ballots; the per-wave histogram row lives in LDS and is only touched by this wave
+#pragma unroll
+    for (int r = 0; r < kSortKPT; r++) {
+      const int local = wave * kSortWaveChunk + r * 64 + lane;
+      const bool valid = local < tileCount;
+      const uint32_t digit = static_cast<uint32_t>(key[r] >> shift) & 255u;
+      uint64_t peers = __ballot(valid);
+#pragma unroll
+      for (int b = 0; b < 8; b++) {
+        const uint64_t m = __ballot((digit >> b) & 1u);
+        peers &= ((digit >> b) & 1u) ? m : ~m;
+      }
+      const uint32_t before = __popcll(peers & ltMask);
+      uint32_t old = 0;
+      if (valid) old = sHist[wave][digit];
+      __builtin_amdgcn_wave_barrier();
+      if (valid && before == 0) sHist[wave][digit] = old + __popcll(peers);
+      __builtin_amdgcn_wave_barrier();
+      rank[r] = static_cast<uint16_t>(old + before);
+    }
+    __syncthreads();
+    // thread d owns digit d: bases of the waves inside the tile, tile histogram, chained scan
+    const int d = threadIdx.x;
+    uint32_t total = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; w++) {
+      const uint32_t c = sHist[w][d];
+      sHist[w][d] = total;
+      total += c;
+    }
+    st_status32(status + static_cast<size_t>(tile) * 256 + d, (tile == 0 ? kFlagInc32 : kFlagAgg32) | total);
+    // exclusive scan of the tile histogram over the 256 digits
+    uint32_t incl = total;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(incl, off);
+      if (lane >= off) incl += t;
+    }
+    if (lane == 63) sWaveTotals[wave] = incl;
+    __syncthreads();
+    uint32_t waveBase = 0;
+    for (int w = 0; w < wave; w++) waveBase += sWaveTotals[w];
+    const uint32_t tileStart = waveBase + incl - total;
+    sTileStart[d] = tileStart;
+    uint32_t exclusive = 0;
+    if (tile > 0) {
+      for (int t = tile - 1; t >= 0; --t) {
+        uint32_t w = ld_status32(status + static_cast<size_t>(t) * 256 + d);
+        while ((w & kFlagMask32) == 0) {
+          __builtin_amdgcn_s_sleep(1);
+          w = ld_status32(status + static_cast<size_t>(t) * 256 + d);
+        }
+        exclusive += w & ~kFlagMask32;
+        if ((w & kFlagMask32) == kFlagInc32) break;
+      }
+      st_status32(status + static_cast<size_t>(tile) * 256 + d, kFlagInc32 | (exclusive + total));
+    }
+    sBase[d] = digitStart[d] + exclusive - tileStart;
+    __syncthreads();
+    // reorder through LDS: tile-local slot = digit start + wave base + rank in wave
+#pragma unroll
+    for (int r = 0; r < kSortKPT; r++) {
+      const int local = wave * kSortWaveChunk + r * 64 + lane;
+      if (local < tileCount) {
+        const uint32_t digit = static_cast<uint32_t>(key[r] >> shift) & 255u;
+        const uint32_t slot = sTileStart[digit] + sHist[wave][digit] + rank[r];
+        sKeys[slot] = key[r];
+        sVals[slot] = val[r];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < kSortKPT; m++) {
+      const int j = m * kBlock + threadIdx.x;
+      if (j < tileCount) {
+        const uint64_t k = sKeys[j];
+        const uint32_t digit = static_cast<uint32_t>(k >> shift) & 255u;
+        const uint32_t dst = sBase[digit] + static_cast<uint32_t>(j);
+        keysOut[dst] = k;
+        valsOut[dst] = sVals[j];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void fill_u64_kernel(uint64_t *p, uint64_t v, int n) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * kBlock)
+    p[i] = v;
+}
+
+static void sort_impl(const DimensionVector &keys, int length, hipStream_t stream) {
+  if (length <= 0) return;
+  if (static_cast<int64_t>(length) >= (1ll << 30))
+    throw std::invalid_argument("Sort supports up to 2^30 - 1 rows per call");
+  const DimLayoutD L = make_dim_layout(keys.NumDimsPerDimWidth);
+  const int numTiles = (length + kSortTile - 1) / kSortTile;
+  const size_t histBytes = 8 * 256 * sizeof(uint32_t);
+  const size_t statusBytes = static_cast<size_t>(numTiles) * 256 * sizeof(uint32_t);
+  // workspace: [hist 8 KiB][8 tickets][status][alt keys][alt vals]
+  const size_t offTicket = histBytes, offStatus = offTicket + 64, offKeys = (offStatus + statusBytes + 255) & ~size_t(255);
+  const size_t offVals = offKeys + sizeof(uint64_t) * static_cast<size_t>(length);
+  StreamBuffer ws(offVals + sizeof(uint32_t) * static_cast<size_t>(length) + 256, stream);
+  uint8_t *base = ws.as<uint8_t>();
+  uint32_t *hist = reinterpret_cast<uint32_t *>(base);
+  unsigned int *tickets = reinterpret_cast<unsigned int *>(base + offTicket);
+  uint32_t *status = reinterpret_cast<uint32_t *>(base + offStatus);
+  uint64_t *altKeys = reinterpret_cast<uint64_t *>(base + offKeys);
+  uint32_t *altVals = reinterpret_cast<uint32_t *>(base + offVals);
+  hip_check(hipMemsetAsync(base, 0, offStatus, stream), "hipMemsetAsync");
+
+  const int grid = capped_grid((static_cast<int64_t>(length) + kBlock - 1) / kBlock, 256 * 8);
+  hipLaunchKernelGGL(sort_hash_hist_kernel, dim3(grid), dim3(kBlock), 0, stream, keys.DimValues, L,
+                     static_cast<size_t>(keys.VectorCapacity), keys.IndexVector, keys.HashValues, length, hist);
+  check_launch("Sort hash");
+  if (L.numDims == 0) return;  // every row hashes alike: a stable sort leaves the order untouched
+  hipLaunchKernelGGL(digit_start_kernel, dim3(8), dim3(256), 0, stream, hist);
+  check_launch("Sort digit starts");
+  const int passGrid = capped_grid(numTiles, 256 * 3);
+  for (int pass = 0; pass < 8; pass++) {
+    hip_check(hipMemsetAsync(status, 0, statusBytes, stream), "hipMemsetAsync");
+    const bool even = (pass & 1) == 0;
+    hipLaunchKernelGGL(radix_pass_kernel, dim3(passGrid), dim3(kBlock), 0, stream,
+                       even ? keys.HashValues : altKeys, even ? keys.IndexVector : altVals,
+                       even ? altKeys : keys.HashValues, even ? altVals : keys.IndexVector, length, 8 * pass,
+                       hist + 256 * pass, tickets + pass, status, numTiles);
+    check_launch("Sort radix pass");
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Reduce
+// ---------------------------------------------------------------------------------------------
+constexpr int kReduceKPT = 8;
+constexpr int kReduceTile = kBlock * kReduceKPT;
+
+struct ReduceParams {
+  const uint64_t *hashes;
+  const uint32_t *indexIn;
+  const uint8_t *valuesIn;
+  uint32_t *indexOut;
+  uint8_t *valuesOut;
+  const uint8_t *dimIn;
+  uint8_t *dimOut;
+  DimLayoutD L;
+  size_t capacity;
+  AggSpec agg;
+  int n;
+  int numTiles;
+  unsigned int *ticket;
+  uint32_t *total;
+  uint64_t *status;
+};
+
+__global__ __launch_bounds__(kBlock) void fill_identity_kernel(uint8_t *values, AggSpec a, int n) {
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * kBlock)
+    store_value_bits(values, a, static_cast<size_t>(i), a.identity);
+}
+
+__global__ __launch_bounds__(kBlock) void reduce_kernel(ReduceParams p) {
+  __shared__ uint32_t sWave[kWaves];
+  __shared__ uint32_t sTileExcl;
+  __shared__ int sTile;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (;;) {
+    if (threadIdx.x == 0) sTile = static_cast<int>(atomicAdd(p.ticket, 1u));
+    __syncthreads();
+    const int tile = sTile;
+    if (tile >= p.numTiles) break;
+    // blocked arrangement: lane owns kReduceKPT consecutive sorted positions
+    const int64_t first = static_cast<int64_t>(tile) * kReduceTile + static_cast<int64_t>(threadIdx.x) * kReduceKPT;
+    uint64_t h[kReduceKPT];
+    uint32_t idx[kReduceKPT];
+    uint64_t prev = 0;
+    if (first > 0 && first < p.n) prev = p.hashes[first - 1];
+#pragma unroll
+    for (int j = 0; j < kReduceKPT; j++) {
+      const int64_t i = first + j;
+      h[j] = i < p.n ? p.hashes[i] : 0;
+      idx[j] = i < p.n ? p.indexIn[i] : 0;
+    }
+    uint32_t heads = 0;  // bit j: position first+j starts a group
+#pragma unroll
+    for (int j = 0; j < kReduceKPT; j++) {
+      const int64_t i = first + j;
+      const bool head = i < p.n && (i == 0 || h[j] != (j == 0 ? prev : h[j - 1]));
+      heads |= static_cast<uint32_t>(head) << j;
+    }
+    const uint32_t myHeads = __popc(heads);
+    // block-wide exclusive scan of the head counts
+    uint32_t incl = myHeads;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(incl, off);
+      if (lane >= off) incl += t;
+    }
+    if (lane == 63) sWave[wave] = incl;
+    __syncthreads();
+    uint32_t waveBase = 0, tileHeads = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; w++) {
+      if (w < wave) waveBase += sWave[w];
+      tileHeads += sWave[w];
+    }
+    if (wave == 0) {
+      if (lane == 0) st_status(p.status + tile, (tile == 0 ? kFlagInclusive : kFlagAggregate) | tileHeads);
+      uint64_t excl = 0;
+      if (tile > 0) {
+        excl = lookback_wave(p.status, tile, lane);
+        if (lane == 0) st_status(p.status + tile, kFlagInclusive | (excl + tileHeads));
+      }
+      if (lane == 0) {
+        sTileExcl = static_cast<uint32_t>(excl);
+        if (tile == p.numTiles - 1) *p.total = static_cast<uint32_t>(excl) + tileHeads;
+      }
+    }
+    __syncthreads();
+    // group number of the run that is open when this lane starts (may have begun in an earlier lane)
+    uint32_t group = sTileExcl + waveBase + (incl - myHeads) - 1;
+    uint64_t acc = p.agg.identity;
+    bool open = false;  // acc holds a partial of `group`
+#pragma unroll
+    for (int j = 0; j < kReduceKPT; j++) {
+      const int64_t i = first + j;
+      if (i >= p.n) break;
+      if ((heads >> j) & 1u) {
+        if (open) aggregate_slot(p.valuesOut + static_cast<size_t>(p.agg.width) * group,
+                                 reinterpret_cast<const uint8_t *>(&acc), p.agg);
+        group++;
+        p.indexOut[group] = idx[j];
+        copy_dim_row(p.dimIn, p.capacity, p.dimOut, p.capacity, p.L, idx[j], group);
+        acc = load_value_bits(p.valuesIn, p.agg, idx[j]);
+      } else {
+        const uint64_t v = load_value_bits(p.valuesIn, p.agg, idx[j]);
+        acc = open ? combine_bits(p.agg, acc, v) : v;
+      }
+      open = true;
+    }
+    // runs that continue across lanes: segmented inclusive scan over the wavefront keyed by the
+    // group of each lane's trailing partial; the last lane of every group emits one atomic
+    uint32_t g = open ? group : 0xffffffffu;
+    uint64_t part = acc;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint64_t otherPart = __shfl_up(part, off);
+      const uint32_t otherG = __shfl_up(g, off);
+      if (lane >= off && otherG == g && g != 0xffffffffu) part = combine_bits(p.agg, otherPart, part);
+    }
+    const uint32_t nextG = __shfl_down(g, 1);
+    if (open && (lane == 63 || nextG != g))
+      aggregate_slot(p.valuesOut + static_cast<size_t>(p.agg.width) * g, reinterpret_cast<const uint8_t *>(&part), p.agg);
+    __syncthreads();
+  }
+}
+
+static int reduce_impl(const DimensionVector &in, uint8_t *inputValues, const DimensionVector &out,
+                       uint8_t *outputValues, int valueBytes, int length, int aggFunc, hipStream_t stream) {
+  ReduceParams p;
+  p.agg = make_agg_spec(aggFunc, valueBytes);
+  if (length <= 0) return 0;
+  p.hashes = in.HashValues;
+  p.indexIn = in.IndexVector;
+  p.valuesIn = inputValues;
+  p.indexOut = out.IndexVector;
+  p.valuesOut = outputValues;
+  p.dimIn = in.DimValues;
+  p.dimOut = out.DimValues;
+  p.L = make_dim_layout(in.NumDimsPerDimWidth);
+  p.capacity = static_cast<size_t>(in.VectorCapacity);
+  p.n = length;
+  p.numTiles = (length + kReduceTile - 1) / kReduceTile;
+  StreamBuffer ws(16 + sizeof(uint64_t) * static_cast<size_t>(p.numTiles), stream);
+  hip_check(hipMemsetAsync(ws.get(), 0, 16 + sizeof(uint64_t) * static_cast<size_t>(p.numTiles), stream),
+            "hipMemsetAsync");
+  p.ticket = ws.as<unsigned int>();
+  p.total = ws.as<uint32_t>() + 1;
+  p.status = reinterpret_cast<uint64_t *>(ws.as<uint8_t>() + 16);
+  // every group slot starts from the aggregate's identity; partials are merged with atomics
+  const int fillGrid = capped_grid((static_cast<int64_t>(length) + kBlock - 1) / kBlock, 256 * 8);
+  hipLaunchKernelGGL(fill_identity_kernel, dim3(fillGrid), dim3(kBlock), 0, stream, outputValues, p.agg, length);
+  check_launch("Reduce init");
+  hipLaunchKernelGGL(reduce_kernel, dim3(capped_grid(p.numTiles)), dim3(kBlock), 0, stream, p);
+  check_launch("Reduce");
+  uint32_t groups = 0;
+  read_back_u32(p.total, &groups, 1, stream);
+  return static_cast<int>(groups);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Expand
+// ---------------------------------------------------------------------------------------------
+constexpr int kExpandKPT = 4;
+constexpr int kExpandTile = kBlock * kExpandKPT;
+
+struct ExpandParams {
+  const uint32_t *baseCounts;
+  const uint32_t *indexVector;
+  int n;
+  int numTiles;
+  uint64_t *offsets;  // exclusive prefix of the run lengths (n + 1 entries)
+  unsigned int *ticket;
+  uint64_t *status;
+};
+
+__global__ __launch_bounds__(kBlock) void expand_offsets_kernel(ExpandParams p) {
+  __shared__ uint64_t sWave[kWaves];
+  __shared__ uint64_t sTileExcl;
+  __shared__ int sTile;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (;;) {
+    if (threadIdx.x == 0) sTile = static_cast<int>(atomicAdd(p.ticket, 1u));
+    __syncthreads();
+    const int tile = sTile;
+    if (tile >= p.numTiles) break;
+    const int64_t first = static_cast<int64_t>(tile) * kExpandTile + static_cast<int64_t>(threadIdx.x) * kExpandKPT;
+    uint32_t c[kExpandKPT];
+    uint64_t mine = 0;
+#pragma unroll
+    for (int j = 0; j < kExpandKPT; j++) {
+      const int64_t i = first + j;
+      c[j] = 0;
+      if (i < p.n) {
+        const uint32_t row = p.indexVector[i];
+        c[j] = p.baseCounts[row + 1] - p.baseCounts[row];
+      }
+      mine += c[j];
+    }
+    uint64_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint64_t t = __shfl_up(incl, off);
+      if (lane >= off) incl += t;
+    }
+    if (lane == 63) sWave[wave] = incl;
+    __syncthreads();
+    uint64_t waveBase = 0, tileTotal = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; w++) {
+      if (w < wave) waveBase += sWave[w];
+      tileTotal += sWave[w];
+    }
+    if (wave == 0) {
+      if (lane == 0) st_status(p.status + tile, (tile == 0 ? kFlagInclusive : kFlagAggregate) | tileTotal);
+      uint64_t excl = 0;
+      if (tile > 0) {
+        excl = lookback_wave(p.status, tile, lane);
+        if (lane == 0) st_status(p.status + tile, kFlagInclusive | (excl + tileTotal));
+      }
+      if (lane == 0) {
+        sTileExcl = excl;
+        if (tile == p.numTiles - 1) p.offsets[p.n] = excl + tileTotal;
+      }
+    }
+    __syncthreads();
+    uint64_t run = sTileExcl + waveBase + incl - mine;
+#pragma unroll
+    for (int j = 0; j < kExpandKPT; j++) {
+      const int64_t i = first + j;
+      if (i < p.n) p.offsets[i] = run;
+      run += c[j];
+    }
+    __syncthreads();
+  }
+}
+
+// output row j copies input dim row i where offsets[i] <= j < offsets[i+1]
+__global__ __launch_bounds__(kBlock) void expand_copy_kernel(const uint64_t *offsets, int n, const uint8_t *dimIn,
+                                                             size_t inCap, uint8_t *dimOut, size_t outCap, DimLayoutD L,
+                                                             int outLen, int occupied) {
+  for (int64_t j = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; j < outLen;
+       j += static_cast<int64_t>(gridDim.x) * kBlock) {
+    int lo = 0, hi = n;  // last i with offsets[i] <= j
+    while (lo < hi) {
+      const int mid = lo + ((hi - lo) >> 1);
+      if (offsets[mid] > static_cast<uint64_t>(j)) hi = mid; else lo = mid + 1;
+    }
+    copy_dim_row(dimIn, inCap, dimOut, outCap, L, static_cast<uint32_t>(lo - 1), static_cast<uint32_t>(occupied + j));
+  }
+}
+
+static int expand_impl(const DimensionVector &in, const DimensionVector &out, uint32_t *baseCounts,
+                       uint32_t *indexVector, int n, int occupied, hipStream_t stream) {
+  if (n <= 0) return occupied;
+  ExpandParams p;
+  p.baseCounts = baseCounts;
+  p.indexVector = indexVector;
+  p.n = n;
+  p.numTiles = (n + kExpandTile - 1) / kExpandTile;
+  const size_t offBytes = sizeof(uint64_t) * (static_cast<size_t>(n) + 1);
+  const size_t statusBytes = sizeof(uint64_t) * static_cast<size_t>(p.numTiles);
+  StreamBuffer ws(16 + statusBytes + offBytes, stream);
+  hip_check(hipMemsetAsync(ws.get(), 0, 16 + statusBytes, stream), "hipMemsetAsync");
+  p.ticket = ws.as<unsigned int>();
+  p.status = reinterpret_cast<uint64_t *>(ws.as<uint8_t>() + 16);
+  p.offsets = reinterpret_cast<uint64_t *>(ws.as<uint8_t>() + 16 + statusBytes);
+  hipLaunchKernelGGL(expand_offsets_kernel, dim3(capped_grid(p.numTiles)), dim3(kBlock), 0, stream, p);
+  check_launch("Expand offsets");
+  uint64_t *pinned = pinned_words();
+  hip_check(hipMemcpyAsync(pinned, p.offsets + n, sizeof(uint64_t), hipMemcpyDeviceToHost, stream), "read back total");
+  hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+  const uint64_t total = pinned[0];
+  const int room = out.VectorCapacity - occupied;
+  const int outLen = static_cast<int>(total < static_cast<uint64_t>(room > 0 ? room : 0) ? total : (room > 0 ? room : 0));
+  if (outLen > 0) {
+    const DimLayoutD L = make_dim_layout(in.NumDimsPerDimWidth);
+    const int grid = capped_grid((static_cast<int64_t>(outLen) + kBlock - 1) / kBlock, 256 * 8);
+    hipLaunchKernelGGL(expand_copy_kernel, dim3(grid), dim3(kBlock), 0, stream, p.offsets, n, in.DimValues,
+                       static_cast<size_t>(in.VectorCapacity), out.DimValues, static_cast<size_t>(out.VectorCapacity), L,
+                       outLen, occupied);
+    check_launch("Expand copy");  // `ws` (offsets) is released in stream order, after this kernel
+  }
+  return outLen + occupied;
+}
+
+}  // namespace ares
+
+using namespace ares;
+
+extern "C" {
+
+CGoCallResHandle Sort(DimensionVector keys, int length, void *cudaStream, int device) {
+  ARES_ABI_BEGIN(device)
+  sort_impl(keys, length, reinterpret_cast<hipStream_t>(cudaStream));
+  ARES_ABI_END("Sort")
+}
+
+CGoCallResHandle Reduce(DimensionVector inputKeys, uint8_t *inputValues, DimensionVector outputKeys,
+                        uint8_t *outputValues, int valueBytes, int length, enum AggregateFunction aggFunc,
+                        void *cudaStream, int device) {
+  ARES_ABI_BEGIN(device)
+  resHandle.res = int_result(reduce_impl(inputKeys, inputValues, outputKeys, outputValues, valueBytes, length, aggFunc,
+                                         reinterpret_cast<hipStream_t>(cudaStream)));
+  ARES_ABI_END("Reduce")
+}
+
+CGoCallResHandle Expand(DimensionVector inputKeys, DimensionVector outputKeys, uint32_t *baseCounts,
+                        uint32_t *indexVector, int indexVectorLen, int outputOccupiedLen, void *cudaStream, int device) {
+  ARES_ABI_BEGIN(device)
+  resHandle.res = int_result(expand_impl(inputKeys, outputKeys, baseCounts, indexVector, indexVectorLen,
+                                         outputOccupiedLen, reinterpret_cast<hipStream_t>(cudaStream)));
+  ARES_ABI_END("Expand")
+}
+
+}  // extern "C"

@@ -1,0 +1,540 @@
+// InitIndexVector, Unary/BinaryTransform, Unary/BinaryFilter for MI355X (gfx950).
+//
+// Reference behaviour: query/algorithm.cu:22-41, query/transform.cu:21-86 + transform.hpp:57-89,
+// query/filter.cu:130-253.  The reference runs thrust::transform (+ thrust::remove_if for
+// filters: a second and third pass over the batch plus a host sync).  Here:
+//   * a transform is ONE pass: decode (value, validity) of every operand, apply the functor,
+//     write the sink; ITEMS independent coalesced loads per lane are issued before any use so
+//     each wavefront keeps several HBM requests in flight;
+//   * a filter is ONE pass as well: predicate evaluation, wavefront ballot + popcount ranking,
+//     LDS scan of the per-wave counts and a decoupled look-back across tiles (single-pass chained
+//     scan) give every surviving row its final position, so the index vector is compacted
+//     stably and IN PLACE without a second read of the predicate vector.
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "binding.hpp"
+#include "common.hpp"
+#include "device_model.hpp"
+#include "lookback.hpp"
+
+namespace ares {
+
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / 64;
+
+// ---------------------------------------------------------------------------------------------
+// InitIndexVector
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void init_index_kernel(uint32_t *idx, uint32_t start, int n) {
+  // 4 consecutive entries per lane -> one 16-byte store per lane
+  const int64_t quads = (static_cast<int64_t>(n) + 3) >> 2;
+  for (int64_t q = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; q < quads;
+       q += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int64_t i = q << 2;
+    const uint32_t v = start + static_cast<uint32_t>(i);
+    if (i + 3 < n && (reinterpret_cast<uintptr_t>(idx) & 15) == 0) {
+      *reinterpret_cast<uint4 *>(idx + i) = make_uint4(v, v + 1, v + 2, v + 3);
+    } else {
+      for (int k = 0; k < 4 && i + k < n; k++) idx[i + k] = v + k;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 32-bit value path: transform
+// ---------------------------------------------------------------------------------------------
+struct EvalParams {
+  OperandD a, b;
+  int arity;
+  int functor;
+  int I;   // common input kind
+  int rk;  // result kind
+  const uint32_t *idx;
+  const uint32_t *baseCounts;
+  uint32_t startCount;
+  int needRow;
+};
+
+template <int ITEMS>
+__global__ __launch_bounds__(kBlock) void transform32_kernel(EvalParams p, SinkD s, int n) {
+  const int64_t tile = static_cast<int64_t>(kBlock) * ITEMS;
+  for (int64_t base = static_cast<int64_t>(blockIdx.x) * tile; base < n;
+       base += static_cast<int64_t>(gridDim.x) * tile) {
+    uint32_t rows[ITEMS];
+    DVal va[ITEMS], vb[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      const int64_t i = base + k * kBlock + threadIdx.x;
+      rows[k] = (i < n && p.needRow) ? p.idx[i] : static_cast<uint32_t>(i);
+    }
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      const int64_t i = base + k * kBlock + threadIdx.x;
+      if (i < n) {
+        va[k] = load32(p.a, static_cast<uint32_t>(i), rows[k], p.baseCounts, p.startCount);
+        if (p.arity == 2) vb[k] = load32(p.b, static_cast<uint32_t>(i), rows[k], p.baseCounts, p.startCount);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+      const int64_t i = base + k * kBlock + threadIdx.x;
+      if (i < n) {
+        DVal x = cvt32(va[k], p.a.kind, p.I);
+        DVal r = p.arity == 1 ? unary32(p.functor, p.I, x)
+                              : binary32(p.functor, p.I, x, cvt32(vb[k], p.b.kind, p.I));
+        sink_store32(s, static_cast<uint32_t>(i), rows[k], r, p.rk);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// wide value path (Int64 / UUID / GeoPoint first operand): rare, one element per lane
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ WVal load_wide(const OperandD &op, uint32_t i, uint32_t row, const uint32_t *baseCounts,
+                                          uint32_t startCount) {
+  WVal r;
+  r.lo = r.hi = 0;
+  r.ok = 0;
+  const int w = op.kind == K_UUID ? 16 : 8;
+  switch (op.type) {
+    case OP_CONST:
+      r.lo = op.c64[0]; r.hi = op.c64[1]; r.ok = op.cok;
+      return r;
+    case OP_SCRATCH:
+      r.lo = *reinterpret_cast<const uint64_t *>(op.base + static_cast<size_t>(w) * i);
+      if (w == 16) r.hi = *reinterpret_cast<const uint64_t *>(op.base + static_cast<size_t>(w) * i + 8);
+      r.ok = op.base[op.nullsOff + i] != 0;
+      return r;
+    case OP_COLUMN: {
+      const uint32_t p = locate(op, row, baseCounts, startCount);
+      const uint8_t *v = op.base + op.valuesOff + static_cast<size_t>(w) * p;
+      r.lo = *reinterpret_cast<const uint64_t *>(v);
+      if (w == 16) r.hi = *reinterpret_cast<const uint64_t *>(v + 8);
+      r.ok = op.mode >= 2 ? get_bit(op.base + op.nullsOff, p + op.bitOff) : 1u;
+      return r;
+    }
+    default: {
+      const RecordID rid = op.rids[i];
+      if (rid.batchID != 0 && (rid.batchID - op.baseBatchID < op.numBatches - 1 ||
+                               rid.index < static_cast<uint32_t>(op.numRecLast))) {
+        const ForeignBatchD b = op.batches[rid.batchID - op.baseBatchID];
+        if (b.isConst) { r.lo = op.c64[0]; r.hi = op.c64[1]; r.ok = op.cok; return r; }
+        const uint8_t *v = b.base + b.valuesOff + static_cast<size_t>(w) * rid.index;
+        r.lo = *reinterpret_cast<const uint64_t *>(v);
+        if (w == 16) r.hi = *reinterpret_cast<const uint64_t *>(v + 8);
+        r.ok = b.valuesOff != 0 ? get_bit(b.base + b.nullsOff, rid.index + b.bitOff) : 1u;
+      }
+      return r;
+    }
+  }
+}
+
+__device__ __forceinline__ void store_from_i64(const SinkD &s, uint32_t i, uint32_t row, int64_t v, uint32_t ok) {
+  uint8_t *dst = s.values + static_cast<size_t>(s.width) * i;
+  if (s.type == SINK_PRED) { s.values[i] = v != 0; return; }
+  if (s.type == SINK_MEASURE) {
+    if (!ok) {
+      if (s.width == 8) *reinterpret_cast<uint64_t *>(dst) = s.identity;
+      else *reinterpret_cast<uint32_t *>(dst) = static_cast<uint32_t>(s.identity);
+      return;
+    }
+    const bool isAvg = s.agg == AGGR_AVG_FLOAT;
+    uint32_t count = 1;
+    if ((isAvg || (s.agg >= AGGR_SUM_UNSIGNED && s.agg <= AGGR_SUM_FLOAT)) && s.baseCounts)
+      count = s.baseCounts[row + 1] - s.baseCounts[row];
+    if (isAvg) {
+      float f;
+      switch (s.dtype) {
+        case Float64: f = static_cast<float>(static_cast<double>(v)); break;
+        case Int32: f = static_cast<float>(static_cast<int32_t>(v)); break;
+        case Uint32: f = static_cast<float>(static_cast<uint32_t>(v)); break;
+        default: f = static_cast<float>(v); break;
+      }
+      reinterpret_cast<uint32_t *>(dst)[0] = f_bits(f);
+      reinterpret_cast<uint32_t *>(dst)[1] = count;
+      return;
+    }
+    switch (s.dtype) {
+      case Int32: case Uint32: *reinterpret_cast<uint32_t *>(dst) = static_cast<uint32_t>(v) * count; break;
+      case Float32: *reinterpret_cast<float *>(dst) = static_cast<float>(v) * static_cast<float>(count); break;
+      case Int64: *reinterpret_cast<uint64_t *>(dst) = static_cast<uint64_t>(v) * count; break;
+      default: *reinterpret_cast<double *>(dst) = static_cast<double>(v) * static_cast<double>(count); break;
+    }
+    return;
+  }
+  switch (s.dtype) {
+    case Bool: *dst = v != 0; break;
+    case Int8: case Uint8: *dst = static_cast<uint8_t>(v); break;
+    case Int16: case Uint16: *reinterpret_cast<uint16_t *>(dst) = static_cast<uint16_t>(v); break;
+    case Int32: case Uint32: *reinterpret_cast<uint32_t *>(dst) = static_cast<uint32_t>(v); break;
+    case Float32: *reinterpret_cast<float *>(dst) = static_cast<float>(v); break;
+    case Int64: *reinterpret_cast<int64_t *>(dst) = v; break;
+    default: break;
+  }
+  s.nulls[i] = ok ? 1 : 0;
+}
+
+__global__ __launch_bounds__(kBlock) void transform_wide_kernel(EvalParams p, SinkD s, int n) {
+  for (int64_t i64 = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i64 < n;
+       i64 += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const uint32_t i = static_cast<uint32_t>(i64);
+    const uint32_t row = p.needRow ? p.idx[i] : i;
+    const WVal a = load_wide(p.a, i, row, p.baseCounts, p.startCount);
+    const int K = p.a.kind;
+    const int ft = p.functor;
+    const bool sinkWide = s.type != SINK_PRED && s.type != SINK_MEASURE && (s.dtype == UUID || s.dtype == GeoPoint);
+    if (p.arity == 2) {  // only Equal against a constant of the same kind (functor.hpp:1079-1133)
+      DVal r;
+      r.bits = 0;
+      r.ok = 0;
+      if (!sinkWide && ft == Equal) {
+        const WVal b = load_wide(p.b, i, row, p.baseCounts, p.startCount);
+        r.ok = a.ok && b.ok;
+        if (r.ok) {
+          if (K == K_UUID) r.bits = a.lo == b.lo && a.hi == b.hi;
+          else {
+            const float alat = bits_f(static_cast<uint32_t>(a.lo)), along = bits_f(static_cast<uint32_t>(a.lo >> 32));
+            const float blat = bits_f(static_cast<uint32_t>(b.lo)), blong = bits_f(static_cast<uint32_t>(b.lo >> 32));
+            r.bits = alat == blat && along == blong;
+          }
+        }
+      }
+      sink_store32(s, i, row, r, K_BOOL);
+      continue;
+    }
+    if (K == K_UUID || K == K_GEO) {
+      if (sinkWide) {  // X -> X is a copy, anything else (zero, null) (functor.hpp:800-881)
+        const bool same = (K == K_UUID) == (s.dtype == UUID);
+        uint8_t *dst = s.values + static_cast<size_t>(s.width) * i;
+        reinterpret_cast<uint64_t *>(dst)[0] = same ? a.lo : 0;
+        if (s.width == 16) reinterpret_cast<uint64_t *>(dst)[1] = same ? a.hi : 0;
+        s.nulls[i] = (same && a.ok) ? 1 : 0;
+        continue;
+      }
+      DVal r;
+      r.bits = 0;
+      r.ok = 0;
+      if (K == K_UUID && ft == GetHLLValue && a.ok) {
+        r.bits = hll_from_hash(a.lo ^ a.hi);
+        r.ok = 1;
+      }
+      sink_store32(s, i, row, r, K_U32);
+      continue;
+    }
+    // Int64 input: the generic unary functor (functor.hpp:660-697)
+    if (sinkWide) {
+      uint8_t *dst = s.values + static_cast<size_t>(s.width) * i;
+      reinterpret_cast<uint64_t *>(dst)[0] = 0;
+      if (s.width == 16) reinterpret_cast<uint64_t *>(dst)[1] = 0;
+      s.nulls[i] = 0;
+      continue;
+    }
+    const int64_t v = static_cast<int64_t>(a.lo);
+    DVal r;
+    switch (ft) {
+      case Not: r.ok = a.ok; r.bits = a.ok ? (v == 0) : 0; sink_store32(s, i, row, r, K_BOOL); continue;
+      case IsNull: r.ok = 1; r.bits = !a.ok; sink_store32(s, i, row, r, K_BOOL); continue;
+      case IsNotNull: r.ok = 1; r.bits = a.ok != 0; sink_store32(s, i, row, r, K_BOOL); continue;
+      case Negate: store_from_i64(s, i, row, a.ok ? static_cast<int64_t>(0ull - a.lo) : 0, a.ok); continue;
+      case BitwiseNot: store_from_i64(s, i, row, a.ok ? ~v : 0, a.ok); continue;
+      case GetHLLValue: {
+        r.ok = a.ok;
+        r.bits = 0;
+        if (a.ok) {
+          uint64_t q[2] = {a.lo, 0};
+          r.bits = hll_from_hash(murmur3_128_lo<2>(q, 8, 0));
+        }
+        sink_store32(s, i, row, r, K_U32);
+        continue;
+      }
+      default: break;
+    }
+    if (ft >= GetWeekStart && ft <= GetQuarterOfYear) {
+      DVal t;
+      t.bits = static_cast<uint32_t>(a.lo);
+      t.ok = a.ok;
+      sink_store32(s, i, row, unary32(ft, K_U32, t), K_U32);
+      continue;
+    }
+    store_from_i64(s, i, row, v, a.ok);  // Noop and unknown functors
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// filter: fused predicate + stable in-place compaction (decoupled look-back)
+// ---------------------------------------------------------------------------------------------
+constexpr int kFilterItems = 8;
+constexpr int kFilterTile = kBlock * kFilterItems;
+struct ScanWorkspace {
+  unsigned int *ticket;  // next tile to process
+  uint32_t *total;       // number of survivors
+  uint64_t *status;      // one word per tile: flag | count
+};
+
+// MODE 0: evaluate the predicate from the operands, write pred[], compact idx
+// MODE 1: read pred[], compact one RecordID vector (8-byte payload)
+// MODE 2: read pred[] (already evaluated by the wide-value kernel), compact idx
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void filter_kernel(EvalParams p, uint8_t *pred, uint32_t *idx, uint64_t *rids,
+                                                        ScanWorkspace ws, int n, int numTiles) {
+  __shared__ uint32_t sCounts[kFilterItems * kWaves + 1];
+  __shared__ int sTile;
+  __shared__ uint32_t sBase;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint64_t ltMask = (1ull << lane) - 1;
+  for (;;) {
+    if (threadIdx.x == 0) sTile = static_cast<int>(atomicAdd(ws.ticket, 1u));
+    __syncthreads();
+    const int tile = sTile;
+    if (tile >= numTiles) break;
+    const int64_t base = static_cast<int64_t>(tile) * kFilterTile;
+
+    uint32_t rows[kFilterItems];
+    uint64_t payload[MODE == 1 ? kFilterItems : 1];
+    uint32_t keep[kFilterItems];
+    if (MODE == 0) {
+      DVal va[kFilterItems], vb[kFilterItems];
+#pragma unroll
+      for (int k = 0; k < kFilterItems; k++) {
+        const int64_t i = base + k * kBlock + threadIdx.x;
+        rows[k] = i < n ? idx[i] : 0u;
+      }
+#pragma unroll
+      for (int k = 0; k < kFilterItems; k++) {
+        const int64_t i = base + k * kBlock + threadIdx.x;
+        if (i < n) {
+          va[k] = load32(p.a, static_cast<uint32_t>(i), rows[k], p.baseCounts, p.startCount);
+          if (p.arity == 2) vb[k] = load32(p.b, static_cast<uint32_t>(i), rows[k], p.baseCounts, p.startCount);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < kFilterItems; k++) {
+        const int64_t i = base + k * kBlock + threadIdx.x;
+        keep[k] = 0;
+        if (i < n) {
+          DVal x = cvt32(va[k], p.a.kind, p.I);
+          DVal r = p.arity == 1 ? unary32(p.functor, p.I, x)
+                                : binary32(p.functor, p.I, x, cvt32(vb[k], p.b.kind, p.I));
+          keep[k] = cvt32(r, p.rk, K_BOOL).bits;  // validity is ignored (functor.hpp:903-915)
+          pred[i] = static_cast<uint8_t>(keep[k]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < kFilterItems; k++) {
+        const int64_t i = base + k * kBlock + threadIdx.x;
+        keep[k] = i < n ? pred[i] : 0u;
+        if (MODE == 1) payload[k] = i < n ? rids[i] : 0ull;
+        else rows[k] = i < n ? idx[i] : 0u;
+      }
+    }
+    // every input of this tile is in registers before the tile's count becomes visible: later
+    // tiles only start overwriting our input range after they have seen our status word
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    uint32_t rank[kFilterItems];
+#pragma unroll
+    for (int k = 0; k < kFilterItems; k++) {
+      const uint64_t m = __ballot(keep[k] != 0);
+      rank[k] = __popcll(m & ltMask);
+      if (lane == 0) sCounts[k * kWaves + wave] = __popcll(m);
+    }
+    __syncthreads();
+    if (wave == 0) {
+      // exclusive scan of the kFilterItems*kWaves (=32) partial counts, position order
+      uint32_t c = lane < kFilterItems * kWaves ? sCounts[lane] : 0u;
+      uint32_t incl = c;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+      }
+      const uint32_t tileCount = __shfl(incl, 63);
+      if (lane == 0) st_status(ws.status + tile, (tile == 0 ? kFlagInclusive : kFlagAggregate) | tileCount);
+      uint32_t exclusive = 0;
+      if (tile > 0) {
+        exclusive = static_cast<uint32_t>(lookback_wave(ws.status, tile, lane));
+        if (lane == 0) st_status(ws.status + tile, kFlagInclusive | (exclusive + tileCount));
+      }
+      if (lane < kFilterItems * kWaves) sCounts[lane] = incl - c;
+      if (lane == 0) {
+        sBase = exclusive;
+        if (tile == numTiles - 1) *ws.total = exclusive + tileCount;
+      }
+    }
+    __syncthreads();
+    const uint32_t blockBase = sBase;
+#pragma unroll
+    for (int k = 0; k < kFilterItems; k++) {
+      if (keep[k]) {
+        const uint32_t dst = blockBase + sCounts[k * kWaves + wave] + rank[k];
+        if (MODE == 1) rids[dst] = payload[k];
+        else idx[dst] = rows[k];
+      }
+    }
+    __syncthreads();  // sCounts / sTile are reused by the next tile
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static void build_params(const InputVector *ins, int arity, hipStream_t stream, const uint32_t *indexVector,
+                         const uint32_t *baseCounts, uint32_t startCount, int functor, EvalParams &p,
+                         CallTemps &temps) {
+  memset(&p, 0, sizeof(p));
+  bind_operand(ins[0], true, stream, p.a, temps);
+  p.arity = arity;
+  p.functor = functor;
+  if (arity == 2) {
+    bind_operand(ins[1], false, stream, p.b, temps);
+    check_binary_kinds(p.a, p.b, ins[1]);
+    p.I = common_kind(p.a.kind, p.b.kind);
+    p.rk = is_wide(p.I) ? K_BOOL : binary_result_kind(functor, p.I);
+  } else {
+    p.I = p.a.kind;
+    p.rk = is_wide(p.I) ? K_NONE : unary_result_kind(functor, p.I);
+  }
+  p.idx = indexVector;
+  p.baseCounts = baseCounts;
+  p.startCount = startCount;
+  p.needRow = indexVector != nullptr && (p.a.type == OP_COLUMN || (arity == 2 && p.b.type == OP_COLUMN));
+}
+
+static int run_transform(const InputVector *ins, int arity, const OutputVector &output, uint32_t *indexVector,
+                         int n, uint32_t *baseCounts, uint32_t startCount, int functor, hipStream_t stream) {
+  if (n <= 0) return n < 0 ? 0 : n;
+  EvalParams p;
+  SinkD s;
+  CallTemps temps;
+  build_params(ins, arity, stream, indexVector, baseCounts, startCount, functor, p, temps);
+  bind_sink(output, baseCounts, s);
+  if (s.type == SINK_MEASURE && s.baseCounts && indexVector) p.needRow = 1;
+  if (is_wide(p.a.kind)) {
+    const int grid = capped_grid((static_cast<int64_t>(n) + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(transform_wide_kernel, dim3(grid), dim3(kBlock), 0, stream, p, s, n);
+  } else {
+    constexpr int ITEMS = 4;
+    const int grid = capped_grid((static_cast<int64_t>(n) + kBlock * ITEMS - 1) / (kBlock * ITEMS), 256 * 16);
+    hipLaunchKernelGGL(transform32_kernel<ITEMS>, dim3(grid), dim3(kBlock), 0, stream, p, s, n);
+  }
+  check_launch("transform");
+  return n;
+}
+
+static int run_filter(const InputVector *ins, int arity, uint32_t *indexVector, uint8_t *pred, int n,
+                      RecordID **recordIDVectors, int numForeignTables, uint32_t *baseCounts, uint32_t startCount,
+                      int functor, hipStream_t stream) {
+  if (numForeignTables < 0 || numForeignTables > 8) throw std::invalid_argument("only support up to 8 foreign tables");
+  if (n <= 0) return 0;
+  EvalParams p;
+  CallTemps temps;
+  build_params(ins, arity, stream, indexVector, baseCounts, startCount, functor, p, temps);
+  p.needRow = 1;
+  if (is_wide(p.a.kind)) {
+    // wide operands: evaluate the predicate with the wide transform kernel, then compact by pred
+    SinkD s;
+    bind_pred_sink(pred, s);
+    p.needRow = indexVector != nullptr;
+    const int grid = capped_grid((static_cast<int64_t>(n) + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(transform_wide_kernel, dim3(grid), dim3(kBlock), 0, stream, p, s, n);
+    check_launch("filter (wide predicate)");
+  }
+  const int numTiles = static_cast<int>((static_cast<int64_t>(n) + kFilterTile - 1) / kFilterTile);
+  const int passes = 1 + numForeignTables;
+  const size_t passBytes = 16 + sizeof(uint64_t) * static_cast<size_t>(numTiles);
+  StreamBuffer wsBuf(passBytes * passes, stream);
+  hip_check(hipMemsetAsync(wsBuf.get(), 0, passBytes * passes, stream), "hipMemsetAsync");
+  const int grid = capped_grid(numTiles);
+  uint32_t *totalDev = nullptr;
+  for (int pass = 0; pass < passes; pass++) {
+    uint8_t *base = wsBuf.as<uint8_t>() + passBytes * pass;
+    ScanWorkspace ws;
+    ws.ticket = reinterpret_cast<unsigned int *>(base);
+    ws.total = reinterpret_cast<uint32_t *>(base + 4);
+    ws.status = reinterpret_cast<uint64_t *>(base + 16);
+    if (pass == 0) {
+      totalDev = ws.total;
+      if (is_wide(p.a.kind)) {
+        hipLaunchKernelGGL(filter_kernel<2>, dim3(grid), dim3(kBlock), 0, stream, p, pred, indexVector,
+                           static_cast<uint64_t *>(nullptr), ws, n, numTiles);
+      } else {
+        hipLaunchKernelGGL(filter_kernel<0>, dim3(grid), dim3(kBlock), 0, stream, p, pred, indexVector,
+                           static_cast<uint64_t *>(nullptr), ws, n, numTiles);
+      }
+    } else {
+      hipLaunchKernelGGL(filter_kernel<1>, dim3(grid), dim3(kBlock), 0, stream, p, pred, indexVector,
+                         reinterpret_cast<uint64_t *>(recordIDVectors[pass - 1]), ws, n, numTiles);
+    }
+    check_launch("filter");
+  }
+  uint32_t total = 0;
+  read_back_u32(totalDev, &total, 1, stream);
+  return static_cast<int>(total);
+}
+
+}  // namespace ares
+
+using namespace ares;
+
+extern "C" {
+
+CGoCallResHandle InitIndexVector(uint32_t *indexVector, uint32_t start, int indexVectorLength, void *cudaStream,
+                                 int device) {
+  ARES_ABI_BEGIN(device)
+  if (indexVectorLength > 0) {
+    const int64_t quads = (static_cast<int64_t>(indexVectorLength) + 3) / 4;
+    const int grid = capped_grid((quads + kBlock - 1) / kBlock, 256 * 16);
+    hipLaunchKernelGGL(init_index_kernel, dim3(grid), dim3(kBlock), 0, reinterpret_cast<hipStream_t>(cudaStream),
+                       indexVector, start, indexVectorLength);
+    check_launch("InitIndexVector");
+  }
+  ARES_ABI_END("InitIndexVector")
+}
+
+CGoCallResHandle UnaryTransform(InputVector input, OutputVector output, uint32_t *indexVector,
+                                int indexVectorLength, uint32_t *baseCounts, uint32_t startCount,
+                                enum UnaryFunctorType functorType, void *cudaStream, int device) {
+  ARES_ABI_BEGIN(device)
+  resHandle.res = int_result(run_transform(&input, 1, output, indexVector, indexVectorLength, baseCounts,
+                                           startCount, functorType, reinterpret_cast<hipStream_t>(cudaStream)));
+  ARES_ABI_END("UnaryTransform")
+}
+
+CGoCallResHandle BinaryTransform(InputVector lhs, InputVector rhs, OutputVector output, uint32_t *indexVector,
+                                 int indexVectorLength, uint32_t *baseCounts, uint32_t startCount,
+                                 enum BinaryFunctorType functorType, void *cudaStream, int device) {
+  ARES_ABI_BEGIN(device)
+  InputVector ins[2] = {lhs, rhs};
+  resHandle.res = int_result(run_transform(ins, 2, output, indexVector, indexVectorLength, baseCounts, startCount,
+                                           functorType, reinterpret_cast<hipStream_t>(cudaStream)));
+  ARES_ABI_END("BinaryTransform")
+}
+
+CGoCallResHandle UnaryFilter(InputVector input, uint32_t *indexVector, uint8_t *predicateVector,
+                             int indexVectorLength, RecordID **recordIDVectors, int numForeignTables,
+                             uint32_t *baseCounts, uint32_t startCount, enum UnaryFunctorType functorType,
+                             void *cudaStream, int device) {
+  ARES_ABI_BEGIN(device)
+  resHandle.res = int_result(run_filter(&input, 1, indexVector, predicateVector, indexVectorLength, recordIDVectors,
+                                        numForeignTables, baseCounts, startCount, functorType,
+                                        reinterpret_cast<hipStream_t>(cudaStream)));
+  ARES_ABI_END("UnaryFilter")
+}
+
+CGoCallResHandle BinaryFilter(InputVector lhs, InputVector rhs, uint32_t *indexVector, uint8_t *predicateVector,
+                              int indexVectorLength, RecordID **recordIDVectors, int numForeignTables,
+                              uint32_t *baseCounts, uint32_t startCount, enum BinaryFunctorType functorType,
+                              void *cudaStream, int device) {
+  ARES_ABI_BEGIN(device)
+  InputVector ins[2] = {lhs, rhs};
+  resHandle.res = int_result(run_filter(ins, 2, indexVector, predicateVector, indexVectorLength, recordIDVectors,
+                                        numForeignTables, baseCounts, startCount, functorType,
+                                        reinterpret_cast<hipStream_t>(cudaStream)));
+  ARES_ABI_END("BinaryFilter")
+}
+
+}  // extern "C"

@@ -1,0 +1,69 @@
+"""One tiny end-to-end pass of the hot path, checked against the oracle (used by
+__graft_entry__.smoke() and tests/test_executor.py): filter d1 < 90, dimensions
+[floor(ts, 3600), d1, d2, d3], sum(m) — the shape of BASELINE config C3 — through both reduction
+paths, over several batches."""
+import numpy as np
+
+from . import abi
+from .columns import DeviceColumn
+from .executor import (BatchContext, BatchExecutor, Binary, Col, Const, DimensionSpec, QueryPlan,
+                       fetch_results)
+
+
+def c3_plan(use_hash_reduction=True, with_filter=True):
+    return QueryPlan(
+        filters=[Binary(abi.LessThan, Col("d1"), Const(90))] if with_filter else [],
+        dimensions=[DimensionSpec(Binary(abi.Floor, Col("ts"), Const(3600)), abi.Uint32),
+                    DimensionSpec(Col("d1"), abi.Uint32), DimensionSpec(Col("d2"), abi.Uint32),
+                    DimensionSpec(Col("d3"), abi.Uint32)],
+        measure=Col("m"), agg=abi.AGGR_SUM_FLOAT, measure_type=abi.Float64,
+        use_hash_reduction=use_hash_reduction)
+
+
+def synth_batch(rng, n, null_fraction=0.0):
+    cols = {
+        "ts": (abi.Uint32, rng.integers(0, 86400 * 7, n).astype(np.uint32)),
+        "d1": (abi.Uint32, rng.integers(0, 100, n).astype(np.uint32)),
+        "d2": (abi.Uint32, np.minimum(rng.zipf(1.1, n) - 1, 49).astype(np.uint32)),
+        "d3": (abi.Uint32, rng.integers(0, 2, n).astype(np.uint32)),
+        "m": (abi.Float32, (rng.integers(0, 400, n) / 4).astype(np.float32)),
+    }
+    valid = {k: (rng.random(n) >= null_fraction) if null_fraction else None for k in cols}
+    return cols, valid
+
+
+def run_query(be, plan, batches):
+    ctx = BatchContext(be, plan)
+    ex = BatchExecutor(ctx)
+    for cols, valid in batches:
+        dev = {k: DeviceColumn(be, t, v, valid=valid[k]) for k, (t, v) in cols.items()}
+        n = len(next(iter(cols.values()))[1])
+        ex.run({k: d.vp for k, d in dev.items()}, n)
+        for d in dev.values():
+            d.free()
+    dims, valids, meas = fetch_results(ctx)
+    calls = ctx.calls
+    ctx.release()
+    n = len(valids[0]) if valids else 0
+    out = {}
+    m = meas.view(np.float64) if plan.measure_type == abi.Float64 else meas.view(np.uint32)
+    for r in range(n):
+        key = tuple((bytes(d[r * len(d) // n:(r + 1) * len(d) // n]), int(v[r])) for d, v in zip(dims, valids))
+        out[key] = m[r]
+    return out, calls
+
+
+def compare_results(got, want, rel=1e-6):
+    assert got.keys() == want.keys(), f"group keys differ: {len(got)} vs {len(want)}"
+    for k, v in want.items():
+        g = got[k]
+        assert abs(g - v) <= rel * max(1.0, abs(v)), (k, g, v)
+
+
+def run_smoke(hip, oracle, n=20000, batches=3, seed=7):
+    rng = np.random.default_rng(seed)
+    data = [synth_batch(rng, n, null_fraction=0.01) for _ in range(batches)]
+    for use_hash in (True, False):
+        got, _ = run_query(hip, c3_plan(use_hash), data)
+        want, _ = run_query(oracle, c3_plan(use_hash), data)
+        compare_results(got, want)

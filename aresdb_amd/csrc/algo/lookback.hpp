@@ -21,6 +21,10 @@ constexpr uint64_t kFlagAggregate = 1ull << 62;
 constexpr uint64_t kFlagInclusive = 2ull << 62;
 constexpr uint64_t kFlagMask = 3ull << 62;
 constexpr uint64_t kValueMask = ~kFlagMask;
+// Every spin is bounded (a predecessor that never publishes would otherwise hang the GPU): after
+// ~2^22 polls (seconds) the waiting lane raises the launch's error word and proceeds with garbage;
+// the host turns the error word into an exception.
+constexpr uint32_t kMaxSpins = 1u << 22;
 
 __device__ __forceinline__ uint64_t ld_status(const uint64_t *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -32,7 +36,7 @@ __device__ __forceinline__ void st_status(uint64_t *p, uint64_t v) {
 // Exclusive prefix of `tile` from its predecessors' status words; must be called by all 64
 // lanes of ONE wavefront.  Lane l inspects tile (look - l); the nearest predecessor that already
 // holds an inclusive prefix terminates the walk.
-__device__ __forceinline__ uint64_t lookback_wave(uint64_t *status, int tile, int lane) {
+__device__ __forceinline__ uint64_t lookback_wave(uint64_t *status, int tile, int lane, uint32_t *error) {
   uint64_t exclusive = 0;
   int look = tile - 1;
   while (look >= 0) {
@@ -40,9 +44,14 @@ __device__ __forceinline__ uint64_t lookback_wave(uint64_t *status, int tile, in
     uint64_t w;
     if (t >= 0) {
       w = ld_status(status + t);
+      uint32_t spins = 0;
       while ((w & kFlagMask) == 0) {
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(2);
         w = ld_status(status + t);
+        if (++spins > kMaxSpins) {  // never hang the device: flag the launch as failed instead
+          atomicOr(error, 1u);
+          w = kFlagInclusive;
+        }
       }
     } else {
       w = kFlagInclusive;  // before the first tile: inclusive prefix 0
@@ -55,21 +64,6 @@ __device__ __forceinline__ uint64_t lookback_wave(uint64_t *status, int tile, in
     exclusive += v;
     if (inclusiveLanes) break;
     look -= 64;
-  }
-  return exclusive;
-}
-
-// Serial variant: ONE lane walks back alone (the radix sort runs 256 of these, one per digit).
-__device__ __forceinline__ uint64_t lookback_serial(const uint64_t *status, int tile, int stride) {
-  uint64_t exclusive = 0;
-  for (int t = tile - 1; t >= 0; --t) {
-    uint64_t w = ld_status(status + static_cast<size_t>(t) * stride);
-    while ((w & kFlagMask) == 0) {
-      __builtin_amdgcn_s_sleep(1);
-      w = ld_status(status + static_cast<size_t>(t) * stride);
-    }
-    exclusive += w & kValueMask;
-    if ((w & kFlagMask) == kFlagInclusive) break;
   }
   return exclusive;
 }

@@ -84,7 +84,8 @@ __device__ __forceinline__ void st_status32(uint32_t *p, uint32_t v) {
 __global__ __launch_bounds__(kBlock) void radix_pass_kernel(const uint64_t *keysIn, const uint32_t *valsIn,
                                                             uint64_t *keysOut, uint32_t *valsOut, int n, int shift,
                                                             const uint32_t *digitStart, unsigned int *ticket,
-                                                            uint32_t *status /* [numTiles][256] */, int numTiles) {
+                                                            uint32_t *error, uint32_t *status /* [numTiles][256] */,
+                                                            int numTiles) {
   __shared__ uint64_t sKeys[kSortTile];
   __shared__ uint32_t sVals[kSortTile];
   __shared__ uint32_t sHist[kWaves][256];  // per-wave digit counts -> per-wave bases inside the tile
@@ -166,9 +167,14 @@ __global__ __launch_bounds__(kBlock) void radix_pass_kernel(const uint64_t *keys
     if (tile > 0) {
       for (int t = tile - 1; t >= 0; --t) {
         uint32_t w = ld_status32(status + static_cast<size_t>(t) * 256 + d);
+        uint32_t spins = 0;
         while ((w & kFlagMask32) == 0) {
-          __builtin_amdgcn_s_sleep(1);
+          __builtin_amdgcn_s_sleep(2);
           w = ld_status32(status + static_cast<size_t>(t) * 256 + d);
+          if (++spins > kMaxSpins) {
+            atomicOr(error, 1u);
+            w = kFlagInc32;
+          }
         }
         exclusive += w & ~kFlagMask32;
         if ((w & kFlagMask32) == kFlagInc32) break;
@@ -244,9 +250,12 @@ static void sort_impl(const DimensionVector &keys, int length, hipStream_t strea
     hipLaunchKernelGGL(radix_pass_kernel, dim3(passGrid), dim3(kBlock), 0, stream,
                        even ? keys.HashValues : altKeys, even ? keys.IndexVector : altVals,
                        even ? altKeys : keys.HashValues, even ? altVals : keys.IndexVector, length, 8 * pass,
-                       hist + 256 * pass, tickets + pass, status, numTiles);
+                       hist + 256 * pass, tickets + pass, tickets + 8, status, numTiles);
     check_launch("Sort radix pass");
   }
+  uint32_t err = 0;
+  read_back_u32(tickets + 8, &err, 1, stream);
+  if (err) throw AlgorithmError("ERROR: Sort: inter-tile scan timed out");
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -270,6 +279,7 @@ struct ReduceParams {
   int numTiles;
   unsigned int *ticket;
   uint32_t *total;
+  uint32_t *error;
   uint64_t *status;
 };
 
@@ -328,7 +338,7 @@ __global__ __launch_bounds__(kBlock) void reduce_kernel(ReduceParams p) {
       if (lane == 0) st_status(p.status + tile, (tile == 0 ? kFlagInclusive : kFlagAggregate) | tileHeads);
       uint64_t excl = 0;
       if (tile > 0) {
-        excl = lookback_wave(p.status, tile, lane);
+        excl = lookback_wave(p.status, tile, lane, p.error);
         if (lane == 0) st_status(p.status + tile, kFlagInclusive | (excl + tileHeads));
       }
       if (lane == 0) {
@@ -396,6 +406,7 @@ static int reduce_impl(const DimensionVector &in, uint8_t *inputValues, const Di
             "hipMemsetAsync");
   p.ticket = ws.as<unsigned int>();
   p.total = ws.as<uint32_t>() + 1;
+  p.error = ws.as<uint32_t>() + 2;
   p.status = reinterpret_cast<uint64_t *>(ws.as<uint8_t>() + 16);
   // every group slot starts from the aggregate's identity; partials are merged with atomics
   const int fillGrid = capped_grid((static_cast<int64_t>(length) + kBlock - 1) / kBlock, 256 * 8);
@@ -403,9 +414,10 @@ static int reduce_impl(const DimensionVector &in, uint8_t *inputValues, const Di
   check_launch("Reduce init");
   hipLaunchKernelGGL(reduce_kernel, dim3(capped_grid(p.numTiles)), dim3(kBlock), 0, stream, p);
   check_launch("Reduce");
-  uint32_t groups = 0;
-  read_back_u32(p.total, &groups, 1, stream);
-  return static_cast<int>(groups);
+  uint32_t result[2] = {0, 0};  // {groups, error}
+  read_back_u32(p.total, result, 2, stream);
+  if (result[1]) throw AlgorithmError("ERROR: Reduce: inter-tile scan timed out");
+  return static_cast<int>(result[0]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -421,6 +433,7 @@ struct ExpandParams {
   int numTiles;
   uint64_t *offsets;  // exclusive prefix of the run lengths (n + 1 entries)
   unsigned int *ticket;
+  uint32_t *error;
   uint64_t *status;
 };
 
@@ -465,7 +478,7 @@ __global__ __launch_bounds__(kBlock) void expand_offsets_kernel(ExpandParams p) 
       if (lane == 0) st_status(p.status + tile, (tile == 0 ? kFlagInclusive : kFlagAggregate) | tileTotal);
       uint64_t excl = 0;
       if (tile > 0) {
-        excl = lookback_wave(p.status, tile, lane);
+        excl = lookback_wave(p.status, tile, lane, p.error);
         if (lane == 0) st_status(p.status + tile, kFlagInclusive | (excl + tileTotal));
       }
       if (lane == 0) {
@@ -513,13 +526,16 @@ static int expand_impl(const DimensionVector &in, const DimensionVector &out, ui
   StreamBuffer ws(16 + statusBytes + offBytes, stream);
   hip_check(hipMemsetAsync(ws.get(), 0, 16 + statusBytes, stream), "hipMemsetAsync");
   p.ticket = ws.as<unsigned int>();
+  p.error = ws.as<uint32_t>() + 2;
   p.status = reinterpret_cast<uint64_t *>(ws.as<uint8_t>() + 16);
   p.offsets = reinterpret_cast<uint64_t *>(ws.as<uint8_t>() + 16 + statusBytes);
   hipLaunchKernelGGL(expand_offsets_kernel, dim3(capped_grid(p.numTiles)), dim3(kBlock), 0, stream, p);
   check_launch("Expand offsets");
   uint64_t *pinned = pinned_words();
   hip_check(hipMemcpyAsync(pinned, p.offsets + n, sizeof(uint64_t), hipMemcpyDeviceToHost, stream), "read back total");
+  hip_check(hipMemcpyAsync(pinned + 1, p.error, sizeof(uint32_t), hipMemcpyDeviceToHost, stream), "read back error");
   hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+  if (static_cast<uint32_t>(pinned[1])) throw AlgorithmError("ERROR: Expand: inter-tile scan timed out");
   const uint64_t total = pinned[0];
   const int room = out.VectorCapacity - occupied;
   const int outLen = static_cast<int>(total < static_cast<uint64_t>(room > 0 ? room : 0) ? total : (room > 0 ? room : 0));

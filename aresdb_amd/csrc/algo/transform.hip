@@ -271,6 +271,7 @@ constexpr int kFilterTile = kBlock * kFilterItems;
 struct ScanWorkspace {
   unsigned int *ticket;  // next tile to process
   uint32_t *total;       // number of survivors
+  uint32_t *error;       // raised when a look-back spin times out
   uint64_t *status;      // one word per tile: flag | count
 };
 
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(kBlock) void filter_kernel(EvalParams p, uint8_t *p
       if (lane == 0) st_status(ws.status + tile, (tile == 0 ? kFlagInclusive : kFlagAggregate) | tileCount);
       uint32_t exclusive = 0;
       if (tile > 0) {
-        exclusive = static_cast<uint32_t>(lookback_wave(ws.status, tile, lane));
+        exclusive = static_cast<uint32_t>(lookback_wave(ws.status, tile, lane, ws.error));
         if (lane == 0) st_status(ws.status + tile, kFlagInclusive | (exclusive + tileCount));
       }
       if (lane < kFilterItems * kWaves) sCounts[lane] = incl - c;
@@ -455,6 +456,7 @@ static int run_filter(const InputVector *ins, int arity, uint32_t *indexVector, 
     ScanWorkspace ws;
     ws.ticket = reinterpret_cast<unsigned int *>(base);
     ws.total = reinterpret_cast<uint32_t *>(base + 4);
+    ws.error = reinterpret_cast<uint32_t *>(wsBuf.as<uint8_t>() + 8);  // shared by all passes
     ws.status = reinterpret_cast<uint64_t *>(base + 16);
     if (pass == 0) {
       totalDev = ws.total;
@@ -471,9 +473,10 @@ static int run_filter(const InputVector *ins, int arity, uint32_t *indexVector, 
     }
     check_launch("filter");
   }
-  uint32_t total = 0;
-  read_back_u32(totalDev, &total, 1, stream);
-  return static_cast<int>(total);
+  uint32_t result[2] = {0, 0};  // {survivors, error}
+  read_back_u32(totalDev, result, 2, stream);
+  if (result[1]) throw AlgorithmError("ERROR: filter: inter-tile scan timed out");
+  return static_cast<int>(result[0]);
 }
 
 }  // namespace ares

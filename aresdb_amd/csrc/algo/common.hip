@@ -1,6 +1,11 @@
 // Host helpers shared by the entry points (see common.hpp).
 #include "common.hpp"
 
+#include <atomic>
+#include <map>
+#include <mutex>
+#include <vector>
+
 namespace ares {
 
 namespace {
@@ -31,4 +36,84 @@ void read_back_u32(const uint32_t *dev, uint32_t *host, int count, hipStream_t s
   for (int i = 0; i < count; i++) host[i] = pinned[i];
 }
 
+// ---- kernel timing -------------------------------------------------------------------------------
+namespace {
+struct TimedLaunch {
+  const char *name;
+  hipEvent_t start, stop;
+};
+std::mutex g_profMutex;
+std::atomic<int> g_profEnabled{0};
+std::vector<TimedLaunch> g_launches;
+std::vector<hipEvent_t> g_freeEvents;
+
+hipEvent_t take_event() {
+  if (!g_freeEvents.empty()) {
+    hipEvent_t e = g_freeEvents.back();
+    g_freeEvents.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  hip_check(hipEventCreate(&e), "hipEventCreate");
+  return e;
+}
+}  // namespace
+
+KernelTimer::KernelTimer(const char *name, hipStream_t stream) : slot_(-1), stream_(stream) {
+  if (!g_profEnabled.load(std::memory_order_relaxed)) return;
+  std::lock_guard<std::mutex> lock(g_profMutex);
+  TimedLaunch t{name, take_event(), take_event()};
+  hip_check(hipEventRecord(t.start, stream), "hipEventRecord");
+  g_launches.push_back(t);
+  slot_ = static_cast<int>(g_launches.size()) - 1;
+}
+
+KernelTimer::~KernelTimer() {
+  if (slot_ < 0) return;
+  std::lock_guard<std::mutex> lock(g_profMutex);
+  if (slot_ < static_cast<int>(g_launches.size())) (void)hipEventRecord(g_launches[slot_].stop, stream_);
+}
+
 }  // namespace ares
+
+// Exported (not part of the reference ABI; declared in include/ares_extensions.h).
+extern "C" void AresProfilerEnable(int on) {
+  std::lock_guard<std::mutex> lock(ares::g_profMutex);
+  ares::g_profEnabled.store(on ? 1 : 0);
+  if (on) {
+    for (auto &t : ares::g_launches) {
+      ares::g_freeEvents.push_back(t.start);
+      ares::g_freeEvents.push_back(t.stop);
+    }
+    ares::g_launches.clear();
+  }
+}
+
+// Writes "name launches total_ms\n" lines for everything recorded since the last enable; returns
+// the number of bytes needed.  The caller must have synchronised the streams it used.
+extern "C" size_t AresProfilerReport(char *buf, size_t len) {
+  std::lock_guard<std::mutex> lock(ares::g_profMutex);
+  std::map<std::string, std::pair<long, double>> agg;
+  for (auto &t : ares::g_launches) {
+    float ms = 0;
+    if (hipEventSynchronize(t.stop) == hipSuccess && hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess) {
+      auto &a = agg[t.name];
+      a.first++;
+      a.second += ms;
+    } else {
+      (void)hipGetLastError();
+    }
+  }
+  std::string out;
+  char line[256];
+  for (auto &kv : agg) {
+    snprintf(line, sizeof(line), "%s %ld %.6f\n", kv.first.c_str(), kv.second.first, kv.second.second);
+    out += line;
+  }
+  if (buf && len) {
+    const size_t n = out.size() < len - 1 ? out.size() : len - 1;
+    memcpy(buf, out.data(), n);
+    buf[n] = 0;
+  }
+  return out.size() + 1;
+}

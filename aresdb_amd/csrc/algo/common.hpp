@@ -77,6 +77,27 @@ uint64_t *pinned_words();
 // Reads `count` 32-bit words written by a kernel at `dev` back to the host; synchronises stream.
 void read_back_u32(const uint32_t *dev, uint32_t *host, int count, hipStream_t stream);
 
+// Optional per-kernel timing with HIP events on the launch stream (off by default).  bench.py
+// switches it on through the exported AresProfilerEnable / AresProfilerReport pair to obtain the
+// average duration of every kernel inside the timed region (the roofline figures).
+class KernelTimer {
+ public:
+  KernelTimer(const char *name, hipStream_t stream);
+  ~KernelTimer();
+
+ private:
+  int slot_;
+  hipStream_t stream_;
+};
+
+// Launch + error check (+ timing when profiling is enabled).
+#define ARES_LAUNCH(name, kernel, grid, block, stream, ...)                              \
+  do {                                                                                   \
+    ares::KernelTimer timer_(name, stream);                                              \
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__);        \
+    ares::check_launch(name);                                                            \
+  } while (0)
+
 // Grid size helper: enough blocks to cover `tiles`, capped so that huge inputs are processed by
 // a few waves of blocks per CU (256 CUs x 8 blocks) with a grid-stride / ticket loop.
 inline int capped_grid(int64_t tiles, int cap = 256 * 8) {

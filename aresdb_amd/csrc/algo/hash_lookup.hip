@@ -139,8 +139,7 @@ extern "C" CGoCallResHandle HashLookup(InputVector input, RecordID *output, uint
     p.numBuckets = static_cast<uint32_t>(hashIndex.numBuckets);
     p.bucketBytes = HASH_BUCKET_SIZE * (8 + 1 + hashIndex.keyBytes);
     const int grid = capped_grid((static_cast<int64_t>(indexVectorLength) + kBlock - 1) / kBlock, 256 * 16);
-    hipLaunchKernelGGL(hash_lookup_kernel, dim3(grid), dim3(kBlock), 0, stream, p, output, indexVectorLength);
-    check_launch("HashLookup");
+    ARES_LAUNCH("hash_lookup_kernel", hash_lookup_kernel, grid, kBlock, stream, p, output, indexVectorLength);
   }
   resHandle.res = int_result(indexVectorLength);
   ARES_ABI_END("HashLookup")

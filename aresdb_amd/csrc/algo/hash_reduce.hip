@@ -98,18 +98,15 @@ extern "C" CGoCallResHandle HashReduce(DimensionVector inputKeys, uint8_t *input
     StreamBuffer keyBuf(tableSize * 8, stream), valBuf(tableSize * a.width, stream), counter(16, stream);
     hip_check(hipMemsetAsync(counter.get(), 0, 16, stream), "hipMemsetAsync");
     const int initGrid = capped_grid(static_cast<int64_t>((tableSize + kBlock - 1) / kBlock), 256 * 16);
-    hipLaunchKernelGGL(hash_table_init_kernel, dim3(initGrid), dim3(kBlock), 0, stream, keyBuf.as<uint64_t>(),
+    ARES_LAUNCH("hash_table_init_kernel", hash_table_init_kernel, initGrid, kBlock, stream, keyBuf.as<uint64_t>(),
                        valBuf.as<uint8_t>(), tableSize, a);
-    check_launch("HashReduce init");
     const int grid = capped_grid((static_cast<int64_t>(length) + kBlock - 1) / kBlock, 256 * 16);
-    hipLaunchKernelGGL(hash_insert_kernel, dim3(grid), dim3(kBlock), 0, stream, inputKeys.DimValues, L,
+    ARES_LAUNCH("hash_insert_kernel", hash_insert_kernel, grid, kBlock, stream, inputKeys.DimValues, L,
                        static_cast<size_t>(inputKeys.VectorCapacity), inputValues, a, keyBuf.as<uint64_t>(),
                        valBuf.as<uint8_t>(), tableSize - 1, length);
-    check_launch("HashReduce insert");
-    hipLaunchKernelGGL(hash_extract_kernel, dim3(initGrid), dim3(kBlock), 0, stream, keyBuf.as<uint64_t>(),
+    ARES_LAUNCH("hash_extract_kernel", hash_extract_kernel, initGrid, kBlock, stream, keyBuf.as<uint64_t>(),
                        valBuf.as<uint8_t>(), tableSize, inputKeys.DimValues, outputKeys.DimValues, L,
                        static_cast<size_t>(inputKeys.VectorCapacity), outputValues, a, counter.as<uint32_t>());
-    check_launch("HashReduce extract");
     uint32_t groups = 0;
     read_back_u32(counter.as<uint32_t>(), &groups, 1, stream);
     resHandle.res = int_result(groups);

@@ -237,21 +237,17 @@ static void sort_impl(const DimensionVector &keys, int length, hipStream_t strea
   hip_check(hipMemsetAsync(base, 0, offStatus, stream), "hipMemsetAsync");
 
   const int grid = capped_grid((static_cast<int64_t>(length) + kBlock - 1) / kBlock, 256 * 8);
-  hipLaunchKernelGGL(sort_hash_hist_kernel, dim3(grid), dim3(kBlock), 0, stream, keys.DimValues, L,
+  ARES_LAUNCH("sort_hash_hist_kernel", sort_hash_hist_kernel, grid, kBlock, stream, keys.DimValues, L,
                      static_cast<size_t>(keys.VectorCapacity), keys.IndexVector, keys.HashValues, length, hist);
-  check_launch("Sort hash");
   if (L.numDims == 0) return;  // every row hashes alike: a stable sort leaves the order untouched
-  hipLaunchKernelGGL(digit_start_kernel, dim3(8), dim3(256), 0, stream, hist);
-  check_launch("Sort digit starts");
+  ARES_LAUNCH("digit_start_kernel", digit_start_kernel, 8, 256, stream, hist);
   const int passGrid = capped_grid(numTiles, 256 * 3);
   for (int pass = 0; pass < 8; pass++) {
     hip_check(hipMemsetAsync(status, 0, statusBytes, stream), "hipMemsetAsync");
     const bool even = (pass & 1) == 0;
-    hipLaunchKernelGGL(radix_pass_kernel, dim3(passGrid), dim3(kBlock), 0, stream,
-                       even ? keys.HashValues : altKeys, even ? keys.IndexVector : altVals,
+    ARES_LAUNCH("radix_pass_kernel", radix_pass_kernel, passGrid, kBlock, stream, even ? keys.HashValues : altKeys, even ? keys.IndexVector : altVals,
                        even ? altKeys : keys.HashValues, even ? altVals : keys.IndexVector, length, 8 * pass,
                        hist + 256 * pass, tickets + pass, tickets + 8, status, numTiles);
-    check_launch("Sort radix pass");
   }
   uint32_t err = 0;
   read_back_u32(tickets + 8, &err, 1, stream);
@@ -410,10 +406,8 @@ static int reduce_impl(const DimensionVector &in, uint8_t *inputValues, const Di
   p.status = reinterpret_cast<uint64_t *>(ws.as<uint8_t>() + 16);
   // every group slot starts from the aggregate's identity; partials are merged with atomics
   const int fillGrid = capped_grid((static_cast<int64_t>(length) + kBlock - 1) / kBlock, 256 * 8);
-  hipLaunchKernelGGL(fill_identity_kernel, dim3(fillGrid), dim3(kBlock), 0, stream, outputValues, p.agg, length);
-  check_launch("Reduce init");
-  hipLaunchKernelGGL(reduce_kernel, dim3(capped_grid(p.numTiles)), dim3(kBlock), 0, stream, p);
-  check_launch("Reduce");
+  ARES_LAUNCH("fill_identity_kernel", fill_identity_kernel, fillGrid, kBlock, stream, outputValues, p.agg, length);
+  ARES_LAUNCH("reduce_kernel", reduce_kernel, capped_grid(p.numTiles), kBlock, stream, p);
   uint32_t result[2] = {0, 0};  // {groups, error}
   read_back_u32(p.total, result, 2, stream);
   if (result[1]) throw AlgorithmError("ERROR: Reduce: inter-tile scan timed out");
@@ -529,8 +523,7 @@ static int expand_impl(const DimensionVector &in, const DimensionVector &out, ui
   p.error = ws.as<uint32_t>() + 2;
   p.status = reinterpret_cast<uint64_t *>(ws.as<uint8_t>() + 16);
   p.offsets = reinterpret_cast<uint64_t *>(ws.as<uint8_t>() + 16 + statusBytes);
-  hipLaunchKernelGGL(expand_offsets_kernel, dim3(capped_grid(p.numTiles)), dim3(kBlock), 0, stream, p);
-  check_launch("Expand offsets");
+  ARES_LAUNCH("expand_offsets_kernel", expand_offsets_kernel, capped_grid(p.numTiles), kBlock, stream, p);
   uint64_t *pinned = pinned_words();
   hip_check(hipMemcpyAsync(pinned, p.offsets + n, sizeof(uint64_t), hipMemcpyDeviceToHost, stream), "read back total");
   hip_check(hipMemcpyAsync(pinned + 1, p.error, sizeof(uint32_t), hipMemcpyDeviceToHost, stream), "read back error");
@@ -542,10 +535,9 @@ static int expand_impl(const DimensionVector &in, const DimensionVector &out, ui
   if (outLen > 0) {
     const DimLayoutD L = make_dim_layout(in.NumDimsPerDimWidth);
     const int grid = capped_grid((static_cast<int64_t>(outLen) + kBlock - 1) / kBlock, 256 * 8);
-    hipLaunchKernelGGL(expand_copy_kernel, dim3(grid), dim3(kBlock), 0, stream, p.offsets, n, in.DimValues,
+    ARES_LAUNCH("expand_copy_kernel", expand_copy_kernel, grid, kBlock, stream, p.offsets, n, in.DimValues,
                        static_cast<size_t>(in.VectorCapacity), out.DimValues, static_cast<size_t>(out.VectorCapacity), L,
-                       outLen, occupied);
-    check_launch("Expand copy");  // `ws` (offsets) is released in stream order, after this kernel
+                       outLen, occupied);  // `ws` (offsets) is released in stream order, after this kernel
   }
   return outLen + occupied;
 }

@@ -268,6 +268,7 @@ __global__ __launch_bounds__(kBlock) void transform_wide_kernel(EvalParams p, Si
 // ---------------------------------------------------------------------------------------------
 constexpr int kFilterItems = 8;
 constexpr int kFilterTile = kBlock * kFilterItems;
+constexpr int kFilterSuper = 8;  // tiles per ticket
 struct ScanWorkspace {
   unsigned int *ticket;  // next tile to process
   uint32_t *total;       // number of survivors
@@ -286,10 +287,18 @@ __global__ __launch_bounds__(kBlock) void filter_kernel(EvalParams p, uint8_t *p
   __shared__ uint32_t sBase;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t ltMask = (1ull << lane) - 1;
-  for (;;) {
-    if (threadIdx.x == 0) sTile = static_cast<int>(atomicAdd(ws.ticket, 1u));
-    __syncthreads();
-    const int tile = sTile;
+  // One ticket covers kFilterSuper consecutive tiles: a single atomic word hands out at most ~90
+  // tickets per microsecond on this chip, which at one ticket per 2048 rows would cap the kernel
+  // far below HBM speed.  Sub-tiles after the first know their prefix without looking back.
+  uint32_t carry = 0;  // inclusive prefix of the previous sub-tile (meaningful in wave 0)
+  for (int sub = kFilterSuper;; sub++) {
+    if (sub == kFilterSuper) {
+      __syncthreads();
+      if (threadIdx.x == 0) sTile = static_cast<int>(atomicAdd(ws.ticket, 1u));
+      __syncthreads();
+      sub = 0;
+    }
+    const int tile = sTile * kFilterSuper + sub;
     if (tile >= numTiles) break;
     const int64_t base = static_cast<int64_t>(tile) * kFilterTile;
 
@@ -354,12 +363,18 @@ __global__ __launch_bounds__(kBlock) void filter_kernel(EvalParams p, uint8_t *p
         if (lane >= off) incl += t;
       }
       const uint32_t tileCount = __shfl(incl, 63);
-      if (lane == 0) st_status(ws.status + tile, (tile == 0 ? kFlagInclusive : kFlagAggregate) | tileCount);
       uint32_t exclusive = 0;
-      if (tile > 0) {
-        exclusive = static_cast<uint32_t>(lookback_wave(ws.status, tile, lane, ws.error));
+      if (sub > 0) {
+        exclusive = carry;
         if (lane == 0) st_status(ws.status + tile, kFlagInclusive | (exclusive + tileCount));
+      } else {
+        if (lane == 0) st_status(ws.status + tile, (tile == 0 ? kFlagInclusive : kFlagAggregate) | tileCount);
+        if (tile > 0) {
+          exclusive = static_cast<uint32_t>(lookback_wave(ws.status, tile, lane, ws.error));
+          if (lane == 0) st_status(ws.status + tile, kFlagInclusive | (exclusive + tileCount));
+        }
       }
+      carry = exclusive + tileCount;
       if (lane < kFilterItems * kWaves) sCounts[lane] = incl - c;
       if (lane == 0) {
         sBase = exclusive;
@@ -376,7 +391,7 @@ __global__ __launch_bounds__(kBlock) void filter_kernel(EvalParams p, uint8_t *p
         else idx[dst] = rows[k];
       }
     }
-    __syncthreads();  // sCounts / sTile are reused by the next tile
+    __syncthreads();  // sCounts is reused by the next tile
   }
 }
 
@@ -416,13 +431,12 @@ static int run_transform(const InputVector *ins, int arity, const OutputVector &
   if (s.type == SINK_MEASURE && s.baseCounts && indexVector) p.needRow = 1;
   if (is_wide(p.a.kind)) {
     const int grid = capped_grid((static_cast<int64_t>(n) + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(transform_wide_kernel, dim3(grid), dim3(kBlock), 0, stream, p, s, n);
+    ARES_LAUNCH("transform_wide_kernel", transform_wide_kernel, grid, kBlock, stream, p, s, n);
   } else {
     constexpr int ITEMS = 4;
     const int grid = capped_grid((static_cast<int64_t>(n) + kBlock * ITEMS - 1) / (kBlock * ITEMS), 256 * 16);
-    hipLaunchKernelGGL(transform32_kernel<ITEMS>, dim3(grid), dim3(kBlock), 0, stream, p, s, n);
+    ARES_LAUNCH("transform32_kernel", transform32_kernel<ITEMS>, grid, kBlock, stream, p, s, n);
   }
-  check_launch("transform");
   return n;
 }
 
@@ -441,15 +455,14 @@ static int run_filter(const InputVector *ins, int arity, uint32_t *indexVector, 
     bind_pred_sink(pred, s);
     p.needRow = indexVector != nullptr;
     const int grid = capped_grid((static_cast<int64_t>(n) + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(transform_wide_kernel, dim3(grid), dim3(kBlock), 0, stream, p, s, n);
-    check_launch("filter (wide predicate)");
+    ARES_LAUNCH("transform_wide_kernel", transform_wide_kernel, grid, kBlock, stream, p, s, n);
   }
   const int numTiles = static_cast<int>((static_cast<int64_t>(n) + kFilterTile - 1) / kFilterTile);
   const int passes = 1 + numForeignTables;
   const size_t passBytes = 16 + sizeof(uint64_t) * static_cast<size_t>(numTiles);
   StreamBuffer wsBuf(passBytes * passes, stream);
   hip_check(hipMemsetAsync(wsBuf.get(), 0, passBytes * passes, stream), "hipMemsetAsync");
-  const int grid = capped_grid(numTiles);
+  const int grid = capped_grid((numTiles + kFilterSuper - 1) / kFilterSuper);
   uint32_t *totalDev = nullptr;
   for (int pass = 0; pass < passes; pass++) {
     uint8_t *base = wsBuf.as<uint8_t>() + passBytes * pass;
@@ -461,17 +474,16 @@ static int run_filter(const InputVector *ins, int arity, uint32_t *indexVector, 
     if (pass == 0) {
       totalDev = ws.total;
       if (is_wide(p.a.kind)) {
-        hipLaunchKernelGGL(filter_kernel<2>, dim3(grid), dim3(kBlock), 0, stream, p, pred, indexVector,
+        ARES_LAUNCH("filter_kernel<2>", filter_kernel<2>, grid, kBlock, stream, p, pred, indexVector,
                            static_cast<uint64_t *>(nullptr), ws, n, numTiles);
       } else {
-        hipLaunchKernelGGL(filter_kernel<0>, dim3(grid), dim3(kBlock), 0, stream, p, pred, indexVector,
-                           static_cast<uint64_t *>(nullptr), ws, n, numTiles);
+        ARES_LAUNCH("filter_kernel<0>", filter_kernel<0>, grid, kBlock, stream, p, pred, indexVector,
+                    static_cast<uint64_t *>(nullptr), ws, n, numTiles);
       }
     } else {
-      hipLaunchKernelGGL(filter_kernel<1>, dim3(grid), dim3(kBlock), 0, stream, p, pred, indexVector,
-                         reinterpret_cast<uint64_t *>(recordIDVectors[pass - 1]), ws, n, numTiles);
+      ARES_LAUNCH("filter_kernel<1>", filter_kernel<1>, grid, kBlock, stream, p, pred, indexVector,
+                  reinterpret_cast<uint64_t *>(recordIDVectors[pass - 1]), ws, n, numTiles);
     }
-    check_launch("filter");
   }
   uint32_t result[2] = {0, 0};  // {survivors, error}
   read_back_u32(totalDev, result, 2, stream);
@@ -491,9 +503,8 @@ CGoCallResHandle InitIndexVector(uint32_t *indexVector, uint32_t start, int inde
   if (indexVectorLength > 0) {
     const int64_t quads = (static_cast<int64_t>(indexVectorLength) + 3) / 4;
     const int grid = capped_grid((quads + kBlock - 1) / kBlock, 256 * 16);
-    hipLaunchKernelGGL(init_index_kernel, dim3(grid), dim3(kBlock), 0, reinterpret_cast<hipStream_t>(cudaStream),
-                       indexVector, start, indexVectorLength);
-    check_launch("InitIndexVector");
+    ARES_LAUNCH("init_index_kernel", init_index_kernel, grid, kBlock, reinterpret_cast<hipStream_t>(cudaStream),
+                indexVector, start, indexVectorLength);
   }
   ARES_ABI_END("InitIndexVector")
 }

@@ -236,12 +236,33 @@ class Backend:
             fn.argtypes, fn.restype = argtypes, CGoCallResHandle
             setattr(self, "_" + sym, fn)
         self._mem.GetFlags.argtypes, self._mem.GetFlags.restype = [], C.c_uint32
+        # optional extensions of the MI355X build (include/ares_extensions.h)
+        self.has_profiler = hasattr(self._algo, "AresProfilerEnable")
+        if self.has_profiler:
+            self._algo.AresProfilerEnable.argtypes, self._algo.AresProfilerEnable.restype = [C.c_int], None
+            self._algo.AresProfilerReport.argtypes = [C.c_char_p, C.c_size_t]
+            self._algo.AresProfilerReport.restype = C.c_size_t
 
     def call(self, sym, *args):
         return _check(getattr(self, "_" + sym)(*args))
 
     def flags(self):
         return self._mem.GetFlags()
+
+    def profiler_enable(self, on=True):
+        self._algo.AresProfilerEnable(1 if on else 0)
+
+    def profiler_report(self):
+        """{kernel name: (launches, total ms)} since the last profiler_enable(True); the caller has
+        synchronised its streams."""
+        need = self._algo.AresProfilerReport(None, 0)
+        buf = C.create_string_buffer(need + 16)
+        self._algo.AresProfilerReport(buf, need + 16)
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, launches, ms = line.rsplit(" ", 2)
+            out[name] = (int(launches), float(ms))
+        return out
 
     # -- convenience wrappers used by tests / host code ----------------------------------------
     def device_alloc(self, nbytes, device=0):

@@ -66,18 +66,56 @@ __global__ __launch_bounds__(kBlock) void hash_insert_kernel(const uint8_t *dimV
   }
 }
 
+// Compacts the occupied slots into output rows.  One returning atomic on a single word costs
+// ~11 ns and a word sustains < 100 of them per microsecond, so survivors are counted per
+// 4096-slot tile (wave scan + LDS) and each tile reserves its output range with ONE atomicAdd.
+constexpr int kExItems = 16;
 __global__ __launch_bounds__(kBlock) void hash_extract_kernel(const uint64_t *keys, const uint8_t *values,
                                                               uint64_t tableSize, const uint8_t *dimIn, uint8_t *dimOut,
                                                               DimLayoutD L, size_t capacity, uint8_t *outputValues,
                                                               AggSpec a, uint32_t *counter) {
-  for (uint64_t s = static_cast<uint64_t>(blockIdx.x) * kBlock + threadIdx.x; s < tableSize;
-       s += static_cast<uint64_t>(gridDim.x) * kBlock) {
-    const uint64_t k = keys[s];
-    if (k == kEmptyKey) continue;
-    const uint32_t dst = atomicAdd(counter, 1u);  // compiler aggregates per wavefront
-    copy_dim_row(dimIn, capacity, dimOut, capacity, L, static_cast<uint32_t>(k), dst);
-    if (a.width == 8) reinterpret_cast<uint64_t *>(outputValues)[dst] = reinterpret_cast<const uint64_t *>(values)[s];
-    else reinterpret_cast<uint32_t *>(outputValues)[dst] = reinterpret_cast<const uint32_t *>(values)[s];
+  __shared__ uint32_t sWave[kBlock / 64];
+  __shared__ uint32_t sBase;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint64_t tileSlots = static_cast<uint64_t>(kBlock) * kExItems;
+  for (uint64_t base = blockIdx.x * tileSlots; base < tableSize; base += gridDim.x * tileSlots) {
+    uint64_t k[kExItems];
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int it = 0; it < kExItems; it++) {
+      const uint64_t s = base + static_cast<uint64_t>(it) * kBlock + threadIdx.x;
+      k[it] = s < tableSize ? keys[s] : kEmptyKey;
+      cnt += k[it] != kEmptyKey;
+    }
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(incl, off);
+      if (lane >= off) incl += t;
+    }
+    if (lane == 63) sWave[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t total = 0;
+      for (int w = 0; w < kBlock / 64; w++) {
+        const uint32_t c = sWave[w];
+        sWave[w] = total;
+        total += c;
+      }
+      sBase = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t dst = sBase + sWave[wave] + incl - cnt;
+#pragma unroll
+    for (int it = 0; it < kExItems; it++) {
+      if (k[it] == kEmptyKey) continue;
+      const uint64_t s = base + static_cast<uint64_t>(it) * kBlock + threadIdx.x;
+      copy_dim_row(dimIn, capacity, dimOut, capacity, L, static_cast<uint32_t>(k[it]), dst);
+      if (a.width == 8) reinterpret_cast<uint64_t *>(outputValues)[dst] = reinterpret_cast<const uint64_t *>(values)[s];
+      else reinterpret_cast<uint32_t *>(outputValues)[dst] = reinterpret_cast<const uint32_t *>(values)[s];
+      dst++;
+    }
+    __syncthreads();  // sWave / sBase are reused by the next tile
   }
 }
 
@@ -104,7 +142,8 @@ extern "C" CGoCallResHandle HashReduce(DimensionVector inputKeys, uint8_t *input
     ARES_LAUNCH("hash_insert_kernel", hash_insert_kernel, grid, kBlock, stream, inputKeys.DimValues, L,
                        static_cast<size_t>(inputKeys.VectorCapacity), inputValues, a, keyBuf.as<uint64_t>(),
                        valBuf.as<uint8_t>(), tableSize - 1, length);
-    ARES_LAUNCH("hash_extract_kernel", hash_extract_kernel, initGrid, kBlock, stream, keyBuf.as<uint64_t>(),
+    const int exGrid = capped_grid(static_cast<int64_t>((tableSize + kBlock * kExItems - 1) / (kBlock * kExItems)), 256 * 8);
+    ARES_LAUNCH("hash_extract_kernel", hash_extract_kernel, exGrid, kBlock, stream, keyBuf.as<uint64_t>(),
                        valBuf.as<uint8_t>(), tableSize, inputKeys.DimValues, outputKeys.DimValues, L,
                        static_cast<size_t>(inputKeys.VectorCapacity), outputValues, a, counter.as<uint32_t>());
     uint32_t groups = 0;

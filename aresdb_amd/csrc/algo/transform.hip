@@ -268,7 +268,6 @@ __global__ __launch_bounds__(kBlock) void transform_wide_kernel(EvalParams p, Si
 // ---------------------------------------------------------------------------------------------
 constexpr int kFilterItems = 8;
 constexpr int kFilterTile = kBlock * kFilterItems;
-constexpr int kFilterSuper = 8;  // tiles per ticket
 struct ScanWorkspace {
   unsigned int *ticket;  // next tile to process
   uint32_t *total;       // number of survivors
@@ -287,18 +286,11 @@ __global__ __launch_bounds__(kBlock) void filter_kernel(EvalParams p, uint8_t *p
   __shared__ uint32_t sBase;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint64_t ltMask = (1ull << lane) - 1;
-  // One ticket covers kFilterSuper consecutive tiles: a single atomic word hands out at most ~90
-  // tickets per microsecond on this chip, which at one ticket per 2048 rows would cap the kernel
-  // far below HBM speed.  Sub-tiles after the first know their prefix without looking back.
-  uint32_t carry = 0;  // inclusive prefix of the previous sub-tile (meaningful in wave 0)
-  for (int sub = kFilterSuper;; sub++) {
-    if (sub == kFilterSuper) {
-      __syncthreads();
-      if (threadIdx.x == 0) sTile = static_cast<int>(atomicAdd(ws.ticket, 1u));
-      __syncthreads();
-      sub = 0;
-    }
-    const int tile = sTile * kFilterSuper + sub;
+  for (;;) {
+    __syncthreads();  // sTile / sCounts are reused from the previous tile
+    if (threadIdx.x == 0) sTile = static_cast<int>(atomicAdd(ws.ticket, 1u));
+    __syncthreads();
+    const int tile = sTile;
     if (tile >= numTiles) break;
     const int64_t base = static_cast<int64_t>(tile) * kFilterTile;
 
@@ -363,18 +355,12 @@ __global__ __launch_bounds__(kBlock) void filter_kernel(EvalParams p, uint8_t *p
         if (lane >= off) incl += t;
       }
       const uint32_t tileCount = __shfl(incl, 63);
+      if (lane == 0) st_status(ws.status + tile, (tile == 0 ? kFlagInclusive : kFlagAggregate) | tileCount);
       uint32_t exclusive = 0;
-      if (sub > 0) {
-        exclusive = carry;
+      if (tile > 0) {
+        exclusive = static_cast<uint32_t>(lookback_wave(ws.status, tile, lane, ws.error));
         if (lane == 0) st_status(ws.status + tile, kFlagInclusive | (exclusive + tileCount));
-      } else {
-        if (lane == 0) st_status(ws.status + tile, (tile == 0 ? kFlagInclusive : kFlagAggregate) | tileCount);
-        if (tile > 0) {
-          exclusive = static_cast<uint32_t>(lookback_wave(ws.status, tile, lane, ws.error));
-          if (lane == 0) st_status(ws.status + tile, kFlagInclusive | (exclusive + tileCount));
-        }
       }
-      carry = exclusive + tileCount;
       if (lane < kFilterItems * kWaves) sCounts[lane] = incl - c;
       if (lane == 0) {
         sBase = exclusive;
@@ -391,7 +377,305 @@ __global__ __launch_bounds__(kBlock) void filter_kernel(EvalParams p, uint8_t *p
         else idx[dst] = rows[k];
       }
     }
-    __syncthreads();  // sCounts is reused by the next tile
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Quad geometry shared by the fast transform / filter kernels
+// ---------------------------------------------------------------------------------------------
+// Every lane owns QUADS groups of 4 CONSECUTIVE output positions, so the index vector is read and
+// the outputs are written 16 bytes per lane per instruction (1 KiB per wavefront instruction), and
+// the operand column is read 16 bytes per lane wherever the four rows are consecutive (always for a
+// fresh index vector, mostly for a lightly filtered one).  gfx950 global accesses only need dword
+// alignment, hence the 4-byte aligned vector types.  Quad k covers positions [4k - pad, 4k - pad + 4)
+// with pad = (address of the 1-byte-per-position output) & 3, so that the validity / predicate
+// bytes of a quad form one aligned dword.
+struct __attribute__((aligned(4))) U32x4 { uint32_t v[4]; };
+struct __attribute__((aligned(4))) U64x2 { uint64_t v[2]; };
+
+// 32-bit column operand + optional constant second operand, as the fast kernels see them
+struct FastOperands {
+  const uint32_t *vals;  // column values
+  const uint8_t *nulls;  // validity bitmap or nullptr (mode 1)
+  uint32_t bitOff;       // bit position of row 0 in the bitmap
+  int akind;             // stored kind of the column
+  int arity, functor, I, rk;
+  int bkind;
+  uint32_t bbits, bok;   // constant second operand
+  const uint32_t *idx;   // index vector or nullptr (identity)
+  int pad;
+};
+
+__device__ __forceinline__ uint32_t valid_nibble(const uint8_t *nulls, uint32_t pos) {
+  // bits pos .. pos+3 of a little-endian bitmap
+  uint32_t w = nulls[pos >> 3] >> (pos & 7);
+  if ((pos & 7) > 4) w |= static_cast<uint32_t>(nulls[(pos >> 3) + 1]) << (8 - (pos & 7));
+  return w & 0xFu;
+}
+
+// Loads rows / values / validity of QUADS quads per lane; positions outside [0, n) get ok = 0.
+template <int QUADS>
+__device__ __forceinline__ void load_quads(const FastOperands &f, int64_t quad0, int n, uint32_t (&rows)[QUADS][4],
+                                           uint32_t (&vals)[QUADS][4], uint32_t (&okb)[QUADS]) {
+#pragma unroll
+  for (int q = 0; q < QUADS; q++) {
+    const int64_t i0 = (quad0 + static_cast<int64_t>(q) * kBlock) * 4 - f.pad;
+    if (i0 >= 0 && i0 + 3 < n) {
+      if (f.idx) {
+        const U32x4 r = *reinterpret_cast<const U32x4 *>(f.idx + i0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) rows[q][j] = r.v[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) rows[q][j] = static_cast<uint32_t>(i0) + j;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int64_t i = i0 + j;
+        rows[q][j] = (i >= 0 && i < n) ? (f.idx ? f.idx[i] : static_cast<uint32_t>(i)) : 0u;
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < QUADS; q++) {
+    const int64_t i0 = (quad0 + static_cast<int64_t>(q) * kBlock) * 4 - f.pad;
+    const uint32_t r0 = rows[q][0];
+    const bool full = i0 >= 0 && i0 + 3 < n;
+    if (full && rows[q][1] == r0 + 1 && rows[q][2] == r0 + 2 && rows[q][3] == r0 + 3) {
+      const U32x4 v = *reinterpret_cast<const U32x4 *>(f.vals + r0);
+#pragma unroll
+      for (int j = 0; j < 4; j++) vals[q][j] = v.v[j];
+      okb[q] = f.nulls ? valid_nibble(f.nulls, r0 + f.bitOff) : 0xFu;
+    } else {
+      okb[q] = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int64_t i = i0 + j;
+        vals[q][j] = 0;
+        if (i >= 0 && i < n) {
+          vals[q][j] = f.vals[rows[q][j]];
+          okb[q] |= (f.nulls ? get_bit(f.nulls, rows[q][j] + f.bitOff) : 1u) << j;
+        }
+      }
+    }
+  }
+}
+
+// The fast kernels inline this once per element (16-32 copies), so it only covers what the hot
+// queries use: unary Noop (a bare column) and the binary functors; the calendar / HLL / logical
+// unary functors stay on the generic kernels.
+__device__ __forceinline__ DVal eval_fast(const FastOperands &f, uint32_t bits, uint32_t ok, DVal y) {
+  DVal x;
+  x.bits = bits;
+  x.ok = ok;
+  x = cvt32(x, f.akind, f.I);
+  return f.arity == 1 ? x : binary32(f.functor, f.I, x, y);
+}
+
+// comparison functors only (what a filter root is in practice): value of (x ft y), null -> false
+__device__ __forceinline__ uint32_t compare_fast(const FastOperands &f, uint32_t bits, uint32_t ok, DVal y) {
+  DVal x;
+  x.bits = bits;
+  x.ok = ok;
+  x = cvt32(x, f.akind, f.I);
+  const int ft = f.functor;
+  bool c;
+  if (f.I == K_F32) {
+    const float a = bits_f(x.bits), b = bits_f(y.bits);
+    c = ft == Equal ? a == b : ft == NotEqual ? a != b : ft == LessThan ? a < b
+        : ft == LessThanOrEqual ? a <= b : ft == GreaterThan ? a > b : a >= b;
+  } else if (f.I == K_I32) {
+    const int32_t a = static_cast<int32_t>(x.bits), b = static_cast<int32_t>(y.bits);
+    c = ft == Equal ? a == b : ft == NotEqual ? a != b : ft == LessThan ? a < b
+        : ft == LessThanOrEqual ? a <= b : ft == GreaterThan ? a > b : a >= b;
+  } else {
+    const uint32_t a = x.bits, b = y.bits;
+    c = ft == Equal ? a == b : ft == NotEqual ? a != b : ft == LessThan ? a < b
+        : ft == LessThanOrEqual ? a <= b : ft == GreaterThan ? a > b : a >= b;
+  }
+  return (x.ok && y.ok && c) ? 1u : 0u;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fast transform: 32-bit column (x constant) -> 4-byte dimension / scratch vector or measure
+// ---------------------------------------------------------------------------------------------
+constexpr int kTQ = 4;  // quads per lane per tile: 16 rows per lane, 4096 rows per workgroup tile
+
+__global__ __launch_bounds__(kBlock) void transform_fast_kernel(FastOperands f, SinkD s, int n, int64_t numQuads) {
+  DVal y;
+  y.bits = f.bbits;
+  y.ok = f.bok;
+  y = cvt32(y, f.bkind, f.I);
+  const int64_t tileQuads = static_cast<int64_t>(kBlock) * kTQ;
+  for (int64_t tq = static_cast<int64_t>(blockIdx.x) * tileQuads; tq < numQuads;
+       tq += static_cast<int64_t>(gridDim.x) * tileQuads) {
+    uint32_t rows[kTQ][4], vals[kTQ][4], okb[kTQ];
+    load_quads<kTQ>(f, tq + threadIdx.x, n, rows, vals, okb);
+#pragma unroll
+    for (int q = 0; q < kTQ; q++) {
+      const int64_t i0 = (tq + threadIdx.x + static_cast<int64_t>(q) * kBlock) * 4 - f.pad;
+      DVal r[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) r[j] = eval_fast(f, vals[q][j], (okb[q] >> j) & 1u, y);
+      const bool full = i0 >= 0 && i0 + 3 < n;
+      if (!full) {  // ragged first / last quad (or past the end): the generic element-wise sink
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int64_t i = i0 + j;
+          if (i >= 0 && i < n) sink_store32(s, static_cast<uint32_t>(i), rows[q][j], r[j], f.rk);
+        }
+      } else if (s.type == SINK_MEASURE) {
+        if (s.width == 8) {
+          uint64_t o[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            if (!r[j].ok) o[j] = s.identity;
+            else if (s.dtype == Float64) o[j] = static_cast<uint64_t>(__double_as_longlong(to_double32(r[j], f.rk)));
+            else o[j] = static_cast<uint64_t>(f.rk == K_F32 ? static_cast<int64_t>(bits_f(r[j].bits))
+                                              : f.rk == K_I32 ? static_cast<int64_t>(static_cast<int32_t>(r[j].bits))
+                                                              : static_cast<int64_t>(r[j].bits));
+          }
+          U64x2 lo, hi;
+          lo.v[0] = o[0]; lo.v[1] = o[1]; hi.v[0] = o[2]; hi.v[1] = o[3];
+          U64x2 *dst = reinterpret_cast<U64x2 *>(s.values + static_cast<size_t>(8) * i0);
+          dst[0] = lo;
+          dst[1] = hi;
+        } else {
+          U32x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            if (!r[j].ok) o.v[j] = static_cast<uint32_t>(s.identity);
+            else o.v[j] = cvt32(r[j], f.rk, s.dtype == Int32 ? K_I32 : s.dtype == Uint32 ? K_U32 : K_F32).bits;
+          }
+          *reinterpret_cast<U32x4 *>(s.values + static_cast<size_t>(4) * i0) = o;
+        }
+      } else {  // 4-byte dimension / scratch value + one validity byte per row
+        const int ok_kind = s.dtype == Int32 ? K_I32 : s.dtype == Uint32 ? K_U32 : K_F32;
+        U32x4 o;
+        uint32_t nb = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          o.v[j] = cvt32(r[j], f.rk, ok_kind).bits;
+          nb |= (r[j].ok ? 1u : 0u) << (8 * j);
+        }
+        *reinterpret_cast<U32x4 *>(s.values + static_cast<size_t>(4) * i0) = o;
+        *reinterpret_cast<uint32_t *>(s.nulls + i0) = nb;  // aligned: pad = nulls address & 3
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fast filter: predicate + stable in-place compaction, 8192-row tiles
+// ---------------------------------------------------------------------------------------------
+// One returning atomic on the ticket word hands out a tile; a single word sustains ~90 tickets per
+// microsecond on this chip, so the tile must be large (8192 rows -> > 700 G rows/s) for the ticket
+// not to cap the kernel.  Survivors are ranked with a packed wavefront scan, staged in LDS in
+// final order and written back with fully coalesced stores.
+constexpr int kFQ = 8;
+constexpr int kFastTile = kBlock * 4 * kFQ;
+
+__global__ __launch_bounds__(kBlock) void filter_fast_kernel(FastOperands f, uint8_t *pred, uint32_t *idx,
+                                                             ScanWorkspace ws, int n, int numTiles) {
+  __shared__ uint32_t sOut[kFastTile];
+  __shared__ uint32_t sCounts[kFQ * kWaves];
+  __shared__ int sTile;
+  __shared__ uint32_t sBase, sTileCount;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  DVal y;
+  y.bits = f.bbits;
+  y.ok = f.bok;
+  y = cvt32(y, f.bkind, f.I);
+  for (;;) {
+    __syncthreads();  // LDS of the previous tile is free again
+    if (threadIdx.x == 0) sTile = static_cast<int>(atomicAdd(ws.ticket, 1u));
+    __syncthreads();
+    const int tile = sTile;
+    if (tile >= numTiles) break;
+    const int64_t tq = static_cast<int64_t>(tile) * (kBlock * kFQ);
+
+    uint32_t rows[kFQ][4], vals[kFQ][4], okb[kFQ];
+    load_quads<kFQ>(f, tq + threadIdx.x, n, rows, vals, okb);
+    uint32_t keep = 0;
+#pragma unroll
+    for (int q = 0; q < kFQ; q++) {
+      const int64_t i0 = (tq + threadIdx.x + static_cast<int64_t>(q) * kBlock) * 4 - f.pad;
+      uint32_t kb = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int64_t i = i0 + j;
+        if (i >= 0 && i < n) {
+          kb |= compare_fast(f, vals[q][j], (okb[q] >> j) & 1u, y) << j;  // result validity is ignored (functor.hpp:903-915)
+        }
+      }
+      keep |= kb << (4 * q);
+      const uint32_t bytes = (kb & 1u) | ((kb & 2u) << 7) | ((kb & 4u) << 14) | ((kb & 8u) << 21);
+      if (i0 >= 0 && i0 + 3 < n) {
+        *reinterpret_cast<uint32_t *>(pred + i0) = bytes;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (i0 + j >= 0 && i0 + j < n) pred[i0 + j] = static_cast<uint8_t>((kb >> j) & 1u);
+      }
+    }
+    // Every index-vector word of this tile has been consumed (the predicate depends on it) before
+    // the tile's count becomes visible: later tiles only overwrite our input range after that.
+
+    // per-lane survivor counts of the 8 quads, two 16-bit fields per word, inclusive wave scan
+    uint32_t pk[kFQ / 2], own[kFQ / 2];
+#pragma unroll
+    for (int h = 0; h < kFQ / 2; h++) {
+      own[h] = __popc((keep >> (8 * h)) & 0xFu) | (__popc((keep >> (8 * h + 4)) & 0xFu) << 16);
+      pk[h] = own[h];
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(pk[h], off);
+        if (lane >= off) pk[h] += t;
+      }
+      if (lane == 63) {
+        sCounts[(2 * h) * kWaves + wave] = pk[h] & 0xFFFFu;
+        sCounts[(2 * h + 1) * kWaves + wave] = pk[h] >> 16;
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {
+      // exclusive scan of the kFQ * kWaves (= 32) partial counts in position order
+      uint32_t c = lane < kFQ * kWaves ? sCounts[lane] : 0u;
+      uint32_t incl = c;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+      }
+      const uint32_t tileCount = __shfl(incl, 63);
+      if (lane == 0) st_status(ws.status + tile, (tile == 0 ? kFlagInclusive : kFlagAggregate) | tileCount);
+      uint32_t exclusive = 0;
+      if (tile > 0) {
+        exclusive = static_cast<uint32_t>(lookback_wave(ws.status, tile, lane, ws.error));
+        if (lane == 0) st_status(ws.status + tile, kFlagInclusive | (exclusive + tileCount));
+      }
+      if (lane < kFQ * kWaves) sCounts[lane] = incl - c;
+      if (lane == 0) {
+        sBase = exclusive;
+        sTileCount = tileCount;
+        if (tile == numTiles - 1) *ws.total = exclusive + tileCount;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kFQ; q++) {
+      const uint32_t field = (q & 1) ? ((pk[q / 2] - own[q / 2]) >> 16) : ((pk[q / 2] - own[q / 2]) & 0xFFFFu);
+      uint32_t at = sCounts[q * kWaves + wave] + field;
+      const uint32_t kb = (keep >> (4 * q)) & 0xFu;
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if ((kb >> j) & 1u) sOut[at++] = rows[q][j];
+    }
+    __syncthreads();
+    const uint32_t count = sTileCount, gbase = sBase;
+    for (uint32_t k = threadIdx.x; k < count; k += kBlock) idx[gbase + k] = sOut[k];
   }
 }
 
@@ -420,6 +704,37 @@ static void build_params(const InputVector *ins, int arity, hipStream_t stream, 
   p.needRow = indexVector != nullptr && (p.a.type == OP_COLUMN || (arity == 2 && p.b.type == OP_COLUMN));
 }
 
+
+// The hot shape of a live-batch query: a 4-byte column (modes 1/2), optionally combined with a
+// constant, feeding a 4-byte vector or a measure.  Everything else takes the generic kernels.
+static bool fast_operands(const EvalParams &p, FastOperands &f, bool compareOnly) {
+  if (p.arity == 1 && (compareOnly || p.functor != Noop)) return false;
+  if (compareOnly && (p.functor < Equal || p.functor > GreaterThanOrEqual)) return false;
+  if (p.a.type != OP_COLUMN || p.a.step != 4 || p.a.mode > 2 || p.a.kind == K_BOOL || is_wide(p.a.kind)) return false;
+  if (p.arity == 2 && (p.b.type != OP_CONST || is_wide(p.b.kind))) return false;
+  if (is_wide(p.I)) return false;
+  memset(&f, 0, sizeof(f));
+  f.vals = reinterpret_cast<const uint32_t *>(p.a.base + p.a.valuesOff);
+  f.nulls = p.a.mode == 2 ? p.a.base + p.a.nullsOff : nullptr;
+  f.bitOff = p.a.bitOff;
+  f.akind = p.a.kind;
+  f.arity = p.arity;
+  f.functor = p.functor;
+  f.I = p.I;
+  f.rk = p.rk;
+  f.bkind = p.arity == 2 ? p.b.kind : p.I;
+  f.bbits = p.b.cbits;
+  f.bok = p.b.cok;
+  f.idx = p.needRow ? p.idx : nullptr;
+  return true;
+}
+
+static bool fast_sink(const SinkD &s) {
+  const bool four = s.dtype == Int32 || s.dtype == Uint32 || s.dtype == Float32;
+  if (s.type == SINK_MEASURE) return s.agg != AGGR_AVG_FLOAT && s.baseCounts == nullptr;
+  return (s.type == SINK_DIM || s.type == SINK_SCRATCH) && four;
+}
+
 static int run_transform(const InputVector *ins, int arity, const OutputVector &output, uint32_t *indexVector,
                          int n, uint32_t *baseCounts, uint32_t startCount, int functor, hipStream_t stream) {
   if (n <= 0) return n < 0 ? 0 : n;
@@ -429,7 +744,14 @@ static int run_transform(const InputVector *ins, int arity, const OutputVector &
   build_params(ins, arity, stream, indexVector, baseCounts, startCount, functor, p, temps);
   bind_sink(output, baseCounts, s);
   if (s.type == SINK_MEASURE && s.baseCounts && indexVector) p.needRow = 1;
-  if (is_wide(p.a.kind)) {
+  FastOperands f;
+  if (fast_sink(s) && fast_operands(p, f, false)) {
+    f.pad = s.type == SINK_MEASURE ? 0 : static_cast<int>(reinterpret_cast<uintptr_t>(s.nulls) & 3);
+    const int64_t numQuads = (static_cast<int64_t>(n) + f.pad + 3) / 4;
+    const int64_t tiles = (numQuads + kBlock * kTQ - 1) / (kBlock * kTQ);
+    ARES_LAUNCH("transform_fast_kernel", transform_fast_kernel, capped_grid(tiles, 256 * 16), kBlock, stream, f, s, n,
+                numQuads);
+  } else if (is_wide(p.a.kind)) {
     const int grid = capped_grid((static_cast<int64_t>(n) + kBlock - 1) / kBlock);
     ARES_LAUNCH("transform_wide_kernel", transform_wide_kernel, grid, kBlock, stream, p, s, n);
   } else {
@@ -457,12 +779,20 @@ static int run_filter(const InputVector *ins, int arity, uint32_t *indexVector, 
     const int grid = capped_grid((static_cast<int64_t>(n) + kBlock - 1) / kBlock);
     ARES_LAUNCH("transform_wide_kernel", transform_wide_kernel, grid, kBlock, stream, p, s, n);
   }
-  const int numTiles = static_cast<int>((static_cast<int64_t>(n) + kFilterTile - 1) / kFilterTile);
+  FastOperands f;
+  const bool fast = !is_wide(p.a.kind) && indexVector != nullptr && fast_operands(p, f, true);
+  int numTiles = static_cast<int>((static_cast<int64_t>(n) + kFilterTile - 1) / kFilterTile);
+  int fastTiles = 0;
+  if (fast) {
+    f.pad = static_cast<int>(reinterpret_cast<uintptr_t>(pred) & 3);
+    const int64_t numQuads = (static_cast<int64_t>(n) + f.pad + 3) / 4;
+    fastTiles = static_cast<int>((numQuads + kBlock * kFQ - 1) / (kBlock * kFQ));
+  }
   const int passes = 1 + numForeignTables;
   const size_t passBytes = 16 + sizeof(uint64_t) * static_cast<size_t>(numTiles);
   StreamBuffer wsBuf(passBytes * passes, stream);
   hip_check(hipMemsetAsync(wsBuf.get(), 0, passBytes * passes, stream), "hipMemsetAsync");
-  const int grid = capped_grid((numTiles + kFilterSuper - 1) / kFilterSuper);
+  const int grid = capped_grid(numTiles);
   uint32_t *totalDev = nullptr;
   for (int pass = 0; pass < passes; pass++) {
     uint8_t *base = wsBuf.as<uint8_t>() + passBytes * pass;
@@ -476,6 +806,9 @@ static int run_filter(const InputVector *ins, int arity, uint32_t *indexVector, 
       if (is_wide(p.a.kind)) {
         ARES_LAUNCH("filter_kernel<2>", filter_kernel<2>, grid, kBlock, stream, p, pred, indexVector,
                            static_cast<uint64_t *>(nullptr), ws, n, numTiles);
+      } else if (fast) {
+        ARES_LAUNCH("filter_fast_kernel", filter_fast_kernel, capped_grid(fastTiles, 256 * 5), kBlock, stream, f, pred,
+                    indexVector, ws, n, fastTiles);
       } else {
         ARES_LAUNCH("filter_kernel<0>", filter_kernel<0>, grid, kBlock, stream, p, pred, indexVector,
                     static_cast<uint64_t *>(nullptr), ws, n, numTiles);

@@ -1,0 +1,22 @@
+"""Query plans of the BASELINE configurations, as the AQL compiler would
+hand them to the batch executor."""
+from . import abi
+from .executor import Binary, Col, Const, DimensionSpec, QueryPlan
+
+
+def c3_plan(use_hash_reduction=True, with_filter=True):
+    return QueryPlan(
+        filters=[Binary(abi.LessThan, Col("d1"), Const(90))] if with_filter else [],
+        dimensions=[DimensionSpec(Binary(abi.Floor, Col("ts"), Const(3600)), abi.Uint32),
+                    DimensionSpec(Col("d1"), abi.Uint32), DimensionSpec(Col("d2"), abi.Uint32),
+                    DimensionSpec(Col("d3"), abi.Uint32)],
+        measure=Col("m"), agg=abi.AGGR_SUM_FLOAT, measure_type=abi.Float64,
+        use_hash_reduction=use_hash_reduction)
+
+
+def c2_plan(threshold):
+    """BASELINE config C2: single uint32 predicate + COUNT(*) — measure literal 1, AGGR_SUM_UNSIGNED,
+    4-byte measure, no dimensions, sort path (query/aql_compiler.go:1191-1197)."""
+    return QueryPlan(filters=[Binary(abi.LessThan, Col("ts"), Const(threshold))], dimensions=[],
+                     measure=Const(1), agg=abi.AGGR_SUM_UNSIGNED, measure_type=abi.Uint32,
+                     use_hash_reduction=False)

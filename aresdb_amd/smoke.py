@@ -6,18 +6,8 @@ import numpy as np
 
 from . import abi
 from .columns import DeviceColumn
-from .executor import (BatchContext, BatchExecutor, Binary, Col, Const, DimensionSpec, QueryPlan,
-                       fetch_results)
-
-
-def c3_plan(use_hash_reduction=True, with_filter=True):
-    return QueryPlan(
-        filters=[Binary(abi.LessThan, Col("d1"), Const(90))] if with_filter else [],
-        dimensions=[DimensionSpec(Binary(abi.Floor, Col("ts"), Const(3600)), abi.Uint32),
-                    DimensionSpec(Col("d1"), abi.Uint32), DimensionSpec(Col("d2"), abi.Uint32),
-                    DimensionSpec(Col("d3"), abi.Uint32)],
-        measure=Col("m"), agg=abi.AGGR_SUM_FLOAT, measure_type=abi.Float64,
-        use_hash_reduction=use_hash_reduction)
+from .executor import BatchContext, BatchExecutor, fetch_results
+from .queries import c3_plan  # noqa: F401  (re-exported for tests)
 
 
 def synth_batch(rng, n, null_fraction=0.0):

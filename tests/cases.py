@@ -127,8 +127,10 @@ class OperandSpec:
 
 
 class OutSpec:
-    def __init__(self, kind, dtype, agg=None):
-        self.kind, self.dtype, self.agg = kind, dtype, agg
+    def __init__(self, kind, dtype, agg=None, offset=0):
+        # offset: the output starts `offset` elements into its buffers (the Go host writes batch
+        # k's dimensions at row offset resultSize, so value / validity pointers are rarely aligned)
+        self.kind, self.dtype, self.agg, self.offset = kind, dtype, agg, offset
 
     def build(self, be, n, keep):
         if self.kind == "scratch":
@@ -136,16 +138,18 @@ class OutSpec:
             keep.append(s)
             return s.output(), lambda: {"values": s.buf.read(np.uint8, 4 * n), "valid": s.valid()}
         w = abi.DATA_TYPE_BYTES[self.dtype]
+        off = self.offset
         if self.kind == "dim":
-            vb = H.Buf(be, nbytes=w * n + 8)
-            nb = H.Buf(be, nbytes=n + 8)
+            vb = H.Buf(be, nbytes=w * (n + off) + 8)
+            nb = H.Buf(be, nbytes=n + off + 8)
             keep.extend([vb, nb])
-            return H.dimension_output(vb.ptr, nb.ptr, self.dtype), \
-                lambda: {"values": vb.read(np.uint8, w * n), "valid": nb.read(np.uint8, n)}
-        vb = H.Buf(be, nbytes=w * n + 8)
+            # the whole buffers are compared: bytes around the output range must stay untouched
+            return H.dimension_output(vb.ptr + w * off, nb.ptr + off, self.dtype), \
+                lambda: {"values": vb.read(np.uint8, w * (n + off) + 8), "valid": nb.read(np.uint8, n + off + 8)}
+        vb = H.Buf(be, nbytes=w * (n + off) + 8)
         keep.append(vb)
-        return H.measure_output(vb.ptr, self.dtype, self.agg), \
-            lambda: {"values": vb.read(np.uint8, w * n)}
+        return H.measure_output(vb.ptr + w * off, self.dtype, self.agg), \
+            lambda: {"values": vb.read(np.uint8, w * (n + off) + 8)}
 
 
 def make_index(rng, rows, style):
@@ -174,6 +178,7 @@ class TransformCase:
         n = self.n
         self.base_counts = None
         self.start_count = 0
+        self.pred_offset = 0
         if arity == 1:
             kind = ["col", "col", "col", "scratch", "cint"][int(rng.integers(0, 5))]
             a = OperandSpec(rng, kind, self.rows, n, small=True, nonneg=True)
@@ -249,14 +254,15 @@ class TransformCase:
         n = self.n
         res = {}
         if self.as_filter:
-            pred = H.Buf(be, nbytes=n + 8)
+            po = self.pred_offset
+            pred = H.Buf(be, nbytes=n + po + 8)
             rbufs = [H.Buf(be, r) for r in self.rids]
             vecs = (C.c_void_p * max(1, len(rbufs)))(*[b.ptr for b in rbufs])
             name = "UnaryFilter" if self.arity == 1 else "BinaryFilter"
-            cnt = be.call(name, *ins, idx.ptr, pred.ptr, n, C.addressof(vecs) if rbufs else None,
+            cnt = be.call(name, *ins, idx.ptr, pred.ptr + po, n, C.addressof(vecs) if rbufs else None,
                           len(rbufs), bcp, self.start_count, self.functor, None, 0)
             res["count"] = cnt
-            res["pred"] = pred.read(np.uint8, n)
+            res["pred"] = pred.read(np.uint8, n + po + 8)
             res["index"] = idx.read(np.uint32, cnt)
             for i, b in enumerate(rbufs):
                 res[f"rid{i}"] = b.read(np.uint32, 2 * cnt)
@@ -270,6 +276,48 @@ class TransformCase:
         for k in keep + [idx] + ([bc] if bc else []):
             k.free()
         return res
+
+
+def fast_path_case(seed, as_filter, rows, style):
+    """The hot live-batch shape the HIP library serves with its vectorised kernels: a 4-byte column
+    (values only or validity + values) against a constant (or bare, for transforms), written to a
+    4-byte dimension / scratch vector or a measure at an arbitrary row offset."""
+    rng = np.random.default_rng(77000 + seed)
+    c = TransformCase(seed, 2, as_filter, rows=rows, index_style=style)
+    dtype = [abi.Uint32, abi.Int32, abi.Float32][seed % 3]
+    mode = 1 + (seed // 3) % 2
+    a = OperandSpec(rng, "col", c.rows, c.n, dtype=dtype, mode=mode, small=True, nonneg=(seed % 5 != 0))
+    c.base_counts, c.start_count = None, 0
+    unary = (not as_filter) and seed % 4 == 0
+    if unary:
+        c.arity, c.ops, c.functor = 1, [a], abi.Noop
+    else:
+        kb = "cfloat" if (dtype == abi.Float32 or seed % 7 == 0) else "cint"
+        b = OperandSpec(rng, kb, c.rows, c.n, small=True, nonzero=True)
+        b.valid = seed % 11 != 0
+        c.arity, c.ops = 2, [a, b]
+        anyf = a.is_float() or b.is_float()
+        if as_filter:
+            c.functor = int(rng.integers(abi.Equal, abi.GreaterThanOrEqual + 1))
+        else:
+            c.functor = int(rng.choice(BINARY_FLOAT_OK if anyf else BINARY_ALL))
+    anyf = any(o.is_float() for o in c.ops)
+    if as_filter:
+        c.pred_offset = seed % 4
+        c.out = None
+    else:
+        off = int(rng.integers(0, 9))
+        k = seed % 3
+        if k == 0:
+            c.out = OutSpec("scratch", abi.Int32 if anyf else [abi.Int32, abi.Uint32][seed % 2])
+        elif k == 1:
+            c.out = OutSpec("dim", abi.Int32 if anyf else [abi.Uint32, abi.Int32][seed % 2], offset=off)
+        else:
+            dt = [abi.Float64, abi.Int64, abi.Float32, abi.Int32][(seed // 3) % 4] if anyf else \
+                [abi.Float64, abi.Uint32, abi.Int64, abi.Int32, abi.Float32][(seed // 3) % 5]
+            agg = [abi.AGGR_SUM_FLOAT, abi.AGGR_SUM_SIGNED, abi.AGGR_MIN_SIGNED, abi.AGGR_MAX_UNSIGNED][seed % 4]
+            c.out = OutSpec("measure", dt, agg, offset=off)
+    return c
 
 
 # ---- cuckoo index builder (layout of memstore/cuckoo_index.go; see oracle HashLookup) ----------

@@ -38,6 +38,20 @@ def test_transform_and_filter_multi_tile(seed, as_filter):
     cases.assert_same(c.run(hip()), c.run(H.oracle_backend()), repr(c))
 
 
+FAST_ROWS = [1, 2, 3, 5, 63, 1000, 4095, 4096, 4099, 8191, 8192, 8197, 40000, 300001]
+
+
+@pytest.mark.parametrize("as_filter", [False, True], ids=["transform", "filter"])
+@pytest.mark.parametrize("seed", range(42))
+def test_fast_path_shapes(seed, as_filter):
+    """4-byte column x constant -> 4-byte vector / measure: the vectorised quad kernels, across
+    tile boundaries, ragged ends, unaligned output offsets and sparse / permuted index vectors."""
+    rows = FAST_ROWS[seed % len(FAST_ROWS)]
+    style = ["identity", "subset", "perm"][(seed // 2) % 3]
+    c = cases.fast_path_case(seed, as_filter, rows, style)
+    cases.assert_same(c.run(hip()), c.run(H.oracle_backend()), repr(c))
+
+
 @pytest.mark.parametrize("seed", range(24))
 def test_hash_lookup(seed):
     c = cases.HashLookupCase(seed, n=(20000 if seed % 3 == 0 else None))

@@ -53,3 +53,14 @@ def test_murmur_known_answers():
     for v, h in exp.items():
         lib.oracle_murmur3_128(bytes([v, 1]), 2, 0, out)
         assert out[0] == h
+
+
+@pytest.mark.parametrize("as_filter", [False, True], ids=["transform", "filter"])
+@pytest.mark.parametrize("seed", range(42))
+def test_fast_path_shapes_oracle_vs_reference(seed, as_filter):
+    """The directed hot-shape cases of tests/test_hip_parity.py::test_fast_path_shapes, pinned on
+    the reference's own build first (small sizes only: the HOST build is single-threaded)."""
+    rows = [1, 2, 3, 5, 63, 1000, 4095, 4096, 4099, 8191, 8192, 8197, 2000, 3001][seed % 14]
+    style = ["identity", "subset", "perm"][(seed // 2) % 3]
+    c = cases.fast_path_case(seed, as_filter, rows, style)
+    cases.assert_same(c.run(H.oracle_backend()), c.run(H.ref_backend()), repr(c))

@@ -1,0 +1,90 @@
+"""N>1 path on CPU: two processes (gloo), one shard each, partial group tables merged with
+aresdb_amd.shard_merge — the same code bench.py runs over RCCL.  The library behind the ABI is the
+oracle here (host memory); the merged table must equal one process reducing both shards
+(the reference's "append previous results + re-reduce" contract,
+query/aql_batchexecutor.go:236-251; combine rules broker/result_merge.go:77-94)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_shard(be, plan, batches):
+    from aresdb_amd.executor import BatchContext, BatchExecutor
+    ctx = BatchContext(be, plan)
+    ex = BatchExecutor(ctx)
+    for b in batches:
+        ex.run({k: rc.vp for k, rc in b.items()}, next(iter(b.values())).length)
+    return ctx
+
+
+def _single_process_result(be, plan, all_batches):
+    from aresdb_amd.executor import fetch_results
+    ctx = _run_shard(be, plan, all_batches)
+    dims, valids, meas = fetch_results(ctx)
+    n = ctx.result_size
+    m = meas.view(np.float64) if plan.measure_bytes == 8 else meas.view(np.uint32)
+    out = {}
+    for r in range(n):
+        key = tuple((bytes(d[r * len(d) // n:(r + 1) * len(d) // n]), int(v[r])) for d, v in zip(dims, valids))
+        out[key] = m[r]
+    ctx.release()
+    return out
+
+
+def _worker(rank, world, port, use_hash, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import harness as H
+    from aresdb_amd import workload
+    from aresdb_amd.queries import c3_plan
+    from aresdb_amd.shard_merge import merge_shard_results, merged_to_dict
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        be = H.oracle_backend()
+        plan = c3_plan(use_hash_reduction=use_hash)
+        shards = [workload.c3_shard(6000 + 500 * r, 2048, seed=1 + r, device="cpu") for r in range(world)]
+        ctx = _run_shard(be, plan, shards[rank])
+        merged = merge_shard_results(ctx, "cpu")
+        got = merged_to_dict(ctx, merged)
+        want = _single_process_result(be, plan, [b for s in shards for b in s])
+        assert got.keys() == want.keys(), (len(got), len(want))
+        for k, v in want.items():
+            assert abs(got[k] - v) <= 1e-9 * max(1.0, abs(v)), (k, got[k], v)
+        ctx.release()
+        q.put((rank, "ok", len(got)))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, f"{type(e).__name__}: {e}", 0))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("use_hash", [True, False], ids=["hash_reduce", "sort_reduce"])
+def test_two_shard_merge_gloo(use_hash):
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, use_hash, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in results), results
+    assert results[0][2] == results[1][2] > 0

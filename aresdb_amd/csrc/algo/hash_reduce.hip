@@ -17,6 +17,7 @@
 #include "common.hpp"
 #include "device_model.hpp"
 #include "dim_layout.hpp"
+#include "hash_reduce_lds.hpp"
 
 namespace ares {
 
@@ -123,13 +124,24 @@ __global__ __launch_bounds__(kBlock) void hash_extract_kernel(const uint64_t *ke
 
 using namespace ares;
 
+// ARES_HASH_REDUCE=global pins the global-table path (tests exercise both implementations).
+static bool global_table_forced() {
+  const char *e = getenv("ARES_HASH_REDUCE");
+  return e && strcmp(e, "global") == 0;
+}
+
 extern "C" CGoCallResHandle HashReduce(DimensionVector inputKeys, uint8_t *inputValues, DimensionVector outputKeys,
                                        uint8_t *outputValues, int valueBytes, int length,
                                        enum AggregateFunction aggFunc, void *cudaStream, int device) {
   ARES_ABI_BEGIN(device)
   hipStream_t stream = reinterpret_cast<hipStream_t>(cudaStream);
   const AggSpec a = make_agg_spec(aggFunc, valueBytes);
-  if (length > 0) {
+  int groups = -1;
+  if (length > 0 && hash_reduce_lds_supported(a) && !global_table_forced())
+    groups = hash_reduce_lds(inputKeys, inputValues, outputKeys, outputValues, a, length, stream);
+  if (groups >= 0) {
+    resHandle.res = int_result(groups);
+  } else if (length > 0) {
     const DimLayoutD L = make_dim_layout(inputKeys.NumDimsPerDimWidth);
     uint64_t tableSize = 1024;
     while (tableSize < 2ull * static_cast<uint64_t>(length)) tableSize <<= 1;

@@ -405,16 +405,19 @@ struct FastOperands {
   uint32_t bbits, bok;   // constant second operand
   const uint32_t *idx;   // index vector or nullptr (identity)
   int pad;
+  int divLike;           // integer Divide / Mod / Floor by the constant: multiply-high division
+  int debug;             // ARES_F_DEBUG: timing experiments only
 };
 
-__device__ __forceinline__ uint32_t valid_nibble(const uint8_t *nulls, uint32_t pos) {
-  // bits pos .. pos+3 of a little-endian bitmap
-  uint32_t w = nulls[pos >> 3] >> (pos & 7);
-  if ((pos & 7) > 4) w |= static_cast<uint32_t>(nulls[(pos >> 3) + 1]) << (8 - (pos & 7));
-  return w & 0xFu;
-}
+struct __attribute__((packed, aligned(1))) PU16 { uint16_t v; };
 
 // Loads rows / values / validity of QUADS quads per lane; positions outside [0, n) get ok = 0.
+// Three phases so that every load of the tile is in flight before the first one is consumed:
+// (A) index vector, (B) values + one 16-bit window of the validity bitmap per quad, (C) bit
+// extraction.  The window starts at the byte holding the first row's bit and covers at least the 8
+// following rows, which is where the other three rows of a filtered quad almost always lie; a
+// wider quad re-reads single bytes.  Reading one byte past the bitmap is safe: in a mode-2 slice
+// the values follow the bitmap inside the same allocation.
 template <int QUADS>
 __device__ __forceinline__ void load_quads(const FastOperands &f, int64_t quad0, int n, uint32_t (&rows)[QUADS][4],
                                            uint32_t (&vals)[QUADS][4], uint32_t (&okb)[QUADS]) {
@@ -431,6 +434,7 @@ __device__ __forceinline__ void load_quads(const FastOperands &f, int64_t quad0,
         for (int j = 0; j < 4; j++) rows[q][j] = static_cast<uint32_t>(i0) + j;
       }
     } else {
+      // ragged quad: positions outside [0, n) read row 0 (always a valid row) and are masked later
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const int64_t i = i0 + j;
@@ -438,40 +442,92 @@ __device__ __forceinline__ void load_quads(const FastOperands &f, int64_t quad0,
       }
     }
   }
+  uint32_t window[QUADS];
 #pragma unroll
   for (int q = 0; q < QUADS; q++) {
-    const int64_t i0 = (quad0 + static_cast<int64_t>(q) * kBlock) * 4 - f.pad;
     const uint32_t r0 = rows[q][0];
-    const bool full = i0 >= 0 && i0 + 3 < n;
-    if (full && rows[q][1] == r0 + 1 && rows[q][2] == r0 + 2 && rows[q][3] == r0 + 3) {
+    if (rows[q][1] == r0 + 1 && rows[q][2] == r0 + 2 && rows[q][3] == r0 + 3) {
       const U32x4 v = *reinterpret_cast<const U32x4 *>(f.vals + r0);
 #pragma unroll
       for (int j = 0; j < 4; j++) vals[q][j] = v.v[j];
-      okb[q] = f.nulls ? valid_nibble(f.nulls, r0 + f.bitOff) : 0xFu;
     } else {
-      okb[q] = 0;
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int64_t i = i0 + j;
-        vals[q][j] = 0;
-        if (i >= 0 && i < n) {
-          vals[q][j] = f.vals[rows[q][j]];
-          okb[q] |= (f.nulls ? get_bit(f.nulls, rows[q][j] + f.bitOff) : 1u) << j;
-        }
-      }
+      for (int j = 0; j < 4; j++) vals[q][j] = f.vals[rows[q][j]];
+    }
+    window[q] = 0xFFFFu;
+    if (f.nulls) window[q] = reinterpret_cast<const PU16 *>(f.nulls + ((r0 + f.bitOff) >> 3))->v;
+  }
+#pragma unroll
+  for (int q = 0; q < QUADS; q++) {
+    const int64_t i0 = (quad0 + static_cast<int64_t>(q) * kBlock) * 4 - f.pad;
+    const uint32_t first = (rows[q][0] + f.bitOff) & ~7u;  // bit position of the window's bit 0
+    okb[q] = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int64_t i = i0 + j;
+      if (i < 0 || i >= n) continue;
+      const uint32_t off = rows[q][j] + f.bitOff - first;  // wraps to a huge value when the row precedes the window
+      uint32_t bit;
+      if (off < 16u) bit = (window[q] >> off) & 1u;
+      else bit = f.nulls ? get_bit(f.nulls, rows[q][j] + f.bitOff) : 1u;
+      okb[q] |= bit << j;
     }
   }
+}
+
+// x / d and x % d for a divisor that is the same for the whole launch: one multiply-high by
+// M = floor(2^32 / d) estimates the quotient to within one (M = 0 marks d < 2).
+struct FastDivisor {
+  uint32_t d, M;
+};
+__device__ __forceinline__ FastDivisor make_fast_divisor(uint32_t d) {
+  FastDivisor r;
+  r.d = d;
+  r.M = d >= 2 ? static_cast<uint32_t>((1ull << 32) / d) : 0u;
+  return r;
+}
+__device__ __forceinline__ void fast_divmod(const FastDivisor &fd, uint32_t x, uint32_t &q, uint32_t &r) {
+  if (fd.d < 2) {  // 0: the reference divides by zero (undefined); binary32 yields q = r = 0 — keep that
+    q = fd.d ? x : 0u;
+    r = 0u;
+    return;
+  }
+  q = __umulhi(x, fd.M);
+  r = x - q * fd.d;
+  if (r >= fd.d) { q++; r -= fd.d; }
 }
 
 // The fast kernels inline this once per element (16-32 copies), so it only covers what the hot
 // queries use: unary Noop (a bare column) and the binary functors; the calendar / HLL / logical
 // unary functors stay on the generic kernels.
-__device__ __forceinline__ DVal eval_fast(const FastOperands &f, uint32_t bits, uint32_t ok, DVal y) {
+__device__ __forceinline__ DVal eval_fast(const FastOperands &f, uint32_t bits, uint32_t ok, DVal y,
+                                          const FastDivisor &fd) {
   DVal x;
   x.bits = bits;
   x.ok = ok;
   x = cvt32(x, f.akind, f.I);
-  return f.arity == 1 ? x : binary32(f.functor, f.I, x, y);
+  if (f.arity == 1) return x;
+  if (f.divLike) {  // Divide / Mod / Floor on integers by the launch-wide constant (functor.hpp:337-351)
+    DVal r;
+    r.ok = x.ok && y.ok;
+    r.bits = 0;
+    if (r.ok) {
+      uint32_t q, m;
+      if (f.I == K_I32) {  // C++ truncating semantics on magnitudes
+        const int32_t sx = static_cast<int32_t>(x.bits), sy = static_cast<int32_t>(y.bits);
+        const uint32_t ax = sx < 0 ? 0u - x.bits : x.bits;
+        fast_divmod(fd, ax, q, m);
+        const uint32_t sq = ((sx < 0) != (sy < 0)) ? 0u - q : q;
+        const uint32_t sm = sx < 0 ? 0u - m : m;
+        r.bits = f.functor == Divide ? sq : f.functor == Mod ? sm : x.bits - sm;
+      } else {
+        fast_divmod(fd, x.bits, q, m);
+        r.bits = f.functor == Divide ? q : f.functor == Mod ? m : x.bits - m;
+      }
+    }
+    return r;
+  }
+  return binary32(f.functor, f.I, x, y);
 }
 
 // comparison functors only (what a filter root is in practice): value of (x ft y), null -> false
@@ -508,6 +564,8 @@ __global__ __launch_bounds__(kBlock) void transform_fast_kernel(FastOperands f, 
   y.bits = f.bbits;
   y.ok = f.bok;
   y = cvt32(y, f.bkind, f.I);
+  const uint32_t ymag = (f.I == K_I32 && static_cast<int32_t>(y.bits) < 0) ? 0u - y.bits : y.bits;
+  const FastDivisor fd = make_fast_divisor(ymag);
   const int64_t tileQuads = static_cast<int64_t>(kBlock) * kTQ;
   for (int64_t tq = static_cast<int64_t>(blockIdx.x) * tileQuads; tq < numQuads;
        tq += static_cast<int64_t>(gridDim.x) * tileQuads) {
@@ -518,7 +576,7 @@ __global__ __launch_bounds__(kBlock) void transform_fast_kernel(FastOperands f, 
       const int64_t i0 = (tq + threadIdx.x + static_cast<int64_t>(q) * kBlock) * 4 - f.pad;
       DVal r[4];
 #pragma unroll
-      for (int j = 0; j < 4; j++) r[j] = eval_fast(f, vals[q][j], (okb[q] >> j) & 1u, y);
+      for (int j = 0; j < 4; j++) r[j] = eval_fast(f, vals[q][j], (okb[q] >> j) & 1u, y, fd);
       const bool full = i0 >= 0 && i0 + 3 < n;
       if (!full) {  // ragged first / last quad (or past the end): the generic element-wise sink
 #pragma unroll
@@ -588,9 +646,10 @@ __global__ __launch_bounds__(kBlock) void filter_fast_kernel(FastOperands f, uin
   y.bits = f.bbits;
   y.ok = f.bok;
   y = cvt32(y, f.bkind, f.I);
-  for (;;) {
+  for (int iter = 0;; iter++) {
     __syncthreads();  // LDS of the previous tile is free again
-    if (threadIdx.x == 0) sTile = static_cast<int>(atomicAdd(ws.ticket, 1u));
+    if (threadIdx.x == 0)
+      sTile = (f.debug & 4) ? static_cast<int>(blockIdx.x + iter * gridDim.x) : static_cast<int>(atomicAdd(ws.ticket, 1u));
     __syncthreads();
     const int tile = sTile;
     if (tile >= numTiles) break;
@@ -623,21 +682,20 @@ __global__ __launch_bounds__(kBlock) void filter_fast_kernel(FastOperands f, uin
     // Every index-vector word of this tile has been consumed (the predicate depends on it) before
     // the tile's count becomes visible: later tiles only overwrite our input range after that.
 
-    // per-lane survivor counts of the 8 quads, two 16-bit fields per word, inclusive wave scan
-    uint32_t pk[kFQ / 2], own[kFQ / 2];
+    // rank of every survivor inside its wavefront: ballots + mbcnt (pure VALU/SALU, no cross-lane
+    // traffic); position order inside the tile is (quad, lane, j)
+    uint32_t lanePrefix[kFQ];
 #pragma unroll
-    for (int h = 0; h < kFQ / 2; h++) {
-      own[h] = __popc((keep >> (8 * h)) & 0xFu) | (__popc((keep >> (8 * h + 4)) & 0xFu) << 16);
-      pk[h] = own[h];
+    for (int q = 0; q < kFQ; q++) {
+      uint32_t before = 0, total = 0;
 #pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t t = __shfl_up(pk[h], off);
-        if (lane >= off) pk[h] += t;
+      for (int j = 0; j < 4; j++) {
+        const uint64_t m = __ballot((keep >> (4 * q + j)) & 1u);
+        before += __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+        total += static_cast<uint32_t>(__popcll(m));
       }
-      if (lane == 63) {
-        sCounts[(2 * h) * kWaves + wave] = pk[h] & 0xFFFFu;
-        sCounts[(2 * h + 1) * kWaves + wave] = pk[h] >> 16;
-      }
+      lanePrefix[q] = before;
+      if (lane == 0) sCounts[q * kWaves + wave] = total;
     }
     __syncthreads();
     if (wave == 0) {
@@ -652,22 +710,22 @@ __global__ __launch_bounds__(kBlock) void filter_fast_kernel(FastOperands f, uin
       const uint32_t tileCount = __shfl(incl, 63);
       if (lane == 0) st_status(ws.status + tile, (tile == 0 ? kFlagInclusive : kFlagAggregate) | tileCount);
       uint32_t exclusive = 0;
-      if (tile > 0) {
+      if (tile > 0 && !(f.debug & 1)) {
         exclusive = static_cast<uint32_t>(lookback_wave(ws.status, tile, lane, ws.error));
         if (lane == 0) st_status(ws.status + tile, kFlagInclusive | (exclusive + tileCount));
       }
+      if (f.debug & 1) exclusive = static_cast<uint32_t>(tile) * 7000u;
       if (lane < kFQ * kWaves) sCounts[lane] = incl - c;
       if (lane == 0) {
         sBase = exclusive;
-        sTileCount = tileCount;
+        sTileCount = (f.debug & 2) ? 0u : tileCount;
         if (tile == numTiles - 1) *ws.total = exclusive + tileCount;
       }
     }
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < kFQ; q++) {
-      const uint32_t field = (q & 1) ? ((pk[q / 2] - own[q / 2]) >> 16) : ((pk[q / 2] - own[q / 2]) & 0xFFFFu);
-      uint32_t at = sCounts[q * kWaves + wave] + field;
+      uint32_t at = sCounts[q * kWaves + wave] + lanePrefix[q];
       const uint32_t kb = (keep >> (4 * q)) & 0xFu;
 #pragma unroll
       for (int j = 0; j < 4; j++)
@@ -726,6 +784,9 @@ static bool fast_operands(const EvalParams &p, FastOperands &f, bool compareOnly
   f.bbits = p.b.cbits;
   f.bok = p.b.cok;
   f.idx = p.needRow ? p.idx : nullptr;
+  f.divLike = p.arity == 2 && (p.I == K_I32 || p.I == K_U32) && (p.functor == Divide || p.functor == Mod || p.functor == Floor);
+  const char *dbg = getenv("ARES_F_DEBUG");
+  f.debug = dbg ? atoi(dbg) : 0;
   return true;
 }
 
@@ -807,7 +868,7 @@ static int run_filter(const InputVector *ins, int arity, uint32_t *indexVector, 
         ARES_LAUNCH("filter_kernel<2>", filter_kernel<2>, grid, kBlock, stream, p, pred, indexVector,
                            static_cast<uint64_t *>(nullptr), ws, n, numTiles);
       } else if (fast) {
-        ARES_LAUNCH("filter_fast_kernel", filter_fast_kernel, capped_grid(fastTiles, 256 * 5), kBlock, stream, f, pred,
+        ARES_LAUNCH("filter_fast_kernel", filter_fast_kernel, capped_grid(fastTiles, (f.debug & 4) ? 256 * 3 : 256 * 5), kBlock, stream, f, pred,
                     indexVector, ws, n, fastTiles);
       } else {
         ARES_LAUNCH("filter_kernel<0>", filter_kernel<0>, grid, kBlock, stream, p, pred, indexVector,

@@ -132,7 +132,8 @@ def main():
         dist.init_process_group("nccl", device_id=tdev)
 
     be = abi.load_hip_backend()  # raises if the HIP libraries are missing — no fallback
-    be.call("BootstrapDevice")
+    if world == 1:
+        be.call("BootstrapDevice")  # touches every visible device (reference utils.cu:63-85): one process per GPU skips it
     stream = be.call("CreateCudaStream", local_rank)
 
     rows, batch_rows = int(args.rows), int(args.batch_rows)

@@ -462,23 +462,23 @@ class GroupByCase:
         self.offsets = []
         value_bytes_total = sum(w * c for w, c in zip(H.DIM_WIDTHS, self.ndw))
         ndims = sum(self.ndw)
-        protos = []
-        for _ in range(ngroups):
-            vals = [rng.integers(0, 256, w, dtype=np.uint8) if rng.random() < 0.9 else
-                    np.zeros(w, np.uint8) for w, c in zip(H.DIM_WIDTHS, self.ndw) for _ in range(c)]
-            valid = (rng.random(ndims) > 0.1).astype(np.uint8)
-            protos.append((vals, valid))
+        # distinct prototype rows, vectorised: per dimension an (ngroups, width) byte matrix (10% of
+        # the values all-zero) and a validity column (10% nulls)
+        widths = [w for w, c in zip(H.DIM_WIDTHS, self.ndw) for _ in range(c)]
+        proto_vals = []
+        for w in widths:
+            m = rng.integers(0, 256, (ngroups, w), dtype=np.uint8)
+            m[rng.random(ngroups) >= 0.9] = 0
+            proto_vals.append(m)
+        proto_valid = (rng.random((ngroups, ndims)) > 0.1).astype(np.uint8)
         pick = rng.integers(0, ngroups, self.length)
         blob = np.zeros((value_bytes_total + ndims) * self.capacity, np.uint8)
-        off, d = 0, 0
-        for w, c in zip(H.DIM_WIDTHS, self.ndw):
-            for _ in range(c):
-                col = np.stack([protos[g][0][d] for g in pick]).reshape(-1)
-                blob[off:off + w * self.length] = col
-                noff = value_bytes_total * self.capacity + d * self.capacity
-                blob[noff:noff + self.length] = [protos[g][1][d] for g in pick]
-                off += w * self.capacity
-                d += 1
+        off = 0
+        for d, w in enumerate(widths):
+            blob[off:off + w * self.length] = proto_vals[d][pick].reshape(-1)
+            noff = value_bytes_total * self.capacity + d * self.capacity
+            blob[noff:noff + self.length] = proto_valid[pick, d]
+            off += w * self.capacity
         self.blob = blob
         aggs = [abi.AGGR_SUM_UNSIGNED, abi.AGGR_SUM_SIGNED, abi.AGGR_SUM_FLOAT, abi.AGGR_MIN_UNSIGNED,
                 abi.AGGR_MIN_SIGNED, abi.AGGR_MIN_FLOAT, abi.AGGR_MAX_UNSIGNED, abi.AGGR_MAX_SIGNED,

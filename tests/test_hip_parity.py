@@ -97,8 +97,42 @@ def test_sort_reduce(seed):
     assert _values_close(c, g["out_values"], w["out_values"]), f"GroupByCase({seed})"
 
 
+@pytest.fixture(params=["lds", "global"])
+def hash_path(request, monkeypatch):
+    """Both HashReduce implementations: the partitioned LDS path (default) and the global-table path
+    (taken for AVG / float min-max, and as overflow fallback)."""
+    if request.param == "global":
+        monkeypatch.setenv("ARES_HASH_REDUCE", "global")
+    else:
+        monkeypatch.delenv("ARES_HASH_REDUCE", raising=False)
+    return request.param
+
+
+def _hash_reduce_same(c, what):
+    g, w = c.run_hash_reduce(hip()), c.run_hash_reduce(H.oracle_backend())
+    assert g["groups"] == w["groups"], what
+    assert g["map"].keys() == w["map"].keys(), what
+    keys = sorted(g["map"].keys())
+    a = np.frombuffer(b"".join(g["map"][k] for k in keys), np.uint8)
+    b = np.frombuffer(b"".join(w["map"][k] for k in keys), np.uint8)
+    assert _values_close(c, a, b), what
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_hash_reduce_many_groups(seed, hash_path):
+    """Enough rows and groups for several partitions, table flushes and multi-round merges: length
+    up to 400k with a third of the rows distinct (the oracle's HOST-style map is O(groups) here)."""
+    length = [30000, 70001, 150000, 400000][seed % 4]
+    groups = [length // 3, length // 50, 7, length - 5][(seed // 4) % 4] if seed < 8 else length // 2
+    aggs = [abi.AGGR_SUM_FLOAT, abi.AGGR_SUM_SIGNED, abi.AGGR_SUM_UNSIGNED]
+    c = cases.GroupByCase(5000 + seed, length=length, groups=max(1, groups), agg=aggs[seed % 3],
+                          ndw=[(0, 0, 4, 0, 0), (0, 1, 1, 1, 1), (1, 0, 0, 0, 2)][seed % 3],
+                          value_bytes=[8, 4][seed % 2])
+    _hash_reduce_same(c, f"GroupByCase({5000 + seed}) {hash_path}")
+
+
 @pytest.mark.parametrize("seed", range(40))
-def test_hash_reduce(seed):
+def test_hash_reduce(seed, hash_path):
     length = [None, None, 5000, 100000][seed % 4]
     aggs = [abi.AGGR_SUM_UNSIGNED, abi.AGGR_SUM_SIGNED, abi.AGGR_SUM_FLOAT, abi.AGGR_AVG_FLOAT]
     c = cases.GroupByCase(1000 + seed, length=length, agg=aggs[seed % 4])

@@ -560,16 +560,26 @@ __global__ __launch_bounds__(kThreads) void hr_merge_kernel(const uint8_t *dimIn
     const uint32_t total = sCount;
     if (threadIdx.x == 0 && total) sBase = atomicAdd(ws.outCount, total);
     __syncthreads();
-    if (mineCount && !(ws.debug & 16)) {
-      uint32_t at = sBase + __hip_atomic_fetch_add(&sClaims, mineCount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (total && !(ws.debug & 16)) {
+      // one output range per wavefront per sweep: consecutive lanes write consecutive rows
+      const int lane = threadIdx.x & 63;
 #pragma unroll
       for (int k = 0; k < kPerLane; k++) {
         const int s = threadIdx.x + k * kThreads;
         const uint64_t key = sKeys[s];
+        const uint64_t m = __ballot(key != kEmpty);
+        if (m == 0) continue;
+        uint32_t waveBase = 0;
+        if (lane == 0)
+          waveBase = __hip_atomic_fetch_add(&sClaims, static_cast<uint32_t>(__popcll(m)), __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_WORKGROUP);
+        waveBase = __builtin_amdgcn_readfirstlane(waveBase);
         if (key == kEmpty) continue;
+        const uint32_t at = sBase + waveBase +
+                            __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
+                                                      __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
         copy_dim_row(dimIn, capacity, dimOut, capacity, L, static_cast<uint32_t>(key), at);
         store_value_bits(outputValues, a, at, sVals[s]);
-        at++;
       }
     }
     __syncthreads();

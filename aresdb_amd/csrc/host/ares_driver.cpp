@@ -1,0 +1,654 @@
+// libaresdriver.so — C++ mirror of the reference's Go batch executor above the cgo C ABI.
+//
+//   AbiLibrary         <- cgo bindings of query/time_series_aggregate.go:17-19 + cgoutils/memory.go:17-19
+//                         and the DoCGoCall error convention (cgoutils/utils.go:26-34)
+//   BatchContext       <- oopkBatchContext (query/aql_context.go, query/aql_processor.go:690-804)
+//   processExpression  <- query/time_series_aggregate.go:491-593 (AST walk, one ABI call per node)
+//   BatchExecutor      <- BatchExecutorImpl (query/aql_batchexecutor.go:103-273)
+//
+// Stage order, ABI calls, buffer ownership (the host allocates and frees every buffer through
+// libmem, the result buffers grow by 12.5 % and are double-buffered) follow the Go code line by
+// line; only the language differs.
+#include "ares_driver.h"
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "ares_memory.h"
+
+namespace {
+
+struct AbiError : std::runtime_error {
+  explicit AbiError(const std::string &m) : std::runtime_error(m) {}
+};
+
+// DoCGoCall: a non-null pStrErr is the callee's malloc'ed message; the Go host panics with it
+intptr_t check(CGoCallResHandle h) {
+  if (h.pStrErr) {
+    std::string msg(h.pStrErr);
+    free(const_cast<char *>(h.pStrErr));
+    throw AbiError(msg);
+  }
+  return reinterpret_cast<intptr_t>(h.res);
+}
+
+struct AbiLibrary {
+  void *algoHandle = nullptr, *memHandle = nullptr;
+  // libalgorithm
+  decltype(&::InitIndexVector) InitIndexVector;
+  decltype(&::HashLookup) HashLookup;
+  decltype(&::UnaryTransform) UnaryTransform;
+  decltype(&::UnaryFilter) UnaryFilter;
+  decltype(&::BinaryTransform) BinaryTransform;
+  decltype(&::BinaryFilter) BinaryFilter;
+  decltype(&::Sort) Sort;
+  decltype(&::Reduce) Reduce;
+  decltype(&::HashReduce) HashReduce;
+  // libmem
+  decltype(&::DeviceAllocate) DeviceAllocate;
+  decltype(&::DeviceFree) DeviceFree;
+  decltype(&::WaitForCudaStream) WaitForCudaStream;
+  decltype(&::AsyncCopyDeviceToDevice) AsyncCopyDeviceToDevice;
+  decltype(&::AsyncCopyDeviceToHost) AsyncCopyDeviceToHost;
+
+  template <typename F>
+  void bind(void *handle, const char *name, F &fn) {
+    fn = reinterpret_cast<F>(dlsym(handle, name));
+    if (!fn) throw AbiError(std::string("missing symbol ") + name);
+  }
+
+  AbiLibrary(const char *algoPath, const char *memPath) {
+    memHandle = dlopen(memPath, RTLD_NOW | RTLD_LOCAL);
+    if (!memHandle) throw AbiError(std::string("dlopen ") + memPath + ": " + dlerror());
+    algoHandle = dlopen(algoPath, RTLD_NOW | RTLD_LOCAL);
+    if (!algoHandle) throw AbiError(std::string("dlopen ") + algoPath + ": " + dlerror());
+    bind(algoHandle, "InitIndexVector", InitIndexVector);
+    bind(algoHandle, "HashLookup", HashLookup);
+    bind(algoHandle, "UnaryTransform", UnaryTransform);
+    bind(algoHandle, "UnaryFilter", UnaryFilter);
+    bind(algoHandle, "BinaryTransform", BinaryTransform);
+    bind(algoHandle, "BinaryFilter", BinaryFilter);
+    bind(algoHandle, "Sort", Sort);
+    bind(algoHandle, "Reduce", Reduce);
+    bind(algoHandle, "HashReduce", HashReduce);
+    bind(memHandle, "DeviceAllocate", DeviceAllocate);
+    bind(memHandle, "DeviceFree", DeviceFree);
+    bind(memHandle, "WaitForCudaStream", WaitForCudaStream);
+    bind(memHandle, "AsyncCopyDeviceToDevice", AsyncCopyDeviceToDevice);
+    bind(memHandle, "AsyncCopyDeviceToHost", AsyncCopyDeviceToHost);
+  }
+  ~AbiLibrary() {
+    if (algoHandle) dlclose(algoHandle);
+    if (memHandle) dlclose(memHandle);
+  }
+};
+
+// The reference header gives ForeignColumnVector a `*const` member, which makes InputVector neither
+// default-constructible nor assignable in C++; a zeroed byte box with the same layout is.
+template <typename T>
+struct Pod {
+  alignas(T) unsigned char bytes[sizeof(T)];
+  Pod() { memset(bytes, 0, sizeof(bytes)); }
+  T &operator*() { return *reinterpret_cast<T *>(bytes); }
+  T *operator->() { return reinterpret_cast<T *>(bytes); }
+  const T &get() const { return *reinterpret_cast<const T *>(bytes); }
+};
+using IV = Pod<InputVector>;
+using OV = Pod<OutputVector>;
+
+constexpr int kDimWidths[NUM_DIM_WIDTH] = {16, 8, 4, 2, 1};
+
+int data_type_bytes(int t) {
+  switch (t) {
+    case Bool: case Int8: case Uint8: return 1;
+    case Int16: case Uint16: return 2;
+    case Int32: case Uint32: case Float32: return 4;
+    case Int64: case Uint64: case Float64: case GeoPoint: return 8;
+    case UUID: return 16;
+    default: throw AbiError("unknown data type");
+  }
+}
+
+// query/common/dim_util.go: (value offset, validity offset) of dimension `dimIndex`
+void dimension_start_offsets(const uint8_t ndw[NUM_DIM_WIDTH], int dimIndex, int64_t capacity, int64_t *valueOff,
+                             int64_t *nullOff) {
+  int64_t before = 0, all = 0;
+  int d = 0, total = 0;
+  for (int w = 0; w < NUM_DIM_WIDTH; w++) total += ndw[w];
+  for (int w = 0; w < NUM_DIM_WIDTH; w++)
+    for (int j = 0; j < ndw[w]; j++, d++) {
+      if (d < dimIndex) before += kDimWidths[w];
+      all += kDimWidths[w];
+    }
+  *valueOff = before * capacity;
+  *nullOff = all * capacity + static_cast<int64_t>(dimIndex) * capacity;
+  (void)total;
+}
+
+struct Plan {
+  std::vector<AresPlanNode> nodes;
+  std::vector<int> filters, foreignFilters, dimNodes, dimTypes;
+  int measureNode, aggFunc, measureType;
+  bool useHashReduction;
+  struct Foreign {
+    AresForeignTable t;
+    std::vector<VectorPartySlice> slices;
+    std::vector<int> dataTypes;
+  };
+  std::vector<Foreign> foreign;
+
+  explicit Plan(const AresQueryPlan &p)
+      : nodes(p.nodes, p.nodes + p.numNodes), filters(p.filters, p.filters + p.numFilters),
+        foreignFilters(p.foreignFilters, p.foreignFilters + p.numForeignFilters),
+        dimNodes(p.dimNodes, p.dimNodes + p.numDims), dimTypes(p.dimTypes, p.dimTypes + p.numDims),
+        measureNode(p.measureNode), aggFunc(p.aggFunc), measureType(p.measureType),
+        useHashReduction(p.useHashReduction != 0) {
+    for (int i = 0; i < p.numForeignTables; i++) {
+      Foreign f;
+      f.t = p.foreignTables[i];
+      f.slices.assign(f.t.slices, f.t.slices + static_cast<size_t>(f.t.numColumns) * f.t.numBatches);
+      f.dataTypes.assign(f.t.dataTypes, f.t.dataTypes + f.t.numColumns);
+      foreign.push_back(std::move(f));
+    }
+  }
+  int measureBytes() const { return data_type_bytes(measureType); }
+  int dimRowBytes() const {
+    int b = 0;
+    for (int t : dimTypes) b += data_type_bytes(t) + 1;
+    return b;
+  }
+};
+
+}  // namespace
+
+struct AresQuery {
+  AbiLibrary *lib;
+  Plan plan;
+  int device;
+  void *stream;
+  // oopkBatchContext
+  uint8_t ndw[NUM_DIM_WIDTH] = {0, 0, 0, 0, 0};
+  std::vector<int> dimVectorIndex;  // query dimension -> position in the width-ordered vector
+  int resultSize = 0, resultCapacity = 0;
+  uint8_t *dimVec[2] = {nullptr, nullptr};
+  uint8_t *measureVec[2] = {nullptr, nullptr};
+  uint64_t *hashVec[2] = {nullptr, nullptr};
+  uint32_t *dimIndexVec[2] = {nullptr, nullptr};
+  int size = 0;
+  uint32_t *indexVec = nullptr;
+  uint8_t *predVec = nullptr;
+  uint32_t *baseCounts = nullptr;
+  uint32_t startRow = 0;
+  const VectorPartySlice *columns = nullptr;
+  int numColumns = 0;
+  std::vector<uint8_t *> stack;
+  std::vector<RecordID *> foreignRids;
+  long calls = 0;
+
+  AresQuery(AbiLibrary *l, const AresQueryPlan &p, int dev, void *s) : lib(l), plan(p), device(dev), stream(s) {
+    // query/aql_compiler.go:1341-1362: dimensions ordered by width 16..1, then query order
+    const int n = static_cast<int>(plan.dimTypes.size());
+    std::vector<int> order(n);
+    for (int i = 0; i < n; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+      return data_type_bytes(plan.dimTypes[a]) > data_type_bytes(plan.dimTypes[b]);
+    });
+    dimVectorIndex.assign(n, 0);
+    for (int p2 = 0; p2 < n; p2++) dimVectorIndex[order[p2]] = p2;
+    for (int t : plan.dimTypes) {
+      const int w = data_type_bytes(t);
+      for (int k = 0; k < NUM_DIM_WIDTH; k++)
+        if (kDimWidths[k] == w) ndw[k]++;
+    }
+  }
+
+  // -- device_allocator.go semantics: every byte is allocated and freed by the host through libmem --
+  template <typename T = uint8_t>
+  T *alloc(size_t bytes) {
+    return reinterpret_cast<T *>(check(lib->DeviceAllocate(bytes ? bytes : 1, device)));
+  }
+  void release(void *p) {
+    if (p) check(lib->DeviceFree(p, device));
+  }
+  void wait() { check(lib->WaitForCudaStream(stream, device)); }
+  void d2d(void *dst, void *src, size_t bytes) {
+    if (bytes) check(lib->AsyncCopyDeviceToDevice(dst, src, bytes, stream, device));
+  }
+
+  // -- aql_processor.go:726-739 --
+  void prepareForFiltering(const VectorPartySlice *cols, int ncols, int n, uint32_t *bc, uint32_t start) {
+    columns = cols;
+    numColumns = ncols;
+    size = n;
+    baseCounts = bc;
+    startRow = start;
+    indexVec = alloc<uint32_t>(static_cast<size_t>(n) * 4);
+    predVec = alloc<uint8_t>(static_cast<size_t>(n));
+  }
+
+  // -- aql_processor.go:743-804: grow the result buffers by 12.5 % and carry the old results over --
+  void prepareForDimAndMeasureEval() {
+    if (resultSize + size <= resultCapacity) return;
+    const int oldCapacity = resultCapacity;
+    resultCapacity = resultSize + size;
+    resultCapacity += resultCapacity / 8;
+    const int64_t cap = resultCapacity;
+    std::vector<int> widths;
+    for (int k = 0; k < NUM_DIM_WIDTH; k++)
+      for (int j = 0; j < ndw[k]; j++) widths.push_back(kDimWidths[k]);
+    {
+      uint8_t *old0 = dimVec[0], *old1 = dimVec[1];
+      const size_t unit = std::max(plan.dimRowBytes(), 1);
+      dimVec[0] = alloc(cap * unit);
+      dimVec[1] = alloc(cap * unit);
+      if (old0 && resultSize) {  // asyncCopyDimensionVector: per-dimension strided D2D copies
+        for (size_t d = 0; d < widths.size(); d++) {
+          int64_t nv, nn, ov, on;
+          dimension_start_offsets(ndw, static_cast<int>(d), cap, &nv, &nn);
+          dimension_start_offsets(ndw, static_cast<int>(d), oldCapacity, &ov, &on);
+          d2d(dimVec[0] + nv, old0 + ov, static_cast<size_t>(resultSize) * widths[d]);
+          d2d(dimVec[0] + nn, old0 + on, static_cast<size_t>(resultSize));
+        }
+      }
+      if (old0 || old1) wait();
+      release(old0);
+      release(old1);
+    }
+    if (!plan.useHashReduction) {
+      release(dimIndexVec[0]); release(dimIndexVec[1]);
+      release(hashVec[0]); release(hashVec[1]);
+      dimIndexVec[0] = alloc<uint32_t>(cap * 4); dimIndexVec[1] = alloc<uint32_t>(cap * 4);
+      hashVec[0] = alloc<uint64_t>(cap * 8); hashVec[1] = alloc<uint64_t>(cap * 8);
+    }
+    {
+      const int mb = plan.measureBytes();
+      uint8_t *old0 = measureVec[0], *old1 = measureVec[1];
+      measureVec[0] = alloc(cap * mb);
+      measureVec[1] = alloc(cap * mb);
+      if (old0 && resultSize) d2d(measureVec[0], old0, static_cast<size_t>(resultSize) * mb);
+      if (old0 || old1) wait();
+      release(old0);
+      release(old1);
+    }
+  }
+
+  // -- time_series_aggregate.go:745-769 --
+  uint8_t *allocateStackFrame(int dataType, uint32_t *nullsOffset) {
+    const int w = (dataType == Int64 || dataType == Uint64 || dataType == Float64 || dataType == GeoPoint) ? 8
+                  : dataType == UUID ? 16 : 4;
+    uint8_t *values = alloc(static_cast<size_t>(w + 1) * size);
+    stack.push_back(values);
+    *nullsOffset = static_cast<uint32_t>(w) * size;
+    return values;
+  }
+  void shrinkStackFrame() {
+    std::swap(stack[stack.size() - 1], stack[stack.size() - 2]);
+    release(stack.back());
+    stack.pop_back();
+  }
+
+  void cleanupBeforeAggregation() {
+    release(indexVec); indexVec = nullptr;
+    release(predVec); predVec = nullptr;
+    for (RecordID *p : foreignRids) release(p);
+    foreignRids.clear();
+    for (uint8_t *p : stack) release(p);
+    stack.clear();
+    foreignSliceArrays.clear();
+  }
+  void swapResultBuffers() {
+    size = 0;
+    std::swap(dimVec[0], dimVec[1]);
+    std::swap(measureVec[0], measureVec[1]);
+    std::swap(hashVec[0], hashVec[1]);
+  }
+  void releaseAll() {
+    for (int i = 0; i < 2; i++) {
+      release(dimVec[i]); release(measureVec[i]); release(hashVec[i]); release(dimIndexVec[i]);
+      dimVec[i] = nullptr; measureVec[i] = nullptr; hashVec[i] = nullptr; dimIndexVec[i] = nullptr;
+    }
+    resultCapacity = 0;
+  }
+
+  // -- processExpression (time_series_aggregate.go:491-593) --
+  std::vector<std::vector<VectorPartySlice>> foreignSliceArrays;  // Go slices handed to the callee for one call
+
+  IV columnInput(const AresPlanNode &n) {
+    IV iv;
+    if (n.table == 0) {
+      if (n.column < 0 || n.column >= numColumns) throw AbiError("column index out of range");
+      iv->Vector.VP = columns[n.column];
+      iv->Type = VectorPartyInput;
+      return iv;
+    }
+    const Plan::Foreign &ft = plan.foreign.at(n.table - 1);
+    foreignSliceArrays.emplace_back(ft.slices.begin() + static_cast<size_t>(n.column) * ft.t.numBatches,
+                                    ft.slices.begin() + static_cast<size_t>(n.column + 1) * ft.t.numBatches);
+    ForeignColumnVector &f = iv->Vector.ForeignVP;
+    f.RecordIDs = foreignRids.at(n.table - 1);
+    f.Batches = foreignSliceArrays.back().data();
+    f.BaseBatchID = ft.t.baseBatchID;
+    f.NumBatches = ft.t.numBatches;
+    f.NumRecordsInLastBatch = ft.t.numRecordsInLastBatch;
+    f.TimezoneLookupSize = 0;  // TimezoneLookup stays NULL (zeroed box)
+    f.DataType = static_cast<DataType>(ft.dataTypes[n.column]);
+    iv->Type = ForeignColumnInput;
+    return iv;
+  }
+  static IV constantInput(const AresPlanNode &n) {
+    IV iv;
+    if (n.kind == ARES_NODE_CONST_FLOAT) {
+      iv->Vector.Constant.Value.FloatVal = n.fval;
+      iv->Vector.Constant.DataType = ConstFloat;
+    } else {
+      iv->Vector.Constant.Value.IntVal = n.ival;
+      iv->Vector.Constant.DataType = ConstInt;
+    }
+    iv->Vector.Constant.IsValid = true;
+    iv->Type = ConstantInput;
+    return iv;
+  }
+  static IV scratchInput(uint8_t *values, uint32_t nullsOffset, int dataType) {
+    IV iv;
+    iv->Vector.ScratchSpace.Values = values;
+    iv->Vector.ScratchSpace.NullsOffset = nullsOffset;
+    iv->Vector.ScratchSpace.DataType = static_cast<DataType>(dataType);
+    iv->Type = ScratchSpaceInput;
+    return iv;
+  }
+  static OV scratchOutput(uint8_t *values, uint32_t nullsOffset, int dataType) {
+    OV ov;
+    ov->Vector.ScratchSpace.Values = values;
+    ov->Vector.ScratchSpace.NullsOffset = nullsOffset;
+    ov->Vector.ScratchSpace.DataType = static_cast<DataType>(dataType);
+    ov->Type = ScratchSpaceOutput;
+    return ov;
+  }
+
+  // root action: what to do with the operands of the expression's root
+  struct Action {
+    enum Kind { NONE, FILTER, MEASURE, DIMENSION } kind = NONE;
+    int dimType = 0;
+    int64_t valueOff = 0, nullOff = 0;
+    int prevResultSize = 0;
+  };
+
+  void runAction(const Action &a, int functor, IV *in, int arity) {
+    if (size <= 0) return;
+    calls++;
+    if (a.kind == Action::FILTER) {
+      RecordID **vecs = foreignRids.empty() ? nullptr : foreignRids.data();
+      const int nf = static_cast<int>(foreignRids.size());
+      const intptr_t n =
+          arity == 1 ? check(lib->UnaryFilter(in[0].get(), indexVec, predVec, size, vecs, nf, baseCounts, startRow,
+                                              static_cast<UnaryFunctorType>(functor), stream, device))
+                     : check(lib->BinaryFilter(in[0].get(), in[1].get(), indexVec, predVec, size, vecs, nf, baseCounts, startRow,
+                                               static_cast<BinaryFunctorType>(functor), stream, device));
+      size = static_cast<int>(n);
+      return;
+    }
+    OV ov;
+    if (a.kind == Action::MEASURE) {
+      ov->Vector.Measure.Values = reinterpret_cast<uint32_t *>(measureVec[0] + static_cast<size_t>(resultSize) * plan.measureBytes());
+      ov->Vector.Measure.DataType = static_cast<DataType>(plan.measureType);
+      ov->Vector.Measure.AggFunc = static_cast<AggregateFunction>(plan.aggFunc);
+      ov->Type = MeasureOutput;
+    } else {
+      const int w = data_type_bytes(a.dimType);
+      ov->Vector.Dimension.DimValues = dimVec[0] + a.valueOff + static_cast<int64_t>(w) * a.prevResultSize;
+      ov->Vector.Dimension.DimNulls = dimVec[0] + a.nullOff + a.prevResultSize;
+      ov->Vector.Dimension.DataType = static_cast<DataType>(a.dimType);
+      ov->Type = DimensionOutput;
+    }
+    if (arity == 1)
+      check(lib->UnaryTransform(in[0].get(), ov.get(), indexVec, size, baseCounts, startRow, static_cast<UnaryFunctorType>(functor),
+                                stream, device));
+    else
+      check(lib->BinaryTransform(in[0].get(), in[1].get(), ov.get(), indexVec, size, baseCounts, startRow,
+                                 static_cast<BinaryFunctorType>(functor), stream, device));
+  }
+
+  // returns the node's value as an InputVector (leaf or scratch frame) when action is NONE,
+  // otherwise performs the root action
+  IV processExpression(int nodeIdx, const Action &action) {
+    const AresPlanNode &n = plan.nodes.at(nodeIdx);
+    IV none;
+    switch (n.kind) {
+      case ARES_NODE_COLUMN:
+      case ARES_NODE_CONST_INT:
+      case ARES_NODE_CONST_FLOAT: {
+        IV iv = n.kind == ARES_NODE_COLUMN ? columnInput(n) : constantInput(n);
+        if (action.kind != Action::NONE) {
+          runAction(action, Noop, &iv, 1);
+          return none;
+        }
+        return iv;
+      }
+      case ARES_NODE_UNARY: {
+        IV in = processExpression(n.lhs, Action());
+        if (action.kind != Action::NONE) {
+          runAction(action, n.op, &in, 1);
+          return none;
+        }
+        uint32_t nullsOff;
+        uint8_t *values = allocateStackFrame(n.outType, &nullsOff);
+        calls++;
+        check(lib->UnaryTransform(in.get(), scratchOutput(values, nullsOff, n.outType).get(), indexVec, size, baseCounts,
+                                  startRow, static_cast<UnaryFunctorType>(n.op), stream, device));
+        if (in->Type == ScratchSpaceInput) shrinkStackFrame();
+        return scratchInput(values, nullsOff, n.outType);
+      }
+      case ARES_NODE_BINARY: {
+        IV in[2];
+        in[0] = processExpression(n.lhs, Action());
+        in[1] = processExpression(n.rhs, Action());
+        if (action.kind != Action::NONE) {
+          runAction(action, n.op, in, 2);
+          return none;
+        }
+        uint32_t nullsOff;
+        uint8_t *values = allocateStackFrame(n.outType, &nullsOff);
+        calls++;
+        check(lib->BinaryTransform(in[0].get(), in[1].get(), scratchOutput(values, nullsOff, n.outType).get(), indexVec, size,
+                                   baseCounts, startRow, static_cast<BinaryFunctorType>(n.op), stream, device));
+        if (in[1]->Type == ScratchSpaceInput) shrinkStackFrame();
+        if (in[0]->Type == ScratchSpaceInput) shrinkStackFrame();
+        return scratchInput(values, nullsOff, n.outType);
+      }
+      default:
+        throw AbiError("unsupported expression node");
+    }
+  }
+
+  DimensionVector dimensionVector(int which) const {
+    DimensionVector dv;
+    memset(&dv, 0, sizeof(dv));
+    dv.DimValues = dimVec[which];
+    dv.HashValues = hashVec[which];
+    dv.IndexVector = dimIndexVec[which];
+    dv.VectorCapacity = resultCapacity;
+    memcpy(dv.NumDimsPerDimWidth, ndw, sizeof(ndw));
+    return dv;
+  }
+
+  // ---- BatchExecutorImpl.Run (aql_batchexecutor.go:103-273) ----
+  void preExec() {
+    if (indexVec && size > 0) {
+      calls++;
+      check(lib->InitIndexVector(indexVec, 0, size, stream, device));
+    }
+  }
+  void filter() {
+    Action a;
+    a.kind = Action::FILTER;
+    for (int f : plan.filters) processExpression(f, a);
+  }
+  void join() {
+    for (const Plan::Foreign &ft : plan.foreign) {
+      RecordID *rids = alloc<RecordID>(static_cast<size_t>(std::max(size, 1)) * 8);
+      foreignRids.push_back(rids);
+      if (size > 0) {
+        AresPlanNode key;
+        memset(&key, 0, sizeof(key));
+        key.kind = ARES_NODE_COLUMN;
+        key.table = 0;
+        key.column = ft.t.joinColumn;
+        calls++;
+        check(lib->HashLookup(columnInput(key).get(), rids, indexVec, size, baseCounts, startRow, ft.t.index, stream, device));
+      }
+    }
+    Action a;
+    a.kind = Action::FILTER;
+    for (int f : plan.foreignFilters) processExpression(f, a);
+  }
+  void project() {
+    prepareForDimAndMeasureEval();
+    const int prev = resultSize;
+    for (size_t i = 0; i < plan.dimNodes.size(); i++) {
+      Action a;
+      a.kind = Action::DIMENSION;
+      a.dimType = plan.dimTypes[i];
+      a.prevResultSize = prev;
+      dimension_start_offsets(ndw, dimVectorIndex[i], resultCapacity, &a.valueOff, &a.nullOff);
+      processExpression(plan.dimNodes[i], a);
+    }
+    Action m;
+    m.kind = Action::MEASURE;
+    processExpression(plan.measureNode, m);
+    wait();
+    cleanupBeforeAggregation();
+  }
+  void reduce() {
+    const int length = resultSize + size;
+    const int mb = plan.measureBytes();
+    if (plan.useHashReduction) {
+      calls++;
+      resultSize = static_cast<int>(check(lib->HashReduce(dimensionVector(0), measureVec[0], dimensionVector(1), measureVec[1],
+                                                          mb, length, static_cast<AggregateFunction>(plan.aggFunc), stream,
+                                                          device)));
+    } else {
+      calls += 3;
+      check(lib->InitIndexVector(dimIndexVec[0], 0, length, stream, device));
+      check(lib->Sort(dimensionVector(0), length, stream, device));
+      resultSize = static_cast<int>(check(lib->Reduce(dimensionVector(0), measureVec[0], dimensionVector(1), measureVec[1], mb,
+                                                      length, static_cast<AggregateFunction>(plan.aggFunc), stream, device)));
+    }
+    wait();
+  }
+  void postExec() { swapResultBuffers(); }
+
+  void runBatch(const VectorPartySlice *cols, int ncols, int n, uint32_t *bc, uint32_t start) {
+    prepareForFiltering(cols, ncols, n, bc, start);
+    preExec();
+    filter();
+    join();
+    project();
+    reduce();
+    postExec();
+  }
+};
+
+// ---- C API ---------------------------------------------------------------------------------------
+namespace {
+void set_err(char *err, int errLen, const char *msg) {
+  if (err && errLen > 0) {
+    strncpy(err, msg, static_cast<size_t>(errLen) - 1);
+    err[errLen - 1] = 0;
+  }
+}
+}  // namespace
+
+extern "C" {
+
+void *AresDriverOpen(const char *libalgorithmPath, const char *libmemPath, char *err, int errLen) {
+  try {
+    return new AbiLibrary(libalgorithmPath, libmemPath);
+  } catch (std::exception &e) {
+    set_err(err, errLen, e.what());
+    return nullptr;
+  }
+}
+
+void AresDriverClose(void *driver) { delete static_cast<AbiLibrary *>(driver); }
+
+AresQuery *AresQueryCreate(void *driver, const AresQueryPlan *plan, int device, void *stream, char *err, int errLen) {
+  try {
+    return new AresQuery(static_cast<AbiLibrary *>(driver), *plan, device, stream);
+  } catch (std::exception &e) {
+    set_err(err, errLen, e.what());
+    return nullptr;
+  }
+}
+
+int AresQueryRunBatch(AresQuery *q, const VectorPartySlice *columns, int numColumns, int size, uint32_t *baseCounts,
+                      uint32_t startRow, char *err, int errLen) {
+  try {
+    q->runBatch(columns, numColumns, size, baseCounts, startRow);
+    return 0;
+  } catch (std::exception &e) {
+    // the Go host recovers the panic, frees every device buffer and fails the query
+    // (query/aql_processor.go:50-64, :263-269)
+    set_err(err, errLen, e.what());
+    try {
+      q->cleanupBeforeAggregation();
+    } catch (...) {
+    }
+    return -1;
+  }
+}
+
+int AresQueryResultSize(const AresQuery *q) { return q->resultSize; }
+int AresQueryResultCapacity(const AresQuery *q) { return q->resultCapacity; }
+uint8_t *AresQueryDimensionVector(const AresQuery *q) { return q->dimVec[0]; }
+uint8_t *AresQueryMeasureVector(const AresQuery *q) { return q->measureVec[0]; }
+long AresQueryNumCalls(const AresQuery *q) { return q->calls; }
+
+int AresQueryFetch(AresQuery *q, uint8_t *dims, uint8_t *measures, char *err, int errLen) {
+  try {
+    const int n = q->resultSize;
+    std::vector<int> widths;
+    for (int k = 0; k < NUM_DIM_WIDTH; k++)
+      for (int j = 0; j < q->ndw[k]; j++) widths.push_back(kDimWidths[k]);
+    uint8_t *out = dims;
+    // asyncCopyDimensionVector to the host (query/aql_processor.go:641-671): the host layout uses
+    // resultSize as its stride
+    for (size_t d = 0; d < widths.size() && n; d++) {
+      int64_t vo, no;
+      dimension_start_offsets(q->ndw, static_cast<int>(d), q->resultCapacity, &vo, &no);
+      check(q->lib->AsyncCopyDeviceToHost(out, q->dimVec[0] + vo, static_cast<size_t>(n) * widths[d], q->stream, q->device));
+      out += static_cast<size_t>(n) * widths[d];
+    }
+    for (size_t d = 0; d < widths.size() && n; d++) {
+      int64_t vo, no;
+      dimension_start_offsets(q->ndw, static_cast<int>(d), q->resultCapacity, &vo, &no);
+      check(q->lib->AsyncCopyDeviceToHost(out, q->dimVec[0] + no, static_cast<size_t>(n), q->stream, q->device));
+      out += n;
+    }
+    if (n) check(q->lib->AsyncCopyDeviceToHost(measures, q->measureVec[0], static_cast<size_t>(n) * q->plan.measureBytes(),
+                                               q->stream, q->device));
+    q->wait();
+    return 0;
+  } catch (std::exception &e) {
+    set_err(err, errLen, e.what());
+    return -1;
+  }
+}
+
+void AresQueryDestroy(AresQuery *q) {
+  if (!q) return;
+  try {
+    q->cleanupBeforeAggregation();
+    q->releaseAll();
+  } catch (...) {
+  }
+  delete q;
+}
+
+}  // extern "C"

@@ -1,0 +1,85 @@
+/* ares_driver.h — C API of libaresdriver.so: the host side of the AQL batch pipeline in C++.
+ *
+ * The reference's host is Go (query/aql_processor.go, aql_batchexecutor.go, aql_context.go,
+ * time_series_aggregate.go) and talks to libalgorithm.so / libmem.so through cgo.  No Go toolchain
+ * exists in this environment, so the same host logic — same stage order, same ABI calls, same buffer
+ * ownership — is written in C++ above the same C ABI, bound with dlopen() instead of cgo.  It is
+ * backend-agnostic: it drives whatever (libalgorithm, libmem) pair it is given.
+ *
+ * The plan is handed over as a flat node array (what the AQL compiler's OOPK context holds as
+ * expr trees, query/aql_context.go:148-150).
+ */
+#ifndef ARES_DRIVER_H_
+#define ARES_DRIVER_H_
+
+#include <stdint.h>
+
+#include "ares_algorithm.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum AresNodeKind { ARES_NODE_COLUMN = 0, ARES_NODE_CONST_INT = 1, ARES_NODE_CONST_FLOAT = 2, ARES_NODE_UNARY = 3, ARES_NODE_BINARY = 4 };
+
+typedef struct {
+  int kind;     /* enum AresNodeKind */
+  int op;       /* Unary/BinaryFunctorType */
+  int lhs, rhs; /* child node indices */
+  int table;    /* 0 = main table, k > 0 = foreign table k-1 */
+  int column;   /* column index inside that table */
+  int32_t ival;
+  float fval;
+  int outType;  /* enum DataType of the scratch vector when this is an inner node */
+} AresPlanNode;
+
+typedef struct {
+  int joinColumn;            /* main-table column the join key comes from */
+  CuckooHashIndex index;     /* device image of the primary-key index */
+  int numColumns;
+  int numBatches;
+  const VectorPartySlice *slices; /* numColumns x numBatches, column-major */
+  const int *dataTypes;      /* per column */
+  int32_t baseBatchID;
+  int32_t numRecordsInLastBatch;
+} AresForeignTable;
+
+typedef struct {
+  const AresPlanNode *nodes;
+  int numNodes;
+  const int *filters; int numFilters;               /* root node of every main-table filter */
+  const int *foreignFilters; int numForeignFilters; /* filters that read joined columns */
+  const int *dimNodes; const int *dimTypes; int numDims; /* dimension roots + their output DataType */
+  int measureNode;
+  int aggFunc;      /* enum AggregateFunction */
+  int measureType;  /* enum DataType of the measure vector */
+  int useHashReduction;
+  const AresForeignTable *foreignTables; int numForeignTables;
+} AresQueryPlan;
+
+typedef struct AresQuery AresQuery; /* oopkBatchContext + executor of one query on one device */
+
+/* Loads the two libraries (dlopen, RTLD_LOCAL) and resolves every ABI symbol; NULL + message on failure. */
+void *AresDriverOpen(const char *libalgorithmPath, const char *libmemPath, char *err, int errLen);
+void AresDriverClose(void *driver);
+
+AresQuery *AresQueryCreate(void *driver, const AresQueryPlan *plan, int device, void *stream, char *err, int errLen);
+/* One batch through preExec / filter / join / project / reduce / postExec
+ * (query/aql_batchexecutor.go:103-273).  columns: one slice per main-table column.  Returns 0, or
+ * -1 with the library's error message in err. */
+int AresQueryRunBatch(AresQuery *q, const VectorPartySlice *columns, int numColumns, int size,
+                      uint32_t *baseCounts, uint32_t startRow, char *err, int errLen);
+int AresQueryResultSize(const AresQuery *q);
+int AresQueryResultCapacity(const AresQuery *q);
+uint8_t *AresQueryDimensionVector(const AresQuery *q); /* device pointer, capacity stride */
+uint8_t *AresQueryMeasureVector(const AresQuery *q);
+long AresQueryNumCalls(const AresQuery *q);            /* ABI calls issued so far */
+/* D2H of the result (query/aql_processor.go:641-671): dims = for each dim in vector order
+ * resultSize*width value bytes, then numDims x resultSize validity bytes; measures. */
+int AresQueryFetch(AresQuery *q, uint8_t *dims, uint8_t *measures, char *err, int errLen);
+void AresQueryDestroy(AresQuery *q);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARES_DRIVER_H_ */

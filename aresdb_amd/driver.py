@@ -1,0 +1,232 @@
+"""ctypes binding of libaresdriver.so — the C++ host side of the batch pipeline
+(aresdb_amd/csrc/host/ares_driver.cpp, a mirror of the reference's Go batch executor).
+
+`NativeQuery` has the same surface as executor.BatchContext/BatchExecutor/fetch_results, so tests
+run one plan through the Python mirror and the C++ driver and compare; bench.py uses the C++ driver
+so that the host side of the timed region is compiled code, as it is in the reference."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+from .executor import DIM_WIDTHS, Binary, Col, Const, QueryPlan, Unary
+
+DRIVER_PATH = os.path.join(abi.LIB_DIR, "libaresdriver.so")
+
+(NODE_COLUMN, NODE_CONST_INT, NODE_CONST_FLOAT, NODE_UNARY, NODE_BINARY) = range(5)
+
+
+class PlanNode(C.Structure):
+    _fields_ = [("kind", C.c_int), ("op", C.c_int), ("lhs", C.c_int), ("rhs", C.c_int), ("table", C.c_int),
+                ("column", C.c_int), ("ival", C.c_int32), ("fval", C.c_float), ("outType", C.c_int)]
+
+
+class ForeignTableC(C.Structure):
+    _fields_ = [("joinColumn", C.c_int), ("index", abi.CuckooHashIndex), ("numColumns", C.c_int),
+                ("numBatches", C.c_int), ("slices", C.POINTER(abi.VectorPartySlice)), ("dataTypes", C.POINTER(C.c_int)),
+                ("baseBatchID", C.c_int32), ("numRecordsInLastBatch", C.c_int32)]
+
+
+class QueryPlanC(C.Structure):
+    _fields_ = [("nodes", C.POINTER(PlanNode)), ("numNodes", C.c_int),
+                ("filters", C.POINTER(C.c_int)), ("numFilters", C.c_int),
+                ("foreignFilters", C.POINTER(C.c_int)), ("numForeignFilters", C.c_int),
+                ("dimNodes", C.POINTER(C.c_int)), ("dimTypes", C.POINTER(C.c_int)), ("numDims", C.c_int),
+                ("measureNode", C.c_int), ("aggFunc", C.c_int), ("measureType", C.c_int),
+                ("useHashReduction", C.c_int),
+                ("foreignTables", C.POINTER(ForeignTableC)), ("numForeignTables", C.c_int)]
+
+
+_lib = None
+
+
+def _driver():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(DRIVER_PATH):
+            raise FileNotFoundError(f"{DRIVER_PATH} is missing — build it first "
+                                    f"(python -c 'import __graft_entry__ as g; g.build()')")
+        lib = C.CDLL(DRIVER_PATH, mode=os.RTLD_NOW | os.RTLD_LOCAL)
+        lib.AresDriverOpen.argtypes, lib.AresDriverOpen.restype = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int], C.c_void_p
+        lib.AresDriverClose.argtypes = [C.c_void_p]
+        lib.AresQueryCreate.argtypes = [C.c_void_p, C.POINTER(QueryPlanC), C.c_int, C.c_void_p, C.c_char_p, C.c_int]
+        lib.AresQueryCreate.restype = C.c_void_p
+        lib.AresQueryRunBatch.argtypes = [C.c_void_p, C.POINTER(abi.VectorPartySlice), C.c_int, C.c_int, C.c_void_p,
+                                          C.c_uint32, C.c_char_p, C.c_int]
+        lib.AresQueryRunBatch.restype = C.c_int
+        for name, res in (("AresQueryResultSize", C.c_int), ("AresQueryResultCapacity", C.c_int),
+                          ("AresQueryDimensionVector", C.c_void_p), ("AresQueryMeasureVector", C.c_void_p),
+                          ("AresQueryNumCalls", C.c_long)):
+            fn = getattr(lib, name)
+            fn.argtypes, fn.restype = [C.c_void_p], res
+        lib.AresQueryFetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
+        lib.AresQueryFetch.restype = C.c_int
+        lib.AresQueryDestroy.argtypes = [C.c_void_p]
+        _lib = lib
+    return _lib
+
+
+_handles = {}
+
+
+def _open(be: abi.Backend):
+    key = (be.algorithm_path, be.memory_path)
+    if key not in _handles:
+        err = C.create_string_buffer(512)
+        h = _driver().AresDriverOpen(be.algorithm_path.encode(), be.memory_path.encode(), err, 512)
+        if not h:
+            raise abi.AresError(err.value.decode())
+        _handles[key] = h
+    return _handles[key]
+
+
+class NativeQuery:
+    """One query on one device, executed by the C++ driver."""
+
+    def __init__(self, be: abi.Backend, plan: QueryPlan, column_names, device=0, stream=None,
+                 foreign_column_names=None):
+        self.be, self.plan, self.device, self.stream = be, plan, device, stream
+        self.column_names = list(column_names)
+        self.foreign_column_names = foreign_column_names or [sorted(ft.batches) for ft in plan.foreign_tables]
+        self._keep = []
+        nodes = []
+
+        def emit(e):
+            n = PlanNode()
+            if isinstance(e, Col):
+                n.kind, n.table = NODE_COLUMN, e.table
+                n.column = self.column_names.index(e.name) if e.table == 0 else \
+                    self.foreign_column_names[e.table - 1].index(e.name)
+            elif isinstance(e, Const):
+                if isinstance(e.value, float):
+                    n.kind, n.fval = NODE_CONST_FLOAT, e.value
+                else:
+                    n.kind, n.ival = NODE_CONST_INT, int(e.value)
+            elif isinstance(e, Unary):
+                n.kind, n.op, n.lhs, n.outType = NODE_UNARY, e.op, emit(e.arg), e.out_type
+            elif isinstance(e, Binary):
+                lhs = emit(e.lhs)
+                rhs = emit(e.rhs)
+                n.kind, n.op, n.lhs, n.rhs, n.outType = NODE_BINARY, e.op, lhs, rhs, e.out_type
+            else:
+                raise TypeError(f"unsupported expression node {e!r}")
+            nodes.append(n)
+            return len(nodes) - 1
+
+        filters = [emit(f) for f in plan.filters]
+        ffilters = [emit(f) for f in plan.foreign_filters]
+        dim_nodes = [emit(d.expr) for d in plan.dimensions]
+        measure = emit(plan.measure)
+
+        def arr(ctype, values):
+            a = (ctype * max(len(values), 1))(*values)
+            self._keep.append(a)
+            return a
+
+        fts = []
+        for ft, names in zip(plan.foreign_tables, self.foreign_column_names):
+            nb = len(ft.batches[names[0]])
+            slices = arr(abi.VectorPartySlice, [s for name in names for s in ft.batches[name]])
+            types = arr(C.c_int, [ft.data_types[name] for name in names])
+            f = ForeignTableC()
+            f.joinColumn = self.column_names.index(ft.join_column)
+            f.index = ft.index
+            f.numColumns, f.numBatches = len(names), nb
+            f.slices, f.dataTypes = slices, types
+            f.baseBatchID, f.numRecordsInLastBatch = ft.base_batch_id, ft.num_records_in_last_batch
+            fts.append(f)
+
+        pc = QueryPlanC()
+        pc.nodes, pc.numNodes = arr(PlanNode, nodes), len(nodes)
+        pc.filters, pc.numFilters = arr(C.c_int, filters), len(filters)
+        pc.foreignFilters, pc.numForeignFilters = arr(C.c_int, ffilters), len(ffilters)
+        pc.dimNodes, pc.numDims = arr(C.c_int, dim_nodes), len(dim_nodes)
+        pc.dimTypes = arr(C.c_int, [d.data_type for d in plan.dimensions])
+        pc.measureNode, pc.aggFunc, pc.measureType = measure, plan.agg, plan.measure_type
+        pc.useHashReduction = int(plan.use_hash_reduction)
+        pc.foreignTables, pc.numForeignTables = arr(ForeignTableC, fts), len(fts)
+        err = C.create_string_buffer(512)
+        self._q = _driver().AresQueryCreate(_open(be), C.byref(pc), device, stream, err, 512)
+        if not self._q:
+            raise abi.AresError(err.value.decode())
+        self._err = C.create_string_buffer(1024)
+
+    def run(self, columns, size, base_counts=None, start_row=0):
+        """columns: {name: VectorPartySlice} of the main table for this batch."""
+        cols = (abi.VectorPartySlice * len(self.column_names))(*[columns[n] for n in self.column_names])
+        rc = _driver().AresQueryRunBatch(self._q, cols, len(self.column_names), size, base_counts, start_row,
+                                         self._err, 1024)
+        if rc != 0:
+            raise abi.AresError(self._err.value.decode().strip())
+
+    @property
+    def result_size(self):
+        return _driver().AresQueryResultSize(self._q)
+
+    @property
+    def result_capacity(self):
+        return _driver().AresQueryResultCapacity(self._q)
+
+    @property
+    def dim_vector(self):
+        return _driver().AresQueryDimensionVector(self._q)
+
+    @property
+    def measure_vector(self):
+        return _driver().AresQueryMeasureVector(self._q)
+
+    @property
+    def calls(self):
+        return _driver().AresQueryNumCalls(self._q)
+
+    # -- the attributes shard_merge.merge_shard_results reads from a batch context --------------------
+    @property
+    def ndw(self):
+        return self.plan.num_dims_per_width()
+
+    @property
+    def dim_index(self):
+        return self.plan.dim_vector_index()
+
+    @property
+    def dim_vec(self):
+        return [self.dim_vector, 0]
+
+    @property
+    def measure_vec(self):
+        return [self.measure_vector, 0]
+
+    def call(self, sym, *args):
+        return self.be.call(sym, *args)
+
+    def fetch(self):
+        """(dims, valids, measures) in query dimension order, like executor.fetch_results."""
+        plan, n = self.plan, self.result_size
+        widths = sorted([d.width for d in plan.dimensions], reverse=True)
+        dims_blob = np.empty(max(n * (sum(widths) + len(widths)), 1), np.uint8)
+        meas = np.empty(max(n * plan.measure_bytes, 1), np.uint8)
+        rc = _driver().AresQueryFetch(self._q, dims_blob.ctypes.data_as(C.c_void_p), meas.ctypes.data_as(C.c_void_p),
+                                      self._err, 1024)
+        if rc != 0:
+            raise abi.AresError(self._err.value.decode().strip())
+        order = plan.dim_vector_index()
+        starts = np.concatenate([[0], np.cumsum([w * n for w in widths])])
+        null_base = int(starts[-1])
+        dims, valids = [], []
+        for q in range(len(plan.dimensions)):
+            d = order[q]
+            dims.append(dims_blob[starts[d]:starts[d] + widths[d] * n].copy())
+            valids.append(dims_blob[null_base + d * n: null_base + (d + 1) * n].copy())
+        return dims, valids, meas[:n * plan.measure_bytes].copy()
+
+    def release(self):
+        if self._q:
+            _driver().AresQueryDestroy(self._q)
+            self._q = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:  # noqa: BLE001
+            pass

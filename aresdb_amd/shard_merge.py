@@ -21,7 +21,7 @@ import torch
 import torch.distributed as dist
 
 from . import abi
-from .executor import DIM_WIDTHS, BatchContext, dimension_start_offsets
+from .executor import DIM_WIDTHS, dimension_start_offsets
 
 
 class MergedResult:
@@ -34,7 +34,7 @@ def _d2d(ctx, dst, src, nbytes):
         ctx.be.call("AsyncCopyDeviceToDevice", dst, src, nbytes, ctx.stream, ctx.device)
 
 
-def merge_shard_results(ctx: BatchContext, tensor_device, group: Optional[dist.ProcessGroup] = None) -> MergedResult:
+def merge_shard_results(ctx, tensor_device, group: Optional[dist.ProcessGroup] = None) -> MergedResult:
     """Merges the result of `ctx` (dim_vec[0] / measure_vec[0] / result_size) across all ranks of
     `group`; every rank returns the full merged table.  `tensor_device` is where the staging
     tensors live: the rank's GPU for the HIP backend, "cpu" for a host-memory backend."""
@@ -113,7 +113,7 @@ def merge_shard_results(ctx: BatchContext, tensor_device, group: Optional[dist.P
     return MergedResult(out_dims, out_meas, n, cap)
 
 
-def merged_to_dict(ctx: BatchContext, res: MergedResult):
+def merged_to_dict(ctx, res: MergedResult):
     """{((value bytes, validity), ...) -> measure} of a merged result, on the host (tests)."""
     import numpy as np
     widths = [w for w, c in zip(DIM_WIDTHS, ctx.ndw) for _ in range(c)]

@@ -43,6 +43,29 @@ def run_query(be, plan, batches):
     return out, calls
 
 
+def run_query_native(be, plan, batches):
+    """The same query through the C++ host driver (libaresdriver.so) instead of the Python mirror."""
+    from .driver import NativeQuery
+    names = list(batches[0][0].keys())
+    q = NativeQuery(be, plan, names)
+    for cols, valid in batches:
+        dev = {k: DeviceColumn(be, t, v, valid=valid[k]) for k, (t, v) in cols.items()}
+        n = len(next(iter(cols.values()))[1])
+        q.run({k: d.vp for k, d in dev.items()}, n)
+        for d in dev.values():
+            d.free()
+    dims, valids, meas = q.fetch()
+    calls = q.calls
+    n = q.result_size
+    q.release()
+    out = {}
+    m = meas.view(np.float64) if plan.measure_type == abi.Float64 else meas.view(np.uint32)
+    for r in range(n):
+        key = tuple((bytes(d[r * len(d) // n:(r + 1) * len(d) // n]), int(v[r])) for d, v in zip(dims, valids))
+        out[key] = m[r]
+    return out, calls
+
+
 def compare_results(got, want, rel=1e-6):
     assert got.keys() == want.keys(), f"group keys differ: {len(got)} vs {len(want)}"
     for k, v in want.items():

@@ -24,8 +24,11 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 from aresdb_amd import abi, workload  # noqa: E402
-from aresdb_amd.executor import BatchContext, BatchExecutor  # noqa: E402
+from aresdb_amd.driver import NativeQuery  # noqa: E402
 from aresdb_amd.queries import c3_plan  # noqa: E402
+from aresdb_amd.workload import C3_COLUMNS  # noqa: E402
+
+COLUMN_NAMES = [name for name, _ in C3_COLUMNS]
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable with a float4 copy)
 
@@ -33,10 +36,9 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable 
 def run_shard(be, plan, batches, device, stream):
     """ProcessQuery for one shard (query/aql_processor.go:49-161): every batch through
     preExec/filter/join/project/reduce/postExec; results accumulate on the device."""
-    ctx = BatchContext(be, plan, device=device, stream=stream)
-    ex = BatchExecutor(ctx)
+    ctx = NativeQuery(be, plan, COLUMN_NAMES, device=device, stream=stream)  # the C++ host driver
     for b in batches:
-        ex.run({k: rc.vp for k, rc in b.items()}, next(iter(b.values())).length)
+        ctx.run({k: rc.vp for k, rc in b.items()}, next(iter(b.values())).length)
     return ctx
 
 
@@ -60,7 +62,7 @@ def expected_total(batches):
 def result_total(ctx, dims_ptr=None):
     n = ctx.result_size
     out = torch.empty(max(n, 1), dtype=torch.float64, device=f"cuda:{ctx.device}")
-    ctx.be.call("AsyncCopyDeviceToDevice", out.data_ptr(), ctx.measure_vec[0], n * 8, ctx.stream, ctx.device)
+    ctx.be.call("AsyncCopyDeviceToDevice", out.data_ptr(), ctx.measure_vector, n * 8, ctx.stream, ctx.device)
     ctx.be.wait(ctx.stream, ctx.device)
     return float(out[:n].sum())
 
@@ -85,15 +87,14 @@ def cpu_baseline(batch, plan_factory, budget_s=15.0):
     cols, valid = workload.batch_to_host(batch, limit=32 * chunk)
     total_rows = len(next(iter(cols.values()))[1])
     plan = plan_factory(use_hash_reduction=False)
-    ctx = BatchContext(be, plan)
-    ex = BatchExecutor(ctx)
+    ctx = NativeQuery(be, plan, COLUMN_NAMES)
     spent, rows, nb = 0.0, 0, 0
     for start in range(0, total_rows, chunk):
         n = min(chunk, total_rows - start)
         dev = {k: DeviceColumn(be, t, v[start:start + n], valid=None if valid[k] is None else valid[k][start:start + n])
                for k, (t, v) in cols.items()}
         t0 = time.perf_counter()
-        ex.run({k: d.vp for k, d in dev.items()}, n)
+        ctx.run({k: d.vp for k, d in dev.items()}, n)
         spent += time.perf_counter() - t0
         for d in dev.values():
             d.free()

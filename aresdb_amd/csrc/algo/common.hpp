@@ -54,6 +54,14 @@ class StreamBuffer {
  public:
   StreamBuffer(size_t bytes, hipStream_t stream) : stream_(stream) {
     if (bytes == 0) bytes = 16;
+    // Request sizes in 1/8-octave steps: workspaces whose size creeps up from batch to batch (the
+    // accumulated result grows) would otherwise never fit a cached block and fall through to the
+    // driver every time (~100 ms for a multi-GB mapping).
+    if (bytes > (1u << 20)) {
+      const int top = 63 - __builtin_clzll(static_cast<unsigned long long>(bytes));
+      const size_t step = static_cast<size_t>(1) << (top - 3);
+      bytes = (bytes + step - 1) / step * step;
+    }
     hip_check(hipMallocAsync(&ptr_, bytes, stream), "hipMallocAsync");
   }
   ~StreamBuffer() {

@@ -25,7 +25,9 @@
 #include "aggregate.hpp"
 #include "common.hpp"
 #include "device_model.hpp"
+#include "ares_extensions.h"
 #include "dim_layout.hpp"
+#include "fast_eval.hpp"
 #include "hash_reduce_lds.hpp"
 
 namespace ares {
@@ -289,11 +291,38 @@ constexpr int kQuadTile = kThreads * 4;                   // rows per tile of th
 constexpr int kQuadFlushAt = kSlots * 3 / 4 - kQuadTile;  // = 2048
 constexpr int kStage = kQuadTile;                         // records staged per DIRECT tile
 
-template <int ND, int VW>
-__global__ __launch_bounds__(kThreads) void hr_partition4_kernel(const uint8_t *dimValues, size_t capacity,
-                                                                 const uint8_t *inputValues, AggSpec a, int length,
-                                                                 Workspace ws) {
-  // TABLE mode: sKeys / sVals are the hash table.  DIRECT mode: the same 128 KiB stage 4096..8192
+// Row source "dimension vector": the ABI's HashReduce input (values per dimension, validity bytes,
+// measures), already projected by the transform calls.
+template <int ND_, int VW>
+struct DimVectorSource {
+  static constexpr int ND = ND_;
+  using Raw = QuadRows<ND_>;
+  const uint8_t *dimValues;
+  size_t capacity;
+  const uint8_t *inputValues;
+  uint32_t rowBase;
+  __device__ __forceinline__ void prepare() {}
+  __device__ __forceinline__ void load(Raw &r, int64_t i0, int length) const {
+    load_quad<ND_, VW>(r, dimValues, capacity, inputValues, i0, length);
+  }
+  // hash + measure bits of the quad's four rows; returns which of them take part (4-bit mask)
+  __device__ __forceinline__ uint32_t rows(const Raw &r, int64_t i0, int length, uint32_t (&h)[4], uint64_t (&v)[4]) const {
+    uint32_t alive = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      alive |= (i0 + j < length ? 1u : 0u) << j;
+      h[j] = hash_quad_row<ND_>(r, j);
+      v[j] = r.val[j];
+    }
+    return alive;
+  }
+};
+
+// The partition kernel body, shared by the ABI path (DimVectorSource) and the fused scan
+// (FusedSource: filter + projection evaluated on the fly from the source columns).
+template <typename Source>
+__device__ __forceinline__ void partition_body(Source &src, const AggSpec &a, int length, const Workspace &ws) {
+  // TABLE mode: sKeys / sVals are the hash table.  DIRECT mode: the same 128 KiB stage up to 4096
   // sorted records (sKeys[k] = {row, hash}, sVals[k] = value).
   __shared__ uint64_t sKeys[kSlots];
   __shared__ uint64_t sVals[kSlots];
@@ -301,7 +330,7 @@ __global__ __launch_bounds__(kThreads) void hr_partition4_kernel(const uint8_t *
   __shared__ uint32_t sPartBase[kMaxPartitions];   // global base of the partition's run
   __shared__ uint32_t sPartLocal[kMaxPartitions];  // DIRECT: first staged index of the partition
   __shared__ uint32_t sWaveSum[kThreads / 64];
-  __shared__ uint32_t sClaims;
+  __shared__ uint32_t sClaims, sStaged;
   const int numParts = 1 << ws.partBits;
   const int pb = ws.partBits;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -309,28 +338,29 @@ __global__ __launch_bounds__(kThreads) void hr_partition4_kernel(const uint8_t *
   for (int p = threadIdx.x; p < numParts; p += kThreads) sPartCount[p] = 0;
   if (threadIdx.x == 0) sClaims = 0;
   __syncthreads();
+  src.prepare();
 
   const int64_t numTiles = (static_cast<int64_t>(length) + kQuadTile - 1) / kQuadTile;
   bool direct = false;
   uint32_t rowsSinceFlush = 0;
-  QuadRows<ND> bufA, bufB;
+  typename Source::Raw buf;
   int64_t tile = blockIdx.x;
-  if (tile < numTiles) load_quad<ND, VW>(bufA, dimValues, capacity, inputValues, tile * kQuadTile + 4 * threadIdx.x, length);
+  if (tile < numTiles) src.load(buf, tile * kQuadTile + 4 * threadIdx.x, length);
 
-  // processes one tile held in registers; returns false when the workgroup is done
-  auto step = [&](QuadRows<ND> &q, int64_t t) -> bool {
+  // processes one tile (hash + measure bits of the lane's four rows); returns false when the
+  // workgroup is done
+  auto step = [&](const uint32_t (&h)[4], const uint64_t (&v)[4], const uint32_t alive, int64_t t) -> bool {
     const bool more = t < numTiles;
     const int64_t i0 = t * kQuadTile + 4 * static_cast<int64_t>(threadIdx.x);
     if (more && !direct) {
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        if (i0 + j < length) {
-          const uint32_t h = hash_quad_row<ND>(q, j);
+        if ((alive >> j) & 1u) {
           if (ws.debug & 1) {
-            if (h == 0x12345678u && q.val[j] == 0x9abcdef012345678ull) sClaims = 1;
+            if (h[j] == 0x12345678u && v[j] == 0x9abcdef012345678ull) sClaims = 1;
           } else {
-            const int slot = lds_find_or_claim(sKeys, h, static_cast<uint32_t>(i0 + j), &sClaims);
-            lds_aggregate(sVals + slot, q.val[j], a);
+            const int slot = lds_find_or_claim(sKeys, h[j], src.rowBase + static_cast<uint32_t>(i0 + j), &sClaims);
+            lds_aggregate(sVals + slot, v[j], a);
           }
         }
       }
@@ -393,12 +423,11 @@ __global__ __launch_bounds__(kThreads) void hr_partition4_kernel(const uint8_t *
     }
     // ---- DIRECT: rows -> records, counting-sorted by partition in LDS, coalesced write-back ----
     if (!more) return false;
-    uint32_t h[4], rank[4];
+    uint32_t rank[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      h[j] = hash_quad_row<ND>(q, j);
       rank[j] = 0;
-      if (i0 + j < length) {
+      if ((alive >> j) & 1u) {
         const uint32_t p = pb ? h[j] >> (32 - pb) : 0u;
         rank[j] = __hip_atomic_fetch_add(&sPartCount[p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
@@ -420,22 +449,22 @@ __global__ __launch_bounds__(kThreads) void hr_partition4_kernel(const uint8_t *
         sPartLocal[threadIdx.x] = before + incl - c;
         if (c) sPartBase[threadIdx.x] = atomicAdd(ws.cursors + threadIdx.x, c);
         sPartCount[threadIdx.x] = 0;
+        if (threadIdx.x == static_cast<uint32_t>(numParts) - 1) sStaged = before + incl;
       }
     }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      if (i0 + j < length) {
+      if ((alive >> j) & 1u) {
         const uint32_t p = pb ? h[j] >> (32 - pb) : 0u;
         const uint32_t at = sPartLocal[p] + rank[j];
-        sKeys[at] = (static_cast<uint64_t>(h[j]) << 32) | static_cast<uint32_t>(i0 + j);
-        sVals[at] = q.val[j];
+        sKeys[at] = (static_cast<uint64_t>(h[j]) << 32) | (src.rowBase + static_cast<uint32_t>(i0 + j));
+        sVals[at] = v[j];
       }
     }
     __syncthreads();
     {
-      const int64_t remaining = static_cast<int64_t>(length) - t * kQuadTile;
-      const uint32_t staged = remaining < kQuadTile ? static_cast<uint32_t>(remaining) : static_cast<uint32_t>(kQuadTile);
+      const uint32_t staged = sStaged;
       for (uint32_t k = threadIdx.x; k < staged; k += kThreads) {
         const uint64_t key = sKeys[k];
         const uint64_t v = sVals[k];
@@ -455,21 +484,231 @@ __global__ __launch_bounds__(kThreads) void hr_partition4_kernel(const uint8_t *
     return true;
   };
 
+  // One register buffer is enough to overlap HBM latency with the LDS work: the tile's rows are
+  // reduced to (hash, measure) pairs first, then the NEXT tile's loads are issued into the same
+  // registers before the current tile goes through the table / the partition sort.
   for (;;) {
-    const int64_t tileB = tile + gridDim.x;
-    if (tileB < numTiles) load_quad<ND, VW>(bufB, dimValues, capacity, inputValues, tileB * kQuadTile + 4 * threadIdx.x, length);
-    if (!step(bufA, tile)) break;
-    const int64_t tileA = tileB + gridDim.x;
-    if (tileA < numTiles) load_quad<ND, VW>(bufA, dimValues, capacity, inputValues, tileA * kQuadTile + 4 * threadIdx.x, length);
-    if (!step(bufB, tileB)) break;
-    tile = tileA;
+    uint32_t h[4];
+    uint64_t v[4];
+    const uint32_t alive = src.rows(buf, tile * kQuadTile + 4 * static_cast<int64_t>(threadIdx.x), length, h, v);  // 0 past the end
+    const int64_t next = tile + gridDim.x;
+    if (next < numTiles) src.load(buf, next * kQuadTile + 4 * threadIdx.x, length);
+    if (!step(h, v, alive, tile)) break;
+    tile = next;
+  }
+}
+
+template <int ND, int VW>
+__global__ __launch_bounds__(kThreads) void hr_partition4_kernel(const uint8_t *dimValues, size_t capacity,
+                                                                 const uint8_t *inputValues, AggSpec a, int length,
+                                                                 Workspace ws) {
+  DimVectorSource<ND, VW> src{dimValues, capacity, inputValues, 0u};
+  partition_body(src, a, length, ws);
+}
+
+
+// ---- row source "fused scan": filter + projection evaluated from the source columns -------------
+// (extension entry point AresFusedFilterHashReduce, include/ares_extensions.h).  The batch's columns
+// are read once, 16 bytes per lane; the conjunction of comparison filters decides which rows take
+// part; dimensions and the measure are evaluated with the very functions the transform kernels use
+// (fast_eval.hpp), so the (value, validity) pairs that are hashed are bit-identical to what the
+// UnaryTransform / BinaryTransform calls would have stored in the dimension vector.
+constexpr int kFusedCols = 6, kFusedFilters = 4, kFusedDims = 4;
+struct FusedColumn {
+  const uint32_t *vals;
+  const uint8_t *nulls;
+  uint32_t bitOff;
+};
+struct FusedExpr {
+  FastOperands f;  // akind / arity / functor / I / rk / constant / divLike (pointers unused)
+  int col;
+  int outKind;     // kind of the stored dimension value
+};
+struct FusedPlanD {
+  int numCols;
+  FusedColumn cols[kFusedCols];
+  int numFilters;
+  FusedExpr filters[kFusedFilters];
+  FusedExpr dims[kFusedDims];
+  FusedExpr measure;
+  int measureDtype, measureWidth;
+  uint64_t identity;  // measure-transform identity of the aggregate (query/utils.hpp:169-184)
+};
+
+struct FusedConst {
+  DVal y;
+  FastDivisor fd;
+};
+__device__ __forceinline__ FusedConst fused_const(const FastOperands &f) {
+  FusedConst c;
+  c.y.bits = f.bbits;
+  c.y.ok = f.bok;
+  c.y = cvt32(c.y, f.bkind, f.I);
+  const uint32_t mag = (f.I == K_I32 && static_cast<int32_t>(c.y.bits) < 0) ? 0u - c.y.bits : c.y.bits;
+  c.fd = make_fast_divisor(mag);
+  return c;
+}
+
+// measure bits of an evaluated value (MeasureProxy, query/iterator.hpp:616-647, no run lengths)
+__device__ __forceinline__ uint64_t fused_measure_bits(const FusedPlanD &p, DVal r) {
+  const int rk = p.measure.f.rk;
+  if (!r.ok) return p.identity;
+  if (p.measureWidth == 8) {
+    if (p.measureDtype == Float64) return static_cast<uint64_t>(__double_as_longlong(to_double32(r, rk)));
+    return static_cast<uint64_t>(rk == K_F32 ? static_cast<int64_t>(bits_f(r.bits))
+                                 : rk == K_I32 ? static_cast<int64_t>(static_cast<int32_t>(r.bits))
+                                               : static_cast<int64_t>(r.bits));
+  }
+  return cvt32(r, rk, p.measureDtype == Int32 ? K_I32 : p.measureDtype == Uint32 ? K_U32 : K_F32).bits;
+}
+
+template <int ND_>
+struct FusedSource {
+  static constexpr int ND = ND_;
+  static constexpr int NC = ND_ + 2;  // distinct columns a plan of ND dimensions may touch
+  struct Raw {
+    uint32_t v[NC][4];
+    uint32_t win[NC];  // 16-bit validity window starting at the byte of the quad's first row
+  };
+  const FusedPlanD &plan;
+  uint32_t rowBase;
+  FusedConst fc[kFusedFilters], dc[ND_], mc;
+
+  __device__ __forceinline__ FusedSource(const FusedPlanD &p, uint32_t base) : plan(p), rowBase(base) {}
+  __device__ __forceinline__ void prepare() {
+#pragma unroll
+    for (int k = 0; k < kFusedFilters; k++)
+      if (k < plan.numFilters) fc[k] = fused_const(plan.filters[k].f);
+#pragma unroll
+    for (int d = 0; d < ND_; d++) dc[d] = fused_const(plan.dims[d].f);
+    mc = fused_const(plan.measure.f);
+  }
+  __device__ __forceinline__ void load(Raw &r, int64_t i0, int length) const {
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+      if (c >= plan.numCols) continue;
+      const FusedColumn col = plan.cols[c];
+      if (i0 + 3 < length) {
+        const PU32x4 v = *reinterpret_cast<const PU32x4 *>(col.vals + i0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) r.v[c][j] = v.v[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) r.v[c][j] = i0 + j < length ? col.vals[i0 + j] : 0u;
+      }
+      r.win[c] = 0xFFFFu;
+      if (col.nulls && i0 < length)
+        r.win[c] = reinterpret_cast<const PU16 *>(col.nulls + ((static_cast<uint32_t>(i0) + col.bitOff) >> 3))->v;
+    }
+  }
+  __device__ __forceinline__ uint32_t rows(const Raw &r, int64_t i0, int length, uint32_t (&h)[4], uint64_t (&v)[4]) const {
+    uint32_t ok[NC];  // validity nibble of the quad per column
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+      ok[c] = 0xFu;
+      if (c < plan.numCols) ok[c] = (r.win[c] >> ((static_cast<uint32_t>(i0) + plan.cols[c].bitOff) & 7u)) & 0xFu;
+    }
+    uint32_t alive = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      bool keep = i0 + j < length;
+#pragma unroll
+      for (int k = 0; k < kFusedFilters; k++) {
+        if (k < plan.numFilters) {
+          const FusedExpr &e = plan.filters[k];
+          uint32_t bits = 0, okb = 0;
+#pragma unroll
+          for (int c = 0; c < NC; c++)
+            if (c == e.col) { bits = r.v[c][j]; okb = (ok[c] >> j) & 1u; }
+          keep = keep && compare_fast(e.f, bits, okb, fc[k].y) != 0;
+        }
+      }
+      alive |= (keep ? 1u : 0u) << j;
+      // dimension d reads column slot d, the measure slot ND (fixed by the host), so only the
+      // filters select their operand at run time
+      Murmur32Stream ms(0);
+      uint32_t validBytes = 0;
+#pragma unroll
+      for (int d = 0; d < ND_; d++) {
+        const FusedExpr &e = plan.dims[d];
+        const DVal x = eval_fast(e.f, r.v[d][j], (ok[d] >> j) & 1u, dc[d].y, dc[d].fd);
+        ms.push(cvt32(x, e.f.rk, e.outKind).bits, 4);
+        validBytes |= (x.ok ? 1u : 0u) << d;
+      }
+#pragma unroll
+      for (int d = 0; d < ND_; d++) ms.push((validBytes >> d) & 1u, 1);
+      h[j] = ms.finish();
+      v[j] = fused_measure_bits(plan, eval_fast(plan.measure.f, r.v[ND_][j], (ok[ND_] >> j) & 1u, mc.y, mc.fd));
+    }
+    return alive;
+  }
+};
+
+template <int ND>
+__global__ __launch_bounds__(kThreads) void hr_fused_scan_kernel(FusedPlanD plan, uint32_t rowBase, AggSpec a, int length,
+                                                                 Workspace ws) {
+  FusedSource<ND> src(plan, rowBase);
+  partition_body(src, a, length, ws);
+}
+
+// dimension values + validity of ONE source row (group representative), for the merge's emission
+template <int ND>
+__device__ __forceinline__ void fused_eval_row(const FusedPlanD &plan, uint32_t row, uint32_t (&bits)[ND], uint32_t (&ok)[ND]) {
+#pragma unroll
+  for (int d = 0; d < ND; d++) {
+    const FusedExpr &e = plan.dims[d];
+    const FusedColumn col = plan.cols[e.col];
+    const FusedConst c = fused_const(e.f);
+    const uint32_t raw = col.vals[row];
+    const uint32_t rok = col.nulls ? get_bit(col.nulls, row + col.bitOff) : 1u;
+    const DVal x = eval_fast(e.f, raw, rok, c.y, c.fd);
+    bits[d] = cvt32(x, e.f.rk, e.outKind).bits;
+    ok[d] = x.ok ? 1u : 0u;
   }
 }
 
 // ---- kernel 2: per-partition merge in LDS, emit groups ---------------------------------------------
-__global__ __launch_bounds__(kThreads) void hr_merge_kernel(const uint8_t *dimIn, uint8_t *dimOut, DimLayoutD L,
-                                                            size_t capacity, uint8_t *outputValues, AggSpec a,
-                                                            Workspace ws) {
+// One record into the round's table; claims a slot only while the round's attempt budget lasts.
+__device__ __forceinline__ void merge_record(uint64_t *sKeys, uint64_t *sVals, uint32_t *sAttempts, uint32_t *sOverflow,
+                                             const uint4 r, const AggSpec &a) {
+  const uint32_t h = r.y;
+  const uint64_t mine = (static_cast<uint64_t>(h) << 32) | r.x;
+  int slot = static_cast<int>(h) & kSlotMask;
+  for (;;) {
+    uint64_t cur = sKeys[slot];
+    if (cur == kEmpty) {
+      if (__hip_atomic_fetch_add(sAttempts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >=
+          static_cast<uint32_t>(kMergeLimit)) {
+        *sOverflow = 1u;
+        return;
+      }
+      unsigned long long expected = kEmpty;
+      if (__hip_atomic_compare_exchange_strong(reinterpret_cast<unsigned long long *>(sKeys + slot), &expected,
+                                               static_cast<unsigned long long>(mine), __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP))
+        break;
+      cur = expected;
+    }
+    if (static_cast<uint32_t>(cur >> 32) == h) {
+      if (mine < cur)
+        __hip_atomic_fetch_min(reinterpret_cast<unsigned long long *>(sKeys + slot), static_cast<unsigned long long>(mine),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      break;
+    }
+    slot = (slot + 1) & kSlotMask;
+  }
+  lds_aggregate(sVals + slot, (static_cast<uint64_t>(r.w) << 32) | r.z, a);
+}
+
+constexpr int kMergeBatch = 4;  // records per lane per pipeline stage
+
+// ND4 = number of dimensions when all are 4 bytes wide (vectorisable emission), 0 = any layout
+// FUSED: rows >= prevSize are source rows of the fused scan — their dimensions are re-evaluated
+// from the columns; rows < prevSize are previous results in dimIn (stride prevCapacity).
+template <int ND4, bool FUSED>
+__device__ __forceinline__ void merge_body(const uint8_t *__restrict__ dimIn, size_t inCapacity, uint8_t *__restrict__ dimOut,
+                                           const DimLayoutD &L, size_t capacity, uint8_t *__restrict__ outputValues,
+                                           const AggSpec &a, const Workspace &ws, const FusedPlanD *plan, uint32_t prevSize) {
   __shared__ uint64_t sKeys[kSlots];
   __shared__ uint64_t sVals[kSlots];
   __shared__ uint32_t sAttempts, sOverflow, sCount, sBase, sClaims;
@@ -477,7 +716,7 @@ __global__ __launch_bounds__(kThreads) void hr_merge_kernel(const uint8_t *dimIn
   const uint32_t cursor = ws.cursors[p];
   const uint64_t n = cursor < ws.cap ? cursor : ws.cap;
   if (n == 0) return;
-  const uint4 *rec = ws.records + static_cast<uint64_t>(p) * ws.cap;
+  const uint4 *__restrict__ rec = ws.records + static_cast<uint64_t>(p) * ws.cap;
   // sub-range of the hash bits below the partition bits, left-aligned to 32 bits
   const int pb = ws.partBits;
   uint64_t lo = 0, width = 1ull << 32;
@@ -485,20 +724,23 @@ __global__ __launch_bounds__(kThreads) void hr_merge_kernel(const uint8_t *dimIn
     uint64_t parts = 1;
     while (parts * 16ull * kMergeLimit < n && width > 1) { parts <<= 1; width >>= 1; }
   }
+  const uint64_t stride = static_cast<uint64_t>(kMergeBatch) * kThreads;
   while (lo < (1ull << 32)) {
     clear_table(sKeys, sVals, a.identity);
     if (threadIdx.x == 0) { sAttempts = 0; sOverflow = 0; sCount = 0; sClaims = 0; }
     __syncthreads();
     const uint64_t hi = lo + width;
-    // kMergeBatch independent 16-byte loads per lane are in flight before any of them is used
-    constexpr int kMergeBatch = 8;
-    for (uint64_t base = 0; base < n; base += static_cast<uint64_t>(kMergeBatch) * kThreads) {
-      uint4 r[kMergeBatch];
+    // two register stages: the loads of the next kMergeBatch records per lane are in flight while
+    // the current ones go through the LDS table
+    uint4 ra[kMergeBatch], rb[kMergeBatch];
+    auto load = [&](uint4 (&r)[kMergeBatch], uint64_t base) {
 #pragma unroll
       for (int k = 0; k < kMergeBatch; k++) {
         const uint64_t i = base + static_cast<uint64_t>(k) * kThreads + threadIdx.x;
         r[k] = i < n ? rec[i] : make_uint4(0, 0, 0, 0);
       }
+    };
+    auto consume = [&](const uint4 (&r)[kMergeBatch], uint64_t base) {
 #pragma unroll
       for (int k = 0; k < kMergeBatch; k++) {
         const uint64_t i = base + static_cast<uint64_t>(k) * kThreads + threadIdx.x;
@@ -509,39 +751,15 @@ __global__ __launch_bounds__(kThreads) void hr_merge_kernel(const uint8_t *dimIn
           if (h == 0x12345678u && r[k].z == 0x9abcdefu) sOverflow = 1u;
           continue;
         }
-        // find the group; claim a slot only while the round's attempt budget lasts
-        const uint64_t mine = (static_cast<uint64_t>(h) << 32) | r[k].x;
-        int slot = static_cast<int>(h) & kSlotMask;
-        bool placed = false;
-        for (;;) {
-          uint64_t cur = sKeys[slot];
-          if (cur == kEmpty) {
-            if (__hip_atomic_fetch_add(&sAttempts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >=
-                static_cast<uint32_t>(kMergeLimit)) {
-              sOverflow = 1u;
-              break;
-            }
-            unsigned long long expected = kEmpty;
-            if (__hip_atomic_compare_exchange_strong(reinterpret_cast<unsigned long long *>(sKeys + slot), &expected,
-                                                     static_cast<unsigned long long>(mine), __ATOMIC_RELAXED,
-                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-              placed = true;
-              break;
-            }
-            cur = expected;
-          }
-          if (static_cast<uint32_t>(cur >> 32) == h) {
-            if (mine < cur)
-              __hip_atomic_fetch_min(reinterpret_cast<unsigned long long *>(sKeys + slot),
-                                     static_cast<unsigned long long>(mine), __ATOMIC_RELAXED,
-                                     __HIP_MEMORY_SCOPE_WORKGROUP);
-            placed = true;
-            break;
-          }
-          slot = (slot + 1) & kSlotMask;
-        }
-        if (placed) lds_aggregate(sVals + slot, (static_cast<uint64_t>(r[k].w) << 32) | r[k].z, a);
+        merge_record(sKeys, sVals, &sAttempts, &sOverflow, r[k], a);
       }
+    };
+    load(ra, 0);
+    for (uint64_t base = 0; base < n; base += 2 * stride) {
+      if (base + stride < n) load(rb, base + stride);
+      consume(ra, base);
+      if (base + 2 * stride < n) load(ra, base + 2 * stride);
+      if (base + stride < n) consume(rb, base + stride);
     }
     __syncthreads();
     const bool overflowed = sOverflow != 0;
@@ -563,23 +781,65 @@ __global__ __launch_bounds__(kThreads) void hr_merge_kernel(const uint8_t *dimIn
     if (total && !(ws.debug & 16)) {
       // one output range per wavefront per sweep: consecutive lanes write consecutive rows
       const int lane = threadIdx.x & 63;
+      uint32_t at[kPerLane], row[kPerLane];
+      bool has[kPerLane];
 #pragma unroll
       for (int k = 0; k < kPerLane; k++) {
-        const int s = threadIdx.x + k * kThreads;
-        const uint64_t key = sKeys[s];
-        const uint64_t m = __ballot(key != kEmpty);
-        if (m == 0) continue;
+        const uint64_t key = sKeys[threadIdx.x + k * kThreads];
+        has[k] = key != kEmpty;
+        row[k] = static_cast<uint32_t>(key);
+        const uint64_t m = __ballot(has[k]);
         uint32_t waveBase = 0;
-        if (lane == 0)
+        if (lane == 0 && m)
           waveBase = __hip_atomic_fetch_add(&sClaims, static_cast<uint32_t>(__popcll(m)), __ATOMIC_RELAXED,
                                             __HIP_MEMORY_SCOPE_WORKGROUP);
         waveBase = __builtin_amdgcn_readfirstlane(waveBase);
-        if (key == kEmpty) continue;
-        const uint32_t at = sBase + waveBase +
-                            __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
-                                                      __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
-        copy_dim_row(dimIn, capacity, dimOut, capacity, L, static_cast<uint32_t>(key), at);
-        store_value_bits(outputValues, a, at, sVals[s]);
+        at[k] = sBase + waveBase +
+                __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+      }
+      if (ND4 > 0) {
+        // all gathers of the lane's groups are issued before the first store
+        const uint8_t *nullsIn = dimIn + static_cast<size_t>(4 * ND4) * inCapacity;
+        uint8_t *nullsOut = dimOut + static_cast<size_t>(4 * ND4) * capacity;
+        // (in two halves: 4 groups x ND4 gathers per lane in flight keeps the kernel inside 128 VGPRs)
+        constexpr int kHalf = kPerLane / 2;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+          uint32_t dv[kHalf][ND4 > 0 ? ND4 : 1];
+          uint32_t nv[kHalf][ND4 > 0 ? ND4 : 1];
+#pragma unroll
+          for (int kk = 0; kk < kHalf; kk++) {
+            const int k = half * kHalf + kk;
+            if (!has[k]) continue;
+            if (FUSED && row[k] >= prevSize) {
+              fused_eval_row<(ND4 > 0 ? ND4 : 1)>(*plan, row[k] - prevSize, dv[kk], nv[kk]);
+              continue;
+            }
+#pragma unroll
+            for (int d = 0; d < ND4; d++) {
+              dv[kk][d] = *reinterpret_cast<const uint32_t *>(dimIn + static_cast<size_t>(4 * d) * inCapacity + 4ull * row[k]);
+              nv[kk][d] = nullsIn[static_cast<size_t>(d) * inCapacity + row[k]];
+            }
+          }
+#pragma unroll
+          for (int kk = 0; kk < kHalf; kk++) {
+            const int k = half * kHalf + kk;
+            if (!has[k]) continue;
+#pragma unroll
+            for (int d = 0; d < ND4; d++) {
+              *reinterpret_cast<uint32_t *>(dimOut + static_cast<size_t>(4 * d) * capacity + 4ull * at[k]) = dv[kk][d];
+              nullsOut[static_cast<size_t>(d) * capacity + at[k]] = static_cast<uint8_t>(nv[kk][d]);
+            }
+            store_value_bits(outputValues, a, at[k], sVals[threadIdx.x + k * kThreads]);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < kPerLane; k++) {
+          if (!has[k]) continue;
+          copy_dim_row(dimIn, inCapacity, dimOut, capacity, L, row[k], at[k]);
+          store_value_bits(outputValues, a, at[k], sVals[threadIdx.x + k * kThreads]);
+        }
       }
     }
     __syncthreads();
@@ -587,6 +847,23 @@ __global__ __launch_bounds__(kThreads) void hr_merge_kernel(const uint8_t *dimIn
     if (total < static_cast<uint32_t>(kMergeLimit / 4) && width < (1ull << 32)) width <<= 1;
     if (lo + width > (1ull << 32)) width = (1ull << 32) - lo;
   }
+}
+
+template <int ND4>
+__global__ __launch_bounds__(kThreads) void hr_merge_kernel(const uint8_t *__restrict__ dimIn, uint8_t *__restrict__ dimOut,
+                                                            DimLayoutD L, size_t capacity,
+                                                            uint8_t *__restrict__ outputValues, AggSpec a, Workspace ws) {
+  merge_body<ND4, false>(dimIn, capacity, dimOut, L, capacity, outputValues, a, ws, nullptr, 0u);
+}
+
+template <int ND>
+__global__ __launch_bounds__(kThreads) void hr_fused_merge_kernel(FusedPlanD plan, const uint8_t *__restrict__ prevDims,
+                                                                  size_t prevCapacity, uint32_t prevSize,
+                                                                  uint8_t *__restrict__ dimOut, size_t outCapacity,
+                                                                  uint8_t *__restrict__ outputValues, AggSpec a, Workspace ws) {
+  DimLayoutD L;  // unused by the all-4-byte emission
+  L.numDims = ND;
+  merge_body<ND, true>(prevDims, prevCapacity, dimOut, L, outCapacity, outputValues, a, ws, &plan, prevSize);
 }
 
 }  // namespace
@@ -642,12 +919,156 @@ int hash_reduce_lds(const DimensionVector &inputKeys, const uint8_t *inputValues
     ARES_LAUNCH("hr_partition_kernel", hr_partition_kernel, grid, kThreads, stream, inputKeys.DimValues, L,
                 static_cast<size_t>(inputKeys.VectorCapacity), inputValues, a, length, ws);
   }
-  ARES_LAUNCH("hr_merge_kernel", hr_merge_kernel, numParts, kThreads, stream, inputKeys.DimValues, outputKeys.DimValues, L,
-              static_cast<size_t>(inputKeys.VectorCapacity), outputValues, a, ws);
+#define ARES_HR_MERGE(ND)                                                                                          \
+  ARES_LAUNCH("hr_merge_kernel", hr_merge_kernel<ND>, numParts, kThreads, stream, inputKeys.DimValues, outputKeys.DimValues, L, \
+              static_cast<size_t>(inputKeys.VectorCapacity), outputValues, a, ws)
+  switch (all4 ? L.numDims : 0) {
+    case 1: ARES_HR_MERGE(1); break;
+    case 2: ARES_HR_MERGE(2); break;
+    case 3: ARES_HR_MERGE(3); break;
+    case 4: ARES_HR_MERGE(4); break;
+    default: ARES_HR_MERGE(0); break;
+  }
+#undef ARES_HR_MERGE
   uint32_t result[2] = {0, 0};  // {groups, overflow}
   read_back_u32(ws.outCount, result, 2, stream);
   if (result[1]) return -1;
   return static_cast<int>(result[0]);
 }
 
+
+// ---- fused extension: host side ---------------------------------------------------------------------
+namespace {
+
+struct NotFusable : std::runtime_error {
+  explicit NotFusable(const std::string &why) : std::runtime_error("not fusable: " + why) {}
+};
+
+// Column slots: dimension d -> slot d, measure -> slot ND (a column used twice is simply loaded
+// twice; the second load hits L1).  Filters reuse a slot that already holds their column, or take
+// the one spare slot ND + 1.
+int fused_column(FusedPlanD &plan, const FastOperands &f, int maxCols, bool reuse) {
+  if (reuse)
+    for (int c = 0; c < plan.numCols; c++)
+      if (plan.cols[c].vals == f.vals && plan.cols[c].nulls == f.nulls && plan.cols[c].bitOff == f.bitOff) return c;
+  if (plan.numCols >= maxCols) throw NotFusable("too many distinct columns");
+  FusedColumn &col = plan.cols[plan.numCols];
+  col.vals = f.vals;
+  col.nulls = f.nulls;
+  col.bitOff = f.bitOff;
+  return plan.numCols++;
+}
+
+void fused_expr(const AresFusedExpr &e, bool compareOnly, int batchRows, hipStream_t stream, FusedPlanD &plan, int maxCols,
+                FusedExpr &out) {
+  if (e.arity != 1 && e.arity != 2) throw NotFusable("arity");
+  if (e.lhs.Type != VectorPartyInput || (e.arity == 2 && e.rhs.Type != ConstantInput))
+    throw NotFusable("operands must be a main-table column and a constant");
+  if (static_cast<int64_t>(e.lhs.Vector.VP.Length) < batchRows) throw NotFusable("column shorter than the batch");
+  InputVector ins[2] = {e.lhs, e.arity == 2 ? e.rhs : e.lhs};
+  EvalParams p;
+  CallTemps temps;
+  build_params(ins, e.arity, stream, nullptr, nullptr, 0, e.functor, p, temps);
+  FastOperands f;
+  if (!fast_operands(p, f, compareOnly)) throw NotFusable("expression shape");
+  out.col = fused_column(plan, f, maxCols, compareOnly);
+  out.f = f;
+  out.f.vals = nullptr;
+  out.f.nulls = nullptr;
+  out.outKind = e.outType == Int32 ? K_I32 : e.outType == Uint32 ? K_U32 : K_F32;
+}
+
+int fused_filter_hash_reduce(const AresFusedQuery &q, int batchRows, const DimensionVector &prevKeys, uint8_t *prevValues,
+                             int prevSize, const DimensionVector &outKeys, uint8_t *outValues, hipStream_t stream) {
+  if (q.numDims < 1 || q.numDims > kFusedDims) throw NotFusable("1..4 dimensions");
+  if (q.numFilters < 0 || q.numFilters > kFusedFilters) throw NotFusable("at most 4 filters");
+  const int nd = q.numDims;
+  for (int k = 0; k < NUM_DIM_WIDTH; k++)
+    if (outKeys.NumDimsPerDimWidth[k] != (k == 2 ? nd : 0) || (prevSize > 0 && prevKeys.NumDimsPerDimWidth[k] != (k == 2 ? nd : 0)))
+      throw NotFusable("dimension vector layout");
+  const int mt = q.measure.outType;
+  if (!(mt == Int32 || mt == Uint32 || mt == Float32 || mt == Int64 || mt == Float64)) throw NotFusable("measure type");
+  const int mw = (mt == Int64 || mt == Float64) ? 8 : 4;
+  const AggSpec a = make_agg_spec(q.aggFunc, mw);
+  if (!hash_reduce_lds_supported(a)) throw NotFusable("aggregate");
+  if (batchRows < 0 || prevSize < 0 || static_cast<int64_t>(batchRows) + prevSize > INT32_MAX) throw NotFusable("size");
+  if (static_cast<int64_t>(outKeys.VectorCapacity) < static_cast<int64_t>(batchRows) + prevSize)
+    throw std::invalid_argument("outKeys.VectorCapacity < prevSize + batchRows");
+
+  FusedPlanD plan;
+  memset(&plan, 0, sizeof(plan));
+  const int maxCols = nd + 2;
+  plan.numFilters = q.numFilters;
+  for (int d = 0; d < nd; d++) {
+    const int t = q.dims[d].outType;
+    if (!(t == Int32 || t == Uint32 || t == Float32)) throw NotFusable("dimension type");
+    fused_expr(q.dims[d], false, batchRows, stream, plan, maxCols, plan.dims[d]);
+  }
+  fused_expr(q.measure, false, batchRows, stream, plan, maxCols, plan.measure);
+  for (int k = 0; k < q.numFilters; k++) fused_expr(q.filters[k], true, batchRows, stream, plan, maxCols, plan.filters[k]);
+  plan.measureDtype = mt;
+  plan.measureWidth = mw;
+  plan.identity = identity_bits(q.aggFunc, mt);
+
+  const int64_t length = static_cast<int64_t>(batchRows) + prevSize;
+  if (length == 0) return 0;
+  int partBits = 0;
+  while ((8192ll << partBits) < length && (1 << partBits) < kMaxPartitions) partBits++;
+  const int numParts = 1 << partBits;
+  Workspace ws;
+  ws.partBits = partBits;
+  ws.debug = 0;
+  ws.cap = ((2ull * (static_cast<uint64_t>(length) / numParts) + 2 * kSlots) | 63ull) + 18;
+  const size_t headBytes = sizeof(uint32_t) * (numParts + 2);
+  const size_t headPadded = (headBytes + 255) / 256 * 256;
+  StreamBuffer buf(headPadded + sizeof(uint4) * ws.cap * numParts, stream);
+  ws.cursors = buf.as<uint32_t>();
+  ws.outCount = ws.cursors + numParts;
+  ws.overflow = ws.outCount + 1;
+  ws.records = reinterpret_cast<uint4 *>(buf.as<uint8_t>() + headPadded);
+  hip_check(hipMemsetAsync(buf.get(), 0, headPadded, stream), "hipMemsetAsync");
+
+  auto grid_for = [](int64_t rows) {
+    const int64_t tiles = (rows + kQuadTile - 1) / kQuadTile;
+    return static_cast<int>(tiles < 256 ? (tiles < 1 ? 1 : tiles) : 256);
+  };
+#define ARES_FUSED_CASE(ND)                                                                                            \
+  case ND:                                                                                                             \
+    if (prevSize > 0) {                                                                                                \
+      if (mw == 8)                                                                                                     \
+        ARES_LAUNCH("hr_partition4_kernel", (hr_partition4_kernel<ND, 8>), grid_for(prevSize), kThreads, stream,        \
+                    prevKeys.DimValues, static_cast<size_t>(prevKeys.VectorCapacity), prevValues, a, prevSize, ws);     \
+      else                                                                                                             \
+        ARES_LAUNCH("hr_partition4_kernel", (hr_partition4_kernel<ND, 4>), grid_for(prevSize), kThreads, stream,        \
+                    prevKeys.DimValues, static_cast<size_t>(prevKeys.VectorCapacity), prevValues, a, prevSize, ws);     \
+    }                                                                                                                  \
+    if (batchRows > 0)                                                                                                 \
+      ARES_LAUNCH("hr_fused_scan_kernel", hr_fused_scan_kernel<ND>, grid_for(batchRows), kThreads, stream, plan,       \
+                  static_cast<uint32_t>(prevSize), a, batchRows, ws);                                                  \
+    ARES_LAUNCH("hr_fused_merge_kernel", hr_fused_merge_kernel<ND>, numParts, kThreads, stream, plan, prevKeys.DimValues, \
+                static_cast<size_t>(prevKeys.VectorCapacity), static_cast<uint32_t>(prevSize), outKeys.DimValues,      \
+                static_cast<size_t>(outKeys.VectorCapacity), outValues, a, ws);                                        \
+    break;
+  switch (nd) {
+    ARES_FUSED_CASE(1) ARES_FUSED_CASE(2) ARES_FUSED_CASE(3) ARES_FUSED_CASE(4)
+  }
+#undef ARES_FUSED_CASE
+  uint32_t result[2] = {0, 0};
+  read_back_u32(ws.outCount, result, 2, stream);
+  if (result[1]) throw NotFusable("a hash partition overflowed (skewed hashes); run the unfused sequence");
+  return static_cast<int>(result[0]);
+}
+
+}  // namespace
+
 }  // namespace ares
+
+extern "C" CGoCallResHandle AresFusedFilterHashReduce(const AresFusedQuery *query, int batchRows, DimensionVector prevKeys,
+                                                      uint8_t *prevValues, int prevSize, DimensionVector outKeys,
+                                                      uint8_t *outValues, void *cudaStream, int device) {
+  ARES_ABI_BEGIN(device)
+  if (!query) throw std::invalid_argument("null query");
+  resHandle.res = ares::int_result(ares::fused_filter_hash_reduce(*query, batchRows, prevKeys, prevValues, prevSize, outKeys,
+                                                                  outValues, reinterpret_cast<hipStream_t>(cudaStream)));
+  ARES_ABI_END("AresFusedFilterHashReduce")
+}

@@ -17,6 +17,7 @@
 #include "binding.hpp"
 #include "common.hpp"
 #include "device_model.hpp"
+#include "fast_eval.hpp"
 #include "lookback.hpp"
 
 namespace ares {
@@ -45,17 +46,6 @@ __global__ __launch_bounds__(kBlock) void init_index_kernel(uint32_t *idx, uint3
 // ---------------------------------------------------------------------------------------------
 // 32-bit value path: transform
 // ---------------------------------------------------------------------------------------------
-struct EvalParams {
-  OperandD a, b;
-  int arity;
-  int functor;
-  int I;   // common input kind
-  int rk;  // result kind
-  const uint32_t *idx;
-  const uint32_t *baseCounts;
-  uint32_t startCount;
-  int needRow;
-};
 
 template <int ITEMS>
 __global__ __launch_bounds__(kBlock) void transform32_kernel(EvalParams p, SinkD s, int n) {
@@ -391,25 +381,6 @@ __global__ __launch_bounds__(kBlock) void filter_kernel(EvalParams p, uint8_t *p
 // alignment, hence the 4-byte aligned vector types.  Quad k covers positions [4k - pad, 4k - pad + 4)
 // with pad = (address of the 1-byte-per-position output) & 3, so that the validity / predicate
 // bytes of a quad form one aligned dword.
-struct __attribute__((aligned(4))) U32x4 { uint32_t v[4]; };
-struct __attribute__((aligned(4))) U64x2 { uint64_t v[2]; };
-
-// 32-bit column operand + optional constant second operand, as the fast kernels see them
-struct FastOperands {
-  const uint32_t *vals;  // column values
-  const uint8_t *nulls;  // validity bitmap or nullptr (mode 1)
-  uint32_t bitOff;       // bit position of row 0 in the bitmap
-  int akind;             // stored kind of the column
-  int arity, functor, I, rk;
-  int bkind;
-  uint32_t bbits, bok;   // constant second operand
-  const uint32_t *idx;   // index vector or nullptr (identity)
-  int pad;
-  int divLike;           // integer Divide / Mod / Floor by the constant: multiply-high division
-  int debug;             // ARES_F_DEBUG: timing experiments only
-};
-
-struct __attribute__((packed, aligned(1))) PU16 { uint16_t v; };
 
 // Loads rows / values / validity of QUADS quads per lane; positions outside [0, n) get ok = 0.
 // Three phases so that every load of the tile is in flight before the first one is consumed:
@@ -473,85 +444,6 @@ __device__ __forceinline__ void load_quads(const FastOperands &f, int64_t quad0,
       okb[q] |= bit << j;
     }
   }
-}
-
-// x / d and x % d for a divisor that is the same for the whole launch: one multiply-high by
-// M = floor(2^32 / d) estimates the quotient to within one (M = 0 marks d < 2).
-struct FastDivisor {
-  uint32_t d, M;
-};
-__device__ __forceinline__ FastDivisor make_fast_divisor(uint32_t d) {
-  FastDivisor r;
-  r.d = d;
-  r.M = d >= 2 ? static_cast<uint32_t>((1ull << 32) / d) : 0u;
-  return r;
-}
-__device__ __forceinline__ void fast_divmod(const FastDivisor &fd, uint32_t x, uint32_t &q, uint32_t &r) {
-  if (fd.d < 2) {  // 0: the reference divides by zero (undefined); binary32 yields q = r = 0 — keep that
-    q = fd.d ? x : 0u;
-    r = 0u;
-    return;
-  }
-  q = __umulhi(x, fd.M);
-  r = x - q * fd.d;
-  if (r >= fd.d) { q++; r -= fd.d; }
-}
-
-// The fast kernels inline this once per element (16-32 copies), so it only covers what the hot
-// queries use: unary Noop (a bare column) and the binary functors; the calendar / HLL / logical
-// unary functors stay on the generic kernels.
-__device__ __forceinline__ DVal eval_fast(const FastOperands &f, uint32_t bits, uint32_t ok, DVal y,
-                                          const FastDivisor &fd) {
-  DVal x;
-  x.bits = bits;
-  x.ok = ok;
-  x = cvt32(x, f.akind, f.I);
-  if (f.arity == 1) return x;
-  if (f.divLike) {  // Divide / Mod / Floor on integers by the launch-wide constant (functor.hpp:337-351)
-    DVal r;
-    r.ok = x.ok && y.ok;
-    r.bits = 0;
-    if (r.ok) {
-      uint32_t q, m;
-      if (f.I == K_I32) {  // C++ truncating semantics on magnitudes
-        const int32_t sx = static_cast<int32_t>(x.bits), sy = static_cast<int32_t>(y.bits);
-        const uint32_t ax = sx < 0 ? 0u - x.bits : x.bits;
-        fast_divmod(fd, ax, q, m);
-        const uint32_t sq = ((sx < 0) != (sy < 0)) ? 0u - q : q;
-        const uint32_t sm = sx < 0 ? 0u - m : m;
-        r.bits = f.functor == Divide ? sq : f.functor == Mod ? sm : x.bits - sm;
-      } else {
-        fast_divmod(fd, x.bits, q, m);
-        r.bits = f.functor == Divide ? q : f.functor == Mod ? m : x.bits - m;
-      }
-    }
-    return r;
-  }
-  return binary32(f.functor, f.I, x, y);
-}
-
-// comparison functors only (what a filter root is in practice): value of (x ft y), null -> false
-__device__ __forceinline__ uint32_t compare_fast(const FastOperands &f, uint32_t bits, uint32_t ok, DVal y) {
-  DVal x;
-  x.bits = bits;
-  x.ok = ok;
-  x = cvt32(x, f.akind, f.I);
-  const int ft = f.functor;
-  bool c;
-  if (f.I == K_F32) {
-    const float a = bits_f(x.bits), b = bits_f(y.bits);
-    c = ft == Equal ? a == b : ft == NotEqual ? a != b : ft == LessThan ? a < b
-        : ft == LessThanOrEqual ? a <= b : ft == GreaterThan ? a > b : a >= b;
-  } else if (f.I == K_I32) {
-    const int32_t a = static_cast<int32_t>(x.bits), b = static_cast<int32_t>(y.bits);
-    c = ft == Equal ? a == b : ft == NotEqual ? a != b : ft == LessThan ? a < b
-        : ft == LessThanOrEqual ? a <= b : ft == GreaterThan ? a > b : a >= b;
-  } else {
-    const uint32_t a = x.bits, b = y.bits;
-    c = ft == Equal ? a == b : ft == NotEqual ? a != b : ft == LessThan ? a < b
-        : ft == LessThanOrEqual ? a <= b : ft == GreaterThan ? a > b : a >= b;
-  }
-  return (x.ok && y.ok && c) ? 1u : 0u;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -740,56 +632,6 @@ __global__ __launch_bounds__(kBlock) void filter_fast_kernel(FastOperands f, uin
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-static void build_params(const InputVector *ins, int arity, hipStream_t stream, const uint32_t *indexVector,
-                         const uint32_t *baseCounts, uint32_t startCount, int functor, EvalParams &p,
-                         CallTemps &temps) {
-  memset(&p, 0, sizeof(p));
-  bind_operand(ins[0], true, stream, p.a, temps);
-  p.arity = arity;
-  p.functor = functor;
-  if (arity == 2) {
-    bind_operand(ins[1], false, stream, p.b, temps);
-    check_binary_kinds(p.a, p.b, ins[1]);
-    p.I = common_kind(p.a.kind, p.b.kind);
-    p.rk = is_wide(p.I) ? K_BOOL : binary_result_kind(functor, p.I);
-  } else {
-    p.I = p.a.kind;
-    p.rk = is_wide(p.I) ? K_NONE : unary_result_kind(functor, p.I);
-  }
-  p.idx = indexVector;
-  p.baseCounts = baseCounts;
-  p.startCount = startCount;
-  p.needRow = indexVector != nullptr && (p.a.type == OP_COLUMN || (arity == 2 && p.b.type == OP_COLUMN));
-}
-
-
-// The hot shape of a live-batch query: a 4-byte column (modes 1/2), optionally combined with a
-// constant, feeding a 4-byte vector or a measure.  Everything else takes the generic kernels.
-static bool fast_operands(const EvalParams &p, FastOperands &f, bool compareOnly) {
-  if (p.arity == 1 && (compareOnly || p.functor != Noop)) return false;
-  if (compareOnly && (p.functor < Equal || p.functor > GreaterThanOrEqual)) return false;
-  if (p.a.type != OP_COLUMN || p.a.step != 4 || p.a.mode > 2 || p.a.kind == K_BOOL || is_wide(p.a.kind)) return false;
-  if (p.arity == 2 && (p.b.type != OP_CONST || is_wide(p.b.kind))) return false;
-  if (is_wide(p.I)) return false;
-  memset(&f, 0, sizeof(f));
-  f.vals = reinterpret_cast<const uint32_t *>(p.a.base + p.a.valuesOff);
-  f.nulls = p.a.mode == 2 ? p.a.base + p.a.nullsOff : nullptr;
-  f.bitOff = p.a.bitOff;
-  f.akind = p.a.kind;
-  f.arity = p.arity;
-  f.functor = p.functor;
-  f.I = p.I;
-  f.rk = p.rk;
-  f.bkind = p.arity == 2 ? p.b.kind : p.I;
-  f.bbits = p.b.cbits;
-  f.bok = p.b.cok;
-  f.idx = p.needRow ? p.idx : nullptr;
-  f.divLike = p.arity == 2 && (p.I == K_I32 || p.I == K_U32) && (p.functor == Divide || p.functor == Mod || p.functor == Floor);
-  const char *dbg = getenv("ARES_F_DEBUG");
-  f.debug = dbg ? atoi(dbg) : 0;
-  return true;
-}
-
 static bool fast_sink(const SinkD &s) {
   const bool four = s.dtype == Int32 || s.dtype == Uint32 || s.dtype == Float32;
   if (s.type == SINK_MEASURE) return s.agg != AGGR_AVG_FLOAT && s.baseCounts == nullptr;

@@ -21,6 +21,7 @@
 #include <string>
 #include <vector>
 
+#include "ares_extensions.h"
 #include "ares_memory.h"
 
 namespace {
@@ -51,6 +52,7 @@ struct AbiLibrary {
   decltype(&::Sort) Sort;
   decltype(&::Reduce) Reduce;
   decltype(&::HashReduce) HashReduce;
+  decltype(&::AresFusedFilterHashReduce) FusedFilterHashReduce = nullptr;  // optional extension
   // libmem
   decltype(&::DeviceAllocate) DeviceAllocate;
   decltype(&::DeviceFree) DeviceFree;
@@ -78,6 +80,7 @@ struct AbiLibrary {
     bind(algoHandle, "Sort", Sort);
     bind(algoHandle, "Reduce", Reduce);
     bind(algoHandle, "HashReduce", HashReduce);
+    FusedFilterHashReduce = reinterpret_cast<decltype(FusedFilterHashReduce)>(dlsym(algoHandle, "AresFusedFilterHashReduce"));
     bind(memHandle, "DeviceAllocate", DeviceAllocate);
     bind(memHandle, "DeviceFree", DeviceFree);
     bind(memHandle, "WaitForCudaStream", WaitForCudaStream);
@@ -137,6 +140,7 @@ struct Plan {
   std::vector<int> filters, foreignFilters, dimNodes, dimTypes;
   int measureNode, aggFunc, measureType;
   bool useHashReduction;
+  bool useFusedExtension;
   struct Foreign {
     AresForeignTable t;
     std::vector<VectorPartySlice> slices;
@@ -149,7 +153,7 @@ struct Plan {
         foreignFilters(p.foreignFilters, p.foreignFilters + p.numForeignFilters),
         dimNodes(p.dimNodes, p.dimNodes + p.numDims), dimTypes(p.dimTypes, p.dimTypes + p.numDims),
         measureNode(p.measureNode), aggFunc(p.aggFunc), measureType(p.measureType),
-        useHashReduction(p.useHashReduction != 0) {
+        useHashReduction(p.useHashReduction != 0), useFusedExtension(p.useFusedExtension != 0) {
     for (int i = 0; i < p.numForeignTables; i++) {
       Foreign f;
       f.t = p.foreignTables[i];
@@ -190,7 +194,8 @@ struct AresQuery {
   int numColumns = 0;
   std::vector<uint8_t *> stack;
   std::vector<RecordID *> foreignRids;
-  long calls = 0;
+  long calls = 0, fusedBatches = 0;
+  bool fusedDeclined = false;  // the library rejected the plan once: stop asking
 
   AresQuery(AbiLibrary *l, const AresQueryPlan &p, int dev, void *s) : lib(l), plan(p), device(dev), stream(s) {
     // query/aql_compiler.go:1341-1362: dimensions ordered by width 16..1, then query order
@@ -544,7 +549,71 @@ struct AresQuery {
   }
   void postExec() { swapResultBuffers(); }
 
+  // ---- fused extension (include/ares_extensions.h): one call per batch --------------------------
+  bool fusedExpr(int nodeIdx, int outType, AresFusedExpr *e) {
+    const AresPlanNode &n = plan.nodes.at(nodeIdx);
+    memset(e, 0, sizeof(*e));
+    e->outType = static_cast<DataType>(outType);
+    auto leafColumn = [&](const AresPlanNode &c, InputVector *iv) {
+      if (c.kind != ARES_NODE_COLUMN || c.table != 0) return false;
+      memcpy(iv, &columnInput(c).get(), sizeof(InputVector));
+      return true;
+    };
+    if (n.kind == ARES_NODE_COLUMN) {
+      e->arity = 1;
+      e->functor = Noop;
+      return leafColumn(n, &e->lhs);
+    }
+    if (n.kind != ARES_NODE_BINARY) return false;
+    const AresPlanNode &l = plan.nodes.at(n.lhs), &r = plan.nodes.at(n.rhs);
+    if (r.kind != ARES_NODE_CONST_INT && r.kind != ARES_NODE_CONST_FLOAT) return false;
+    if (!leafColumn(l, &e->lhs)) return false;
+    memcpy(&e->rhs, &constantInput(r).get(), sizeof(InputVector));
+    e->arity = 2;
+    e->functor = n.op;
+    return true;
+  }
+
+  // returns false when this batch must take the ordinary sequence
+  bool runBatchFused(const VectorPartySlice *cols, int ncols, int n) {
+    if (!plan.useFusedExtension || !plan.useHashReduction || fusedDeclined || !lib->FusedFilterHashReduce) return false;
+    if (!plan.foreign.empty() || !plan.foreignFilters.empty() || baseCounts) return false;
+    if (plan.dimNodes.empty() || plan.dimNodes.size() > 4 || plan.filters.size() > 4) return false;
+    columns = cols;
+    numColumns = ncols;
+    Pod<AresFusedQuery> q;
+    q->numFilters = static_cast<int>(plan.filters.size());
+    for (size_t i = 0; i < plan.filters.size(); i++)
+      if (!fusedExpr(plan.filters[i], Bool, &q->filters[i])) return false;
+    // dimensions in vector order (all 4 bytes wide: vector order == query order)
+    q->numDims = static_cast<int>(plan.dimNodes.size());
+    for (size_t i = 0; i < plan.dimNodes.size(); i++) {
+      if (data_type_bytes(plan.dimTypes[i]) != 4) return false;
+      if (!fusedExpr(plan.dimNodes[i], plan.dimTypes[i], &q->dims[dimVectorIndex[i]])) return false;
+    }
+    if (!fusedExpr(plan.measureNode, plan.measureType, &q->measure)) return false;
+    q->aggFunc = static_cast<AggregateFunction>(plan.aggFunc);
+    size = n;
+    prepareForDimAndMeasureEval();  // result buffers sized for resultSize + n, previous results carried over
+    calls++;
+    CGoCallResHandle h = lib->FusedFilterHashReduce(&q.get(), n, dimensionVector(0), measureVec[0], resultSize,
+                                                    dimensionVector(1), measureVec[1], stream, device);
+    if (h.pStrErr && strncmp(h.pStrErr, "not fusable", 11) == 0) {
+      free(const_cast<char *>(h.pStrErr));
+      fusedDeclined = true;
+      size = 0;
+      return false;
+    }
+    resultSize = static_cast<int>(check(h));
+    wait();
+    swapResultBuffers();
+    fusedBatches++;
+    return true;
+  }
+
   void runBatch(const VectorPartySlice *cols, int ncols, int n, uint32_t *bc, uint32_t start) {
+    baseCounts = bc;
+    if (runBatchFused(cols, ncols, n)) return;
     prepareForFiltering(cols, ncols, n, bc, start);
     preExec();
     filter();
@@ -609,6 +678,7 @@ int AresQueryResultCapacity(const AresQuery *q) { return q->resultCapacity; }
 uint8_t *AresQueryDimensionVector(const AresQuery *q) { return q->dimVec[0]; }
 uint8_t *AresQueryMeasureVector(const AresQuery *q) { return q->measureVec[0]; }
 long AresQueryNumCalls(const AresQuery *q) { return q->calls; }
+long AresQueryNumFusedBatches(const AresQuery *q) { return q->fusedBatches; }
 
 int AresQueryFetch(AresQuery *q, uint8_t *dims, uint8_t *measures, char *err, int errLen) {
   try {

@@ -55,6 +55,10 @@ typedef struct {
   int measureType;  /* enum DataType of the measure vector */
   int useHashReduction;
   const AresForeignTable *foreignTables; int numForeignTables;
+  /* when set (and the library exports AresFusedFilterHashReduce, include/ares_extensions.h) a batch
+   * whose plan has the fusable shape is executed by ONE fused call instead of the per-node sequence;
+   * any other plan, and any batch the library declines, runs the ordinary sequence */
+  int useFusedExtension;
 } AresQueryPlan;
 
 typedef struct AresQuery AresQuery; /* oopkBatchContext + executor of one query on one device */
@@ -74,6 +78,7 @@ int AresQueryResultCapacity(const AresQuery *q);
 uint8_t *AresQueryDimensionVector(const AresQuery *q); /* device pointer, capacity stride */
 uint8_t *AresQueryMeasureVector(const AresQuery *q);
 long AresQueryNumCalls(const AresQuery *q);            /* ABI calls issued so far */
+long AresQueryNumFusedBatches(const AresQuery *q);     /* batches that took the fused extension */
 /* D2H of the result (query/aql_processor.go:641-671): dims = for each dim in vector order
  * resultSize*width value bytes, then numDims x resultSize validity bytes; measures. */
 int AresQueryFetch(AresQuery *q, uint8_t *dims, uint8_t *measures, char *err, int errLen);

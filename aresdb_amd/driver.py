@@ -35,7 +35,8 @@ class QueryPlanC(C.Structure):
                 ("dimNodes", C.POINTER(C.c_int)), ("dimTypes", C.POINTER(C.c_int)), ("numDims", C.c_int),
                 ("measureNode", C.c_int), ("aggFunc", C.c_int), ("measureType", C.c_int),
                 ("useHashReduction", C.c_int),
-                ("foreignTables", C.POINTER(ForeignTableC)), ("numForeignTables", C.c_int)]
+                ("foreignTables", C.POINTER(ForeignTableC)), ("numForeignTables", C.c_int),
+                ("useFusedExtension", C.c_int)]
 
 
 _lib = None
@@ -57,7 +58,7 @@ def _driver():
         lib.AresQueryRunBatch.restype = C.c_int
         for name, res in (("AresQueryResultSize", C.c_int), ("AresQueryResultCapacity", C.c_int),
                           ("AresQueryDimensionVector", C.c_void_p), ("AresQueryMeasureVector", C.c_void_p),
-                          ("AresQueryNumCalls", C.c_long)):
+                          ("AresQueryNumCalls", C.c_long), ("AresQueryNumFusedBatches", C.c_long)):
             fn = getattr(lib, name)
             fn.argtypes, fn.restype = [C.c_void_p], res
         lib.AresQueryFetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
@@ -146,6 +147,7 @@ class NativeQuery:
         pc.measureNode, pc.aggFunc, pc.measureType = measure, plan.agg, plan.measure_type
         pc.useHashReduction = int(plan.use_hash_reduction)
         pc.foreignTables, pc.numForeignTables = arr(ForeignTableC, fts), len(fts)
+        pc.useFusedExtension = int(getattr(plan, "use_fused_extension", False))
         err = C.create_string_buffer(512)
         self._q = _driver().AresQueryCreate(_open(be), C.byref(pc), device, stream, err, 512)
         if not self._q:
@@ -179,6 +181,10 @@ class NativeQuery:
     @property
     def calls(self):
         return _driver().AresQueryNumCalls(self._q)
+
+    @property
+    def fused_batches(self):
+        return _driver().AresQueryNumFusedBatches(self._q)
 
     # -- the attributes shard_merge.merge_shard_results reads from a batch context --------------------
     @property

@@ -79,6 +79,7 @@ class QueryPlan:
     agg: int
     measure_type: int  # data type of the measure output vector
     use_hash_reduction: bool = False
+    use_fused_extension: bool = False  # C++ driver only: one fused call per batch where the plan allows
     foreign_tables: List[ForeignTable] = field(default_factory=list)
     foreign_filters: List[object] = field(default_factory=list)
 

@@ -10,6 +10,10 @@ from .executor import BatchContext, BatchExecutor, fetch_results
 from .queries import c3_plan  # noqa: F401  (re-exported for tests)
 
 
+_MEASURE_NP = {abi.Float64: np.float64, abi.Int64: np.int64, abi.Float32: np.float32, abi.Int32: np.int32,
+               abi.Uint32: np.uint32}
+
+
 def synth_batch(rng, n, null_fraction=0.0):
     cols = {
         "ts": (abi.Uint32, rng.integers(0, 86400 * 7, n).astype(np.uint32)),
@@ -36,7 +40,7 @@ def run_query(be, plan, batches):
     ctx.release()
     n = len(valids[0]) if valids else 0
     out = {}
-    m = meas.view(np.float64) if plan.measure_type == abi.Float64 else meas.view(np.uint32)
+    m = meas.view(_MEASURE_NP[plan.measure_type])
     for r in range(n):
         key = tuple((bytes(d[r * len(d) // n:(r + 1) * len(d) // n]), int(v[r])) for d, v in zip(dims, valids))
         out[key] = m[r]
@@ -57,9 +61,10 @@ def run_query_native(be, plan, batches):
     dims, valids, meas = q.fetch()
     calls = q.calls
     n = q.result_size
+    run_query_native.last_fused_batches = q.fused_batches
     q.release()
     out = {}
-    m = meas.view(np.float64) if plan.measure_type == abi.Float64 else meas.view(np.uint32)
+    m = meas.view(_MEASURE_NP[plan.measure_type])
     for r in range(n):
         key = tuple((bytes(d[r * len(d) // n:(r + 1) * len(d) // n]), int(v[r])) for d, v in zip(dims, valids))
         out[key] = m[r]

@@ -118,6 +118,7 @@ def main():
     ap.add_argument("--batch-rows", type=float, default=float(1 << 26))
     ap.add_argument("--null-fraction", type=float, default=0.01)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fused-leg", action="store_true", help="skip the extra AresFusedFilterHashReduce measurement")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -209,6 +210,33 @@ def main():
                     "note": "algorithmic = 20 B/row of compulsory column reads (+5 validity bits/row), "
                             "SURVEY.md 8d; traffic from rocprofv3 PMC passes is in profiles/"}
 
+    # Extra leg (reported separately, never `value`): the same query through the fused extension entry
+    # point (include/ares_extensions.h) — one call per batch instead of the per-node ABI sequence.
+    fused = None
+    if not args.no_fused_leg and be.has_profiler:
+        fplan = c3_plan(use_hash_reduction=True)
+        fplan.use_fused_extension = True
+        fctx = run_shard(be, fplan, batches, local_rank, stream)
+        fctx.release()
+        sync()
+        be.profiler_enable(True)
+        t1 = time.perf_counter()
+        for k in range(args.steps):
+            fctx = run_shard(be, fplan, batches, local_rank, stream)
+            if k + 1 < args.steps:
+                fctx.release()
+        torch.cuda.synchronize()
+        felapsed = time.perf_counter() - t1
+        fk = be.profiler_report()
+        be.profiler_enable(False)
+        fgot = result_total(fctx)
+        fused = {"rows_per_sec_per_gpu": rows * args.steps / felapsed, "ms_per_step": felapsed / args.steps * 1e3,
+                 "fused_batches": fctx.fused_batches, "groups": fctx.result_size,
+                 "check_sum_of_measures": "ok" if abs(fgot - want) <= 1e-9 * max(1.0, abs(want)) else f"MISMATCH {fgot} vs {want}",
+                 "algorithmic_GBps": rows * args.steps / felapsed * bytes_per_row / 1e9,
+                 "kernels": {n: {"launches": c, "avg_ms": ms / c} for n, (c, ms) in sorted(fk.items(), key=lambda kv: -kv[1][1])}}
+        fctx.release()
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(batches[0], c3_plan, args.cpu_budget)
@@ -229,7 +257,7 @@ def main():
             "rows_per_sec_per_gpu": value / world,
             "algorithmic_GBps_end_to_end": value / world * bytes_per_row / 1e9,
             "check_sum_of_measures": "ok" if check else f"MISMATCH got {got} want {want}",
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": kern_out,
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kern_out, "fused_extension": fused,
         }
         print(json.dumps(out), flush=True)
         if not check:

@@ -6,6 +6,8 @@
 
 #include <stddef.h>
 
+#include "ares_algorithm.h"
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -17,6 +19,41 @@ extern "C" {
  * of query/stats.go:160-169, which must synchronise the stream after every stage instead. */
 void AresProfilerEnable(int on);
 size_t AresProfilerReport(char *buf, size_t len);
+
+/* Fused batch execution: filter -> dimension / measure projection -> hash reduction of ONE batch in
+ * a single pass over the source columns, without the index / predicate / dimension vectors the
+ * one-call-per-AST-node ABI materialises in between (~145 B/row of HBM traffic on
+ * BASELINE config C3; this path moves ~53 B/row).  It replaces, for one batch, the call sequence
+ *   InitIndexVector, BinaryFilter x numFilters, Unary/BinaryTransform x (numDims + 1), HashReduce
+ * of query/aql_batchexecutor.go:103-273 and produces the same groups and aggregates.
+ *
+ * Shapes accepted (anything else returns an error string starting with "not fusable", and the host
+ * simply runs the ordinary sequence): every expression is a main-table VectorPartyInput of a
+ * 4-byte type (modes 1/2), bare (arity 1, Noop) or combined with a ConstantInput by a binary
+ * functor (arity 2); filters are comparison functors (ANDed); dimensions are stored as
+ * Int32 / Uint32 / Float32; the aggregate is one HashReduce supports with native LDS atomics.
+ * prevKeys / prevValues hold the prevSize groups accumulated so far (the reference keeps them as the
+ * first rows of the input vectors, query/aql_processor.go:752-774); outKeys.VectorCapacity must be
+ * at least prevSize + batchRows.  res = number of groups written to outKeys / outValues. */
+typedef struct {
+  InputVector lhs, rhs; /* rhs is read only when arity == 2 */
+  int arity;
+  int functor; /* Unary/BinaryFunctorType */
+  enum DataType outType;
+} AresFusedExpr;
+
+typedef struct {
+  int numFilters;
+  AresFusedExpr filters[4];
+  int numDims;
+  AresFusedExpr dims[4];
+  AresFusedExpr measure; /* outType = data type of the measure vector */
+  enum AggregateFunction aggFunc;
+} AresFusedQuery;
+
+CGoCallResHandle AresFusedFilterHashReduce(const AresFusedQuery *query, int batchRows, DimensionVector prevKeys,
+                                           uint8_t *prevValues, int prevSize, DimensionVector outKeys,
+                                           uint8_t *outValues, void *cudaStream, int device);
 
 #ifdef __cplusplus
 }

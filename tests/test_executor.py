@@ -162,3 +162,62 @@ def test_join_group_by_foreign_column(be, native):
     assert {k: int(v) for k, v in got.items()} == want
     for b in keep:
         b.free()
+
+
+# ---- fused extension (include/ares_extensions.h): one call per batch, same groups and sums -------------
+def _fused_plan(variant, use_fused):
+    dims_by_variant = [
+        [DimensionSpec(Binary(abi.Floor, Col("ts"), Const(3600)), abi.Uint32), DimensionSpec(Col("d1"), abi.Uint32),
+         DimensionSpec(Col("d2"), abi.Uint32), DimensionSpec(Col("d3"), abi.Uint32)],
+        [DimensionSpec(Binary(abi.Plus, Col("d1"), Const(7)), abi.Int32), DimensionSpec(Col("d3"), abi.Uint32)],
+        [DimensionSpec(Binary(abi.Mod, Col("ts"), Const(11)), abi.Int32)],
+        [DimensionSpec(Col("d2"), abi.Uint32), DimensionSpec(Binary(abi.Multiply, Col("m"), Const(2.0)), abi.Float32),
+         DimensionSpec(Binary(abi.Divide, Col("ts"), Const(86400)), abi.Uint32)],
+    ]
+    filters_by_variant = [
+        [Binary(abi.LessThan, Col("d1"), Const(90))],
+        [],
+        [Binary(abi.GreaterThanOrEqual, Col("ts"), Const(1000)), Binary(abi.NotEqual, Col("d2"), Const(0)),
+         Binary(abi.LessThan, Col("m"), Const(80.5))],
+        [Binary(abi.Equal, Col("d3"), Const(1))],
+    ]
+    measures = [(Col("m"), abi.AGGR_SUM_FLOAT, abi.Float64), (Col("d1"), abi.AGGR_SUM_SIGNED, abi.Int64),
+                (Binary(abi.Plus, Col("d2"), Const(1)), abi.AGGR_SUM_SIGNED, abi.Int32), (Col("m"), abi.AGGR_SUM_FLOAT, abi.Float64)]
+    m, agg, mt = measures[variant]
+    return QueryPlan(filters=filters_by_variant[variant], dimensions=dims_by_variant[variant], measure=m, agg=agg,
+                     measure_type=mt, use_hash_reduction=True, use_fused_extension=use_fused)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nulls", [0.0, 0.05], ids=["mode1", "mode2"])
+@pytest.mark.parametrize("variant", range(4))
+def test_fused_extension_matches_unfused_sequence(variant, nulls):
+    """The fused call must produce exactly the groups (keys bit-exact) and sums of the ordinary
+    per-node sequence run on the oracle, over several batches (previous results are re-reduced)."""
+    hip = H.hip_backend()
+    rng = np.random.default_rng(100 + variant)
+    sizes = [5000, 17, 40001, 1]
+    data = [smoke.synth_batch(rng, n, null_fraction=nulls) for n in sizes]
+    got, calls = smoke.run_query_native(hip, _fused_plan(variant, True), data)
+    assert smoke.run_query_native.last_fused_batches == len(sizes)
+    assert calls == len(sizes)
+    want, _ = smoke.run_query(H.oracle_backend(), _fused_plan(variant, False), data)
+    smoke.compare_results(got, want)
+    unfused, _ = smoke.run_query_native(hip, _fused_plan(variant, False), data)
+    smoke.compare_results(unfused, want)
+
+
+@pytest.mark.gpu
+def test_fused_extension_declines_unsupported_plans():
+    """A plan outside the fusable shape (nested expression) silently takes the ordinary sequence."""
+    hip = H.hip_backend()
+    rng = np.random.default_rng(9)
+    data = [smoke.synth_batch(rng, 3000) for _ in range(2)]
+    plan = QueryPlan(filters=[Binary(abi.Equal, Binary(abi.Mod, Col("ts"), Const(7), abi.Int32), Const(3))],
+                     dimensions=[DimensionSpec(Col("d1"), abi.Uint32)], measure=Col("m"), agg=abi.AGGR_SUM_FLOAT,
+                     measure_type=abi.Float64, use_hash_reduction=True, use_fused_extension=True)
+    got, _ = smoke.run_query_native(hip, plan, data)
+    assert smoke.run_query_native.last_fused_batches == 0
+    plan.use_fused_extension = False
+    want, _ = smoke.run_query(H.oracle_backend(), plan, data)
+    smoke.compare_results(got, want)

@@ -36,6 +36,94 @@ void read_back_u32(const uint32_t *dev, uint32_t *host, int count, hipStream_t s
   for (int i = 0; i < count; i++) host[i] = pinned[i];
 }
 
+// ---- stream-local block cache ---------------------------------------------------------------------
+namespace {
+struct CachedBlock {
+  void *ptr;
+  size_t size;
+};
+struct StreamCache {
+  std::map<size_t, std::vector<void *>> bins;  // rounded size -> free blocks
+  size_t bytes = 0;
+};
+std::mutex g_cacheMutex;
+std::map<std::pair<int, hipStream_t>, StreamCache> g_caches;
+std::map<void *, size_t> g_blockSize;  // every block handed out or cached -> rounded size
+size_t g_cachedBytes = 0;
+
+size_t cache_bin(size_t bytes) {
+  if (bytes < 256) return 256;
+  const int top = 63 - __builtin_clzll(static_cast<unsigned long long>(bytes));
+  const size_t step = static_cast<size_t>(1) << (top > 3 ? top - 3 : 0);
+  return (bytes + step - 1) / step * step;
+}
+
+// frees every cached block (all streams of all devices); the caller holds g_cacheMutex.  hipFree
+// waits for outstanding work, so blocks still referenced by enqueued kernels stay valid until then.
+void drop_all_cached() {
+  for (auto &kv : g_caches) {
+    for (auto &bin : kv.second.bins)
+      for (void *p : bin.second) {
+        (void)hipFree(p);
+        g_blockSize.erase(p);
+      }
+    kv.second.bins.clear();
+    kv.second.bytes = 0;
+  }
+  g_cachedBytes = 0;
+}
+}  // namespace
+
+void *stream_alloc(size_t bytes, hipStream_t stream) {
+  const size_t rounded = cache_bin(bytes);
+  int device = 0;
+  hip_check(hipGetDevice(&device), "hipGetDevice");
+  {
+    std::lock_guard<std::mutex> lock(g_cacheMutex);
+    StreamCache &c = g_caches[{device, stream}];
+    auto it = c.bins.find(rounded);
+    if (it != c.bins.end() && !it->second.empty()) {
+      void *p = it->second.back();
+      it->second.pop_back();
+      c.bytes -= rounded;
+      g_cachedBytes -= rounded;
+      return p;
+    }
+  }
+  void *p = nullptr;
+  hipError_t e = hipMalloc(&p, rounded);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    {
+      std::lock_guard<std::mutex> lock(g_cacheMutex);
+      drop_all_cached();
+    }
+    hip_check(hipMalloc(&p, rounded), "hipMalloc");
+  }
+  std::lock_guard<std::mutex> lock(g_cacheMutex);
+  g_blockSize[p] = rounded;
+  return p;
+}
+
+void stream_release(void *ptr, hipStream_t stream) {
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess) {
+    (void)hipGetLastError();
+    return;
+  }
+  std::lock_guard<std::mutex> lock(g_cacheMutex);
+  auto it = g_blockSize.find(ptr);
+  if (it == g_blockSize.end()) return;
+  const size_t rounded = it->second;
+  StreamCache &c = g_caches[{device, stream}];
+  c.bins[rounded].push_back(ptr);
+  c.bytes += rounded;
+  g_cachedBytes += rounded;
+  // keep the cache below a quarter of the device: drop everything when it outgrows that
+  size_t freeB = 0, totalB = 0;
+  if (g_cachedBytes > (1ull << 30) && hipMemGetInfo(&freeB, &totalB) == hipSuccess && g_cachedBytes > totalB / 4) drop_all_cached();
+}
+
 // ---- kernel timing -------------------------------------------------------------------------------
 namespace {
 struct TimedLaunch {

@@ -48,24 +48,19 @@ inline void check_launch(const char *what) { hip_check(hipGetLastError(), what);
 
 inline void *int_result(int64_t v) { return reinterpret_cast<void *>(static_cast<intptr_t>(v)); }
 
-// Stream-ordered temporary device memory (tile descriptors, hash tables, radix-sort ping-pong
-// buffers).  Comes from the device's default pool, so after warm-up it costs no driver call.
+// Stream-local temporary device memory (tile descriptors, hash-partition regions, radix-sort
+// ping-pong buffers).  Blocks are cached per (device, stream) in 1/8-octave size bins: a block
+// released on stream S is only ever handed to a later request on the SAME stream, so plain stream
+// order makes the reuse safe — no events, no driver call after warm-up, and no reliance on
+// cross-stream reuse inside the runtime's own pool.
+void *stream_alloc(size_t bytes, hipStream_t stream);
+void stream_release(void *ptr, hipStream_t stream);
+
 class StreamBuffer {
  public:
-  StreamBuffer(size_t bytes, hipStream_t stream) : stream_(stream) {
-    if (bytes == 0) bytes = 16;
-    // Request sizes in 1/8-octave steps: workspaces whose size creeps up from batch to batch (the
-    // accumulated result grows) would otherwise never fit a cached block and fall through to the
-    // driver every time (~100 ms for a multi-GB mapping).
-    if (bytes > (1u << 20)) {
-      const int top = 63 - __builtin_clzll(static_cast<unsigned long long>(bytes));
-      const size_t step = static_cast<size_t>(1) << (top - 3);
-      bytes = (bytes + step - 1) / step * step;
-    }
-    hip_check(hipMallocAsync(&ptr_, bytes, stream), "hipMallocAsync");
-  }
+  StreamBuffer(size_t bytes, hipStream_t stream) : stream_(stream) { ptr_ = stream_alloc(bytes ? bytes : 16, stream); }
   ~StreamBuffer() {
-    if (ptr_) (void)hipFreeAsync(ptr_, stream_);
+    if (ptr_) stream_release(ptr_, stream_);
   }
   StreamBuffer(const StreamBuffer &) = delete;
   StreamBuffer &operator=(const StreamBuffer &) = delete;

@@ -289,7 +289,6 @@ __device__ __forceinline__ uint32_t hash_quad_row(const QuadRows<ND> &q, int j) 
 
 constexpr int kQuadTile = kThreads * 4;                   // rows per tile of the hot-layout kernel
 constexpr int kQuadFlushAt = kSlots * 3 / 4 - kQuadTile;  // = 2048
-constexpr int kStage = kQuadTile;                         // records staged per DIRECT tile
 
 // Row source "dimension vector": the ABI's HashReduce input (values per dimension, validity bytes,
 // measures), already projected by the transform calls.

@@ -4,10 +4,12 @@
 // rmm_alloc.cu) with one HIP implementation designed for a 288 GB HBM3E device:
 //   * host memory is pinned + portable (hipHostMalloc) and zero-filled, so AsyncCopyHostToDevice
 //     is a true asynchronous DMA (reference cuda_malloc.cu:44-52);
-//   * device memory comes from the device's stream-ordered pool (hipMallocAsync) with the release
-//     threshold lifted, so the per-batch, per-column alloc/free pattern of the Go host
-//     (query/aql_processor.go:726-804, :1345-1431) never reaches the driver after warm-up; the
-//     block is zeroed before DeviceAllocate returns (reference cuda_malloc.cu:97-104 contract);
+//   * device memory comes from a per-device cache of hipMalloc'ed blocks in size bins; a freed block
+//     is fenced with events on every stream the host uses and only reused once the fence has
+//     passed, so the per-batch, per-column alloc/free pattern of the Go host
+//     (query/aql_processor.go:726-804, :1345-1431) never reaches the driver after warm-up and never
+//     synchronises the device; the block is zeroed before DeviceAllocate returns (reference
+//     cuda_malloc.cu:97-104 contract);
 //   * ARES_MEM_POOL=0 switches to plain hipMalloc/hipFree (debugging aid, same semantics).
 // Every Go-facing entry point selects the device itself; the lower-case ones assume the caller
 // (libalgorithm.so) already did (reference cgoutils/memory.h:88-98).
@@ -17,7 +19,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <iterator>
+#include <map>
 #include <mutex>
+#include <unordered_map>
+#include <vector>
 
 #include "ares_memory.h"
 
@@ -61,30 +67,42 @@ bool use_pool() {
   return v;
 }
 
-// One allocation stream per device: DeviceAllocate = hipMallocAsync + hipMemsetAsync + sync on
-// this stream, so the zeroed block is ready for any other stream when the call returns.
+// ---- device memory cache -----------------------------------------------------------------------------
+// The Go host allocates and frees per column, per scratch frame, per batch
+// (query/aql_processor.go:726-804, :1345-1431) and — because cudaFree synchronises the device — may
+// free a buffer right after enqueueing the kernel that reads it (shrinkStackFrame,
+// query/time_series_aggregate.go:756-769).  A drop-in allocator therefore has to (a) make frees
+// cheap and (b) never hand a block out again while work enqueued before its free may still touch it.
+//
+// Design: blocks come from hipMalloc and are cached per device in size bins (1/8-octave steps).
+// DeviceFree records one event on every stream the host uses on that device (the streams made by
+// CreateCudaStream plus the null stream) and parks the block with that fence; DeviceAllocate reuses
+// a parked block of the bin only once its whole fence has completed, zero-fills it on a private
+// stream and waits for the fill.  No driver allocation after warm-up, no device-wide
+// synchronisation ever, and no reliance on cross-stream reuse inside HIP's own stream-ordered pool
+// (which libalgorithm.so uses for its stream-local temporaries only).
+struct ParkedBlock {
+  void *ptr;
+  std::vector<hipEvent_t> fence;
+};
+
 struct DeviceState {
   std::once_flag once;
   hipStream_t allocStream = nullptr;
   hipError_t initError = hipSuccess;
+  std::mutex mu;
+  std::vector<hipStream_t> streams;                      // streams created through CreateCudaStream
+  std::map<size_t, std::vector<ParkedBlock>> bins;       // rounded size -> parked blocks
+  std::unordered_map<void *, size_t> live;               // allocation -> rounded size
+  std::vector<hipEvent_t> freeEvents;
+  size_t parkedBytes = 0;
 };
 DeviceState g_devices[kMaxDevices];
 
 hipError_t device_state(int device, DeviceState **out) {
   if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
   DeviceState &st = g_devices[device];
-  std::call_once(st.once, [&] {
-    hipError_t e = hipStreamCreateWithFlags(&st.allocStream, hipStreamNonBlocking);
-    if (e == hipSuccess && use_pool()) {
-      hipMemPool_t pool;
-      e = hipDeviceGetDefaultMemPool(&pool, device);
-      if (e == hipSuccess) {
-        uint64_t keep = UINT64_MAX;  // never trim: batches re-use the same sizes every ~ms
-        e = hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-      }
-    }
-    st.initError = e;
-  });
+  std::call_once(st.once, [&] { st.initError = hipStreamCreateWithFlags(&st.allocStream, hipStreamNonBlocking); });
   *out = &st;
   return st.initError;
 }
@@ -96,27 +114,132 @@ hipError_t current_device_state(DeviceState **out) {
   return device_state(device, out);
 }
 
+size_t bin_size(size_t bytes) {
+  if (bytes < 256) return 256;
+  const int top = 63 - __builtin_clzll(static_cast<unsigned long long>(bytes));
+  const size_t step = static_cast<size_t>(1) << (top > 3 ? top - 3 : 0);
+  return (bytes + step - 1) / step * step;
+}
+
+bool fence_done(const ParkedBlock &b) {
+  for (hipEvent_t e : b.fence)
+    if (hipEventQuery(e) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+  return true;
+}
+
+// caller holds st->mu
+void recycle_events(DeviceState *st, ParkedBlock &b) {
+  for (hipEvent_t e : b.fence) st->freeEvents.push_back(e);
+  b.fence.clear();
+}
+
+// Releases parked blocks (oldest bins first) until `need` more bytes fit under the cap or nothing
+// is left; used when hipMalloc fails or the cache grows past half of the device.
+void trim(DeviceState *st, size_t keepBytes) {
+  for (auto it = st->bins.begin(); it != st->bins.end() && st->parkedBytes > keepBytes;) {
+    auto &vec = it->second;
+    while (!vec.empty() && st->parkedBytes > keepBytes) {
+      ParkedBlock b = vec.back();
+      vec.pop_back();
+      for (hipEvent_t e : b.fence) (void)hipEventSynchronize(e);
+      recycle_events(st, b);
+      (void)hipFree(b.ptr);
+      st->parkedBytes -= it->first;
+    }
+    it = vec.empty() ? st->bins.erase(it) : std::next(it);
+  }
+}
+
 hipError_t pool_alloc(DeviceState *st, void **p, size_t bytes, bool zero) {
   if (bytes == 0) bytes = 1;
-  hipError_t e;
-  if (use_pool()) {
-    e = hipMallocAsync(p, bytes, st->allocStream);
+  if (!use_pool()) {
+    hipError_t e = hipMalloc(p, bytes);
     if (e != hipSuccess) return e;
-    if (zero) {
-      e = hipMemsetAsync(*p, 0, bytes, st->allocStream);
+    return zero ? hipMemset(*p, 0, bytes) : hipSuccess;
+  }
+  const size_t rounded = bin_size(bytes);
+  void *ptr = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(st->mu);
+    auto it = st->bins.find(rounded);
+    if (it != st->bins.end()) {
+      auto &vec = it->second;
+      for (size_t i = 0; i < vec.size(); i++) {
+        if (fence_done(vec[i])) {
+          ptr = vec[i].ptr;
+          recycle_events(st, vec[i]);
+          vec[i] = vec.back();
+          vec.pop_back();
+          st->parkedBytes -= rounded;
+          break;
+        }
+      }
+    }
+  }
+  if (!ptr) {
+    hipError_t e = hipMalloc(&ptr, rounded);
+    if (e != hipSuccess) {  // out of memory: give the cache back and retry once
+      (void)hipGetLastError();
+      {
+        std::lock_guard<std::mutex> lock(st->mu);
+        trim(st, 0);
+      }
+      e = hipMalloc(&ptr, rounded);
       if (e != hipSuccess) return e;
     }
+  }
+  {
+    std::lock_guard<std::mutex> lock(st->mu);
+    st->live[ptr] = rounded;
+  }
+  *p = ptr;
+  if (zero) {
+    hipError_t e = hipMemsetAsync(ptr, 0, bytes, st->allocStream);
+    if (e != hipSuccess) return e;
     return hipStreamSynchronize(st->allocStream);
   }
-  e = hipMalloc(p, bytes);
-  if (e != hipSuccess) return e;
-  return zero ? hipMemset(*p, 0, bytes) : hipSuccess;
+  return hipSuccess;
 }
 
 hipError_t pool_free(DeviceState *st, void *p) {
   if (p == nullptr) return hipSuccess;
-  if (use_pool()) return hipFreeAsync(p, st->allocStream);
-  return hipFree(p);
+  if (!use_pool()) return hipFree(p);
+  std::lock_guard<std::mutex> lock(st->mu);
+  auto it = st->live.find(p);
+  if (it == st->live.end()) return hipFree(p);  // not ours (allocated before the pool was switched on)
+  const size_t rounded = it->second;
+  st->live.erase(it);
+  ParkedBlock b;
+  b.ptr = p;
+  auto fence_on = [&](hipStream_t s) -> hipError_t {
+    hipEvent_t e;
+    if (!st->freeEvents.empty()) {
+      e = st->freeEvents.back();
+      st->freeEvents.pop_back();
+    } else {
+      hipError_t err = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+      if (err != hipSuccess) return err;
+    }
+    hipError_t err = hipEventRecord(e, s);
+    b.fence.push_back(e);
+    return err;
+  };
+  hipError_t err = fence_on(nullptr);
+  for (hipStream_t s : st->streams)
+    if (err == hipSuccess) err = fence_on(s);
+  if (err != hipSuccess) {  // cannot fence: fall back to the synchronising free of the reference
+    (void)hipGetLastError();
+    recycle_events(st, b);
+    return hipFree(p);
+  }
+  st->bins[rounded].push_back(b);
+  st->parkedBytes += rounded;
+  size_t freeB = 0, totalB = 0;
+  if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && st->parkedBytes > totalB / 2) trim(st, totalB / 4);
+  return hipSuccess;
 }
 
 }  // namespace
@@ -153,6 +276,12 @@ CGoCallResHandle CreateCudaStream(int device) {
   MEM_TRY(hipSetDevice(device), "CreateCudaStream");
   hipStream_t s = nullptr;
   MEM_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "CreateCudaStream");
+  DeviceState *st;
+  MEM_TRY(device_state(device, &st), "CreateCudaStream");
+  {
+    std::lock_guard<std::mutex> lock(st->mu);
+    st->streams.push_back(s);  // frees are fenced against every stream the host works on
+  }
   return ok(reinterpret_cast<void *>(s));
 }
 
@@ -164,7 +293,22 @@ CGoCallResHandle WaitForCudaStream(void *s, int device) {
 
 CGoCallResHandle DestroyCudaStream(void *s, int device) {
   MEM_TRY(hipSetDevice(device), "DestroyCudaStream");
-  if (s) MEM_TRY(hipStreamDestroy(reinterpret_cast<hipStream_t>(s)), "DestroyCudaStream");
+  if (s) {
+    DeviceState *st;
+    MEM_TRY(device_state(device, &st), "DestroyCudaStream");
+    {
+      std::lock_guard<std::mutex> lock(st->mu);
+      for (size_t i = 0; i < st->streams.size(); i++)
+        if (st->streams[i] == reinterpret_cast<hipStream_t>(s)) {
+          st->streams[i] = st->streams.back();
+          st->streams.pop_back();
+          break;
+        }
+    }
+    // fences already recorded on this stream stay valid: destruction completes its queued work
+    MEM_TRY(hipStreamSynchronize(reinterpret_cast<hipStream_t>(s)), "DestroyCudaStream");
+    MEM_TRY(hipStreamDestroy(reinterpret_cast<hipStream_t>(s)), "DestroyCudaStream");
+  }
   return ok();
 }
 

@@ -47,13 +47,13 @@ def run_query(be, plan, batches):
     return out, calls
 
 
-def run_query_native(be, plan, batches):
+def run_query_native(be, plan, batches, stream=None):
     """The same query through the C++ host driver (libaresdriver.so) instead of the Python mirror."""
     from .driver import NativeQuery
     names = list(batches[0][0].keys())
-    q = NativeQuery(be, plan, names)
+    q = NativeQuery(be, plan, names, stream=stream)
     for cols, valid in batches:
-        dev = {k: DeviceColumn(be, t, v, valid=valid[k]) for k, (t, v) in cols.items()}
+        dev = {k: DeviceColumn(be, t, v, valid=valid[k], stream=stream) for k, (t, v) in cols.items()}
         n = len(next(iter(cols.values()))[1])
         q.run({k: d.vp for k, d in dev.items()}, n)
         for d in dev.values():

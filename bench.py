@@ -129,8 +129,15 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     tdev = torch.device(f"cuda:{local_rank}")
-    if world > 1:
+    # ARES_BENCH_FORCE_DIST=1: exercise the multi-rank code path (RCCL init, merge) with one rank
+    force_dist = os.environ.get("ARES_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        if os.environ.get("NCCL_DEBUG", "").upper() in ("", "VERSION"):
+            os.environ["NCCL_DEBUG"] = "WARN"  # keep RCCL's version banner out of stdout (one JSON line)
         dist.init_process_group("nccl", device_id=tdev)
 
     be = abi.load_hip_backend()  # raises if the HIP libraries are missing — no fallback
@@ -146,14 +153,14 @@ def main():
     def step():
         ctx = run_shard(be, plan, batches, local_rank, stream)
         merged = None
-        if world > 1:
+        if world > 1 or force_dist:
             from aresdb_amd.shard_merge import merge_shard_results
             merged = merge_shard_results(ctx, tdev)
         return ctx, merged
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or force_dist:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -175,7 +182,7 @@ def main():
         be.profiler_enable(False)
     else:
         kernels = {}
-    if world > 1:
+    if world > 1 or force_dist:
         dist.barrier()
         t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -253,7 +260,7 @@ def main():
                                    f"{args.null_fraction:.0%} nulls, shard resident in HBM",
                        "rows_per_gpu": rows, "batch_rows": batch_rows, "batches": len(batches),
                        "groups_per_shard": groups, "merged_groups": merged_groups, "rows_after_filter": kept,
-                       "parallelism": f"{world} shard(s), one per GPU" + (", RCCL all_gather merge" if world > 1 else "")},
+                       "parallelism": f"{world} shard(s), one per GPU" + (", RCCL all_gather merge" if (world > 1 or force_dist) else "")},
             "rows_per_sec_per_gpu": value / world,
             "algorithmic_GBps_end_to_end": value / world * bytes_per_row / 1e9,
             "check_sum_of_measures": "ok" if check else f"MISMATCH got {got} want {want}",
@@ -262,7 +269,7 @@ def main():
         print(json.dumps(out), flush=True)
         if not check:
             sys.exit(1)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

@@ -221,3 +221,35 @@ def test_fused_extension_declines_unsupported_plans():
     plan.use_fused_extension = False
     want, _ = smoke.run_query(H.oracle_backend(), plan, data)
     smoke.compare_results(got, want)
+
+
+@pytest.mark.gpu
+def test_concurrent_queries_on_two_streams():
+    """Two queries at once from two host threads, each on its own stream (the Go host runs queries
+    on separate goroutines and overlaps batch k+1's transfer with batch k's execution,
+    query/aql_processor.go:860-881): allocator, temporaries and kernels must not interfere."""
+    import threading
+    hip = H.hip_backend()
+    rng = np.random.default_rng(77)
+    datasets = [[smoke.synth_batch(rng, 200000, null_fraction=0.01) for _ in range(4)] for _ in range(2)]
+    plans = [smoke.c3_plan(True), smoke.c3_plan(False)]
+    want = [smoke.run_query(H.oracle_backend(), plans[i], datasets[i])[0] for i in range(2)]
+    streams = [hip.call("CreateCudaStream", 0) for _ in range(2)]
+    for attempt in range(3):
+        got, errs = [None, None], []
+
+        def work(i):
+            try:
+                got[i] = smoke.run_query_native(hip, plans[i], datasets[i], stream=streams[i])[0]
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+        threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errs, errs
+        for i in range(2):
+            smoke.compare_results(got[i], want[i])
+    for s_ in streams:
+        hip.call("DestroyCudaStream", s_, 0)

@@ -295,6 +295,7 @@ constexpr int kQuadFlushAt = kSlots * 3 / 4 - kQuadTile;  // = 2048
 template <int ND_, int VW>
 struct DimVectorSource {
   static constexpr int ND = ND_;
+  static constexpr bool kPairDirect = true;  // registers allow two tiles per partition sort
   using Raw = QuadRows<ND_>;
   const uint8_t *dimValues;
   size_t capacity;
@@ -420,11 +421,16 @@ __device__ __forceinline__ void partition_body(Source &src, const AggSpec &a, in
       }
       return more;
     }
-    // ---- DIRECT: rows -> records, counting-sorted by partition in LDS, coalesced write-back ----
-    if (!more) return false;
-    uint32_t rank[4];
+    return more;  // DIRECT tiles are handled in pairs by direct_pair below
+  };
+
+  // ---- DIRECT: rows -> records, counting-sorted by partition in LDS, coalesced write-back ----
+  // Two tiles (8192 rows, the whole 128 KiB stage) per sort: one cursor reservation per partition
+  // and one set of barriers per 8192 rows, runs of ~8192 / numParts records per partition.
+  auto direct_pair = [&](const uint32_t (&h)[8], const uint64_t (&v)[8], const uint32_t alive, const uint32_t (&rowId)[8]) {
+    uint32_t rank[8];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < 8; j++) {
       rank[j] = 0;
       if ((alive >> j) & 1u) {
         const uint32_t p = pb ? h[j] >> (32 - pb) : 0u;
@@ -453,11 +459,11 @@ __device__ __forceinline__ void partition_body(Source &src, const AggSpec &a, in
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < 8; j++) {
       if ((alive >> j) & 1u) {
         const uint32_t p = pb ? h[j] >> (32 - pb) : 0u;
         const uint32_t at = sPartLocal[p] + rank[j];
-        sKeys[at] = (static_cast<uint64_t>(h[j]) << 32) | (src.rowBase + static_cast<uint32_t>(i0 + j));
+        sKeys[at] = (static_cast<uint64_t>(h[j]) << 32) | rowId[j];
         sVals[at] = v[j];
       }
     }
@@ -466,34 +472,89 @@ __device__ __forceinline__ void partition_body(Source &src, const AggSpec &a, in
       const uint32_t staged = sStaged;
       for (uint32_t k = threadIdx.x; k < staged; k += kThreads) {
         const uint64_t key = sKeys[k];
-        const uint64_t v = sVals[k];
+        const uint64_t val = sVals[k];
         const uint32_t p = pb ? static_cast<uint32_t>(key >> (64 - pb)) : 0u;
         const uint64_t at = static_cast<uint64_t>(sPartBase[p]) + (k - sPartLocal[p]);
         if (ws.debug & 2) {
         } else if (at < ws.cap) {
           ws.records[static_cast<uint64_t>(p) * ws.cap + at] =
-              make_uint4(static_cast<uint32_t>(key), static_cast<uint32_t>(key >> 32), static_cast<uint32_t>(v),
-                         static_cast<uint32_t>(v >> 32));
+              make_uint4(static_cast<uint32_t>(key), static_cast<uint32_t>(key >> 32), static_cast<uint32_t>(val),
+                         static_cast<uint32_t>(val >> 32));
         } else {
           *ws.overflow = 1u;
         }
       }
     }
-    __syncthreads();  // the stage is reused by the next tile
-    return true;
+    __syncthreads();  // the stage is reused by the next pair
   };
 
-  // One register buffer is enough to overlap HBM latency with the LDS work: the tile's rows are
-  // reduced to (hash, measure) pairs first, then the NEXT tile's loads are issued into the same
-  // registers before the current tile goes through the table / the partition sort.
+  // TABLE mode: one register buffer is enough to overlap HBM latency with the LDS work — the tile's
+  // rows are reduced to (hash, measure) pairs first, then the NEXT tile's loads are issued into the
+  // same registers before the current tile goes through the table.
   for (;;) {
     uint32_t h[4];
     uint64_t v[4];
     const uint32_t alive = src.rows(buf, tile * kQuadTile + 4 * static_cast<int64_t>(threadIdx.x), length, h, v);  // 0 past the end
     const int64_t next = tile + gridDim.x;
     if (next < numTiles) src.load(buf, next * kQuadTile + 4 * threadIdx.x, length);
-    if (!step(h, v, alive, tile)) break;
+    const bool more = step(h, v, alive, tile);
     tile = next;
+    if (!more) return;
+    if (direct) break;
+  }
+  if constexpr (Source::kPairDirect) {
+    // DIRECT mode: `buf` holds tile `tile` (when it exists); a second buffer takes its partner.
+    typename Source::Raw buf2;
+    {
+      const int64_t partner = tile + gridDim.x;
+      if (partner < numTiles) src.load(buf2, partner * kQuadTile + 4 * threadIdx.x, length);
+    }
+    while (tile < numTiles) {
+      const int64_t tileB = tile + gridDim.x;
+      const int64_t i0A = tile * kQuadTile + 4 * static_cast<int64_t>(threadIdx.x);
+      const int64_t i0B = tileB * kQuadTile + 4 * static_cast<int64_t>(threadIdx.x);
+      uint32_t h[8], rowId[8];
+      uint64_t v[8];
+      uint32_t alive;
+      {
+        uint32_t hA[4], hB[4];
+        uint64_t vA[4], vB[4];
+        const uint32_t aliveA = src.rows(buf, i0A, length, hA, vA);
+        const uint32_t aliveB = tileB < numTiles ? src.rows(buf2, i0B, length, hB, vB) : 0u;
+        alive = aliveA | (aliveB << 4);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          h[j] = hA[j]; v[j] = vA[j]; rowId[j] = src.rowBase + static_cast<uint32_t>(i0A + j);
+          h[4 + j] = hB[j]; v[4 + j] = vB[j]; rowId[4 + j] = src.rowBase + static_cast<uint32_t>(i0B + j);
+        }
+      }
+      const int64_t nextA = tileB + gridDim.x, nextB = nextA + gridDim.x;
+      if (nextA < numTiles) src.load(buf, nextA * kQuadTile + 4 * threadIdx.x, length);
+      if (nextB < numTiles) src.load(buf2, nextB * kQuadTile + 4 * threadIdx.x, length);
+      direct_pair(h, v, alive, rowId);
+      tile = nextA;
+    }
+  } else {
+    while (tile < numTiles) {  // one tile per sort
+      const int64_t i0 = tile * kQuadTile + 4 * static_cast<int64_t>(threadIdx.x);
+      uint32_t h[8], rowId[8];
+      uint64_t v[8];
+      uint32_t alive;
+      {
+        uint32_t hA[4];
+        uint64_t vA[4];
+        alive = src.rows(buf, i0, length, hA, vA);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          h[j] = hA[j]; v[j] = vA[j]; rowId[j] = src.rowBase + static_cast<uint32_t>(i0 + j);
+          h[4 + j] = 0; v[4 + j] = 0; rowId[4 + j] = 0;
+        }
+      }
+      const int64_t next = tile + gridDim.x;
+      if (next < numTiles) src.load(buf, next * kQuadTile + 4 * threadIdx.x, length);
+      direct_pair(h, v, alive, rowId);
+      tile = next;
+    }
   }
 }
 
@@ -564,6 +625,7 @@ __device__ __forceinline__ uint64_t fused_measure_bits(const FusedPlanD &p, DVal
 template <int ND_>
 struct FusedSource {
   static constexpr int ND = ND_;
+  static constexpr bool kPairDirect = false;  // expression evaluation needs the registers
   static constexpr int NC = ND_ + 2;  // distinct columns a plan of ND dimensions may touch
   struct Raw {
     uint32_t v[NC][4];

@@ -209,9 +209,18 @@ def main():
     roofline = None
     if dominant:
         name, (launches, ms) = dominant
+        # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE /
+        # WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes), when they were taken at this batch size
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if pmc.get("rows_per_batch") == batch_rows and name in pmc["kernels"]:
+                traffic = pmc["kernels"][name]["hbm_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
         achieved = bytes_per_row * total_rows_rank / (ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                    "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                     "algorithmic_bytes_per_launch": bytes_per_row * total_rows_rank / launches,
                     "avg_launch_ms": ms / launches, "launches": launches,
                     "note": "algorithmic = 20 B/row of compulsory column reads (+5 validity bits/row), "

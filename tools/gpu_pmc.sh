@@ -14,6 +14,6 @@ for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_
   timeout 600 rocprofv3 --kernel-trace --pmc $pmc --output-format csv -d $OUT/pass$i -o p -- python $R/tools/pmc_driver.py $ROWS 2 > $OUT/pass$i.log 2>&1
   echo "pass $i ($pmc) exit $?"
 done
-python $R/tools/pmc_summary.py $OUT > $OUT/summary.md 2>&1
+python $R/tools/pmc_summary.py $OUT $ROWS > $OUT/summary.md 2>&1
 cat $OUT/summary.md
 find $OUT -name '*kernel_trace.csv' -delete

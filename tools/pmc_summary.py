@@ -26,3 +26,17 @@ print()
 print("Values are per-dispatch averages.  FETCH_SIZE / WRITE_SIZE are in KiB as rocprofv3 reports them;")
 print("MI355X_MICROARCH.md: on gfx950 FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads, i.e.")
 print("HBM read bytes = 2 x FETCH_SIZE x 1024 for 16 B/lane streams (narrower accesses uncalibrated).")
+
+# machine-readable per-launch HBM traffic (gfx950 correction applied to the read side)
+import json
+out = {}
+for k in sorted(acc):
+    f = acc[k].get("FETCH_SIZE"); w = acc[k].get("WRITE_SIZE")
+    if f is None or w is None:
+        continue
+    fpl = f / calls[k]["FETCH_SIZE"]; wpl = w / calls[k]["WRITE_SIZE"]
+    out[k] = {"fetch_size_KiB_per_launch": fpl, "write_size_KiB_per_launch": wpl,
+              "hbm_bytes_per_launch": 2 * fpl * 1024 + wpl * 1024,
+              "note": "2 x FETCH_SIZE (gfx950 counts 64 B per 128-B request on wide reads) + WRITE_SIZE"}
+rows = int(sys.argv[2]) if len(sys.argv) > 2 else 67108864
+json.dump({"rows_per_batch": rows, "kernels": out}, open(os.path.join(root, "traffic.json"), "w"), indent=1)

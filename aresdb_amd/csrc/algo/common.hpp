@@ -33,10 +33,18 @@ inline void hip_check(hipError_t e, const char *what) {
 // Checks the launch that was just enqueued (reference CheckCUDAError, utils.cu:44-59).
 inline void check_launch(const char *what) { hip_check(hipGetLastError(), what); }
 
-#define ARES_ABI_BEGIN(device)                         \
+// launches the transforms held back for cross-call fusion on `device` (transform.hip)
+void flush_deferred(int device);
+
+// NOFLUSH: only for the transform entry points, which decide themselves whether to queue or flush
+#define ARES_ABI_BEGIN_NOFLUSH(device)                 \
   CGoCallResHandle resHandle = {nullptr, nullptr};     \
   try {                                                \
     ares::hip_check(hipSetDevice(device), "hipSetDevice");
+
+#define ARES_ABI_BEGIN(device)     \
+  ARES_ABI_BEGIN_NOFLUSH(device)   \
+  ares::flush_deferred(device);
 
 #define ARES_ABI_END(name)                                            \
   }                                                                   \

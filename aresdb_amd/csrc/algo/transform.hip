@@ -12,7 +12,14 @@
 //     stably and IN PLACE without a second read of the predicate vector.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
+#include <map>
+#include <mutex>
+#include <string>
 #include <vector>
+
+#include "ares_extensions.h"
 
 #include "binding.hpp"
 #include "common.hpp"
@@ -390,14 +397,13 @@ __global__ __launch_bounds__(kBlock) void filter_kernel(EvalParams p, uint8_t *p
 // wider quad re-reads single bytes.  Reading one byte past the bitmap is safe: in a mode-2 slice
 // the values follow the bitmap inside the same allocation.
 template <int QUADS>
-__device__ __forceinline__ void load_quads(const FastOperands &f, int64_t quad0, int n, uint32_t (&rows)[QUADS][4],
-                                           uint32_t (&vals)[QUADS][4], uint32_t (&okb)[QUADS]) {
+__device__ __forceinline__ void load_rows(const uint32_t *idx, int pad, int64_t quad0, int n, uint32_t (&rows)[QUADS][4]) {
 #pragma unroll
   for (int q = 0; q < QUADS; q++) {
-    const int64_t i0 = (quad0 + static_cast<int64_t>(q) * kBlock) * 4 - f.pad;
+    const int64_t i0 = (quad0 + static_cast<int64_t>(q) * kBlock) * 4 - pad;
     if (i0 >= 0 && i0 + 3 < n) {
-      if (f.idx) {
-        const U32x4 r = *reinterpret_cast<const U32x4 *>(f.idx + i0);
+      if (idx) {
+        const U32x4 r = *reinterpret_cast<const U32x4 *>(idx + i0);
 #pragma unroll
         for (int j = 0; j < 4; j++) rows[q][j] = r.v[j];
       } else {
@@ -409,11 +415,15 @@ __device__ __forceinline__ void load_quads(const FastOperands &f, int64_t quad0,
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const int64_t i = i0 + j;
-        rows[q][j] = (i >= 0 && i < n) ? (f.idx ? f.idx[i] : static_cast<uint32_t>(i)) : 0u;
+        rows[q][j] = (i >= 0 && i < n) ? (idx ? idx[i] : static_cast<uint32_t>(i)) : 0u;
       }
     }
   }
-  uint32_t window[QUADS];
+}
+
+template <int QUADS>
+__device__ __forceinline__ void issue_values(const FastOperands &f, const uint32_t (&rows)[QUADS][4], uint32_t (&vals)[QUADS][4],
+                                             uint32_t (&window)[QUADS]) {
 #pragma unroll
   for (int q = 0; q < QUADS; q++) {
     const uint32_t r0 = rows[q][0];
@@ -428,9 +438,15 @@ __device__ __forceinline__ void load_quads(const FastOperands &f, int64_t quad0,
     window[q] = 0xFFFFu;
     if (f.nulls) window[q] = reinterpret_cast<const PU16 *>(f.nulls + ((r0 + f.bitOff) >> 3))->v;
   }
+}
+
+template <int QUADS>
+__device__ __forceinline__ void extract_valid(const FastOperands &f, int pad, int64_t quad0, int n,
+                                              const uint32_t (&rows)[QUADS][4], const uint32_t (&window)[QUADS],
+                                              uint32_t (&okb)[QUADS]) {
 #pragma unroll
   for (int q = 0; q < QUADS; q++) {
-    const int64_t i0 = (quad0 + static_cast<int64_t>(q) * kBlock) * 4 - f.pad;
+    const int64_t i0 = (quad0 + static_cast<int64_t>(q) * kBlock) * 4 - pad;
     const uint32_t first = (rows[q][0] + f.bitOff) & ~7u;  // bit position of the window's bit 0
     okb[q] = 0;
 #pragma unroll
@@ -446,73 +462,128 @@ __device__ __forceinline__ void load_quads(const FastOperands &f, int64_t quad0,
   }
 }
 
+template <int QUADS>
+__device__ __forceinline__ void load_values(const FastOperands &f, int pad, int64_t quad0, int n,
+                                            const uint32_t (&rows)[QUADS][4], uint32_t (&vals)[QUADS][4],
+                                            uint32_t (&okb)[QUADS]) {
+  uint32_t window[QUADS];
+  issue_values<QUADS>(f, rows, vals, window);
+  extract_valid<QUADS>(f, pad, quad0, n, rows, window, okb);
+}
+
+template <int QUADS>
+__device__ __forceinline__ void load_quads(const FastOperands &f, int64_t quad0, int n, uint32_t (&rows)[QUADS][4],
+                                           uint32_t (&vals)[QUADS][4], uint32_t (&okb)[QUADS]) {
+  load_rows<QUADS>(f.idx, f.pad, quad0, n, rows);
+  load_values<QUADS>(f, f.pad, quad0, n, rows, vals, okb);
+}
+
 // ---------------------------------------------------------------------------------------------
 // fast transform: 32-bit column (x constant) -> 4-byte dimension / scratch vector or measure
 // ---------------------------------------------------------------------------------------------
 constexpr int kTQ = 4;  // quads per lane per tile: 16 rows per lane, 4096 rows per workgroup tile
 
-__global__ __launch_bounds__(kBlock) void transform_fast_kernel(FastOperands f, SinkD s, int n, int64_t numQuads) {
+struct __attribute__((packed, aligned(1))) PU32s { uint32_t v; };
+
+// evaluates and stores one tile (kTQ quads per lane) of one transform whose rows are already loaded;
+// ALIGNED_NULLS: the quad grid was shifted so that the 4 validity bytes form an aligned dword
+template <int QUADS, bool ALIGNED_NULLS>
+__device__ __forceinline__ void store_tile(const FastOperands &f, const SinkD &s, int pad, int64_t quad0, int n,
+                                           const uint32_t (&rows)[QUADS][4], const uint32_t (&vals)[QUADS][4],
+                                           const uint32_t (&okb)[QUADS]) {
   DVal y;
   y.bits = f.bbits;
   y.ok = f.bok;
   y = cvt32(y, f.bkind, f.I);
   const uint32_t ymag = (f.I == K_I32 && static_cast<int32_t>(y.bits) < 0) ? 0u - y.bits : y.bits;
   const FastDivisor fd = make_fast_divisor(ymag);
+#pragma unroll
+  for (int q = 0; q < QUADS; q++) {
+    const int64_t i0 = (quad0 + static_cast<int64_t>(q) * kBlock) * 4 - pad;
+    DVal r[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) r[j] = eval_fast(f, vals[q][j], (okb[q] >> j) & 1u, y, fd);
+    const bool full = i0 >= 0 && i0 + 3 < n;
+    if (!full) {  // ragged first / last quad (or past the end): the generic element-wise sink
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int64_t i = i0 + j;
+        if (i >= 0 && i < n) sink_store32(s, static_cast<uint32_t>(i), rows[q][j], r[j], f.rk);
+      }
+    } else if (s.type == SINK_MEASURE) {
+      if (s.width == 8) {
+        uint64_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          if (!r[j].ok) o[j] = s.identity;
+          else if (s.dtype == Float64) o[j] = static_cast<uint64_t>(__double_as_longlong(to_double32(r[j], f.rk)));
+          else o[j] = static_cast<uint64_t>(f.rk == K_F32 ? static_cast<int64_t>(bits_f(r[j].bits))
+                                            : f.rk == K_I32 ? static_cast<int64_t>(static_cast<int32_t>(r[j].bits))
+                                                            : static_cast<int64_t>(r[j].bits));
+        }
+        U64x2 lo, hi;
+        lo.v[0] = o[0]; lo.v[1] = o[1]; hi.v[0] = o[2]; hi.v[1] = o[3];
+        U64x2 *dst = reinterpret_cast<U64x2 *>(s.values + static_cast<size_t>(8) * i0);
+        dst[0] = lo;
+        dst[1] = hi;
+      } else {
+        U32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          if (!r[j].ok) o.v[j] = static_cast<uint32_t>(s.identity);
+          else o.v[j] = cvt32(r[j], f.rk, s.dtype == Int32 ? K_I32 : s.dtype == Uint32 ? K_U32 : K_F32).bits;
+        }
+        *reinterpret_cast<U32x4 *>(s.values + static_cast<size_t>(4) * i0) = o;
+      }
+    } else {  // 4-byte dimension / scratch value + one validity byte per row
+      const int ok_kind = s.dtype == Int32 ? K_I32 : s.dtype == Uint32 ? K_U32 : K_F32;
+      U32x4 o;
+      uint32_t nb = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        o.v[j] = cvt32(r[j], f.rk, ok_kind).bits;
+        nb |= (r[j].ok ? 1u : 0u) << (8 * j);
+      }
+      *reinterpret_cast<U32x4 *>(s.values + static_cast<size_t>(4) * i0) = o;
+      if (ALIGNED_NULLS) *reinterpret_cast<uint32_t *>(s.nulls + i0) = nb;  // pad = nulls address & 3
+      else reinterpret_cast<PU32s *>(s.nulls + i0)->v = nb;                // byte-aligned dword store
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void transform_fast_kernel(FastOperands f, SinkD s, int n, int64_t numQuads) {
   const int64_t tileQuads = static_cast<int64_t>(kBlock) * kTQ;
   for (int64_t tq = static_cast<int64_t>(blockIdx.x) * tileQuads; tq < numQuads;
        tq += static_cast<int64_t>(gridDim.x) * tileQuads) {
     uint32_t rows[kTQ][4], vals[kTQ][4], okb[kTQ];
-    load_quads<kTQ>(f, tq + threadIdx.x, n, rows, vals, okb);
-#pragma unroll
-    for (int q = 0; q < kTQ; q++) {
-      const int64_t i0 = (tq + threadIdx.x + static_cast<int64_t>(q) * kBlock) * 4 - f.pad;
-      DVal r[4];
-#pragma unroll
-      for (int j = 0; j < 4; j++) r[j] = eval_fast(f, vals[q][j], (okb[q] >> j) & 1u, y, fd);
-      const bool full = i0 >= 0 && i0 + 3 < n;
-      if (!full) {  // ragged first / last quad (or past the end): the generic element-wise sink
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const int64_t i = i0 + j;
-          if (i >= 0 && i < n) sink_store32(s, static_cast<uint32_t>(i), rows[q][j], r[j], f.rk);
-        }
-      } else if (s.type == SINK_MEASURE) {
-        if (s.width == 8) {
-          uint64_t o[4];
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            if (!r[j].ok) o[j] = s.identity;
-            else if (s.dtype == Float64) o[j] = static_cast<uint64_t>(__double_as_longlong(to_double32(r[j], f.rk)));
-            else o[j] = static_cast<uint64_t>(f.rk == K_F32 ? static_cast<int64_t>(bits_f(r[j].bits))
-                                              : f.rk == K_I32 ? static_cast<int64_t>(static_cast<int32_t>(r[j].bits))
-                                                              : static_cast<int64_t>(r[j].bits));
-          }
-          U64x2 lo, hi;
-          lo.v[0] = o[0]; lo.v[1] = o[1]; hi.v[0] = o[2]; hi.v[1] = o[3];
-          U64x2 *dst = reinterpret_cast<U64x2 *>(s.values + static_cast<size_t>(8) * i0);
-          dst[0] = lo;
-          dst[1] = hi;
-        } else {
-          U32x4 o;
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            if (!r[j].ok) o.v[j] = static_cast<uint32_t>(s.identity);
-            else o.v[j] = cvt32(r[j], f.rk, s.dtype == Int32 ? K_I32 : s.dtype == Uint32 ? K_U32 : K_F32).bits;
-          }
-          *reinterpret_cast<U32x4 *>(s.values + static_cast<size_t>(4) * i0) = o;
-        }
-      } else {  // 4-byte dimension / scratch value + one validity byte per row
-        const int ok_kind = s.dtype == Int32 ? K_I32 : s.dtype == Uint32 ? K_U32 : K_F32;
-        U32x4 o;
-        uint32_t nb = 0;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          o.v[j] = cvt32(r[j], f.rk, ok_kind).bits;
-          nb |= (r[j].ok ? 1u : 0u) << (8 * j);
-        }
-        *reinterpret_cast<U32x4 *>(s.values + static_cast<size_t>(4) * i0) = o;
-        *reinterpret_cast<uint32_t *>(s.nulls + i0) = nb;  // aligned: pad = nulls address & 3
-      }
+    load_rows<kTQ>(f.idx, f.pad, tq + threadIdx.x, n, rows);
+    load_values<kTQ>(f, f.pad, tq + threadIdx.x, n, rows, vals, okb);
+    store_tile<kTQ, true>(f, s, f.pad, tq + threadIdx.x, n, rows, vals, okb);
+  }
+}
+
+// Several transforms of one batch over the same index vector in ONE pass (cross-call fusion, see
+// include/ares_extensions.h): the index vector is read once per tile, each job then reads its own
+// column and writes its own sink.  The quad grid is unshifted (pad 0): validity bytes use
+// byte-aligned dword stores.  (Measured: running the jobs one after the other per tile, 16 rows per
+// lane each, beats issuing every job's loads up front — 4.4 vs 3.2 TB/s on BASELINE config C3.)
+constexpr int kMaxMultiJobs = 8;
+struct MultiJobs {
+  int count;
+  FastOperands f[kMaxMultiJobs];
+  SinkD s[kMaxMultiJobs];
+};
+
+__global__ __launch_bounds__(kBlock) void transform_multi_kernel(MultiJobs jobs, const uint32_t *idx, int n, int64_t numQuads) {
+  const int64_t tileQuads = static_cast<int64_t>(kBlock) * kTQ;
+  for (int64_t tq = static_cast<int64_t>(blockIdx.x) * tileQuads; tq < numQuads;
+       tq += static_cast<int64_t>(gridDim.x) * tileQuads) {
+    uint32_t rows[kTQ][4];
+    load_rows<kTQ>(idx, 0, tq + threadIdx.x, n, rows);
+    for (int j = 0; j < jobs.count; j++) {
+      uint32_t vals[kTQ][4], okb[kTQ];
+      load_values<kTQ>(jobs.f[j], 0, tq + threadIdx.x, n, rows, vals, okb);
+      store_tile<kTQ, false>(jobs.f[j], jobs.s[j], 0, tq + threadIdx.x, n, rows, vals, okb);
     }
   }
 }
@@ -632,6 +703,106 @@ __global__ __launch_bounds__(kBlock) void filter_fast_kernel(FastOperands f, uin
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+
+// ---------------------------------------------------------------------------------------------
+// cross-call fusion: root transforms are queued per (device, stream) and launched together
+// ---------------------------------------------------------------------------------------------
+// Contract and flush points: include/ares_extensions.h.  A queue holds jobs that share the index
+// vector and length; a job whose buffers overlap a queued job's (read-after-write or
+// write-after-anything) forces the queue out first, so the fused launch never reorders dependent
+// work.
+namespace {
+struct ByteRange {
+  const uint8_t *lo, *hi;
+  bool overlaps(const ByteRange &o) const { return lo < o.hi && o.lo < hi; }
+};
+struct PendingQueue {
+  MultiJobs jobs;
+  const uint32_t *idx = nullptr;
+  int n = 0;
+  std::vector<ByteRange> reads, writes;
+};
+std::mutex g_deferMutex;
+std::map<std::pair<int, hipStream_t>, PendingQueue> g_pending;
+
+// registers the flush hook with the sibling libmem.so; false = deferral is off for this process
+bool defer_available() {
+  static const bool ok = [] {
+    const char *e = getenv("ARES_DEFER");
+    if (e && e[0] == '0') return false;
+    Dl_info info;
+    if (!dladdr(reinterpret_cast<void *>(&AresFlushDeferred), &info) || !info.dli_fname) return false;
+    std::string path(info.dli_fname);
+    const size_t slash = path.rfind('/');
+    path = (slash == std::string::npos ? std::string(".") : path.substr(0, slash)) + "/libmem.so";
+    void *h = dlopen(path.c_str(), RTLD_NOW | RTLD_NOLOAD);  // only if the host already uses it
+    if (!h) return false;
+    auto set = reinterpret_cast<void (*)(void (*)(int))>(dlsym(h, "AresMemSetFlushHook"));
+    if (!set) return false;
+    set(&AresFlushDeferred);
+    return true;
+  }();
+  return ok;
+}
+
+// caller holds g_deferMutex and has selected the device
+void launch_queue(hipStream_t stream, PendingQueue &q) {
+  if (q.jobs.count == 0) return;
+  const int64_t numQuads = (static_cast<int64_t>(q.n) + 3) / 4;
+  const int64_t tiles = (numQuads + kBlock * kTQ - 1) / (kBlock * kTQ);
+  if (q.jobs.count == 1) {
+    FastOperands f = q.jobs.f[0];
+    f.idx = q.idx;
+    f.pad = q.jobs.s[0].type == SINK_MEASURE ? 0 : static_cast<int>(reinterpret_cast<uintptr_t>(q.jobs.s[0].nulls) & 3);
+    const int64_t nq = (static_cast<int64_t>(q.n) + f.pad + 3) / 4;
+    const int64_t t1 = (nq + kBlock * kTQ - 1) / (kBlock * kTQ);
+    ARES_LAUNCH("transform_fast_kernel", transform_fast_kernel, capped_grid(t1, 256 * 16), kBlock, stream, f, q.jobs.s[0], q.n, nq);
+  } else {
+    ARES_LAUNCH("transform_multi_kernel", transform_multi_kernel, capped_grid(tiles, 256 * 16), kBlock, stream, q.jobs, q.idx,
+                q.n, numQuads);
+  }
+  q.jobs.count = 0;
+  q.reads.clear();
+  q.writes.clear();
+}
+}  // namespace
+
+void flush_deferred(int device) {
+  std::lock_guard<std::mutex> lock(g_deferMutex);
+  for (auto &kv : g_pending)
+    if (kv.first.first == device) launch_queue(kv.first.second, kv.second);
+}
+
+// Queues one fast-path transform; returns false when deferral is unavailable (the caller launches it).
+static bool defer_transform(int device, hipStream_t stream, const FastOperands &f, const SinkD &s, int n, uint32_t colRows) {
+  if (!defer_available()) return false;
+  std::lock_guard<std::mutex> lock(g_deferMutex);
+  // everything pending on OTHER streams of the device is unrelated; only this stream's queue matters
+  PendingQueue &q = g_pending[{device, stream}];
+  ByteRange rv{reinterpret_cast<const uint8_t *>(f.vals), reinterpret_cast<const uint8_t *>(f.vals) + 4ull * colRows};
+  ByteRange rn{f.nulls, f.nulls ? f.nulls + (static_cast<uint64_t>(colRows) + f.bitOff + 7) / 8 + 2 : f.nulls};
+  ByteRange ri{reinterpret_cast<const uint8_t *>(f.idx), reinterpret_cast<const uint8_t *>(f.idx) + (f.idx ? 4ull * n : 0)};
+  ByteRange wv{s.values, s.values + static_cast<uint64_t>(s.width) * n};
+  ByteRange wn{s.nulls, s.nulls ? s.nulls + n : s.nulls};
+  bool conflict = q.jobs.count == kMaxMultiJobs || (q.jobs.count > 0 && (q.idx != f.idx || q.n != n));
+  for (const ByteRange &w : q.writes) conflict = conflict || w.overlaps(rv) || w.overlaps(rn) || w.overlaps(ri) || w.overlaps(wv) || w.overlaps(wn);
+  for (const ByteRange &r : q.reads) conflict = conflict || r.overlaps(wv) || r.overlaps(wn);
+  if (conflict) launch_queue(stream, q);
+  q.idx = f.idx;
+  q.n = n;
+  FastOperands fq = f;
+  fq.pad = 0;
+  q.jobs.f[q.jobs.count] = fq;
+  q.jobs.s[q.jobs.count] = s;
+  q.jobs.count++;
+  q.reads.push_back(rv);
+  if (f.nulls) q.reads.push_back(rn);
+  if (f.idx) q.reads.push_back(ri);
+  q.writes.push_back(wv);
+  if (s.nulls) q.writes.push_back(wn);
+  return true;
+}
+
 static bool fast_sink(const SinkD &s) {
   const bool four = s.dtype == Int32 || s.dtype == Uint32 || s.dtype == Float32;
   if (s.type == SINK_MEASURE) return s.agg != AGGR_AVG_FLOAT && s.baseCounts == nullptr;
@@ -639,8 +810,11 @@ static bool fast_sink(const SinkD &s) {
 }
 
 static int run_transform(const InputVector *ins, int arity, const OutputVector &output, uint32_t *indexVector,
-                         int n, uint32_t *baseCounts, uint32_t startCount, int functor, hipStream_t stream) {
-  if (n <= 0) return n < 0 ? 0 : n;
+                         int n, uint32_t *baseCounts, uint32_t startCount, int functor, hipStream_t stream, int device) {
+  if (n <= 0) {
+    flush_deferred(device);
+    return n < 0 ? 0 : n;
+  }
   EvalParams p;
   SinkD s;
   CallTemps temps;
@@ -648,7 +822,11 @@ static int run_transform(const InputVector *ins, int arity, const OutputVector &
   bind_sink(output, baseCounts, s);
   if (s.type == SINK_MEASURE && s.baseCounts && indexVector) p.needRow = 1;
   FastOperands f;
-  if (fast_sink(s) && fast_operands(p, f, false)) {
+  const bool fast = fast_sink(s) && fast_operands(p, f, false);
+  // root outputs of the hot shape are held back and fused with their siblings (same index vector)
+  if (fast && (s.type == SINK_DIM || s.type == SINK_MEASURE) && defer_transform(device, stream, f, s, n, p.a.length)) return n;
+  flush_deferred(device);
+  if (fast) {
     f.pad = s.type == SINK_MEASURE ? 0 : static_cast<int>(reinterpret_cast<uintptr_t>(s.nulls) & 3);
     const int64_t numQuads = (static_cast<int64_t>(n) + f.pad + 3) / 4;
     const int64_t tiles = (numQuads + kBlock * kTQ - 1) / (kBlock * kTQ);
@@ -733,6 +911,21 @@ using namespace ares;
 
 extern "C" {
 
+void AresFlushDeferred(int device) {
+  int current = 0;
+  if (hipGetDevice(&current) != hipSuccess) {
+    (void)hipGetLastError();
+    return;
+  }
+  try {
+    if (current != device) hip_check(hipSetDevice(device), "hipSetDevice");
+    flush_deferred(device);
+    if (current != device) (void)hipSetDevice(current);
+  } catch (std::exception &e) {
+    fprintf(stderr, "Exception happened when flushing deferred transforms: %s\n", e.what());
+  }
+}
+
 CGoCallResHandle InitIndexVector(uint32_t *indexVector, uint32_t start, int indexVectorLength, void *cudaStream,
                                  int device) {
   ARES_ABI_BEGIN(device)
@@ -748,19 +941,19 @@ CGoCallResHandle InitIndexVector(uint32_t *indexVector, uint32_t start, int inde
 CGoCallResHandle UnaryTransform(InputVector input, OutputVector output, uint32_t *indexVector,
                                 int indexVectorLength, uint32_t *baseCounts, uint32_t startCount,
                                 enum UnaryFunctorType functorType, void *cudaStream, int device) {
-  ARES_ABI_BEGIN(device)
+  ARES_ABI_BEGIN_NOFLUSH(device)
   resHandle.res = int_result(run_transform(&input, 1, output, indexVector, indexVectorLength, baseCounts,
-                                           startCount, functorType, reinterpret_cast<hipStream_t>(cudaStream)));
+                                           startCount, functorType, reinterpret_cast<hipStream_t>(cudaStream), device));
   ARES_ABI_END("UnaryTransform")
 }
 
 CGoCallResHandle BinaryTransform(InputVector lhs, InputVector rhs, OutputVector output, uint32_t *indexVector,
                                  int indexVectorLength, uint32_t *baseCounts, uint32_t startCount,
                                  enum BinaryFunctorType functorType, void *cudaStream, int device) {
-  ARES_ABI_BEGIN(device)
+  ARES_ABI_BEGIN_NOFLUSH(device)
   InputVector ins[2] = {lhs, rhs};
   resHandle.res = int_result(run_transform(ins, 2, output, indexVector, indexVectorLength, baseCounts, startCount,
-                                           functorType, reinterpret_cast<hipStream_t>(cudaStream)));
+                                           functorType, reinterpret_cast<hipStream_t>(cudaStream), device));
   ARES_ABI_END("BinaryTransform")
 }
 

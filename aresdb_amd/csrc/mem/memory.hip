@@ -59,6 +59,19 @@ inline CGoCallResHandle fail(const char *what, hipError_t err) {
     if (e_ != hipSuccess) return fail(what, e_);   \
   } while (0)
 
+// libalgorithm.so may hold transforms it has accepted but not launched yet (cross-call fusion,
+// aresdb_amd/csrc/algo/transform.hip); it registers a hook here, and every entry point through
+// which the host could observe, free or overwrite device memory runs it first.
+typedef void (*FlushHook)(int device);
+std::atomic<FlushHook> g_flushHook{nullptr};
+inline void flush_pending(int device) {
+  if (FlushHook h = g_flushHook.load(std::memory_order_acquire)) h(device);
+}
+inline void flush_pending_current() {
+  int device = 0;
+  if (hipGetDevice(&device) == hipSuccess) flush_pending(device);
+}
+
 bool use_pool() {
   static const bool v = [] {
     const char *e = getenv("ARES_MEM_POOL");
@@ -246,6 +259,9 @@ hipError_t pool_free(DeviceState *st, void *p) {
 
 extern "C" {
 
+// extension (include/ares_extensions.h): called by the sibling libalgorithm.so, never by the host
+void AresMemSetFlushHook(void (*hook)(int device)) { g_flushHook.store(hook, std::memory_order_release); }
+
 DeviceMemoryFlags GetFlags(void) {
   // reference cuda_malloc.cu:36-42 / rmm_alloc.cu:84-91
   DeviceMemoryFlags f = DEVICE_MEMORY_IMPLEMENTATION_FLAG | HASH_REDUCTION_SUPPORT;
@@ -287,12 +303,14 @@ CGoCallResHandle CreateCudaStream(int device) {
 
 CGoCallResHandle WaitForCudaStream(void *s, int device) {
   MEM_TRY(hipSetDevice(device), "WaitForCudaStream");
+  flush_pending(device);
   MEM_TRY(hipStreamSynchronize(reinterpret_cast<hipStream_t>(s)), "WaitForCudaStream");
   return ok();
 }
 
 CGoCallResHandle DestroyCudaStream(void *s, int device) {
   MEM_TRY(hipSetDevice(device), "DestroyCudaStream");
+  flush_pending(device);
   if (s) {
     DeviceState *st;
     MEM_TRY(device_state(device, &st), "DestroyCudaStream");
@@ -323,6 +341,7 @@ CGoCallResHandle DeviceAllocate(size_t bytes, int device) {
 
 CGoCallResHandle DeviceFree(void *p, int device) {
   MEM_TRY(hipSetDevice(device), "DeviceFree");
+  flush_pending(device);
   DeviceState *st;
   MEM_TRY(device_state(device, &st), "DeviceFree");
   MEM_TRY(pool_free(st, p), "DeviceFree");
@@ -331,6 +350,7 @@ CGoCallResHandle DeviceFree(void *p, int device) {
 
 CGoCallResHandle AsyncCopyHostToDevice(void *dst, void *src, size_t bytes, void *stream, int device) {
   MEM_TRY(hipSetDevice(device), "AsyncCopyHostToDevice");
+  flush_pending(device);
   if (bytes)
     MEM_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, reinterpret_cast<hipStream_t>(stream)),
             "AsyncCopyHostToDevice");
@@ -339,6 +359,7 @@ CGoCallResHandle AsyncCopyHostToDevice(void *dst, void *src, size_t bytes, void 
 
 CGoCallResHandle AsyncCopyDeviceToDevice(void *dst, void *src, size_t bytes, void *stream, int device) {
   MEM_TRY(hipSetDevice(device), "AsyncCopyDeviceToDevice");
+  flush_pending(device);
   if (bytes)
     MEM_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, reinterpret_cast<hipStream_t>(stream)),
             "AsyncCopyDeviceToDevice");
@@ -347,6 +368,7 @@ CGoCallResHandle AsyncCopyDeviceToDevice(void *dst, void *src, size_t bytes, voi
 
 CGoCallResHandle AsyncCopyDeviceToHost(void *dst, void *src, size_t bytes, void *stream, int device) {
   MEM_TRY(hipSetDevice(device), "AsyncCopyDeviceToHost");
+  flush_pending(device);
   if (bytes)
     MEM_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, reinterpret_cast<hipStream_t>(stream)),
             "AsyncCopyDeviceToHost");
@@ -374,6 +396,7 @@ CGoCallResHandle CudaProfilerStart(void) {
 }
 
 CGoCallResHandle CudaProfilerStop(void) {
+  flush_pending_current();
   MEM_TRY(hipDeviceSynchronize(), "cudaProfilerStop");
   (void)hipProfilerStop();
   (void)hipGetLastError();
@@ -395,6 +418,7 @@ CGoCallResHandle deviceMalloc(void **devPtr, size_t size) {
 }
 
 CGoCallResHandle deviceFree(void *devPtr) {
+  flush_pending_current();
   DeviceState *st;
   MEM_TRY(current_device_state(&st), "deviceFree");
   MEM_TRY(pool_free(st, devPtr), "deviceFree");
@@ -402,11 +426,13 @@ CGoCallResHandle deviceFree(void *devPtr) {
 }
 
 CGoCallResHandle deviceMemset(void *devPtr, int value, size_t count) {
+  flush_pending_current();
   MEM_TRY(hipMemset(devPtr, value, count), "deviceMemset");
   return ok();
 }
 
 CGoCallResHandle asyncCopyHostToDevice(void *dst, const void *src, size_t count, void *stream) {
+  flush_pending_current();
   if (count)
     MEM_TRY(hipMemcpyAsync(dst, src, count, hipMemcpyHostToDevice, reinterpret_cast<hipStream_t>(stream)),
             "asyncCopyHostToDevice");
@@ -414,6 +440,7 @@ CGoCallResHandle asyncCopyHostToDevice(void *dst, const void *src, size_t count,
 }
 
 CGoCallResHandle asyncCopyDeviceToHost(void *dst, const void *src, size_t count, void *stream) {
+  flush_pending_current();
   if (count)
     MEM_TRY(hipMemcpyAsync(dst, src, count, hipMemcpyDeviceToHost, reinterpret_cast<hipStream_t>(stream)),
             "asyncCopyDeviceToHost");
@@ -421,6 +448,7 @@ CGoCallResHandle asyncCopyDeviceToHost(void *dst, const void *src, size_t count,
 }
 
 CGoCallResHandle waitForCudaStream(void *stream) {
+  flush_pending_current();
   MEM_TRY(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)), "waitForCudaStream");
   return ok();
 }

@@ -20,6 +20,19 @@ extern "C" {
 void AresProfilerEnable(int on);
 size_t AresProfilerReport(char *buf, size_t len);
 
+/* Cross-call fusion inside the unchanged ABI.  Root transforms of the hot shape (a 4-byte column,
+ * optionally combined with a constant, written to a dimension vector or a measure vector) are not
+ * launched one by one: libalgorithm.so keeps up to 8 of them per (device, stream) and runs them as
+ * ONE kernel that reads the index vector once.  Nothing observable changes: every other
+ * libalgorithm.so entry point, and every libmem.so entry point through which the host could read,
+ * overwrite or free device memory (WaitForCudaStream, AsyncCopy*, DeviceFree, DestroyCudaStream,
+ * CudaProfilerStop), first launches what is pending.  libalgorithm.so finds the sibling libmem.so
+ * (same directory) at run time and registers AresFlushDeferred through AresMemSetFlushHook; when
+ * that is not possible (another allocator library in use) or ARES_DEFER=0 is set, every transform
+ * is launched immediately as before. */
+void AresFlushDeferred(int device);                      /* exported by libalgorithm.so */
+void AresMemSetFlushHook(void (*hook)(int device));      /* exported by libmem.so */
+
 /* Fused batch execution: filter -> dimension / measure projection -> hash reduction of ONE batch in
  * a single pass over the source columns, without the index / predicate / dimension vectors the
  * one-call-per-AST-node ABI materialises in between (~145 B/row of HBM traffic on

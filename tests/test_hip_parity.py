@@ -202,3 +202,40 @@ def test_sort_large_property():
     assert r["groups"] == len(starts)
     assert np.array_equal(r["out_values"].view(np.uint32), sums)
     assert np.array_equal(r["out_index"], ix[starts])
+
+
+def _dim_out(values_ptr, nulls_ptr):
+    return H.dimension_output(values_ptr, nulls_ptr, abi.Uint32)
+
+
+@pytest.mark.parametrize("be_name", ["hip"])
+def test_deferred_transforms_respect_dependencies(be_name):
+    """Cross-call fusion (include/ares_extensions.h) holds root transforms back; a transform that
+    READS what a queued one WRITES, or overwrites what a queued one reads/writes, must still see
+    program order.  Chain: X = a + 1;  Y = X * 3 (reads X);  X = a + 5 (overwrites X);  Z = X - 1."""
+    be = H.get_backend(be_name)
+    n = 100003
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 1000, n).astype(np.uint32)
+    col = H.Column(be, abi.Uint32, a)
+    idx = H.Buf(be, np.arange(n, dtype=np.uint32))
+    bufs = {k: (H.Buf(be, nbytes=4 * n + 16), H.Buf(be, nbytes=n + 16)) for k in "XYZ"}
+    from aresdb_amd.columns import slice_from_pointer
+    from aresdb_amd.executor import column_input, constant_input
+
+    def call(src, const, functor, dst):
+        be.call("BinaryTransform", src, constant_input(const), _dim_out(bufs[dst][0].ptr, bufs[dst][1].ptr), idx.ptr, n,
+                None, 0, functor, None, 0)
+    x_as_column = column_input(slice_from_pointer(bufs["X"][0].ptr, abi.Uint32, n))
+    call(col.input(), 1, abi.Plus, "X")
+    call(x_as_column, 3, abi.Multiply, "Y")
+    call(col.input(), 5, abi.Plus, "X")
+    call(x_as_column, 1, abi.Minus, "Z")
+    got = {k: bufs[k][0].read(np.uint32, n) for k in "XYZ"}
+    assert np.array_equal(got["Y"], (a + 1) * 3)
+    assert np.array_equal(got["X"], a + 5)
+    assert np.array_equal(got["Z"], a + 4)
+    for k in "XYZ":
+        assert bufs[k][1].read(np.uint8, n).all()
+    for b in [col, idx] + [x for pair in bufs.values() for x in pair]:
+        b.free()

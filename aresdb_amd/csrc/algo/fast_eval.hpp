@@ -128,6 +128,100 @@ __device__ __forceinline__ uint32_t compare_fast(const FastOperands &f, uint32_t
 }
 
 
+// Four elements of one expression with ONE dispatch on its shape: bare column, integer
+// divide / modulo / floor by the constant, integer add / subtract / multiply; anything else goes
+// through eval_fast element by element.  r[j] = result bits (kind f.rk), return = validity nibble.
+// Bit-identical to eval_fast: a null operand of a binary functor yields bits 0, of a bare column
+// the stored bits (query/functor.hpp:337-351, :660-697).
+__device__ __forceinline__ uint32_t eval_quad(const FastOperands &f, const uint32_t (&v)[4], uint32_t ok, DVal y,
+                                              const FastDivisor &fd, uint32_t (&r)[4]) {
+  const bool intKinds = f.akind != K_F32 && f.I != K_F32 && f.akind != K_BOOL;
+  if (f.arity == 1 && (f.akind == f.I || intKinds)) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) r[j] = v[j];
+    return ok;
+  }
+  if (f.arity == 2 && intKinds && y.ok) {
+    if (f.divLike) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        uint32_t q, m;
+        if (f.I == K_I32) {
+          const int32_t sx = static_cast<int32_t>(v[j]), sy = static_cast<int32_t>(y.bits);
+          fast_divmod(fd, sx < 0 ? 0u - v[j] : v[j], q, m);
+          const uint32_t sq = ((sx < 0) != (sy < 0)) ? 0u - q : q;
+          const uint32_t sm = sx < 0 ? 0u - m : m;
+          r[j] = f.functor == Divide ? sq : f.functor == Mod ? sm : v[j] - sm;
+        } else {
+          fast_divmod(fd, v[j], q, m);
+          r[j] = f.functor == Divide ? q : f.functor == Mod ? m : v[j] - m;
+        }
+        if (!((ok >> j) & 1u)) r[j] = 0;
+      }
+      return ok;
+    }
+    if (f.functor == Plus || f.functor == Minus || f.functor == Multiply) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint32_t x = f.functor == Plus ? v[j] + y.bits : f.functor == Minus ? v[j] - y.bits : v[j] * y.bits;
+        r[j] = ((ok >> j) & 1u) ? x : 0u;
+      }
+      return ok;
+    }
+  }
+  uint32_t outOk = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const DVal x = eval_fast(f, v[j], (ok >> j) & 1u, y, fd);
+    r[j] = x.bits;
+    outOk |= (x.ok ? 1u : 0u) << j;
+  }
+  return outOk;
+}
+
+// The same comparison for the QUADS x 4 elements of a tile with ONE dispatch on (kind, functor): the
+// per-element form above costs a chain of scalar branches per element, which is what bounds the
+// streaming filter kernels once the memory system keeps up.  kb[q] = 4 keep bits of quad q;
+// in[q] = which of the quad's positions exist.
+template <int QUADS>
+__device__ __forceinline__ void compare_tile(const FastOperands &f, const uint32_t (&vals)[QUADS][4], const uint32_t (&okb)[QUADS],
+                                             const uint32_t (&in)[QUADS], DVal y, uint32_t (&kb)[QUADS]) {
+  const bool sameBits = f.akind == f.I || (f.akind != K_F32 && f.I != K_F32 && f.akind != K_BOOL);
+  if (!sameBits || !y.ok) {  // value conversion needed (or a null constant): element-wise form
+#pragma unroll
+    for (int q = 0; q < QUADS; q++) {
+      kb[q] = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if ((in[q] >> j) & 1u) kb[q] |= compare_fast(f, vals[q][j], (okb[q] >> j) & 1u, y) << j;
+    }
+    return;
+  }
+#define ARES_CMP_LOOP(T, CONV, OP)                                                     \
+  _Pragma("unroll") for (int q = 0; q < QUADS; q++) {                                  \
+    uint32_t m = 0;                                                                    \
+    _Pragma("unroll") for (int j = 0; j < 4; j++) m |= (CONV(vals[q][j]) OP b ? 1u : 0u) << j; \
+    kb[q] = m & okb[q] & in[q];                                                        \
+  }
+#define ARES_CMP_TYPE(T, CONV)                        \
+  {                                                   \
+    const T b = CONV(y.bits);                         \
+    switch (f.functor) {                              \
+      case Equal: ARES_CMP_LOOP(T, CONV, ==) break;   \
+      case NotEqual: ARES_CMP_LOOP(T, CONV, !=) break; \
+      case LessThan: ARES_CMP_LOOP(T, CONV, <) break; \
+      case LessThanOrEqual: ARES_CMP_LOOP(T, CONV, <=) break; \
+      case GreaterThan: ARES_CMP_LOOP(T, CONV, >) break; \
+      default: ARES_CMP_LOOP(T, CONV, >=) break;      \
+    }                                                 \
+  }
+  if (f.I == K_F32) ARES_CMP_TYPE(float, bits_f)
+  else if (f.I == K_I32) ARES_CMP_TYPE(int32_t, static_cast<int32_t>)
+  else ARES_CMP_TYPE(uint32_t, static_cast<uint32_t>)
+#undef ARES_CMP_TYPE
+#undef ARES_CMP_LOOP
+}
+
 // ---- host side ------------------------------------------------------------------------------------
 inline void build_params(const InputVector *ins, int arity, hipStream_t stream, const uint32_t *indexVector,
                          const uint32_t *baseCounts, uint32_t startCount, int functor, EvalParams &p,

@@ -669,37 +669,62 @@ struct FusedSource {
       ok[c] = 0xFu;
       if (c < plan.numCols) ok[c] = (r.win[c] >> ((static_cast<uint32_t>(i0) + plan.cols[c].bitOff) & 7u)) & 0xFu;
     }
-    uint32_t alive = 0;
+    // one dispatch per expression per quad (eval_quad / compare_tile), not per element
+    uint32_t in[1] = {0u};
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      bool keep = i0 + j < length;
+    for (int j = 0; j < 4; j++) in[0] |= (i0 + j < length ? 1u : 0u) << j;
+    uint32_t alive = in[0];
 #pragma unroll
-      for (int k = 0; k < kFusedFilters; k++) {
-        if (k < plan.numFilters) {
-          const FusedExpr &e = plan.filters[k];
-          uint32_t bits = 0, okb = 0;
+    for (int k = 0; k < kFusedFilters; k++) {
+      if (k < plan.numFilters) {
+        const FusedExpr &e = plan.filters[k];
+        uint32_t fv[1][4] = {{0u, 0u, 0u, 0u}}, fok[1] = {0u}, kb[1];
 #pragma unroll
-          for (int c = 0; c < NC; c++)
-            if (c == e.col) { bits = r.v[c][j]; okb = (ok[c] >> j) & 1u; }
-          keep = keep && compare_fast(e.f, bits, okb, fc[k].y) != 0;
+        for (int c = 0; c < NC; c++)
+          if (c == e.col) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) fv[0][j] = r.v[c][j];
+            fok[0] = ok[c];
+          }
+        compare_tile<1>(e.f, fv, fok, in, fc[k].y, kb);
+        alive &= kb[0];
+      }
+    }
+    // dimension d reads column slot d, the measure slot ND (fixed by the host), so only the filters
+    // select their operand at run time
+    uint32_t dimBits[ND_][4], dimOk[ND_];
+#pragma unroll
+    for (int d = 0; d < ND_; d++) {
+      const FusedExpr &e = plan.dims[d];
+      uint32_t rb[4];
+      dimOk[d] = eval_quad(e.f, r.v[d], ok[d], dc[d].y, dc[d].fd, rb);
+      const bool plain = e.f.rk == e.outKind || (e.f.rk != K_F32 && e.outKind != K_F32 && e.f.rk != K_BOOL);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if (plain) {
+          dimBits[d][j] = rb[j];
+        } else {
+          DVal x;
+          x.bits = rb[j];
+          x.ok = 1;
+          dimBits[d][j] = cvt32(x, e.f.rk, e.outKind).bits;
         }
       }
-      alive |= (keep ? 1u : 0u) << j;
-      // dimension d reads column slot d, the measure slot ND (fixed by the host), so only the
-      // filters select their operand at run time
+    }
+    uint32_t mb[4];
+    const uint32_t mok = eval_quad(plan.measure.f, r.v[ND_], ok[ND_], mc.y, mc.fd, mb);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
       Murmur32Stream ms(0);
-      uint32_t validBytes = 0;
 #pragma unroll
-      for (int d = 0; d < ND_; d++) {
-        const FusedExpr &e = plan.dims[d];
-        const DVal x = eval_fast(e.f, r.v[d][j], (ok[d] >> j) & 1u, dc[d].y, dc[d].fd);
-        ms.push(cvt32(x, e.f.rk, e.outKind).bits, 4);
-        validBytes |= (x.ok ? 1u : 0u) << d;
-      }
+      for (int d = 0; d < ND_; d++) ms.push(dimBits[d][j], 4);
 #pragma unroll
-      for (int d = 0; d < ND_; d++) ms.push((validBytes >> d) & 1u, 1);
+      for (int d = 0; d < ND_; d++) ms.push((dimOk[d] >> j) & 1u, 1);
       h[j] = ms.finish();
-      v[j] = fused_measure_bits(plan, eval_fast(plan.measure.f, r.v[ND_][j], (ok[ND_] >> j) & 1u, mc.y, mc.fd));
+      DVal x;
+      x.bits = mb[j];
+      x.ok = (mok >> j) & 1u;
+      v[j] = fused_measure_bits(plan, x);
     }
     return alive;
   }

@@ -448,6 +448,12 @@ __device__ __forceinline__ void extract_valid(const FastOperands &f, int pad, in
   for (int q = 0; q < QUADS; q++) {
     const int64_t i0 = (quad0 + static_cast<int64_t>(q) * kBlock) * 4 - pad;
     const uint32_t first = (rows[q][0] + f.bitOff) & ~7u;  // bit position of the window's bit 0
+    if (i0 >= 0 && i0 + 3 < n && rows[q][3] - rows[q][0] == 3u && rows[q][1] - rows[q][0] == 1u &&
+        rows[q][2] - rows[q][0] == 2u) {
+      // four consecutive rows inside the batch: their bits are contiguous in the 16-bit window
+      okb[q] = (window[q] >> ((rows[q][0] + f.bitOff) & 7u)) & 0xFu;
+      continue;
+    }
     okb[q] = 0;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -501,8 +507,15 @@ __device__ __forceinline__ void store_tile(const FastOperands &f, const SinkD &s
   for (int q = 0; q < QUADS; q++) {
     const int64_t i0 = (quad0 + static_cast<int64_t>(q) * kBlock) * 4 - pad;
     DVal r[4];
+    {
+      uint32_t rb[4];
+      const uint32_t rok = eval_quad(f, vals[q], okb[q], y, fd, rb);
 #pragma unroll
-    for (int j = 0; j < 4; j++) r[j] = eval_fast(f, vals[q][j], (okb[q] >> j) & 1u, y, fd);
+      for (int j = 0; j < 4; j++) {
+        r[j].bits = rb[j];
+        r[j].ok = (rok >> j) & 1u;
+      }
+    }
     const bool full = i0 >= 0 && i0 + 3 < n;
     if (!full) {  // ragged first / last quad (or past the end): the generic element-wise sink
 #pragma unroll
@@ -574,7 +587,7 @@ struct MultiJobs {
   SinkD s[kMaxMultiJobs];
 };
 
-__global__ __launch_bounds__(kBlock) void transform_multi_kernel(MultiJobs jobs, const uint32_t *idx, int n, int64_t numQuads) {
+__global__ __launch_bounds__(kBlock, 4) void transform_multi_kernel(MultiJobs jobs, const uint32_t *idx, int n, int64_t numQuads) {
   const int64_t tileQuads = static_cast<int64_t>(kBlock) * kTQ;
   for (int64_t tq = static_cast<int64_t>(blockIdx.x) * tileQuads; tq < numQuads;
        tq += static_cast<int64_t>(gridDim.x) * tileQuads) {
@@ -701,6 +714,242 @@ __global__ __launch_bounds__(kBlock) void filter_fast_kernel(FastOperands f, uin
 }
 
 // ---------------------------------------------------------------------------------------------
+// two-phase filter: predicate + per-tile counts, scan, in-place compaction without a chain
+// ---------------------------------------------------------------------------------------------
+// The one-pass kernel above is bound by the latency of its per-tile chain (index -> column loads,
+// ranking, look-back, staging).  Splitting it removes every inter-tile dependency from the hot
+// loops: (1) a streaming kernel evaluates the predicate, writes the predicate bytes and one
+// survivor count per 4096-row tile; (2) a single small workgroup turns the counts into offsets;
+// (3) the compaction kernel re-reads predicate bytes + index vector and writes each tile's
+// survivors at its known offset.  In-place safety in (3): a tile writes only after every tile whose
+// INPUT range overlaps its OUTPUT range has flagged "loaded" (those are earlier tiles, claimed
+// earlier by running workgroups through the ticket, so the wait cannot deadlock); with a virtual
+// index vector (rows = position, see the iota registry below) nothing is read from the index
+// vector and no wait is needed.  Traffic: 9.1 + 8.6 B/row instead of 12.7, at streaming speed.
+constexpr int kPQ = 4;                        // quads per lane per tile
+constexpr int kPTile = kBlock * 4 * kPQ;      // 4096 rows
+constexpr int kTilesPerTicket = 4;
+
+__global__ __launch_bounds__(kBlock) void filter_pred_kernel(FastOperands f, uint8_t *pred, uint32_t *tileCounts, int n,
+                                                             int numTiles) {
+  const int lane = threadIdx.x & 63;
+  DVal y;
+  y.bits = f.bbits;
+  y.ok = f.bok;
+  y = cvt32(y, f.bkind, f.I);
+  for (int tile = blockIdx.x; tile < numTiles; tile += gridDim.x) {
+    const int64_t tq = static_cast<int64_t>(tile) * (kBlock * kPQ);
+    uint32_t rows[kPQ][4], vals[kPQ][4], okb[kPQ];
+    load_quads<kPQ>(f, tq + threadIdx.x, n, rows, vals, okb);
+    uint32_t count = 0, in[kPQ], kbs[kPQ];
+#pragma unroll
+    for (int q = 0; q < kPQ; q++) {
+      const int64_t i0 = (tq + threadIdx.x + static_cast<int64_t>(q) * kBlock) * 4 - f.pad;
+      in[q] = 0xFu;
+      if (i0 < 0 || i0 + 3 >= n) {
+        in[q] = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) in[q] |= ((i0 + j >= 0 && i0 + j < n) ? 1u : 0u) << j;
+      }
+    }
+    compare_tile<kPQ>(f, vals, okb, in, y, kbs);  // result validity is ignored (functor.hpp:903-915)
+#pragma unroll
+    for (int q = 0; q < kPQ; q++) {
+      const int64_t i0 = (tq + threadIdx.x + static_cast<int64_t>(q) * kBlock) * 4 - f.pad;
+      const uint32_t kb = kbs[q];
+      count += __popc(kb);
+      const uint32_t bytes = (kb & 1u) | ((kb & 2u) << 7) | ((kb & 4u) << 14) | ((kb & 8u) << 21);
+      if (i0 >= 0 && i0 + 3 < n) {
+        *reinterpret_cast<uint32_t *>(pred + i0) = bytes;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (i0 + j >= 0 && i0 + j < n) pred[i0 + j] = static_cast<uint8_t>((kb >> j) & 1u);
+      }
+    }
+    // one atomic per wavefront into the (zeroed) tile count: no workgroup barrier in this kernel
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) count += __shfl_xor(count, off);
+    if (lane == 0 && count) atomicAdd(tileCounts + tile, count);
+  }
+}
+
+// exclusive scan of the tile counts by ONE workgroup (numTiles <= a few hundred thousand)
+__global__ __launch_bounds__(1024) void filter_scan_kernel(const uint32_t *tileCounts, uint32_t *tileOffsets, int numTiles,
+                                                           uint32_t *total) {
+  constexpr int kPer = 8;  // consecutive tiles per lane
+  __shared__ uint32_t sWave[16];
+  __shared__ uint32_t sCarry;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) sCarry = 0;
+  __syncthreads();
+  for (int base = 0; base < numTiles; base += 1024 * kPer) {
+    const int t0 = base + threadIdx.x * kPer;
+    uint32_t c[kPer], mine = 0;
+#pragma unroll
+    for (int k = 0; k < kPer; k++) {
+      c[k] = t0 + k < numTiles ? tileCounts[t0 + k] : 0u;
+      mine += c[k];
+    }
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t v = __shfl_up(incl, off);
+      if (lane >= off) incl += v;
+    }
+    if (lane == 63) sWave[wave] = incl;
+    __syncthreads();
+    uint32_t before = sCarry;
+    for (int w = 0; w < wave; w++) before += sWave[w];
+    uint32_t run = before + incl - mine;
+#pragma unroll
+    for (int k = 0; k < kPer; k++) {
+      if (t0 + k < numTiles) tileOffsets[t0 + k] = run;
+      run += c[k];
+    }
+    __syncthreads();
+    if (threadIdx.x == 1023) sCarry = before + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    tileOffsets[numTiles] = sCarry;
+    *total = sCarry;
+  }
+}
+
+struct CompactWorkspace {
+  unsigned int *ticket;
+  uint32_t *error;
+  const uint32_t *tileOffsets;
+  uint32_t *loaded;  // one word per tile: its input is in registers
+};
+
+// PAYLOAD: uint32_t (index vector) or uint64_t (RecordID vector).  VIRTUAL: the index vector is
+// iota(start) and has not been materialised: nothing is read from it.
+template <typename PAYLOAD, bool VIRTUAL>
+__global__ __launch_bounds__(kBlock) void filter_compact_kernel(const uint8_t *pred, PAYLOAD *data, uint32_t iotaStart, int pad,
+                                                                CompactWorkspace ws, int n, int numTiles) {
+  __shared__ PAYLOAD sOut[kPTile];
+  __shared__ uint32_t sCounts[kPQ * kWaves];
+  __shared__ int sTicket;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) sTicket = static_cast<int>(atomicAdd(ws.ticket, 1u));
+    __syncthreads();
+    const int firstTile = sTicket * kTilesPerTicket;
+    if (firstTile >= numTiles) break;
+    // phase A: the input of ALL tiles of this ticket goes to registers, then they are flagged
+    // "loaded" at once — nobody ever waits for a tile this workgroup has not reached yet
+    PAYLOAD rows[kTilesPerTicket][kPQ][4];
+    uint32_t keep[kTilesPerTicket];
+#pragma unroll
+    for (int tt = 0; tt < kTilesPerTicket; tt++) {
+      const int tile = firstTile + tt;
+      const int64_t tq = static_cast<int64_t>(tile) * (kBlock * kPQ);
+      keep[tt] = 0;
+#pragma unroll
+      for (int q = 0; q < kPQ; q++) {
+        const int64_t i0 = (tq + threadIdx.x + static_cast<int64_t>(q) * kBlock) * 4 - pad;
+        uint32_t pb = 0;
+        if (tile < numTiles && i0 >= 0 && i0 + 3 < n) {
+          pb = *reinterpret_cast<const uint32_t *>(pred + i0);
+          if (VIRTUAL) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) rows[tt][q][j] = static_cast<PAYLOAD>(iotaStart + static_cast<uint32_t>(i0) + j);
+          } else if (sizeof(PAYLOAD) == 4) {
+            const U32x4 r = *reinterpret_cast<const U32x4 *>(data + i0);
+#pragma unroll
+            for (int j = 0; j < 4; j++) rows[tt][q][j] = static_cast<PAYLOAD>(r.v[j]);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) rows[tt][q][j] = data[i0 + j];
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const int64_t i = i0 + j;
+            rows[tt][q][j] = 0;
+            if (tile < numTiles && i >= 0 && i < n) {
+              pb |= static_cast<uint32_t>(pred[i]) << (8 * j);
+              rows[tt][q][j] = VIRTUAL ? static_cast<PAYLOAD>(iotaStart + static_cast<uint32_t>(i)) : data[i];
+            }
+          }
+        }
+        const uint32_t kb = ((pb & 0xFFu) ? 1u : 0u) | ((pb & 0xFF00u) ? 2u : 0u) | ((pb & 0xFF0000u) ? 4u : 0u) |
+                            ((pb & 0xFF000000u) ? 8u : 0u);
+        keep[tt] |= kb << (4 * q);
+      }
+    }
+    if (!VIRTUAL) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (threadIdx.x < kTilesPerTicket && firstTile + static_cast<int>(threadIdx.x) < numTiles)
+        __hip_atomic_store(ws.loaded + firstTile + threadIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // phase B: rank, stage in final order, wait for the input tiles under the output range, write
+#pragma unroll
+    for (int tt = 0; tt < kTilesPerTicket; tt++) {
+      const int tile = firstTile + tt;
+      if (tile >= numTiles) break;
+      uint32_t lanePrefix[kPQ];
+#pragma unroll
+      for (int q = 0; q < kPQ; q++) {
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const uint64_t m = __ballot((keep[tt] >> (4 * q + j)) & 1u);
+          before += __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+          total += static_cast<uint32_t>(__popcll(m));
+        }
+        lanePrefix[q] = before;
+        if (lane == 0) sCounts[q * kWaves + wave] = total;
+      }
+      __syncthreads();
+      uint32_t base[kPQ];
+      {
+        uint32_t run = 0;  // every lane scans the 16 partial counts (position order: quad, wave)
+#pragma unroll
+        for (int q = 0; q < kPQ; q++)
+#pragma unroll
+          for (int w = 0; w < kWaves; w++) {
+            if (w == wave) base[q] = run;
+            run += sCounts[q * kWaves + w];
+          }
+      }
+#pragma unroll
+      for (int q = 0; q < kPQ; q++) {
+        uint32_t at = base[q] + lanePrefix[q];
+        const uint32_t kb = (keep[tt] >> (4 * q)) & 0xFu;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if ((kb >> j) & 1u) sOut[at++] = rows[tt][q][j];
+      }
+      const uint32_t gbase = ws.tileOffsets[tile], count = ws.tileOffsets[tile + 1] - gbase;
+      if (!VIRTUAL && count > 0) {
+        const int lo = static_cast<int>((static_cast<int64_t>(gbase) + pad) / kPTile);
+        const int hi = static_cast<int>((static_cast<int64_t>(gbase) + count - 1 + pad) / kPTile);
+        if (threadIdx.x == 0) {
+          for (int s2 = lo; s2 <= hi && s2 < firstTile; s2++) {  // this ticket's own tiles are loaded
+            uint32_t spins = 0;
+            while (__hip_atomic_load(ws.loaded + s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+              __builtin_amdgcn_s_sleep(2);
+              if (++spins > kMaxSpins) {
+                atomicOr(ws.error, 1u);
+                break;
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();
+      for (uint32_t k = threadIdx.x; k < count; k += kBlock) data[gbase + k] = sOut[k];
+      __syncthreads();  // sOut / sCounts are reused by the next tile
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 
@@ -724,6 +973,17 @@ struct PendingQueue {
 };
 std::mutex g_deferMutex;
 std::map<std::pair<int, hipStream_t>, PendingQueue> g_pending;
+
+// Index vectors that InitIndexVector has defined but not written yet ("virtual iota"): the fast
+// filter and transform kernels that consume them compute rows = position instead of loading 4 bytes
+// per row; any other use (every flush point) materialises them first.
+struct PendingIota {
+  int device;
+  hipStream_t stream;
+  uint32_t start;
+  int n;
+};
+std::map<uint32_t *, PendingIota> g_iotas;
 
 // registers the flush hook with the sibling libmem.so; false = deferral is off for this process
 bool defer_available() {
@@ -767,10 +1027,44 @@ void launch_queue(hipStream_t stream, PendingQueue &q) {
 }
 }  // namespace
 
+// caller holds g_deferMutex and has selected the device
+static void launch_init_index(uint32_t *indexVector, uint32_t start, int n, hipStream_t stream) {
+  if (n <= 0) return;
+  const int64_t quads = (static_cast<int64_t>(n) + 3) / 4;
+  const int grid = capped_grid((quads + kBlock - 1) / kBlock, 256 * 16);
+  ARES_LAUNCH("init_index_kernel", init_index_kernel, grid, kBlock, stream, indexVector, start, n);
+}
+
 void flush_deferred(int device) {
   std::lock_guard<std::mutex> lock(g_deferMutex);
+  for (auto it = g_iotas.begin(); it != g_iotas.end();) {
+    if (it->second.device == device) {
+      launch_init_index(it->first, it->second.start, it->second.n, it->second.stream);
+      it = g_iotas.erase(it);
+    } else {
+      ++it;
+    }
+  }
   for (auto &kv : g_pending)
     if (kv.first.first == device) launch_queue(kv.first.second, kv.second);
+}
+
+// InitIndexVector: remember instead of writing (when the flush hook is in place)
+static bool defer_iota(int device, hipStream_t stream, uint32_t *indexVector, uint32_t start, int n) {
+  if (!defer_available() || n <= 0) return false;
+  std::lock_guard<std::mutex> lock(g_deferMutex);
+  g_iotas[indexVector] = PendingIota{device, stream, start, n};
+  return true;
+}
+
+// true when `indexVector` is a virtual iota(0) of exactly n rows on this device; `take` removes it
+// (the caller is about to give the vector real contents)
+static bool virtual_iota(int device, uint32_t *indexVector, int n, bool take) {
+  std::lock_guard<std::mutex> lock(g_deferMutex);
+  auto it = g_iotas.find(indexVector);
+  if (it == g_iotas.end() || it->second.device != device || it->second.start != 0 || it->second.n != n) return false;
+  if (take) g_iotas.erase(it);
+  return true;
 }
 
 // Queues one fast-path transform; returns false when deferral is unavailable (the caller launches it).
@@ -823,6 +1117,7 @@ static int run_transform(const InputVector *ins, int arity, const OutputVector &
   if (s.type == SINK_MEASURE && s.baseCounts && indexVector) p.needRow = 1;
   FastOperands f;
   const bool fast = fast_sink(s) && fast_operands(p, f, false);
+  if (fast && f.idx && virtual_iota(device, indexVector, n, false)) f.idx = nullptr;  // rows = position
   // root outputs of the hot shape are held back and fused with their siblings (same index vector)
   if (fast && (s.type == SINK_DIM || s.type == SINK_MEASURE) && defer_transform(device, stream, f, s, n, p.a.length)) return n;
   flush_deferred(device);
@@ -845,13 +1140,25 @@ static int run_transform(const InputVector *ins, int arity, const OutputVector &
 
 static int run_filter(const InputVector *ins, int arity, uint32_t *indexVector, uint8_t *pred, int n,
                       RecordID **recordIDVectors, int numForeignTables, uint32_t *baseCounts, uint32_t startCount,
-                      int functor, hipStream_t stream) {
+                      int functor, hipStream_t stream, int device) {
   if (numForeignTables < 0 || numForeignTables > 8) throw std::invalid_argument("only support up to 8 foreign tables");
-  if (n <= 0) return 0;
+  if (n <= 0) {
+    flush_deferred(device);
+    return 0;
+  }
   EvalParams p;
   CallTemps temps;
   build_params(ins, arity, stream, indexVector, baseCounts, startCount, functor, p, temps);
   p.needRow = 1;
+  // a filter of the hot shape consumes a not-yet-written iota index vector directly; everything
+  // else that is pending on the device is launched first
+  bool virtualIdx = false;
+  {
+    FastOperands probe;
+    if (!is_wide(p.a.kind) && indexVector != nullptr && numForeignTables == 0 && fast_operands(p, probe, true))
+      virtualIdx = virtual_iota(device, indexVector, n, true);
+  }
+  flush_deferred(device);
   if (is_wide(p.a.kind)) {
     // wide operands: evaluate the predicate with the wide transform kernel, then compact by pred
     SinkD s;
@@ -862,6 +1169,58 @@ static int run_filter(const InputVector *ins, int arity, uint32_t *indexVector, 
   }
   FastOperands f;
   const bool fast = !is_wide(p.a.kind) && indexVector != nullptr && fast_operands(p, f, true);
+  static const bool onePass = [] {
+    const char *e = getenv("ARES_FILTER");
+    return e && strcmp(e, "onepass") == 0;
+  }();
+  if (fast && !onePass) {
+    // two-phase path: predicate + tile counts, scan, chain-free compaction of the index vector and
+    // of every RecordID vector
+    f.pad = static_cast<int>(reinterpret_cast<uintptr_t>(pred) & 3);
+    const int64_t numQuads = (static_cast<int64_t>(n) + f.pad + 3) / 4;
+    const int tiles = static_cast<int>((numQuads + kBlock * kPQ - 1) / (kBlock * kPQ));
+    const int passes = 1 + numForeignTables;
+    // layout: [total, error, tickets[passes], pad][tileCounts][tileOffsets + 1][loaded x passes]
+    const size_t head = 64;
+    const size_t words = static_cast<size_t>(tiles) * (2 + passes) + 1;
+    StreamBuffer wsBuf(head + 4 * words, stream);
+    uint32_t *w = wsBuf.as<uint32_t>();
+    uint32_t *total = w, *error = w + 1;
+    unsigned int *tickets = w + 2;
+    uint32_t *tileCounts = w + 16, *tileOffsets = tileCounts + tiles, *loaded = tileOffsets + tiles + 1;
+    hip_check(hipMemsetAsync(w, 0, head, stream), "hipMemsetAsync");
+    hip_check(hipMemsetAsync(tileCounts, 0, 4 * static_cast<size_t>(tiles), stream), "hipMemsetAsync");
+    hip_check(hipMemsetAsync(loaded, 0, 4 * static_cast<size_t>(tiles) * passes, stream), "hipMemsetAsync");
+    if (virtualIdx) f.idx = nullptr;  // rows = position
+    ARES_LAUNCH("filter_pred_kernel", filter_pred_kernel, capped_grid(tiles, 256 * 16), kBlock, stream, f, pred, tileCounts, n, tiles);
+    ARES_LAUNCH("filter_scan_kernel", filter_scan_kernel, 1, 1024, stream, tileCounts, tileOffsets, tiles, total);
+    const int cgrid = capped_grid((tiles + kTilesPerTicket - 1) / kTilesPerTicket, 256 * 8);
+    if (virtualIdx) f.idx = nullptr;
+    for (int pass = 0; pass < passes; pass++) {
+      CompactWorkspace cw;
+      cw.ticket = tickets + pass;
+      cw.error = error;
+      cw.tileOffsets = tileOffsets;
+      cw.loaded = loaded + static_cast<size_t>(tiles) * pass;
+      if (pass == 0 && virtualIdx)
+        ARES_LAUNCH("filter_compact_kernel<iota>", (filter_compact_kernel<uint32_t, true>), cgrid, kBlock, stream, pred, indexVector,
+                    0u, f.pad, cw, n, tiles);
+      else if (pass == 0)
+        ARES_LAUNCH("filter_compact_kernel", (filter_compact_kernel<uint32_t, false>), cgrid, kBlock, stream, pred, indexVector, 0u,
+                    f.pad, cw, n, tiles);
+      else
+        ARES_LAUNCH("filter_compact_kernel<rid>", (filter_compact_kernel<uint64_t, false>), cgrid, kBlock, stream, pred,
+                    reinterpret_cast<uint64_t *>(recordIDVectors[pass - 1]), 0u, f.pad, cw, n, tiles);
+    }
+    uint32_t result[2] = {0, 0};  // {survivors, error}
+    read_back_u32(total, result, 2, stream);
+    if (result[1]) throw AlgorithmError("ERROR: filter: compaction wait timed out");
+    return static_cast<int>(result[0]);
+  }
+  if (virtualIdx) {  // the one-pass kernels read the index vector: write it now
+    std::lock_guard<std::mutex> lock(g_deferMutex);
+    launch_init_index(indexVector, 0, n, stream);
+  }
   int numTiles = static_cast<int>((static_cast<int64_t>(n) + kFilterTile - 1) / kFilterTile);
   int fastTiles = 0;
   if (fast) {
@@ -928,12 +1287,12 @@ void AresFlushDeferred(int device) {
 
 CGoCallResHandle InitIndexVector(uint32_t *indexVector, uint32_t start, int indexVectorLength, void *cudaStream,
                                  int device) {
-  ARES_ABI_BEGIN(device)
-  if (indexVectorLength > 0) {
-    const int64_t quads = (static_cast<int64_t>(indexVectorLength) + 3) / 4;
-    const int grid = capped_grid((quads + kBlock - 1) / kBlock, 256 * 16);
-    ARES_LAUNCH("init_index_kernel", init_index_kernel, grid, kBlock, reinterpret_cast<hipStream_t>(cudaStream),
-                indexVector, start, indexVectorLength);
+  ARES_ABI_BEGIN_NOFLUSH(device)
+  hipStream_t stream = reinterpret_cast<hipStream_t>(cudaStream);
+  if (!defer_iota(device, stream, indexVector, start, indexVectorLength)) {
+    flush_deferred(device);
+    std::lock_guard<std::mutex> lock(g_deferMutex);
+    launch_init_index(indexVector, start, indexVectorLength, stream);
   }
   ARES_ABI_END("InitIndexVector")
 }
@@ -961,10 +1320,10 @@ CGoCallResHandle UnaryFilter(InputVector input, uint32_t *indexVector, uint8_t *
                              int indexVectorLength, RecordID **recordIDVectors, int numForeignTables,
                              uint32_t *baseCounts, uint32_t startCount, enum UnaryFunctorType functorType,
                              void *cudaStream, int device) {
-  ARES_ABI_BEGIN(device)
+  ARES_ABI_BEGIN_NOFLUSH(device)
   resHandle.res = int_result(run_filter(&input, 1, indexVector, predicateVector, indexVectorLength, recordIDVectors,
                                         numForeignTables, baseCounts, startCount, functorType,
-                                        reinterpret_cast<hipStream_t>(cudaStream)));
+                                        reinterpret_cast<hipStream_t>(cudaStream), device));
   ARES_ABI_END("UnaryFilter")
 }
 
@@ -972,11 +1331,11 @@ CGoCallResHandle BinaryFilter(InputVector lhs, InputVector rhs, uint32_t *indexV
                               int indexVectorLength, RecordID **recordIDVectors, int numForeignTables,
                               uint32_t *baseCounts, uint32_t startCount, enum BinaryFunctorType functorType,
                               void *cudaStream, int device) {
-  ARES_ABI_BEGIN(device)
+  ARES_ABI_BEGIN_NOFLUSH(device)
   InputVector ins[2] = {lhs, rhs};
   resHandle.res = int_result(run_filter(ins, 2, indexVector, predicateVector, indexVectorLength, recordIDVectors,
                                         numForeignTables, baseCounts, startCount, functorType,
-                                        reinterpret_cast<hipStream_t>(cudaStream)));
+                                        reinterpret_cast<hipStream_t>(cudaStream), device));
   ARES_ABI_END("BinaryFilter")
 }
 

@@ -31,10 +31,11 @@ def main():
                                None, 0, None, 0, abi.LessThan, None, 0)
             cnt, k = timed(f)
             fbytes = n * (4 + 4 + (0.125 if nullf else 0) + 1) + cnt * 4
-            ms = k["filter_fast_kernel"]
+            ms = sum(v for name, v in k.items() if name.startswith("filter_"))
             print(json.dumps({"op": "filter", "nulls": nullf, "sel": sel, "rows": n, "survivors": cnt, "ms": round(ms, 4),
                               "traffic_GBps": round(fbytes / ms / 1e6, 1), "rows_per_s_G": round(n / ms / 1e6, 1),
-                              "init_ms": round(k["init_index_kernel"], 4)}), flush=True)
+                              "init_ms": round(k.get("init_index_kernel", 0), 4),
+                              "parts": {name: round(v, 4) for name, v in k.items() if name.startswith("filter_")}}), flush=True)
             ov = abi.OutputVector(); ov.Vector.Dimension.DimValues, ov.Vector.Dimension.DimNulls = dimv.data_ptr(), dimn.data_ptr()
             ov.Vector.Dimension.DataType = abi.Uint32; ov.Type = abi.DimensionOutput
             _, k = timed(lambda: be.call("BinaryTransform", column_input(b["ts"].vp), constant_input(3600), ov, idx.data_ptr(), cnt,

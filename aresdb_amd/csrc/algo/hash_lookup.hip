@@ -13,6 +13,7 @@
 #include "binding.hpp"
 #include "common.hpp"
 #include "device_model.hpp"
+#include "fast_eval.hpp"
 
 namespace ares {
 
@@ -32,12 +33,14 @@ struct LookupParams {
   uint32_t bucketBytes;
 };
 
+struct __attribute__((packed, aligned(1))) KeyWord { uint32_t v; };
+
 __device__ __forceinline__ bool key_equal(const uint8_t *slotKey, const uint32_t (&key)[4], int keyBytes) {
-  // keys are stored unaligned (offset 72 + j*keyBytes): compare byte-wise for odd sizes,
-  // word-wise when the size allows
-  if ((keyBytes & 3) == 0 && (reinterpret_cast<uintptr_t>(slotKey) & 3) == 0) {
+  // keys are stored unaligned (offset 72 + j*keyBytes): word-wise with byte-aligned loads when the
+  // size allows (gfx950 global loads need no alignment), byte-wise for odd sizes
+  if ((keyBytes & 3) == 0) {
     for (int w = 0; w < (keyBytes >> 2); w++)
-      if (reinterpret_cast<const uint32_t *>(slotKey)[w] != key[w]) return false;
+      if (reinterpret_cast<const KeyWord *>(slotKey)[w].v != key[w]) return false;
     return true;
   }
   for (int b = 0; b < keyBytes; b++)
@@ -46,6 +49,7 @@ __device__ __forceinline__ bool key_equal(const uint8_t *slotKey, const uint32_t
 }
 
 __global__ __launch_bounds__(kBlock) void hash_lookup_kernel(LookupParams p, RecordID *out, int n) {
+  const FastDivisor bucketDiv = make_fast_divisor(p.numBuckets);  // hv % numBuckets by multiply-high
   for (int64_t i64 = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i64 < n;
        i64 += static_cast<int64_t>(gridDim.x) * kBlock) {
     const uint32_t i = static_cast<uint32_t>(i64);
@@ -82,7 +86,10 @@ __global__ __launch_bounds__(kBlock) void hash_lookup_kernel(LookupParams p, Rec
       bool found = false;
       for (int h = 0; h < p.numHashes && !found; h++) {
         const uint32_t hv = murmur3_32_words<4>(key, p.keyBytes, p.seeds[h]);
-        const uint8_t *bucket = p.buckets + static_cast<size_t>(hv % p.numBuckets) * p.bucketBytes;
+        uint32_t bq, bidx;
+        fast_divmod(bucketDiv, hv, bq, bidx);
+        if (p.numBuckets == 1) bidx = 0;
+        const uint8_t *bucket = p.buckets + static_cast<size_t>(bidx) * p.bucketBytes;
         uint32_t sig = hv >> 24;
         if (sig < 1) sig = 1;
         // 8 signature bytes at offset 64 (bucket start is 8-byte aligned: bucketBytes % 8 == 0)

@@ -216,11 +216,25 @@ __global__ __launch_bounds__(kBlock) void fill_u64_kernel(uint64_t *p, uint64_t 
     p[i] = v;
 }
 
+// no dimensions: every row is the empty row, one constant hash (and nothing to sort)
+__global__ __launch_bounds__(kBlock) void sort_const_hash_kernel(uint64_t *hashes, int n) {
+  Murmur128Stream ms(0);
+  const uint64_t h = ms.finish();
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
+       i += static_cast<int64_t>(gridDim.x) * kBlock)
+    hashes[i] = h;
+}
+
 static void sort_impl(const DimensionVector &keys, int length, hipStream_t stream) {
   if (length <= 0) return;
   if (static_cast<int64_t>(length) >= (1ll << 30))
     throw std::invalid_argument("Sort supports up to 2^30 - 1 rows per call");
   const DimLayoutD L = make_dim_layout(keys.NumDimsPerDimWidth);
+  if (L.numDims == 0) {  // a stable sort of equal keys leaves the index vector untouched
+    ARES_LAUNCH("sort_const_hash_kernel", sort_const_hash_kernel, capped_grid((static_cast<int64_t>(length) + kBlock - 1) / kBlock, 256 * 8),
+                kBlock, stream, keys.HashValues, length);
+    return;
+  }
   const int numTiles = (length + kSortTile - 1) / kSortTile;
   const size_t histBytes = 8 * 256 * sizeof(uint32_t);
   const size_t statusBytes = static_cast<size_t>(numTiles) * 256 * sizeof(uint32_t);
@@ -239,7 +253,6 @@ static void sort_impl(const DimensionVector &keys, int length, hipStream_t strea
   const int grid = capped_grid((static_cast<int64_t>(length) + kBlock - 1) / kBlock, 256 * 8);
   ARES_LAUNCH("sort_hash_hist_kernel", sort_hash_hist_kernel, grid, kBlock, stream, keys.DimValues, L,
                      static_cast<size_t>(keys.VectorCapacity), keys.IndexVector, keys.HashValues, length, hist);
-  if (L.numDims == 0) return;  // every row hashes alike: a stable sort leaves the order untouched
   ARES_LAUNCH("digit_start_kernel", digit_start_kernel, 8, 256, stream, hist);
   const int passGrid = capped_grid(numTiles, 256 * 3);
   for (int pass = 0; pass < 8; pass++) {
@@ -286,6 +299,8 @@ __global__ __launch_bounds__(kBlock) void fill_identity_kernel(uint8_t *values, 
 }
 
 __global__ __launch_bounds__(kBlock) void reduce_kernel(ReduceParams p) {
+  __shared__ uint32_t sTrailG[kWaves], sTrailWhole[kWaves];
+  __shared__ uint64_t sTrailP[kWaves];
   __shared__ uint32_t sWave[kWaves];
   __shared__ uint32_t sTileExcl;
   __shared__ int sTile;
@@ -375,8 +390,39 @@ __global__ __launch_bounds__(kBlock) void reduce_kernel(ReduceParams p) {
       if (lane >= off && otherG == g && g != 0xffffffffu) part = combine_bits(p.agg, otherPart, part);
     }
     const uint32_t nextG = __shfl_down(g, 1);
-    if (open && (lane == 63 || nextG != g))
+    // runs that end inside the wavefront: one atomic each (different groups, little contention)
+    if (open && lane != 63 && nextG != g)
       aggregate_slot(p.valuesOut + static_cast<size_t>(p.agg.width) * g, reinterpret_cast<const uint8_t *>(&part), p.agg);
+    // the wavefront's trailing run may continue in the next one: when whole wavefronts belong to
+    // the same group their partials are combined in LDS first, so a group that spans the tile costs
+    // ONE atomic per tile instead of one per wavefront (a single hot address sustains < 100
+    // atomics per microsecond)
+    const uint32_t firstG = __shfl(g, 0);
+    const bool wholeWave = __ballot(open && g == firstG) == ~0ull;
+    if (lane == 63) {
+      sTrailG[wave] = open ? g : 0xffffffffu;
+      sTrailP[wave] = part;
+      sTrailWhole[wave] = wholeWave ? 1u : 0u;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t carryG = 0xffffffffu;
+      uint64_t carryP = 0;
+      for (int w = 0; w < kWaves; w++) {
+        const uint32_t gw = sTrailG[w];
+        if (gw == 0xffffffffu) continue;
+        if (carryG == gw && sTrailWhole[w]) {
+          carryP = combine_bits(p.agg, carryP, sTrailP[w]);
+        } else {
+          if (carryG != 0xffffffffu)
+            aggregate_slot(p.valuesOut + static_cast<size_t>(p.agg.width) * carryG, reinterpret_cast<const uint8_t *>(&carryP), p.agg);
+          carryG = gw;
+          carryP = sTrailP[w];
+        }
+      }
+      if (carryG != 0xffffffffu)
+        aggregate_slot(p.valuesOut + static_cast<size_t>(p.agg.width) * carryG, reinterpret_cast<const uint8_t *>(&carryP), p.agg);
+    }
     __syncthreads();
   }
 }

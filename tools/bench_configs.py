@@ -1,0 +1,92 @@
+"""BASELINE configs C2 and C4 at bench scale on one GPU (supplementary to bench.py, which is C3):
+  C2  100 M rows, single uint32 predicate + COUNT(*)            (filter + reduce only)
+  C4  N rows, fk -> cuckoo HashLookup join, group by (fk, joined attr) through Sort + Reduce
+Prints one JSON line per config with per-kernel HIP-event times."""
+import json, os, sys, time
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from aresdb_amd import abi, queries, workload
+from aresdb_amd.driver import NativeQuery
+from aresdb_amd.executor import Col, DimensionSpec, ForeignTable, QueryPlan
+
+
+def timed(be, fn, reps=3):
+    fn()
+    best, rep = 1e9, None
+    for _ in range(reps):
+        be.profiler_enable(True); torch.cuda.synchronize(); t0 = time.perf_counter()
+        r = fn(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        k = be.profiler_report(); be.profiler_enable(False)
+        if dt < best: best, rep, res = dt, k, r
+    return best, rep, res
+
+
+def c2(be, dev, rows):
+    g = torch.Generator(device=dev); g.manual_seed(1)
+    hi = 86400 * 30
+    ts = torch.randint(0, hi, (rows,), dtype=torch.int32, device=dev, generator=g)
+    valid = torch.rand((rows,), device=dev, generator=g) >= 0.01
+    col = workload._pack_column(torch.where(valid, ts, torch.zeros((), dtype=torch.int32, device=dev)), valid, abi.Uint32)
+    out = []
+    for sel in (0.1, 0.5, 0.9):
+        thr = int(hi * sel)
+        def run():
+            q = NativeQuery(be, queries.c2_plan(thr), ["ts"]); q.run({"ts": col.vp}, rows)
+            m = torch.empty(1, dtype=torch.int32, device=dev)
+            be.call("AsyncCopyDeviceToDevice", m.data_ptr(), q.measure_vector, 4, None, 0); be.wait()
+            c = int(m.item()); q.release(); return c
+        dt, k, cnt = timed(be, run)
+        want = int(((ts < thr) & valid).sum())
+        out.append({"config": "C2", "rows": rows, "selectivity": sel, "count": cnt, "count_ok": cnt == want, "ms": dt * 1e3,
+                    "rows_per_s": rows / dt, "algorithmic_GBps": rows * 4.125 / dt / 1e9,
+                    "kernels": {n: round(ms / c, 4) for n, (c, ms) in k.items()}})
+    return out
+
+
+def c4(be, dev, rows, nkeys):
+    import cases, harness as H
+    rng = np.random.default_rng(6)
+    per_batch = 1 << 20
+    keys = rng.choice(1 << 30, nkeys, replace=False).astype(np.uint32)
+    attr = rng.integers(0, 1000, nkeys).astype(np.uint32)
+    seeds = [int(x) for x in rng.integers(0, 1 << 32, 4)]
+    nb = (nkeys + per_batch - 1) // per_batch
+    table, placed = cases.build_cuckoo([int(k).to_bytes(4, "little") for k in keys], 4, max(nkeys // 6, 1), seeds, rng,
+                                       record_of=lambda i: (1 + i // per_batch, i % per_batch))
+    usable = np.array([i for i, k in enumerate(keys) if int(k).to_bytes(4, "little") in placed])
+    tb = H.Buf(be, table)
+    idx = abi.CuckooHashIndex(); idx.buckets = tb.ptr
+    for i, s in enumerate(seeds): idx.seeds[i] = s
+    idx.keyBytes, idx.numHashes, idx.numBuckets = 4, 4, max(nkeys // 6, 1)
+    dcols = [H.Column(be, abi.Uint32, attr[b * per_batch:(b + 1) * per_batch]) for b in range(nb)]
+    ft = ForeignTable(join_column="fk", index=idx, batches={"attr": [c.vp for c in dcols]}, data_types={"attr": abi.Uint32},
+                      base_batch_id=1, num_records_in_last_batch=nkeys - (nb - 1) * per_batch)
+    plan = QueryPlan(filters=[], foreign_tables=[ft], foreign_filters=[],
+                     dimensions=[DimensionSpec(Col("fk"), abi.Uint32), DimensionSpec(Col("attr", table=1), abi.Uint32)],
+                     measure=Col("amount"), agg=abi.AGGR_SUM_UNSIGNED, measure_type=abi.Uint32, use_hash_reduction=False)
+    g = torch.Generator(device=dev); g.manual_seed(2)
+    pick = torch.randint(0, len(usable), (rows,), device=dev, generator=g)
+    fk = torch.from_numpy(keys[usable].astype(np.int64)).to(dev)[pick].to(torch.int32)
+    amount = torch.randint(0, 100, (rows,), dtype=torch.int32, device=dev, generator=g)
+    cf, ca = workload._pack_column(fk, None, abi.Uint32), workload._pack_column(amount, None, abi.Uint32)
+    def run():
+        q = NativeQuery(be, plan, ["fk", "amount"]); q.run({"fk": cf.vp, "amount": ca.vp}, rows)
+        n = q.result_size
+        m = torch.empty(n, dtype=torch.int32, device=dev)
+        be.call("AsyncCopyDeviceToDevice", m.data_ptr(), q.measure_vector, 4 * n, None, 0); be.wait()
+        tot = int(m.to(torch.int64).sum()); q.release(); return n, tot
+    dt, k, (groups, tot) = timed(be, run)
+    return [{"config": "C4", "rows": rows, "keys": int(len(usable)), "groups": groups, "sum_ok": tot == int(amount.to(torch.int64).sum()),
+             "ms": dt * 1e3, "rows_per_s": rows / dt, "kernels": {n: round(ms / c, 4) for n, (c, ms) in k.items()}}]
+
+
+def main():
+    be = abi.load_hip_backend(); be.call("BootstrapDevice")
+    dev = torch.device("cuda:0")
+    res = c2(be, dev, 100_000_000) + c4(be, dev, 1 << 26, 200_000)
+    for r in res: print(json.dumps(r), flush=True)
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(res, open("gpurun_out/bench_configs.json", "w"), indent=1)
+main()

@@ -28,9 +28,9 @@ def main():
         return v
     mval = torch.rand((rows,), dtype=torch.float64, device=dev, generator=g)
     outm = torch.empty(cap, dtype=torch.float64, device=dev)
-    for mode in ("c3", "16000000"):
+    for mode in ("c3",):
         dims = mk(mode); outd = torch.empty_like(dims); torch.cuda.synchronize()
-        for env in [("lds", "0"), ("lds", "16")]:
+        for env in [("lds", "0"), ("lds", "8"), ("lds", "16"), ("lds", "24")]:
             if env[0] == "global": os.environ["ARES_HASH_REDUCE"] = "global"
             else: os.environ.pop("ARES_HASH_REDUCE", None)
             os.environ["ARES_HR_DEBUG"] = env[1]

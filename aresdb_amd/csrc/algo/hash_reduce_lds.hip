@@ -438,6 +438,8 @@ __device__ __forceinline__ void partition_body(Source &src, const AggSpec &a, in
       }
     }
     __syncthreads();
+    uint32_t reservedBase = 0;
+    bool reserved = false;
     {  // exclusive scan of the partition counts (numParts <= kThreads), global reservation
       const uint32_t c = threadIdx.x < static_cast<uint32_t>(numParts) ? sPartCount[threadIdx.x] : 0u;
       uint32_t incl = c;
@@ -452,7 +454,10 @@ __device__ __forceinline__ void partition_body(Source &src, const AggSpec &a, in
       for (int w = 0; w < wave; w++) before += sWaveSum[w];
       if (threadIdx.x < static_cast<uint32_t>(numParts)) {
         sPartLocal[threadIdx.x] = before + incl - c;
-        if (c) sPartBase[threadIdx.x] = atomicAdd(ws.cursors + threadIdx.x, c);
+        // the reservation's round trip (a returning global atomic, ~2 us) overlaps the staging below:
+        // its result is only published to LDS right before the write-back needs it
+        if (c) reservedBase = atomicAdd(ws.cursors + threadIdx.x, c);
+        reserved = c != 0;
         sPartCount[threadIdx.x] = 0;
         if (threadIdx.x == static_cast<uint32_t>(numParts) - 1) sStaged = before + incl;
       }
@@ -467,6 +472,7 @@ __device__ __forceinline__ void partition_body(Source &src, const AggSpec &a, in
         sVals[at] = v[j];
       }
     }
+    if (reserved) sPartBase[threadIdx.x] = reservedBase;
     __syncthreads();
     {
       const uint32_t staged = sStaged;

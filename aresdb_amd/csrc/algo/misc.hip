@@ -1,5 +1,5 @@
 // Entry points of the ABI that are outside the hot-path scope of this build (SURVEY.md 8:
-// HyperLogLog is "next", geo intersection is out) plus BootstrapDevice.  They are exported so
+// geo intersection) plus BootstrapDevice.  They are exported so
 // that the library is link-compatible with the Go host (query/time_series_aggregate.go binds all
 // 14 symbols); calling one returns a clean error through the cgo convention instead of crashing.
 #include "common.hpp"
@@ -7,13 +7,6 @@
 using namespace ares;
 
 extern "C" {
-
-CGoCallResHandle HyperLogLog(DimensionVector, DimensionVector, uint32_t *, uint32_t *, int, int, bool, uint8_t **,
-                             size_t *, uint16_t **, void *, int device) {
-  ARES_ABI_BEGIN(device)
-  throw AlgorithmError("HyperLogLog is not implemented by the MI355X library yet (SURVEY.md 8f item 2)");
-  ARES_ABI_END("HyperLogLog")
-}
 
 CGoCallResHandle GeoBatchIntersects(GeoShapeBatch, InputVector, uint32_t *, int, uint32_t, RecordID **, int,
                                     uint32_t *, bool, void *, int device) {

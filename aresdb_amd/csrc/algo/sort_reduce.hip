@@ -28,9 +28,13 @@ constexpr int kWaves = kBlock / 64;
 // ---------------------------------------------------------------------------------------------
 // Sort step 1: hashes + global digit histograms
 // ---------------------------------------------------------------------------------------------
+// hllValues != nullptr: the key is the HyperLogLog sort key (query/functor.hpp:1296-1305): the dim
+// hash with its low 16 bits replaced by the register id of entry i.  iotaOut != nullptr: the
+// payload that travels with the keys is the entry's position.
 __global__ __launch_bounds__(kBlock) void sort_hash_hist_kernel(const uint8_t *dimValues, DimLayoutD L, size_t capacity,
                                                                 const uint32_t *indexVector, uint64_t *hashes, int n,
-                                                                uint32_t *globalHist /* [8][256] */) {
+                                                                uint32_t *globalHist /* [8][256] */,
+                                                                const uint32_t *hllValues, uint32_t *iotaOut) {
   __shared__ uint32_t sHist[8 * 256];
   for (int i = threadIdx.x; i < 8 * 256; i += kBlock) sHist[i] = 0;
   __syncthreads();
@@ -38,7 +42,9 @@ __global__ __launch_bounds__(kBlock) void sort_hash_hist_kernel(const uint8_t *d
        i += static_cast<int64_t>(gridDim.x) * kBlock) {
     Murmur128Stream ms(0);
     hash_dim_row(ms, dimValues, L, capacity, indexVector[i]);
-    const uint64_t h = ms.finish();
+    uint64_t h = ms.finish();
+    if (hllValues) h = (h & 0xFFFFFFFFFFFF0000ull) | (hllValues[i] & 0x3FFFu);
+    if (iotaOut) iotaOut[i] = static_cast<uint32_t>(i);
     hashes[i] = h;
 #pragma unroll
     for (int p = 0; p < 8; p++) atomicAdd(&sHist[p * 256 + ((h >> (8 * p)) & 255)], 1u);
@@ -225,14 +231,15 @@ __global__ __launch_bounds__(kBlock) void sort_const_hash_kernel(uint64_t *hashe
     hashes[i] = h;
 }
 
-static void sort_impl(const DimensionVector &keys, int length, hipStream_t stream) {
+void sort_rows(const uint8_t *dimValues, const DimLayoutD &L, size_t capacity, const uint32_t *rowIndex,
+               const uint32_t *hllValues, uint64_t *keyVector, uint32_t *payload, bool iotaPayload, int length,
+               hipStream_t stream) {
   if (length <= 0) return;
   if (static_cast<int64_t>(length) >= (1ll << 30))
     throw std::invalid_argument("Sort supports up to 2^30 - 1 rows per call");
-  const DimLayoutD L = make_dim_layout(keys.NumDimsPerDimWidth);
-  if (L.numDims == 0) {  // a stable sort of equal keys leaves the index vector untouched
+  if (L.numDims == 0 && !hllValues) {  // a stable sort of equal keys leaves the index vector untouched
     ARES_LAUNCH("sort_const_hash_kernel", sort_const_hash_kernel, capped_grid((static_cast<int64_t>(length) + kBlock - 1) / kBlock, 256 * 8),
-                kBlock, stream, keys.HashValues, length);
+                kBlock, stream, keyVector, length);
     return;
   }
   const int numTiles = (length + kSortTile - 1) / kSortTile;
@@ -251,20 +258,25 @@ static void sort_impl(const DimensionVector &keys, int length, hipStream_t strea
   hip_check(hipMemsetAsync(base, 0, offStatus, stream), "hipMemsetAsync");
 
   const int grid = capped_grid((static_cast<int64_t>(length) + kBlock - 1) / kBlock, 256 * 8);
-  ARES_LAUNCH("sort_hash_hist_kernel", sort_hash_hist_kernel, grid, kBlock, stream, keys.DimValues, L,
-                     static_cast<size_t>(keys.VectorCapacity), keys.IndexVector, keys.HashValues, length, hist);
+  ARES_LAUNCH("sort_hash_hist_kernel", sort_hash_hist_kernel, grid, kBlock, stream, dimValues, L, capacity, rowIndex,
+              keyVector, length, hist, hllValues, iotaPayload ? payload : nullptr);
   ARES_LAUNCH("digit_start_kernel", digit_start_kernel, 8, 256, stream, hist);
   const int passGrid = capped_grid(numTiles, 256 * 3);
   for (int pass = 0; pass < 8; pass++) {
     hip_check(hipMemsetAsync(status, 0, statusBytes, stream), "hipMemsetAsync");
     const bool even = (pass & 1) == 0;
-    ARES_LAUNCH("radix_pass_kernel", radix_pass_kernel, passGrid, kBlock, stream, even ? keys.HashValues : altKeys, even ? keys.IndexVector : altVals,
-                       even ? altKeys : keys.HashValues, even ? altVals : keys.IndexVector, length, 8 * pass,
+    ARES_LAUNCH("radix_pass_kernel", radix_pass_kernel, passGrid, kBlock, stream, even ? keyVector : altKeys, even ? payload : altVals,
+                       even ? altKeys : keyVector, even ? altVals : payload, length, 8 * pass,
                        hist + 256 * pass, tickets + pass, tickets + 8, status, numTiles);
   }
   uint32_t err = 0;
   read_back_u32(tickets + 8, &err, 1, stream);
   if (err) throw AlgorithmError("ERROR: Sort: inter-tile scan timed out");
+}
+
+static void sort_impl(const DimensionVector &keys, int length, hipStream_t stream) {
+  sort_rows(keys.DimValues, make_dim_layout(keys.NumDimsPerDimWidth), static_cast<size_t>(keys.VectorCapacity),
+            keys.IndexVector, nullptr, keys.HashValues, keys.IndexVector, false, length, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -290,6 +302,11 @@ struct ReduceParams {
   uint32_t *total;
   uint32_t *error;
   uint64_t *status;
+  // HyperLogLog's reduceCurrentBatch (query/hll.cu:211-231): indexIn holds entry positions; the
+  // value and the dimension row of an entry are valuesIn[pos] and indexSrc[pos], the run's key goes
+  // to hashOut and no dimension row is copied
+  const uint32_t *indexSrc;
+  uint64_t *hashOut;
 };
 
 __global__ __launch_bounds__(kBlock) void fill_identity_kernel(uint8_t *values, AggSpec a, int n) {
@@ -298,6 +315,7 @@ __global__ __launch_bounds__(kBlock) void fill_identity_kernel(uint8_t *values, 
     store_value_bits(values, a, static_cast<size_t>(i), a.identity);
 }
 
+template <bool HLL>
 __global__ __launch_bounds__(kBlock) void reduce_kernel(ReduceParams p) {
   __shared__ uint32_t sTrailG[kWaves], sTrailWhole[kWaves];
   __shared__ uint64_t sTrailP[kWaves];
@@ -370,8 +388,13 @@ __global__ __launch_bounds__(kBlock) void reduce_kernel(ReduceParams p) {
         if (open) aggregate_slot(p.valuesOut + static_cast<size_t>(p.agg.width) * group,
                                  reinterpret_cast<const uint8_t *>(&acc), p.agg);
         group++;
-        p.indexOut[group] = idx[j];
-        copy_dim_row(p.dimIn, p.capacity, p.dimOut, p.capacity, p.L, idx[j], group);
+        if (HLL) {
+          p.indexOut[group] = p.indexSrc[idx[j]];
+          p.hashOut[group] = h[j];
+        } else {
+          p.indexOut[group] = idx[j];
+          copy_dim_row(p.dimIn, p.capacity, p.dimOut, p.capacity, p.L, idx[j], group);
+        }
         acc = load_value_bits(p.valuesIn, p.agg, idx[j]);
       } else {
         const uint64_t v = load_value_bits(p.valuesIn, p.agg, idx[j]);
@@ -453,10 +476,46 @@ static int reduce_impl(const DimensionVector &in, uint8_t *inputValues, const Di
   // every group slot starts from the aggregate's identity; partials are merged with atomics
   const int fillGrid = capped_grid((static_cast<int64_t>(length) + kBlock - 1) / kBlock, 256 * 8);
   ARES_LAUNCH("fill_identity_kernel", fill_identity_kernel, fillGrid, kBlock, stream, outputValues, p.agg, length);
-  ARES_LAUNCH("reduce_kernel", reduce_kernel, capped_grid(p.numTiles), kBlock, stream, p);
+  p.indexSrc = nullptr;
+  p.hashOut = nullptr;
+  ARES_LAUNCH("reduce_kernel", reduce_kernel<false>, capped_grid(p.numTiles), kBlock, stream, p);
   uint32_t result[2] = {0, 0};  // {groups, error}
   read_back_u32(p.total, result, 2, stream);
   if (result[1]) throw AlgorithmError("ERROR: Reduce: inter-tile scan timed out");
+  return static_cast<int>(result[0]);
+}
+
+int hll_reduce_sorted(const uint64_t *keys, const uint32_t *positions, const uint32_t *indexSrc,
+                      const uint32_t *valuesSrc, uint64_t *hashOut, uint32_t *indexOut, uint32_t *valuesOut,
+                      int length, hipStream_t stream) {
+  if (length <= 0) return 0;
+  ReduceParams p;
+  p.agg = make_agg_spec(AGGR_MAX_UNSIGNED, 4);
+  p.hashes = keys;
+  p.indexIn = positions;
+  p.valuesIn = reinterpret_cast<const uint8_t *>(valuesSrc);
+  p.indexOut = indexOut;
+  p.valuesOut = reinterpret_cast<uint8_t *>(valuesOut);
+  p.dimIn = nullptr;
+  p.dimOut = nullptr;
+  p.L = DimLayoutD{};
+  p.capacity = 0;
+  p.n = length;
+  p.numTiles = (length + kReduceTile - 1) / kReduceTile;
+  p.indexSrc = indexSrc;
+  p.hashOut = hashOut;
+  StreamBuffer ws(16 + sizeof(uint64_t) * static_cast<size_t>(p.numTiles), stream);
+  hip_check(hipMemsetAsync(ws.get(), 0, 16 + sizeof(uint64_t) * static_cast<size_t>(p.numTiles), stream),
+            "hipMemsetAsync");
+  p.ticket = ws.as<unsigned int>();
+  p.total = ws.as<uint32_t>() + 1;
+  p.error = ws.as<uint32_t>() + 2;
+  p.status = reinterpret_cast<uint64_t *>(ws.as<uint8_t>() + 16);
+  hip_check(hipMemsetAsync(valuesOut, 0, sizeof(uint32_t) * static_cast<size_t>(length), stream), "hipMemsetAsync");
+  ARES_LAUNCH("hll_reduce_kernel", reduce_kernel<true>, capped_grid(p.numTiles), kBlock, stream, p);
+  uint32_t result[2] = {0, 0};  // {runs, error}
+  read_back_u32(p.total, result, 2, stream);
+  if (result[1]) throw AlgorithmError("ERROR: HyperLogLog: inter-tile scan timed out");
   return static_cast<int>(result[0]);
 }
 

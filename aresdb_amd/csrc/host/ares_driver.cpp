@@ -57,6 +57,7 @@ struct AbiLibrary {
   decltype(&::DeviceAllocate) DeviceAllocate;
   decltype(&::DeviceFree) DeviceFree;
   decltype(&::WaitForCudaStream) WaitForCudaStream;
+  decltype(&::HyperLogLog) HyperLogLog;
   decltype(&::AsyncCopyDeviceToDevice) AsyncCopyDeviceToDevice;
   decltype(&::AsyncCopyDeviceToHost) AsyncCopyDeviceToHost;
 
@@ -80,6 +81,7 @@ struct AbiLibrary {
     bind(algoHandle, "Sort", Sort);
     bind(algoHandle, "Reduce", Reduce);
     bind(algoHandle, "HashReduce", HashReduce);
+    bind(algoHandle, "HyperLogLog", HyperLogLog);
     FusedFilterHashReduce = reinterpret_cast<decltype(FusedFilterHashReduce)>(dlsym(algoHandle, "AresFusedFilterHashReduce"));
     bind(memHandle, "DeviceAllocate", DeviceAllocate);
     bind(memHandle, "DeviceFree", DeviceFree);
@@ -163,6 +165,7 @@ struct Plan {
     }
   }
   int measureBytes() const { return data_type_bytes(measureType); }
+  bool isHLL() const { return aggFunc == AGGR_HLL; }  // OOPKContext.IsHLL, query/aql_context.go:421-424
   int dimRowBytes() const {
     int b = 0;
     for (int t : dimTypes) b += data_type_bytes(t) + 1;
@@ -183,6 +186,11 @@ struct AresQuery {
   int resultSize = 0, resultCapacity = 0;
   uint8_t *dimVec[2] = {nullptr, nullptr};
   uint8_t *measureVec[2] = {nullptr, nullptr};
+  // HyperLogLog queries (query/aql_context.go:289-294): allocated by the library on the last batch
+  uint8_t *hllVector = nullptr;
+  uint16_t *hllDimRegIDCount = nullptr;
+  size_t hllVectorSize = 0;
+  bool isLastBatch = false;
   uint64_t *hashVec[2] = {nullptr, nullptr};
   uint32_t *dimIndexVec[2] = {nullptr, nullptr};
   int size = 0;
@@ -266,11 +274,17 @@ struct AresQuery {
       release(old0);
       release(old1);
     }
-    if (!plan.useHashReduction) {
+    if (plan.isHLL() || !plan.useHashReduction) {
       release(dimIndexVec[0]); release(dimIndexVec[1]);
-      release(hashVec[0]); release(hashVec[1]);
       dimIndexVec[0] = alloc<uint32_t>(cap * 4); dimIndexVec[1] = alloc<uint32_t>(cap * 4);
+      uint64_t *old0 = hashVec[0], *old1 = hashVec[1];
       hashVec[0] = alloc<uint64_t>(cap * 8); hashVec[1] = alloc<uint64_t>(cap * 8);
+      // HyperLogLog keeps the merged keys of the earlier batches in hash vector [0]
+      if (plan.isHLL() && old0 && resultSize) {
+        d2d(hashVec[0], old0, static_cast<size_t>(resultSize) * 8);
+        wait();
+      }
+      release(old0); release(old1);
     }
     {
       const int mb = plan.measureBytes();
@@ -319,6 +333,8 @@ struct AresQuery {
       release(dimVec[i]); release(measureVec[i]); release(hashVec[i]); release(dimIndexVec[i]);
       dimVec[i] = nullptr; measureVec[i] = nullptr; hashVec[i] = nullptr; dimIndexVec[i] = nullptr;
     }
+    release(hllVector); release(hllDimRegIDCount);
+    hllVector = nullptr; hllDimRegIDCount = nullptr; hllVectorSize = 0;
     resultCapacity = 0;
   }
 
@@ -402,6 +418,8 @@ struct AresQuery {
     OV ov;
     if (a.kind == Action::MEASURE) {
       ov->Vector.Measure.Values = reinterpret_cast<uint32_t *>(measureVec[0] + static_cast<size_t>(resultSize) * plan.measureBytes());
+      // hll values of the batch go to measure vector [1] (time_series_aggregate.go:404-408)
+      if (plan.isHLL()) ov->Vector.Measure.Values = reinterpret_cast<uint32_t *>(measureVec[1]);
       ov->Vector.Measure.DataType = static_cast<DataType>(plan.measureType);
       ov->Vector.Measure.AggFunc = static_cast<AggregateFunction>(plan.aggFunc);
       ov->Type = MeasureOutput;
@@ -533,7 +551,21 @@ struct AresQuery {
   void reduce() {
     const int length = resultSize + size;
     const int mb = plan.measureBytes();
-    if (plan.useHashReduction) {
+    if (plan.isHLL()) {  // query/aql_batchexecutor.go:221-233, query/time_series_aggregate.go:661-680
+      calls += 3;
+      check(lib->InitIndexVector(dimIndexVec[0], 0, resultSize, stream, device));
+      check(lib->InitIndexVector(dimIndexVec[1], static_cast<uint32_t>(resultSize), length, stream, device));
+      uint8_t *vec = nullptr;
+      uint16_t *counts = nullptr;
+      size_t vecSize = 0;
+      resultSize = static_cast<int>(check(lib->HyperLogLog(
+          dimensionVector(0), dimensionVector(1), reinterpret_cast<uint32_t *>(measureVec[0]),
+          reinterpret_cast<uint32_t *>(measureVec[1]), resultSize, size, isLastBatch, &vec, &vecSize, &counts, stream, device)));
+      if (vec || counts) {
+        release(hllVector); release(hllDimRegIDCount);
+        hllVector = vec; hllDimRegIDCount = counts; hllVectorSize = vecSize;
+      }
+    } else if (plan.useHashReduction) {
       calls++;
       resultSize = static_cast<int>(check(lib->HashReduce(dimensionVector(0), measureVec[0], dimensionVector(1), measureVec[1],
                                                           mb, length, static_cast<AggregateFunction>(plan.aggFunc), stream,
@@ -679,6 +711,23 @@ uint8_t *AresQueryDimensionVector(const AresQuery *q) { return q->dimVec[0]; }
 uint8_t *AresQueryMeasureVector(const AresQuery *q) { return q->measureVec[0]; }
 long AresQueryNumCalls(const AresQuery *q) { return q->calls; }
 long AresQueryNumFusedBatches(const AresQuery *q) { return q->fusedBatches; }
+void AresQuerySetLastBatch(AresQuery *q, int isLast) { q->isLastBatch = isLast != 0; }
+int64_t AresQueryHLLVectorSize(const AresQuery *q) { return static_cast<int64_t>(q->hllVectorSize); }
+
+int AresQueryFetchHLL(AresQuery *q, uint16_t *regCounts, uint8_t *hllVector, char *err, int errLen) {
+  try {
+    const int n = q->resultSize;
+    if (n && q->hllDimRegIDCount)
+      check(q->lib->AsyncCopyDeviceToHost(regCounts, q->hllDimRegIDCount, static_cast<size_t>(n) * 2, q->stream, q->device));
+    if (n && q->hllVector)
+      check(q->lib->AsyncCopyDeviceToHost(hllVector, q->hllVector, q->hllVectorSize, q->stream, q->device));
+    q->wait();
+    return 0;
+  } catch (std::exception &e) {
+    set_err(err, errLen, e.what());
+    return -1;
+  }
+}
 
 int AresQueryFetch(AresQuery *q, uint8_t *dims, uint8_t *measures, char *err, int errLen) {
   try {
@@ -701,7 +750,7 @@ int AresQueryFetch(AresQuery *q, uint8_t *dims, uint8_t *measures, char *err, in
       check(q->lib->AsyncCopyDeviceToHost(out, q->dimVec[0] + no, static_cast<size_t>(n), q->stream, q->device));
       out += n;
     }
-    if (n) check(q->lib->AsyncCopyDeviceToHost(measures, q->measureVec[0], static_cast<size_t>(n) * q->plan.measureBytes(),
+    if (n && measures) check(q->lib->AsyncCopyDeviceToHost(measures, q->measureVec[0], static_cast<size_t>(n) * q->plan.measureBytes(),
                                                q->stream, q->device));
     q->wait();
     return 0;

@@ -82,6 +82,13 @@ long AresQueryNumFusedBatches(const AresQuery *q);     /* batches that took the 
 /* D2H of the result (query/aql_processor.go:641-671): dims = for each dim in vector order
  * resultSize*width value bytes, then numDims x resultSize validity bytes; measures. */
 int AresQueryFetch(AresQuery *q, uint8_t *dims, uint8_t *measures, char *err, int errLen);
+/* HyperLogLog queries (aggFunc == AGGR_HLL, measure = GetHLLValue(column) into a Uint32 vector):
+ * the executor must know which batch is the last one (query/aql_batchexecutor.go:62-100); after it,
+ * the result is the dimension columns (AresQueryFetch, measures may be NULL), the registers per
+ * dimension (uint16 x resultSize) and the encoded HLL vector (query/hll.go:52-63). */
+void AresQuerySetLastBatch(AresQuery *q, int isLast);
+int64_t AresQueryHLLVectorSize(const AresQuery *q);
+int AresQueryFetchHLL(AresQuery *q, uint16_t *regCounts, uint8_t *hllVector, char *err, int errLen);
 void AresQueryDestroy(AresQuery *q);
 
 #ifdef __cplusplus

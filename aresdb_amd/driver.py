@@ -64,6 +64,10 @@ def _driver():
         lib.AresQueryFetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
         lib.AresQueryFetch.restype = C.c_int
         lib.AresQueryDestroy.argtypes = [C.c_void_p]
+        lib.AresQuerySetLastBatch.argtypes = [C.c_void_p, C.c_int]
+        lib.AresQueryHLLVectorSize.argtypes, lib.AresQueryHLLVectorSize.restype = [C.c_void_p], C.c_int64
+        lib.AresQueryFetchHLL.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
+        lib.AresQueryFetchHLL.restype = C.c_int
         _lib = lib
     return _lib
 
@@ -154,8 +158,9 @@ class NativeQuery:
             raise abi.AresError(err.value.decode())
         self._err = C.create_string_buffer(1024)
 
-    def run(self, columns, size, base_counts=None, start_row=0):
+    def run(self, columns, size, base_counts=None, start_row=0, is_last_batch=False):
         """columns: {name: VectorPartySlice} of the main table for this batch."""
+        _driver().AresQuerySetLastBatch(self._q, int(is_last_batch))
         cols = (abi.VectorPartySlice * len(self.column_names))(*[columns[n] for n in self.column_names])
         rc = _driver().AresQueryRunBatch(self._q, cols, len(self.column_names), size, base_counts, start_row,
                                          self._err, 1024)
@@ -225,6 +230,19 @@ class NativeQuery:
             dims.append(dims_blob[starts[d]:starts[d] + widths[d] * n].copy())
             valids.append(dims_blob[null_base + d * n: null_base + (d + 1) * n].copy())
         return dims, valids, meas[:n * plan.measure_bytes].copy()
+
+    def fetch_hll(self):
+        """(dims, valids, registers per dimension, encoded HLL vector) of a HyperLogLog query."""
+        dims, valids, _ = self.fetch()
+        n = self.result_size
+        counts = np.empty(max(n, 1), np.uint16)
+        vec = np.empty(max(_driver().AresQueryHLLVectorSize(self._q) if n else 0, 1), np.uint8)
+        rc = _driver().AresQueryFetchHLL(self._q, counts.ctypes.data_as(C.c_void_p), vec.ctypes.data_as(C.c_void_p),
+                                         self._err, 1024)
+        if rc != 0:
+            raise abi.AresError(self._err.value.decode().strip())
+        size = _driver().AresQueryHLLVectorSize(self._q) if n else 0
+        return dims, valids, counts[:n].copy(), vec[:size].copy()
 
     def release(self):
         if self._q:

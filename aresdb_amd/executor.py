@@ -87,6 +87,11 @@ class QueryPlan:
     def measure_bytes(self):
         return abi.DATA_TYPE_BYTES[self.measure_type]
 
+    @property
+    def is_hll(self):
+        """OOPKContext.IsHLL (query/aql_context.go:421-424)."""
+        return self.agg == abi.AGGR_HLL
+
     def num_dims_per_width(self):
         return tuple(sum(1 for d in self.dimensions if d.width == w) for w in DIM_WIDTHS)
 
@@ -155,6 +160,11 @@ class BatchContext:
         self.foreign_rids: List[int] = []
         self._keepalive = []
         self.calls = 0  # ABI calls issued (for tests / stats)
+        # HyperLogLog queries: buffers the library allocates on the last batch
+        # (query/aql_context.go:289-294), released with DeviceFree like every other buffer
+        self.hll_vector = 0
+        self.hll_dim_reg_count = 0
+        self.hll_vector_size = 0
 
     # -- allocation helpers (device_allocator.go semantics: every byte is tracked and freed) --------
     def _alloc(self, nbytes):
@@ -214,8 +224,12 @@ class BatchContext:
                                  self.stream, self.device)
 
         realloc(self.dim_vec, max(plan.dim_row_bytes, 1), copy_dims)
-        if not plan.use_hash_reduction:
+        if plan.is_hll or not plan.use_hash_reduction:
             realloc(self.dim_index_vec, 4, None)
+        if plan.is_hll:  # the merged keys of the earlier batches live in hash vector [0]
+            realloc(self.hash_vec, 8, lambda to, frm: self.result_size and self.be.call(
+                "AsyncCopyDeviceToDevice", to, frm, self.result_size * 8, self.stream, self.device))
+        elif not plan.use_hash_reduction:
             realloc(self.hash_vec, 8, None)
         mb = plan.measure_bytes
         realloc(self.measure_vec, mb, lambda to, frm: self.result_size and self.be.call(
@@ -256,6 +270,9 @@ class BatchContext:
                 self._free(pair[i])
                 pair[i] = 0
         self.result_capacity = 0
+        self._free(self.hll_vector)
+        self._free(self.hll_dim_reg_count)
+        self.hll_vector = self.hll_dim_reg_count = 0
 
     # -- processExpression (time_series_aggregate.go:491-593) ---------------------------------------
     def _foreign_input(self, e: Col):
@@ -351,6 +368,8 @@ class BatchContext:
         plan = self.plan
         ov = abi.OutputVector()
         ov.Vector.Measure.Values = self.measure_vec[0] + self.result_size * plan.measure_bytes
+        if plan.is_hll:  # hll values of the batch go to measure vector [1] (time_series_aggregate.go:404-408)
+            ov.Vector.Measure.Values = self.measure_vec[1]
         ov.Vector.Measure.DataType = plan.measure_type
         ov.Vector.Measure.AggFunc = plan.agg
         ov.Type = abi.MeasureOutput
@@ -388,9 +407,12 @@ class BatchExecutor:
 
     def __init__(self, ctx: BatchContext):
         self.ctx = ctx
+        self.is_last_batch = False
 
-    def run(self, columns: Dict[str, abi.VectorPartySlice], size: int, base_counts=None, start_row=0):
+    def run(self, columns: Dict[str, abi.VectorPartySlice], size: int, base_counts=None, start_row=0,
+            is_last_batch=False):
         c = self.ctx
+        self.is_last_batch = is_last_batch
         c.prepare_for_filtering(columns, size, base_counts, start_row)
         self.pre_exec()
         self.filter()
@@ -435,7 +457,18 @@ class BatchExecutor:
         c = self.ctx
         plan = c.plan
         length = c.result_size + c.size
-        if plan.use_hash_reduction:
+        if plan.is_hll:  # query/aql_batchexecutor.go:221-233, query/time_series_aggregate.go:661-680
+            c.call("InitIndexVector", c.dim_index_vec[0], 0, c.result_size, c.stream, c.device)
+            c.call("InitIndexVector", c.dim_index_vec[1], c.result_size, length, c.stream, c.device)
+            vec, size, counts = C.c_void_p(0), C.c_size_t(0), C.c_void_p(0)
+            c.result_size = c.call("HyperLogLog", c.dimension_vector(0), c.dimension_vector(1), c.measure_vec[0],
+                                   c.measure_vec[1], c.result_size, c.size, bool(self.is_last_batch),
+                                   C.addressof(vec), C.addressof(size), C.addressof(counts), c.stream, c.device)
+            if vec.value or counts.value:
+                c._free(c.hll_vector)
+                c._free(c.hll_dim_reg_count)
+                c.hll_vector, c.hll_dim_reg_count, c.hll_vector_size = vec.value or 0, counts.value or 0, size.value
+        elif plan.use_hash_reduction:
             c.result_size = c.call("HashReduce", c.dimension_vector(0), c.measure_vec[0], c.dimension_vector(1),
                                    c.measure_vec[1], plan.measure_bytes, length, plan.agg, c.stream, c.device)
         else:
@@ -468,3 +501,26 @@ def fetch_results(ctx: BatchContext):
         be.d2h(meas.ctypes.data_as(C.c_void_p), ctx.measure_vec[0], meas.nbytes, ctx.stream, ctx.device)
     be.wait(ctx.stream, ctx.device)
     return dims, valids, meas
+
+
+def fetch_hll_results(ctx: BatchContext):
+    """What SerializeHLL copies to the host (query/hll.go:52-63): the dimension columns, the
+    registers-per-dimension counts (uint16) and the encoded HLL vector."""
+    be, plan, n = ctx.be, ctx.plan, ctx.result_size
+    dims, valids = [], []
+    for i, dim in enumerate(plan.dimensions):
+        vo, no = dimension_start_offsets(ctx.ndw, ctx.dim_index[i], ctx.result_capacity)
+        v = np.empty(n * dim.width, np.uint8)
+        m = np.empty(n, np.uint8)
+        if n:
+            be.d2h(v.ctypes.data_as(C.c_void_p), ctx.dim_vec[0] + vo, v.nbytes, ctx.stream, ctx.device)
+            be.d2h(m.ctypes.data_as(C.c_void_p), ctx.dim_vec[0] + no, m.nbytes, ctx.stream, ctx.device)
+        dims.append(v)
+        valids.append(m)
+    counts = np.empty(n, np.uint16)
+    vec = np.empty(ctx.hll_vector_size if n else 0, np.uint8)
+    if n:
+        be.d2h(counts.ctypes.data_as(C.c_void_p), ctx.hll_dim_reg_count, counts.nbytes, ctx.stream, ctx.device)
+        be.d2h(vec.ctypes.data_as(C.c_void_p), ctx.hll_vector, vec.nbytes, ctx.stream, ctx.device)
+    be.wait(ctx.stream, ctx.device)
+    return dims, valids, counts, vec

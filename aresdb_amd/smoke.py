@@ -71,6 +71,56 @@ def run_query_native(be, plan, batches, stream=None):
     return out, calls
 
 
+def _hll_groups(dims, valids, counts, vec):
+    """{dimension key: sorted register list [(register, rho)]} from the encoded HLL vector
+    (sparse: uint32 rho << 16 | register; dense: one rho byte per register; query/common/hll.go:547-575)."""
+    n = len(counts)
+    out, off = {}, 0
+    for r in range(n):
+        key = tuple((bytes(d[r * len(d) // n:(r + 1) * len(d) // n]), int(v[r])) for d, v in zip(dims, valids))
+        c = int(counts[r])
+        if c < 4096:
+            words = vec[off:off + 4 * c].view(np.uint32)
+            regs = sorted((int(w & 0xFFFF), int(w >> 16)) for w in words)
+            off += 4 * c
+        else:
+            dense = vec[off:off + 16384]
+            regs = [(int(i), int(dense[i])) for i in np.nonzero(dense)[0]]
+            off += 16384
+        assert key not in out
+        out[key] = regs
+    assert off == len(vec)
+    return out
+
+
+def run_hll_query(be, plan, batches, native=False, stream=None):
+    """A HyperLogLog query (plan.agg == AGGR_HLL) over `batches`; returns ({key: registers}, calls)."""
+    from .executor import fetch_hll_results
+    if native:
+        from .driver import NativeQuery
+        q = NativeQuery(be, plan, list(batches[0][0].keys()), stream=stream)
+    else:
+        ctx = BatchContext(be, plan)
+        ex = BatchExecutor(ctx)
+    for b, (cols, valid) in enumerate(batches):
+        dev = {k: DeviceColumn(be, t, v, valid=valid[k], stream=stream) for k, (t, v) in cols.items()}
+        n = len(next(iter(cols.values()))[1])
+        last = b == len(batches) - 1
+        if native:
+            q.run({k: d.vp for k, d in dev.items()}, n, is_last_batch=last)
+        else:
+            ex.run({k: d.vp for k, d in dev.items()}, n, is_last_batch=last)
+        for d in dev.values():
+            d.free()
+    if native:
+        res, calls = q.fetch_hll(), q.calls
+        q.release()
+    else:
+        res, calls = fetch_hll_results(ctx), ctx.calls
+        ctx.release()
+    return _hll_groups(*res), calls
+
+
 def compare_results(got, want, rel=1e-6):
     assert got.keys() == want.keys(), f"group keys differ: {len(got)} vs {len(want)}"
     for k, v in want.items():

@@ -1254,15 +1254,167 @@ CGoCallResHandle Expand(DimensionVector inputKeys, DimensionVector outputKeys,
   return HANDLE_OK(outLen + outputOccupiedLen);
 }
 
+/* ---- HyperLogLog (query/hll.cu:62-290) -------------------------------------------------------
+ * State carried between batches by the host (query/aql_processor.go:717-723 swaps [0]<->[1] of the
+ * dimension / measure / hash vectors; the two index vectors are re-initialised per batch,
+ * query/aql_batchexecutor.go:221-224): rows [0, prevResultSize) of prev{Dim,Hash,Values} are the
+ * merged (dim hash | register, hll value) entries of the earlier batches, sorted by (hash asc,
+ * value desc); rows [prevResultSize, +curBatchSize) of prevDim hold the dimension rows of the
+ * current batch, curValuesOut[0, curBatchSize) their hll values (rho << 16 | register), and
+ * curDimOut.IndexVector[i] the dimension row of entry i. */
+typedef struct { uint64_t h; uint32_t idx; uint32_t val; } HllEntry;
+
+static void hll_merge_sort(HllEntry *a, HllEntry *tmp, int n) { /* stable, key = h */
+  if (n < 2) return;
+  int m = n / 2;
+  hll_merge_sort(a, tmp, m);
+  hll_merge_sort(a + m, tmp, n - m);
+  int i = 0, j = m, k = 0;
+  while (i < m && j < n) tmp[k++] = (a[j].h < a[i].h) ? a[j++] : a[i++];
+  while (i < m) tmp[k++] = a[i++];
+  while (j < n) tmp[k++] = a[j++];
+  memcpy(a, tmp, sizeof(HllEntry) * (size_t)n);
+}
+
+/* HLLMergeComparator (functor.hpp:1316-1328): hash ascending, ties by value descending */
+static bool hll_less(uint64_t h1, uint32_t v1, uint64_t h2, uint32_t v2) {
+  return h1 == h2 ? v1 > v2 : h1 < h2;
+}
+
+CGoCallResHandle deviceMalloc(void **devPtr, size_t size);
+CGoCallResHandle deviceMemset(void *devPtr, int value, size_t count);
+
 CGoCallResHandle HyperLogLog(DimensionVector prevDimOut, DimensionVector curDimOut,
                              uint32_t *prevValuesOut, uint32_t *curValuesOut, int prevResultSize,
                              int curBatchSize, bool isLastBatch, uint8_t **hllVectorPtr,
                              size_t *hllVectorSizePtr, uint16_t **hllDimRegIDCountPtr,
                              void *cudaStream, int device) {
-  (void)prevDimOut; (void)curDimOut; (void)prevValuesOut; (void)curValuesOut;
-  (void)prevResultSize; (void)curBatchSize; (void)isLastBatch; (void)hllVectorPtr;
-  (void)hllVectorSizePtr; (void)hllDimRegIDCountPtr; (void)cudaStream; (void)device;
-  return HANDLE_ERR("HyperLogLog is not restated by the oracle (SURVEY.md 8f: next tier)");
+  (void)cudaStream; (void)device;
+  DimLayout L;
+  dim_layout(curDimOut.NumDimsPerDimWidth, &L);
+  const int P = prevResultSize, n = curBatchSize;
+
+  /* 1. sortCurrentBatch (hll.cu:70-88): key = dim hash with its low 16 bits replaced by the
+   *    register id (HLLHashFunctor, functor.hpp:1299-1305); stable sort of (index, value) */
+  HllEntry *e = (HllEntry *)malloc(sizeof(HllEntry) * (size_t)(n > 0 ? n : 1) * 2);
+  if (!e) return HANDLE_ERR("out of memory");
+  for (int i = 0; i < n; i++) {
+    uint8_t row[64];
+    uint64_t out[2];
+    pack_dim_row(prevDimOut.DimValues, curDimOut.VectorCapacity, &L, curDimOut.IndexVector[i], row);
+    oracle_murmur3_128(row, L.rowBytes, 0, out);
+    e[i].h = (out[0] & 0xFFFFFFFFFFFF0000ull) | (curValuesOut[i] & 0x3FFF);
+    e[i].idx = curDimOut.IndexVector[i];
+    e[i].val = curValuesOut[i];
+  }
+  hll_merge_sort(e, e + n, n);
+  for (int i = 0; i < n; i++) {
+    curDimOut.HashValues[i] = e[i].h;
+    curDimOut.IndexVector[i] = e[i].idx;
+    curValuesOut[i] = e[i].val;
+  }
+
+  /* 2. reduceCurrentBatch (hll.cu:211-231): runs of equal keys -> (first index, max value),
+   *    appended behind the previous results */
+  int c = 0;
+  for (int i = 0; i < n;) {
+    int j = i;
+    uint32_t best = e[i].val;
+    while (j + 1 < n && e[j + 1].h == e[i].h) { j++; if (e[j].val > best) best = e[j].val; }
+    prevDimOut.HashValues[P + c] = e[i].h;
+    prevDimOut.IndexVector[P + c] = e[i].idx;
+    prevValuesOut[P + c] = best;
+    c++;
+    i = j + 1;
+  }
+  free(e);
+
+  /* 3. merge (hll.cu:191-209): stable merge of previous and current entries into cur* */
+  {
+    int i = 0, j = P, k = 0;
+    const int endB = P + c;
+    while (i < P && j < endB) {
+      int take = hll_less(prevDimOut.HashValues[j], prevValuesOut[j], prevDimOut.HashValues[i], prevValuesOut[i]) ? j++ : i++;
+      curDimOut.HashValues[k] = prevDimOut.HashValues[take];
+      curValuesOut[k] = prevValuesOut[take];
+      curDimOut.IndexVector[k] = prevDimOut.IndexVector[take];
+      k++;
+    }
+    for (; i < P; i++, k++) {
+      curDimOut.HashValues[k] = prevDimOut.HashValues[i];
+      curValuesOut[k] = prevValuesOut[i];
+      curDimOut.IndexVector[k] = prevDimOut.IndexVector[i];
+    }
+    for (; j < endB; j++, k++) {
+      curDimOut.HashValues[k] = prevDimOut.HashValues[j];
+      curValuesOut[k] = prevValuesOut[j];
+      curDimOut.IndexVector[k] = prevDimOut.IndexVector[j];
+    }
+  }
+  int resSize = P + c;
+
+  /* 4. makeHLLVector (hll.cu:233-254, 108-166), last batch only */
+  if (isLastBatch && resSize > 0) {
+    const uint64_t *H = curDimOut.HashValues;
+    /* dimension heads: the first 48 bits of the key differ (HLLDimNotEqualFunctor) */
+    int dims = 0;
+    for (int i = 0; i < resSize; i++)
+      if (i == 0 || (H[i] >> 16) != (H[i - 1] >> 16)) dims++;
+    uint16_t *regCount = NULL;
+    CGoCallResHandle h = deviceMalloc((void **)&regCount, (size_t)dims * sizeof(uint16_t));
+    if (h.pStrErr) return h;
+    uint64_t *offsets = (uint64_t *)calloc((size_t)dims + 1, sizeof(uint64_t));
+    if (!offsets) return HANDLE_ERR("out of memory");
+    /* registers per dimension = distinct keys of the run (HLLRegIDHeadFlagIterator) */
+    int d = -1;
+    uint32_t count = 0;
+    for (int i = 0; i < resSize; i++) {
+      if (i == 0 || (H[i] >> 16) != (H[i - 1] >> 16)) {
+        if (d >= 0) regCount[d] = (uint16_t)count;
+        d++;
+        count = 0;
+        curDimOut.IndexVector[d] = curDimOut.IndexVector[i]; /* remove_if on the dim heads */
+      }
+      if (i == 0 || H[i] != H[i - 1]) count++;
+    }
+    regCount[d] = (uint16_t)count;
+    for (int k = 0; k < dims; k++) /* HLLDimByteCountFunctor (functor.hpp:1331-1340) */
+      offsets[k + 1] = offsets[k] + (regCount[k] < HLL_DENSE_THRESHOLD ? (uint64_t)regCount[k] * 4 : HLL_DENSE_SIZE);
+    uint8_t *vec = NULL;
+    h = deviceMalloc((void **)&vec, offsets[dims]);
+    if (h.pStrErr) { free(offsets); return h; }
+    deviceMemset(vec, 0, offsets[dims]);
+    /* CopyHLLFunctor (functor.hpp:1351-1374) through HLLValueOutputIterator (iterator.hpp:1197-1257) */
+    d = -1;
+    uint32_t regInDim = 0;
+    for (int i = 0; i < resSize; i++) {
+      if (i == 0 || (H[i] >> 16) != (H[i - 1] >> 16)) { d++; regInDim = 0; }
+      if (i == 0 || H[i] != H[i - 1]) {
+        const uint32_t value = curValuesOut[i];
+        const uint16_t regID = (uint16_t)(value & 0x3FFF);
+        const uint8_t rho = (uint8_t)((uint8_t)((value >> 16) & 0xFF) + 1);
+        if (regCount[d] < HLL_DENSE_THRESHOLD) {
+          const uint32_t w = (uint32_t)rho << 16 | regID;
+          memcpy(vec + offsets[d] + (uint64_t)regInDim * 4, &w, 4);
+        } else {
+          vec[offsets[d] + regID] = rho;
+        }
+        regInDim++;
+      }
+    }
+    *hllVectorPtr = vec;
+    *hllVectorSizePtr = (size_t)offsets[dims];
+    *hllDimRegIDCountPtr = regCount;
+    free(offsets);
+    resSize = dims;
+  }
+
+  /* 5. copyDim (hll.cu:169-187): gather the dimension rows of the surviving entries; both
+   *    strides are the INPUT capacity, like Reduce */
+  for (int i = 0; i < resSize; i++)
+    copy_dim_row(prevDimOut.DimValues, prevDimOut.VectorCapacity, curDimOut.DimValues,
+                 prevDimOut.VectorCapacity, &L, curDimOut.IndexVector[i], (uint32_t)i);
+  return HANDLE_OK(resSize);
 }
 
 CGoCallResHandle GeoBatchIntersects(GeoShapeBatch geoShapeBatch, InputVector points,

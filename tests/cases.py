@@ -551,6 +551,144 @@ class GroupByCase:
         return np.uint64 if self.vb == 8 else np.uint32
 
 
+class HllCase:
+    """Several batches through HyperLogLog, replaying the Go host's protocol
+    (query/aql_batchexecutor.go:219-233, query/aql_processor.go:717-723): dimension rows of the
+    batch behind the previous results in dim[0], hll values in measure[1], index vectors
+    re-initialised per batch, dim / measure / hash vectors swapped after every call."""
+
+    def __init__(self, seed, batches=None, batch_rows=None, groups=None, registers=None, ndw=None):
+        rng = np.random.default_rng(seed)
+        self.seed = seed
+        self.ndw = ndw or [(0, 0, 1, 0, 0), (0, 0, 0, 0, 1), (0, 0, 1, 1, 1), (0, 1, 0, 0, 2), (1, 0, 1, 0, 0)][seed % 5]
+        self.widths = [w for w, c in zip(H.DIM_WIDTHS, self.ndw) for _ in range(c)]
+        nb = batches or int(rng.integers(1, 5))
+        self.sizes = [int(batch_rows if batch_rows is not None else rng.integers(0, 3000)) for _ in range(nb)]
+        ngroups = groups or int(rng.integers(1, 40))
+        nregs = registers or int(rng.choice([3, 50, 5000, 1 << 14]))
+        ndims = len(self.widths)
+        proto_vals = [rng.integers(0, 256, (ngroups, w), dtype=np.uint8) for w in self.widths]
+        proto_valid = (rng.random((ngroups, ndims)) > 0.1).astype(np.uint8)
+        for d in range(ndims):  # a null dimension carries zero bytes, as the transforms write it
+            proto_vals[d][proto_valid[:, d] == 0] = 0
+        self.batches = []
+        for n in self.sizes:
+            pick = rng.integers(0, ngroups, n)
+            if ngroups > 1 and n:  # group 0 is hot: it may cross the dense threshold
+                pick[rng.random(n) < 0.5] = 0
+            regs = rng.integers(0, nregs, n).astype(np.uint32)
+            rho = rng.integers(0, 51, n).astype(np.uint32)
+            vals = (rho << 16) | regs
+            self.batches.append(([proto_vals[d][pick] for d in range(ndims)], proto_valid[pick], vals))
+        self.capacity = sum(self.sizes) + int(rng.integers(1, 20))
+
+    def __repr__(self):
+        return f"HllCase(seed={self.seed}, ndw={self.ndw}, sizes={self.sizes})"
+
+    def run(self, be, keep_state=True):
+        cap = self.capacity
+        dims = [H.DimVector(be, cap, self.ndw), H.DimVector(be, cap, self.ndw)]
+        meas = [H.Buf(be, nbytes=4 * cap), H.Buf(be, nbytes=4 * cap)]
+        offs = dims[0].dim_offsets()
+        res, size = {}, 0
+        for b, (vals, valid, hll) in enumerate(self.batches):
+            n = len(hll)
+            last = b == len(self.batches) - 1
+            for d, (vo, no, w) in enumerate(offs):
+                if n:
+                    dims[0].values.write(vals[d].reshape(-1), offset=vo + size * w)
+                    dims[0].values.write(valid[:, d].copy(), offset=no + size)
+            if n:
+                meas[1].write(hll)
+            # the index vectors are never swapped: [0] numbers the previous results, [1] the batch
+            be.call("InitIndexVector", dims[0].index.ptr, 0, size, None, 0)
+            be.call("InitIndexVector", dims[1].index.ptr, size, n, None, 0)
+            prev, cur = dims[0], dims[1]
+            dv_prev, dv_cur = prev.struct(), cur.struct()
+            dv_prev.IndexVector, dv_cur.IndexVector = dims[0].index.ptr, dims[1].index.ptr
+            g, vec, reg = H.hyperloglog(be, _Fixed(dv_prev), _Fixed(dv_cur), meas[0], meas[1], size, n, last)
+            res[f"size{b}"] = g
+            if not (last and size + n > 0) and keep_state:
+                res[f"hash{b}"] = cur.hash.read(np.uint64, g)
+                res[f"values{b}"] = meas[1].read(np.uint32, g)
+                res[f"index{b}"] = dims[1].index.read(np.uint32, g)
+            res[f"dims{b}"] = cur.rows(g) if g < 4000 else cur.values.read(np.uint8)
+            if vec is not None:
+                res["hll"], res["reg_counts"] = vec, reg
+            size = g
+            # swapResultBufferForNextBatch: everything but the index vectors
+            idx0, idx1 = dims[0].index, dims[1].index
+            dims.reverse()
+            meas.reverse()
+            dims[0].index, dims[1].index = idx0, idx1
+        for x in dims + meas:
+            x.free()
+        return res
+
+
+def hll_estimate_check(be, per_batch, distinct, tolerance=0.04):
+    """GetHLLValue measure transform + HyperLogLog over two batches of a one-dimension query whose
+    groups have known distinct counts; decodes the sparse / dense registers like the host does
+    (query/common/hll.go:547-575) and checks the classic HyperLogLog estimate (p = 14)."""
+    rng = np.random.default_rng(5)
+    cap = 2 * per_batch + 64
+    dims = [H.DimVector(be, cap, (0, 0, 1, 0, 0)), H.DimVector(be, cap, (0, 0, 1, 0, 0))]
+    meas = [H.Buf(be, nbytes=4 * cap), H.Buf(be, nbytes=4 * cap)]
+    size = 0
+    seen = []
+    for b in range(2):
+        group = rng.integers(0, len(distinct), per_batch).astype(np.uint32)
+        user = (rng.integers(0, 1 << 62, per_batch) % np.array(distinct)[group]).astype(np.uint32)
+        seen.append(group.astype(np.uint64) << np.uint64(32) | user)
+        col = H.Column(be, abi.Uint32, user)
+        dims[0].values.write(group, offset=4 * size)
+        dims[0].values.write(np.ones(per_batch, np.uint8), offset=4 * cap + size)
+        be.call("InitIndexVector", dims[1].index.ptr, 0, per_batch, None, 0)
+        be.call("UnaryTransform", col.input(), H.measure_output(meas[1].ptr, abi.Uint32, abi.AGGR_HLL),
+                dims[1].index.ptr, per_batch, None, 0, abi.GetHLLValue, None, 0)
+        be.call("InitIndexVector", dims[0].index.ptr, 0, size, None, 0)
+        be.call("InitIndexVector", dims[1].index.ptr, size, per_batch, None, 0)
+        size, vec, reg = H.hyperloglog(be, dims[0], dims[1], meas[0], meas[1], size, per_batch, b == 1)
+        idx0, idx1 = dims[0].index, dims[1].index
+        dims.reverse()
+        meas.reverse()
+        dims[0].index, dims[1].index = idx0, idx1
+        col.free()
+    assert size == len(distinct)
+    truth = np.bincount((np.unique(np.concatenate(seen)) >> np.uint64(32)).astype(np.int64), minlength=len(distinct))
+    keys = dims[0].values.read(np.uint32, size)
+    assert sorted(keys.tolist()) == list(range(len(distinct)))
+    off = 0
+    for g, count in zip(keys.tolist(), reg.tolist()):
+        if count < 4096:
+            words = vec[off:off + 4 * count].view(np.uint32)
+            regs = np.zeros(1 << 14, np.uint8)
+            regs[words & 0xFFFF] = (words >> 16).astype(np.uint8)
+            off += 4 * count
+        else:
+            regs = vec[off:off + (1 << 14)]
+            off += 1 << 14
+        m = float(1 << 14)
+        est = 0.7213 / (1 + 1.079 / m) * m * m / np.sum(2.0 ** -regs.astype(np.float64))
+        zeros = int(np.count_nonzero(regs == 0))
+        if est <= 2.5 * m and zeros:
+            est = m * np.log(m / zeros)
+        assert abs(est - truth[g]) / truth[g] < tolerance, (g, est, truth[g])
+    assert off == len(vec)
+    for x in dims + meas:
+        x.free()
+
+
+class _Fixed:
+    """A DimensionVector struct prepared by the caller, with the DimVector.struct() interface."""
+
+    def __init__(self, dv):
+        self.dv = dv
+
+    def struct(self):
+        return self.dv
+
+
 def assert_same(a, b, what=""):
     assert a.keys() == b.keys(), what
     for k in a:

@@ -316,3 +316,30 @@ def record_id_array(pairs):
     for i, (b, x) in enumerate(pairs):
         arr[i] = (b, x)
     return arr
+
+
+def read_device_bytes(be, ptr, nbytes):
+    out = np.empty(int(nbytes), np.uint8)
+    if nbytes:
+        be.d2h(out.ctypes.data_as(C.c_void_p), ptr, int(nbytes))
+        be.wait()
+    return out
+
+
+def hyperloglog(be, prev, cur, prev_values, cur_values, prev_size, batch_size, last):
+    """One HyperLogLog call (query/hll.cu:21-60).  Returns (result size, hll vector bytes,
+    registers per dimension) — the last two are None unless the call produced them; the buffers the
+    callee allocated are released with DeviceFree, as the Go host does
+    (query/aql_postprocessor.go:217-219)."""
+    vec, size, counts = C.c_void_p(0), C.c_size_t(0), C.c_void_p(0)
+    n = be.call("HyperLogLog", prev.struct(), cur.struct(), prev_values.ptr, cur_values.ptr, prev_size, batch_size,
+                bool(last), C.addressof(vec), C.addressof(size), C.addressof(counts), None, 0)
+    be.wait()
+    hll, reg = None, None
+    if vec.value:
+        hll = read_device_bytes(be, vec.value, size.value)
+        be.device_free(vec.value)
+    if counts.value:
+        reg = read_device_bytes(be, counts.value, 2 * n).view(np.uint16)
+        be.device_free(counts.value)
+    return n, hll, reg

@@ -101,6 +101,68 @@ def test_native_driver_inner_expressions(be):
     assert calls_cc == calls_py
 
 
+# ---- HyperLogLog queries (countdistincthll): query/aql_batchexecutor.go:221-233 -------------------------
+def _hll_plan():
+    return QueryPlan(filters=[Binary(abi.LessThan, Col("d1"), Const(90))],
+                     dimensions=[DimensionSpec(Binary(abi.Floor, Col("ts"), Const(86400)), abi.Uint32),
+                                 DimensionSpec(Col("d3"), abi.Uint32)],
+                     measure=Unary(abi.GetHLLValue, Col("user")), agg=abi.AGGR_HLL, measure_type=abi.Uint32)
+
+
+def _hll_batches(rng, sizes, null_fraction=0.02):
+    out = []
+    for n in sizes:
+        cols, valid = smoke.synth_batch(rng, n, null_fraction=null_fraction)
+        cols["user"] = (abi.Uint32, rng.integers(0, 30000, n).astype(np.uint32))
+        valid["user"] = (rng.random(n) >= null_fraction) if null_fraction else None
+        out.append((cols, valid))
+    return out
+
+
+def _numpy_hll(batches):
+    """Registers per group, computed independently: murmur3_x64_128 of the 4 value bytes, register =
+    low 14 bits, rho = trailing zeros of the rest (query/functor.hpp:431-466); a null user counts as
+    value 0 / rho 0 into register 0 (query/utils.hpp:169-184: the HLL identity is 0)."""
+    import ctypes
+    lib = ctypes.CDLL(H.ORACLE_SO)
+    lib.oracle_murmur3_128.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64)]
+    h = (ctypes.c_uint64 * 2)()
+    out = {}
+    for cols, valid in batches:
+        ts, d1, d3, user = (cols[k][1] for k in ("ts", "d1", "d3", "user"))
+        n = len(ts)
+        ok = {k: (np.ones(n, bool) if valid[k] is None else valid[k]) for k in cols}
+        for i in np.nonzero((d1 < 90) & ok["d1"])[0]:
+            key = ((np.uint32(ts[i] - ts[i] % 86400 if ok["ts"][i] else 0).tobytes(), int(ok["ts"][i])),
+                   (np.uint32(d3[i]).tobytes(), int(ok["d3"][i])))
+            reg, rho = 0, 0
+            if ok["user"][i]:
+                lib.oracle_murmur3_128(np.uint32(user[i]).tobytes(), 4, 0, h)
+                reg = h[0] & 0x3FFF
+                rest = h[0] >> 14
+                while rho + 14 < 32 and not (rest >> rho) & 1:  # the reference tests a 32-bit mask
+                    rho += 1
+            g = out.setdefault(key, {})
+            g[reg] = max(g.get(reg, 0), rho + 1)
+    return {k: sorted(v.items()) for k, v in out.items()}
+
+
+def test_hll_query_matches_independent_registers(be):
+    rng = np.random.default_rng(31)
+    data = _hll_batches(rng, [3000, 0, 2500, 1200])
+    got, _ = smoke.run_hll_query(be, _hll_plan(), data)
+    assert got == _numpy_hll(data)
+
+
+def test_hll_query_native_driver_matches_python_executor(be):
+    rng = np.random.default_rng(32)
+    data = _hll_batches(rng, [4000, 4000, 100])
+    want, calls_py = smoke.run_hll_query(be, _hll_plan(), data)
+    got, calls_cc = smoke.run_hll_query(be, _hll_plan(), data, native=True)
+    assert got == want
+    assert calls_cc == calls_py
+
+
 def _join_fixture(be, rng, n, keep):
     """Fact table with a foreign key into a 2-batch dimension table reached through a cuckoo index
     (memstore/cuckoo_index.go layout), as prepareForeignTable uploads it (aql_processor.go:398-457)."""

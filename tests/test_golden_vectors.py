@@ -412,3 +412,47 @@ def test_expand_fill_partial(be):
            3, 0, 0, 0] + [0] * 16 + [1, 0, 2, 0, 2, 0, 3, 0, 3, 0, 3, 0] + [0] * 8 + \
           [1, 2, 2, 3, 3, 3, 0, 0, 0, 0] + ([1] * 6 + [0] * 4) * 3
     assert n == 6 and got == exp
+
+
+# ---- HyperLogLogTest (:1229-1420) -------------------------------------------------------------
+def test_hyperloglog_sparse_mode(be):
+    """HyperLogLogTest.CheckSparseMode (:1229-1302)."""
+    prev = H.DimVector(be, 8, (0, 0, 0, 0, 1), init=[1, 1, 2, 2, 3, 3, 4, 4] + [1] * 8)
+    cur = H.DimVector(be, 8, (0, 0, 0, 0, 1))
+    cur.index.write(np.arange(8, dtype=np.uint32))
+    pv = H.Buf(be, nbytes=32)
+    cv = H.Buf(be, np.array([0x010001, 0x020002, 0x010002, 0x020002, 0x010003, 0x020003, 0x010004, 0x020004],
+                            np.uint32))
+    n, hll, reg = H.hyperloglog(be, prev, cur, pv, cv, 0, 8, True)
+    assert n == 4
+    assert hll.tolist() == [2, 0, 3, 0, 4, 0, 3, 0, 3, 0, 3, 0, 1, 0, 2, 0, 2, 0, 3, 0]
+    assert reg.tolist() == [1, 1, 1, 2]
+    assert cur.values.read(np.uint8, 16).tolist() == [2, 4, 3, 1, 0, 0, 0, 0, 1, 1, 1, 1, 0, 0, 0, 0]
+
+
+def test_hyperloglog_dense_mode(be):
+    """HyperLogLogTest.CheckDenseMode (:1305-1420)."""
+    dims = np.zeros(10000, np.uint8)
+    dims[0:4] = [1, 1, 2, 2]
+    dims[5000:] = 1
+    prev = H.DimVector(be, 5000, (0, 0, 0, 0, 1), init=dims)
+    cur = H.DimVector(be, 5000, (0, 0, 0, 0, 1))
+    cur.index.write(np.arange(5000, dtype=np.uint32))
+    vals = np.zeros(5000, np.uint32)
+    vals[0:4] = [0x010001, 0x020002, 0x010002, 0x020002]
+    vals[4:] = 0x010000 | np.arange(4996, dtype=np.uint32)
+    pv = H.Buf(be, nbytes=20000)
+    cv = H.Buf(be, vals)
+    n, hll, reg = H.hyperloglog(be, prev, cur, pv, cv, 0, 5000, True)
+    assert n == 3
+    assert len(hll) == 16396
+    exp = np.zeros(16396, np.uint8)
+    exp[0:4] = [2, 0, 3, 0]
+    exp[4:5000] = 2
+    exp[16388:] = [1, 0, 2, 0, 2, 0, 3, 0]
+    assert np.array_equal(hll, exp)
+    assert reg.tolist() == [1, 4996, 2]
+    exp_dims = np.zeros(10000, np.uint8)
+    exp_dims[0:3] = [2, 0, 1]
+    exp_dims[5000:5003] = 1
+    assert np.array_equal(cur.values.read(np.uint8, 10000), exp_dims)

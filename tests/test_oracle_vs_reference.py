@@ -43,6 +43,19 @@ def test_hash_reduce(seed):
                       f"GroupByCase({1000 + seed}) hash reduce")
 
 
+@pytest.mark.parametrize("seed", range(40))
+def test_hyperloglog(seed):
+    c = cases.HllCase(seed)
+    cases.assert_same(c.run(H.oracle_backend()), c.run(H.ref_backend()), repr(c))
+
+
+def test_hyperloglog_dense_groups():
+    c = cases.HllCase(500, batches=3, batch_rows=30000, groups=40, registers=1 << 14)
+    r = c.run(H.oracle_backend())
+    assert (r["reg_counts"] >= 4096).any() and (r["reg_counts"] < 4096).any()
+    cases.assert_same(r, c.run(H.ref_backend()), repr(c))
+
+
 def test_murmur_known_answers():
     """Row hashes recorded from the reference build: row = {value, validity=1}."""
     import ctypes as C

@@ -1264,6 +1264,72 @@ static int run_filter(const InputVector *ins, int arity, uint32_t *indexVector, 
   return static_cast<int>(result[0]);
 }
 
+// tile counts of an existing predicate vector, in filter_pred_kernel's tile geometry
+__global__ __launch_bounds__(kBlock) void pred_count_kernel(const uint8_t *pred, uint32_t *tileCounts, int pad, int n,
+                                                            int numTiles) {
+  const int lane = threadIdx.x & 63;
+  for (int tile = blockIdx.x; tile < numTiles; tile += gridDim.x) {
+    const int64_t tq = static_cast<int64_t>(tile) * (kBlock * kPQ);
+    uint32_t count = 0;
+#pragma unroll
+    for (int q = 0; q < kPQ; q++) {
+      const int64_t i0 = (tq + threadIdx.x + static_cast<int64_t>(q) * kBlock) * 4 - pad;
+      if (i0 >= 0 && i0 + 3 < n) {
+        const uint32_t pb = *reinterpret_cast<const uint32_t *>(pred + i0);
+        count += ((pb & 0xFFu) ? 1u : 0u) + ((pb & 0xFF00u) ? 1u : 0u) + ((pb & 0xFF0000u) ? 1u : 0u) +
+                 ((pb & 0xFF000000u) ? 1u : 0u);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (i0 + j >= 0 && i0 + j < n && pred[i0 + j]) count++;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) count += __shfl_xor(count, off);
+    if (lane == 0 && count) atomicAdd(tileCounts + tile, count);
+  }
+}
+
+// Stable in-place compaction of the index vector and of every RecordID vector by an existing
+// predicate vector (keep = byte != 0): the tail of the two-phase filter, for callers that compute
+// their predicate elsewhere (geo intersection).
+int compact_by_predicate(const uint8_t *pred, uint32_t *indexVector, RecordID **recordIDVectors, int numForeignTables,
+                         int n, hipStream_t stream) {
+  if (n <= 0) return 0;
+  const int pad = static_cast<int>(reinterpret_cast<uintptr_t>(pred) & 3);
+  const int64_t numQuads = (static_cast<int64_t>(n) + pad + 3) / 4;
+  const int tiles = static_cast<int>((numQuads + kBlock * kPQ - 1) / (kBlock * kPQ));
+  const int passes = 1 + numForeignTables;
+  const size_t head = 64;
+  const size_t words = static_cast<size_t>(tiles) * (2 + passes) + 1;
+  StreamBuffer wsBuf(head + 4 * words, stream);
+  uint32_t *w = wsBuf.as<uint32_t>();
+  uint32_t *total = w, *error = w + 1;
+  unsigned int *tickets = w + 2;
+  uint32_t *tileCounts = w + 16, *tileOffsets = tileCounts + tiles, *loaded = tileOffsets + tiles + 1;
+  hip_check(hipMemsetAsync(w, 0, head + 4 * words, stream), "hipMemsetAsync");
+  ARES_LAUNCH("pred_count_kernel", pred_count_kernel, capped_grid(tiles, 256 * 16), kBlock, stream, pred, tileCounts, pad, n, tiles);
+  ARES_LAUNCH("filter_scan_kernel", filter_scan_kernel, 1, 1024, stream, tileCounts, tileOffsets, tiles, total);
+  const int cgrid = capped_grid((tiles + kTilesPerTicket - 1) / kTilesPerTicket, 256 * 8);
+  for (int pass = 0; pass < passes; pass++) {
+    CompactWorkspace cw;
+    cw.ticket = tickets + pass;
+    cw.error = error;
+    cw.tileOffsets = tileOffsets;
+    cw.loaded = loaded + static_cast<size_t>(tiles) * pass;
+    if (pass == 0)
+      ARES_LAUNCH("filter_compact_kernel", (filter_compact_kernel<uint32_t, false>), cgrid, kBlock, stream, pred, indexVector, 0u,
+                  pad, cw, n, tiles);
+    else
+      ARES_LAUNCH("filter_compact_kernel<rid>", (filter_compact_kernel<uint64_t, false>), cgrid, kBlock, stream, pred,
+                  reinterpret_cast<uint64_t *>(recordIDVectors[pass - 1]), 0u, pad, cw, n, tiles);
+  }
+  uint32_t result[2] = {0, 0};  // {survivors, error}
+  read_back_u32(total, result, 2, stream);
+  if (result[1]) throw AlgorithmError("ERROR: filter: compaction wait timed out");
+  return static_cast<int>(result[0]);
+}
+
 }  // namespace ares
 
 using namespace ares;

@@ -1417,23 +1417,118 @@ CGoCallResHandle HyperLogLog(DimensionVector prevDimOut, DimensionVector curDimO
   return HANDLE_OK(resSize);
 }
 
+/* ---- geo intersection (query/geo_intersects.cu, query/iterator.hpp:1260-1452) -------------------
+ * GeoShapeBatch.LatLongs = [latitudes f32 x N][longitudes f32 x N][shape index u8 x N]; a polygon
+ * is a run of points with the same shape index, (FLT_MAX, FLT_MAX) separates its rings.  Entry i
+ * of the index vector owns TotalWords predicate words; bit s is toggled once per polygon edge the
+ * horizontal ray from the point crosses (even-odd rule). */
+
+/* the point of entry i and its validity */
+static bool geo_point_at(const InputVector *points, const uint32_t *indexVector, int i, GeoPointT *out) {
+  memset(out, 0, sizeof(*out));
+  if (points->Type == VectorPartyInput) { /* VectorPartyIterator<GeoPointT>, iterator.hpp:291-352 */
+    const VectorPartySlice *vp = &points->Vector.VP;
+    const uint32_t row = indexVector[i];
+    *out = ((const GeoPointT *)(vp->BasePtr + vp->ValuesOffset))[row];
+    if (vp->ValuesOffset == 0) return true;
+    return get_bit(vp->BasePtr, row + vp->StartingIndex);
+  }
+  /* RecordIDJoinIterator<GeoPointT>, iterator.hpp:911-930 */
+  const ForeignColumnVector *f = &points->Vector.ForeignVP;
+  const RecordID rid = f->RecordIDs[i];
+  if (rid.batchID && (rid.batchID - f->BaseBatchID < f->NumBatches - 1 ||
+                      rid.index < (uint32_t)f->NumRecordsInLastBatch)) {
+    const VectorPartySlice *vp = &f->Batches[rid.batchID - f->BaseBatchID];
+    if (vp->BasePtr == NULL) {
+      *out = f->DefaultValue.Value.GeoPointVal;
+      return f->DefaultValue.HasDefault;
+    }
+    *out = ((const GeoPointT *)(vp->BasePtr + vp->ValuesOffset))[rid.index];
+    if (vp->ValuesOffset == 0) return true;
+    return get_bit(vp->BasePtr, rid.index + vp->StartingIndex);
+  }
+  return false;
+}
+
+/* GeoPredicateIterator (iterator.hpp:1263-1315): first set bit as an int8 — shapes 128..255 wrap to
+ * negative values, which every consumer reads as "no shape" */
+static int8_t geo_first_shape(const uint32_t *words, int totalWords) {
+  for (int w = 0; w < totalWords; w++)
+    for (int b = 0; b < 32; b++)
+      if ((words[w] >> b) & 1) return (int8_t)(w * 32 + b);
+  return -1;
+}
+
 CGoCallResHandle GeoBatchIntersects(GeoShapeBatch geoShapeBatch, InputVector points,
                                     uint32_t *indexVector, int indexVectorLength,
                                     uint32_t startCount, RecordID **recordIDVectors,
                                     int numForeignTables, uint32_t *outputPredicate, bool inOrOut,
                                     void *cudaStream, int device) {
-  (void)geoShapeBatch; (void)points; (void)indexVector; (void)indexVectorLength; (void)startCount;
-  (void)recordIDVectors; (void)numForeignTables; (void)outputPredicate; (void)inOrOut;
-  (void)cudaStream; (void)device;
-  return HANDLE_ERR("GeoBatchIntersects is out of the hot-path scope (SURVEY.md 8)");
+  (void)startCount; (void)cudaStream; (void)device;
+  if (points.Type == VectorPartyInput) {
+    if (points.Vector.VP.DataType != GeoPoint)
+      return HANDLE_ERR("only geo point column are allowed in geo_intersects");
+    if (points.Vector.VP.BasePtr == NULL) return HANDLE_OK(0);
+  } else if (points.Type == ForeignColumnInput) {
+    if (points.Vector.ForeignVP.DataType != GeoPoint)
+      return HANDLE_ERR("only geo point column are allowed in geo_intersects");
+  } else {
+    return HANDLE_ERR("Unsupported data type for geo intersection contexts");
+  }
+  const int N = geoShapeBatch.TotalNumPoints, W = geoShapeBatch.TotalWords;
+  const float *lats = (const float *)geoShapeBatch.LatLongs;
+  const float *longs = lats + N;
+  const uint8_t *shape = geoShapeBatch.LatLongs + (size_t)N * 8;
+  /* calculateBatchIntersection (geo_intersects.cu:246-276): every (entry, polygon point) pair */
+  for (int i = 0; i < indexVectorLength; i++) {
+    uint32_t *pred = outputPredicate + (size_t)i * W;
+    GeoPointT pt;
+    const bool ok = geo_point_at(&points, indexVector, i, &pt);
+    for (int p = 0; p < N; p++) { /* GeoBatchIntersectIterator::dereference, iterator.hpp:1356-1421 */
+      if (p >= N - 1) continue;             /* last point: no edge starts here */
+      if (shape[p] != shape[p + 1]) continue; /* last point of a shape */
+      if (!ok) { /* a null point: the first edge writes the verdict, nobody toggles */
+        if (p == 0)
+          for (int w = 0; w < W; w++) pred[w] = !inOrOut;
+        continue;
+      }
+      const float lat1 = lats[p], lat2 = lats[p + 1];
+      if (lat1 < FLT_MAX && lat2 < FLT_MAX) {
+        const float long1 = longs[p], long2 = longs[p + 1];
+        if (((long1 > pt.Long) != (long2 > pt.Long)) &&
+            (pt.Lat < (lat2 - lat1) * (pt.Long - long1) / (long2 - long1) + lat1))
+          pred[shape[p] / 32] ^= (1u << (shape[p] % 32));
+      }
+    }
+  }
+  if (numForeignTables < 0 || numForeignTables > 8) return HANDLE_ERR("only support up to 8 foreign tables");
+  /* GeoRemoveFilter (geo_intersects.cu:214-239): drop entry i when inOrOut == "in no shape" */
+  int k = 0;
+  for (int i = 0; i < indexVectorLength; i++) {
+    const bool none = geo_first_shape(outputPredicate + (size_t)i * W, W) < 0;
+    if (inOrOut == none) continue;
+    indexVector[k] = indexVector[i];
+    for (int t = 0; t < numForeignTables; t++) recordIDVectors[t][k] = recordIDVectors[t][i];
+    k++;
+  }
+  return HANDLE_OK(k);
 }
 
+/* write_geo_shape_dim (geo_intersects.cu:318-337): the first intersected shape of every entry that
+ * is inside some shape, in entry order, as a uint8 dimension with validity 1 */
 CGoCallResHandle WriteGeoShapeDim(int shapeTotalWords, DimensionOutputVector dimOut,
                                   int indexVectorLengthBeforeGeo, uint32_t *outputPredicate,
                                   void *cudaStream, int device) {
-  (void)shapeTotalWords; (void)dimOut; (void)indexVectorLengthBeforeGeo; (void)outputPredicate;
   (void)cudaStream; (void)device;
-  return HANDLE_ERR("WriteGeoShapeDim is out of the hot-path scope (SURVEY.md 8)");
+  int k = 0;
+  for (int i = 0; i < indexVectorLengthBeforeGeo; i++) {
+    const int8_t s = geo_first_shape(outputPredicate + (size_t)i * (uint8_t)shapeTotalWords, (uint8_t)shapeTotalWords);
+    if (s < 0) continue;
+    dimOut.DimValues[k] = (uint8_t)s;
+    dimOut.DimNulls[k] = 1;
+    k++;
+  }
+  return HANDLE_OK(0);
 }
 
 CGoCallResHandle BootstrapDevice(void) { return HANDLE_OK(0); }

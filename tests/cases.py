@@ -626,6 +626,113 @@ class HllCase:
         return res
 
 
+class GeoCase:
+    """Random polygons (one or two rings each) x random points through GeoBatchIntersects and
+    WriteGeoShapeDim: non-identity index vectors, null points, RecordID vectors that must be
+    compacted alongside, up to 200 shapes (shape numbers >= 128 wrap negative in the reference's
+    int8 predicate iterator), points read from the main table or through a join."""
+
+    def __init__(self, seed, rows=None, shapes=None, foreign_points=None):
+        rng = np.random.default_rng(seed)
+        self.seed = seed
+        self.num_shapes = shapes or int(rng.choice([1, 3, 33, 70, 200]))
+        lats, longs, sidx = [], [], []
+        flt_max = np.finfo(np.float32).max
+        for sh in range(self.num_shapes):
+            cx, cy = rng.uniform(-50, 50, 2)
+            for ring in range(int(rng.integers(1, 3))):
+                k = int(rng.integers(3, 9))
+                ang = np.sort(rng.uniform(0, 2 * np.pi, k))
+                rad = rng.uniform(2, 30) / (1 + 2 * ring)
+                ys = (cy + rad * np.sin(ang)).astype(np.float32)
+                xs = (cx + rad * np.cos(ang)).astype(np.float32)
+                if ring:
+                    lats.append(flt_max), longs.append(flt_max), sidx.append(sh)
+                lats += list(ys) + [ys[0]]
+                longs += list(xs) + [xs[0]]
+                sidx += [sh] * (k + 1)
+        self.lats, self.longs, self.sidx = np.float32(lats), np.float32(longs), np.uint8(sidx)
+        self.length = int(rows if rows is not None else rng.integers(1, 3000))
+        self.points = rng.uniform(-60, 60, (self.length, 2)).astype(np.float32)
+        # a few points exactly on polygon vertices
+        for i in rng.integers(0, self.length, min(5, self.length)):
+            j = int(rng.integers(0, len(lats)))
+            if lats[j] < flt_max:
+                self.points[i] = (lats[j], longs[j])
+        self.valid = None if seed % 4 == 0 else (rng.random(self.length) > 0.1)
+        self.starting_index = int(rng.integers(0, 8)) if self.valid is not None else 0
+        style = ["identity", "subset", "perm"][seed % 3]
+        self.foreign_points = bool(seed % 5 == 3) if foreign_points is None else foreign_points
+        if self.foreign_points:
+            style = "identity"
+        self.index = make_index(rng, self.length, style)
+        self.n = len(self.index)
+        self.in_or_out = bool(seed % 2 == 0)
+        self.num_foreign = int(rng.integers(0, 3))
+        self.rids = [H.record_id_array([(int(b), int(x)) for b, x in zip(rng.integers(-5, 5, self.n), rng.integers(0, 1000, self.n))])
+                     for _ in range(self.num_foreign)]
+        self.words = (self.num_shapes + 31) // 32
+        self.prefill = rng.integers(0, 1 << 32, self.n * self.words, dtype=np.uint64).astype(np.uint32) \
+            if seed % 7 == 0 else None
+        self.batch_of = rng.integers(0, 3, self.length)  # joined table: 3 batches
+
+    def __repr__(self):
+        return f"GeoCase(seed={self.seed}, shapes={self.num_shapes}, rows={self.length}, n={self.n})"
+
+    def run(self, be):
+        shapes = H.GeoShapes(be, self.lats, self.longs, self.sidx, self.num_shapes)
+        keep = [shapes]
+        idx = H.Buf(be, self.index)
+        rid_bufs = [H.Buf(be, r) for r in self.rids]
+        vecs = (C.c_void_p * max(self.num_foreign, 1))(*[b.ptr for b in rid_bufs]) if self.num_foreign else None
+        pred = H.Buf(be, self.prefill) if self.prefill is not None else H.Buf(be, nbytes=4 * self.n * self.words)
+        if self.foreign_points:
+            # three batches hold the points; entry i joins record (batch_of[i], i); batch 0 of the
+            # join is a constant (mode 0) batch without a default: its points are null
+            slices = (abi.VectorPartySlice * 3)()
+            for b in range(3):
+                if b == 0:
+                    slices[b].BasePtr, slices[b].DataType = None, abi.GeoPoint
+                    continue
+                col = H.geo_column(be, self.points, valid=self.valid, starting_index=self.starting_index)
+                keep.append(col)
+                slices[b] = col.vp
+            point_rids = H.Buf(be, H.record_id_array([(7 + int(self.batch_of[r]), int(r)) for r in self.index]))
+            keep.append(point_rids)
+            iv = abi.InputVector()
+            f = iv.Vector.ForeignVP
+            f.RecordIDs, f.Batches = point_rids.ptr, C.addressof(slices)
+            f.BaseBatchID, f.NumBatches, f.NumRecordsInLastBatch = 7, 3, self.length
+            f.TimezoneLookup, f.TimezoneLookupSize, f.DataType = None, 0, abi.GeoPoint
+            iv.Type = abi.ForeignColumnInput
+        else:
+            col = H.geo_column(be, self.points, valid=self.valid, starting_index=self.starting_index)
+            keep.append(col)
+            iv = col.input()
+        kept = be.call("GeoBatchIntersects", shapes.struct(), iv, idx.ptr, self.n, 0,
+                       C.addressof(vecs) if self.num_foreign else None, self.num_foreign, pred.ptr, self.in_or_out,
+                       None, 0)
+        dim = H.Buf(be, nbytes=2 * self.n + 16)
+        dv = abi.DimensionOutputVector()
+        dv.DimValues, dv.DimNulls, dv.DataType = dim.ptr, dim.ptr + self.n + 8, abi.Uint8
+        be.call("WriteGeoShapeDim", self.words, dv, self.n, pred.ptr, None, 0)
+        be.wait()
+        words = pred.read(np.uint32, self.n * self.words).reshape(self.n, self.words)
+        first = np.full(self.n, -1, np.int64)
+        for w in range(self.words - 1, -1, -1):
+            col_w = words[:, w]
+            low = np.where(col_w != 0, np.log2((col_w & -col_w.astype(np.int64)).astype(np.float64) + (col_w == 0)), -1)
+            first = np.where(col_w != 0, w * 32 + low.astype(np.int64), first)
+        inside = int(np.count_nonzero((first >= 0) & (first < 128)))
+        res = {"kept": kept, "pred": words.copy(), "index": idx.read(np.uint32, kept), "inside": inside,
+               "dim_values": dim.read(np.uint8, inside), "dim_nulls": dim.read(np.uint8, inside, self.n + 8)}
+        for t, b in enumerate(rid_bufs):
+            res[f"rids{t}"] = b.read(np.uint64, kept)
+        for b in keep + [idx, pred, dim] + rid_bufs:
+            b.free()
+        return res
+
+
 def hll_estimate_check(be, per_batch, distinct, tolerance=0.04):
     """GetHLLValue measure transform + HyperLogLog over two batches of a one-dimension query whose
     groups have known distinct counts; decodes the sparse / dense registers like the host does

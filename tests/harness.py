@@ -343,3 +343,30 @@ def hyperloglog(be, prev, cur, prev_values, cur_values, prev_size, batch_size, l
         reg = read_device_bytes(be, counts.value, 2 * n).view(np.uint16)
         be.device_free(counts.value)
     return n, hll, reg
+
+
+class GeoShapes:
+    """GeoShapeBatch on a backend: [latitudes f32][longitudes f32][shape index u8] of all polygon
+    points (query/time_series_aggregate.h:316-330, query/unittest_utils.hpp:270-293)."""
+
+    def __init__(self, be, lats, longs, shape_index, num_shapes):
+        lats = np.asarray(lats, np.float32)
+        longs = np.asarray(longs, np.float32)
+        shape_index = np.asarray(shape_index, np.uint8)
+        self.num_points = len(lats)
+        self.total_words = (num_shapes + 31) // 32
+        blob = np.concatenate([lats.view(np.uint8), longs.view(np.uint8), shape_index])
+        self.buf = Buf(be, blob)
+
+    def struct(self):
+        g = abi.GeoShapeBatch()
+        g.LatLongs, g.TotalNumPoints, g.TotalWords = self.buf.ptr, self.num_points, self.total_words
+        return g
+
+    def free(self):
+        self.buf.free()
+
+
+def geo_column(be, points, valid=None, starting_index=0):
+    return Column(be, abi.GeoPoint, raw_values=np.asarray(points, np.float32).tobytes(), valid=valid,
+                  starting_index=starting_index)

@@ -456,3 +456,70 @@ def test_hyperloglog_dense_mode(be):
     exp_dims[0:3] = [2, 0, 1]
     exp_dims[5000:5003] = 1
     assert np.array_equal(cur.values.read(np.uint8, 10000), exp_dims)
+
+
+# ---- GeoBatchIntersectTest / GeoBatchIntersectionJoinTest (:1502-1745) -------------------------
+FLT_MAX = np.finfo(np.float32).max
+# 1. square (1,1),(1,-1),(-1,-1),(-1,1)  2. triangle (3,3),(2,2),(4,2)
+# 3. square (0,6),(3,6),(3,3),(0,3) with the hole (1,5),(2,5),(2,4),(1,4)
+GEO_LATS = [1, 1, -1, -1, 1, 3, 2, 4, 3, 0, 3, 3, 0, 0, FLT_MAX, 1, 2, 2, 1, 1]
+GEO_LONGS = [1, -1, -1, 1, 1, 3, 2, 2, 3, 6, 6, 3, 3, 6, FLT_MAX, 5, 5, 4, 4, 5]
+GEO_SHAPE = [0] * 5 + [1] * 4 + [2] * 11
+GEO_POINTS = [[0, 0], [3, 2.5], [1.5, 3.5], [1.5, 4.5], [0, 0]]  # in 1, in 2, in 3, in the hole, null
+
+
+@pytest.mark.parametrize("in_or_out,kept,pred", [(True, 3, [1, 2, 4, 0, 0]), (False, 1, [1, 2, 4, 0, 1])])
+def test_geo_batch_intersects(be, in_or_out, kept, pred):
+    """CheckInShape (:1502-1552) and CheckNotInShape (:1636-1685)."""
+    shapes = H.GeoShapes(be, GEO_LATS, GEO_LONGS, GEO_SHAPE, 3)
+    col = H.geo_column(be, GEO_POINTS, valid=[1, 1, 1, 1, 0])
+    idx = H.Buf(be, np.arange(5, dtype=np.uint32))
+    out = H.Buf(be, nbytes=20)
+    n = be.call("GeoBatchIntersects", shapes.struct(), col.input(), idx.ptr, 5, 0, None, 0, out.ptr, in_or_out, None, 0)
+    assert n == kept
+    assert out.read(np.uint32, 5).tolist() == pred
+
+
+def test_geo_batch_intersects_record_id_join(be):
+    """CheckRecordIDJoinIterator (:1554-1634): the points come from a joined table, one per batch."""
+    shapes = H.GeoShapes(be, GEO_LATS, GEO_LONGS, GEO_SHAPE, 3)
+    base_batch = -2147483648
+    rids = H.Buf(be, H.record_id_array([(base_batch + i, i) for i in range(5)]))
+    cols, slices = [], (abi.VectorPartySlice * 5)()
+    for i in range(5):
+        pts = np.zeros((5, 2), np.float32)
+        pts[i] = GEO_POINTS[i]
+        c = H.geo_column(be, pts, valid=[1, 1, 1, 1, 0])
+        cols.append(c)
+        slices[i] = c.vp
+    iv = abi.InputVector()
+    f = iv.Vector.ForeignVP
+    f.RecordIDs, f.Batches = rids.ptr, C.addressof(slices)
+    f.BaseBatchID, f.NumBatches, f.NumRecordsInLastBatch = base_batch, 5, 5
+    f.TimezoneLookup, f.TimezoneLookupSize, f.DataType = None, 0, abi.GeoPoint
+    iv.Type = abi.ForeignColumnInput
+    idx = H.Buf(be, np.arange(5, dtype=np.uint32))
+    out = H.Buf(be, nbytes=20)
+    n = be.call("GeoBatchIntersects", shapes.struct(), iv, idx.ptr, 5, 0, None, 0, out.ptr, True, None, 0)
+    assert n == 3
+    assert out.read(np.uint32, 5).tolist() == [1, 2, 4, 0, 0]
+
+
+def test_geo_shape_dimension_writing(be):
+    """GeoBatchIntersectionJoinTest.DimensionWriting (:1687-1745)."""
+    lats = [1, 1, -1, -1, 1, 2, 2, -2, -2, 2, 1.6, 1.6, 1.4, 1.4, 1.6]
+    longs = [1, -1, -1, 1, 1, 2, -2, -2, 2, 2, 3.6, 3.4, 3.6, 3.4, 3.6]
+    shapes = H.GeoShapes(be, np.float32(lats), np.float32(longs), [0] * 5 + [1] * 5 + [2] * 5, 3)
+    col = H.geo_column(be, [[1.5, 1.5], [0, 0], [1.5, 4.5], [1.5, 3.5], [0, 0]], valid=[1, 1, 1, 1, 0])
+    idx = H.Buf(be, np.arange(5, dtype=np.uint32))
+    out = H.Buf(be, nbytes=20)
+    dim = H.Buf(be, nbytes=16)
+    n = be.call("GeoBatchIntersects", shapes.struct(), col.input(), idx.ptr, 5, 0, None, 0, out.ptr, True, None, 0)
+    assert n == 3
+    dv = abi.DimensionOutputVector()
+    dv.DimValues, dv.DimNulls, dv.DataType = dim.ptr, dim.ptr + 5, abi.Uint8
+    be.call("WriteGeoShapeDim", 1, dv, 5, out.ptr, None, 0)
+    be.wait()
+    assert out.read(np.uint32, 5).tolist() == [2, 3, 0, 4, 0]
+    assert dim.read(np.uint8, 5).tolist() == [1, 0, 2, 0, 0]
+    assert dim.read(np.uint8, 5, 5).tolist() == [1, 1, 1, 0, 0]

@@ -230,6 +230,21 @@ def test_hyperloglog_estimate_property():
     cases.hll_estimate_check(hip(), 1 << 21, [2000, 150000, 1200000])
 
 
+@pytest.mark.parametrize("seed", range(40))
+def test_geo_intersects(seed):
+    """Predicate words, compacted index / RecordID vectors and the shape dimension are bit-identical
+    (same float operations in the same order as the reference: no contraction, IEEE division)."""
+    c = cases.GeoCase(seed)
+    cases.assert_same(c.run(hip()), c.run(H.oracle_backend()), repr(c))
+
+
+@pytest.mark.parametrize("seed,rows,shapes,foreign", [(900, 150000, 200, False), (901, 100000, 33, True),
+                                                      (902, 300000, 1, False), (903, 70000, 70, False)])
+def test_geo_intersects_multi_tile(seed, rows, shapes, foreign):
+    c = cases.GeoCase(seed, rows=rows, shapes=shapes, foreign_points=foreign)
+    cases.assert_same(c.run(hip()), c.run(H.oracle_backend()), repr(c))
+
+
 def _dim_out(values_ptr, nulls_ptr):
     return H.dimension_output(values_ptr, nulls_ptr, abi.Uint32)
 

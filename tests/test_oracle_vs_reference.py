@@ -56,6 +56,13 @@ def test_hyperloglog_dense_groups():
     cases.assert_same(r, c.run(H.ref_backend()), repr(c))
 
 
+@pytest.mark.parametrize("seed", range(60))
+def test_geo_intersects(seed):
+    c = cases.GeoCase(seed)
+    r = c.run(H.oracle_backend())
+    cases.assert_same(r, c.run(H.ref_backend()), repr(c))
+
+
 def test_murmur_known_answers():
     """Row hashes recorded from the reference build: row = {value, validity=1}."""
     import ctypes as C

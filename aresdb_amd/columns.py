@@ -22,6 +22,8 @@ class DeviceColumn:
         values = np.asarray(values)
         if data_type == abi.Bool:
             vbytes = np.packbits(values.astype(bool), bitorder="little")
+        elif data_type == abi.GeoPoint:  # (n, 2) float32 {lat, long}
+            vbytes = np.ascontiguousarray(values.astype(np.float32)).reshape(-1).view(np.uint8)
         else:
             vbytes = np.ascontiguousarray(values.astype(_NP_OF[data_type])).view(np.uint8)
         cbytes = np.zeros(0, np.uint8) if counts is None else np.asarray(counts, np.uint32).view(np.uint8)

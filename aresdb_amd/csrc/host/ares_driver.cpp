@@ -58,6 +58,8 @@ struct AbiLibrary {
   decltype(&::DeviceFree) DeviceFree;
   decltype(&::WaitForCudaStream) WaitForCudaStream;
   decltype(&::HyperLogLog) HyperLogLog;
+  decltype(&::GeoBatchIntersects) GeoBatchIntersects;
+  decltype(&::WriteGeoShapeDim) WriteGeoShapeDim;
   decltype(&::AsyncCopyDeviceToDevice) AsyncCopyDeviceToDevice;
   decltype(&::AsyncCopyDeviceToHost) AsyncCopyDeviceToHost;
 
@@ -82,6 +84,8 @@ struct AbiLibrary {
     bind(algoHandle, "Reduce", Reduce);
     bind(algoHandle, "HashReduce", HashReduce);
     bind(algoHandle, "HyperLogLog", HyperLogLog);
+    bind(algoHandle, "GeoBatchIntersects", GeoBatchIntersects);
+    bind(algoHandle, "WriteGeoShapeDim", WriteGeoShapeDim);
     FusedFilterHashReduce = reinterpret_cast<decltype(FusedFilterHashReduce)>(dlsym(algoHandle, "AresFusedFilterHashReduce"));
     bind(memHandle, "DeviceAllocate", DeviceAllocate);
     bind(memHandle, "DeviceFree", DeviceFree);
@@ -149,6 +153,8 @@ struct Plan {
     std::vector<int> dataTypes;
   };
   std::vector<Foreign> foreign;
+  bool hasGeo = false;
+  AresGeoIntersection geo;
 
   explicit Plan(const AresQueryPlan &p)
       : nodes(p.nodes, p.nodes + p.numNodes), filters(p.filters, p.filters + p.numFilters),
@@ -162,6 +168,11 @@ struct Plan {
       f.slices.assign(f.t.slices, f.t.slices + static_cast<size_t>(f.t.numColumns) * f.t.numBatches);
       f.dataTypes.assign(f.t.dataTypes, f.t.dataTypes + f.t.numColumns);
       foreign.push_back(std::move(f));
+    }
+    memset(&geo, 0, sizeof(geo));
+    if (p.geo) {
+      hasGeo = true;
+      geo = *p.geo;
     }
   }
   int measureBytes() const { return data_type_bytes(measureType); }
@@ -191,6 +202,8 @@ struct AresQuery {
   uint16_t *hllDimRegIDCount = nullptr;
   size_t hllVectorSize = 0;
   bool isLastBatch = false;
+  uint32_t *geoPredicateVec = nullptr;
+  int sizeBeforeGeoFilter = 0;
   uint64_t *hashVec[2] = {nullptr, nullptr};
   uint32_t *dimIndexVec[2] = {nullptr, nullptr};
   int size = 0;
@@ -318,6 +331,7 @@ struct AresQuery {
     release(predVec); predVec = nullptr;
     for (RecordID *p : foreignRids) release(p);
     foreignRids.clear();
+    release(geoPredicateVec); geoPredicateVec = nullptr;
     for (uint8_t *p : stack) release(p);
     stack.clear();
     foreignSliceArrays.clear();
@@ -530,6 +544,26 @@ struct AresQuery {
     Action a;
     a.kind = Action::FILTER;
     for (int f : plan.foreignFilters) processExpression(f, a);
+    // geo intersection (query/aql_batchexecutor.go:146-165, query/time_series_aggregate.go:636-660)
+    const int words = (plan.geo.numShapes + 31) / 32;
+    if (plan.hasGeo) geoPredicateVec = alloc<uint32_t>(static_cast<size_t>(std::max(size, 1)) * 4 * words);
+    sizeBeforeGeoFilter = size;
+    if (plan.hasGeo && size > 0 && plan.geo.shapeLatLongs) {
+      GeoShapeBatch shapes;
+      shapes.LatLongs = const_cast<uint8_t *>(plan.geo.shapeLatLongs);
+      shapes.TotalNumPoints = plan.geo.totalNumPoints;
+      shapes.TotalWords = static_cast<uint8_t>(words);
+      AresPlanNode pointNode;
+      memset(&pointNode, 0, sizeof(pointNode));
+      pointNode.kind = ARES_NODE_COLUMN;
+      pointNode.table = plan.geo.pointTable;
+      pointNode.column = plan.geo.pointColumn;
+      const int nf = static_cast<int>(foreignRids.size());
+      calls++;
+      size = static_cast<int>(check(lib->GeoBatchIntersects(shapes, columnInput(pointNode).get(), indexVec, size, startRow,
+                                                            nf ? foreignRids.data() : nullptr, nf, geoPredicateVec,
+                                                            plan.geo.inOrOut != 0, stream, device)));
+    }
   }
   void project() {
     prepareForDimAndMeasureEval();
@@ -540,6 +574,17 @@ struct AresQuery {
       a.dimType = plan.dimTypes[i];
       a.prevResultSize = prev;
       dimension_start_offsets(ndw, dimVectorIndex[i], resultCapacity, &a.valueOff, &a.nullOff);
+      if (plan.hasGeo && plan.geo.dimIndex == static_cast<int>(i)) {  // the shape number (time_series_aggregate.go:611-634)
+        if (size > 0 && plan.geo.shapeLatLongs) {
+          DimensionOutputVector dv;
+          dv.DimValues = dimVec[0] + a.valueOff + prev;
+          dv.DimNulls = dimVec[0] + a.nullOff + prev;
+          dv.DataType = Uint8;
+          calls++;
+          check(lib->WriteGeoShapeDim((plan.geo.numShapes + 31) / 32, dv, sizeBeforeGeoFilter, geoPredicateVec, stream, device));
+        }
+        continue;
+      }
       processExpression(plan.dimNodes[i], a);
     }
     Action m;
@@ -609,6 +654,7 @@ struct AresQuery {
   // returns false when this batch must take the ordinary sequence
   bool runBatchFused(const VectorPartySlice *cols, int ncols, int n) {
     if (!plan.useFusedExtension || !plan.useHashReduction || fusedDeclined || !lib->FusedFilterHashReduce) return false;
+    if (plan.hasGeo || plan.isHLL()) return false;
     if (!plan.foreign.empty() || !plan.foreignFilters.empty() || baseCounts) return false;
     if (plan.dimNodes.empty() || plan.dimNodes.size() > 4 || plan.filters.size() > 4) return false;
     columns = cols;

@@ -44,6 +44,17 @@ typedef struct {
   int32_t numRecordsInLastBatch;
 } AresForeignTable;
 
+/* geoIntersection (query/aql_context.go:327-353) once the shapes are on the device */
+typedef struct {
+  const uint8_t *shapeLatLongs; /* device: [lats f32][longs f32][shape index u8] of all polygon points */
+  int numShapes;
+  int totalNumPoints;
+  int pointTable;  /* 0 = main table, k > 0 = foreign table k-1 */
+  int pointColumn; /* column index inside that table */
+  int inOrOut;
+  int dimIndex;    /* query dimension that is the shape number (uint8), < 0: filter only */
+} AresGeoIntersection;
+
 typedef struct {
   const AresPlanNode *nodes;
   int numNodes;
@@ -59,6 +70,7 @@ typedef struct {
    * whose plan has the fusable shape is executed by ONE fused call instead of the per-node sequence;
    * any other plan, and any batch the library declines, runs the ordinary sequence */
   int useFusedExtension;
+  const AresGeoIntersection *geo; /* NULL: no geo intersection in this query */
 } AresQueryPlan;
 
 typedef struct AresQuery AresQuery; /* oopkBatchContext + executor of one query on one device */

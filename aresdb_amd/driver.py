@@ -28,6 +28,11 @@ class ForeignTableC(C.Structure):
                 ("baseBatchID", C.c_int32), ("numRecordsInLastBatch", C.c_int32)]
 
 
+class GeoIntersectionC(C.Structure):
+    _fields_ = [("shapeLatLongs", C.c_void_p), ("numShapes", C.c_int), ("totalNumPoints", C.c_int),
+                ("pointTable", C.c_int), ("pointColumn", C.c_int), ("inOrOut", C.c_int), ("dimIndex", C.c_int)]
+
+
 class QueryPlanC(C.Structure):
     _fields_ = [("nodes", C.POINTER(PlanNode)), ("numNodes", C.c_int),
                 ("filters", C.POINTER(C.c_int)), ("numFilters", C.c_int),
@@ -36,7 +41,7 @@ class QueryPlanC(C.Structure):
                 ("measureNode", C.c_int), ("aggFunc", C.c_int), ("measureType", C.c_int),
                 ("useHashReduction", C.c_int),
                 ("foreignTables", C.POINTER(ForeignTableC)), ("numForeignTables", C.c_int),
-                ("useFusedExtension", C.c_int)]
+                ("useFusedExtension", C.c_int), ("geo", C.POINTER(GeoIntersectionC))]
 
 
 _lib = None
@@ -152,6 +157,15 @@ class NativeQuery:
         pc.useHashReduction = int(plan.use_hash_reduction)
         pc.foreignTables, pc.numForeignTables = arr(ForeignTableC, fts), len(fts)
         pc.useFusedExtension = int(getattr(plan, "use_fused_extension", False))
+        geo = getattr(plan, "geo", None)
+        if geo is not None:
+            g = GeoIntersectionC()
+            g.shapeLatLongs, g.numShapes, g.totalNumPoints = geo.shape_lat_longs, geo.num_shapes, geo.total_num_points
+            g.pointTable, g.inOrOut, g.dimIndex = geo.point_table, int(geo.in_or_out), geo.dim_index
+            g.pointColumn = self.column_names.index(geo.point_column) if geo.point_table == 0 else \
+                self.foreign_column_names[geo.point_table - 1].index(geo.point_column)
+            self._keep.append(g)
+            pc.geo = C.pointer(g)
         err = C.create_string_buffer(512)
         self._q = _driver().AresQueryCreate(_open(be), C.byref(pc), device, stream, err, 512)
         if not self._q:

@@ -72,6 +72,18 @@ class ForeignTable:
 
 
 @dataclass
+class GeoIntersection:
+    """geoIntersection (query/aql_context.go:327-353) after the processor uploaded the shapes."""
+    shape_lat_longs: int        # device pointer: [lats f32][longs f32][shape index u8]
+    num_shapes: int
+    total_num_points: int
+    point_column: str
+    point_table: int = 0        # 0 = main table, k > 0 = foreign table k-1
+    in_or_out: bool = True
+    dim_index: int = -1         # query dimension that is the shape number, < 0: filter only
+
+
+@dataclass
 class QueryPlan:
     filters: List[object]
     dimensions: List[DimensionSpec]
@@ -82,6 +94,7 @@ class QueryPlan:
     use_fused_extension: bool = False  # C++ driver only: one fused call per batch where the plan allows
     foreign_tables: List[ForeignTable] = field(default_factory=list)
     foreign_filters: List[object] = field(default_factory=list)
+    geo: Optional[GeoIntersection] = None
 
     @property
     def measure_bytes(self):
@@ -158,6 +171,7 @@ class BatchContext:
         self.columns: Dict[str, abi.VectorPartySlice] = {}
         self.stack: List[int] = []
         self.foreign_rids: List[int] = []
+        self.geo_predicate_vec = 0
         self._keepalive = []
         self.calls = 0  # ABI calls issued (for tests / stats)
         # HyperLogLog queries: buffers the library allocates on the last batch
@@ -254,6 +268,8 @@ class BatchContext:
         for p in self.foreign_rids:
             self._free(p)
         self.foreign_rids = []
+        self._free(self.geo_predicate_vec)
+        self.geo_predicate_vec = 0
         for p in self.stack:
             self._free(p)
         self.stack = []
@@ -391,6 +407,33 @@ class BatchContext:
                       self.stream, self.device)
         return action
 
+    # -- geo (time_series_aggregate.go:596-660) ------------------------------------------------------------
+    def geo_intersect(self):
+        geo = self.plan.geo
+        if self.size <= 0 or not geo.shape_lat_longs:
+            return
+        shapes = abi.GeoShapeBatch()
+        shapes.LatLongs, shapes.TotalNumPoints = geo.shape_lat_longs, geo.total_num_points
+        shapes.TotalWords = (geo.num_shapes + 31) // 32
+        points = column_input(self.columns[geo.point_column]) if geo.point_table == 0 else \
+            self._foreign_input(Col(geo.point_column, geo.point_table))
+        nf = len(self.foreign_rids)
+        vecs = (C.c_void_p * max(nf, 1))(*self.foreign_rids) if nf else None
+        self.size = self.call("GeoBatchIntersects", shapes, points, self.index_vec, self.size, self.start_row,
+                              C.addressof(vecs) if nf else None, nf, self.geo_predicate_vec, geo.in_or_out,
+                              self.stream, self.device)
+
+    def write_geo_shape_dim(self, value_off, null_off, size_before_geo, prev_result_size):
+        geo = self.plan.geo
+        if self.size <= 0 or not geo.shape_lat_longs:
+            return
+        dv = abi.DimensionOutputVector()
+        dv.DimValues = self.dim_vec[0] + value_off + prev_result_size
+        dv.DimNulls = self.dim_vec[0] + null_off + prev_result_size
+        dv.DataType = abi.Uint8
+        self.call("WriteGeoShapeDim", (geo.num_shapes + 31) // 32, dv, size_before_geo, self.geo_predicate_vec,
+                  self.stream, self.device)
+
     def dimension_vector(self, which):
         dv = abi.DimensionVector()
         dv.DimValues = self.dim_vec[which]
@@ -408,6 +451,7 @@ class BatchExecutor:
     def __init__(self, ctx: BatchContext):
         self.ctx = ctx
         self.is_last_batch = False
+        self.size_before_geo = 0
 
     def run(self, columns: Dict[str, abi.VectorPartySlice], size: int, base_counts=None, start_row=0,
             is_last_batch=False):
@@ -441,6 +485,12 @@ class BatchExecutor:
                        c.base_counts, c.start_row, ft.index, c.stream, c.device)
         for f in c.plan.foreign_filters:
             c.process_expression(f, c.filter_action)
+        if c.plan.geo is not None:  # query/aql_batchexecutor.go:146-165
+            words = (c.plan.geo.num_shapes + 31) // 32
+            c.geo_predicate_vec = c._alloc(max(c.size, 1) * 4 * words)
+        self.size_before_geo = c.size
+        if c.plan.geo is not None:
+            c.geo_intersect()
 
     def project(self):
         c = self.ctx
@@ -448,6 +498,9 @@ class BatchExecutor:
         prev = c.result_size
         for i, dim in enumerate(c.plan.dimensions):
             vo, no = dimension_start_offsets(c.ndw, c.dim_index[i], c.result_capacity)
+            if c.plan.geo is not None and c.plan.geo.dim_index == i:
+                c.write_geo_shape_dim(vo, no, self.size_before_geo, prev)
+                continue
             c.process_expression(dim.expr, c.make_dimension_action(dim, vo, no, prev))
         c.process_expression(c.plan.measure, c.measure_action)
         c.be.wait(c.stream, c.device)

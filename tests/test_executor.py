@@ -163,6 +163,78 @@ def test_hll_query_native_driver_matches_python_executor(be):
     assert calls_cc == calls_py
 
 
+# ---- geo intersection queries (geography_intersects join): query/aql_batchexecutor.go:146-196 -------------
+def _geo_query(be, rng, in_or_out, with_dim):
+    from aresdb_amd.executor import GeoIntersection
+    # three disjoint axis-parallel-free polygons (closed rings), the second with a hole
+    rings = [[(10, 10), (20, 12), (18, 22), (9, 19)],
+             [(-30, -30), (-10, -28), (-8, -8), (-29, -11)], [(-22, -22), (-16, -21), (-17, -15), (-23, -16)],
+             [(30, -20), (45, -18), (38, -5)]]
+    shape_of_ring = [0, 1, 1, 2]
+    lats, longs, sidx = [], [], []
+    flt_max = float(np.finfo(np.float32).max)
+    for r, (ring, sh) in enumerate(zip(rings, shape_of_ring)):
+        if r and shape_of_ring[r - 1] == sh:
+            lats.append(flt_max), longs.append(flt_max), sidx.append(sh)
+        for la, lo in ring + [ring[0]]:
+            lats.append(la), longs.append(lo), sidx.append(sh)
+    shapes = H.GeoShapes(be, np.float32(lats), np.float32(longs), sidx, 3)
+    dims = [DimensionSpec(Col("d3"), abi.Uint32)]
+    if with_dim:
+        dims.append(DimensionSpec(Const(0), abi.Uint8))  # placeholder: written by WriteGeoShapeDim
+    plan = QueryPlan(filters=[Binary(abi.LessThan, Col("d1"), Const(90))], dimensions=dims, measure=Const(1),
+                     agg=abi.AGGR_SUM_UNSIGNED, measure_type=abi.Uint32, use_hash_reduction=False,
+                     geo=GeoIntersection(shapes.buf.ptr, 3, len(lats), "pt", 0, in_or_out, 1 if with_dim else -1))
+    batches = []
+    for n in (3000, 2000):
+        cols, valid = smoke.synth_batch(rng, n, null_fraction=0.02)
+        cols["pt"] = (abi.GeoPoint, (rng.integers(-200, 200, (n, 2)) / 4 + 0.125).astype(np.float32))
+        valid["pt"] = rng.random(n) >= 0.05
+        batches.append((cols, valid))
+
+    def inside(lat, lng):  # even-odd rule in float64; the test points sit off every edge
+        hit = []
+        for sh in range(3):
+            c = 0
+            for ring, s in zip(rings, shape_of_ring):
+                if s != sh:
+                    continue
+                for (la1, lo1), (la2, lo2) in zip(ring, ring[1:] + ring[:1]):
+                    if (lo1 > lng) != (lo2 > lng) and lat < (la2 - la1) * (lng - lo1) / (lo2 - lo1) + la1:
+                        c ^= 1
+            if c:
+                hit.append(sh)
+        return hit
+
+    want = {}
+    for cols, valid in batches:
+        d1, d3, pt = cols["d1"][1], cols["d3"][1], cols["pt"][1]
+        for i in range(len(d1)):
+            if not (valid["d1"][i] and d1[i] < 90):
+                continue
+            if not valid["pt"][i]:  # a null point never survives, whichever way the filter asks
+                continue            # (query/iterator.hpp:1372-1381)
+            hit = inside(float(pt[i, 0]), float(pt[i, 1]))
+            if in_or_out != bool(hit):
+                continue
+            key = [(np.uint32(d3[i]).tobytes(), int(valid["d3"][i]))]
+            if with_dim:
+                key.append((bytes([hit[0]]), 1))
+            want[tuple(key)] = want.get(tuple(key), 0) + 1
+    return plan, batches, want, shapes
+
+
+@pytest.mark.parametrize("in_or_out,with_dim", [(True, True), (True, False), (False, False)])
+def test_geo_query_matches_independent_point_in_polygon(be, in_or_out, with_dim):
+    plan, batches, want, shapes = _geo_query(be, np.random.default_rng(41), in_or_out, with_dim)
+    got, calls_py = smoke.run_query(be, plan, batches)
+    assert {k: int(v) for k, v in got.items()} == want
+    got_cc, calls_cc = smoke.run_query_native(be, plan, batches)
+    assert {k: int(v) for k, v in got_cc.items()} == want
+    assert calls_cc == calls_py
+    shapes.free()
+
+
 def _join_fixture(be, rng, n, keep):
     """Fact table with a foreign key into a 2-batch dimension table reached through a cuckoo index
     (memstore/cuckoo_index.go layout), as prepareForeignTable uploads it (aql_processor.go:398-457)."""

@@ -82,10 +82,71 @@ def c4(be, dev, rows, nkeys):
              "ms": dt * 1e3, "rows_per_s": rows / dt, "kernels": {n: round(ms / c, 4) for n, (c, ms) in k.items()}}]
 
 
+def hll(be, dev, rows, groups, users, batches=2):
+    """countdistincthll(user) group by g: `batches` batches of `rows` rows through the C++ driver."""
+    from aresdb_amd.executor import Unary
+    plan = QueryPlan(filters=[], dimensions=[DimensionSpec(Col("g"), abi.Uint32)], measure=Unary(abi.GetHLLValue, Col("user")),
+                     agg=abi.AGGR_HLL, measure_type=abi.Uint32)
+    gen = torch.Generator(device=dev); gen.manual_seed(3)
+    cols = []
+    for _ in range(batches):
+        gcol = torch.randint(0, groups, (rows,), dtype=torch.int32, device=dev, generator=gen)
+        ucol = torch.randint(0, users, (rows,), dtype=torch.int32, device=dev, generator=gen)
+        cols.append((workload._pack_column(gcol, None, abi.Uint32), workload._pack_column(ucol, None, abi.Uint32)))
+    def run():
+        q = NativeQuery(be, plan, ["g", "user"])
+        for b, (cg, cu) in enumerate(cols):
+            q.run({"g": cg.vp, "user": cu.vp}, rows, is_last_batch=b == batches - 1)
+        n = q.result_size
+        dims, valids, counts, vec = q.fetch_hll()
+        q.release(); return n, int(counts.astype(np.int64).sum()), len(vec)
+    dt, k, (n, regs, nbytes) = timed(be, run)
+    return [{"config": "HLL", "rows": rows * batches, "groups": groups, "users": users, "result_dims": n, "registers": regs,
+             "hll_bytes": nbytes, "ms": dt * 1e3, "rows_per_s": rows * batches / dt,
+             "kernels": {n_: round(ms / c, 4) for n_, (c, ms) in k.items()}}]
+
+
+def geo(be, dev, rows, num_shapes, pts_per_shape):
+    """geography_intersects filter + shape dimension + COUNT over `rows` points."""
+    import harness as H
+    from aresdb_amd.executor import Const, GeoIntersection
+    rng = np.random.default_rng(9)
+    lats, longs, sidx = [], [], []
+    for sh in range(num_shapes):
+        cx, cy = rng.uniform(-80, 80, 2)
+        ang = np.sort(rng.uniform(0, 2 * np.pi, pts_per_shape)); rad = rng.uniform(3, 12)
+        ys, xs = (cy + rad * np.sin(ang)).astype(np.float32), (cx + rad * np.cos(ang)).astype(np.float32)
+        lats += list(ys) + [ys[0]]; longs += list(xs) + [xs[0]]; sidx += [sh] * (pts_per_shape + 1)
+    shapes = H.GeoShapes(be, np.float32(lats), np.float32(longs), sidx, num_shapes)
+    plan = QueryPlan(filters=[], dimensions=[DimensionSpec(Const(0), abi.Uint8)], measure=Const(1), agg=abi.AGGR_SUM_UNSIGNED,
+                     measure_type=abi.Uint32, use_hash_reduction=False,
+                     geo=GeoIntersection(shapes.buf.ptr, num_shapes, len(lats), "pt", 0, True, 0))
+    gen = torch.Generator(device=dev); gen.manual_seed(4)
+    pts = (torch.rand((rows, 2), device=dev, generator=gen) * 200 - 100).to(torch.float32).contiguous()
+    vp = abi.VectorPartySlice()
+    vp.BasePtr, vp.NullsOffset, vp.ValuesOffset, vp.DataType, vp.Length, vp.StartingIndex = pts.data_ptr(), 0, 0, abi.GeoPoint, rows, 0
+    def run():
+        q = NativeQuery(be, plan, ["pt"]); q.run({"pt": vp}, rows)
+        n = q.result_size
+        m = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        be.call("AsyncCopyDeviceToDevice", m.data_ptr(), q.measure_vector, 4 * n, None, 0); be.wait()
+        tot = int(m[:n].to(torch.int64).sum()); q.release(); return n, tot
+    dt, k, (n, inside) = timed(be, run)
+    return [{"config": "GEO", "rows": rows, "shapes": num_shapes, "polygon_points": len(lats), "groups": n, "inside": inside,
+             "ms": dt * 1e3, "rows_per_s": rows / dt, "edge_tests_per_s": rows * (len(lats) - 1) / dt,
+             "kernels": {n_: round(ms / c, 4) for n_, (c, ms) in k.items()}}]
+
+
 def main():
     be = abi.load_hip_backend(); be.call("BootstrapDevice")
     dev = torch.device("cuda:0")
-    res = c2(be, dev, 100_000_000) + c4(be, dev, 1 << 26, 200_000)
+    which = sys.argv[1:] or ["c2", "c4", "hll", "geo"]
+    res = []
+    if "c2" in which: res += c2(be, dev, 100_000_000)
+    if "c4" in which: res += c4(be, dev, 1 << 26, 200_000)
+    if "hll" in which:
+        res += hll(be, dev, 1 << 25, 1000, 5_000_000) + hll(be, dev, 1 << 25, 4, 50_000_000)
+    if "geo" in which: res += geo(be, dev, 1 << 24, 100, 20) + geo(be, dev, 1 << 22, 250, 400)
     for r in res: print(json.dumps(r), flush=True)
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(res, open("gpurun_out/bench_configs.json", "w"), indent=1)

@@ -4,13 +4,11 @@
 // query/iterator.hpp:1260-1452 (GeoPredicateIterator, GeoBatchIntersectIterator).
 //
 // The reference launches one thread per (entry, polygon point) pair and toggles predicate bits with
-// atomicXor.  Here one lane owns one entry: polygon edges stream through LDS in chunks (every lane
-// reads the same LDS address: a broadcast, no bank conflicts), edges that cannot count — the
-// closing point of a shape, ring separators — are decided once per chunk and skipped with a
-// scalar branch, and the crossing parity accumulates in registers (up to 8 words = 256 shapes): no
-// atomics, one read-modify-write of the predicate words per entry.  The same pass writes a keep
-// byte per entry; the index vector and the RecordID vectors are then compacted by the filter's
-// chain-free compaction kernels (transform.hip).
+// atomicXor.  Here one lane owns one entry and a wavefront walks the polygon edges 64 at a time with
+// register broadcasts (see geo_intersect_kernel); the crossing parity accumulates in registers (up
+// to 8 words = 256 shapes): no atomics, no LDS, one read-modify-write of the predicate words per
+// entry.  The same pass writes a keep byte per entry; the index vector and the RecordID vectors are
+// then compacted by the filter's chain-free compaction kernels (transform.hip).
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
@@ -29,7 +27,6 @@ int compact_by_predicate(const uint8_t *pred, uint32_t *indexVector, RecordID **
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kEdgeChunk = 1024;  // polygon edges staged per LDS pass (20 KiB)
 
 // where the geo points of the entries come from
 struct GeoPointsD {
@@ -93,15 +90,23 @@ __device__ __forceinline__ int first_shape(const uint32_t (&words)[W], int total
   return -1;
 }
 
+// One wavefront = 64 entries x all polygon edges, 64 edges at a time:
+//   * lane l fetches polygon points e0+l and e0+l+1 (edge l of the chunk) — coalesced, cached;
+//   * hot loop, no memory and no branches: for every polygon point k of the chunk the longitude is
+//     broadcast with v_readlane and compared with the lane's own test longitude; the 65 results
+//     form a per-lane bit string G, and "edge k straddles the test longitude" is G ^ (G >> 1),
+//     masked with the wave-uniform set of real edges (same shape, no ring separator);
+//   * only the few straddling edges of each lane reach the exact test: the lane pulls that edge's
+//     coordinates out of the owning lane with ds_bpermute and evaluates the reference's
+//     expression (same operations, same order, IEEE division) — every lane works on its own edge.
 template <int W>
 __global__ __launch_bounds__(kBlock) void geo_intersect_kernel(GeoPointsD P, const float *lats, const float *longs,
                                                                const uint8_t *shape, int numPoints, uint32_t *pred,
                                                                uint8_t *keep, int n, int totalWords, int inOrOut) {
-  __shared__ float4 sEdge[kEdgeChunk];  // {lat1, long1, long2, lat2 - lat1}
-  __shared__ int sShape[kEdgeChunk];    // shape of the edge, -1: the pair of points is not an edge
   // a null point: "the first edge writes the verdict" (query/iterator.hpp:1372-1381) — if there is one
   const bool firstEdge = numPoints >= 2 && shape[0] == shape[1];
   const int numEdges = numPoints - 1;
+  const int lane = threadIdx.x & 63;
   for (int64_t blockStart = static_cast<int64_t>(blockIdx.x) * kBlock; blockStart < n;
        blockStart += static_cast<int64_t>(gridDim.x) * kBlock) {
     const int64_t i = blockStart + threadIdx.x;
@@ -109,35 +114,58 @@ __global__ __launch_bounds__(kBlock) void geo_intersect_kernel(GeoPointsD P, con
     pt.lat = pt.lng = 0.f;
     pt.ok = false;
     if (i < n) pt = load_point(P, i);
+    // a lane without a valid point compares false against everything
+    const float testLong = pt.ok ? pt.lng : __int_as_float(0x7fc00000);
     uint32_t acc[W];
 #pragma unroll
     for (int w = 0; w < W; w++) acc[w] = 0;
-    for (int e0 = 0; e0 < numEdges; e0 += kEdgeChunk) {
-      const int count = numEdges - e0 < kEdgeChunk ? numEdges - e0 : kEdgeChunk;
-      __syncthreads();
-      for (int e = threadIdx.x; e < count; e += kBlock) {
-        const int p = e0 + e;
-        const float lat1 = lats[p], lat2 = lats[p + 1];
-        const float long1 = longs[p], long2 = longs[p + 1];
-        const int s = shape[p];
-        sEdge[e] = make_float4(lat1, long1, long2, __fsub_rn(lat2, lat1));
-        sShape[e] = (s == shape[p + 1] && lat1 < FLT_MAX && lat2 < FLT_MAX) ? s : -1;
+    for (int e0 = 0; e0 < numEdges; e0 += 64) {
+      const int p = e0 + lane;
+      const bool have = p < numEdges;
+      float lat1 = 0.f, lat2 = 0.f, long1 = 0.f, long2 = 0.f;
+      int s1 = -1, s2 = -2;
+      if (p < numPoints) {  // the chunk's last edge ends on a point that starts no edge of its own
+        lat1 = lats[p];
+        long1 = longs[p];
+        s1 = shape[p];
       }
-      __syncthreads();
-      if (pt.ok) {
-        for (int e = 0; e < count; e++) {
-          const int s = __builtin_amdgcn_readfirstlane(sShape[e]);
-          if (s < 0) continue;
-          const float4 g = sEdge[e];
-          if ((g.y > pt.lng) != (g.z > pt.lng)) {
-            // (lat2 - lat1) * (testLong - long1) / (long2 - long1) + lat1, in the reference's order
-            const float t = __fadd_rn(
-                __fdiv_rn(__fmul_rn(g.w, __fsub_rn(pt.lng, g.y)), __fsub_rn(g.z, g.y)), g.x);
-            if (pt.lat < t) {
+      if (have) {
+        lat2 = lats[p + 1];
+        long2 = longs[p + 1];
+        s2 = shape[p + 1];
+      }
+      const uint64_t edges = __ballot(have && s1 == s2 && lat1 < FLT_MAX && lat2 < FLT_MAX);
+      if (edges == 0) continue;
+      // G: bit k = (longitude of polygon point e0+k > test longitude), k = 0..64
+      const int long1Bits = __float_as_int(long1);
+      uint32_t gLo = 0, gHi = 0;
 #pragma unroll
-              for (int w = 0; w < W; w++)
-                if ((s >> 5) == w) acc[w] ^= 1u << (s & 31);
-            }
+      for (int k = 0; k < 32; k++) {
+        const float a = __int_as_float(__builtin_amdgcn_readlane(long1Bits, k));
+        const float b = __int_as_float(__builtin_amdgcn_readlane(long1Bits, k + 32));
+        gLo |= a > testLong ? (1u << k) : 0u;
+        gHi |= b > testLong ? (1u << k) : 0u;
+      }
+      const float last = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(long2), 63));
+      const uint64_t g = (static_cast<uint64_t>(gHi) << 32) | gLo;
+      const uint64_t gNext = (g >> 1) | (last > testLong ? (1ull << 63) : 0ull);
+      uint64_t cross = (g ^ gNext) & edges;
+      const float dLat = __fsub_rn(lat2, lat1);
+      while (__ballot(cross != 0)) {
+        const bool active = cross != 0;
+        const int k = active ? __builtin_ctzll(cross) : 0;
+        cross &= cross - 1;
+        const float eLat1 = __shfl(lat1, k), eLong1 = __shfl(long1, k), eLong2 = __shfl(long2, k);
+        const float eDLat = __shfl(dLat, k);
+        const int s = __shfl(s1, k);
+        if (active) {
+          // (lat2 - lat1) * (testLong - long1) / (long2 - long1) + lat1, in the reference's order
+          const float t = __fadd_rn(
+              __fdiv_rn(__fmul_rn(eDLat, __fsub_rn(testLong, eLong1)), __fsub_rn(eLong2, eLong1)), eLat1);
+          if (pt.lat < t) {
+#pragma unroll
+            for (int w = 0; w < W; w++)
+              if ((s >> 5) == w) acc[w] ^= 1u << (s & 31);
           }
         }
       }

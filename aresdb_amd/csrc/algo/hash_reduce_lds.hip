@@ -40,7 +40,7 @@ constexpr int kSlotMask = kSlots - 1;
 constexpr int kRowsPerLane = 2;           // rows inserted per lane between occupancy checks
 constexpr int kTileRows = kThreads * kRowsPerLane;
 constexpr int kFlushAt = kSlots * 3 / 4 - kTileRows;  // flush when more entries than this are held
-constexpr int kMergeLimit = kSlots * 7 / 8;           // claim attempts per merge round
+constexpr int kMergeLimit = kSlots - kThreads - 128;   // groups per merge round (every lane may claim one more)
 constexpr int kMaxPartitions = 512;
 constexpr uint64_t kEmpty = ~0ull;
 
@@ -761,24 +761,28 @@ __device__ __forceinline__ void fused_eval_row(const FusedPlanD &plan, uint32_t 
 
 // ---- kernel 2: per-partition merge in LDS, emit groups ---------------------------------------------
 // One record into the round's table; claims a slot only while the round's attempt budget lasts.
-__device__ __forceinline__ void merge_record(uint64_t *sKeys, uint64_t *sVals, uint32_t *sAttempts, uint32_t *sOverflow,
+__device__ __forceinline__ void merge_record(uint64_t *sKeys, uint64_t *sVals, uint32_t *sClaimed, uint32_t *sOverflow,
                                              const uint4 r, const AggSpec &a) {
+  // a round that has run out of slots is discarded as a whole: stop filling the table (every lane
+  // claims at most one more slot after the flag is up, so the table can never fill completely and
+  // the probe loop below always terminates)
+  if (__hip_atomic_load(sOverflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return;
   const uint32_t h = r.y;
   const uint64_t mine = (static_cast<uint64_t>(h) << 32) | r.x;
   int slot = static_cast<int>(h) & kSlotMask;
   for (;;) {
     uint64_t cur = sKeys[slot];
     if (cur == kEmpty) {
-      if (__hip_atomic_fetch_add(sAttempts, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >=
-          static_cast<uint32_t>(kMergeLimit)) {
-        *sOverflow = 1u;
-        return;
-      }
       unsigned long long expected = kEmpty;
       if (__hip_atomic_compare_exchange_strong(reinterpret_cast<unsigned long long *>(sKeys + slot), &expected,
                                                static_cast<unsigned long long>(mine), __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_WORKGROUP))
+                                               __HIP_MEMORY_SCOPE_WORKGROUP)) {
+        // occupied slots are counted exactly (lost races are not new groups)
+        if (__hip_atomic_fetch_add(sClaimed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >=
+            static_cast<uint32_t>(kMergeLimit))
+          __hip_atomic_store(sOverflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         break;
+      }
       cur = expected;
     }
     if (static_cast<uint32_t>(cur >> 32) == h) {
@@ -803,19 +807,18 @@ __device__ __forceinline__ void merge_body(const uint8_t *__restrict__ dimIn, si
                                            const AggSpec &a, const Workspace &ws, const FusedPlanD *plan, uint32_t prevSize) {
   __shared__ uint64_t sKeys[kSlots];
   __shared__ uint64_t sVals[kSlots];
-  __shared__ uint32_t sAttempts, sOverflow, sCount, sBase, sClaims;
+  __shared__ uint32_t sAttempts, sOverflow, sCount, sBase, sClaims, sProgress;
   const int p = blockIdx.x;
   const uint32_t cursor = ws.cursors[p];
   const uint64_t n = cursor < ws.cap ? cursor : ws.cap;
   if (n == 0) return;
   const uint4 *__restrict__ rec = ws.records + static_cast<uint64_t>(p) * ws.cap;
-  // sub-range of the hash bits below the partition bits, left-aligned to 32 bits
+  // Rounds over sub-ranges of the hash bits below the partition bits (left-aligned to 32 bits).
+  // The first round is optimistic — the whole range: a partition usually holds far fewer groups than
+  // the table has slots.  A round that runs out of slots stops streaming at once, and how far it
+  // got tells how much narrower the next attempt must be, so a wrong guess costs a partial pass.
   const int pb = ws.partBits;
   uint64_t lo = 0, width = 1ull << 32;
-  if (n > 16ull * kMergeLimit) {
-    uint64_t parts = 1;
-    while (parts * 16ull * kMergeLimit < n && width > 1) { parts <<= 1; width >>= 1; }
-  }
   const uint64_t stride = static_cast<uint64_t>(kMergeBatch) * kThreads;
   while (lo < (1ull << 32)) {
     clear_table(sKeys, sVals, a.identity);
@@ -823,13 +826,15 @@ __device__ __forceinline__ void merge_body(const uint8_t *__restrict__ dimIn, si
     __syncthreads();
     const uint64_t hi = lo + width;
     // two register stages: the loads of the next kMergeBatch records per lane are in flight while
-    // the current ones go through the LDS table
+    // the current ones go through the LDS table.  The loads are unconditional (the index is clamped
+    // to the last record; `consume` ignores positions past the end): with branches around them the
+    // compiler cannot count outstanding loads and waits for the prefetch as well.
     uint4 ra[kMergeBatch], rb[kMergeBatch];
     auto load = [&](uint4 (&r)[kMergeBatch], uint64_t base) {
 #pragma unroll
       for (int k = 0; k < kMergeBatch; k++) {
         const uint64_t i = base + static_cast<uint64_t>(k) * kThreads + threadIdx.x;
-        r[k] = i < n ? rec[i] : make_uint4(0, 0, 0, 0);
+        r[k] = rec[i < n ? i : n - 1];
       }
     };
     auto consume = [&](const uint4 (&r)[kMergeBatch], uint64_t base) {
@@ -838,26 +843,36 @@ __device__ __forceinline__ void merge_body(const uint8_t *__restrict__ dimIn, si
         const uint64_t i = base + static_cast<uint64_t>(k) * kThreads + threadIdx.x;
         const uint32_t h = r[k].y;
         const uint64_t u = static_cast<uint64_t>(pb ? (h << pb) : h);
-        if (i >= n || u < lo || u >= hi) continue;
-        if (ws.debug & 8) {  // experiment: loads only
-          if (h == 0x12345678u && r[k].z == 0x9abcdefu) sOverflow = 1u;
-          continue;
+        if (i < n && u >= lo && u < hi) {
+          if (ws.debug & 8) {  // experiment: loads only
+            if (h == 0x12345678u && r[k].z == 0x9abcdefu) sOverflow = 1u;
+          } else {
+            merge_record(sKeys, sVals, &sAttempts, &sOverflow, r[k], a);
+          }
         }
-        merge_record(sKeys, sVals, &sAttempts, &sOverflow, r[k], a);
       }
     };
     load(ra, 0);
-    for (uint64_t base = 0; base < n; base += 2 * stride) {
-      if (base + stride < n) load(rb, base + stride);
+    uint64_t base = 0;
+    for (; base < n; base += 2 * stride) {
+      if (__hip_atomic_load(&sOverflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) && !(ws.debug & 8)) break;
+      load(rb, base + stride);
       consume(ra, base);
-      if (base + 2 * stride < n) load(ra, base + 2 * stride);
-      if (base + stride < n) consume(rb, base + stride);
+      load(ra, base + 2 * stride);
+      consume(rb, base + stride);
     }
+    if (threadIdx.x == 0) sProgress = static_cast<uint32_t>(base < n ? base : n);
     __syncthreads();
-    const bool overflowed = sOverflow != 0;
-    __syncthreads();  // everyone has read the flag before the next round resets it
-    if (overflowed && width > 1) {  // too many groups in this sub-range: nothing is emitted, retry with half of it
-      width >>= 1;                  // (a single hash value cannot overflow the table)
+    const bool overflowed = sOverflow != 0 && !(ws.debug & 8);
+    const uint64_t progress = sProgress;
+    __syncthreads();  // everyone has read the flags before the next round resets them
+    if (overflowed && width > 1) {  // too many groups in this sub-range: nothing is emitted
+      // ~kMergeLimit groups showed up in the first `progress` records: aim for half a table per round
+      uint64_t shrink = 2 * n / (progress > stride ? progress : stride);
+      do {  // (a single hash value cannot overflow the table)
+        width >>= 1;
+        shrink >>= 1;
+      } while (shrink > 1 && width > 1);
       continue;
     }
     // emit: count occupied slots, reserve output rows once, then copy

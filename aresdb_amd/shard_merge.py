@@ -34,6 +34,13 @@ def _d2d(ctx, dst, src, nbytes):
         ctx.be.call("AsyncCopyDeviceToDevice", dst, src, nbytes, ctx.stream, ctx.device)
 
 
+def _torch_ready(t):
+    """torch fills its tensors on its own stream; the ABI copies run on the query's (non-blocking)
+    stream — the fill must have finished before a copy may land in the tensor."""
+    if t.is_cuda:
+        torch.cuda.synchronize(t.device)
+
+
 def merge_shard_results(ctx, tensor_device, group: Optional[dist.ProcessGroup] = None) -> MergedResult:
     """Merges the result of `ctx` (dim_vec[0] / measure_vec[0] / result_size) across all ranks of
     `group`; every rank returns the full merged table.  `tensor_device` is where the staging
@@ -58,6 +65,7 @@ def merge_shard_results(ctx, tensor_device, group: Optional[dist.ProcessGroup] =
     for _ in range(nd):
         sect.append((off, 1)); off += gmax
     sect.append((off, mb))
+    _torch_ready(packed)
     g = ctx.result_size
     for d, w in enumerate(widths):
         vo, no = dimension_start_offsets(ctx.ndw, d, ctx.result_capacity)
@@ -76,6 +84,7 @@ def merge_shard_results(ctx, tensor_device, group: Optional[dist.ProcessGroup] =
     in_meas = torch.zeros(cap * mb, dtype=torch.uint8, device=tensor_device)
     out_dims = torch.zeros_like(in_dims)
     out_meas = torch.zeros_like(in_meas)
+    _torch_ready(out_meas)
     base = 0
     for r in range(world):
         src = gathered.data_ptr() + r * packed.numel()
@@ -105,6 +114,7 @@ def merge_shard_results(ctx, tensor_device, group: Optional[dist.ProcessGroup] =
         h1 = torch.zeros(cap, dtype=torch.int64, device=tensor_device)
         i0 = torch.zeros(cap, dtype=torch.int32, device=tensor_device)
         i1 = torch.zeros(cap, dtype=torch.int32, device=tensor_device)
+        _torch_ready(i1)
         ctx.call("InitIndexVector", i0.data_ptr(), 0, total, ctx.stream, ctx.device)
         ctx.call("Sort", dvec(in_dims, h0, i0), total, ctx.stream, ctx.device)
         n = ctx.call("Reduce", dvec(in_dims, h0, i0), in_meas.data_ptr(), dvec(out_dims, h1, i1), out_meas.data_ptr(),

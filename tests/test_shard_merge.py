@@ -88,3 +88,55 @@ def test_two_shard_merge_gloo(use_hash):
         p.join(timeout=60)
     assert all(r[1] == "ok" for r in results), results
     assert results[0][2] == results[1][2] > 0
+
+
+def _gpu_worker(port, use_hash, q):
+    """One rank over RCCL on the GPU box: all_gather + re-reduce through the HIP library on the
+    query's own (non-blocking) stream; the merged table must equal the shard's own result."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    try:
+        import harness as H
+        from aresdb_amd import workload
+        from aresdb_amd.driver import NativeQuery
+        from aresdb_amd.queries import c3_plan
+        from aresdb_amd.shard_merge import merge_shard_results, merged_to_dict
+        os.environ["NCCL_DEBUG"] = "WARN"
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda:0")
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+        be = H.hip_backend()
+        stream = be.call("CreateCudaStream", 0)
+        plan = c3_plan(use_hash_reduction=use_hash)
+        batches = workload.c3_shard(300000, 1 << 17, seed=3, device=dev)
+        names = [n for n, _ in workload.C3_COLUMNS]
+        ctx = NativeQuery(be, plan, names, device=0, stream=stream)
+        for b in batches:
+            ctx.run({k: rc.vp for k, rc in b.items()}, next(iter(b.values())).length)
+        dims, valids, meas = ctx.fetch()
+        n = ctx.result_size
+        m = meas.view(np.float64)
+        want = {tuple((bytes(d[r * len(d) // n:(r + 1) * len(d) // n]), int(v[r])) for d, v in zip(dims, valids)): m[r]
+                for r in range(n)}
+        merged = merge_shard_results(ctx, dev)
+        got = merged_to_dict(ctx, merged)
+        assert got.keys() == want.keys(), (len(got), len(want))
+        for k, v in want.items():
+            assert abs(got[k] - v) <= 1e-9 * max(1.0, abs(v)), (k, got[k], v)
+        ctx.release()
+        dist.destroy_process_group()
+        q.put(("ok", len(got)))
+    except Exception as e:  # noqa: BLE001
+        q.put((f"{type(e).__name__}: {e}", 0))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_hash", [True, False], ids=["hash_reduce", "sort_reduce"])
+def test_single_rank_merge_rccl(use_hash):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_gpu_worker, args=(_free_port(), use_hash, q))
+    p.start()
+    res = q.get(timeout=300)
+    p.join(timeout=60)
+    assert res[0] == "ok" and res[1] > 0, res

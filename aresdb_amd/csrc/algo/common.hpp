@@ -35,6 +35,11 @@ inline void check_launch(const char *what) { hip_check(hipGetLastError(), what);
 
 // launches the transforms held back for cross-call fusion on `device` (transform.hip)
 void flush_deferred(int device);
+// second-stage fusion (transform.hip, include/ares_extensions.h)
+bool fuse_pending_into_hash_reduce(int device, hipStream_t stream, const DimensionVector &in, const uint8_t *inValues,
+                                   const DimensionVector &out, uint8_t *outValues, int valueBytes, int length, int aggFunc,
+                                   int *groups);
+void invalidate_filter_journal(const uint32_t *indexVector);
 
 // NOFLUSH: only for the transform entry points, which decide themselves whether to queue or flush
 #define ARES_ABI_BEGIN_NOFLUSH(device)                 \

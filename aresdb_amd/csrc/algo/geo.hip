@@ -321,6 +321,7 @@ int geo_batch_intersects(const GeoShapeBatch &shapes, const InputVector &points,
     throw std::invalid_argument("Unsupported data type for geo intersection contexts");
   }
   if (numForeignTables < 0 || numForeignTables > 8) throw std::invalid_argument("only support up to 8 foreign tables");
+  invalidate_filter_journal(indexVector);  // the index vector is compacted by something a fused scan cannot replay
   if (n <= 0) return 0;
   const int N = shapes.TotalNumPoints, W = shapes.TotalWords;
   if (W > 8) throw std::invalid_argument("geo intersection supports up to 256 shapes");

@@ -133,8 +133,16 @@ static bool global_table_forced() {
 extern "C" CGoCallResHandle HashReduce(DimensionVector inputKeys, uint8_t *inputValues, DimensionVector outputKeys,
                                        uint8_t *outputValues, int valueBytes, int length,
                                        enum AggregateFunction aggFunc, void *cudaStream, int device) {
-  ARES_ABI_BEGIN(device)
+  ARES_ABI_BEGIN_NOFLUSH(device)
   hipStream_t stream = reinterpret_cast<hipStream_t>(cudaStream);
+  // the dimension / measure transforms of this batch may still be pending: evaluate them on the fly
+  int fusedGroups = 0;
+  if (length > 0 && fuse_pending_into_hash_reduce(device, stream, inputKeys, inputValues, outputKeys, outputValues,
+                                                  valueBytes, length, aggFunc, &fusedGroups)) {
+    resHandle.res = int_result(fusedGroups);
+    return resHandle;
+  }
+  flush_deferred(device);
   const AggSpec a = make_agg_spec(aggFunc, valueBytes);
   int groups = -1;
   if (length > 0 && hash_reduce_lds_supported(a) && !global_table_forced())

@@ -579,28 +579,6 @@ __global__ __launch_bounds__(kThreads) void hr_partition4_kernel(const uint8_t *
 // part; dimensions and the measure are evaluated with the very functions the transform kernels use
 // (fast_eval.hpp), so the (value, validity) pairs that are hashed are bit-identical to what the
 // UnaryTransform / BinaryTransform calls would have stored in the dimension vector.
-constexpr int kFusedCols = 6, kFusedFilters = 4, kFusedDims = 4;
-struct FusedColumn {
-  const uint32_t *vals;
-  const uint8_t *nulls;
-  uint32_t bitOff;
-};
-struct FusedExpr {
-  FastOperands f;  // akind / arity / functor / I / rk / constant / divLike (pointers unused)
-  int col;
-  int outKind;     // kind of the stored dimension value
-};
-struct FusedPlanD {
-  int numCols;
-  FusedColumn cols[kFusedCols];
-  int numFilters;
-  FusedExpr filters[kFusedFilters];
-  FusedExpr dims[kFusedDims];
-  FusedExpr measure;
-  int measureDtype, measureWidth;
-  uint64_t identity;  // measure-transform identity of the aggregate (query/utils.hpp:169-184)
-};
-
 struct FusedConst {
   DVal y;
   FastDivisor fd;
@@ -1044,6 +1022,65 @@ int hash_reduce_lds(const DimensionVector &inputKeys, const uint8_t *inputValues
 }
 
 
+// The fused pipeline for an already built plan (shared by the extension entry point and by the
+// in-ABI fusion of pending transforms into HashReduce, transform.hip).  Returns the number of groups
+// or -1 when a partition region overflowed.
+int fused_hash_reduce_run(const FusedPlanD &plan, int batchRows, const DimensionVector &prevKeys, const uint8_t *prevValues,
+                          int prevSize, const DimensionVector &outKeys, uint8_t *outValues, const AggSpec &a,
+                          hipStream_t stream) {
+  int nd = 0;
+  for (int k = 0; k < NUM_DIM_WIDTH; k++) nd += outKeys.NumDimsPerDimWidth[k];
+  const int mw = plan.measureWidth;
+  const int64_t length = static_cast<int64_t>(batchRows) + prevSize;
+  if (length == 0) return 0;
+  int partBits = 0;
+  while ((8192ll << partBits) < length && (1 << partBits) < kMaxPartitions) partBits++;
+  const int numParts = 1 << partBits;
+  Workspace ws;
+  ws.partBits = partBits;
+  ws.debug = 0;
+  ws.cap = ((2ull * (static_cast<uint64_t>(length) / numParts) + 2 * kSlots) | 63ull) + 18;
+  const size_t headBytes = sizeof(uint32_t) * (numParts + 2);
+  const size_t headPadded = (headBytes + 255) / 256 * 256;
+  StreamBuffer buf(headPadded + sizeof(uint4) * ws.cap * numParts, stream);
+  ws.cursors = buf.as<uint32_t>();
+  ws.outCount = ws.cursors + numParts;
+  ws.overflow = ws.outCount + 1;
+  ws.records = reinterpret_cast<uint4 *>(buf.as<uint8_t>() + headPadded);
+  hip_check(hipMemsetAsync(buf.get(), 0, headPadded, stream), "hipMemsetAsync");
+
+  auto grid_for = [](int64_t rows) {
+    const int64_t tiles = (rows + kQuadTile - 1) / kQuadTile;
+    return static_cast<int>(tiles < 256 ? (tiles < 1 ? 1 : tiles) : 256);
+  };
+#define ARES_FUSED_CASE(ND)                                                                                            \
+  case ND:                                                                                                             \
+    if (prevSize > 0) {                                                                                                \
+      if (mw == 8)                                                                                                     \
+        ARES_LAUNCH("hr_partition4_kernel", (hr_partition4_kernel<ND, 8>), grid_for(prevSize), kThreads, stream,        \
+                    prevKeys.DimValues, static_cast<size_t>(prevKeys.VectorCapacity), prevValues, a, prevSize, ws);     \
+      else                                                                                                             \
+        ARES_LAUNCH("hr_partition4_kernel", (hr_partition4_kernel<ND, 4>), grid_for(prevSize), kThreads, stream,        \
+                    prevKeys.DimValues, static_cast<size_t>(prevKeys.VectorCapacity), prevValues, a, prevSize, ws);     \
+    }                                                                                                                  \
+    if (batchRows > 0)                                                                                                 \
+      ARES_LAUNCH("hr_fused_scan_kernel", hr_fused_scan_kernel<ND>, grid_for(batchRows), kThreads, stream, plan,       \
+                  static_cast<uint32_t>(prevSize), a, batchRows, ws);                                                  \
+    ARES_LAUNCH("hr_fused_merge_kernel", hr_fused_merge_kernel<ND>, numParts, kThreads, stream, plan, prevKeys.DimValues, \
+                static_cast<size_t>(prevKeys.VectorCapacity), static_cast<uint32_t>(prevSize), outKeys.DimValues,      \
+                static_cast<size_t>(outKeys.VectorCapacity), outValues, a, ws);                                        \
+    break;
+  switch (nd) {
+    ARES_FUSED_CASE(1) ARES_FUSED_CASE(2) ARES_FUSED_CASE(3) ARES_FUSED_CASE(4)
+  }
+#undef ARES_FUSED_CASE
+  uint32_t result[2] = {0, 0};
+  read_back_u32(ws.outCount, result, 2, stream);
+  if (result[1]) return -1;
+  return static_cast<int>(result[0]);
+}
+
+
 // ---- fused extension: host side ---------------------------------------------------------------------
 namespace {
 
@@ -1117,53 +1154,9 @@ int fused_filter_hash_reduce(const AresFusedQuery &q, int batchRows, const Dimen
   plan.measureWidth = mw;
   plan.identity = identity_bits(q.aggFunc, mt);
 
-  const int64_t length = static_cast<int64_t>(batchRows) + prevSize;
-  if (length == 0) return 0;
-  int partBits = 0;
-  while ((8192ll << partBits) < length && (1 << partBits) < kMaxPartitions) partBits++;
-  const int numParts = 1 << partBits;
-  Workspace ws;
-  ws.partBits = partBits;
-  ws.debug = 0;
-  ws.cap = ((2ull * (static_cast<uint64_t>(length) / numParts) + 2 * kSlots) | 63ull) + 18;
-  const size_t headBytes = sizeof(uint32_t) * (numParts + 2);
-  const size_t headPadded = (headBytes + 255) / 256 * 256;
-  StreamBuffer buf(headPadded + sizeof(uint4) * ws.cap * numParts, stream);
-  ws.cursors = buf.as<uint32_t>();
-  ws.outCount = ws.cursors + numParts;
-  ws.overflow = ws.outCount + 1;
-  ws.records = reinterpret_cast<uint4 *>(buf.as<uint8_t>() + headPadded);
-  hip_check(hipMemsetAsync(buf.get(), 0, headPadded, stream), "hipMemsetAsync");
-
-  auto grid_for = [](int64_t rows) {
-    const int64_t tiles = (rows + kQuadTile - 1) / kQuadTile;
-    return static_cast<int>(tiles < 256 ? (tiles < 1 ? 1 : tiles) : 256);
-  };
-#define ARES_FUSED_CASE(ND)                                                                                            \
-  case ND:                                                                                                             \
-    if (prevSize > 0) {                                                                                                \
-      if (mw == 8)                                                                                                     \
-        ARES_LAUNCH("hr_partition4_kernel", (hr_partition4_kernel<ND, 8>), grid_for(prevSize), kThreads, stream,        \
-                    prevKeys.DimValues, static_cast<size_t>(prevKeys.VectorCapacity), prevValues, a, prevSize, ws);     \
-      else                                                                                                             \
-        ARES_LAUNCH("hr_partition4_kernel", (hr_partition4_kernel<ND, 4>), grid_for(prevSize), kThreads, stream,        \
-                    prevKeys.DimValues, static_cast<size_t>(prevKeys.VectorCapacity), prevValues, a, prevSize, ws);     \
-    }                                                                                                                  \
-    if (batchRows > 0)                                                                                                 \
-      ARES_LAUNCH("hr_fused_scan_kernel", hr_fused_scan_kernel<ND>, grid_for(batchRows), kThreads, stream, plan,       \
-                  static_cast<uint32_t>(prevSize), a, batchRows, ws);                                                  \
-    ARES_LAUNCH("hr_fused_merge_kernel", hr_fused_merge_kernel<ND>, numParts, kThreads, stream, plan, prevKeys.DimValues, \
-                static_cast<size_t>(prevKeys.VectorCapacity), static_cast<uint32_t>(prevSize), outKeys.DimValues,      \
-                static_cast<size_t>(outKeys.VectorCapacity), outValues, a, ws);                                        \
-    break;
-  switch (nd) {
-    ARES_FUSED_CASE(1) ARES_FUSED_CASE(2) ARES_FUSED_CASE(3) ARES_FUSED_CASE(4)
-  }
-#undef ARES_FUSED_CASE
-  uint32_t result[2] = {0, 0};
-  read_back_u32(ws.outCount, result, 2, stream);
-  if (result[1]) throw NotFusable("a hash partition overflowed (skewed hashes); run the unfused sequence");
-  return static_cast<int>(result[0]);
+  const int groups = fused_hash_reduce_run(plan, batchRows, prevKeys, prevValues, prevSize, outKeys, outValues, a, stream);
+  if (groups < 0) throw NotFusable("a hash partition overflowed (skewed hashes); run the unfused sequence");
+  return groups;
 }
 
 }  // namespace

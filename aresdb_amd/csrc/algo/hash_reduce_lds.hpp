@@ -5,6 +5,7 @@
 
 #include "aggregate.hpp"
 #include "ares_algorithm.h"
+#include "fast_eval.hpp"
 
 namespace ares {
 
@@ -16,5 +17,34 @@ bool hash_reduce_lds_supported(const AggSpec &a);
 // global-table path; outputs written so far are simply overwritten).
 int hash_reduce_lds(const DimensionVector &inputKeys, const uint8_t *inputValues, const DimensionVector &outputKeys,
                     uint8_t *outputValues, const AggSpec &a, int length, hipStream_t stream);
+
+// ---- fused scan: filter + projection evaluated from the source columns ------------------------------
+constexpr int kFusedCols = 6, kFusedFilters = 4, kFusedDims = 4;
+struct FusedColumn {
+  const uint32_t *vals;
+  const uint8_t *nulls;
+  uint32_t bitOff;
+};
+struct FusedExpr {
+  FastOperands f;  // akind / arity / functor / I / rk / constant / divLike (pointers unused)
+  int col;
+  int outKind;     // kind of the stored dimension value
+};
+struct FusedPlanD {
+  int numCols;
+  FusedColumn cols[kFusedCols];
+  int numFilters;
+  FusedExpr filters[kFusedFilters];
+  FusedExpr dims[kFusedDims];
+  FusedExpr measure;
+  int measureDtype, measureWidth;
+  uint64_t identity;  // measure-transform identity of the aggregate (query/utils.hpp:169-184)
+};
+
+// Column slots of a plan of ND dimensions: dimension d -> slot d, measure -> slot ND; a filter reuses
+// a slot that already holds its column or takes the one spare slot ND + 1.
+int fused_hash_reduce_run(const FusedPlanD &plan, int batchRows, const DimensionVector &prevKeys, const uint8_t *prevValues,
+                          int prevSize, const DimensionVector &outKeys, uint8_t *outValues, const AggSpec &a,
+                          hipStream_t stream);
 
 }  // namespace ares

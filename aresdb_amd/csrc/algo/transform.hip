@@ -25,6 +25,7 @@
 #include "common.hpp"
 #include "device_model.hpp"
 #include "fast_eval.hpp"
+#include "hash_reduce_lds.hpp"
 #include "lookback.hpp"
 
 namespace ares {
@@ -967,12 +968,37 @@ struct ByteRange {
 };
 struct PendingQueue {
   MultiJobs jobs;
+  uint32_t colRows[kMaxMultiJobs];  // rows of each job's source column
   const uint32_t *idx = nullptr;
   int n = 0;
   std::vector<ByteRange> reads, writes;
+  // the host has waited for the stream since these jobs were queued (second-stage fusion,
+  // include/ares_extensions.h): a late launch from outside the stream's own call order must
+  // restore "the stream is idle" before anybody looks
+  bool overWait = false;
 };
 std::mutex g_deferMutex;
 std::map<std::pair<int, hipStream_t>, PendingQueue> g_pending;
+
+// Filters of the hot shape that have compacted an index vector since its InitIndexVector: with them
+// HashReduce can re-derive the survivors from the source columns instead of reading index, dimension
+// and measure vectors.  Any other writer of the index vector invalidates the entry.
+struct FilterJournal {
+  int device;
+  hipStream_t stream;
+  uint32_t start;
+  int n0;
+  bool valid;
+  std::vector<FastOperands> filters;
+  std::vector<uint32_t> colRows;
+};
+std::map<const uint32_t *, FilterJournal> g_journals;
+
+// Queues that a HashReduce consumed on the fly: their outputs were never written.  They stay
+// launchable (their inputs are held by libmem.so) until the stream starts its next batch or the
+// outputs are freed; a copy that touches an output launches them first.
+std::map<std::pair<int, hipStream_t>, PendingQueue> g_limbo;
+void (*g_releaseHeld)(int) = nullptr;  // AresMemReleaseHeld of the sibling libmem.so
 
 // Index vectors that InitIndexVector has defined but not written yet ("virtual iota"): the fast
 // filter and transform kernels that consume them compute rows = position instead of loading 4 bytes
@@ -984,6 +1010,10 @@ struct PendingIota {
   int n;
 };
 std::map<uint32_t *, PendingIota> g_iotas;
+
+void hook_on_wait(int device, void *stream);
+int hook_on_free(int device, void *ptr, size_t bytes);
+void hook_on_access(int device, const void *ptr, size_t bytes);
 
 // registers the flush hook with the sibling libmem.so; false = deferral is off for this process
 bool defer_available() {
@@ -1000,14 +1030,28 @@ bool defer_available() {
     auto set = reinterpret_cast<void (*)(void (*)(int))>(dlsym(h, "AresMemSetFlushHook"));
     if (!set) return false;
     set(&AresFlushDeferred);
+    // second stage (optional: an older libmem.so only knows the flush hook)
+    const char *fuse = getenv("ARES_FUSE");
+    auto setHooks = reinterpret_cast<void (*)(const AresDeferralHooks *)>(dlsym(h, "AresMemSetDeferralHooks"));
+    auto release = reinterpret_cast<void (*)(int)>(dlsym(h, "AresMemReleaseHeld"));
+    if (setHooks && release && !(fuse && fuse[0] == '0')) {
+      static const AresDeferralHooks hooks = {&AresFlushDeferred, &hook_on_wait, &hook_on_free, &hook_on_access};
+      g_releaseHeld = release;
+      setHooks(&hooks);
+    }
     return true;
   }();
   return ok;
 }
+bool fuse_available() { return defer_available() && g_releaseHeld != nullptr; }
 
-// caller holds g_deferMutex and has selected the device
-void launch_queue(hipStream_t stream, PendingQueue &q) {
+// caller holds g_deferMutex and has selected the device.  inOrder: the launch is part of the
+// stream's own call sequence (a later call on the same stream follows); otherwise a queue the host
+// has already waited for is synchronised after its late launch.
+void launch_queue(hipStream_t stream, PendingQueue &q, bool inOrder = false) {
   if (q.jobs.count == 0) return;
+  const bool syncAfter = q.overWait && !inOrder;
+  q.overWait = false;
   const int64_t numQuads = (static_cast<int64_t>(q.n) + 3) / 4;
   const int64_t tiles = (numQuads + kBlock * kTQ - 1) / (kBlock * kTQ);
   if (q.jobs.count == 1) {
@@ -1024,6 +1068,29 @@ void launch_queue(hipStream_t stream, PendingQueue &q) {
   q.jobs.count = 0;
   q.reads.clear();
   q.writes.clear();
+  if (syncAfter) hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+}
+
+// caller holds g_deferMutex.  Launches the skipped transforms of every limbo entry of the device
+// (all = true) or of those whose outputs overlap `range`, and forgets the entries.
+bool materialize_limbo(int device, const ByteRange *range) {
+  bool any = false;
+  for (auto it = g_limbo.begin(); it != g_limbo.end();) {
+    bool hit = it->first.first == device;
+    if (hit && range) {
+      hit = false;
+      for (const ByteRange &w : it->second.writes) hit = hit || w.overlaps(*range);
+    }
+    if (hit) {
+      it->second.overWait = true;  // the host believes this work is long done
+      launch_queue(it->first.second, it->second);
+      it = g_limbo.erase(it);
+      any = true;
+    } else {
+      ++it;
+    }
+  }
+  return any;
 }
 }  // namespace
 
@@ -1045,9 +1112,55 @@ void flush_deferred(int device) {
       ++it;
     }
   }
+  bool held = false;
   for (auto &kv : g_pending)
-    if (kv.first.first == device) launch_queue(kv.first.second, kv.second);
+    if (kv.first.first == device) {
+      held = held || kv.second.overWait;
+      launch_queue(kv.first.second, kv.second);
+    }
+  held = materialize_limbo(device, nullptr) || held;
+  if (held && g_releaseHeld) g_releaseHeld(device);
 }
+
+// InitIndexVector opens a batch on the stream: what the previous batch's HashReduce skipped is dead
+// now (the host has swapped its result buffers), and the new index vector starts a filter journal.
+static void begin_batch(int device, hipStream_t stream, const uint32_t *indexVector, uint32_t start, int n) {
+  if (!fuse_available()) return;
+  bool release = false;
+  {
+    std::lock_guard<std::mutex> lock(g_deferMutex);
+    release = g_limbo.erase({device, stream}) > 0;
+    FilterJournal j;
+    j.device = device;
+    j.stream = stream;
+    j.start = start;
+    j.n0 = n;
+    j.valid = true;
+    g_journals[indexVector] = j;
+  }
+  if (release) g_releaseHeld(device);
+}
+
+// a fast filter has compacted `indexVector` (f == nullptr: something else has — forget the journal)
+static void journal_filter(const uint32_t *indexVector, const FastOperands *f, uint32_t colRows, int rowsBefore) {
+  if (!fuse_available()) return;
+  std::lock_guard<std::mutex> lock(g_deferMutex);
+  auto it = g_journals.find(indexVector);
+  if (it == g_journals.end()) return;
+  FilterJournal &j = it->second;
+  if (!f || !j.valid || j.filters.size() >= static_cast<size_t>(kFusedFilters) ||
+      (j.filters.empty() && rowsBefore != j.n0)) {
+    j.valid = false;
+    return;
+  }
+  FastOperands copy = *f;
+  copy.idx = nullptr;
+  copy.pad = 0;
+  j.filters.push_back(copy);
+  j.colRows.push_back(colRows);
+}
+
+void invalidate_filter_journal(const uint32_t *indexVector) { journal_filter(indexVector, nullptr, 0, 0); }
 
 // InitIndexVector: remember instead of writing (when the flush hook is in place)
 static bool defer_iota(int device, hipStream_t stream, uint32_t *indexVector, uint32_t start, int n) {
@@ -1088,6 +1201,7 @@ static bool defer_transform(int device, hipStream_t stream, const FastOperands &
   fq.pad = 0;
   q.jobs.f[q.jobs.count] = fq;
   q.jobs.s[q.jobs.count] = s;
+  q.colRows[q.jobs.count] = colRows;
   q.jobs.count++;
   q.reads.push_back(rv);
   if (f.nulls) q.reads.push_back(rn);
@@ -1173,6 +1287,10 @@ static int run_filter(const InputVector *ins, int arity, uint32_t *indexVector, 
     const char *e = getenv("ARES_FILTER");
     return e && strcmp(e, "onepass") == 0;
   }();
+  if (fast && !onePass && numForeignTables == 0 && baseCounts == nullptr)
+    journal_filter(indexVector, &f, p.a.length, n);
+  else
+    journal_filter(indexVector, nullptr, 0, 0);
   if (fast && !onePass) {
     // two-phase path: predicate + tile counts, scan, chain-free compaction of the index vector and
     // of every RecordID vector
@@ -1262,6 +1380,282 @@ static int run_filter(const InputVector *ins, int arity, uint32_t *indexVector, 
   read_back_u32(totalDev, result, 2, stream);
   if (result[1]) throw AlgorithmError("ERROR: filter: inter-tile scan timed out");
   return static_cast<int>(result[0]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// second-stage fusion: notifications from libmem.so, and HashReduce consuming the pending queue
+// ---------------------------------------------------------------------------------------------
+namespace {
+ByteRange range_of(const void *ptr, size_t bytes) {
+  const uint8_t *lo = static_cast<const uint8_t *>(ptr);
+  return ByteRange{lo, lo + (bytes ? bytes : 1)};
+}
+bool touches(const std::vector<ByteRange> &v, const ByteRange &r) {
+  for (const ByteRange &x : v)
+    if (x.overlaps(r)) return true;
+  return false;
+}
+struct DeviceGuard {  // hooks run on libmem.so's threads: select the device, restore it afterwards
+  int previous = -1;
+  explicit DeviceGuard(int device) {
+    if (hipGetDevice(&previous) != hipSuccess) previous = -1;
+    if (previous != device) (void)hipSetDevice(device);
+  }
+  ~DeviceGuard() {
+    if (previous >= 0) (void)hipSetDevice(previous);
+  }
+};
+
+// WaitForCudaStream: a queue whose results only a HashReduce on the same stream will consume may stay
+void hook_on_wait(int device, void *streamPtr) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(streamPtr);
+  try {
+    DeviceGuard guard(device);
+    std::lock_guard<std::mutex> lock(g_deferMutex);
+    // a wait on one stream says nothing about the others: their pending work is left alone
+    for (auto it = g_iotas.begin(); it != g_iotas.end();) {
+      if (it->second.device == device && it->second.stream == stream) {
+        launch_init_index(it->first, it->second.start, it->second.n, it->second.stream);
+        it = g_iotas.erase(it);
+      } else {
+        ++it;
+      }
+    }
+    for (auto &kv : g_pending) {
+      if (kv.first.first != device || kv.first.second != stream || kv.second.jobs.count == 0 || kv.second.overWait) continue;
+      PendingQueue &q = kv.second;
+      bool keep = true;
+      if (q.idx) {  // the survivors must be re-derivable from the filter journal
+        auto j = g_journals.find(q.idx);
+        keep = j != g_journals.end() && j->second.valid && j->second.device == device && j->second.stream == stream &&
+               j->second.start == 0;
+        if (keep)  // the filters' columns are inputs of the pending work from now on
+          for (size_t k = 0; k < j->second.filters.size(); k++) {
+            const FastOperands &f = j->second.filters[k];
+            q.reads.push_back(range_of(f.vals, 4ull * j->second.colRows[k]));
+            if (f.nulls) q.reads.push_back(range_of(f.nulls, (static_cast<uint64_t>(j->second.colRows[k]) + f.bitOff + 7) / 8 + 2));
+          }
+      }
+      if (keep)
+        q.overWait = true;
+      else
+        launch_queue(kv.first.second, q);
+    }
+  } catch (std::exception &e) {
+    fprintf(stderr, "Exception happened when handling a stream wait: %s\n", e.what());
+  }
+}
+
+// DeviceFree: 1 = keep the block aside, pending (or skipped) work still reads it
+int hook_on_free(int device, void *ptr, size_t bytes) {
+  const ByteRange r = range_of(ptr, bytes);
+  bool hold = false, release = false;
+  try {
+    DeviceGuard guard(device);
+    std::lock_guard<std::mutex> lock(g_deferMutex);
+    for (auto it = g_iotas.begin(); it != g_iotas.end();) {  // an index vector nobody has read yet
+      const ByteRange v = range_of(it->first, 4ull * it->second.n);
+      it = (it->second.device == device && v.overlaps(r)) ? g_iotas.erase(it) : std::next(it);
+    }
+    for (auto it = g_journals.begin(); it != g_journals.end();) {
+      const bool dead = it->second.device == device && range_of(it->first, 4).overlaps(r);
+      bool pending = false;  // ... unless a kept queue still refers to it
+      if (dead)
+        for (auto &kv : g_pending) pending = pending || (kv.second.jobs.count && kv.second.idx == it->first);
+      it = (dead && !pending) ? g_journals.erase(it) : std::next(it);
+    }
+    for (auto &kv : g_pending) {
+      if (kv.first.first != device || kv.second.jobs.count == 0) continue;
+      if (touches(kv.second.writes, r)) {
+        release = release || kv.second.overWait;
+        launch_queue(kv.first.second, kv.second);  // an output is freed: run the work, the fence follows it
+      } else if (touches(kv.second.reads, r)) {
+        hold = true;
+      }
+    }
+    for (auto it = g_limbo.begin(); it != g_limbo.end();) {
+      if (it->first.first == device && touches(it->second.writes, r)) {  // the skipped outputs die unseen
+        it = g_limbo.erase(it);
+        release = true;
+      } else {
+        if (it->first.first == device && touches(it->second.reads, r)) hold = true;
+        ++it;
+      }
+    }
+  } catch (std::exception &e) {
+    fprintf(stderr, "Exception happened when handling a device free: %s\n", e.what());
+  }
+  if (release && g_releaseHeld) g_releaseHeld(device);
+  return hold ? 1 : 0;
+}
+
+// a copy is about to touch [ptr, ptr + bytes)
+void hook_on_access(int device, const void *ptr, size_t bytes) {
+  const ByteRange r = range_of(ptr, bytes);
+  bool release = false;
+  try {
+    DeviceGuard guard(device);
+    std::lock_guard<std::mutex> lock(g_deferMutex);
+    for (auto it = g_iotas.begin(); it != g_iotas.end();) {
+      const ByteRange v = range_of(it->first, 4ull * it->second.n);
+      if (it->second.device == device && v.overlaps(r)) {
+        launch_init_index(it->first, it->second.start, it->second.n, it->second.stream);
+        hip_check(hipStreamSynchronize(it->second.stream), "hipStreamSynchronize");
+        it = g_iotas.erase(it);
+      } else {
+        ++it;
+      }
+    }
+    for (auto &kv : g_pending) {
+      if (kv.first.first != device || kv.second.jobs.count == 0) continue;
+      if (touches(kv.second.writes, r) || touches(kv.second.reads, r)) {
+        release = release || kv.second.overWait;
+        launch_queue(kv.first.second, kv.second);
+      }
+    }
+    release = materialize_limbo(device, &r) || release;
+  } catch (std::exception &e) {
+    fprintf(stderr, "Exception happened when handling a device copy: %s\n", e.what());
+  }
+  if (release && g_releaseHeld) g_releaseHeld(device);
+}
+}  // namespace
+
+// HashReduce's first move: when the stream's pending queue is exactly "the dimension columns and the
+// measure of rows [prev, prev + n) of inputKeys / inputValues", evaluate it on the fly (the fused
+// scan of hash_reduce_lds.hip) instead of launching it.  Returns false when the call must take the
+// ordinary path (whatever was pending has been launched, in stream order).
+bool fuse_pending_into_hash_reduce(int device, hipStream_t stream, const DimensionVector &in, const uint8_t *inValues,
+                                   const DimensionVector &out, uint8_t *outValues, int valueBytes, int length, int aggFunc,
+                                   int *groups) {
+  if (!fuse_available()) return false;
+  const char *forced = getenv("ARES_HASH_REDUCE");
+  PendingQueue q;
+  FusedPlanD plan;
+  memset(&plan, 0, sizeof(plan));
+  int nd = 0, prev = 0, n0 = 0;
+  AggSpec a;
+  {
+    std::lock_guard<std::mutex> lock(g_deferMutex);
+    auto it = g_pending.find({device, stream});
+    if (it == g_pending.end() || it->second.jobs.count == 0) return false;
+    PendingQueue &pq = it->second;
+    bool ok = !(forced && strcmp(forced, "global") == 0);
+    nd = in.NumDimsPerDimWidth[2];
+    for (int k = 0; k < NUM_DIM_WIDTH; k++)
+      ok = ok && in.NumDimsPerDimWidth[k] == (k == 2 ? nd : 0) && out.NumDimsPerDimWidth[k] == in.NumDimsPerDimWidth[k];
+    ok = ok && nd >= 1 && nd <= kFusedDims && pq.jobs.count == nd + 1;
+    prev = length - pq.n;
+    ok = ok && prev >= 0 && pq.n > 0;
+    if (ok) {
+      try {
+        a = make_agg_spec(aggFunc, valueBytes);
+        ok = hash_reduce_lds_supported(a);
+      } catch (std::exception &) {
+        ok = false;
+      }
+    }
+    // survivors: the whole batch (no filter ran) or what the journalled filters keep
+    const FilterJournal *journal = nullptr;
+    n0 = pq.n;
+    if (ok && pq.idx) {
+      auto j = g_journals.find(pq.idx);
+      ok = j != g_journals.end() && j->second.valid && j->second.start == 0 && j->second.device == device;
+      if (ok) {
+        journal = &j->second;
+        n0 = journal->n0;
+      }
+    }
+    // every dimension column and the measure of rows [prev, prev + n) must be a pending sink
+    const size_t cap = static_cast<size_t>(in.VectorCapacity);
+    int dimJob[kFusedDims] = {-1, -1, -1, -1}, measureJob = -1;
+    for (int k = 0; ok && k < pq.jobs.count; k++) {
+      const SinkD &s = pq.jobs.s[k];
+      ok = pq.colRows[k] >= static_cast<uint32_t>(n0);
+      if (s.type == SINK_MEASURE) {
+        ok = ok && measureJob < 0 && s.values == inValues + static_cast<size_t>(valueBytes) * prev && s.width == valueBytes &&
+             s.agg == aggFunc && s.baseCounts == nullptr;
+        measureJob = k;
+      } else {
+        int d = -1;
+        for (int c = 0; c < nd; c++)
+          if (s.values == in.DimValues + 4 * cap * c + 4ull * prev && s.nulls == in.DimValues + 4 * cap * nd + cap * c + prev) d = c;
+        ok = ok && s.type == SINK_DIM && d >= 0 && dimJob[d] < 0 && s.width == 4;
+        if (ok) dimJob[d] = k;
+      }
+    }
+    ok = ok && measureJob >= 0;
+    for (int c = 0; ok && c < nd; c++) ok = dimJob[c] >= 0;
+    if (ok) {
+      auto column_of = [](const FastOperands &f) { return FusedColumn{f.vals, f.nulls, f.bitOff}; };
+      auto strip = [](FastOperands f) {
+        f.vals = nullptr;
+        f.nulls = nullptr;
+        f.idx = nullptr;
+        f.pad = 0;
+        return f;
+      };
+      auto kind_of = [](int dtype) { return dtype == Int32 ? K_I32 : dtype == Uint32 ? K_U32 : K_F32; };
+      for (int c = 0; c < nd; c++) {
+        const int k = dimJob[c];
+        plan.cols[c] = column_of(pq.jobs.f[k]);
+        plan.dims[c].f = strip(pq.jobs.f[k]);
+        plan.dims[c].col = c;
+        plan.dims[c].outKind = kind_of(pq.jobs.s[k].dtype);
+      }
+      plan.cols[nd] = column_of(pq.jobs.f[measureJob]);
+      plan.measure.f = strip(pq.jobs.f[measureJob]);
+      plan.measure.col = nd;
+      plan.measure.outKind = kind_of(pq.jobs.s[measureJob].dtype);
+      plan.measureDtype = pq.jobs.s[measureJob].dtype;
+      plan.measureWidth = valueBytes;
+      plan.identity = pq.jobs.s[measureJob].identity;
+      plan.numCols = nd + 1;
+      if (journal) {
+        ok = journal->filters.size() <= static_cast<size_t>(kFusedFilters);
+        for (size_t k = 0; ok && k < journal->filters.size(); k++) {
+          const FastOperands &f = journal->filters[k];
+          ok = journal->colRows[k] >= static_cast<uint32_t>(n0);
+          int col = -1;
+          for (int c = 0; c < plan.numCols; c++)
+            if (plan.cols[c].vals == f.vals && plan.cols[c].nulls == f.nulls && plan.cols[c].bitOff == f.bitOff) col = c;
+          if (col < 0 && plan.numCols < nd + 2) {
+            col = plan.numCols++;
+            plan.cols[col] = column_of(f);
+          }
+          ok = ok && col >= 0;
+          plan.filters[k].f = strip(f);
+          plan.filters[k].col = col;
+          plan.filters[k].outKind = K_BOOL;
+        }
+        plan.numFilters = static_cast<int>(journal->filters.size());
+      }
+    }
+    if (!ok) {  // the ordinary path: the pending work runs now, ahead of this call on the same stream
+      const bool release = pq.overWait;
+      launch_queue(stream, pq, /*inOrder=*/true);
+      if (release) g_releaseHeld(device);
+      return false;
+    }
+    q = pq;  // taken out of the queue: nobody else launches it
+    pq.jobs.count = 0;
+    pq.reads.clear();
+    pq.writes.clear();
+    pq.overWait = false;
+    if (q.idx) g_journals.erase(q.idx);
+  }
+  DimensionVector prevKeys = in;
+  const int result = fused_hash_reduce_run(plan, n0, prevKeys, inValues, prev, out, outValues, a, stream);
+  std::unique_lock<std::mutex> lock(g_deferMutex);
+  if (result < 0) {  // a partition region overflowed: materialise the inputs after all
+    launch_queue(stream, q, /*inOrder=*/true);
+    lock.unlock();
+    g_releaseHeld(device);
+    return false;
+  }
+  g_limbo[{device, stream}] = q;  // launchable until the next batch begins (begin_batch)
+  *groups = result;
+  return true;
 }
 
 // tile counts of an existing predicate vector, in filter_pred_kernel's tile geometry
@@ -1355,6 +1749,7 @@ CGoCallResHandle InitIndexVector(uint32_t *indexVector, uint32_t start, int inde
                                  int device) {
   ARES_ABI_BEGIN_NOFLUSH(device)
   hipStream_t stream = reinterpret_cast<hipStream_t>(cudaStream);
+  begin_batch(device, stream, indexVector, start, indexVectorLength);
   if (!defer_iota(device, stream, indexVector, start, indexVectorLength)) {
     flush_deferred(device);
     std::lock_guard<std::mutex> lock(g_deferMutex);

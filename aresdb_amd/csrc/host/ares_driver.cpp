@@ -204,6 +204,7 @@ struct AresQuery {
   bool isLastBatch = false;
   uint32_t *geoPredicateVec = nullptr;
   int sizeBeforeGeoFilter = 0;
+  std::vector<void *> ownedColumns;  // device allocations of the batch's columns handed over by the caller
   uint64_t *hashVec[2] = {nullptr, nullptr};
   uint32_t *dimIndexVec[2] = {nullptr, nullptr};
   int size = 0;
@@ -327,6 +328,9 @@ struct AresQuery {
   }
 
   void cleanupBeforeAggregation() {
+    // the batch's input columns go first (query/aql_processor.go:695-699)
+    for (void *p : ownedColumns) release(p);
+    ownedColumns.clear();
     release(indexVec); indexVec = nullptr;
     release(predVec); predVec = nullptr;
     for (RecordID *p : foreignRids) release(p);
@@ -758,6 +762,9 @@ uint8_t *AresQueryMeasureVector(const AresQuery *q) { return q->measureVec[0]; }
 long AresQueryNumCalls(const AresQuery *q) { return q->calls; }
 long AresQueryNumFusedBatches(const AresQuery *q) { return q->fusedBatches; }
 void AresQuerySetLastBatch(AresQuery *q, int isLast) { q->isLastBatch = isLast != 0; }
+void AresQueryAdoptColumns(AresQuery *q, void *const *allocations, int count) {
+  q->ownedColumns.assign(allocations, allocations + count);
+}
 int64_t AresQueryHLLVectorSize(const AresQuery *q) { return static_cast<int64_t>(q->hllVectorSize); }
 
 int AresQueryFetchHLL(AresQuery *q, uint16_t *regCounts, uint8_t *hllVector, char *err, int errLen) {

@@ -99,6 +99,11 @@ int AresQueryFetch(AresQuery *q, uint8_t *dims, uint8_t *measures, char *err, in
  * the result is the dimension columns (AresQueryFetch, measures may be NULL), the registers per
  * dimension (uint16 x resultSize) and the encoded HLL vector (query/hll.go:52-63). */
 void AresQuerySetLastBatch(AresQuery *q, int isLast);
+/* Device allocations (DeviceAllocate) holding the NEXT batch's columns: the driver releases them with
+ * DeviceFree in cleanupBeforeAggregation — between project() and reduce() — exactly where the Go host
+ * frees a batch's input columns (query/aql_processor.go:695-699).  Without this call the columns stay
+ * the caller's (a device-resident column cache). */
+void AresQueryAdoptColumns(AresQuery *q, void *const *allocations, int count);
 int64_t AresQueryHLLVectorSize(const AresQuery *q);
 int AresQueryFetchHLL(AresQuery *q, uint16_t *regCounts, uint8_t *hllVector, char *err, int errLen);
 void AresQueryDestroy(AresQuery *q);

@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "ares_memory.h"
+#include "ares_extensions.h"
 
 #pragma clang diagnostic ignored "-Wdeprecated-declarations"  // hipProfilerStart/Stop: the ABI asks for them
 
@@ -64,12 +65,36 @@ inline CGoCallResHandle fail(const char *what, hipError_t err) {
 // which the host could observe, free or overwrite device memory runs it first.
 typedef void (*FlushHook)(int device);
 std::atomic<FlushHook> g_flushHook{nullptr};
+// finer-grained notifications (include/ares_extensions.h: AresDeferralHooks); null = use the flush hook
+std::atomic<const AresDeferralHooks *> g_hooks{nullptr};
 inline void flush_pending(int device) {
   if (FlushHook h = g_flushHook.load(std::memory_order_acquire)) h(device);
 }
 inline void flush_pending_current() {
   int device = 0;
   if (hipGetDevice(&device) == hipSuccess) flush_pending(device);
+}
+// the host waits for a stream: pending work MAY stay pending when nothing but later library calls
+// can observe its results
+inline void notify_wait(int device, void *stream) {
+  const AresDeferralHooks *h = g_hooks.load(std::memory_order_acquire);
+  if (h && h->on_wait) h->on_wait(device, stream); else flush_pending(device);
+}
+// a copy is about to read or write [ptr, ptr + bytes)
+inline void notify_access(int device, const void *ptr, size_t bytes) {
+  const AresDeferralHooks *h = g_hooks.load(std::memory_order_acquire);
+  if (h && h->on_access) h->on_access(device, ptr, bytes); else flush_pending(device);
+}
+inline void notify_access_current(const void *ptr, size_t bytes) {
+  int device = 0;
+  if (hipGetDevice(&device) == hipSuccess) notify_access(device, ptr, bytes);
+}
+// the host frees a block: true = work that has not been launched yet still reads it, keep it aside
+inline bool notify_free(int device, void *ptr, size_t bytes) {
+  const AresDeferralHooks *h = g_hooks.load(std::memory_order_acquire);
+  if (h && h->on_free) return h->on_free(device, ptr, bytes) != 0;
+  flush_pending(device);
+  return false;
 }
 
 bool use_pool() {
@@ -109,6 +134,7 @@ struct DeviceState {
   std::unordered_map<void *, size_t> live;               // allocation -> rounded size
   std::vector<hipEvent_t> freeEvents;
   size_t parkedBytes = 0;
+  std::vector<void *> held;  // freed by the host while deferred work still reads them (AresMemReleaseHeld)
 };
 DeviceState g_devices[kMaxDevices];
 
@@ -261,6 +287,27 @@ extern "C" {
 
 // extension (include/ares_extensions.h): called by the sibling libalgorithm.so, never by the host
 void AresMemSetFlushHook(void (*hook)(int device)) { g_flushHook.store(hook, std::memory_order_release); }
+void AresMemSetDeferralHooks(const AresDeferralHooks *hooks) {
+  if (hooks && hooks->flush) g_flushHook.store(hooks->flush, std::memory_order_release);
+  g_hooks.store(hooks, std::memory_order_release);
+}
+
+// The work that was reading the held blocks has been launched (or dropped): fence them like any
+// other free — the fence is recorded now, behind that work.
+void AresMemReleaseHeld(int device) {
+  if (device < 0 || device >= kMaxDevices) return;
+  DeviceState *st = &g_devices[device];
+  std::vector<void *> blocks;
+  {
+    std::lock_guard<std::mutex> lock(st->mu);
+    blocks.swap(st->held);
+  }
+  if (blocks.empty()) return;
+  int current = 0;
+  const bool switched = hipGetDevice(&current) == hipSuccess && current != device && hipSetDevice(device) == hipSuccess;
+  for (void *p : blocks) (void)pool_free(st, p);
+  if (switched) (void)hipSetDevice(current);
+}
 
 DeviceMemoryFlags GetFlags(void) {
   // reference cuda_malloc.cu:36-42 / rmm_alloc.cu:84-91
@@ -303,7 +350,7 @@ CGoCallResHandle CreateCudaStream(int device) {
 
 CGoCallResHandle WaitForCudaStream(void *s, int device) {
   MEM_TRY(hipSetDevice(device), "WaitForCudaStream");
-  flush_pending(device);
+  notify_wait(device, s);
   MEM_TRY(hipStreamSynchronize(reinterpret_cast<hipStream_t>(s)), "WaitForCudaStream");
   return ok();
 }
@@ -339,18 +386,42 @@ CGoCallResHandle DeviceAllocate(size_t bytes, int device) {
   return ok(p);
 }
 
+// size of a live allocation (0 = unknown)
+size_t allocation_size(DeviceState *st, void *p) {
+  if (use_pool()) {
+    std::lock_guard<std::mutex> lock(st->mu);
+    auto it = st->live.find(p);
+    if (it != st->live.end()) return it->second;
+  }
+  size_t bytes = 0;
+  if (hipMemPtrGetInfo(p, &bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    bytes = 0;
+  }
+  return bytes;
+}
+
+hipError_t free_or_hold(DeviceState *st, void *p, int device) {
+  if (p == nullptr) return hipSuccess;
+  if (notify_free(device, p, allocation_size(st, p))) {
+    std::lock_guard<std::mutex> lock(st->mu);
+    st->held.push_back(p);
+    return hipSuccess;
+  }
+  return pool_free(st, p);
+}
+
 CGoCallResHandle DeviceFree(void *p, int device) {
   MEM_TRY(hipSetDevice(device), "DeviceFree");
-  flush_pending(device);
   DeviceState *st;
   MEM_TRY(device_state(device, &st), "DeviceFree");
-  MEM_TRY(pool_free(st, p), "DeviceFree");
+  MEM_TRY(free_or_hold(st, p, device), "DeviceFree");
   return ok();
 }
 
 CGoCallResHandle AsyncCopyHostToDevice(void *dst, void *src, size_t bytes, void *stream, int device) {
   MEM_TRY(hipSetDevice(device), "AsyncCopyHostToDevice");
-  flush_pending(device);
+  notify_access(device, dst, bytes);
   if (bytes)
     MEM_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, reinterpret_cast<hipStream_t>(stream)),
             "AsyncCopyHostToDevice");
@@ -359,7 +430,8 @@ CGoCallResHandle AsyncCopyHostToDevice(void *dst, void *src, size_t bytes, void 
 
 CGoCallResHandle AsyncCopyDeviceToDevice(void *dst, void *src, size_t bytes, void *stream, int device) {
   MEM_TRY(hipSetDevice(device), "AsyncCopyDeviceToDevice");
-  flush_pending(device);
+  notify_access(device, dst, bytes);
+  notify_access(device, src, bytes);
   if (bytes)
     MEM_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, reinterpret_cast<hipStream_t>(stream)),
             "AsyncCopyDeviceToDevice");
@@ -368,7 +440,7 @@ CGoCallResHandle AsyncCopyDeviceToDevice(void *dst, void *src, size_t bytes, voi
 
 CGoCallResHandle AsyncCopyDeviceToHost(void *dst, void *src, size_t bytes, void *stream, int device) {
   MEM_TRY(hipSetDevice(device), "AsyncCopyDeviceToHost");
-  flush_pending(device);
+  notify_access(device, src, bytes);
   if (bytes)
     MEM_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, reinterpret_cast<hipStream_t>(stream)),
             "AsyncCopyDeviceToHost");
@@ -418,21 +490,22 @@ CGoCallResHandle deviceMalloc(void **devPtr, size_t size) {
 }
 
 CGoCallResHandle deviceFree(void *devPtr) {
-  flush_pending_current();
+  int device = 0;
+  MEM_TRY(hipGetDevice(&device), "deviceFree");
   DeviceState *st;
-  MEM_TRY(current_device_state(&st), "deviceFree");
-  MEM_TRY(pool_free(st, devPtr), "deviceFree");
+  MEM_TRY(device_state(device, &st), "deviceFree");
+  MEM_TRY(free_or_hold(st, devPtr, device), "deviceFree");
   return ok();
 }
 
 CGoCallResHandle deviceMemset(void *devPtr, int value, size_t count) {
-  flush_pending_current();
+  notify_access_current(devPtr, count);
   MEM_TRY(hipMemset(devPtr, value, count), "deviceMemset");
   return ok();
 }
 
 CGoCallResHandle asyncCopyHostToDevice(void *dst, const void *src, size_t count, void *stream) {
-  flush_pending_current();
+  notify_access_current(dst, count);
   if (count)
     MEM_TRY(hipMemcpyAsync(dst, src, count, hipMemcpyHostToDevice, reinterpret_cast<hipStream_t>(stream)),
             "asyncCopyHostToDevice");
@@ -440,7 +513,7 @@ CGoCallResHandle asyncCopyHostToDevice(void *dst, const void *src, size_t count,
 }
 
 CGoCallResHandle asyncCopyDeviceToHost(void *dst, const void *src, size_t count, void *stream) {
-  flush_pending_current();
+  notify_access_current(src, count);
   if (count)
     MEM_TRY(hipMemcpyAsync(dst, src, count, hipMemcpyDeviceToHost, reinterpret_cast<hipStream_t>(stream)),
             "asyncCopyDeviceToHost");
@@ -448,7 +521,10 @@ CGoCallResHandle asyncCopyDeviceToHost(void *dst, const void *src, size_t count,
 }
 
 CGoCallResHandle waitForCudaStream(void *stream) {
-  flush_pending_current();
+  {
+    int device = 0;
+    if (hipGetDevice(&device) == hipSuccess) notify_wait(device, stream);
+  }
   MEM_TRY(hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream)), "waitForCudaStream");
   return ok();
 }

@@ -70,6 +70,7 @@ def _driver():
         lib.AresQueryFetch.restype = C.c_int
         lib.AresQueryDestroy.argtypes = [C.c_void_p]
         lib.AresQuerySetLastBatch.argtypes = [C.c_void_p, C.c_int]
+        lib.AresQueryAdoptColumns.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int]
         lib.AresQueryHLLVectorSize.argtypes, lib.AresQueryHLLVectorSize.restype = [C.c_void_p], C.c_int64
         lib.AresQueryFetchHLL.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
         lib.AresQueryFetchHLL.restype = C.c_int
@@ -172,9 +173,13 @@ class NativeQuery:
             raise abi.AresError(err.value.decode())
         self._err = C.create_string_buffer(1024)
 
-    def run(self, columns, size, base_counts=None, start_row=0, is_last_batch=False):
-        """columns: {name: VectorPartySlice} of the main table for this batch."""
+    def run(self, columns, size, base_counts=None, start_row=0, is_last_batch=False, owned_allocations=()):
+        """columns: {name: VectorPartySlice} of the main table for this batch.  owned_allocations:
+        device pointers of the batch's columns that the driver frees before the aggregation stage,
+        like the Go host."""
         _driver().AresQuerySetLastBatch(self._q, int(is_last_batch))
+        owned = (C.c_void_p * max(len(owned_allocations), 1))(*owned_allocations)
+        _driver().AresQueryAdoptColumns(self._q, owned, len(owned_allocations))
         cols = (abi.VectorPartySlice * len(self.column_names))(*[columns[n] for n in self.column_names])
         rc = _driver().AresQueryRunBatch(self._q, cols, len(self.column_names), size, base_counts, start_row,
                                          self._err, 1024)

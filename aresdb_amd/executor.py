@@ -172,6 +172,7 @@ class BatchContext:
         self.stack: List[int] = []
         self.foreign_rids: List[int] = []
         self.geo_predicate_vec = 0
+        self.owned_columns = []  # callables that free the batch's device columns
         self._keepalive = []
         self.calls = 0  # ABI calls issued (for tests / stats)
         # HyperLogLog queries: buffers the library allocates on the last batch
@@ -262,6 +263,10 @@ class BatchContext:
         self._free(self.stack.pop())
 
     def cleanup_before_aggregation(self):
+        # the batch's input columns go first (query/aql_processor.go:695-699)
+        for release in self.owned_columns:
+            release()
+        self.owned_columns = []
         self._free(self.index_vec)
         self._free(self.pred_vec)
         self.index_vec = self.pred_vec = 0
@@ -454,8 +459,11 @@ class BatchExecutor:
         self.size_before_geo = 0
 
     def run(self, columns: Dict[str, abi.VectorPartySlice], size: int, base_counts=None, start_row=0,
-            is_last_batch=False):
+            is_last_batch=False, owned_columns=()):
+        """owned_columns: callables releasing the batch's device columns; the Go host frees them in
+        cleanupBeforeAggregation, i.e. between project() and reduce()."""
         c = self.ctx
+        c.owned_columns = list(owned_columns)
         self.is_last_batch = is_last_batch
         c.prepare_for_filtering(columns, size, base_counts, start_row)
         self.pre_exec()

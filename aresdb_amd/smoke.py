@@ -32,9 +32,8 @@ def run_query(be, plan, batches):
     for cols, valid in batches:
         dev = {k: DeviceColumn(be, t, v, valid=valid[k]) for k, (t, v) in cols.items()}
         n = len(next(iter(cols.values()))[1])
-        ex.run({k: d.vp for k, d in dev.items()}, n)
-        for d in dev.values():
-            d.free()
+        # like the Go host, the batch's columns are released before the aggregation stage
+        ex.run({k: d.vp for k, d in dev.items()}, n, owned_columns=[d.free for d in dev.values()])
     dims, valids, meas = fetch_results(ctx)
     calls = ctx.calls
     ctx.release()
@@ -55,9 +54,9 @@ def run_query_native(be, plan, batches, stream=None):
     for cols, valid in batches:
         dev = {k: DeviceColumn(be, t, v, valid=valid[k], stream=stream) for k, (t, v) in cols.items()}
         n = len(next(iter(cols.values()))[1])
-        q.run({k: d.vp for k, d in dev.items()}, n)
+        q.run({k: d.vp for k, d in dev.items()}, n, owned_allocations=[d.ptr for d in dev.values()])
         for d in dev.values():
-            d.free()
+            d.ptr = 0  # released by the driver before the aggregation stage, like the Go host
     dims, valids, meas = q.fetch()
     calls = q.calls
     n = q.result_size

@@ -33,6 +33,33 @@ size_t AresProfilerReport(char *buf, size_t len);
 void AresFlushDeferred(int device);                      /* exported by libalgorithm.so */
 void AresMemSetFlushHook(void (*hook)(int device));      /* exported by libmem.so */
 
+/* Cross-call fusion, second stage: the pending dimension / measure transforms of a batch are never
+ * launched when the HashReduce call that follows can evaluate them on the fly (the kernels of
+ * AresFusedFilterHashReduce below): the dimension and measure vectors of the batch's rows are then
+ * neither written nor read.  For that the pending work must survive the two things the Go host does
+ * between project() and reduce() (query/aql_batchexecutor.go:213-216): WaitForCudaStream, and
+ * DeviceFree of the batch's columns and of the index vector.  libmem.so therefore reports those
+ * events instead of flushing blindly:
+ *   on_wait   — the host waits for `stream`; libalgorithm.so keeps work pending only if nothing but
+ *               a later libalgorithm.so call can observe its results;
+ *   on_free   — returns 1 when not-yet-launched work still reads the block: libmem.so keeps the block
+ *               aside (not reusable) until AresMemReleaseHeld; frees of a pending OUTPUT launch the
+ *               work first;
+ *   on_access — a copy is about to touch [ptr, ptr + bytes): work whose inputs or outputs overlap
+ *               is launched first (also work that HashReduce had skipped: the skipped transforms
+ *               stay launchable until the next batch begins);
+ *   flush     — everything pending on the device is launched (all other entry points).
+ * A HashReduce that cannot use the pending work as it is (other aggregate, layout, joins, ...) simply
+ * launches it and proceeds as before.  ARES_FUSE=0 switches this stage off, ARES_DEFER=0 both. */
+typedef struct {
+  void (*flush)(int device);
+  void (*on_wait)(int device, void *stream);
+  int (*on_free)(int device, void *ptr, size_t bytes);
+  void (*on_access)(int device, const void *ptr, size_t bytes);
+} AresDeferralHooks;
+void AresMemSetDeferralHooks(const AresDeferralHooks *hooks); /* exported by libmem.so */
+void AresMemReleaseHeld(int device);                          /* exported by libmem.so */
+
 /* Fused batch execution: filter -> dimension / measure projection -> hash reduction of ONE batch in
  * a single pass over the source columns, without the index / predicate / dimension vectors the
  * one-call-per-AST-node ABI materialises in between (~145 B/row of HBM traffic on

@@ -1,5 +1,7 @@
 """Query-level replay: the Go batch executor's call sequence (aresdb_amd/executor.py) against
 every backend; results must agree with the oracle and, independently, with a numpy group-by."""
+import os
+
 import numpy as np
 import pytest
 
@@ -355,6 +357,94 @@ def test_fused_extension_declines_unsupported_plans():
     plan.use_fused_extension = False
     want, _ = smoke.run_query(H.oracle_backend(), plan, data)
     smoke.compare_results(got, want)
+
+
+# ---- second-stage fusion inside the unchanged ABI (include/ares_extensions.h) -------------------------
+def _kernels_of(hip, fn):
+    hip.profiler_enable(True)
+    try:
+        res = fn()
+        hip.wait()
+        return res, hip.profiler_report()
+    finally:
+        hip.profiler_enable(False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", range(4))
+@pytest.mark.parametrize("native", [True, False], ids=["cpp_driver", "python_mirror"])
+def test_pending_transforms_are_consumed_by_hash_reduce(variant, native):
+    """The Go call sequence, columns freed between project() and reduce(): the batch's dimension and
+    measure transforms never launch — HashReduce evaluates them on the fly — and the result is the
+    oracle's."""
+    hip = H.hip_backend()
+    rng = np.random.default_rng(300 + variant)
+    data = [smoke.synth_batch(rng, n, null_fraction=0.03) for n in (6000, 1, 45000, 300)]
+    plan = _fused_plan(variant, False)
+    run = smoke.run_query_native if native else smoke.run_query
+    (got, _), kernels = _kernels_of(hip, lambda: run(hip, plan, data))
+    want, _ = smoke.run_query(H.oracle_backend(), plan, data)
+    smoke.compare_results(got, want)
+    if os.environ.get("ARES_FUSE", "1") != "0" and os.environ.get("ARES_DEFER", "1") != "0":
+        assert "hr_fused_scan_kernel" in kernels, kernels
+        assert not any(k.startswith("transform_") for k in kernels), kernels
+
+
+@pytest.mark.gpu
+def test_skipped_transform_outputs_materialise_on_copy():
+    """A host that copies the INPUT dimension / measure vectors back after HashReduce (the Go host
+    never does) still sees what the transforms would have written: the skipped work is launched
+    before the copy."""
+    be, oracle = H.hip_backend(), H.oracle_backend()
+    rng = np.random.default_rng(8)
+    n = 20000
+    d1 = rng.integers(0, 100, n).astype(np.uint32)
+    ts = rng.integers(0, 86400 * 7, n).astype(np.uint32)
+    m = (rng.integers(0, 400, n) / 4).astype(np.float32)
+    valid = rng.random(n) > 0.05
+
+    def sequence(b, read_inputs):
+        cap = n + 10
+        cols = {"d1": H.Column(b, abi.Uint32, d1, valid=valid), "ts": H.Column(b, abi.Uint32, ts), "m": H.Column(b, abi.Float32, m)}
+        idx, pred = H.Buf(b, nbytes=4 * n), H.Buf(b, nbytes=n)
+        din, dout = H.DimVector(b, cap, (0, 0, 2, 0, 0), False, False), H.DimVector(b, cap, (0, 0, 2, 0, 0), False, False)
+        vin, vout = H.Buf(b, nbytes=8 * cap), H.Buf(b, nbytes=8 * cap)
+        b.call("InitIndexVector", idx.ptr, 0, n, None, 0)
+        kept = b.call("BinaryFilter", cols["d1"].input(), H.const_int(90), idx.ptr, pred.ptr, n, None, 0, None, 0, abi.LessThan, None, 0)
+        offs = din.dim_offsets()
+        b.call("BinaryTransform", cols["ts"].input(), H.const_int(3600),
+               H.dimension_output(din.values.ptr + offs[0][0], din.values.ptr + offs[0][1], abi.Uint32), idx.ptr, kept, None, 0,
+               abi.Floor, None, 0)
+        b.call("UnaryTransform", cols["d1"].input(),
+               H.dimension_output(din.values.ptr + offs[1][0], din.values.ptr + offs[1][1], abi.Uint32), idx.ptr, kept, None, 0,
+               abi.Noop, None, 0)
+        b.call("UnaryTransform", cols["m"].input(), H.measure_output(vin.ptr, abi.Float64, abi.AGGR_SUM_FLOAT), idx.ptr, kept,
+               None, 0, abi.Noop, None, 0)
+        b.wait()
+        for c in cols.values():  # cleanupBeforeAggregation: columns, index vector, predicate vector
+            c.free()
+        idx.free(), pred.free()
+        groups = b.call("HashReduce", din.struct(), vin.ptr, dout.struct(), vout.ptr, 8, kept, abi.AGGR_SUM_FLOAT, None, 0)
+        b.wait()
+        res = {"kept": kept, "groups": groups}
+        if read_inputs:
+            res["in_dims"] = din.values.read(np.uint8)
+            res["in_measures"] = vin.read(np.float64, kept)
+        rows = dout.rows(groups)
+        sums = vout.read(np.float64, groups)
+        res["map"] = {r: float(v) for r, v in zip(rows, sums)}
+        for x in (din, dout, vin, vout):
+            x.free()
+        return res
+
+    (got, kernels) = _kernels_of(be, lambda: sequence(be, True))
+    want = sequence(oracle, True)
+    assert got["kept"] == want["kept"] and got["groups"] == want["groups"]
+    assert got["map"] == want["map"]
+    assert np.array_equal(got["in_dims"], want["in_dims"])
+    assert np.array_equal(got["in_measures"], want["in_measures"])
+    if os.environ.get("ARES_FUSE", "1") != "0" and os.environ.get("ARES_DEFER", "1") != "0":
+        assert "hr_fused_scan_kernel" in kernels and any(k.startswith("transform_") for k in kernels), kernels
 
 
 @pytest.mark.gpu

@@ -456,13 +456,14 @@ __device__ __forceinline__ void partition_body(Source &src, const AggSpec &a, in
         sPartLocal[threadIdx.x] = before + incl - c;
         // the reservation's round trip (a returning global atomic, ~2 us) overlaps the staging below:
         // its result is only published to LDS right before the write-back needs it
-        if (c) reservedBase = atomicAdd(ws.cursors + threadIdx.x, c);
+        if (c) reservedBase = (ws.debug & 32) ? 0u : atomicAdd(ws.cursors + threadIdx.x, c);
         reserved = c != 0;
         sPartCount[threadIdx.x] = 0;
         if (threadIdx.x == static_cast<uint32_t>(numParts) - 1) sStaged = before + incl;
       }
     }
     __syncthreads();
+    if (ws.debug & 64) return;  // experiment: hash + count only
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       if ((alive >> j) & 1u) {
@@ -1038,7 +1039,10 @@ int fused_hash_reduce_run(const FusedPlanD &plan, int batchRows, const Dimension
   const int numParts = 1 << partBits;
   Workspace ws;
   ws.partBits = partBits;
-  ws.debug = 0;
+  {
+    const char *dbg = getenv("ARES_HR_DEBUG");  // timing experiments only
+    ws.debug = dbg ? atoi(dbg) : 0;
+  }
   ws.cap = ((2ull * (static_cast<uint64_t>(length) / numParts) + 2 * kSlots) | 63ull) + 18;
   const size_t headBytes = sizeof(uint32_t) * (numParts + 2);
   const size_t headPadded = (headBytes + 255) / 256 * 256;

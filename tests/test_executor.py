@@ -386,7 +386,7 @@ def test_pending_transforms_are_consumed_by_hash_reduce(variant, native):
     want, _ = smoke.run_query(H.oracle_backend(), plan, data)
     smoke.compare_results(got, want)
     if os.environ.get("ARES_FUSE", "1") != "0" and os.environ.get("ARES_DEFER", "1") != "0":
-        assert "hr_fused_scan_kernel" in kernels, kernels
+        assert any(k.startswith("hr_fused_scan_kernel") for k in kernels), kernels
         assert not any(k.startswith("transform_") for k in kernels), kernels
 
 
@@ -444,7 +444,8 @@ def test_skipped_transform_outputs_materialise_on_copy():
     assert np.array_equal(got["in_dims"], want["in_dims"])
     assert np.array_equal(got["in_measures"], want["in_measures"])
     if os.environ.get("ARES_FUSE", "1") != "0" and os.environ.get("ARES_DEFER", "1") != "0":
-        assert "hr_fused_scan_kernel" in kernels and any(k.startswith("transform_") for k in kernels), kernels
+        assert any(k.startswith("hr_fused_scan_kernel") for k in kernels), kernels
+        assert any(k.startswith("transform_") for k in kernels), kernels
 
 
 @pytest.mark.gpu

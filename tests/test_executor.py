@@ -449,6 +449,64 @@ def test_skipped_transform_outputs_materialise_on_copy():
 
 
 @pytest.mark.gpu
+def test_pending_transforms_that_do_not_match_are_launched():
+    """Pending transforms whose outputs are NOT the rows HashReduce is asked to reduce (here: they
+    target another dimension vector) are simply launched; HashReduce reduces what its arguments say."""
+    be, oracle = H.hip_backend(), H.oracle_backend()
+    rng = np.random.default_rng(12)
+    n = 9000
+    d1 = rng.integers(0, 50, n).astype(np.uint32)
+    m = (rng.integers(0, 400, n) / 4).astype(np.float32)
+    pre = rng.integers(0, 7, n).astype(np.uint32)
+
+    def sequence(b):
+        cap = n + 4
+        c1, cm = H.Column(b, abi.Uint32, d1), H.Column(b, abi.Float32, m)
+        idx, pred = H.Buf(b, nbytes=4 * n), H.Buf(b, nbytes=n)
+        other = H.DimVector(b, cap, (0, 0, 1, 0, 0), False, False)
+        blob = np.zeros(5 * cap, np.uint8)
+        blob[:4 * n] = pre.view(np.uint8)
+        blob[4 * cap:4 * cap + n] = 1
+        din = H.DimVector(b, cap, (0, 0, 1, 0, 0), False, False, init=blob)
+        dout = H.DimVector(b, cap, (0, 0, 1, 0, 0), False, False)
+        vin, vout = H.Buf(b, nbytes=8 * cap), H.Buf(b, nbytes=8 * cap)
+        b.call("InitIndexVector", idx.ptr, 0, n, None, 0)
+        kept = b.call("BinaryFilter", c1.input(), H.const_int(40), idx.ptr, pred.ptr, n, None, 0, None, 0, abi.LessThan, None, 0)
+        o = other.dim_offsets()
+        b.call("UnaryTransform", c1.input(), H.dimension_output(other.values.ptr + o[0][0], other.values.ptr + o[0][1], abi.Uint32),
+               idx.ptr, kept, None, 0, abi.Noop, None, 0)
+        b.call("UnaryTransform", cm.input(), H.measure_output(vin.ptr, abi.Float64, abi.AGGR_SUM_FLOAT), idx.ptr, kept, None, 0,
+               abi.Noop, None, 0)
+        b.wait()
+        groups = b.call("HashReduce", din.struct(), vin.ptr, dout.struct(), vout.ptr, 8, kept, abi.AGGR_SUM_FLOAT, None, 0)
+        b.wait()
+        res = {"kept": kept, "groups": groups, "other": other.values.read(np.uint8),
+               "map": {r: float(v) for r, v in zip(dout.rows(groups), vout.read(np.float64, groups))}}
+        for x in (c1, cm, idx, pred, other, din, dout, vin, vout):
+            x.free()
+        return res
+
+    got, want = sequence(be), sequence(oracle)
+    assert got["kept"] == want["kept"] and got["groups"] == want["groups"] == 7
+    assert got["map"] == want["map"]
+    assert np.array_equal(got["other"], want["other"])
+
+
+@pytest.mark.gpu
+def test_query_results_do_not_depend_on_the_fusion_switches():
+    """ARES_FUSE=0 (one launch per transform batch) and ARES_DEFER=0 (one launch per call) are read
+    once per process: the query-level tests are re-run in child processes with each of them."""
+    import subprocess
+    import sys
+    tests = ["tests/test_executor.py::test_c3_shape_matches_oracle", "tests/test_executor.py::test_native_driver_matches_python_executor",
+             "tests/test_executor.py::test_pending_transforms_are_consumed_by_hash_reduce"]
+    for env in ({"ARES_FUSE": "0"}, {"ARES_DEFER": "0"}):
+        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-k", "hip or cpp_driver or python_mirror", *tests],
+                           cwd=H.ROOT, env={**os.environ, **env}, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (env, r.stdout[-2000:], r.stderr[-1000:])
+
+
+@pytest.mark.gpu
 def test_concurrent_queries_on_two_streams():
     """Two queries at once from two host threads, each on its own stream (the Go host runs queries
     on separate goroutines and overlaps batch k+1's transfer with batch k's execution,

@@ -1,6 +1,7 @@
 """Filter / transform kernels alone on a 100 M-row resident column (BASELINE config C2 shape):
 per-kernel HIP-event time and the HBM traffic each call must move (development aid)."""
 import json, os, sys
+os.environ.setdefault("ARES_FUSE", "0")  # time every transform launch on its own (no second-stage fusion)
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from aresdb_amd import abi, workload

@@ -40,6 +40,7 @@ bool fuse_pending_into_hash_reduce(int device, hipStream_t stream, const Dimensi
                                    const DimensionVector &out, uint8_t *outValues, int valueBytes, int length, int aggFunc,
                                    int *groups);
 void invalidate_filter_journal(const uint32_t *indexVector);
+void flush_deferred_for_inputs(int device, const void *a, size_t aBytes, const void *b, size_t bBytes);
 
 // NOFLUSH: only for the transform entry points, which decide themselves whether to queue or flush
 #define ARES_ABI_BEGIN_NOFLUSH(device)                 \

@@ -142,7 +142,11 @@ extern "C" CGoCallResHandle HashReduce(DimensionVector inputKeys, uint8_t *input
     resHandle.res = int_result(fusedGroups);
     return resHandle;
   }
-  flush_deferred(device);
+  {  // launch what is pending; of the work an earlier HashReduce skipped only what this call reads
+    const DimLayoutD layout = make_dim_layout(inputKeys.NumDimsPerDimWidth);
+    flush_deferred_for_inputs(device, inputKeys.DimValues, static_cast<size_t>(layout.rowBytes) * inputKeys.VectorCapacity,
+                              inputValues, static_cast<size_t>(valueBytes) * (length > 0 ? length : 0));
+  }
   const AggSpec a = make_agg_spec(aggFunc, valueBytes);
   int groups = -1;
   if (length > 0 && hash_reduce_lds_supported(a) && !global_table_forced())

@@ -1102,7 +1102,9 @@ static void launch_init_index(uint32_t *indexVector, uint32_t start, int n, hipS
   ARES_LAUNCH("init_index_kernel", init_index_kernel, grid, kBlock, stream, indexVector, start, n);
 }
 
-void flush_deferred(int device) {
+// limboA/limboB: when given, only the skipped work whose outputs overlap these byte ranges is
+// launched (the caller reads nothing else); otherwise all of it
+static void flush_deferred_impl(int device, const ByteRange *limboA, const ByteRange *limboB) {
   std::lock_guard<std::mutex> lock(g_deferMutex);
   for (auto it = g_iotas.begin(); it != g_iotas.end();) {
     if (it->second.device == device) {
@@ -1118,8 +1120,22 @@ void flush_deferred(int device) {
       held = held || kv.second.overWait;
       launch_queue(kv.first.second, kv.second);
     }
-  held = materialize_limbo(device, nullptr) || held;
+  if (limboA) {
+    held = materialize_limbo(device, limboA) || held;
+    if (limboB) held = materialize_limbo(device, limboB) || held;
+  } else {
+    held = materialize_limbo(device, nullptr) || held;
+  }
   if (held && g_releaseHeld) g_releaseHeld(device);
+}
+
+void flush_deferred(int device) { flush_deferred_impl(device, nullptr, nullptr); }
+
+// for an entry point that reads exactly [a, a + aBytes) and [b, b + bBytes) of device memory
+void flush_deferred_for_inputs(int device, const void *a, size_t aBytes, const void *b, size_t bBytes) {
+  const ByteRange ra{static_cast<const uint8_t *>(a), static_cast<const uint8_t *>(a) + (aBytes ? aBytes : 1)};
+  const ByteRange rb{static_cast<const uint8_t *>(b), static_cast<const uint8_t *>(b) + (bBytes ? bBytes : 1)};
+  flush_deferred_impl(device, &ra, &rb);
 }
 
 // InitIndexVector opens a batch on the stream: what the previous batch's HashReduce skipped is dead

@@ -1411,6 +1411,19 @@ bool touches(const std::vector<ByteRange> &v, const ByteRange &r) {
     if (x.overlaps(r)) return true;
   return false;
 }
+// the index vector itself (its first n0 entries) or a column one of the journalled filters read
+bool journal_touched(const uint32_t *indexVector, const FilterJournal &j, const ByteRange &r, bool *indexOnly) {
+  const bool idx = range_of(indexVector, 4ull * (j.n0 > 0 ? j.n0 : 1)).overlaps(r);
+  bool cols = false;
+  for (size_t k = 0; k < j.filters.size(); k++) {
+    const FastOperands &f = j.filters[k];
+    cols = cols || range_of(f.vals, 4ull * j.colRows[k]).overlaps(r);
+    if (f.nulls) cols = cols || range_of(f.nulls, (static_cast<uint64_t>(j.colRows[k]) + f.bitOff + 7) / 8 + 2).overlaps(r);
+  }
+  if (indexOnly) *indexOnly = idx && !cols;
+  return idx || cols;
+}
+
 struct DeviceGuard {  // hooks run on libmem.so's threads: select the device, restore it afterwards
   int previous = -1;
   explicit DeviceGuard(int device) {
@@ -1474,11 +1487,13 @@ int hook_on_free(int device, void *ptr, size_t bytes) {
       it = (it->second.device == device && v.overlaps(r)) ? g_iotas.erase(it) : std::next(it);
     }
     for (auto it = g_journals.begin(); it != g_journals.end();) {
-      const bool dead = it->second.device == device && range_of(it->first, 4).overlaps(r);
-      bool pending = false;  // ... unless a kept queue still refers to it
+      // a journal dies with its index vector or with a column its filters read — unless a queue the
+      // host has already waited for still refers to it (then the block is held below, contents intact)
+      const bool dead = it->second.device == device && journal_touched(it->first, it->second, r, nullptr);
+      bool kept = false;
       if (dead)
-        for (auto &kv : g_pending) pending = pending || (kv.second.jobs.count && kv.second.idx == it->first);
-      it = (dead && !pending) ? g_journals.erase(it) : std::next(it);
+        for (auto &kv : g_pending) kept = kept || (kv.second.jobs.count && kv.second.overWait && kv.second.idx == it->first);
+      it = (dead && !kept) ? g_journals.erase(it) : std::next(it);
     }
     for (auto &kv : g_pending) {
       if (kv.first.first != device || kv.second.jobs.count == 0) continue;
@@ -1530,6 +1545,10 @@ void hook_on_access(int device, const void *ptr, size_t bytes) {
       }
     }
     release = materialize_limbo(device, &r) || release;
+    // a copy into an index vector or into a column a journalled filter has read: the survivors can
+    // no longer be re-derived (queues that depended on the journal were launched above)
+    for (auto it = g_journals.begin(); it != g_journals.end();)
+      it = (it->second.device == device && journal_touched(it->first, it->second, r, nullptr)) ? g_journals.erase(it) : std::next(it);
   } catch (std::exception &e) {
     fprintf(stderr, "Exception happened when handling a device copy: %s\n", e.what());
   }

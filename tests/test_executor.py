@@ -449,6 +449,45 @@ def test_skipped_transform_outputs_materialise_on_copy():
 
 
 @pytest.mark.gpu
+def test_filter_column_overwritten_before_reduce():
+    """The host overwrites the column a filter has read (a plain H2D copy into the same buffer) before
+    HashReduce: the survivors must still be those of the filter call, not a re-evaluation."""
+    be, oracle = H.hip_backend(), H.oracle_backend()
+    rng = np.random.default_rng(14)
+    n = 12000
+    x = rng.integers(0, 100, n).astype(np.uint32)
+    y = rng.integers(0, 30, n).astype(np.uint32)
+    m = rng.integers(0, 1000, n).astype(np.uint32)
+
+    def sequence(b):
+        cap = n + 8
+        cx, cy, cm = H.Column(b, abi.Uint32, x), H.Column(b, abi.Uint32, y), H.Column(b, abi.Uint32, m)
+        idx, pred = H.Buf(b, nbytes=4 * n), H.Buf(b, nbytes=n)
+        din, dout = H.DimVector(b, cap, (0, 0, 1, 0, 0), False, False), H.DimVector(b, cap, (0, 0, 1, 0, 0), False, False)
+        vin, vout = H.Buf(b, nbytes=8 * cap), H.Buf(b, nbytes=8 * cap)
+        b.call("InitIndexVector", idx.ptr, 0, n, None, 0)
+        kept = b.call("BinaryFilter", cx.input(), H.const_int(50), idx.ptr, pred.ptr, n, None, 0, None, 0, abi.LessThan, None, 0)
+        cx.buf.write(np.zeros(n, np.uint32), offset=cx.vp.BasePtr - cx.buf.ptr)  # every value would pass now
+        o = din.dim_offsets()
+        b.call("UnaryTransform", cy.input(), H.dimension_output(din.values.ptr + o[0][0], din.values.ptr + o[0][1], abi.Uint32),
+               idx.ptr, kept, None, 0, abi.Noop, None, 0)
+        b.call("UnaryTransform", cm.input(), H.measure_output(vin.ptr, abi.Int64, abi.AGGR_SUM_SIGNED), idx.ptr, kept, None, 0,
+               abi.Noop, None, 0)
+        b.wait()
+        groups = b.call("HashReduce", din.struct(), vin.ptr, dout.struct(), vout.ptr, 8, kept, abi.AGGR_SUM_SIGNED, None, 0)
+        b.wait()
+        res = {"kept": kept, "groups": groups,
+               "map": {r: int(v) for r, v in zip(dout.rows(groups), vout.read(np.int64, groups))}}
+        for t in (cx, cy, cm, idx, pred, din, dout, vin, vout):
+            t.free()
+        return res
+
+    got, want = sequence(be), sequence(oracle)
+    assert want["kept"] == int((x < 50).sum()) and want["groups"] == 30
+    assert got == want
+
+
+@pytest.mark.gpu
 def test_pending_transforms_that_do_not_match_are_launched():
     """Pending transforms whose outputs are NOT the rows HashReduce is asked to reduce (here: they
     target another dimension vector) are simply launched; HashReduce reduces what its arguments say."""

@@ -65,6 +65,20 @@ def test_libmem_exports_every_declared_symbol():
         assert getattr(lib, n) is not None
 
 
+def test_extension_symbols_are_exported_by_the_library_that_declares_them():
+    """include/ares_extensions.h: profiler, deferral hooks between the two libraries, fused entry point."""
+    algo, mem = _built()
+    src = open(os.path.join(ROOT, "include", "ares_extensions.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    declared = set(re.findall(r"^(?:void|size_t|CGoCallResHandle)\s+(\w+)\s*\(", src, flags=re.M))
+    in_mem = {"AresMemSetFlushHook", "AresMemSetDeferralHooks", "AresMemReleaseHeld"}
+    assert in_mem <= declared and {"AresFlushDeferred", "AresProfilerEnable", "AresProfilerReport",
+                                   "AresFusedFilterHashReduce"} <= declared
+    la, lm = C.CDLL(algo, mode=os.RTLD_NOW | os.RTLD_LOCAL), C.CDLL(mem, mode=os.RTLD_NOW | os.RTLD_LOCAL)
+    for n in declared:
+        assert getattr(lm if n in in_mem else la, n) is not None
+
+
 def test_libalgorithm_does_not_depend_on_libmem_or_oracle():
     """Either library can be swapped on its own, and the product never links test infrastructure."""
     algo, mem = _built()

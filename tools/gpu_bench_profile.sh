@@ -17,9 +17,14 @@ tail -c 3000 $OUT/bench_$TAG.json; tail -5 $OUT/bench_$TAG.err
 if [ "${SKIP_PROF:-0}" != "1" ]; then
   export TMPDIR=/tmp
   cd /tmp
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o trace -- python $R/bench.py --rows 2.5e8 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/prof_$TAG.log 2>&1; echo "rocprof exit $?"
-  find $OUT/prof_$TAG -name '*kernel_stats*' | head; 
-  f=$(find $OUT/prof_$TAG -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && head -20 $f
+  # the SAME command as the bench line above (defaults: 1e9 rows, 3 steps, 1 warm-up); the CPU baseline
+  # leg is skipped under the profiler (it launches nothing on the GPU)
+  timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o trace -- python $R/bench.py --rows $ROWS --no-cpu-baseline > $OUT/prof_$TAG.log 2>&1; echo "rocprof exit $?"
+  f=$(find $OUT/prof_$TAG -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && grep "ares::" $f | cut -c1-160 | head -12
   # keep only the summaries (the raw trace can be large)
   find $OUT/prof_$TAG -name '*kernel_trace.csv' -size +8M -delete
+fi
+if [ "${SKIP_CONFIGS:-0}" != "1" ]; then
+  cd $R
+  timeout 600 python tools/bench_configs.py c2 c4 hll geo 2>/dev/null | cut -c1-300
 fi

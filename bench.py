@@ -206,18 +206,24 @@ def main():
         for name, (launches, ms) in sorted(kernels.items(), key=lambda kv: -kv[1][1]):
             kern_out[name] = {"launches": launches, "avg_ms": ms / launches, "share": ms / tot_ms}
         dominant = max(kernels.items(), key=lambda kv: kv[1][1])
+    # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, corrected
+    # as MI355X_MICROARCH.md prescribes), when they were taken at this batch size
+    pmc_kernels = {}
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if pmc.get("rows_per_batch") == batch_rows:
+            pmc_kernels = pmc["kernels"]
+    except (OSError, ValueError, KeyError):
+        pass
+    for name, k in kern_out.items():  # measured traffic rate of every kernel (not the algorithmic roofline)
+        base = name.split("<")[0]
+        if base in pmc_kernels:
+            k["hbm_bytes_per_launch"] = pmc_kernels[base]["hbm_bytes_per_launch"]
+            k["hbm_GBps"] = k["hbm_bytes_per_launch"] / (k["avg_ms"] * 1e-3) / 1e9
     roofline = None
     if dominant:
         name, (launches, ms) = dominant
-        # HBM bytes per launch of that kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE /
-        # WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes), when they were taken at this batch size
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if pmc.get("rows_per_batch") == batch_rows and name in pmc["kernels"]:
-                traffic = pmc["kernels"][name]["hbm_bytes_per_launch"]
-        except (OSError, ValueError, KeyError):
-            pass
+        traffic = pmc_kernels.get(name.split("<")[0], {}).get("hbm_bytes_per_launch")
         achieved = bytes_per_row * total_rows_rank / (ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,

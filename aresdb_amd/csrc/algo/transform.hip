@@ -15,6 +15,7 @@
 #include <dlfcn.h>
 
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -1000,6 +1001,23 @@ std::map<const uint32_t *, FilterJournal> g_journals;
 std::map<std::pair<int, hipStream_t>, PendingQueue> g_limbo;
 void (*g_releaseHeld)(int) = nullptr;  // AresMemReleaseHeld of the sibling libmem.so
 
+// A fast filter has written the predicate vector and returned the survivor count, but the compaction
+// of its index vector has not run: when HashReduce re-derives the survivors from the filter journal
+// nobody ever reads the compacted vector.  Whatever does read it (a second filter, transforms that
+// are launched after all, a copy, any other entry point) runs the compaction first.
+struct PendingCompact {
+  int device;
+  hipStream_t stream;
+  uint32_t *idx;
+  const uint8_t *pred;
+  int n, pad, tiles;
+  bool virtualIdx;
+  std::shared_ptr<StreamBuffer> ws;  // [total, error, ticket ...][tile counts][tile offsets + 1][loaded]
+  unsigned int *ticket;
+  uint32_t *error, *tileOffsets, *loaded;
+};
+std::map<const uint32_t *, PendingCompact> g_compactions;
+
 // Index vectors that InitIndexVector has defined but not written yet ("virtual iota"): the fast
 // filter and transform kernels that consume them compute rows = position instead of loading 4 bytes
 // per row; any other use (every flush point) materialises them first.
@@ -1045,6 +1063,33 @@ bool defer_available() {
 }
 bool fuse_available() { return defer_available() && g_releaseHeld != nullptr; }
 
+// caller holds g_deferMutex and has selected the device: runs the pending compaction of `idx` (if
+// there is one) on the stream its filter ran on
+void run_compaction(const uint32_t *idx) {
+  auto it = g_compactions.find(idx);
+  if (it == g_compactions.end()) return;
+  const PendingCompact c = it->second;
+  g_compactions.erase(it);
+  CompactWorkspace cw;
+  cw.ticket = c.ticket;
+  cw.error = c.error;
+  cw.tileOffsets = c.tileOffsets;
+  cw.loaded = c.loaded;
+  const int cgrid = capped_grid((c.tiles + kTilesPerTicket - 1) / kTilesPerTicket, 256 * 8);
+  if (c.virtualIdx)
+    ARES_LAUNCH("filter_compact_kernel<iota>", (filter_compact_kernel<uint32_t, true>), cgrid, kBlock, c.stream, c.pred, c.idx, 0u,
+                c.pad, cw, c.n, c.tiles);
+  else
+    ARES_LAUNCH("filter_compact_kernel", (filter_compact_kernel<uint32_t, false>), cgrid, kBlock, c.stream, c.pred, c.idx, 0u,
+                c.pad, cw, c.n, c.tiles);
+  // (c.ws is released to the stream's cache when the last copy of the shared_ptr goes: behind the launch)
+}
+bool compaction_touches(const PendingCompact &c, const ByteRange &r) {
+  const ByteRange ri{reinterpret_cast<const uint8_t *>(c.idx), reinterpret_cast<const uint8_t *>(c.idx) + 4ull * c.n};
+  const ByteRange rp{c.pred, c.pred + c.n};
+  return ri.overlaps(r) || rp.overlaps(r);
+}
+
 // caller holds g_deferMutex and has selected the device.  inOrder: the launch is part of the
 // stream's own call sequence (a later call on the same stream follows); otherwise a queue the host
 // has already waited for is synchronised after its late launch.
@@ -1052,6 +1097,7 @@ void launch_queue(hipStream_t stream, PendingQueue &q, bool inOrder = false) {
   if (q.jobs.count == 0) return;
   const bool syncAfter = q.overWait && !inOrder;
   q.overWait = false;
+  if (q.idx) run_compaction(q.idx);  // the transforms read the compacted index vector
   const int64_t numQuads = (static_cast<int64_t>(q.n) + 3) / 4;
   const int64_t tiles = (numQuads + kBlock * kTQ - 1) / (kBlock * kTQ);
   if (q.jobs.count == 1) {
@@ -1114,6 +1160,12 @@ static void flush_deferred_impl(int device, const ByteRange *limboA, const ByteR
       ++it;
     }
   }
+  for (;;) {  // pending compactions: whoever comes next may read the index vector
+    auto c = g_compactions.begin();
+    while (c != g_compactions.end() && c->second.device != device) ++c;
+    if (c == g_compactions.end()) break;
+    run_compaction(c->first);
+  }
   bool held = false;
   for (auto &kv : g_pending)
     if (kv.first.first == device) {
@@ -1145,7 +1197,13 @@ static void begin_batch(int device, hipStream_t stream, const uint32_t *indexVec
   bool release = false;
   {
     std::lock_guard<std::mutex> lock(g_deferMutex);
-    release = g_limbo.erase({device, stream}) > 0;
+    auto lim = g_limbo.find({device, stream});
+    if (lim != g_limbo.end()) {  // the skipped work of the previous batch dies, and with it the compaction it would need
+      if (lim->second.idx) g_compactions.erase(lim->second.idx);
+      g_limbo.erase(lim);
+      release = true;
+    }
+    g_compactions.erase(indexVector);  // the vector is redefined
     FilterJournal j;
     j.device = device;
     j.stream = stream;
@@ -1177,6 +1235,18 @@ static void journal_filter(const uint32_t *indexVector, const FastOperands *f, u
 }
 
 void invalidate_filter_journal(const uint32_t *indexVector) { journal_filter(indexVector, nullptr, 0, 0); }
+
+static bool journal_is_valid(const uint32_t *indexVector) {
+  if (!fuse_available()) return false;
+  static const bool lazy = [] {
+    const char *e = getenv("ARES_LAZY_COMPACT");
+    return !(e && e[0] == '0');
+  }();
+  if (!lazy) return false;
+  std::lock_guard<std::mutex> lock(g_deferMutex);
+  auto it = g_journals.find(indexVector);
+  return it != g_journals.end() && it->second.valid;
+}
 
 // InitIndexVector: remember instead of writing (when the flush hook is in place)
 static bool defer_iota(int device, hipStream_t stream, uint32_t *indexVector, uint32_t start, int n) {
@@ -1317,8 +1387,8 @@ static int run_filter(const InputVector *ins, int arity, uint32_t *indexVector, 
     // layout: [total, error, tickets[passes], pad][tileCounts][tileOffsets + 1][loaded x passes]
     const size_t head = 64;
     const size_t words = static_cast<size_t>(tiles) * (2 + passes) + 1;
-    StreamBuffer wsBuf(head + 4 * words, stream);
-    uint32_t *w = wsBuf.as<uint32_t>();
+    auto wsBuf = std::make_shared<StreamBuffer>(head + 4 * words, stream);
+    uint32_t *w = wsBuf->as<uint32_t>();
     uint32_t *total = w, *error = w + 1;
     unsigned int *tickets = w + 2;
     uint32_t *tileCounts = w + 16, *tileOffsets = tileCounts + tiles, *loaded = tileOffsets + tiles + 1;
@@ -1328,6 +1398,29 @@ static int run_filter(const InputVector *ins, int arity, uint32_t *indexVector, 
     if (virtualIdx) f.idx = nullptr;  // rows = position
     ARES_LAUNCH("filter_pred_kernel", filter_pred_kernel, capped_grid(tiles, 256 * 16), kBlock, stream, f, pred, tileCounts, n, tiles);
     ARES_LAUNCH("filter_scan_kernel", filter_scan_kernel, 1, 1024, stream, tileCounts, tileOffsets, tiles, total);
+    if (numForeignTables == 0 && journal_is_valid(indexVector)) {
+      // The count is known; the compaction waits until somebody needs the compacted vector — a
+      // HashReduce that re-derives the survivors from the journal never does.
+      uint32_t result[2] = {0, 0};
+      read_back_u32(total, result, 2, stream);
+      PendingCompact c;
+      c.device = device;
+      c.stream = stream;
+      c.idx = indexVector;
+      c.pred = pred;
+      c.n = n;
+      c.pad = f.pad;
+      c.tiles = tiles;
+      c.virtualIdx = virtualIdx;
+      c.ws = wsBuf;
+      c.ticket = tickets;
+      c.error = error;
+      c.tileOffsets = tileOffsets;
+      c.loaded = loaded;
+      std::lock_guard<std::mutex> lock(g_deferMutex);
+      g_compactions[indexVector] = c;
+      return static_cast<int>(result[0]);
+    }
     const int cgrid = capped_grid((tiles + kTilesPerTicket - 1) / kTilesPerTicket, 256 * 8);
     if (virtualIdx) f.idx = nullptr;
     for (int pass = 0; pass < passes; pass++) {
@@ -1504,8 +1597,31 @@ int hook_on_free(int device, void *ptr, size_t bytes) {
         hold = true;
       }
     }
+    for (auto it = g_compactions.begin(); it != g_compactions.end();) {
+      if (it->second.device != device || !compaction_touches(it->second, r)) {
+        ++it;
+        continue;
+      }
+      // the index or predicate vector of a pending compaction is freed
+      const uint32_t *key = it->first;
+      bool waited = false, queued = false, skipped = false;
+      for (auto &kv : g_pending)
+        if (kv.second.jobs.count && kv.second.idx == key) (kv.second.overWait ? waited : queued) = true;
+      for (auto &kv : g_limbo) skipped = skipped || kv.second.idx == key;
+      if (waited || skipped) {  // still needed if that work is launched after all: keep the block intact
+        hold = true;
+        ++it;
+      } else if (queued) {  // transforms the host has not even waited for: run everything now
+        for (auto &kv : g_pending)
+          if (kv.second.jobs.count && kv.second.idx == key) launch_queue(kv.first.second, kv.second);
+        it = g_compactions.begin();  // (launch_queue erased the entry)
+      } else {  // nobody will read the compacted vector
+        it = g_compactions.erase(it);
+      }
+    }
     for (auto it = g_limbo.begin(); it != g_limbo.end();) {
       if (it->first.first == device && touches(it->second.writes, r)) {  // the skipped outputs die unseen
+        if (it->second.idx) g_compactions.erase(it->second.idx);
         it = g_limbo.erase(it);
         release = true;
       } else {
@@ -1545,6 +1661,16 @@ void hook_on_access(int device, const void *ptr, size_t bytes) {
       }
     }
     release = materialize_limbo(device, &r) || release;
+    for (auto it = g_compactions.begin(); it != g_compactions.end();) {
+      if (it->second.device == device && compaction_touches(it->second, r)) {
+        const hipStream_t cs = it->second.stream;
+        run_compaction(it->first);
+        hip_check(hipStreamSynchronize(cs), "hipStreamSynchronize");
+        it = g_compactions.begin();
+      } else {
+        ++it;
+      }
+    }
     // a copy into an index vector or into a column a journalled filter has read: the survivors can
     // no longer be re-derived (queues that depended on the journal were launched above)
     for (auto it = g_journals.begin(); it != g_journals.end();)

@@ -50,7 +50,11 @@ void AresMemSetFlushHook(void (*hook)(int device));      /* exported by libmem.s
  *               stay launchable until the next batch begins);
  *   flush     — everything pending on the device is launched (all other entry points).
  * A HashReduce that cannot use the pending work as it is (other aggregate, layout, joins, ...) simply
- * launches it and proceeds as before.  ARES_FUSE=0 switches this stage off, ARES_DEFER=0 both. */
+ * launches it and proceeds as before.  ARES_FUSE=0 switches this stage off, ARES_DEFER=0 both.
+ * The same bookkeeping lets a fast filter return its survivor count without compacting the index
+ * vector yet (the predicate vector is written): the compaction runs as soon as anything reads the
+ * vector — a second filter, transforms that are launched after all, a copy, any other entry point —
+ * and never when HashReduce re-derives the survivors itself.  ARES_LAZY_COMPACT=0 compacts at once. */
 typedef struct {
   void (*flush)(int device);
   void (*on_wait)(int device, void *stream);

@@ -517,11 +517,13 @@ def test_pending_transforms_that_do_not_match_are_launched():
         b.call("UnaryTransform", cm.input(), H.measure_output(vin.ptr, abi.Float64, abi.AGGR_SUM_FLOAT), idx.ptr, kept, None, 0,
                abi.Noop, None, 0)
         b.wait()
+        for x in (c1, cm, idx, pred):  # cleanupBeforeAggregation: the pending work still reads all four
+            x.free()
         groups = b.call("HashReduce", din.struct(), vin.ptr, dout.struct(), vout.ptr, 8, kept, abi.AGGR_SUM_FLOAT, None, 0)
         b.wait()
         res = {"kept": kept, "groups": groups, "other": other.values.read(np.uint8),
                "map": {r: float(v) for r, v in zip(dout.rows(groups), vout.read(np.float64, groups))}}
-        for x in (c1, cm, idx, pred, other, din, dout, vin, vout):
+        for x in (other, din, dout, vin, vout):
             x.free()
         return res
 
@@ -533,13 +535,14 @@ def test_pending_transforms_that_do_not_match_are_launched():
 
 @pytest.mark.gpu
 def test_query_results_do_not_depend_on_the_fusion_switches():
-    """ARES_FUSE=0 (one launch per transform batch) and ARES_DEFER=0 (one launch per call) are read
-    once per process: the query-level tests are re-run in child processes with each of them."""
+    """ARES_FUSE=0 (one launch per transform batch), ARES_DEFER=0 (one launch per call) and
+    ARES_LAZY_COMPACT=0 (filters compact their index vector at once) are read once per process: the
+    query-level tests are re-run in child processes with each of them."""
     import subprocess
     import sys
     tests = ["tests/test_executor.py::test_c3_shape_matches_oracle", "tests/test_executor.py::test_native_driver_matches_python_executor",
              "tests/test_executor.py::test_pending_transforms_are_consumed_by_hash_reduce"]
-    for env in ({"ARES_FUSE": "0"}, {"ARES_DEFER": "0"}):
+    for env in ({"ARES_FUSE": "0"}, {"ARES_DEFER": "0"}, {"ARES_LAZY_COMPACT": "0"}):
         r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-k", "hip or cpp_driver or python_mirror", *tests],
                            cwd=H.ROOT, env={**os.environ, **env}, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, (env, r.stdout[-2000:], r.stderr[-1000:])

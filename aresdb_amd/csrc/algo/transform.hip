@@ -999,7 +999,18 @@ std::map<const uint32_t *, FilterJournal> g_journals;
 // launchable (their inputs are held by libmem.so) until the stream starts its next batch or the
 // outputs are freed; a copy that touches an output launches them first.
 std::map<std::pair<int, hipStream_t>, PendingQueue> g_limbo;
-void (*g_releaseHeld)(int) = nullptr;  // AresMemReleaseHeld of the sibling libmem.so
+void (*g_releaseHeld)(int, uintptr_t) = nullptr;  // AresMemReleaseHeld of the sibling libmem.so
+// Blocks are held on behalf of ONE stream's pending work: the tag names that stream, so that one
+// query's progress never releases what another query's not-yet-launched kernels still read.
+uintptr_t hold_tag(hipStream_t stream) { return reinterpret_cast<uintptr_t>(stream) + 1; }
+struct ReleaseSet {
+  std::vector<uintptr_t> tags;
+  void add(hipStream_t s) { tags.push_back(hold_tag(s)); }
+  void run(int device) const {
+    if (g_releaseHeld)
+      for (uintptr_t t : tags) g_releaseHeld(device, t);
+  }
+};
 
 // A fast filter has written the predicate vector and returned the survivor count, but the compaction
 // of its index vector has not run: when HashReduce re-derives the survivors from the filter journal
@@ -1030,7 +1041,7 @@ struct PendingIota {
 std::map<uint32_t *, PendingIota> g_iotas;
 
 void hook_on_wait(int device, void *stream);
-int hook_on_free(int device, void *ptr, size_t bytes);
+uintptr_t hook_on_free(int device, void *ptr, size_t bytes);
 void hook_on_access(int device, const void *ptr, size_t bytes);
 
 // registers the flush hook with the sibling libmem.so; false = deferral is off for this process
@@ -1051,7 +1062,7 @@ bool defer_available() {
     // second stage (optional: an older libmem.so only knows the flush hook)
     const char *fuse = getenv("ARES_FUSE");
     auto setHooks = reinterpret_cast<void (*)(const AresDeferralHooks *)>(dlsym(h, "AresMemSetDeferralHooks"));
-    auto release = reinterpret_cast<void (*)(int)>(dlsym(h, "AresMemReleaseHeld"));
+    auto release = reinterpret_cast<void (*)(int, uintptr_t)>(dlsym(h, "AresMemReleaseHeld"));
     if (setHooks && release && !(fuse && fuse[0] == '0')) {
       static const AresDeferralHooks hooks = {&AresFlushDeferred, &hook_on_wait, &hook_on_free, &hook_on_access};
       g_releaseHeld = release;
@@ -1119,7 +1130,7 @@ void launch_queue(hipStream_t stream, PendingQueue &q, bool inOrder = false) {
 
 // caller holds g_deferMutex.  Launches the skipped transforms of every limbo entry of the device
 // (all = true) or of those whose outputs overlap `range`, and forgets the entries.
-bool materialize_limbo(int device, const ByteRange *range) {
+bool materialize_limbo(int device, const ByteRange *range, ReleaseSet *released) {
   bool any = false;
   for (auto it = g_limbo.begin(); it != g_limbo.end();) {
     bool hit = it->first.first == device;
@@ -1130,6 +1141,7 @@ bool materialize_limbo(int device, const ByteRange *range) {
     if (hit) {
       it->second.overWait = true;  // the host believes this work is long done
       launch_queue(it->first.second, it->second);
+      if (released) released->add(it->first.second);
       it = g_limbo.erase(it);
       any = true;
     } else {
@@ -1166,19 +1178,19 @@ static void flush_deferred_impl(int device, const ByteRange *limboA, const ByteR
     if (c == g_compactions.end()) break;
     run_compaction(c->first);
   }
-  bool held = false;
+  ReleaseSet released;
   for (auto &kv : g_pending)
     if (kv.first.first == device) {
-      held = held || kv.second.overWait;
+      if (kv.second.overWait && kv.second.jobs.count) released.add(kv.first.second);
       launch_queue(kv.first.second, kv.second);
     }
   if (limboA) {
-    held = materialize_limbo(device, limboA) || held;
-    if (limboB) held = materialize_limbo(device, limboB) || held;
+    materialize_limbo(device, limboA, &released);
+    if (limboB) materialize_limbo(device, limboB, &released);
   } else {
-    held = materialize_limbo(device, nullptr) || held;
+    materialize_limbo(device, nullptr, &released);
   }
-  if (held && g_releaseHeld) g_releaseHeld(device);
+  released.run(device);
 }
 
 void flush_deferred(int device) { flush_deferred_impl(device, nullptr, nullptr); }
@@ -1212,7 +1224,7 @@ static void begin_batch(int device, hipStream_t stream, const uint32_t *indexVec
     j.valid = true;
     g_journals[indexVector] = j;
   }
-  if (release) g_releaseHeld(device);
+  if (release) g_releaseHeld(device, hold_tag(stream));
 }
 
 // a fast filter has compacted `indexVector` (f == nullptr: something else has — forget the journal)
@@ -1568,10 +1580,12 @@ void hook_on_wait(int device, void *streamPtr) {
   }
 }
 
-// DeviceFree: 1 = keep the block aside, pending (or skipped) work still reads it
-int hook_on_free(int device, void *ptr, size_t bytes) {
+// DeviceFree: nonzero = keep the block aside on behalf of that stream's pending (or skipped) work,
+// which still reads it (the value is the tag AresMemReleaseHeld will be called with)
+uintptr_t hook_on_free(int device, void *ptr, size_t bytes) {
   const ByteRange r = range_of(ptr, bytes);
-  bool hold = false, release = false;
+  uintptr_t hold = 0;
+  ReleaseSet released;
   try {
     DeviceGuard guard(device);
     std::lock_guard<std::mutex> lock(g_deferMutex);
@@ -1591,10 +1605,15 @@ int hook_on_free(int device, void *ptr, size_t bytes) {
     for (auto &kv : g_pending) {
       if (kv.first.first != device || kv.second.jobs.count == 0) continue;
       if (touches(kv.second.writes, r)) {
-        release = release || kv.second.overWait;
+        released.add(kv.first.second);
         launch_queue(kv.first.second, kv.second);  // an output is freed: run the work, the fence follows it
       } else if (touches(kv.second.reads, r)) {
-        hold = true;
+        if (kv.second.overWait) {
+          hold = hold_tag(kv.first.second);
+        } else {  // not even waited for: run it now, the free is fenced behind it
+          released.add(kv.first.second);
+          launch_queue(kv.first.second, kv.second);
+        }
       }
     }
     for (auto it = g_compactions.begin(); it != g_compactions.end();) {
@@ -1604,16 +1623,20 @@ int hook_on_free(int device, void *ptr, size_t bytes) {
       }
       // the index or predicate vector of a pending compaction is freed
       const uint32_t *key = it->first;
+      const hipStream_t owner = it->second.stream;
       bool waited = false, queued = false, skipped = false;
       for (auto &kv : g_pending)
         if (kv.second.jobs.count && kv.second.idx == key) (kv.second.overWait ? waited : queued) = true;
       for (auto &kv : g_limbo) skipped = skipped || kv.second.idx == key;
       if (waited || skipped) {  // still needed if that work is launched after all: keep the block intact
-        hold = true;
+        hold = hold_tag(owner);
         ++it;
       } else if (queued) {  // transforms the host has not even waited for: run everything now
         for (auto &kv : g_pending)
-          if (kv.second.jobs.count && kv.second.idx == key) launch_queue(kv.first.second, kv.second);
+          if (kv.second.jobs.count && kv.second.idx == key) {
+            released.add(kv.first.second);
+            launch_queue(kv.first.second, kv.second);
+          }
         it = g_compactions.begin();  // (launch_queue erased the entry)
       } else {  // nobody will read the compacted vector
         it = g_compactions.erase(it);
@@ -1622,24 +1645,24 @@ int hook_on_free(int device, void *ptr, size_t bytes) {
     for (auto it = g_limbo.begin(); it != g_limbo.end();) {
       if (it->first.first == device && touches(it->second.writes, r)) {  // the skipped outputs die unseen
         if (it->second.idx) g_compactions.erase(it->second.idx);
+        released.add(it->first.second);
         it = g_limbo.erase(it);
-        release = true;
       } else {
-        if (it->first.first == device && touches(it->second.reads, r)) hold = true;
+        if (it->first.first == device && touches(it->second.reads, r)) hold = hold_tag(it->first.second);
         ++it;
       }
     }
   } catch (std::exception &e) {
     fprintf(stderr, "Exception happened when handling a device free: %s\n", e.what());
   }
-  if (release && g_releaseHeld) g_releaseHeld(device);
-  return hold ? 1 : 0;
+  released.run(device);
+  return hold;
 }
 
 // a copy is about to touch [ptr, ptr + bytes)
 void hook_on_access(int device, const void *ptr, size_t bytes) {
   const ByteRange r = range_of(ptr, bytes);
-  bool release = false;
+  ReleaseSet released;
   try {
     DeviceGuard guard(device);
     std::lock_guard<std::mutex> lock(g_deferMutex);
@@ -1656,11 +1679,11 @@ void hook_on_access(int device, const void *ptr, size_t bytes) {
     for (auto &kv : g_pending) {
       if (kv.first.first != device || kv.second.jobs.count == 0) continue;
       if (touches(kv.second.writes, r) || touches(kv.second.reads, r)) {
-        release = release || kv.second.overWait;
+        released.add(kv.first.second);
         launch_queue(kv.first.second, kv.second);
       }
     }
-    release = materialize_limbo(device, &r) || release;
+    materialize_limbo(device, &r, &released);
     for (auto it = g_compactions.begin(); it != g_compactions.end();) {
       if (it->second.device == device && compaction_touches(it->second, r)) {
         const hipStream_t cs = it->second.stream;
@@ -1678,7 +1701,7 @@ void hook_on_access(int device, const void *ptr, size_t bytes) {
   } catch (std::exception &e) {
     fprintf(stderr, "Exception happened when handling a device copy: %s\n", e.what());
   }
-  if (release && g_releaseHeld) g_releaseHeld(device);
+  released.run(device);
 }
 }  // namespace
 
@@ -1793,9 +1816,8 @@ bool fuse_pending_into_hash_reduce(int device, hipStream_t stream, const Dimensi
       }
     }
     if (!ok) {  // the ordinary path: the pending work runs now, ahead of this call on the same stream
-      const bool release = pq.overWait;
       launch_queue(stream, pq, /*inOrder=*/true);
-      if (release) g_releaseHeld(device);
+      g_releaseHeld(device, hold_tag(stream));
       return false;
     }
     q = pq;  // taken out of the queue: nobody else launches it
@@ -1811,7 +1833,7 @@ bool fuse_pending_into_hash_reduce(int device, hipStream_t stream, const Dimensi
   if (result < 0) {  // a partition region overflowed: materialise the inputs after all
     launch_queue(stream, q, /*inOrder=*/true);
     lock.unlock();
-    g_releaseHeld(device);
+    g_releaseHeld(device, hold_tag(stream));
     return false;
   }
   g_limbo[{device, stream}] = q;  // launchable until the next batch begins (begin_batch)

@@ -90,11 +90,11 @@ inline void notify_access_current(const void *ptr, size_t bytes) {
   if (hipGetDevice(&device) == hipSuccess) notify_access(device, ptr, bytes);
 }
 // the host frees a block: true = work that has not been launched yet still reads it, keep it aside
-inline bool notify_free(int device, void *ptr, size_t bytes) {
+inline uintptr_t notify_free(int device, void *ptr, size_t bytes) {
   const AresDeferralHooks *h = g_hooks.load(std::memory_order_acquire);
-  if (h && h->on_free) return h->on_free(device, ptr, bytes) != 0;
+  if (h && h->on_free) return h->on_free(device, ptr, bytes);
   flush_pending(device);
-  return false;
+  return 0;
 }
 
 bool use_pool() {
@@ -134,7 +134,8 @@ struct DeviceState {
   std::unordered_map<void *, size_t> live;               // allocation -> rounded size
   std::vector<hipEvent_t> freeEvents;
   size_t parkedBytes = 0;
-  std::vector<void *> held;  // freed by the host while deferred work still reads them (AresMemReleaseHeld)
+  // freed by the host while deferred work of one stream (the tag) still reads them (AresMemReleaseHeld)
+  std::vector<std::pair<void *, uintptr_t>> held;
 };
 DeviceState g_devices[kMaxDevices];
 
@@ -294,13 +295,21 @@ void AresMemSetDeferralHooks(const AresDeferralHooks *hooks) {
 
 // The work that was reading the held blocks has been launched (or dropped): fence them like any
 // other free — the fence is recorded now, behind that work.
-void AresMemReleaseHeld(int device) {
+void AresMemReleaseHeld(int device, uintptr_t tag) {
   if (device < 0 || device >= kMaxDevices) return;
   DeviceState *st = &g_devices[device];
   std::vector<void *> blocks;
   {
     std::lock_guard<std::mutex> lock(st->mu);
-    blocks.swap(st->held);
+    for (size_t i = 0; i < st->held.size();) {
+      if (tag == 0 || st->held[i].second == tag) {
+        blocks.push_back(st->held[i].first);
+        st->held[i] = st->held.back();
+        st->held.pop_back();
+      } else {
+        i++;
+      }
+    }
   }
   if (blocks.empty()) return;
   int current = 0;
@@ -403,9 +412,9 @@ size_t allocation_size(DeviceState *st, void *p) {
 
 hipError_t free_or_hold(DeviceState *st, void *p, int device) {
   if (p == nullptr) return hipSuccess;
-  if (notify_free(device, p, allocation_size(st, p))) {
+  if (const uintptr_t tag = notify_free(device, p, allocation_size(st, p))) {
     std::lock_guard<std::mutex> lock(st->mu);
-    st->held.push_back(p);
+    st->held.emplace_back(p, tag);
     return hipSuccess;
   }
   return pool_free(st, p);

@@ -5,6 +5,7 @@
 #define ARES_EXTENSIONS_H_
 
 #include <stddef.h>
+#include <stdint.h>
 
 #include "ares_algorithm.h"
 
@@ -42,9 +43,10 @@ void AresMemSetFlushHook(void (*hook)(int device));      /* exported by libmem.s
  * events instead of flushing blindly:
  *   on_wait   — the host waits for `stream`; libalgorithm.so keeps work pending only if nothing but
  *               a later libalgorithm.so call can observe its results;
- *   on_free   — returns 1 when not-yet-launched work still reads the block: libmem.so keeps the block
- *               aside (not reusable) until AresMemReleaseHeld; frees of a pending OUTPUT launch the
- *               work first;
+ *   on_free   — returns a non-zero tag (it names the stream whose work it is) when not-yet-launched work
+ *               still reads the block: libmem.so keeps the block aside (not reusable) until
+ *               AresMemReleaseHeld is called with that tag; frees of a pending OUTPUT launch the work
+ *               first;
  *   on_access — a copy is about to touch [ptr, ptr + bytes): work whose inputs or outputs overlap
  *               is launched first (also work that HashReduce had skipped: the skipped transforms
  *               stay launchable until the next batch begins);
@@ -58,11 +60,11 @@ void AresMemSetFlushHook(void (*hook)(int device));      /* exported by libmem.s
 typedef struct {
   void (*flush)(int device);
   void (*on_wait)(int device, void *stream);
-  int (*on_free)(int device, void *ptr, size_t bytes);
+  uintptr_t (*on_free)(int device, void *ptr, size_t bytes);
   void (*on_access)(int device, const void *ptr, size_t bytes);
 } AresDeferralHooks;
 void AresMemSetDeferralHooks(const AresDeferralHooks *hooks); /* exported by libmem.so */
-void AresMemReleaseHeld(int device);                          /* exported by libmem.so */
+void AresMemReleaseHeld(int device, uintptr_t tag);           /* exported by libmem.so; tag 0 = every held block */
 
 /* Fused batch execution: filter -> dimension / measure projection -> hash reduction of ONE batch in
  * a single pass over the source columns, without the index / predicate / dimension vectors the

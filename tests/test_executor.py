@@ -549,6 +549,38 @@ def test_query_results_do_not_depend_on_the_fusion_switches():
 
 
 @pytest.mark.gpu
+def test_concurrent_fused_queries_on_four_streams():
+    """Four hash-path queries at once, each on its own stream and host thread: the filter journals,
+    pending queues, held blocks and skipped work of one stream must never leak into another's."""
+    import threading
+    hip = H.hip_backend()
+    rng = np.random.default_rng(91)
+    nq = 4
+    datasets = [[smoke.synth_batch(rng, 60000 + 7000 * q, null_fraction=0.02) for _ in range(5)] for q in range(nq)]
+    plans = [_fused_plan(q % 4, False) for q in range(nq)]
+    want = [smoke.run_query(H.oracle_backend(), plans[q], datasets[q])[0] for q in range(nq)]
+    streams = [hip.call("CreateCudaStream", 0) for _ in range(nq)]
+    for attempt in range(3):
+        got, errs = [None] * nq, []
+
+        def work(q):
+            try:
+                got[q] = smoke.run_query_native(hip, plans[q], datasets[q], stream=streams[q])[0]
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+        threads = [threading.Thread(target=work, args=(q,)) for q in range(nq)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errs, errs
+        for q in range(nq):
+            smoke.compare_results(got[q], want[q])
+    for s_ in streams:
+        hip.call("DestroyCudaStream", s_, 0)
+
+
+@pytest.mark.gpu
 def test_concurrent_queries_on_two_streams():
     """Two queries at once from two host threads, each on its own stream (the Go host runs queries
     on separate goroutines and overlaps batch k+1's transfer with batch k's execution,

@@ -1,0 +1,185 @@
+"""Verification helpers for BASELINE config C3 — used by bench.py (outside the timed region) and by
+the GPU tests, never by the product path.
+
+`exact_groups` is an independent exact group-by of the synthetic shard (torch, dense accumulation
+over the small key space of C3); `predict_hash_merges` applies the reference's group identity —
+HashReduce identifies a group by the 32-bit murmur3 of its packed dimension row
+(query/hash_reduction.cu:216-243, query/utils.cu:113-155), so distinct rows with equal hashes form
+ONE group whose dimensions are those of its first row — and `compare_result` checks a fetched
+result against that, key by key: group count, every (dimension row -> sum) and every representative.
+"""
+import numpy as np
+import torch
+
+# radices of the dense key code: value range + 1 slot for "null"
+_R_TS, _R_D1, _R_D2, _R_D3 = 169, 101, 51, 3
+KEY_SPACE = _R_TS * _R_D1 * _R_D2 * _R_D3
+
+
+def _rotl(x, r):
+    return ((x << np.uint32(r)) | (x >> np.uint32(32 - r))).astype(np.uint32)
+
+
+def murmur3_32_rows(values, valids):
+    """murmur3_x86_32 (seed 0) of the packed dimension rows [v0..v3 little-endian uint32][validity
+    bytes] — 4 x 4 + 4 = 20 bytes (query/utils.cu:113-155, query/hash_reduction.cu:216-243)."""
+    assert len(values) == 4 and len(valids) == 4
+    c1, c2 = np.uint32(0xcc9e2d51), np.uint32(0x1b873593)
+    h = np.zeros(len(values[0]), np.uint32)
+    tail = np.zeros(len(values[0]), np.uint32)
+    for d, v in enumerate(valids):
+        tail |= (v.astype(np.uint32) & np.uint32(0xFF)) << np.uint32(8 * d)
+    with np.errstate(over="ignore"):
+        for k in [v.astype(np.uint32) for v in values] + [tail]:
+            k = (k * c1).astype(np.uint32)
+            k = (_rotl(k, 15) * c2).astype(np.uint32)
+            h ^= k
+            h = (_rotl(h, 13) * np.uint32(5) + np.uint32(0xe6546b64)).astype(np.uint32)
+        h ^= np.uint32(20)
+        h ^= h >> np.uint32(16)
+        h = (h * np.uint32(0x85ebca6b)).astype(np.uint32)
+        h ^= h >> np.uint32(13)
+        h = (h * np.uint32(0xc2b2ae35)).astype(np.uint32)
+        h ^= h >> np.uint32(16)
+    return h
+
+
+def _codes_of_batch(b, limit=None):
+    """dense key code, keep mask and float64 measure of every row of one C3 batch (torch, on the
+    batch's device); a null dimension is its own key slot, a null measure contributes 0."""
+    def col(name):
+        rc = b[name]
+        n = rc.length if limit is None else min(limit, rc.length)
+        v = rc.values()[:n]
+        ok = rc.valid()
+        return v, (None if ok is None else ok[:n])
+    ts, tsv = col("ts")
+    d1, d1v = col("d1")
+    d2, d2v = col("d2")
+    d3, d3v = col("d3")
+    m, mv = col("m")
+    tsb = torch.div(ts, 3600, rounding_mode="floor").to(torch.int64)
+    keep = d1 < 90
+    if d1v is not None:
+        keep &= d1v
+    def code(v, ok, null_code):
+        v = v.to(torch.int64)
+        return v if ok is None else torch.where(ok, v, torch.full_like(v, null_code))
+    c = ((code(tsb, tsv, _R_TS - 1) * _R_D1 + code(d1, d1v, _R_D1 - 1)) * _R_D2 + code(d2, d2v, _R_D2 - 1)) * _R_D3 \
+        + code(d3, d3v, _R_D3 - 1)
+    mm = m.to(torch.float64)
+    if mv is not None:
+        mm = torch.where(mv, mm, torch.zeros_like(mm))
+    return c, keep, mm
+
+
+def exact_groups(batches, limit_first_batch=None):
+    """Exact group-by of the C3 query over `batches` (all rows, or the first `limit_first_batch` rows
+    of the first batch only).  Returns numpy arrays (code, sum, first_row, rows) of the groups."""
+    dev = batches[0]["m"].blob.device
+    acc = torch.zeros(KEY_SPACE, dtype=torch.float64, device=dev)
+    cnt = torch.zeros(KEY_SPACE, dtype=torch.int64, device=dev)
+    first = torch.full((KEY_SPACE,), torch.iinfo(torch.int64).max, dtype=torch.int64, device=dev)
+    offset = 0
+    for b in (batches[:1] if limit_first_batch is not None else batches):
+        c, keep, mm = _codes_of_batch(b, limit_first_batch)
+        idx = c[keep]
+        acc.index_add_(0, idx, mm[keep])
+        cnt.index_add_(0, idx, torch.ones_like(idx))
+        rows = torch.arange(offset, offset + c.numel(), dtype=torch.int64, device=dev)[keep]
+        first.scatter_reduce_(0, idx, rows, reduce="amin", include_self=True)
+        offset += c.numel()
+        del c, keep, mm, idx, rows
+    live = torch.nonzero(cnt > 0).reshape(-1)
+    return (live.cpu().numpy(), acc[live].cpu().numpy(), first[live].cpu().numpy(), cnt[live].cpu().numpy())
+
+
+def decode_codes(code):
+    """(values[4], valids[4]) of dense key codes, as the dimension vector stores them: a null
+    dimension holds value 0 with validity 0 (the synthetic columns keep zeros under nulls)."""
+    c = code.astype(np.int64)
+    d3 = c % _R_D3; c //= _R_D3
+    d2 = c % _R_D2; c //= _R_D2
+    d1 = c % _R_D1; c //= _R_D1
+    ts = c
+    out_v, out_ok = [], []
+    for v, null_code, scale in ((ts, _R_TS - 1, 3600), (d1, _R_D1 - 1, 1), (d2, _R_D2 - 1, 1), (d3, _R_D3 - 1, 1)):
+        ok = v != null_code
+        out_v.append(np.where(ok, v * scale, 0).astype(np.uint32))
+        out_ok.append(ok.astype(np.uint8))
+    return out_v, out_ok
+
+
+def encode_rows(values, valids):
+    """dense key codes of fetched dimension rows (inverse of decode_codes)."""
+    ts, d1, d2, d3 = [np.asarray(v).view(np.uint32).astype(np.int64) for v in values]
+    oks = [np.asarray(v).astype(bool) for v in valids]
+    tsc = np.where(oks[0], ts // 3600, _R_TS - 1)
+    d1c = np.where(oks[1], d1, _R_D1 - 1)
+    d2c = np.where(oks[2], d2, _R_D2 - 1)
+    d3c = np.where(oks[3], d3, _R_D3 - 1)
+    return ((tsc * _R_D1 + d1c) * _R_D2 + d2c) * _R_D3 + d3c
+
+
+def predict_hash_merges(code, sums, first_row):
+    """Groups as HashReduce forms them: one per distinct 32-bit hash; representative = the member
+    whose first row comes first; value = sum over the members."""
+    values, valids = decode_codes(code)
+    h = murmur3_32_rows(values, valids)
+    order = np.lexsort((first_row, h))
+    hs = h[order]
+    head = np.ones(len(hs), bool)
+    head[1:] = hs[1:] != hs[:-1]
+    seg = np.cumsum(head) - 1
+    merged_sum = np.zeros(int(seg[-1]) + 1 if len(seg) else 0, np.float64)
+    np.add.at(merged_sum, seg, sums[order])
+    rep_code = code[order][head]
+    return rep_code, merged_sum, int(len(code) - len(rep_code))
+
+
+def compare_tables(got_code, got_sum, want_code, want_sum, rel=0.0):
+    """None when the two group tables hold the same keys with the same sums, else a description."""
+    if len(got_code) != len(want_code):
+        return f"group count {len(got_code)} != expected {len(want_code)}"
+    go, wo = np.argsort(got_code, kind="stable"), np.argsort(want_code, kind="stable")
+    gc, wc = got_code[go], want_code[wo]
+    if len(gc) > 1 and (gc[1:] == gc[:-1]).any():
+        return "duplicate dimension rows in the result"
+    bad = np.nonzero(gc != wc)[0]
+    if len(bad):
+        return f"{len(bad)} dimension rows differ (first: got code {gc[bad[0]]}, expected {wc[bad[0]]})"
+    gs, ws = got_sum[go], want_sum[wo]
+    tol = rel * np.maximum(1.0, np.abs(ws))
+    bad = np.nonzero(np.abs(gs - ws) > tol)[0]
+    if len(bad):
+        return f"{len(bad)} sums differ (first: key {gc[bad[0]]} got {gs[bad[0]]!r} expected {ws[bad[0]]!r})"
+    return None
+
+
+def compare_result(fetched, expected, hash_identity=True, rel=0.0):
+    """fetched = (dims, valids, measures) of NativeQuery.fetch(); expected = exact_groups(...).
+    hash_identity: the result comes from HashReduce (groups are hashes); False: Sort+Reduce on the
+    64-bit hash (exact groups at these cardinalities).  Returns a report dict."""
+    dims, valids, meas = fetched
+    code, sums, first_row, _ = expected
+    got_code = encode_rows([np.frombuffer(d, np.uint32) for d in dims], [np.frombuffer(v, np.uint8) for v in valids])
+    got_sum = np.frombuffer(meas, np.float64)
+    merged = 0
+    if hash_identity:
+        want_code, want_sum, merged = predict_hash_merges(code, sums, first_row)
+    else:
+        want_code, want_sum = code, sums
+    why = compare_tables(got_code, got_sum, want_code, want_sum, rel)
+    return {"status": "ok" if why is None else "MISMATCH: " + why, "groups": int(len(got_code)),
+            "expected_groups": int(len(want_code)), "distinct_dimension_rows": int(len(code)),
+            "merged_by_32bit_hash": merged}
+
+
+def fetched_from_columnar(dims, measures, size, capacity, nd=4):
+    """(dims, valids, measures) in NativeQuery.fetch() form from a device-layout dimension vector of
+    nd 4-byte dimensions (values per dimension with stride `capacity`, then validity bytes) and a
+    float64 measure vector."""
+    dims = np.asarray(dims, np.uint8)
+    values = [dims[4 * capacity * d: 4 * capacity * d + 4 * size].copy() for d in range(nd)]
+    valids = [dims[4 * capacity * nd + capacity * d: 4 * capacity * nd + capacity * d + size].copy() for d in range(nd)]
+    return values, valids, np.asarray(measures, np.uint8)[:8 * size].copy()

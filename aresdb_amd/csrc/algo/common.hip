@@ -74,6 +74,48 @@ void drop_all_cached() {
 }
 }  // namespace
 
+void (*g_memTrimCache)(int) = nullptr;  // AresMemTrimCache of the sibling libmem.so (transform.hip resolves it)
+
+// A stream is being destroyed (the host has synchronised it): its cached temporaries go back to the
+// driver — the Go host creates and destroys two streams per query, blocks cached under dead handles
+// would only pile up.
+void stream_cache_purge(int device, hipStream_t stream) {
+  std::vector<void *> blocks;
+  {
+    std::lock_guard<std::mutex> lock(g_cacheMutex);
+    auto it = g_caches.find({device, stream});
+    if (it == g_caches.end()) return;
+    for (auto &bin : it->second.bins)
+      for (void *p : bin.second) {
+        blocks.push_back(p);
+        g_blockSize.erase(p);
+      }
+    g_cachedBytes -= it->second.bytes;
+    g_caches.erase(it);
+  }
+  for (void *p : blocks) (void)hipFree(p);
+}
+
+// gives every cached block of the device back to the driver (the sibling library ran out of memory)
+void stream_cache_trim(int device) {
+  std::vector<void *> blocks;
+  {
+    std::lock_guard<std::mutex> lock(g_cacheMutex);
+    for (auto &kv : g_caches) {
+      if (kv.first.first != device) continue;
+      for (auto &bin : kv.second.bins)
+        for (void *p : bin.second) {
+          blocks.push_back(p);
+          g_blockSize.erase(p);
+        }
+      kv.second.bins.clear();
+      g_cachedBytes -= kv.second.bytes;
+      kv.second.bytes = 0;
+    }
+  }
+  for (void *p : blocks) (void)hipFree(p);
+}
+
 void *stream_alloc(size_t bytes, hipStream_t stream) {
   const size_t rounded = cache_bin(bytes);
   int device = 0;
@@ -98,6 +140,7 @@ void *stream_alloc(size_t bytes, hipStream_t stream) {
       std::lock_guard<std::mutex> lock(g_cacheMutex);
       drop_all_cached();
     }
+    if (g_memTrimCache) g_memTrimCache(device);  // the sibling allocator's parked blocks too
     hip_check(hipMalloc(&p, rounded), "hipMalloc");
   }
   std::lock_guard<std::mutex> lock(g_cacheMutex);
@@ -119,9 +162,9 @@ void stream_release(void *ptr, hipStream_t stream) {
   c.bins[rounded].push_back(ptr);
   c.bytes += rounded;
   g_cachedBytes += rounded;
-  // keep the cache below a quarter of the device: drop everything when it outgrows that
+  // keep the cache below an eighth of the device: drop everything when it outgrows that
   size_t freeB = 0, totalB = 0;
-  if (g_cachedBytes > (1ull << 30) && hipMemGetInfo(&freeB, &totalB) == hipSuccess && g_cachedBytes > totalB / 4) drop_all_cached();
+  if (g_cachedBytes > (1ull << 30) && hipMemGetInfo(&freeB, &totalB) == hipSuccess && g_cachedBytes > totalB / 8) drop_all_cached();
 }
 
 // ---- kernel timing -------------------------------------------------------------------------------

@@ -40,7 +40,17 @@ bool fuse_pending_into_hash_reduce(int device, hipStream_t stream, const Dimensi
                                    const DimensionVector &out, uint8_t *outValues, int valueBytes, int length, int aggFunc,
                                    int *groups);
 void invalidate_filter_journal(const uint32_t *indexVector);
+// true when the sibling libmem.so reports waits, frees and copies to this library (transform.hip)
+bool deferral_hooks_active();
+// something writes (or frees) [ptr, ptr + bytes): partition-grouped results that overlap are no longer
+// trusted (hash_reduce_lds.hip)
+void grouped_note_write(int device, const void *ptr, size_t bytes);
+void grouped_note_write(int device, const DimensionVector &v);  // the whole vector
 void flush_deferred_for_inputs(int device, const void *a, size_t aBytes, const void *b, size_t bBytes);
+// the same for an entry point that reads a whole dimension vector and a value vector
+void flush_deferred_for_vector(int device, const DimensionVector &v, const void *values, size_t valueBytes);
+// skipped work whose outputs lie in ranges that are about to be overwritten is dropped, never launched
+void drop_skipped_outputs(int device, const void *a, size_t aBytes, const void *b, size_t bBytes);
 
 // NOFLUSH: only for the transform entry points, which decide themselves whether to queue or flush
 #define ARES_ABI_BEGIN_NOFLUSH(device)                 \
@@ -69,6 +79,9 @@ inline void *int_result(int64_t v) { return reinterpret_cast<void *>(static_cast
 // cross-stream reuse inside the runtime's own pool.
 void *stream_alloc(size_t bytes, hipStream_t stream);
 void stream_release(void *ptr, hipStream_t stream);
+void stream_cache_purge(int device, hipStream_t stream);  // the stream is being destroyed
+void stream_cache_trim(int device);                       // out of memory elsewhere: give everything back
+extern void (*g_memTrimCache)(int device);                // sibling libmem.so's AresMemTrimCache, when present
 
 class StreamBuffer {
  public:

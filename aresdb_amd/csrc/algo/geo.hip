@@ -387,6 +387,7 @@ CGoCallResHandle GeoBatchIntersects(GeoShapeBatch geoShapeBatch, InputVector poi
 CGoCallResHandle WriteGeoShapeDim(int shapeTotalWords, DimensionOutputVector dimOut, int indexVectorLengthBeforeGeo,
                                   uint32_t *outputPredicate, void *cudaStream, int device) {
   ARES_ABI_BEGIN(device)
+  grouped_note_write(device, dimOut.DimValues, static_cast<size_t>(indexVectorLengthBeforeGeo > 0 ? indexVectorLengthBeforeGeo : 1));
   write_geo_shape_dim(shapeTotalWords, dimOut, indexVectorLengthBeforeGeo, outputPredicate,
                       reinterpret_cast<hipStream_t>(cudaStream));
   ARES_ABI_END("WriteGeoShapeDim")

@@ -135,6 +135,12 @@ extern "C" CGoCallResHandle HashReduce(DimensionVector inputKeys, uint8_t *input
                                        enum AggregateFunction aggFunc, void *cudaStream, int device) {
   ARES_ABI_BEGIN_NOFLUSH(device)
   hipStream_t stream = reinterpret_cast<hipStream_t>(cudaStream);
+  {  // whatever an earlier HashReduce skipped that would write into this call's outputs is dead
+    const DimLayoutD outLayout = make_dim_layout(outputKeys.NumDimsPerDimWidth);
+    drop_skipped_outputs(device, outputKeys.DimValues,
+                         static_cast<size_t>(outLayout.rowBytes) * (inputKeys.VectorCapacity > 0 ? inputKeys.VectorCapacity : 0),
+                         outputValues, static_cast<size_t>(valueBytes) * (length > 0 ? length : 0));
+  }
   // the dimension / measure transforms of this batch may still be pending: evaluate them on the fly
   int fusedGroups = 0;
   if (length > 0 && fuse_pending_into_hash_reduce(device, stream, inputKeys, inputValues, outputKeys, outputValues,
@@ -150,11 +156,13 @@ extern "C" CGoCallResHandle HashReduce(DimensionVector inputKeys, uint8_t *input
   const AggSpec a = make_agg_spec(aggFunc, valueBytes);
   int groups = -1;
   if (length > 0 && hash_reduce_lds_supported(a) && !global_table_forced())
-    groups = hash_reduce_lds(inputKeys, inputValues, outputKeys, outputValues, a, length, stream);
+    groups = hash_reduce_lds(device, inputKeys, inputValues, outputKeys, outputValues, a, length, stream);
   if (groups >= 0) {
     resHandle.res = int_result(groups);
   } else if (length > 0) {
     const DimLayoutD L = make_dim_layout(inputKeys.NumDimsPerDimWidth);
+    grouped_note_write(device, outputKeys.DimValues, static_cast<size_t>(L.rowBytes) * inputKeys.VectorCapacity);
+    grouped_note_write(device, outputValues, static_cast<size_t>(a.width) * length);
     uint64_t tableSize = 1024;
     while (tableSize < 2ull * static_cast<uint64_t>(length)) tableSize <<= 1;
     StreamBuffer keyBuf(tableSize * 8, stream), valBuf(tableSize * a.width, stream), counter(16, stream);

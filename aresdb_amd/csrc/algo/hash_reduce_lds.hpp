@@ -15,8 +15,9 @@ bool hash_reduce_lds_supported(const AggSpec &a);
 
 // Returns the number of groups, or -1 when a partition region overflowed (the caller then runs the
 // global-table path; outputs written so far are simply overwritten).
-int hash_reduce_lds(const DimensionVector &inputKeys, const uint8_t *inputValues, const DimensionVector &outputKeys,
-                    uint8_t *outputValues, const AggSpec &a, int length, hipStream_t stream);
+int hash_reduce_lds(int device, const DimensionVector &inputKeys, const uint8_t *inputValues,
+                    const DimensionVector &outputKeys, uint8_t *outputValues, const AggSpec &a, int length,
+                    hipStream_t stream);
 
 // ---- fused scan: filter + projection evaluated from the source columns ------------------------------
 constexpr int kFusedCols = 6, kFusedFilters = 4, kFusedDims = 4;
@@ -43,8 +44,8 @@ struct FusedPlanD {
 
 // Column slots of a plan of ND dimensions: dimension d -> slot d, measure -> slot ND; a filter reuses
 // a slot that already holds its column or takes the one spare slot ND + 1.
-int fused_hash_reduce_run(const FusedPlanD &plan, int batchRows, const DimensionVector &prevKeys, const uint8_t *prevValues,
-                          int prevSize, const DimensionVector &outKeys, uint8_t *outValues, const AggSpec &a,
-                          hipStream_t stream);
+int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, const DimensionVector &prevKeys,
+                          const uint8_t *prevValues, int prevSize, const DimensionVector &outKeys, uint8_t *outValues,
+                          const AggSpec &a, hipStream_t stream);
 
 }  // namespace ares

@@ -449,6 +449,10 @@ extern "C" CGoCallResHandle HyperLogLog(DimensionVector prevDimOut, DimensionVec
                                         uint8_t **hllVectorPtr, size_t *hllVectorSizePtr,
                                         uint16_t **hllDimRegIDCountPtr, void *cudaStream, int device) {
   ARES_ABI_BEGIN(device)
+  flush_deferred_for_vector(device, prevDimOut, nullptr, 0);
+  flush_deferred_for_vector(device, curDimOut, nullptr, 0);
+  grouped_note_write(device, prevDimOut);
+  grouped_note_write(device, curDimOut);
   resHandle.res = reinterpret_cast<void *>(static_cast<intptr_t>(
       hyperloglog(prevDimOut, curDimOut, prevValuesOut, curValuesOut, prevResultSize, curBatchSize, isLastBatch,
                   hllVectorPtr, hllVectorSizePtr, hllDimRegIDCountPtr, reinterpret_cast<hipStream_t>(cudaStream))));

@@ -655,6 +655,7 @@ extern "C" {
 
 CGoCallResHandle Sort(DimensionVector keys, int length, void *cudaStream, int device) {
   ARES_ABI_BEGIN(device)
+  flush_deferred_for_vector(device, keys, nullptr, 0);  // rows a HashReduce skipped, should a host sort them after all
   sort_impl(keys, length, reinterpret_cast<hipStream_t>(cudaStream));
   ARES_ABI_END("Sort")
 }
@@ -663,6 +664,10 @@ CGoCallResHandle Reduce(DimensionVector inputKeys, uint8_t *inputValues, Dimensi
                         uint8_t *outputValues, int valueBytes, int length, enum AggregateFunction aggFunc,
                         void *cudaStream, int device) {
   ARES_ABI_BEGIN(device)
+  flush_deferred_for_vector(device, inputKeys, inputValues, static_cast<size_t>(valueBytes) * (length > 0 ? length : 0));
+  grouped_note_write(device, outputKeys);
+  grouped_note_write(device, outputValues, static_cast<size_t>(valueBytes) * (length > 0 ? length : 0));
+  drop_skipped_outputs(device, outputKeys.DimValues, 1, outputValues, static_cast<size_t>(valueBytes) * (length > 0 ? length : 0));
   resHandle.res = int_result(reduce_impl(inputKeys, inputValues, outputKeys, outputValues, valueBytes, length, aggFunc,
                                          reinterpret_cast<hipStream_t>(cudaStream)));
   ARES_ABI_END("Reduce")
@@ -671,6 +676,8 @@ CGoCallResHandle Reduce(DimensionVector inputKeys, uint8_t *inputValues, Dimensi
 CGoCallResHandle Expand(DimensionVector inputKeys, DimensionVector outputKeys, uint32_t *baseCounts,
                         uint32_t *indexVector, int indexVectorLen, int outputOccupiedLen, void *cudaStream, int device) {
   ARES_ABI_BEGIN(device)
+  flush_deferred_for_vector(device, inputKeys, nullptr, 0);
+  grouped_note_write(device, outputKeys);
   resHandle.res = int_result(expand_impl(inputKeys, outputKeys, baseCounts, indexVector, indexVectorLen,
                                          outputOccupiedLen, reinterpret_cast<hipStream_t>(cudaStream)));
   ARES_ABI_END("Expand")

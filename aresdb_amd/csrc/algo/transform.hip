@@ -979,6 +979,32 @@ struct PendingQueue {
   bool overWait = false;
 };
 std::mutex g_deferMutex;
+// Stream synchronisations that work done under g_deferMutex asks for (a queue the host has already
+// waited for was launched late; a copy is about to read what a late launch writes): they run after
+// the mutex is released, so one query's late launch never stalls the other streams of the device.
+thread_local std::vector<hipStream_t> t_syncAfterUnlock;
+struct DeferLock {
+  std::unique_lock<std::mutex> lock;
+  DeferLock() : lock(g_deferMutex) {}
+  void unlock() {
+    if (lock.owns_lock()) lock.unlock();
+    drain();
+  }
+  static void drain() {
+    std::vector<hipStream_t> todo;
+    todo.swap(t_syncAfterUnlock);
+    for (size_t i = 0; i < todo.size(); i++) {
+      bool seen = false;
+      for (size_t j = 0; j < i; j++) seen = seen || todo[j] == todo[i];
+      if (!seen) hip_check(hipStreamSynchronize(todo[i]), "hipStreamSynchronize");
+    }
+  }
+  ~DeferLock() noexcept(false) {
+    if (lock.owns_lock()) lock.unlock();
+    if (std::uncaught_exceptions() == 0) drain();
+    else t_syncAfterUnlock.clear();
+  }
+};
 std::map<std::pair<int, hipStream_t>, PendingQueue> g_pending;
 
 // Filters of the hot shape that have compacted an index vector since its InitIndexVector: with them
@@ -1043,6 +1069,9 @@ std::map<uint32_t *, PendingIota> g_iotas;
 void hook_on_wait(int device, void *stream);
 uintptr_t hook_on_free(int device, void *ptr, size_t bytes);
 void hook_on_access(int device, const void *ptr, size_t bytes);
+void hook_on_write(int device, const void *ptr, size_t bytes);
+void hook_on_stream_destroy(int device, void *stream);
+void hook_trim(int device);
 
 // registers the flush hook with the sibling libmem.so; false = deferral is off for this process
 bool defer_available() {
@@ -1068,11 +1097,70 @@ bool defer_available() {
       g_releaseHeld = release;
       setHooks(&hooks);
     }
+    auto setAux = reinterpret_cast<void (*)(const AresMemAuxHooks *)>(dlsym(h, "AresMemSetAuxHooks"));
+    if (setAux) {
+      static const AresMemAuxHooks aux = {sizeof(AresMemAuxHooks), &hook_on_write, &hook_on_stream_destroy, &hook_trim};
+      setAux(&aux);
+    }
+    g_memTrimCache = reinterpret_cast<void (*)(int)>(dlsym(h, "AresMemTrimCache"));
     return true;
   }();
   return ok;
 }
 bool fuse_available() { return defer_available() && g_releaseHeld != nullptr; }
+}  // namespace
+bool deferral_hooks_active() { return fuse_available(); }
+namespace {
+
+// The error word of a lazily launched compaction (a bounded wait inside filter_compact_kernel timed
+// out) cannot be read back where the launch happens — that may be inside a free or a copy.  It is
+// copied to pinned memory behind the kernel and looked at by the following entry points of the
+// device: the first one that finds it set reports the failure to the host.
+struct ErrorCheck {
+  int device;
+  hipEvent_t done;
+  uint32_t *pinned;
+  std::shared_ptr<StreamBuffer> ws;  // keeps the error word alive until the copy has run
+};
+std::vector<ErrorCheck> g_errorChecks;
+std::vector<std::pair<hipEvent_t, uint32_t *>> g_errorSlots;  // recycled (event, pinned word) pairs
+
+// caller holds g_deferMutex
+void watch_error_word(int device, hipStream_t stream, const uint32_t *errorDev, std::shared_ptr<StreamBuffer> ws) {
+  ErrorCheck c;
+  c.device = device;
+  c.ws = std::move(ws);
+  if (!g_errorSlots.empty()) {
+    c.done = g_errorSlots.back().first;
+    c.pinned = g_errorSlots.back().second;
+    g_errorSlots.pop_back();
+  } else {
+    hip_check(hipEventCreateWithFlags(&c.done, hipEventDisableTiming), "hipEventCreate");
+    hip_check(hipHostMalloc(reinterpret_cast<void **>(&c.pinned), sizeof(uint32_t), hipHostMallocPortable), "hipHostMalloc");
+  }
+  *c.pinned = 0;
+  hip_check(hipMemcpyAsync(c.pinned, errorDev, sizeof(uint32_t), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync");
+  hip_check(hipEventRecord(c.done, stream), "hipEventRecord");
+  g_errorChecks.push_back(std::move(c));
+}
+
+// caller holds g_deferMutex; throws when a finished lazy compaction reported a failure
+void poll_error_words(int device) {
+  bool failed = false;
+  for (size_t i = 0; i < g_errorChecks.size();) {
+    ErrorCheck &c = g_errorChecks[i];
+    if (c.device == device && hipEventQuery(c.done) == hipSuccess) {
+      failed = failed || *c.pinned != 0;
+      g_errorSlots.emplace_back(c.done, c.pinned);
+      g_errorChecks[i] = std::move(g_errorChecks.back());
+      g_errorChecks.pop_back();
+    } else {
+      (void)hipGetLastError();
+      i++;
+    }
+  }
+  if (failed) throw AlgorithmError("ERROR: filter: compaction wait timed out (reported by a deferred compaction)");
+}
 
 // caller holds g_deferMutex and has selected the device: runs the pending compaction of `idx` (if
 // there is one) on the stream its filter ran on
@@ -1093,7 +1181,9 @@ void run_compaction(const uint32_t *idx) {
   else
     ARES_LAUNCH("filter_compact_kernel", (filter_compact_kernel<uint32_t, false>), cgrid, kBlock, c.stream, c.pred, c.idx, 0u,
                 c.pad, cw, c.n, c.tiles);
-  // (c.ws is released to the stream's cache when the last copy of the shared_ptr goes: behind the launch)
+  watch_error_word(c.device, c.stream, c.error, c.ws);
+  // (c.ws is released to the stream's cache when the last copy of the shared_ptr goes: behind the launch
+  // and the copy of the error word)
 }
 bool compaction_touches(const PendingCompact &c, const ByteRange &r) {
   const ByteRange ri{reinterpret_cast<const uint8_t *>(c.idx), reinterpret_cast<const uint8_t *>(c.idx) + 4ull * c.n};
@@ -1125,7 +1215,7 @@ void launch_queue(hipStream_t stream, PendingQueue &q, bool inOrder = false) {
   q.jobs.count = 0;
   q.reads.clear();
   q.writes.clear();
-  if (syncAfter) hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+  if (syncAfter) t_syncAfterUnlock.push_back(stream);  // (DeferLock: after the mutex is released)
 }
 
 // caller holds g_deferMutex.  Launches the skipped transforms of every limbo entry of the device
@@ -1163,7 +1253,8 @@ static void launch_init_index(uint32_t *indexVector, uint32_t start, int n, hipS
 // limboA/limboB: when given, only the skipped work whose outputs overlap these byte ranges is
 // launched (the caller reads nothing else); otherwise all of it
 static void flush_deferred_impl(int device, const ByteRange *limboA, const ByteRange *limboB) {
-  std::lock_guard<std::mutex> lock(g_deferMutex);
+  DeferLock lock;
+  poll_error_words(device);
   for (auto it = g_iotas.begin(); it != g_iotas.end();) {
     if (it->second.device == device) {
       launch_init_index(it->first, it->second.start, it->second.n, it->second.stream);
@@ -1184,16 +1275,49 @@ static void flush_deferred_impl(int device, const ByteRange *limboA, const ByteR
       if (kv.second.overWait && kv.second.jobs.count) released.add(kv.first.second);
       launch_queue(kv.first.second, kv.second);
     }
-  if (limboA) {
-    materialize_limbo(device, limboA, &released);
-    if (limboB) materialize_limbo(device, limboB, &released);
-  } else {
-    materialize_limbo(device, nullptr, &released);
-  }
+  // Work that a HashReduce skipped (limbo) is only launched for byte ranges the caller reads: a full
+  // flush from an unrelated call (the next batch's first filter on the query's other stream, say)
+  // leaves it alone.
+  if (limboA) materialize_limbo(device, limboA, &released);
+  if (limboB) materialize_limbo(device, limboB, &released);
   released.run(device);
 }
 
 void flush_deferred(int device) { flush_deferred_impl(device, nullptr, nullptr); }
+
+void flush_deferred_for_vector(int device, const DimensionVector &v, const void *values, size_t valueBytes) {
+  size_t rowBytes = 0;
+  for (int w = 0; w < NUM_DIM_WIDTH; w++) rowBytes += static_cast<size_t>(v.NumDimsPerDimWidth[w]) * ((1u << (NUM_DIM_WIDTH - 1 - w)) + 1);
+  flush_deferred_for_inputs(device, v.DimValues, rowBytes * static_cast<size_t>(v.VectorCapacity > 0 ? v.VectorCapacity : 0),
+                            values, valueBytes);
+}
+
+// A HashReduce (or any other writer) is about to overwrite [a, a + aBytes) and [b, b + bBytes): work
+// that an earlier HashReduce skipped and whose outputs lie in there must never be launched any more —
+// it would overwrite the new results (the Go host ping-pongs its result buffers and alternates two
+// streams: batch k's skipped transforms target the buffer batch k+1 reduces into).
+void drop_skipped_outputs(int device, const void *a, size_t aBytes, const void *b, size_t bBytes) {
+  if (!fuse_available()) return;
+  const ByteRange ra{static_cast<const uint8_t *>(a), static_cast<const uint8_t *>(a) + (aBytes ? aBytes : 1)};
+  const ByteRange rb{static_cast<const uint8_t *>(b), static_cast<const uint8_t *>(b) + (bBytes ? bBytes : 1)};
+  ReleaseSet released;
+  {
+    DeferLock lock;
+    for (auto it = g_limbo.begin(); it != g_limbo.end();) {
+      bool hit = false;
+      if (it->first.first == device)
+        for (const ByteRange &w : it->second.writes) hit = hit || w.overlaps(ra) || w.overlaps(rb);
+      if (hit) {
+        if (it->second.idx) g_compactions.erase(it->second.idx);
+        released.add(it->first.second);
+        it = g_limbo.erase(it);
+      } else {
+        ++it;
+      }
+    }
+  }
+  released.run(device);
+}
 
 // for an entry point that reads exactly [a, a + aBytes) and [b, b + bBytes) of device memory
 void flush_deferred_for_inputs(int device, const void *a, size_t aBytes, const void *b, size_t bBytes) {
@@ -1208,7 +1332,7 @@ static void begin_batch(int device, hipStream_t stream, const uint32_t *indexVec
   if (!fuse_available()) return;
   bool release = false;
   {
-    std::lock_guard<std::mutex> lock(g_deferMutex);
+    DeferLock lock;
     auto lim = g_limbo.find({device, stream});
     if (lim != g_limbo.end()) {  // the skipped work of the previous batch dies, and with it the compaction it would need
       if (lim->second.idx) g_compactions.erase(lim->second.idx);
@@ -1230,7 +1354,7 @@ static void begin_batch(int device, hipStream_t stream, const uint32_t *indexVec
 // a fast filter has compacted `indexVector` (f == nullptr: something else has — forget the journal)
 static void journal_filter(const uint32_t *indexVector, const FastOperands *f, uint32_t colRows, int rowsBefore) {
   if (!fuse_available()) return;
-  std::lock_guard<std::mutex> lock(g_deferMutex);
+  DeferLock lock;
   auto it = g_journals.find(indexVector);
   if (it == g_journals.end()) return;
   FilterJournal &j = it->second;
@@ -1255,7 +1379,7 @@ static bool journal_is_valid(const uint32_t *indexVector) {
     return !(e && e[0] == '0');
   }();
   if (!lazy) return false;
-  std::lock_guard<std::mutex> lock(g_deferMutex);
+  DeferLock lock;
   auto it = g_journals.find(indexVector);
   return it != g_journals.end() && it->second.valid;
 }
@@ -1263,7 +1387,7 @@ static bool journal_is_valid(const uint32_t *indexVector) {
 // InitIndexVector: remember instead of writing (when the flush hook is in place)
 static bool defer_iota(int device, hipStream_t stream, uint32_t *indexVector, uint32_t start, int n) {
   if (!defer_available() || n <= 0) return false;
-  std::lock_guard<std::mutex> lock(g_deferMutex);
+  DeferLock lock;
   g_iotas[indexVector] = PendingIota{device, stream, start, n};
   return true;
 }
@@ -1271,7 +1395,7 @@ static bool defer_iota(int device, hipStream_t stream, uint32_t *indexVector, ui
 // true when `indexVector` is a virtual iota(0) of exactly n rows on this device; `take` removes it
 // (the caller is about to give the vector real contents)
 static bool virtual_iota(int device, uint32_t *indexVector, int n, bool take) {
-  std::lock_guard<std::mutex> lock(g_deferMutex);
+  DeferLock lock;
   auto it = g_iotas.find(indexVector);
   if (it == g_iotas.end() || it->second.device != device || it->second.start != 0 || it->second.n != n) return false;
   if (take) g_iotas.erase(it);
@@ -1281,7 +1405,7 @@ static bool virtual_iota(int device, uint32_t *indexVector, int n, bool take) {
 // Queues one fast-path transform; returns false when deferral is unavailable (the caller launches it).
 static bool defer_transform(int device, hipStream_t stream, const FastOperands &f, const SinkD &s, int n, uint32_t colRows) {
   if (!defer_available()) return false;
-  std::lock_guard<std::mutex> lock(g_deferMutex);
+  DeferLock lock;
   // everything pending on OTHER streams of the device is unrelated; only this stream's queue matters
   PendingQueue &q = g_pending[{device, stream}];
   ByteRange rv{reinterpret_cast<const uint8_t *>(f.vals), reinterpret_cast<const uint8_t *>(f.vals) + 4ull * colRows};
@@ -1327,6 +1451,10 @@ static int run_transform(const InputVector *ins, int arity, const OutputVector &
   build_params(ins, arity, stream, indexVector, baseCounts, startCount, functor, p, temps);
   bind_sink(output, baseCounts, s);
   if (s.type == SINK_MEASURE && s.baseCounts && indexVector) p.needRow = 1;
+  if (s.type == SINK_DIM || s.type == SINK_MEASURE) {  // rows of a result vector are (about to be) rewritten
+    grouped_note_write(device, s.values, static_cast<size_t>(s.width) * n);
+    if (s.nulls) grouped_note_write(device, s.nulls, static_cast<size_t>(n));
+  }
   FastOperands f;
   const bool fast = fast_sink(s) && fast_operands(p, f, false);
   if (fast && f.idx && virtual_iota(device, indexVector, n, false)) f.idx = nullptr;  // rows = position
@@ -1429,7 +1557,7 @@ static int run_filter(const InputVector *ins, int arity, uint32_t *indexVector, 
       c.error = error;
       c.tileOffsets = tileOffsets;
       c.loaded = loaded;
-      std::lock_guard<std::mutex> lock(g_deferMutex);
+      DeferLock lock;
       g_compactions[indexVector] = c;
       return static_cast<int>(result[0]);
     }
@@ -1457,7 +1585,7 @@ static int run_filter(const InputVector *ins, int arity, uint32_t *indexVector, 
     return static_cast<int>(result[0]);
   }
   if (virtualIdx) {  // the one-pass kernels read the index vector: write it now
-    std::lock_guard<std::mutex> lock(g_deferMutex);
+    DeferLock lock;
     launch_init_index(indexVector, 0, n, stream);
   }
   int numTiles = static_cast<int>((static_cast<int64_t>(n) + kFilterTile - 1) / kFilterTile);
@@ -1545,7 +1673,7 @@ void hook_on_wait(int device, void *streamPtr) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(streamPtr);
   try {
     DeviceGuard guard(device);
-    std::lock_guard<std::mutex> lock(g_deferMutex);
+    DeferLock lock;
     // a wait on one stream says nothing about the others: their pending work is left alone
     for (auto it = g_iotas.begin(); it != g_iotas.end();) {
       if (it->second.device == device && it->second.stream == stream) {
@@ -1584,11 +1712,12 @@ void hook_on_wait(int device, void *streamPtr) {
 // which still reads it (the value is the tag AresMemReleaseHeld will be called with)
 uintptr_t hook_on_free(int device, void *ptr, size_t bytes) {
   const ByteRange r = range_of(ptr, bytes);
+  grouped_note_write(device, ptr, bytes);
   uintptr_t hold = 0;
   ReleaseSet released;
   try {
     DeviceGuard guard(device);
-    std::lock_guard<std::mutex> lock(g_deferMutex);
+    DeferLock lock;
     for (auto it = g_iotas.begin(); it != g_iotas.end();) {  // an index vector nobody has read yet
       const ByteRange v = range_of(it->first, 4ull * it->second.n);
       it = (it->second.device == device && v.overlaps(r)) ? g_iotas.erase(it) : std::next(it);
@@ -1638,8 +1767,13 @@ uintptr_t hook_on_free(int device, void *ptr, size_t bytes) {
             launch_queue(kv.first.second, kv.second);
           }
         it = g_compactions.begin();  // (launch_queue erased the entry)
-      } else {  // nobody will read the compacted vector
-        it = g_compactions.erase(it);
+      } else if (range_of(it->second.idx, 4ull * it->second.n).overlaps(r)) {
+        it = g_compactions.erase(it);  // the index vector itself goes: nobody will read the compacted vector
+      } else {
+        // only the predicate vector goes, the index vector stays live (a later transform, filter or
+        // copy may read it): compact now — the free is fenced behind the launch
+        run_compaction(key);
+        it = g_compactions.begin();
       }
     }
     for (auto it = g_limbo.begin(); it != g_limbo.end();) {
@@ -1665,12 +1799,12 @@ void hook_on_access(int device, const void *ptr, size_t bytes) {
   ReleaseSet released;
   try {
     DeviceGuard guard(device);
-    std::lock_guard<std::mutex> lock(g_deferMutex);
+    DeferLock lock;
     for (auto it = g_iotas.begin(); it != g_iotas.end();) {
       const ByteRange v = range_of(it->first, 4ull * it->second.n);
       if (it->second.device == device && v.overlaps(r)) {
         launch_init_index(it->first, it->second.start, it->second.n, it->second.stream);
-        hip_check(hipStreamSynchronize(it->second.stream), "hipStreamSynchronize");
+        t_syncAfterUnlock.push_back(it->second.stream);
         it = g_iotas.erase(it);
       } else {
         ++it;
@@ -1688,7 +1822,7 @@ void hook_on_access(int device, const void *ptr, size_t bytes) {
       if (it->second.device == device && compaction_touches(it->second, r)) {
         const hipStream_t cs = it->second.stream;
         run_compaction(it->first);
-        hip_check(hipStreamSynchronize(cs), "hipStreamSynchronize");
+        t_syncAfterUnlock.push_back(cs);
         it = g_compactions.begin();
       } else {
         ++it;
@@ -1702,6 +1836,46 @@ void hook_on_access(int device, const void *ptr, size_t bytes) {
     fprintf(stderr, "Exception happened when handling a device copy: %s\n", e.what());
   }
   released.run(device);
+}
+}  // namespace
+
+namespace {
+void hook_on_write(int device, const void *ptr, size_t bytes) { grouped_note_write(device, ptr, bytes); }
+
+void hook_trim(int device) {
+  try {
+    DeviceGuard guard(device);
+    stream_cache_trim(device);
+  } catch (std::exception &) {
+  }
+}
+
+// DestroyCudaStream (the stream has been flushed and synchronised): nothing may outlive the handle —
+// a later stream can get the same address
+void hook_on_stream_destroy(int device, void *streamPtr) {
+  hipStream_t stream = reinterpret_cast<hipStream_t>(streamPtr);
+  try {
+    DeviceGuard guard(device);
+    {
+      DeferLock lock;
+      g_pending.erase({device, stream});
+      auto lim = g_limbo.find({device, stream});
+      if (lim != g_limbo.end()) {
+        if (lim->second.idx) g_compactions.erase(lim->second.idx);
+        g_limbo.erase(lim);
+      }
+      for (auto it = g_journals.begin(); it != g_journals.end();)
+        it = (it->second.device == device && it->second.stream == stream) ? g_journals.erase(it) : std::next(it);
+      for (auto it = g_compactions.begin(); it != g_compactions.end();)
+        it = (it->second.device == device && it->second.stream == stream) ? g_compactions.erase(it) : std::next(it);
+      for (auto it = g_iotas.begin(); it != g_iotas.end();)
+        it = (it->second.device == device && it->second.stream == stream) ? g_iotas.erase(it) : std::next(it);
+    }
+    if (g_releaseHeld) g_releaseHeld(device, hold_tag(stream));
+    stream_cache_purge(device, stream);
+  } catch (std::exception &e) {
+    fprintf(stderr, "Exception happened when handling a stream destruction: %s\n", e.what());
+  }
 }
 }  // namespace
 
@@ -1720,7 +1894,7 @@ bool fuse_pending_into_hash_reduce(int device, hipStream_t stream, const Dimensi
   int nd = 0, prev = 0, n0 = 0;
   AggSpec a;
   {
-    std::lock_guard<std::mutex> lock(g_deferMutex);
+    DeferLock lock;
     auto it = g_pending.find({device, stream});
     if (it == g_pending.end() || it->second.jobs.count == 0) return false;
     PendingQueue &pq = it->second;
@@ -1795,8 +1969,9 @@ bool fuse_pending_into_hash_reduce(int device, hipStream_t stream, const Dimensi
       plan.measureWidth = valueBytes;
       plan.identity = pq.jobs.s[measureJob].identity;
       plan.numCols = nd + 1;
+      ok = !(valueBytes == 8 && plan.identity != 0);  // records carry 4 bytes: a null must widen to the identity
       if (journal) {
-        ok = journal->filters.size() <= static_cast<size_t>(kFusedFilters);
+        ok = ok && journal->filters.size() <= static_cast<size_t>(kFusedFilters);
         for (size_t k = 0; ok && k < journal->filters.size(); k++) {
           const FastOperands &f = journal->filters[k];
           ok = journal->colRows[k] >= static_cast<uint32_t>(n0);
@@ -1828,8 +2003,8 @@ bool fuse_pending_into_hash_reduce(int device, hipStream_t stream, const Dimensi
     if (q.idx) g_journals.erase(q.idx);
   }
   DimensionVector prevKeys = in;
-  const int result = fused_hash_reduce_run(plan, n0, prevKeys, inValues, prev, out, outValues, a, stream);
-  std::unique_lock<std::mutex> lock(g_deferMutex);
+  const int result = fused_hash_reduce_run(device, plan, n0, prevKeys, inValues, prev, out, outValues, a, stream);
+  DeferLock lock;
   if (result < 0) {  // a partition region overflowed: materialise the inputs after all
     launch_queue(stream, q, /*inOrder=*/true);
     lock.unlock();
@@ -1935,7 +2110,7 @@ CGoCallResHandle InitIndexVector(uint32_t *indexVector, uint32_t start, int inde
   begin_batch(device, stream, indexVector, start, indexVectorLength);
   if (!defer_iota(device, stream, indexVector, start, indexVectorLength)) {
     flush_deferred(device);
-    std::lock_guard<std::mutex> lock(g_deferMutex);
+    DeferLock lock;
     launch_init_index(indexVector, start, indexVectorLength, stream);
   }
   ARES_ABI_END("InitIndexVector")

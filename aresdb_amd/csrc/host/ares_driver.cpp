@@ -191,6 +191,9 @@ struct AresQuery {
   Plan plan;
   int device;
   void *stream;
+  // the Go host owns two streams per query and swaps them after every batch
+  // (query/aql_processor.go:66-67, :218, :247): batch k's calls go to one, batch k+1's to the other
+  void *otherStream = nullptr;
   // oopkBatchContext
   uint8_t ndw[NUM_DIM_WIDTH] = {0, 0, 0, 0, 0};
   std::vector<int> dimVectorIndex;  // query dimension -> position in the width-ordered vector
@@ -629,6 +632,9 @@ struct AresQuery {
     wait();
   }
   void postExec() { swapResultBuffers(); }
+  void swapStreams() {
+    if (otherStream) std::swap(stream, otherStream);
+  }
 
   // ---- fused extension (include/ares_extensions.h): one call per batch --------------------------
   bool fusedExpr(int nodeIdx, int outType, AresFusedExpr *e) {
@@ -695,7 +701,10 @@ struct AresQuery {
 
   void runBatch(const VectorPartySlice *cols, int ncols, int n, uint32_t *bc, uint32_t start) {
     baseCounts = bc;
-    if (runBatchFused(cols, ncols, n)) return;
+    if (runBatchFused(cols, ncols, n)) {
+      swapStreams();
+      return;
+    }
     prepareForFiltering(cols, ncols, n, bc, start);
     preExec();
     filter();
@@ -703,6 +712,7 @@ struct AresQuery {
     project();
     reduce();
     postExec();
+    swapStreams();
   }
 };
 
@@ -762,6 +772,7 @@ uint8_t *AresQueryMeasureVector(const AresQuery *q) { return q->measureVec[0]; }
 long AresQueryNumCalls(const AresQuery *q) { return q->calls; }
 long AresQueryNumFusedBatches(const AresQuery *q) { return q->fusedBatches; }
 void AresQuerySetLastBatch(AresQuery *q, int isLast) { q->isLastBatch = isLast != 0; }
+void AresQuerySetSecondStream(AresQuery *q, void *stream) { q->otherStream = stream; }
 void AresQueryAdoptColumns(AresQuery *q, void *const *allocations, int count) {
   q->ownedColumns.assign(allocations, allocations + count);
 }

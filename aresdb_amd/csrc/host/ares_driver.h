@@ -99,6 +99,10 @@ int AresQueryFetch(AresQuery *q, uint8_t *dims, uint8_t *measures, char *err, in
  * the result is the dimension columns (AresQueryFetch, measures may be NULL), the registers per
  * dimension (uint16 x resultSize) and the encoded HLL vector (query/hll.go:52-63). */
 void AresQuerySetLastBatch(AresQuery *q, int isLast);
+/* The Go host owns two streams per query and swaps them after every batch
+ * (query/aql_processor.go:66-67, :218, :247).  With a second stream set the driver does the same:
+ * batch k's calls go to one stream, batch k+1's to the other; fetches use the current one. */
+void AresQuerySetSecondStream(AresQuery *q, void *stream);
 /* Device allocations (DeviceAllocate) holding the NEXT batch's columns: the driver releases them with
  * DeviceFree in cleanupBeforeAggregation — between project() and reduce() — exactly where the Go host
  * frees a batch's input columns (query/aql_processor.go:695-699).  Without this call the columns stay

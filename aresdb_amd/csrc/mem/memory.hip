@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -95,6 +96,25 @@ inline uintptr_t notify_free(int device, void *ptr, size_t bytes) {
   if (h && h->on_free) return h->on_free(device, ptr, bytes);
   flush_pending(device);
   return 0;
+}
+
+std::atomic<const AresMemAuxHooks *> g_aux{nullptr};
+inline void notify_write(int device, const void *ptr, size_t bytes) {
+  const AresMemAuxHooks *h = g_aux.load(std::memory_order_acquire);
+  if (h && h->size >= offsetof(AresMemAuxHooks, on_write) + sizeof(h->on_write) && h->on_write) h->on_write(device, ptr, bytes);
+}
+inline void notify_write_current(const void *ptr, size_t bytes) {
+  int device = 0;
+  if (hipGetDevice(&device) == hipSuccess) notify_write(device, ptr, bytes);
+}
+inline void notify_stream_destroy(int device, void *stream) {
+  const AresMemAuxHooks *h = g_aux.load(std::memory_order_acquire);
+  if (h && h->size >= offsetof(AresMemAuxHooks, on_stream_destroy) + sizeof(h->on_stream_destroy) && h->on_stream_destroy)
+    h->on_stream_destroy(device, stream);
+}
+inline void notify_trim(int device) {
+  const AresMemAuxHooks *h = g_aux.load(std::memory_order_acquire);
+  if (h && h->size >= offsetof(AresMemAuxHooks, trim) + sizeof(h->trim) && h->trim) h->trim(device);
 }
 
 bool use_pool() {
@@ -221,12 +241,14 @@ hipError_t pool_alloc(DeviceState *st, void **p, size_t bytes, bool zero) {
   }
   if (!ptr) {
     hipError_t e = hipMalloc(&ptr, rounded);
-    if (e != hipSuccess) {  // out of memory: give the cache back and retry once
+    if (e != hipSuccess) {  // out of memory: give both libraries' caches back and retry once
       (void)hipGetLastError();
       {
         std::lock_guard<std::mutex> lock(st->mu);
         trim(st, 0);
       }
+      int device = 0;
+      if (hipGetDevice(&device) == hipSuccess) notify_trim(device);
       e = hipMalloc(&ptr, rounded);
       if (e != hipSuccess) return e;
     }
@@ -278,7 +300,7 @@ hipError_t pool_free(DeviceState *st, void *p) {
   st->bins[rounded].push_back(b);
   st->parkedBytes += rounded;
   size_t freeB = 0, totalB = 0;
-  if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && st->parkedBytes > totalB / 2) trim(st, totalB / 4);
+  if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && st->parkedBytes > totalB / 4) trim(st, totalB / 8);
   return hipSuccess;
 }
 
@@ -291,6 +313,20 @@ void AresMemSetFlushHook(void (*hook)(int device)) { g_flushHook.store(hook, std
 void AresMemSetDeferralHooks(const AresDeferralHooks *hooks) {
   if (hooks && hooks->flush) g_flushHook.store(hooks->flush, std::memory_order_release);
   g_hooks.store(hooks, std::memory_order_release);
+}
+
+void AresMemSetAuxHooks(const AresMemAuxHooks *hooks) { g_aux.store(hooks, std::memory_order_release); }
+
+void AresMemTrimCache(int device) {
+  if (device < 0 || device >= kMaxDevices) return;
+  DeviceState *st = &g_devices[device];
+  int current = 0;
+  const bool switched = hipGetDevice(&current) == hipSuccess && current != device && hipSetDevice(device) == hipSuccess;
+  {
+    std::lock_guard<std::mutex> lock(st->mu);
+    trim(st, 0);
+  }
+  if (switched) (void)hipSetDevice(current);
 }
 
 // The work that was reading the held blocks has been launched (or dropped): fence them like any
@@ -381,6 +417,7 @@ CGoCallResHandle DestroyCudaStream(void *s, int device) {
     }
     // fences already recorded on this stream stay valid: destruction completes its queued work
     MEM_TRY(hipStreamSynchronize(reinterpret_cast<hipStream_t>(s)), "DestroyCudaStream");
+    notify_stream_destroy(device, s);
     MEM_TRY(hipStreamDestroy(reinterpret_cast<hipStream_t>(s)), "DestroyCudaStream");
   }
   return ok();
@@ -431,6 +468,7 @@ CGoCallResHandle DeviceFree(void *p, int device) {
 CGoCallResHandle AsyncCopyHostToDevice(void *dst, void *src, size_t bytes, void *stream, int device) {
   MEM_TRY(hipSetDevice(device), "AsyncCopyHostToDevice");
   notify_access(device, dst, bytes);
+  notify_write(device, dst, bytes);
   if (bytes)
     MEM_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, reinterpret_cast<hipStream_t>(stream)),
             "AsyncCopyHostToDevice");
@@ -441,6 +479,7 @@ CGoCallResHandle AsyncCopyDeviceToDevice(void *dst, void *src, size_t bytes, voi
   MEM_TRY(hipSetDevice(device), "AsyncCopyDeviceToDevice");
   notify_access(device, dst, bytes);
   notify_access(device, src, bytes);
+  notify_write(device, dst, bytes);
   if (bytes)
     MEM_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, reinterpret_cast<hipStream_t>(stream)),
             "AsyncCopyDeviceToDevice");
@@ -509,12 +548,14 @@ CGoCallResHandle deviceFree(void *devPtr) {
 
 CGoCallResHandle deviceMemset(void *devPtr, int value, size_t count) {
   notify_access_current(devPtr, count);
+  notify_write_current(devPtr, count);
   MEM_TRY(hipMemset(devPtr, value, count), "deviceMemset");
   return ok();
 }
 
 CGoCallResHandle asyncCopyHostToDevice(void *dst, const void *src, size_t count, void *stream) {
   notify_access_current(dst, count);
+  notify_write_current(dst, count);
   if (count)
     MEM_TRY(hipMemcpyAsync(dst, src, count, hipMemcpyHostToDevice, reinterpret_cast<hipStream_t>(stream)),
             "asyncCopyHostToDevice");

@@ -70,6 +70,7 @@ def _driver():
         lib.AresQueryFetch.restype = C.c_int
         lib.AresQueryDestroy.argtypes = [C.c_void_p]
         lib.AresQuerySetLastBatch.argtypes = [C.c_void_p, C.c_int]
+        lib.AresQuerySetSecondStream.argtypes = [C.c_void_p, C.c_void_p]
         lib.AresQueryAdoptColumns.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int]
         lib.AresQueryHLLVectorSize.argtypes, lib.AresQueryHLLVectorSize.restype = [C.c_void_p], C.c_int64
         lib.AresQueryFetchHLL.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
@@ -96,7 +97,11 @@ class NativeQuery:
     """One query on one device, executed by the C++ driver."""
 
     def __init__(self, be: abi.Backend, plan: QueryPlan, column_names, device=0, stream=None,
-                 foreign_column_names=None):
+                 foreign_column_names=None, streams=None):
+        """streams: two stream handles -> the driver alternates them per batch like the Go host
+        (query/aql_processor.go:218,247); `stream` alone: every batch on that stream."""
+        if streams:
+            stream = streams[0]
         self.be, self.plan, self.device, self.stream = be, plan, device, stream
         self.column_names = list(column_names)
         self.foreign_column_names = foreign_column_names or [sorted(ft.batches) for ft in plan.foreign_tables]
@@ -171,6 +176,8 @@ class NativeQuery:
         self._q = _driver().AresQueryCreate(_open(be), C.byref(pc), device, stream, err, 512)
         if not self._q:
             raise abi.AresError(err.value.decode())
+        if streams and len(streams) > 1:
+            _driver().AresQuerySetSecondStream(self._q, streams[1])
         self._err = C.create_string_buffer(1024)
 
     def run(self, columns, size, base_counts=None, start_row=0, is_last_batch=False, owned_allocations=()):

@@ -2,17 +2,27 @@
 """Contract benchmark: BASELINE config C3 — a 1 B-row filter -> 4-dimension / 1-measure
 time-bucketised SUM group-by through the hash-reduction path — driven through the C ABI of the
 HIP libalgorithm.so / libmem.so exactly as the Go batch executor would
-(query/aql_batchexecutor.go:103-273), with the fact-table shard already resident in HBM.
+(query/aql_batchexecutor.go:103-273, two streams alternating per batch as query/aql_processor.go:218),
+with the fact-table shard already resident in HBM.
 
 One "step" = one full pass of the query over the rank's shard (all batches, reduce included; for
 N > 1 also the cross-device merge of the per-shard group tables).  N ranks = N shards (weak
 scaling): `value` = rows of all shards / max-over-ranks step time.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--rows R] [--batch-rows B]
+
+`--gpus N` with N > 1 and no torchrun environment spawns the N ranks itself (one process per GPU).
+Outside the timed region the final group table is verified key by key (aresdb_amd/check.py), the
+reference's own HOST build is timed on a bounded sample (cpu_baseline) and compared key by key with
+the same independent group-by, and a few secondary legs are reported (never `value`): the same query
+with the in-ABI fusion stages switched off, at the reference's live-batch size, and through the
+explicit fused extension.
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -23,7 +33,7 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-from aresdb_amd import abi, workload  # noqa: E402
+from aresdb_amd import abi, check, workload  # noqa: E402
 from aresdb_amd.driver import NativeQuery  # noqa: E402
 from aresdb_amd.queries import c3_plan  # noqa: E402
 from aresdb_amd.workload import C3_COLUMNS  # noqa: E402
@@ -31,40 +41,16 @@ from aresdb_amd.workload import C3_COLUMNS  # noqa: E402
 COLUMN_NAMES = [name for name, _ in C3_COLUMNS]
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable with a float4 copy)
+LIVE_BATCH_ROWS = 1 << 21  # the reference's example live-batch size (examples/1k_trips/schema/trips.json:46)
 
 
-def run_shard(be, plan, batches, device, stream):
+def run_shard(be, plan, vps, device, streams):
     """ProcessQuery for one shard (query/aql_processor.go:49-161): every batch through
     preExec/filter/join/project/reduce/postExec; results accumulate on the device."""
-    ctx = NativeQuery(be, plan, COLUMN_NAMES, device=device, stream=stream)  # the C++ host driver
-    for b in batches:
-        ctx.run({k: rc.vp for k, rc in b.items()}, next(iter(b.values())).length)
+    ctx = NativeQuery(be, plan, COLUMN_NAMES, device=device, streams=streams)  # the C++ host driver
+    for cols, n in vps:
+        ctx.run(cols, n)
     return ctx
-
-
-def expected_total(batches):
-    """sum(m) over rows passing `d1 < 90` with d1 and m valid — float64, any order is exact because
-    the synthetic measures are multiples of 0.25."""
-    tot = torch.zeros((), dtype=torch.float64, device=batches[0]["m"].blob.device)
-    rows = 0
-    for b in batches:
-        keep = b["d1"].values() < 90
-        if b["d1"].has_nulls:
-            keep &= b["d1"].valid()
-        rows += int(keep.sum())
-        mv = b["m"].values().to(torch.float64)
-        if b["m"].has_nulls:
-            mv = mv * b["m"].valid()
-        tot += (mv * keep).sum()
-    return float(tot), rows
-
-
-def result_total(ctx, dims_ptr=None):
-    n = ctx.result_size
-    out = torch.empty(max(n, 1), dtype=torch.float64, device=f"cuda:{ctx.device}")
-    ctx.be.call("AsyncCopyDeviceToDevice", out.data_ptr(), ctx.measure_vector, n * 8, ctx.stream, ctx.device)
-    ctx.be.wait(ctx.stream, ctx.device)
-    return float(out[:n].sum())
 
 
 def cpu_baseline(batch, plan_factory, budget_s=15.0):
@@ -72,7 +58,7 @@ def cpu_baseline(batch, plan_factory, budget_s=15.0):
     build is absent, the C restatement (kind "port"), single-threaded like thrust::host
     (query/utils.hpp:236-241), on a bounded sample of the same workload.  HOST HashReduce's
     extraction is O(groups^2) (query/concurrent_unordered_map.hpp:154-159), so the sample goes
-    through the HOST Sort+Reduce path."""
+    through the HOST Sort+Reduce path.  Returns (report, fetched result, rows)."""
     from aresdb_amd.columns import DeviceColumn
     ref_algo = os.path.join(ROOT, "oracle", "_ref", "libalgorithm.so")
     ref_mem = os.path.join(ROOT, "oracle", "_ref", "libmem.so")
@@ -82,8 +68,8 @@ def cpu_baseline(batch, plan_factory, budget_s=15.0):
     elif os.path.exists(port):
         be, kind = abi.Backend("oracle", port, port, device_memory=False), "port"
     else:
-        return None
-    chunk = 1 << 21  # the reference's example live-batch size (examples/1k_trips/schema/trips.json:46)
+        return None, None, 0
+    chunk = LIVE_BATCH_ROWS
     cols, valid = workload.batch_to_host(batch, limit=32 * chunk)
     total_rows = len(next(iter(cols.values()))[1])
     plan = plan_factory(use_hash_reduction=False)
@@ -103,13 +89,61 @@ def cpu_baseline(batch, plan_factory, budget_s=15.0):
         if spent > budget_s:
             break
     groups = ctx.result_size
+    fetched = ctx.fetch()
     ctx.release()
-    return {"value": rows / spent, "unit": "rows/s", "cores": 1, "kind": kind,
-            "sample": f"{rows} rows of the same C3 shard as {nb} live batches of {chunk} rows, "
-                      f"QUERY_MODE=HOST filter+transforms+Sort+Reduce, {groups} groups, {spent:.1f} s"}
+    report = {"value": rows / spent, "unit": "rows/s", "cores": 1, "kind": kind,
+              "sample": f"{rows} rows of the same C3 shard as {nb} live batches of {chunk} rows, "
+                        f"QUERY_MODE=HOST filter+transforms+Sort+Reduce, {groups} groups, {spent:.1f} s"}
+    return report, fetched, rows
 
 
-def main():
+def library_sha():
+    h = hashlib.sha256()
+    with open(abi.hip_library_paths()[0], "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()[:16]
+
+
+def kernel_table(kernels):
+    out = {}
+    tot = sum(v[1] for v in kernels.values()) or 1.0
+    for name, (launches, ms) in sorted(kernels.items(), key=lambda kv: -kv[1][1]):
+        out[name] = {"launches": launches, "avg_ms": ms / launches, "share": ms / tot}
+    return out
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` outside torchrun: one process per GPU (RANK / LOCAL_RANK /
+    WORLD_SIZE from torch.distributed.run), rendezvous on 127.0.0.1."""
+    visible = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if visible < n:
+        raise SystemExit(f"bench.py --gpus {n}: only {visible} GPU(s) visible — refusing to report a smaller job as n_gpus={n}")
+    port = os.environ.get("MASTER_PORT", "29517")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__), *argv]
+    raise SystemExit(subprocess.call(cmd, env={**os.environ, "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")}))
+
+
+def run_leg(env, argv, timeout=900):
+    """A secondary measurement in a child process (the fusion switches are read once per process):
+    this script with --leg, printing one JSON line."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--leg", *argv]
+    try:
+        r = subprocess.run(cmd, env={**os.environ, **env}, capture_output=True, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        return {"error": "timeout"}
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": f"rc {r.returncode}", "stderr": r.stderr[-400:]}
+    return json.loads(lines[-1])
+
+
+def main(argv=None, backend=None, tensor_device=None):
+    """backend / tensor_device: injected by the multi-process CPU test of this file's distributed
+    path (tests/test_bench_distributed.py); the benchmark itself always loads the HIP libraries and
+    fails without a GPU — there is no CPU fallback."""
+    argv = sys.argv[1:] if argv is None else argv
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -118,101 +152,148 @@ def main():
     ap.add_argument("--batch-rows", type=float, default=float(1 << 26))
     ap.add_argument("--null-fraction", type=float, default=0.01)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-fused-leg", action="store_true", help="skip the extra AresFusedFilterHashReduce measurement")
+    ap.add_argument("--no-legs", action="store_true", help="skip the secondary legs (fusion off, live batches, extension)")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
-    args = ap.parse_args()
+    ap.add_argument("--one-stream", action="store_true", help="every batch on one stream (the Go host alternates two)")
+    ap.add_argument("--verify-merged", action="store_true",
+                    help="N > 1: rank 0 regenerates every shard and checks the merged table key by key (small sizes)")
+    ap.add_argument("--leg", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--fused-extension", action="store_true", help=argparse.SUPPRESS)
+    args = ap.parse_args(argv)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and backend is None:
+        spawn_ranks(args.gpus, argv)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
+    if world != args.gpus and not (world == 1 and args.gpus <= 1):
+        raise SystemExit(f"bench.py --gpus {args.gpus} but the launcher started {world} rank(s)")
+    on_gpu = backend is None
+    if on_gpu and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    tdev = torch.device(f"cuda:{local_rank}")
+    if on_gpu:
+        torch.cuda.set_device(local_rank)
+        tdev = torch.device(f"cuda:{local_rank}")
+    else:
+        tdev = torch.device(tensor_device or "cpu")
     # ARES_BENCH_FORCE_DIST=1: exercise the multi-rank code path (RCCL init, merge) with one rank
     force_dist = os.environ.get("ARES_BENCH_FORCE_DIST") == "1"
-    if world > 1 or force_dist:
+    distributed = world > 1 or force_dist
+    if distributed and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         if os.environ.get("NCCL_DEBUG", "").upper() in ("", "VERSION"):
             os.environ["NCCL_DEBUG"] = "WARN"  # keep RCCL's version banner out of stdout (one JSON line)
-        dist.init_process_group("nccl", device_id=tdev)
+        if on_gpu:
+            dist.init_process_group("nccl", device_id=tdev)
+        else:
+            dist.init_process_group("gloo")
+    if distributed and dist.get_world_size() != world:
+        raise SystemExit(f"the process group has {dist.get_world_size()} ranks, expected {world}")
 
-    be = abi.load_hip_backend()  # raises if the HIP libraries are missing — no fallback
-    if world == 1:
+    be = backend if backend is not None else abi.load_hip_backend()  # raises if the HIP libraries are missing
+    device_index = local_rank if on_gpu else 0
+    if on_gpu and world == 1:
         be.call("BootstrapDevice")  # touches every visible device (reference utils.cu:63-85): one process per GPU skips it
-    stream = be.call("CreateCudaStream", local_rank)
+    n_streams = 1 if args.one_stream or not on_gpu else 2
+    streams = [be.call("CreateCudaStream", device_index) for _ in range(n_streams)]
 
     rows, batch_rows = int(args.rows), int(args.batch_rows)
     batches = workload.c3_shard(rows, batch_rows, seed=1 + rank, device=tdev, null_fraction=args.null_fraction)
-    torch.cuda.synchronize()
+    vps = [({k: rc.vp for k, rc in b.items()}, next(iter(b.values())).length) for b in batches]
     plan = c3_plan(use_hash_reduction=True)
-
-    def step():
-        ctx = run_shard(be, plan, batches, local_rank, stream)
-        merged = None
-        if world > 1 or force_dist:
-            from aresdb_amd.shard_merge import merge_shard_results
-            merged = merge_shard_results(ctx, tdev)
-        return ctx, merged
+    plan.use_fused_extension = bool(args.fused_extension)
 
     def sync():
-        torch.cuda.synchronize()
-        if world > 1 or force_dist:
+        if on_gpu:
+            torch.cuda.synchronize()
+        if distributed:
             dist.barrier()
 
+    def merge(ctx):
+        from aresdb_amd.shard_merge import merge_shard_results
+        return merge_shard_results(ctx, tdev)
+
+    # ---- the timed region: W warm-up steps, then exactly K steps between barrier + synchronize ----
     for _ in range(args.warmup):
-        ctx, _ = step()
+        ctx = run_shard(be, plan, vps, device_index, streams)
+        if distributed:
+            merge(ctx)
         ctx.release()
     sync()
     if be.has_profiler:
         be.profiler_enable(True)
+    shard_s = merge_s = 0.0
     t0 = time.perf_counter()
-    last = None
-    for k in range(args.steps):
+    last = merged = None
+    for _ in range(args.steps):
         if last is not None:
-            last[0].release()
-        last = step()
-    torch.cuda.synchronize()
+            last.release()
+        t1 = time.perf_counter()
+        last = run_shard(be, plan, vps, device_index, streams)
+        if distributed:
+            if on_gpu:
+                torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            merged = merge(last)
+            if on_gpu:
+                torch.cuda.synchronize()
+            shard_s += t2 - t1
+            merge_s += time.perf_counter() - t2
+    sync()
     elapsed = time.perf_counter() - t0
+    kernels = {}
     if be.has_profiler:
         kernels = be.profiler_report()
         be.profiler_enable(False)
-    else:
-        kernels = {}
-    if world > 1 or force_dist:
+    rank_times = None
+    if distributed:
         dist.barrier()
-        t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
+        t = torch.tensor([elapsed, shard_s, merge_s], dtype=torch.float64, device=tdev)
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        rank_times = [[float(x) / args.steps * 1e3 for x in g] for g in gathered]
+        elapsed = max(float(g[0]) for g in gathered)
+    ctx = last
 
-    ctx, merged = last
-    # outside the timed region: the aggregate must account for every surviving row
-    want, kept = expected_total(batches)
-    got = result_total(ctx)
+    # ---- outside the timed region: key-level verification of this rank's final group table ----
+    report = check.compare_result(ctx.fetch(), check.exact_groups(batches), hash_identity=True)
     groups = ctx.result_size
-    check = abs(got - want) <= 1e-9 * max(1.0, abs(want))
-    merged_groups = merged.size if merged is not None else None
+    ok = report["status"] == "ok" and report["groups"] == groups
+    merged_groups = int(merged.size) if merged is not None else None
+    merged_check = None
+    if merged is not None and args.verify_merged and rank == 0:
+        every = []
+        for r in range(world):
+            every += workload.c3_shard(rows, batch_rows, seed=1 + r, device=tdev, null_fraction=args.null_fraction)
+        fetched = check.fetched_from_columnar(merged.dims.cpu().numpy(), merged.measures.cpu().numpy(), merged.size,
+                                              merged.capacity)
+        merged_check = check.compare_result(fetched, check.exact_groups(every), hash_identity=True)
+        ok = ok and merged_check["status"] == "ok"
     ctx.release()
 
     bytes_per_row = 5 * 4 + (5 / 8 if args.null_fraction > 0 else 0)
     total_rows_rank = rows * args.steps
-    dominant = None
-    kern_out = {}
-    if kernels:
-        tot_ms = sum(v[1] for v in kernels.values())
-        for name, (launches, ms) in sorted(kernels.items(), key=lambda kv: -kv[1][1]):
-            kern_out[name] = {"launches": launches, "avg_ms": ms / launches, "share": ms / tot_ms}
-        dominant = max(kernels.items(), key=lambda kv: kv[1][1])
+    if args.leg:  # a secondary leg: the measurement and its check, nothing else
+        print(json.dumps({"rows_per_sec_per_gpu": rows * args.steps / elapsed, "ms_per_step": elapsed / args.steps * 1e3,
+                          "batches": len(vps), "groups": groups, "check_groups": report["status"],
+                          "algorithmic_GBps": rows * args.steps / elapsed * bytes_per_row / 1e9,
+                          "kernels": {n: {"launches": c, "avg_ms": ms / c} for n, (c, ms) in
+                                      sorted(kernels.items(), key=lambda kv: -kv[1][1])}}), flush=True)
+        sys.exit(0 if ok else 1)
+
+    kern_out = kernel_table(kernels)
     # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, corrected
-    # as MI355X_MICROARCH.md prescribes), when they were taken at this batch size
-    pmc_kernels = {}
+    # as MI355X_MICROARCH.md prescribes) — only when they were taken on THIS build of libalgorithm.so
+    # at this batch size; otherwise `traffic` is null rather than stale
+    pmc_kernels, pmc_note = {}, "no PMC pass of this libalgorithm.so build at this batch size under profiles/"
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        if pmc.get("rows_per_batch") == batch_rows:
+        if pmc.get("rows_per_batch") == batch_rows and pmc.get("libalgorithm_sha256_16") == library_sha() and on_gpu:
             pmc_kernels = pmc["kernels"]
+            pmc_note = f"profiles/pmc_traffic.json (build {pmc['libalgorithm_sha256_16']})"
     except (OSError, ValueError, KeyError):
         pass
     for name, k in kern_out.items():  # measured traffic rate of every kernel (not the algorithmic roofline)
@@ -220,48 +301,39 @@ def main():
         if base in pmc_kernels:
             k["hbm_bytes_per_launch"] = pmc_kernels[base]["hbm_bytes_per_launch"]
             k["hbm_GBps"] = k["hbm_bytes_per_launch"] / (k["avg_ms"] * 1e-3) / 1e9
-    roofline = None
-    if dominant:
-        name, (launches, ms) = dominant
+    roofline = chain = None
+    if kernels:
+        name, (launches, ms) = max(kernels.items(), key=lambda kv: kv[1][1])
         traffic = pmc_kernels.get(name.split("<")[0], {}).get("hbm_bytes_per_launch")
         achieved = bytes_per_row * total_rows_rank / (ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                    "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": pmc_note,
                     "algorithmic_bytes_per_launch": bytes_per_row * total_rows_rank / launches,
                     "avg_launch_ms": ms / launches, "launches": launches,
-                    "note": "algorithmic = 20 B/row of compulsory column reads (+5 validity bits/row), "
-                            "SURVEY.md 8d; traffic from rocprofv3 PMC passes is in profiles/"}
+                    "note": "algorithmic = 20 B/row of compulsory column reads (+5 validity bits/row), SURVEY.md 8d"}
+        all_ms = sum(v[1] for v in kernels.values())
+        chain = {"kernel_ms_per_step": all_ms / args.steps,
+                 "achieved": bytes_per_row * total_rows_rank / (all_ms * 1e-3) / 1e9, "unit": "GB/s",
+                 "frac": bytes_per_row * total_rows_rank / (all_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                 "note": "the same algorithmic bytes over the summed time of EVERY kernel of the step"}
 
-    # Extra leg (reported separately, never `value`): the same query through the fused extension entry
-    # point (include/ares_extensions.h) — one call per batch instead of the per-node ABI sequence.
-    fused = None
-    if not args.no_fused_leg and be.has_profiler:
-        fplan = c3_plan(use_hash_reduction=True)
-        fplan.use_fused_extension = True
-        fctx = run_shard(be, fplan, batches, local_rank, stream)
-        fctx.release()
-        sync()
-        be.profiler_enable(True)
-        t1 = time.perf_counter()
-        for k in range(args.steps):
-            fctx = run_shard(be, fplan, batches, local_rank, stream)
-            if k + 1 < args.steps:
-                fctx.release()
-        torch.cuda.synchronize()
-        felapsed = time.perf_counter() - t1
-        fk = be.profiler_report()
-        be.profiler_enable(False)
-        fgot = result_total(fctx)
-        fused = {"rows_per_sec_per_gpu": rows * args.steps / felapsed, "ms_per_step": felapsed / args.steps * 1e3,
-                 "fused_batches": fctx.fused_batches, "groups": fctx.result_size,
-                 "check_sum_of_measures": "ok" if abs(fgot - want) <= 1e-9 * max(1.0, abs(want)) else f"MISMATCH {fgot} vs {want}",
-                 "algorithmic_GBps": rows * args.steps / felapsed * bytes_per_row / 1e9,
-                 "kernels": {n: {"launches": c, "avg_ms": ms / c} for n, (c, ms) in sorted(fk.items(), key=lambda kv: -kv[1][1])}}
-        fctx.release()
-
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(batches[0], c3_plan, args.cpu_budget)
+    cpu = ref_check = None
+    legs = {}
+    if rank == 0 and world == 1 and on_gpu:
+        if not args.no_cpu_baseline:
+            cpu, ref_fetched, ref_rows = cpu_baseline(batches[0], c3_plan, args.cpu_budget)
+            if cpu is not None:  # the reference's HOST result of the sample, key by key against the same group-by
+                ref_check = check.compare_result(ref_fetched, check.exact_groups(batches, limit_first_batch=ref_rows),
+                                                 hash_identity=False)
+                ref_check["rows"] = ref_rows
+                ok = ok and ref_check["status"] == "ok"
+        if not args.no_legs:
+            common = ["--rows", str(rows), "--null-fraction", str(args.null_fraction), "--steps", "1", "--warmup", "1"]
+            big = common + ["--batch-rows", str(batch_rows)]
+            legs["unfused_abi_ARES_FUSE=0"] = run_leg({"ARES_FUSE": "0"}, big)
+            legs["eager_abi_ARES_DEFER=0"] = run_leg({"ARES_DEFER": "0"}, big)
+            legs["fused_extension"] = run_leg({}, big + ["--fused-extension"])
+            legs[f"live_batches_{LIVE_BATCH_ROWS}_rows"] = run_leg({}, common + ["--batch-rows", str(LIVE_BATCH_ROWS)])
 
     if rank == 0:
         value = rows * world * args.steps / elapsed
@@ -274,18 +346,30 @@ def main():
                                    "SUM(m float32 -> float64) via HashReduce, validity bitmaps with "
                                    f"{args.null_fraction:.0%} nulls, shard resident in HBM",
                        "rows_per_gpu": rows, "batch_rows": batch_rows, "batches": len(batches),
-                       "groups_per_shard": groups, "merged_groups": merged_groups, "rows_after_filter": kept,
-                       "parallelism": f"{world} shard(s), one per GPU" + (", RCCL all_gather merge" if (world > 1 or force_dist) else "")},
+                       "streams_per_query": n_streams,
+                       "groups_per_shard": groups, "merged_groups": merged_groups,
+                       "parallelism": f"{world} shard(s), one per GPU" + (", all_gather + re-reduce merge" if distributed else "")},
             "rows_per_sec_per_gpu": value / world,
             "algorithmic_GBps_end_to_end": value / world * bytes_per_row / 1e9,
-            "check_sum_of_measures": "ok" if check else f"MISMATCH got {got} want {want}",
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": kern_out, "fused_extension": fused,
+            "check_groups": report, "check_merged_groups": merged_check, "reference_host_check": ref_check,
+            "per_rank_ms_per_step": None if rank_times is None else [
+                {"step": t[0], "shard": t[1], "merge": t[2]} for t in rank_times],
+            "roofline": roofline, "roofline_all_kernels": chain, "cpu_baseline": cpu, "kernels": kern_out, "legs": legs,
         }
         print(json.dumps(out), flush=True)
-        if not check:
-            sys.exit(1)
-    if world > 1 or force_dist:
-        dist.destroy_process_group()
+    if distributed:
+        okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=tdev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        ok = bool(int(okt))
+        if backend is None:
+            dist.destroy_process_group()
+    for s in streams:
+        be.call("DestroyCudaStream", s, device_index)
+    if not ok:
+        if rank == 0:
+            print(f"bench.py: verification failed: {report['status']} / {ref_check}", file=sys.stderr)
+        sys.exit(1)
+    return 0
 
 
 if __name__ == "__main__":

@@ -66,6 +66,25 @@ typedef struct {
 void AresMemSetDeferralHooks(const AresDeferralHooks *hooks); /* exported by libmem.so */
 void AresMemReleaseHeld(int device, uintptr_t tag);           /* exported by libmem.so; tag 0 = every held block */
 
+/* Further notifications from libmem.so to libalgorithm.so (optional; `size` = sizeof of the caller's
+ * struct, members past it are taken as absent):
+ *   on_write          — a copy / memset is about to WRITE [ptr, ptr + bytes) (on_access is called as
+ *                       well): results whose layout libalgorithm.so remembers (partition-grouped
+ *                       HashReduce outputs) are no longer trusted;
+ *   on_stream_destroy — DestroyCudaStream, after the stream has been synchronised: per-stream caches
+ *                       and bookkeeping of libalgorithm.so are released;
+ *   trim              — libmem.so could not allocate: libalgorithm.so gives its cached temporaries back.
+ * AresMemTrimCache is the opposite direction: libalgorithm.so could not allocate, libmem.so releases its
+ * parked blocks of the device. */
+typedef struct {
+  size_t size;
+  void (*on_write)(int device, const void *ptr, size_t bytes);
+  void (*on_stream_destroy)(int device, void *stream);
+  void (*trim)(int device);
+} AresMemAuxHooks;
+void AresMemSetAuxHooks(const AresMemAuxHooks *hooks); /* exported by libmem.so */
+void AresMemTrimCache(int device);                     /* exported by libmem.so */
+
 /* Fused batch execution: filter -> dimension / measure projection -> hash reduction of ONE batch in
  * a single pass over the source columns, without the index / predicate / dimension vectors the
  * one-call-per-AST-node ABI materialises in between (~145 B/row of HBM traffic on

@@ -13,6 +13,7 @@
 #include "fast_eval.hpp"
 #include "hash_reduce_lds.hpp"
 #include "hr_kernels.hpp"
+#include "hr_rtc.hpp"
 
 namespace ares {
 
@@ -149,6 +150,16 @@ struct Regions {
   std::unique_ptr<StreamBuffer> buf;
   size_t headBytes;
 };
+
+// previous groups from which a query is taken to be high-cardinality (ARES_LEAN_MIN_GROUPS overrides:
+// 0 sends every fusable batch to the specialised DIRECT-mode kernel — tests)
+int lean_min_groups() {
+  static const int v = [] {
+    const char *e = getenv("ARES_LEAN_MIN_GROUPS");
+    return e ? atoi(e) : 16384;
+  }();
+  return v;
+}
 
 int part_bits_for(int64_t length) {
   int partBits = 0;
@@ -336,8 +347,12 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
                  prev.partBits == partBits && prev.size == prevSize;
   uint32_t *outRanges = grouped_enabled() ? take_ranges(device) : nullptr;
   MergeResult res{0, 0, 0};
+  // A query that already has more groups than an LDS table holds goes straight to DIRECT mode, with the
+  // scan kernel compiled for this plan (hr_rtc.hip); the adaptive generic kernel takes the first batch
+  // (nothing known yet), low-cardinality queries and every plan the generator does not cover.
+  const bool lean = prevSize >= lean_min_groups() && rtc_scan_available();
   for (;;) {
-    const int streams = batchRows > 0 ? grid_for(batchRows) : 0;
+    const int streams = batchRows > 0 ? (lean ? rtc_scan_grid(batchRows) : grid_for(batchRows)) : 0;
     Regions r;
     make_regions(r, partBits, length, batchRows, streams, 3, stream);
     Workspace &ws = r.ws;
@@ -359,7 +374,7 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
         ARES_LAUNCH("hr_partition4_kernel", (hr_partition4_kernel<ND, 4>), grid_for(prevSize), kThreads, stream,        \
                     prevKeys.DimValues, prevCapacity, prevValues, 0u, a, prevSize, wsPrev, 0);                         \
     }                                                                                                                  \
-    if (batchRows > 0)                                                                                                 \
+    if (batchRows > 0 && !(lean && rtc_scan_launch(device, plan, ND, static_cast<uint32_t>(prevSize), batchRows, ws, stream))) \
       ARES_LAUNCH("hr_fused_scan_kernel", hr_fused_scan_kernel<ND>, streams, kThreads, stream, plan,                   \
                   static_cast<uint32_t>(prevSize), a, batchRows, ws);                                                  \
     ARES_LAUNCH("hr_fused_merge_kernel", hr_fused_merge_kernel<ND>, numParts, kThreads, stream, plan, prevKeys.DimValues, \

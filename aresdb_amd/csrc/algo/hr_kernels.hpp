@@ -80,9 +80,11 @@ struct Workspace {
   uint4 *recA;
   uint32_t *cursorsA;    // records appended per partition
   uint64_t capA;
-  // region B: private streams [partition][workgroup][capB] of rwB-word records {row, hash, value...}
+  // region B: private streams [workgroup][partition][capB] of rwB-word records {row, hash, value...}
+  // (workgroup-major: the 512 streams one workgroup appends to lie within a few MB — a few TLB
+  // entries — while the merge reads whole runs, where a TLB miss per run does not matter)
   uint32_t *recB;
-  uint32_t *countsB;     // [partition][workgroup]
+  uint32_t *countsB;     // [workgroup][partition]
   uint32_t capB;
   int streams;           // workgroups of the partition launch that wrote B (0 = none)
   uint32_t *outCount;    // groups emitted; [1] = a region overflowed; [2] = the grouped previous result is stale
@@ -563,7 +565,7 @@ __device__ __forceinline__ void partition_body(Source &src, const AggSpec &a, in
   // every flush) is the stream cursor of partition p; no barrier, no global atomic: the wavefronts
   // run free and hide each other's latencies.
   const uint32_t capB = ws.capB;
-  const uint64_t streams = static_cast<uint64_t>(ws.streams);
+  uint32_t *myB = ws.recB + static_cast<uint64_t>(blockIdx.x) * numParts * capB * RW;  // this workgroup's streams
   while (tile < numTiles) {
     const int64_t i0 = tile * kQuadTile + 4 * static_cast<int64_t>(threadIdx.x);
     uint32_t h[4];
@@ -584,7 +586,7 @@ __device__ __forceinline__ void partition_body(Source &src, const AggSpec &a, in
     for (int j = 0; j < 4; j++) {
       if (rank[j] < capB) {  // (a full stream is reported once, by the epilogue)
         const uint32_t p = pb ? h[j] >> (32 - pb) : 0u;
-        uint32_t *dst = ws.recB + ((static_cast<uint64_t>(p) * streams + blockIdx.x) * capB + rank[j]) * RW;
+        uint32_t *dst = myB + (p * capB + rank[j]) * RW;
         if constexpr (RW == 4) {
           *reinterpret_cast<uint4 *>(dst) = make_uint4(src.row_id(i0 + j), h[j], static_cast<uint32_t>(c[j]),
                                                        static_cast<uint32_t>(c[j] >> 32));
@@ -609,7 +611,7 @@ __device__ __forceinline__ void partition_body(Source &src, const AggSpec &a, in
         *ws_overflow(ws) = 1u;
         cnt = capB;
       }
-      ws.countsB[static_cast<uint64_t>(p) * streams + blockIdx.x] = cnt;
+      ws.countsB[static_cast<uint64_t>(blockIdx.x) * numParts + p] = cnt;
     }
   }
 }
@@ -730,7 +732,7 @@ __device__ __forceinline__ void merge_body(const uint8_t *__restrict__ dimIn, si
   {
     uint32_t mine = 0;
     if (static_cast<int>(threadIdx.x) < G) {
-      mine = ws.countsB[static_cast<uint64_t>(p) * G + threadIdx.x];
+      mine = ws.countsB[static_cast<uint64_t>(threadIdx.x) * (1u << pb) + p];
       sRunCount[threadIdx.x] = mine;
     }
     if (threadIdx.x < nPrevRanges) mine += prevRanges[2 + 2 * threadIdx.x];
@@ -830,7 +832,7 @@ __device__ __forceinline__ void merge_body(const uint8_t *__restrict__ dimIn, si
         while (g < G) {
           const uint32_t cnt = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(sRunCount[g])));
           if (offB < cnt) {
-            c.ptr = ws.recB + ((static_cast<uint64_t>(p) * G + g) * capB + offB) * RWB;
+            c.ptr = ws.recB + ((static_cast<uint64_t>(g) * (1u << pb) + p) * capB + offB) * RWB;
             c.rem = cnt - offB;
             offB += kChunk;
             break;

@@ -1263,9 +1263,18 @@ static void flush_deferred_impl(int device, const ByteRange *limboA, const ByteR
       ++it;
     }
   }
-  for (;;) {  // pending compactions: whoever comes next may read the index vector
+  // pending compactions: whoever comes next may read the index vector — except where only work that a
+  // HashReduce skipped would read it (the previous batch of the query's other stream): that stays
+  // dormant with its skipped work and dies with it
+  auto dormant = [&](const uint32_t *idx) {
+    bool skipped = false, queued = false;
+    for (auto &kv : g_limbo) skipped = skipped || kv.second.idx == idx;
+    for (auto &kv : g_pending) queued = queued || (kv.second.jobs.count && kv.second.idx == idx);
+    return skipped && !queued;
+  };
+  for (;;) {
     auto c = g_compactions.begin();
-    while (c != g_compactions.end() && c->second.device != device) ++c;
+    while (c != g_compactions.end() && (c->second.device != device || dormant(c->first))) ++c;
     if (c == g_compactions.end()) break;
     run_compaction(c->first);
   }

@@ -386,7 +386,7 @@ def test_pending_transforms_are_consumed_by_hash_reduce(variant, native):
     want, _ = smoke.run_query(H.oracle_backend(), plan, data)
     smoke.compare_results(got, want)
     if os.environ.get("ARES_FUSE", "1") != "0" and os.environ.get("ARES_DEFER", "1") != "0":
-        assert any(k.startswith("hr_fused_scan_kernel") for k in kernels), kernels
+        assert any(k.startswith("hr_fused_scan_kernel") or k.startswith("hr_scan_rtc") for k in kernels), kernels
         assert not any(k.startswith("transform_") for k in kernels), kernels
 
 
@@ -444,7 +444,7 @@ def test_skipped_transform_outputs_materialise_on_copy():
     assert np.array_equal(got["in_dims"], want["in_dims"])
     assert np.array_equal(got["in_measures"], want["in_measures"])
     if os.environ.get("ARES_FUSE", "1") != "0" and os.environ.get("ARES_DEFER", "1") != "0":
-        assert any(k.startswith("hr_fused_scan_kernel") for k in kernels), kernels
+        assert any(k.startswith("hr_fused_scan_kernel") or k.startswith("hr_scan_rtc") for k in kernels), kernels
         assert any(k.startswith("transform_") for k in kernels), kernels
 
 
@@ -542,8 +542,12 @@ def test_query_results_do_not_depend_on_the_fusion_switches():
     import sys
     tests = ["tests/test_executor.py::test_c3_shape_matches_oracle", "tests/test_executor.py::test_native_driver_matches_python_executor",
              "tests/test_executor.py::test_pending_transforms_are_consumed_by_hash_reduce"]
-    for env in ({"ARES_FUSE": "0"}, {"ARES_DEFER": "0"}, {"ARES_LAZY_COMPACT": "0"}):
-        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-k", "hip or cpp_driver or python_mirror", *tests],
+    tests_lean = tests + ["tests/test_executor.py::test_fused_extension_matches_unfused_sequence"]
+    for env in ({"ARES_FUSE": "0"}, {"ARES_DEFER": "0"}, {"ARES_LAZY_COMPACT": "0"}, {"ARES_GROUPED": "0"}, {"ARES_RTC": "0"},
+                {"ARES_LEAN_MIN_GROUPS": "0"}):
+        if "ARES_LEAN_MIN_GROUPS" in env:  # every fusable batch through the run-time compiled DIRECT-mode scan kernel
+            tests = tests_lean
+        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-k", "hip or cpp_driver or python_mirror or fused_extension", *tests],
                            cwd=H.ROOT, env={**os.environ, **env}, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, (env, r.stdout[-2000:], r.stderr[-1000:])
 

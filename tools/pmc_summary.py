@@ -8,9 +8,9 @@ calls = defaultdict(lambda: defaultdict(int))
 for f in glob.glob(os.path.join(root, "pass*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         name = r.get("Kernel_Name", "")
-        if "ares::" not in name:
+        if "ares::" not in name and "hr_scan_rtc" not in name:
             continue
-        short = name.split("ares::")[1].replace("(anonymous namespace)::", "").split("(")[0].split("<")[0]
+        short = (name.split("ares::")[1] if "ares::" in name else name).replace("(anonymous namespace)::", "").split("(")[0].split("<")[0]
         acc[short][r["Counter_Name"]] += float(r["Counter_Value"])
         calls[short][r["Counter_Name"]] += 1
 counters = sorted({c for k in acc.values() for c in k})
@@ -39,4 +39,7 @@ for k in sorted(acc):
               "hbm_bytes_per_launch": 2 * fpl * 1024 + wpl * 1024,
               "note": "2 x FETCH_SIZE (gfx950 counts 64 B per 128-B request on wide reads) + WRITE_SIZE"}
 rows = int(sys.argv[2]) if len(sys.argv) > 2 else 67108864
-json.dump({"rows_per_batch": rows, "kernels": out}, open(os.path.join(root, "traffic.json"), "w"), indent=1)
+import hashlib
+lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "aresdb_amd", "lib", "libalgorithm.so")
+sha = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16]
+json.dump({"rows_per_batch": rows, "libalgorithm_sha256_16": sha, "kernels": out}, open(os.path.join(root, "traffic.json"), "w"), indent=1)

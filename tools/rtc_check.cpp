@@ -1,0 +1,55 @@
+// Builds the C3 plan by hand, prints the hiprtc source the library generates for it, compiles it for
+// gfx950 (no GPU needed) and writes the code object next to it:  tools/bin/rtc_check [out-prefix]
+// Links against aresdb_amd/lib/libalgorithm.so (ares::rtc_scan_source is an ordinary exported symbol).
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "hash_reduce_lds.hpp"
+#include "hr_rtc.hpp"
+
+using namespace ares;
+
+static FastOperands col(int akind) {
+  FastOperands f;
+  memset(&f, 0, sizeof(f));
+  f.akind = akind; f.arity = 1; f.functor = Noop; f.I = akind; f.rk = akind; f.bkind = akind;
+  return f;
+}
+
+int main(int argc, char **argv) {
+  FusedPlanD p;
+  memset(&p, 0, sizeof(p));
+  p.numCols = 5;
+  for (int c = 0; c < 5; c++) { p.cols[c].vals = reinterpret_cast<const uint32_t *>(0x1000); p.cols[c].nulls = reinterpret_cast<const uint8_t *>(0x2000); }
+  p.numFilters = 1;
+  p.filters[0].f = col(K_U32); p.filters[0].f.arity = 2; p.filters[0].f.functor = LessThan; p.filters[0].f.bkind = K_I32;
+  p.filters[0].f.bbits = 90; p.filters[0].f.bok = 1; p.filters[0].col = 1; p.filters[0].outKind = K_BOOL;
+  p.dims[0].f = col(K_U32); p.dims[0].f.arity = 2; p.dims[0].f.functor = Floor; p.dims[0].f.bkind = K_I32; p.dims[0].f.bbits = 3600;
+  p.dims[0].f.bok = 1; p.dims[0].f.divLike = 1; p.dims[0].col = 0; p.dims[0].outKind = K_U32;
+  for (int d = 1; d < 4; d++) { p.dims[d].f = col(K_U32); p.dims[d].col = d; p.dims[d].outKind = K_U32; }
+  p.measure.f = col(K_F32); p.measure.col = 4; p.measure.outKind = K_F32;
+  p.measureDtype = Float64; p.measureWidth = 8; p.identity = 0;
+  const std::string src = rtc_scan_source(p, 4, 9);
+  if (src.empty()) { puts("unsupported plan"); return 2; }
+  const std::string prefix = argc > 1 ? argv[1] : "/tmp/hr_scan_rtc";
+  std::ofstream(prefix + ".hip") << src;
+  hiprtcProgram prog;
+  if (hiprtcCreateProgram(&prog, src.c_str(), "hr_scan_rtc.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return 3;
+  const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics"};
+  const hiprtcResult rc = hiprtcCompileProgram(prog, 4, opts);
+  size_t n = 0; hiprtcGetProgramLogSize(prog, &n);
+  std::string log(n, 0); if (n) hiprtcGetProgramLog(prog, &log[0]);
+  printf("compile rc %d\n%s\n", static_cast<int>(rc), log.c_str());
+  if (rc != HIPRTC_SUCCESS) return 4;
+  size_t cs = 0; hiprtcGetCodeSize(prog, &cs);
+  std::vector<char> code(cs); hiprtcGetCode(prog, code.data());
+  std::ofstream(prefix + ".co", std::ios::binary).write(code.data(), static_cast<std::streamsize>(cs));
+  printf("code object %zu bytes -> %s.co\n", cs, prefix.c_str());
+  return 0;
+}

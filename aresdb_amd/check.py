@@ -183,3 +183,22 @@ def fetched_from_columnar(dims, measures, size, capacity, nd=4):
     values = [dims[4 * capacity * d: 4 * capacity * d + 4 * size].copy() for d in range(nd)]
     valids = [dims[4 * capacity * nd + capacity * d: 4 * capacity * nd + capacity * d + size].copy() for d in range(nd)]
     return values, valids, np.asarray(measures, np.uint8)[:8 * size].copy()
+
+
+def hash_groups_of_rows(values, valids, measures):
+    """Groups as HashReduce forms them over explicit rows (4 uint32 dimension columns, their validity
+    bytes, float64 measures; rows in input order): {representative dimension row -> sum}.  Distinct
+    rows with equal 32-bit hashes merge under the first one."""
+    h = murmur3_32_rows(values, valids)
+    order = np.argsort(h, kind="stable")  # stable: input order inside a hash
+    hs = h[order]
+    head = np.ones(len(hs), bool)
+    head[1:] = hs[1:] != hs[:-1]
+    seg = np.cumsum(head) - 1
+    sums = np.zeros(int(seg[-1]) + 1 if len(seg) else 0, np.float64)
+    np.add.at(sums, seg, np.asarray(measures, np.float64)[order])
+    rep = order[head]
+    out = {}
+    for i, r in enumerate(rep):
+        out[tuple((int(values[d][r]), int(valids[d][r])) for d in range(4))] = sums[i]
+    return out

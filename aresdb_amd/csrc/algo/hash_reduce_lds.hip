@@ -50,7 +50,7 @@ __global__ __launch_bounds__(kThreads) void hr_merge_kernel(const uint8_t *__res
   merge_body<ND4, false, RWB>(dimIn, capacity, inValues, dimOut, L, capacity, outputValues, a, ws, nullptr, prevSize);
 }
 
-template <int ND>
+template <int ND, int RWB>
 __global__ __launch_bounds__(kThreads) void hr_fused_merge_kernel(FusedPlanD plan, const uint8_t *__restrict__ prevDims,
                                                                   size_t prevCapacity,
                                                                   const uint8_t *__restrict__ prevValues, uint32_t prevSize,
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(kThreads) void hr_fused_merge_kernel(FusedPlanD pla
                                                                   uint8_t *__restrict__ outputValues, AggSpec a, Workspace ws) {
   DimLayoutD L;  // unused by the all-4-byte emission
   L.numDims = ND;
-  merge_body<ND, true, 3>(prevDims, prevCapacity, prevValues, dimOut, L, outCapacity, outputValues, a, ws, &plan, prevSize);
+  merge_body<ND, true, RWB>(prevDims, prevCapacity, prevValues, dimOut, L, outCapacity, outputValues, a, ws, &plan, prevSize);
 }
 
 // ---- partition-grouped results ---------------------------------------------------------------------
@@ -174,7 +174,8 @@ int grid_for(int64_t rows) {
 
 // rowsA: rows that may end up as region-A records (TABLE-mode flushes, ungrouped previous groups);
 // rowsB / streams / rwB: rows, workgroups and record width of the launch that may write region B
-void make_regions(Regions &r, int partBits, int64_t rowsA, int64_t rowsB, int streams, int rwB, hipStream_t stream) {
+void make_regions(Regions &r, int partBits, int64_t rowsA, int64_t rowsB, int streams, int rwB, hipStream_t stream,
+                  bool lines = false) {
   const int numParts = 1 << partBits;
   Workspace &ws = r.ws;
   memset(&ws, 0, sizeof(ws));
@@ -184,11 +185,17 @@ void make_regions(Regions &r, int partBits, int64_t rowsA, int64_t rowsB, int st
   // merge workgroups, which stream their regions in lockstep, do not camp on the same HBM channels
   ws.capA = ((2ull * (static_cast<uint64_t>(rowsA) / numParts) + 2 * kSlots) | 63ull) + 18;
   ws.capB = 0;
-  if (streams > 0)
-    ws.capB = static_cast<uint32_t>(((2ull * (static_cast<uint64_t>(rowsB) / (static_cast<uint64_t>(numParts) * streams)) + 64) | 15ull) + 6);
+  ws.lineRecords = lines ? 8 : 0;
+  if (streams > 0) {
+    const uint64_t mean = static_cast<uint64_t>(rowsB) / (static_cast<uint64_t>(numParts) * streams);
+    if (lines)  // whole 128-byte lines of 8 records; an odd number of lines per stream keeps the strides off powers of two
+      ws.capB = static_cast<uint32_t>(((2 * mean + 64 + 7) / 8 * 8) | 8ull);
+    else
+      ws.capB = static_cast<uint32_t>(((2 * mean + 64) | 15ull) + 6);
+  }
   const size_t headBytes = (sizeof(uint32_t) * (numParts + 4) + 255) / 256 * 256;
   const size_t countsBytes = (sizeof(uint32_t) * static_cast<size_t>(numParts) * (streams > 0 ? streams : 1) + 255) / 256 * 256;
-  const size_t aBytes = sizeof(uint4) * ws.capA * numParts;
+  const size_t aBytes = (sizeof(uint4) * ws.capA * numParts + 255) / 256 * 256;
   const size_t bBytes = (sizeof(uint32_t) * rwB * static_cast<size_t>(ws.capB) * numParts * (streams > 0 ? streams : 0) + 255) / 256 * 256;
   r.buf.reset(new StreamBuffer(headBytes + countsBytes + aBytes + bBytes + 256, stream));
   uint8_t *base = r.buf->as<uint8_t>();
@@ -202,12 +209,12 @@ void make_regions(Regions &r, int partBits, int64_t rowsA, int64_t rowsB, int st
 }
 
 struct MergeResult {
-  uint32_t groups, overflow, stale;
+  uint32_t groups, overflow, stale, needGeneric;
 };
 MergeResult read_result(const Workspace &ws, hipStream_t stream) {
-  uint32_t w[3] = {0, 0, 0};
-  read_back_u32(ws.outCount, w, 3, stream);
-  return MergeResult{w[0], w[1], w[2]};
+  uint32_t w[4] = {0, 0, 0, 0};
+  read_back_u32(ws.outCount, w, 4, stream);
+  return MergeResult{w[0], w[1], w[2], w[3]};
 }
 
 }  // namespace
@@ -254,7 +261,7 @@ int hash_reduce_lds(int device, const DimensionVector &inputKeys, const uint8_t 
   bool grouped = all4 && grouped_lookup(device, inputKeys.DimValues, inputValues, capacity, L.numDims, a.width, &prev) &&
                  prev.partBits == partBits && prev.size > 0 && prev.size <= length;
   uint32_t *outRanges = (all4 && grouped_enabled()) ? take_ranges(device) : nullptr;
-  MergeResult res{0, 0, 0};
+  MergeResult res{0, 0, 0, 0};
   for (;;) {
     const int start = grouped ? prev.size : 0;
     const int rows = length - start;
@@ -346,15 +353,16 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
   bool grouped = prevSize > 0 && grouped_lookup(device, prevKeys.DimValues, prevValues, prevCapacity, nd, mw, &prev) &&
                  prev.partBits == partBits && prev.size == prevSize;
   uint32_t *outRanges = grouped_enabled() ? take_ranges(device) : nullptr;
-  MergeResult res{0, 0, 0};
+  MergeResult res{0, 0, 0, 0};
   // A query that already has more groups than an LDS table holds goes straight to DIRECT mode, with the
   // scan kernel compiled for this plan (hr_rtc.hip); the adaptive generic kernel takes the first batch
   // (nothing known yet), low-cardinality queries and every plan the generator does not cover.
-  const bool lean = prevSize >= lean_min_groups() && rtc_scan_available();
+  void *lean = nullptr;
+  if (batchRows > 0 && prevSize >= lean_min_groups() && rtc_scan_available()) lean = rtc_scan_lookup(device, plan, nd, partBits);
   for (;;) {
     const int streams = batchRows > 0 ? (lean ? rtc_scan_grid(batchRows) : grid_for(batchRows)) : 0;
     Regions r;
-    make_regions(r, partBits, length, batchRows, streams, 3, stream);
+    make_regions(r, partBits, length, batchRows, streams, lean ? 4 : 3, stream, lean != nullptr);
     Workspace &ws = r.ws;
     ws.widen.mode = mw == 8 ? 1 : 0;
     ws.widen.rk = plan.measure.f.rk;
@@ -364,6 +372,8 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
     if (outRanges) hip_check(hipMemsetAsync(outRanges, 0, kRangesBytes, stream), "hipMemsetAsync");
     Workspace wsPrev = ws;  // previous groups that are not grouped by partition: TABLE-mode pass into region A
     wsPrev.streams = 0;
+    // the specialised merge reads region B and grouped previous results only
+    void *leanMerge = (lean && (prevSize == 0 || grouped)) ? rtc_merge_lookup(device, plan, nd, partBits, a, ws.widen) : nullptr;
 #define ARES_FUSED_CASE(ND)                                                                                            \
   case ND:                                                                                                             \
     if (prevSize > 0 && !grouped) {                                                                                    \
@@ -374,17 +384,44 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
         ARES_LAUNCH("hr_partition4_kernel", (hr_partition4_kernel<ND, 4>), grid_for(prevSize), kThreads, stream,        \
                     prevKeys.DimValues, prevCapacity, prevValues, 0u, a, prevSize, wsPrev, 0);                         \
     }                                                                                                                  \
-    if (batchRows > 0 && !(lean && rtc_scan_launch(device, plan, ND, static_cast<uint32_t>(prevSize), batchRows, ws, stream))) \
+    if (batchRows > 0 && lean)                                                                                         \
+      rtc_scan_launch(lean, plan, static_cast<uint32_t>(prevSize), batchRows, ws, stream);                             \
+    else if (batchRows > 0)                                                                                            \
       ARES_LAUNCH("hr_fused_scan_kernel", hr_fused_scan_kernel<ND>, streams, kThreads, stream, plan,                   \
                   static_cast<uint32_t>(prevSize), a, batchRows, ws);                                                  \
-    ARES_LAUNCH("hr_fused_merge_kernel", hr_fused_merge_kernel<ND>, numParts, kThreads, stream, plan, prevKeys.DimValues, \
-                prevCapacity, prevValues, static_cast<uint32_t>(prevSize), outKeys.DimValues, outCapacity, outValues, a, ws); \
+    if (leanMerge)                                                                                                     \
+      rtc_merge_launch(leanMerge, plan, prevKeys.DimValues, prevCapacity, prevValues, static_cast<uint32_t>(prevSize),  \
+                       outKeys.DimValues, outCapacity, outValues, ws, stream);                                         \
+    else if (lean)                                                                                                     \
+      ARES_LAUNCH("hr_fused_merge_kernel", (hr_fused_merge_kernel<ND, 4>), numParts, kThreads, stream, plan,            \
+                  prevKeys.DimValues, prevCapacity, prevValues, static_cast<uint32_t>(prevSize), outKeys.DimValues,    \
+                  outCapacity, outValues, a, ws);                                                                      \
+    else                                                                                                               \
+      ARES_LAUNCH("hr_fused_merge_kernel", (hr_fused_merge_kernel<ND, 3>), numParts, kThreads, stream, plan,            \
+                  prevKeys.DimValues, prevCapacity, prevValues, static_cast<uint32_t>(prevSize), outKeys.DimValues,    \
+                  outCapacity, outValues, a, ws);                                                                      \
     break;
     switch (nd) {
       ARES_FUSED_CASE(1) ARES_FUSED_CASE(2) ARES_FUSED_CASE(3) ARES_FUSED_CASE(4)
     }
-#undef ARES_FUSED_CASE
     res = read_result(ws, stream);
+    if (leanMerge && res.needGeneric && !res.overflow && !(grouped && res.stale)) {
+      // a partition holds more groups than one LDS table: the generic multi-round merge over the same records
+      hip_check(hipMemsetAsync(ws.outCount, 0, 4 * sizeof(uint32_t), stream), "hipMemsetAsync");
+      if (outRanges) hip_check(hipMemsetAsync(outRanges, 0, kRangesBytes, stream), "hipMemsetAsync");
+      switch (nd) {
+#define ARES_FUSED_REMERGE(ND)                                                                                         \
+  case ND:                                                                                                             \
+    ARES_LAUNCH("hr_fused_merge_kernel", (hr_fused_merge_kernel<ND, 4>), numParts, kThreads, stream, plan,              \
+                prevKeys.DimValues, prevCapacity, prevValues, static_cast<uint32_t>(prevSize), outKeys.DimValues,      \
+                outCapacity, outValues, a, ws);                                                                        \
+    break;
+        ARES_FUSED_REMERGE(1) ARES_FUSED_REMERGE(2) ARES_FUSED_REMERGE(3) ARES_FUSED_REMERGE(4)
+#undef ARES_FUSED_REMERGE
+      }
+      res = read_result(ws, stream);
+    }
+#undef ARES_FUSED_CASE
     if (grouped && res.stale) {
       grouped_note_write(device, prevKeys.DimValues, 5ull * nd * prevCapacity);
       grouped = false;

@@ -87,6 +87,9 @@ struct Workspace {
   uint32_t *countsB;     // [workgroup][partition]
   uint32_t capB;
   int streams;           // workgroups of the partition launch that wrote B (0 = none)
+  // 16-byte B records {row, hash, 4-byte carried measure, 0} written in whole 128-byte lines by the
+  // run-time compiled scan (hr_rtc.hip); streams end with null records (row = ~0) that pad the last line
+  int lineRecords;
   uint32_t *outCount;    // groups emitted; [1] = a region overflowed; [2] = the grouped previous result is stale
   int partBits;
   Widen widen;
@@ -849,8 +852,16 @@ __device__ __forceinline__ void merge_body(const uint8_t *__restrict__ dimIn, si
           const uint32_t i = static_cast<uint32_t>(k) * 64u + lane;
           if (i < take && in_round(s.w[k][1])) {
             uint64_t v;
-            if constexpr (RWB == 4) v = (static_cast<uint64_t>(s.w[k][3]) << 32) | s.w[k][2];
-            else v = widen_value(ws.widen, s.w[k][2]);
+            if constexpr (RWB == 4) {
+              if (ws.lineRecords) {
+                if (s.w[k][0] == 0xFFFFFFFFu) continue;  // padding of a stream's last line
+                v = widen_value(ws.widen, s.w[k][2]);
+              } else {
+                v = (static_cast<uint64_t>(s.w[k][3]) << 32) | s.w[k][2];
+              }
+            } else {
+              v = widen_value(ws.widen, s.w[k][2]);
+            }
             merge_record(sKeys, sVals, &sClaimed, &sOverflow, s.w[k][0], s.w[k][1], v, a);
           }
         }

@@ -8,12 +8,14 @@
 // bucket division itself), hiprtc compiles it for gfx950 (~0.5 s, cached per plan signature and
 // device for the life of the process) and the result is launched through the module API.
 //
-// The generated kernel covers DIRECT mode only (rows -> 12-byte records in the workgroup's private
-// streams, hr_kernels.hpp): the host uses it when the query is known to have more groups than an LDS
-// table holds; otherwise, and for every plan outside the supported shapes, the generic kernel runs.
-// Wavefronts work independently (no barrier between prologue and epilogue): each walks its own
-// 256-row tiles with two register buffers, so a tile's loads are in flight while the previous tile
-// is evaluated, hashed and scattered.
+// The generated scan covers DIRECT mode only (every row becomes a record; see hr_kernels.hpp for the
+// modes): the host uses it when the query is known to have more groups than an LDS table holds;
+// otherwise, and for every plan outside the supported shapes, the generic adaptive kernel runs.  Its
+// write path is what matters (tools/ubench_scatter.hip, profiles/r2_ubench_write_path*.txt): reading
+// and hashing the columns runs at 6 TB/s, but a CU retires only one scattered small store per ~4.5
+// cycles and HBM write time follows the number of 64-byte write requests, so records are counting-
+// sorted by partition in LDS and leave the CU only as whole aligned 128-byte lines of 8 records.
+// The matching merge (generate_merge below) is specialised the same way.
 //
 // Supported shapes (everything else: generic kernel) — exactly the fast paths of eval_quad /
 // compare_tile in fast_eval.hpp, so results are bit-identical:
@@ -206,15 +208,14 @@ std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t null
       o << "  r.win[" << c << "] = 0xFFFFu;\n";
   }
   o << "}\n";
-  // ---- evaluate + hash + scatter one quad ----
-  o << "__device__ __forceinline__ void process(const Raw &r, const Args &a, u32 i0, u32 *sCursor, u32 *myB) {\n"
+  // ---- evaluate + hash one quad: hash, carried measure bits and "takes part" of its four rows ----
+  o << "__device__ __forceinline__ void eval4(const Raw &r, const Args &a, u32 i0, u32 (&hh)[4], u32 (&cv)[4], u32 (&alive)[4]) {\n"
        "  u32 okc[NC];\n";
   for (int c = 0; c < nc; c++) {
     if (nullMask & (1u << c)) o << "  okc[" << c << "] = (r.win[" << c << "] >> ((i0 + a.bitOff[" << c << "]) & 7u)) & 0xFu;\n";
     else o << "  okc[" << c << "] = 0xFu;\n";
   }
-  o << "  u32 hh[4], cv[4], alive[4];\n"
-       "#pragma unroll\n"
+  o << "#pragma unroll\n"
        "  for (int j = 0; j < 4; j++) {\n"
        "    u32 keep = (int)(i0 + j) < a.length ? 1u : 0u;\n";
   for (int k = 0; k < plan.numFilters; k++) {
@@ -250,59 +251,412 @@ std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t null
       if (!plain_store(e.f.rk, target)) return "";
       o << "      cv[j] = okb ? x : " << hex(static_cast<uint32_t>(plan.identity)) << ";\n";
     }
-    o << "    }\n  }\n";
+    o << "    }\n  }\n}\n";
   }
-  o << "  u32 rank[4];\n"
+  // ---- the kernel.  One 1024-lane workgroup per CU walks 4096-row tiles.  The write path is what
+  // bounds this kernel (tools/ubench_scatter.hip): a CU retires one scattered small store per ~4.5
+  // cycles, and HBM write time follows the number of 64-byte write requests — whole aligned 128-byte
+  // lines cost half of anything partial.  So records (16 bytes: row, hash, 4-byte measure, 0) are
+  // counting-sorted by partition in LDS and ONLY whole lines of 8 records leave the CU, each written
+  // by 8 adjacent lanes with one store; the < 8 records a partition has left over stay in LDS and go
+  // first in the next tile's lines.  Streams are private to the workgroup: no global atomics.
+  o << "#define T 4096u\n#define SR (T + NP * 7u)\n"
+       "__device__ __forceinline__ u32 lane_up(u32 v, u32 lane, u32 off) { return (u32)__builtin_amdgcn_ds_bpermute((int)((lane - off) << 2), (int)v); }\n"
+       "extern \"C\" __global__ void __launch_bounds__(1024) hr_scan_rtc(Args a) {\n"
+       "  __shared__ u32 sRow[SR], sHash[SR], sVal[SR];\n"
+       "  __shared__ u32 sLeft[NP * 21];\n"
+       "  __shared__ u32 sCount[2][NP];\n"
+       "  __shared__ u32 sStart[NP], sLeftN[NP], sCursor[NP];\n"
+       "  __shared__ u32 sLines[SR / 8u + 1u];\n"
+       "  __shared__ u32 sWave[16];\n"
+       "  __shared__ u32 sTotalLines;\n"
+       "  const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;\n"
+       "  for (u32 p = tid; p < NP; p += 1024u) { sCount[0][p] = 0u; sCount[1][p] = 0u; sLeftN[p] = 0u; sCursor[p] = 0u; }\n"
+       "  __syncthreads();\n"
+       "  u32 *myB = a.recB + (u64)blockIdx.x * NP * a.capB * 4u;\n"
+       "  const u32 numTiles = ((u32)a.length + T - 1u) / T, fullTiles = (u32)a.length / T;\n"
+       "  u32 tile = blockIdx.x, par = 0u;\n"
+       "  Raw R;\n"
+       "  if (tile < fullTiles) load_full(R, a, tile * T + tid * 4u);\n"
+       "  else if (tile < numTiles) load_tail(R, a, tile * T + tid * 4u);\n"
+       "  while (tile < numTiles) {\n"
+       "    const u32 i0 = tile * T + tid * 4u;\n"
+       "    u32 hh[4], cv[4], alive[4], rank[4];\n"
+       "    eval4(R, a, i0, hh, cv, alive);\n"
+       "    const u32 next = tile + gridDim.x;\n"
+       "    if (next < fullTiles) load_full(R, a, next * T + tid * 4u);\n"  // in flight during the sort below
+       "    else if (next < numTiles) load_tail(R, a, next * T + tid * 4u);\n"
+       "    u32 *cnt = sCount[par];\n"
        "#pragma unroll\n"
-       "  for (int j = 0; j < 4; j++) {\n"
-       "    rank[j] = a.capB;\n"
-       "    if (alive[j]) rank[j] = __hip_atomic_fetch_add(&sCursor[PB ? hh[j] >> (32 - (PB ? PB : 1)) : 0u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
-       "  }\n"
-       "#pragma unroll\n"
-       "  for (int j = 0; j < 4; j++) {\n"
-       "    if (rank[j] < a.capB) {\n"
-       "      const u32 p = PB ? hh[j] >> (32 - (PB ? PB : 1)) : 0u;\n"
-       "      Rec3 rec; rec.row = a.rowBase + i0 + j; rec.hash = hh[j]; rec.val = cv[j];\n"
-       "      *reinterpret_cast<Rec3 *>(myB + (p * a.capB + rank[j]) * 3u) = rec;\n"
+       "    for (int j = 0; j < 4; j++) {\n"
+       "      rank[j] = 0u;\n"
+       "      if (alive[j]) rank[j] = __hip_atomic_fetch_add(&cnt[PB ? hh[j] >> (32 - (PB ? PB : 1)) : 0u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
        "    }\n"
+       "    __syncthreads();\n"
+       // exclusive scans of (new records, whole lines) per partition, packed in one word
+       "    u32 myCount = 0u, myLeft = 0u;\n"
+       "    if (tid < NP) { myCount = cnt[tid]; myLeft = sLeftN[tid]; }\n"
+       "    const u32 myHave = myCount + myLeft, myLines = myHave >> 3;\n"
+       "    const u32 packed = (myCount << 16) | myLines;\n"
+       "    u32 incl = packed;\n"
+       "#pragma unroll\n"
+       "    for (u32 off = 1u; off < 64u; off <<= 1) { const u32 t = lane_up(incl, lane, off); if (lane >= off) incl += t; }\n"
+       "    if (lane == 63u) sWave[wave] = incl;\n"
+       "    __syncthreads();\n"
+       "    u32 before = 0u;\n"
+       "    for (u32 w = 0u; w < wave; w++) before += sWave[w];\n"
+       "    const u32 excl = before + incl - packed;\n"
+       "    const u32 myStart = excl >> 16, myLineStart = excl & 0xFFFFu;\n"
+       "    if (tid < NP) {\n"
+       "      sStart[tid] = myStart;\n"
+       "      for (u32 c = 0u; c < myLines; c++) sLines[myLineStart + c] = tid | (c << 9);\n"
+       "      if (tid == NP - 1u) sTotalLines = myLineStart + myLines;\n"
+       "    }\n"
+       "    __syncthreads();\n"
+       "#pragma unroll\n"
+       "    for (int j = 0; j < 4; j++) {\n"
+       "      if (alive[j]) {\n"
+       "        const u32 pos = sStart[PB ? hh[j] >> (32 - (PB ? PB : 1)) : 0u] + rank[j];\n"
+       "        sRow[pos] = a.rowBase + i0 + j; sHash[pos] = hh[j]; sVal[pos] = cv[j];\n"
+       "      }\n"
+       "    }\n"
+       "    __syncthreads();\n"
+       // whole lines: 8 adjacent lanes write the 8 records of one aligned 128-byte line with one store
+       "    const u32 totalLines = sTotalLines;\n"
+       "    for (u32 L = tid >> 3; L < totalLines; L += 128u) {\n"
+       "      const u32 e = sLines[L], p = e & 511u, idx = (e >> 9) * 8u + (tid & 7u);\n"
+       "      const u32 left = sLeftN[p];\n"
+       "      u32 r0, r1, r2;\n"
+       "      if (idx < left) { const u32 *s = sLeft + (p * 7u + idx) * 3u; r0 = s[0]; r1 = s[1]; r2 = s[2]; }\n"
+       "      else { const u32 k = sStart[p] + idx - left; r0 = sRow[k]; r1 = sHash[k]; r2 = sVal[k]; }\n"
+       "      const u32 at = sCursor[p] + idx;\n"
+       "      if (at < a.capB) *reinterpret_cast<uint4 *>(myB + ((u64)p * a.capB + at) * 4u) = make_uint4(r0, r1, r2, 0u);\n"
+       "    }\n"
+       "    __syncthreads();\n"
+       // what is left of each partition (< 8 records) moves to its LDS remainder; cursors advance
+       "    if (tid < NP) {\n"
+       "      const u32 rem = myHave & 7u;\n"
+       "      if (myLines) {\n"
+       "        for (u32 k = 0u; k < rem; k++) { const u32 src = myStart + myLines * 8u + k - myLeft; u32 *d = sLeft + (tid * 7u + k) * 3u; d[0] = sRow[src]; d[1] = sHash[src]; d[2] = sVal[src]; }\n"
+       "      } else {\n"
+       "        for (u32 k = 0u; k < myCount; k++) { const u32 src = myStart + k; u32 *d = sLeft + (tid * 7u + myLeft + k) * 3u; d[0] = sRow[src]; d[1] = sHash[src]; d[2] = sVal[src]; }\n"
+       "      }\n"
+       "      sLeftN[tid] = rem;\n"
+       "      u32 cur = sCursor[tid] + myLines * 8u;\n"
+       "      if (cur > a.capB) { *a.overflow = 1u; cur = a.capB; }\n"
+       "      sCursor[tid] = cur;\n"
+       "      cnt[tid] = 0u;\n"  // this counter set is used again two tiles from now
+       "    }\n"
+       "    par ^= 1u;\n"
+       "    tile = next;\n"
+       "  }\n"
+       "  __syncthreads();\n"
+       // the remainders go out as one last line each, padded with null records (row = ~0) the merge skips
+       "  for (u32 p = tid >> 3; p < NP; p += 128u) {\n"
+       "    const u32 left = sLeftN[p], j = tid & 7u, cur = sCursor[p];\n"
+       "    const bool fits = cur + 8u <= a.capB;\n"
+       "    if (left && fits) {\n"
+       "      uint4 rec = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);\n"
+       "      if (j < left) { const u32 *s = sLeft + (p * 7u + j) * 3u; rec = make_uint4(s[0], s[1], s[2], 0u); }\n"
+       "      *reinterpret_cast<uint4 *>(myB + ((u64)p * a.capB + cur + j) * 4u) = rec;\n"
+       "    }\n"
+       "    if (left && !fits) *a.overflow = 1u;\n"
+       "    if (j == 0u) a.countsB[(u64)blockIdx.x * NP + p] = (left && fits) ? cur + 8u : cur;\n"
        "  }\n"
        "}\n";
-  // ---- the kernel: every wavefront walks its own 256-row tiles, two register buffers ----
-  o << "extern \"C\" __global__ void __launch_bounds__(1024) hr_scan_rtc(Args a) {\n"
-       "  __shared__ u32 sCursor[NP];\n"
-       "  for (int p = threadIdx.x; p < NP; p += 1024) sCursor[p] = 0u;\n"
+  return o.str();
+}
+
+
+// ---- specialised merge ------------------------------------------------------------------------------
+// One workgroup per partition, like merge_body<ND, true, 4> (hr_kernels.hpp) for the case the
+// specialised scan produces: 16-byte line records in region B only, previous groups (if any) read
+// from their partition-grouped ranges, the whole hash range in one round.  What changes is the cost
+// per record: the aggregate, the widening of the carried measure and the dimension expressions are
+// literals (the generic kernel spends ~90 VALU + ~120 SALU instructions per record on dispatch), and
+// the four records a lane holds are probed together — four LDS key reads in flight, then one
+// non-returning LDS atomic each for records that meet their group in the first slot (all of them,
+// once the groups exist); only misses walk the probe loop.  A partition with more groups than the
+// table holds raises a flag and the host runs the generic multi-round merge instead.
+struct RtcMergeArgs {  // mirrors `struct MArgs` of the generated source
+  const uint32_t *vals[kFusedCols];
+  const uint8_t *nulls[kFusedCols];
+  const uint32_t *recB;
+  const uint32_t *countsB;
+  const uint32_t *prevRanges;
+  const uint8_t *prevDims;
+  const uint8_t *prevValues;
+  uint8_t *dimOut;
+  uint8_t *outValues;
+  uint32_t *outCount;
+  uint32_t *outRanges;
+  uint64_t prevCapacity, outCapacity;
+  uint32_t bitOff[kFusedCols];
+  uint32_t capB, streams, prevSize, pad;
+};
+
+std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w) {
+  if (nd < 1 || nd > kFusedDims) return "";
+  std::ostringstream o;
+  o << "typedef unsigned int u32; typedef unsigned long long u64; typedef unsigned char u8; typedef int i32; typedef long long i64;\n"
+       "struct MArgs { const u32 *vals[" << kFusedCols << "]; const u8 *nulls[" << kFusedCols << "]; const u32 *recB; const u32 *countsB;\n"
+       "  const u32 *prevRanges; const u8 *prevDims; const u8 *prevValues; u8 *dimOut; u8 *outValues; u32 *outCount; u32 *outRanges;\n"
+       "  u64 prevCapacity, outCapacity; u32 bitOff[" << kFusedCols << "]; u32 capB, streams, prevSize, pad; };\n"
+       "#define ND " << nd << "\n#define PB " << partBits << "\n#define NP " << (1 << partBits) << "\n"
+       "#define SLOTS " << hr::kSlots << "\n#define LIMIT " << hr::kMergeLimit << "u\n#define RANGEWORDS " << hr::kRangeWords
+    << "\n#define MAXRANGES " << hr::kMaxRanges << "u\n#define EMPTY 0xFFFFFFFFFFFFFFFFull\n"
+       "__device__ __forceinline__ u32 rotl(u32 x, int r) { return (x << r) | (x >> (32 - r)); }\n"
+       "__device__ __forceinline__ u32 mix(u32 h, u32 k) { k *= 0xcc9e2d51u; k = rotl(k, 15) * 0x1b873593u; h ^= k; return rotl(h, 13) * 5u + 0xe6546b64u; }\n";
+  // value of a carried measure (hr::widen_value)
+  o << "__device__ __forceinline__ u64 widen(u32 raw) {\n";
+  if (w.mode == 0) o << "  return raw;\n";
+  else if (w.dtype == Float64)
+    o << (w.rk == K_F32 ? "  return (u64)__double_as_longlong((double)__uint_as_float(raw));\n"
+          : w.rk == K_I32 ? "  return (u64)__double_as_longlong((double)(i32)raw);\n"
+                          : "  return (u64)__double_as_longlong((double)raw);\n");
+  else
+    o << (w.rk == K_F32 ? "  return (u64)(i64)__uint_as_float(raw);\n" : w.rk == K_I32 ? "  return (u64)(i64)(i32)raw;\n" : "  return (u64)(i64)raw;\n");
+  o << "}\n";
+  // the aggregate on an LDS slot (hr::lds_aggregate)
+  o << "__device__ __forceinline__ void agg(u64 *slot, u64 bits) {\n";
+  switch (a.vtype) {
+    case V_F64: o << "  __hip_atomic_fetch_add(reinterpret_cast<double *>(slot), __longlong_as_double((long long)bits), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"; break;
+    case V_U64: case V_I64: o << "  __hip_atomic_fetch_add(slot, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"; break;
+    case V_F32: o << "  __hip_atomic_fetch_add(reinterpret_cast<float *>(slot), __uint_as_float((u32)bits), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"; break;
+    case V_U32:
+      o << "  __hip_atomic_fetch_" << (a.op == OP_SUM ? "add" : a.op == OP_MIN ? "min" : "max")
+        << "(reinterpret_cast<u32 *>(slot), (u32)bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n";
+      break;
+    case V_I32:
+      o << "  __hip_atomic_fetch_" << (a.op == OP_SUM ? "add" : a.op == OP_MIN ? "min" : "max")
+        << "(reinterpret_cast<i32 *>(slot), (i32)(u32)bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n";
+      break;
+    default: return "";
+  }
+  o << "}\n";
+  char ident[32];
+  snprintf(ident, sizeof(ident), "0x%016llxull", static_cast<unsigned long long>(a.identity));
+  o << "#define IDENT " << ident << "\n";
+  // The table is probed by buckets of four keys (32 bytes, two LDS reads): a record meets its group in
+  // its home bucket ~93 % of the time at this load, so a wavefront rarely takes more than two or three
+  // rounds — with one key per probe the longest probe sequence among 64 lanes paced every wave.  A
+  // lane's four records go through the rounds together: their bucket reads are in flight at once.
+  // Claims only ever turn the LOWEST empty slot of a bucket into a key, so a hash cannot end up twice.
+  o << "#define BUCKETS (SLOTS / 4)\n"
+       "struct __attribute__((aligned(16))) U64x2 { u64 x, y; };\n"
+       "struct Probe { u32 b, slot; u64 seen; bool done, fresh; };\n"
+       // One round for one record, written without branches except for the rare claim: the merge is bound by
+       // instruction issue (divergent control flow costs ~6 scalar instructions per `if`), not by LDS or HBM.
+       "__device__ __forceinline__ void probe_round(u64 *sKeys, u32 *sClaimed, u32 *sOverflow, Probe &q, u32 h, u64 mine) {\n"
+       "  const U64x2 lo = *reinterpret_cast<const U64x2 *>(sKeys + 4u * q.b), hi = *reinterpret_cast<const U64x2 *>(sKeys + 4u * q.b + 2u);\n"
+       "  const u64 k0 = lo.x, k1 = lo.y, k2 = hi.x, k3 = hi.y;\n"
+       "  const bool e0 = k0 == EMPTY, e1 = k1 == EMPTY, e2 = k2 == EMPTY, e3 = k3 == EMPTY;\n"
+       "  const bool m0 = !e0 && (u32)(k0 >> 32) == h, m1 = !e1 && (u32)(k1 >> 32) == h, m2 = !e2 && (u32)(k2 >> 32) == h, m3 = !e3 && (u32)(k3 >> 32) == h;\n"
+       "  const bool anyM = m0 | m1 | m2 | m3, anyE = e0 | e1 | e2 | e3;\n"
+       "  const u32 mi = m0 ? 0u : m1 ? 1u : m2 ? 2u : 3u, ei = e0 ? 0u : e1 ? 1u : e2 ? 2u : 3u;\n"
+       "  const u64 mk = m0 ? k0 : m1 ? k1 : m2 ? k2 : k3;\n"
+       "  const bool active = !q.done, hit = active & anyM;\n"
+       "  q.slot = hit ? 4u * q.b + mi : q.slot;\n"
+       "  q.seen = hit ? mk : q.seen;\n"
+       "  bool claimed = false;\n"
+       "  if (active & !anyM & anyE) {\n"  // a group that is new in this partition: rare once the groups exist
+       "    u64 expected = EMPTY;\n"
+       "    if (__hip_atomic_compare_exchange_strong(sKeys + 4u * q.b + ei, &expected, mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {\n"
+       "      if (__hip_atomic_fetch_add(sClaimed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= LIMIT)\n"
+       "        __hip_atomic_store(sOverflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
+       "      q.slot = 4u * q.b + ei; q.fresh = true; claimed = true;\n"
+       "    }\n"  // lost the slot: the same bucket again next round (the winner may be this very group)
+       "  }\n"
+       "  q.b = (active & !anyM & !anyE) ? (q.b + 1u) & (BUCKETS - 1u) : q.b;\n"
+       "  q.done = q.done | hit | claimed;\n"
+       "}\n"
+       "__device__ __forceinline__ void finish(u64 *sKeys, u64 *sVals, const Probe &q, u64 mine, u64 value) {\n"
+       "  if (!q.fresh && mine < q.seen) __hip_atomic_fetch_min(sKeys + q.slot, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
+       "  agg(sVals + q.slot, value);\n"
+       "}\n"
+       // one record (previous groups)
+       "__device__ __forceinline__ void insert(u64 *sKeys, u64 *sVals, u32 *sClaimed, u32 *sOverflow, u32 row, u32 h, u64 value) {\n"
+       "  const u64 mine = ((u64)h << 32) | row;\n"
+       "  Probe q; q.b = h & (BUCKETS - 1u); q.slot = 0u; q.seen = 0ull; q.done = false; q.fresh = false;\n"
+       "  for (u32 tries = 0u; tries < 4u * BUCKETS && !q.done; tries++) probe_round(sKeys, sClaimed, sOverflow, q, h, mine);\n"
+       "  if (q.done) finish(sKeys, sVals, q, mine, value);\n"
+       "  else __hip_atomic_store(sOverflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"  // table full: the round is void anyway
+       "}\n";
+  o << "struct Chunk { const uint4 *ptr; u32 rem; };\n"
+       "struct Stage { uint4 r[4]; };\n"
+       "__device__ __forceinline__ void load_chunk(Stage &s, const Chunk &c, u32 lane) {\n"
+       "  const u32 last = c.rem ? c.rem - 1u : 0u;\n"
+       "#pragma unroll\n"
+       "  for (int k = 0; k < 4; k++) { const u32 i = (u32)k * 64u + lane; s.r[k] = c.ptr[i < last ? i : last]; }\n"
+       "}\n"
+       // A stage = four records per lane.  Round one looks at every record's home bucket with straight-line
+       // code (no claim, no advance): a record whose group sits there — ~93 % once the groups exist — costs
+       // one LDS atomic more.  What is left (the group lives further on, or is new) goes through the general
+       // probe loop one record per lane at a time: lanes with nothing pending drop out at once.
+       // A stage = four records per lane.  Round one looks at every record's home bucket with straight-line
+       // code (no claim, no advance): a record whose group sits there — ~93 % once the groups exist — costs
+       // one LDS atomic more.  The rest (the group lives further on, or is new) takes the general probe loop.
+       "__device__ __forceinline__ void consume(const Stage &s, const Chunk &c, u32 lane, u64 *sKeys, u64 *sVals, u32 *sClaimed, u32 *sOverflow) {\n"
+       "  const u32 take = c.rem < 256u ? c.rem : 256u;\n"
+       "  bool pend[4];\n"
+       "#pragma unroll\n"
+       "  for (int k = 0; k < 4; k++) {\n"
+       "    const u32 i = (u32)k * 64u + lane;\n"
+       "    const bool valid = i < take && s.r[k].x != 0xFFFFFFFFu;\n"  // not past the run / padding of its last line
+       "    const u32 h = s.r[k].y, b = h & (BUCKETS - 1u);\n"
+       "    const U64x2 lo = *reinterpret_cast<const U64x2 *>(sKeys + 4u * b), hi = *reinterpret_cast<const U64x2 *>(sKeys + 4u * b + 2u);\n"
+       "    const bool m0 = (u32)(lo.x >> 32) == h && lo.x != EMPTY, m1 = (u32)(lo.y >> 32) == h && lo.y != EMPTY;\n"
+       "    const bool m2 = (u32)(hi.x >> 32) == h && hi.x != EMPTY, m3 = (u32)(hi.y >> 32) == h && hi.y != EMPTY;\n"
+       "    const bool hit = valid && (m0 || m1 || m2 || m3);\n"
+       "    if (hit) {\n"
+       "      const u32 mi = m0 ? 0u : m1 ? 1u : m2 ? 2u : 3u;\n"
+       "      const u32 seenRow = m0 ? (u32)lo.x : m1 ? (u32)lo.y : m2 ? (u32)hi.x : (u32)hi.y;\n"
+       "      if (s.r[k].x < seenRow) __hip_atomic_fetch_min(sKeys + 4u * b + mi, ((u64)h << 32) | s.r[k].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
+       "      agg(sVals + 4u * b + mi, widen(s.r[k].z));\n"
+       "    }\n"
+       "    pend[k] = valid && !hit;\n"
+       "  }\n"
+       "#pragma unroll\n"
+       "  for (int k = 0; k < 4; k++)\n"
+       "    if (pend[k]) insert(sKeys, sVals, sClaimed, sOverflow, s.r[k].x, s.r[k].y, widen(s.r[k].z));\n"
+       "}\n";
+  // dimensions of a source row (hr::fused_eval_row), for groups that are new in this batch
+  o << "__device__ __forceinline__ void eval_row(const MArgs &a, u32 row, u32 (&bits)[ND], u32 (&ok)[ND]) {\n";
+  for (int d = 0; d < nd; d++) {
+    const FusedExpr &e = plan.dims[d];
+    if (!plain_store(e.f.rk, e.outKind)) return "";
+    const int c = e.col;
+    o << "  {\n    const u32 v = a.vals[" << c << "][row];\n";
+    if (plan.cols[c].nulls) o << "    const u32 bit = row + a.bitOff[" << c << "]; const u32 okb = (a.nulls[" << c << "][bit >> 3] >> (bit & 7u)) & 1u;\n";
+    else o << "    const u32 okb = 1u;\n";
+    o << "    u32 x;\n";
+    if (!gen_value(e.f, o, "v", "okb", "x")) return "";
+    o << "    bits[" << d << "] = x; ok[" << d << "] = okb;\n  }\n";
+  }
+  o << "}\n";
+  const bool wide = a.width == 8;
+  o << "extern \"C\" __global__ void __launch_bounds__(1024) hr_merge_rtc(MArgs a) {\n"
+       "  __shared__ u64 sKeys[SLOTS];\n"
+       "  __shared__ u64 sVals[SLOTS];\n"
+       "  __shared__ u32 sRunCount[256];\n"
+       "  __shared__ u32 sClaimed, sOverflow, sCount, sBase, sEmit;\n"
+       "  const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, p = blockIdx.x;\n"
+       "  for (u32 s = tid; s < SLOTS; s += 1024u) { sKeys[s] = EMPTY; sVals[s] = IDENT; }\n"
+       "  if (tid == 0u) { sClaimed = 0u; sOverflow = 0u; sCount = 0u; sEmit = 0u; }\n"
+       "  const u32 G = a.streams;\n"
+       "  if (tid < G) sRunCount[tid] = a.countsB[(u64)tid * NP + p];\n"
+       "  const u32 *ranges = a.prevRanges ? a.prevRanges + (u64)p * RANGEWORDS : nullptr;\n"
+       "  u32 nRanges = ranges ? ranges[0] : 0u;\n"
+       "  if (nRanges > MAXRANGES) { if (tid == 0u) a.outCount[2] = 1u; nRanges = 0u; }\n"
        "  __syncthreads();\n"
-       "  const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;\n"
-       "  u32 *myB = a.recB + (u64)blockIdx.x * NP * a.capB * 3u;\n"
-       "  const u32 fullTiles = (u32)a.length >> 8;\n"
-       "  const u32 stride = gridDim.x * 16u;\n"
-       "  u32 tile = blockIdx.x * 16u + wave;\n"
-       "  if (tile < fullTiles) {\n"
-       "    const u32 last = fullTiles - 1u;\n"
-       "    Raw A, B;\n"
-       "    load_full(A, a, tile * 256u + lane * 4u);\n"
-       "    for (;;) {\n"
-       "      const u32 t2 = tile + stride;\n"
-       "      load_full(B, a, (t2 < last ? t2 : last) * 256u + lane * 4u);\n"  // unconditional: the compiler counts the loads
-       "      process(A, a, tile * 256u + lane * 4u, sCursor, myB);\n"
-       "      if (t2 >= fullTiles) break;\n"
-       "      const u32 t3 = t2 + stride;\n"
-       "      load_full(A, a, (t3 < last ? t3 : last) * 256u + lane * 4u);\n"
-       "      process(B, a, t2 * 256u + lane * 4u, sCursor, myB);\n"
-       "      if (t3 >= fullTiles) break;\n"
-       "      tile = t3;\n"
+       // previous groups of this partition (always the lowest row indices: they stay the representatives)
+       "  {\n"
+       "    const u8 *nullsIn = a.prevDims + (u64)(4 * ND) * a.prevCapacity;\n"
+       "    for (u32 r = 0u; r < nRanges; r++) {\n"
+       "      const u32 start = ranges[1u + 2u * r], cnt = ranges[2u + 2u * r];\n"
+       "      for (u32 i = tid; i < cnt; i += 1024u) {\n"
+       "        const u32 row = start + i;\n"
+       "        u32 h = 0u, okbytes = 0u;\n"
+       "#pragma unroll\n"
+       "        for (int d = 0; d < ND; d++) {\n"
+       "          h = mix(h, *reinterpret_cast<const u32 *>(a.prevDims + (u64)(4 * d) * a.prevCapacity + 4ull * row));\n"
+       "          okbytes |= (u32)nullsIn[(u64)d * a.prevCapacity + row] << (8 * d);\n"
+       "        }\n";
+  if (nd == 4) o << "        h = mix(h, okbytes);\n";
+  else o << "        { u32 k = okbytes * 0xcc9e2d51u; k = rotl(k, 15) * 0x1b873593u; h ^= k; }\n";
+  o << "        h ^= " << 5 * nd << "u; h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;\n"
+       "        if (row >= a.prevSize || (PB && (h >> (32 - (PB ? PB : 1))) != p)) { a.outCount[2] = 1u; continue; }\n"
+    << (wide ? "        const u64 val = reinterpret_cast<const u64 *>(a.prevValues)[row];\n"
+             : "        const u64 val = reinterpret_cast<const u32 *>(a.prevValues)[row];\n")
+    << "        insert(sKeys, sVals, &sClaimed, &sOverflow, row, h, val);\n"
+       "      }\n"
        "    }\n"
        "  }\n"
-       "  if (((u32)a.length & 255u) && (fullTiles % stride) == blockIdx.x * 16u + wave) {\n"  // the partial tile
-       "    Raw T;\n"
-       "    load_tail(T, a, fullTiles * 256u + lane * 4u);\n"
-       "    process(T, a, fullTiles * 256u + lane * 4u, sCursor, myB);\n"
+       "  __syncthreads();\n"
+       // the partition's runs: every wavefront streams whole runs, two register stages
+       "  if (G > 0u) {\n"
+       "    const uint4 *dummy = reinterpret_cast<const uint4 *>(a.recB);\n"
+       "    u32 g = wave, off = 0u;\n"
+       "    auto next = [&]() -> Chunk {\n"
+       "      Chunk c{dummy, 0u};\n"
+       "      while (g < G) {\n"
+       "        const u32 cnt = (u32)__builtin_amdgcn_readfirstlane((int)sRunCount[g]);\n"
+       "        if (off < cnt) {\n"
+       "          c.ptr = reinterpret_cast<const uint4 *>(a.recB) + ((u64)g * NP + p) * a.capB + off;\n"
+       "          c.rem = cnt - off;\n"
+       "          off += 256u;\n"
+       "          break;\n"
+       "        }\n"
+       "        g += 16u; off = 0u;\n"
+       "      }\n"
+       "      return c;\n"
+       "    };\n"
+       "    Stage sa, sb;\n"
+       "    Chunk ca = next();\n"
+       "    load_chunk(sa, ca, lane);\n"
+       "    while (ca.rem) {\n"
+       "      Chunk cb = next();\n"
+       "      load_chunk(sb, cb, lane);\n"
+       "      consume(sa, ca, lane, sKeys, sVals, &sClaimed, &sOverflow);\n"
+       "      if (!cb.rem) break;\n"
+       "      ca = next();\n"
+       "      load_chunk(sa, ca, lane);\n"
+       "      consume(sb, cb, lane, sKeys, sVals, &sClaimed, &sOverflow);\n"
+       "    }\n"
        "  }\n"
        "  __syncthreads();\n"
-       "  for (int p = threadIdx.x; p < NP; p += 1024) {\n"
-       "    u32 cnt = sCursor[p];\n"
-       "    if (cnt > a.capB) { *a.overflow = 1u; cnt = a.capB; }\n"
-       "    a.countsB[(u64)blockIdx.x * NP + p] = cnt;\n"
+       "  if (sOverflow) { if (tid == 0u) a.outCount[3] = 1u; return; }\n"  // more groups than one table: the generic merge takes over
+       // emit: count occupied slots, reserve output rows once, then copy (as hr::merge_body)
+       "  u32 mineCount = 0u;\n"
+       "#pragma unroll\n"
+       "  for (int k = 0; k < SLOTS / 1024; k++) mineCount += sKeys[tid + (u32)k * 1024u] != EMPTY;\n"
+       "  if (mineCount) __hip_atomic_fetch_add(&sCount, mineCount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
+       "  __syncthreads();\n"
+       "  const u32 total = sCount;\n"
+       "  if (tid == 0u) {\n"
+       "    u32 base = 0u;\n"
+       "    if (total) base = atomicAdd(a.outCount, total);\n"
+       "    sBase = base;\n"
+       "    if (a.outRanges) { u32 *o = a.outRanges + (u64)p * RANGEWORDS; o[0] = total ? 1u : 0u; o[1] = base; o[2] = total; }\n"
+       "  }\n"
+       "  __syncthreads();\n"
+       "  if (!total) return;\n"
+       "  const u8 *nullsIn = a.prevDims + (u64)(4 * ND) * a.prevCapacity;\n"
+       "  u8 *nullsOut = a.dimOut + (u64)(4 * ND) * a.outCapacity;\n"
+       "#pragma unroll\n"
+       "  for (int half = 0; half < 2; half++) {\n"
+       "    u32 dv[4][ND], nv[4][ND], at[4]; bool has[4];\n"
+       "#pragma unroll\n"
+       "    for (int kk = 0; kk < 4; kk++) {\n"
+       "      const u32 s = tid + (u32)(half * 4 + kk) * 1024u;\n"
+       "      const u64 key = sKeys[s];\n"
+       "      has[kk] = key != EMPTY;\n"
+       "      const u64 m = __ballot(has[kk]);\n"
+       "      u32 waveBase = 0u;\n"
+       "      if (lane == 0u && m) waveBase = __hip_atomic_fetch_add(&sEmit, (u32)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
+       "      waveBase = (u32)__builtin_amdgcn_readfirstlane((int)waveBase);\n"
+       "      at[kk] = sBase + waveBase + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));\n"
+       "      if (!has[kk]) continue;\n"
+       "      const u32 row = (u32)key;\n"
+       "      if (row >= a.prevSize) { eval_row(a, row - a.prevSize, dv[kk], nv[kk]); continue; }\n"
+       "#pragma unroll\n"
+       "      for (int d = 0; d < ND; d++) {\n"
+       "        dv[kk][d] = *reinterpret_cast<const u32 *>(a.prevDims + (u64)(4 * d) * a.prevCapacity + 4ull * row);\n"
+       "        nv[kk][d] = nullsIn[(u64)d * a.prevCapacity + row];\n"
+       "      }\n"
+       "    }\n"
+       "#pragma unroll\n"
+       "    for (int kk = 0; kk < 4; kk++) {\n"
+       "      if (!has[kk]) continue;\n"
+       "      const u32 s = tid + (u32)(half * 4 + kk) * 1024u;\n"
+       "#pragma unroll\n"
+       "      for (int d = 0; d < ND; d++) {\n"
+       "        *reinterpret_cast<u32 *>(a.dimOut + (u64)(4 * d) * a.outCapacity + 4ull * at[kk]) = dv[kk][d];\n"
+       "        nullsOut[(u64)d * a.outCapacity + at[kk]] = (u8)nv[kk][d];\n"
+       "      }\n"
+    << (wide ? "      reinterpret_cast<u64 *>(a.outValues)[at[kk]] = sVals[s];\n"
+             : "      reinterpret_cast<u32 *>(a.outValues)[at[kk]] = (u32)sVals[s];\n")
+    << "    }\n"
        "  }\n"
        "}\n";
   return o.str();
@@ -316,7 +670,7 @@ std::mutex g_rtcMutex;
 std::map<std::pair<int, std::string>, Compiled> g_rtcCache;
 
 // compiles (or finds) the kernel of this source on the current device
-hipFunction_t compiled_kernel(int device, const std::string &source) {
+hipFunction_t compiled_kernel(int device, const std::string &source, const char *entry) {
   std::lock_guard<std::mutex> lock(g_rtcMutex);
   auto it = g_rtcCache.find({device, source});
   if (it != g_rtcCache.end()) return it->second.fn;
@@ -331,7 +685,7 @@ hipFunction_t compiled_kernel(int device, const std::string &source) {
       if (api.codeSize(prog, &size) == 0 && size) {
         std::vector<char> code(size);
         if (api.code(prog, code.data()) == 0 && hipModuleLoadData(&c.module, code.data()) == hipSuccess) {
-          if (hipModuleGetFunction(&c.fn, c.module, "hr_scan_rtc") != hipSuccess) c.fn = nullptr;
+          if (hipModuleGetFunction(&c.fn, c.module, entry) != hipSuccess) c.fn = nullptr;
         }
         (void)hipGetLastError();
       }
@@ -342,7 +696,7 @@ hipFunction_t compiled_kernel(int device, const std::string &source) {
         log.resize(n);
         api.log(prog, &log[0]);
       }
-      fprintf(stderr, "libalgorithm: hiprtc could not compile a specialised scan kernel (generic kernel used): %s\n", log.c_str());
+      fprintf(stderr, "libalgorithm: hiprtc could not compile %s (generic kernel used): %s\n", entry, log.c_str());
     }
     api.destroy(&prog);
   }
@@ -354,16 +708,19 @@ hipFunction_t compiled_kernel(int device, const std::string &source) {
 
 bool rtc_scan_available() { return rtc_api().ok; }
 
-bool rtc_scan_launch(int device, const FusedPlanD &plan, int nd, uint32_t rowBase, int length, const hr::Workspace &ws,
-                     hipStream_t stream) {
-  if (!rtc_api().ok || length <= 0 || ws.streams <= 0) return false;
+void *rtc_scan_lookup(int device, const FusedPlanD &plan, int nd, int partBits) {
+  if (!rtc_api().ok) return nullptr;
   uint32_t nullMask = 0;
   for (int c = 0; c < plan.numCols; c++)
     if (plan.cols[c].nulls) nullMask |= 1u << c;
-  const std::string source = generate(plan, nd, ws.partBits, nullMask);
-  if (source.empty()) return false;
-  hipFunction_t fn = compiled_kernel(device, source);
-  if (!fn) return false;
+  const std::string source = generate(plan, nd, partBits, nullMask);
+  if (source.empty()) return nullptr;
+  return compiled_kernel(device, source, "hr_scan_rtc");
+}
+
+void rtc_scan_launch(void *kernel, const FusedPlanD &plan, uint32_t rowBase, int length, const hr::Workspace &ws,
+                     hipStream_t stream) {
+  hipFunction_t fn = static_cast<hipFunction_t>(kernel);
   RtcArgs args;
   memset(&args, 0, sizeof(args));
   for (int c = 0; c < plan.numCols; c++) {
@@ -382,14 +739,56 @@ bool rtc_scan_launch(int device, const FusedPlanD &plan, int nd, uint32_t rowBas
   KernelTimer timer("hr_scan_rtc", stream);
   hip_check(hipModuleLaunchKernel(fn, static_cast<unsigned>(ws.streams), 1, 1, hr::kThreads, 1, 1, 0, stream, nullptr, config),
             "hipModuleLaunchKernel");
-  return true;
+}
+
+
+void *rtc_merge_lookup(int device, const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w) {
+  if (!rtc_api().ok) return nullptr;
+  const std::string source = generate_merge(plan, nd, partBits, a, w);
+  if (source.empty()) return nullptr;
+  return compiled_kernel(device, source, "hr_merge_rtc");
+}
+
+void rtc_merge_launch(void *kernel, const FusedPlanD &plan, const uint8_t *prevDims, size_t prevCapacity, const uint8_t *prevValues,
+                      uint32_t prevSize, uint8_t *dimOut, size_t outCapacity, uint8_t *outValues, const hr::Workspace &ws,
+                      hipStream_t stream) {
+  hipFunction_t fn = static_cast<hipFunction_t>(kernel);
+  RtcMergeArgs args;
+  memset(&args, 0, sizeof(args));
+  for (int c = 0; c < plan.numCols; c++) {
+    args.vals[c] = plan.cols[c].vals;
+    args.nulls[c] = plan.cols[c].nulls;
+    args.bitOff[c] = plan.cols[c].bitOff;
+  }
+  args.recB = ws.recB;
+  args.countsB = ws.countsB;
+  args.prevRanges = ws.prevRanges;
+  args.prevDims = prevDims;
+  args.prevValues = prevValues;
+  args.dimOut = dimOut;
+  args.outValues = outValues;
+  args.outCount = ws.outCount;
+  args.outRanges = ws.outRanges;
+  args.prevCapacity = prevCapacity;
+  args.outCapacity = outCapacity;
+  args.capB = ws.capB;
+  args.streams = static_cast<uint32_t>(ws.streams);
+  args.prevSize = prevSize;
+  size_t size = sizeof(args);
+  void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+  KernelTimer timer("hr_merge_rtc", stream);
+  hip_check(hipModuleLaunchKernel(fn, 1u << ws.partBits, 1, 1, hr::kThreads, 1, 1, 0, stream, nullptr, config),
+            "hipModuleLaunchKernel");
+}
+
+std::string rtc_merge_source(const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w) {
+  return generate_merge(plan, nd, partBits, a, w);
 }
 
 // number of workgroups (= private streams per partition) the specialised kernel wants for `rows` rows
 int rtc_scan_grid(int64_t rows) {
-  const int64_t waveTiles = (rows + 255) / 256;
-  const int64_t groups = (waveTiles + 15) / 16;
-  return static_cast<int>(groups < hr::kMaxStreams ? (groups < 1 ? 1 : groups) : hr::kMaxStreams);
+  const int64_t tiles = (rows + 4095) / 4096;
+  return static_cast<int>(tiles < hr::kMaxStreams ? (tiles < 1 ? 1 : tiles) : hr::kMaxStreams);
 }
 
 // source text of the kernel a plan would get (tests / tools; empty = unsupported shape)

@@ -7,20 +7,34 @@
 
 #include "hash_reduce_lds.hpp"
 
+#include "aggregate.hpp"
+
 namespace ares {
 namespace hr {
 struct Workspace;
+struct Widen;
 }
 
 // hiprtc could be loaded (and ARES_RTC is not 0)
 bool rtc_scan_available();
 // workgroups (= private record streams per partition) for a batch of `rows` rows
 int rtc_scan_grid(int64_t rows);
-// Launches the specialised DIRECT-mode scan of `plan` over rows [0, length) of its columns into the
-// private streams of `ws` (ws.streams workgroups).  false = the plan is outside the supported shapes or
-// the kernel could not be built: the caller launches the generic kernel instead.
-bool rtc_scan_launch(int device, const FusedPlanD &plan, int nd, uint32_t rowBase, int length, const hr::Workspace &ws,
+// The specialised DIRECT-mode scan kernel of `plan` on `device` (generated, compiled and cached on first
+// use); nullptr = the plan is outside the supported shapes or the kernel could not be built: the caller
+// uses the generic kernel.
+void *rtc_scan_lookup(int device, const FusedPlanD &plan, int nd, int partBits);
+// Launches it over rows [0, length) of the plan's columns into the private streams of `ws`
+// (ws.streams workgroups; 16-byte records in whole 128-byte lines, ws.capB a multiple of 8).
+void rtc_scan_launch(void *kernel, const FusedPlanD &plan, uint32_t rowBase, int length, const hr::Workspace &ws,
                      hipStream_t stream);
+// The specialised merge for what that scan produces (line records in region B, previous groups in their
+// partition-grouped ranges or none, one round over the whole hash range).  It raises outCount[3] when a
+// partition holds more groups than one LDS table: the caller then runs the generic merge.
+void *rtc_merge_lookup(int device, const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w);
+void rtc_merge_launch(void *kernel, const FusedPlanD &plan, const uint8_t *prevDims, size_t prevCapacity, const uint8_t *prevValues,
+                      uint32_t prevSize, uint8_t *dimOut, size_t outCapacity, uint8_t *outValues, const hr::Workspace &ws,
+                      hipStream_t stream);
+std::string rtc_merge_source(const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w);
 // the generated source (empty = unsupported shape); for tools and tests
 std::string rtc_scan_source(const FusedPlanD &plan, int nd, int partBits);
 

@@ -8,7 +8,7 @@ calls = defaultdict(lambda: defaultdict(int))
 for f in glob.glob(os.path.join(root, "pass*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         name = r.get("Kernel_Name", "")
-        if "ares::" not in name and "hr_scan_rtc" not in name:
+        if "ares::" not in name and "_rtc" not in name:
             continue
         short = (name.split("ares::")[1] if "ares::" in name else name).replace("(anonymous namespace)::", "").split("(")[0].split("<")[0]
         acc[short][r["Counter_Name"]] += float(r["Counter_Value"])

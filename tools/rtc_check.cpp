@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "hash_reduce_lds.hpp"
+#include "hr_kernels.hpp"
 #include "hr_rtc.hpp"
 
 using namespace ares;
@@ -51,5 +52,22 @@ int main(int argc, char **argv) {
   std::vector<char> code(cs); hiprtcGetCode(prog, code.data());
   std::ofstream(prefix + ".co", std::ios::binary).write(code.data(), static_cast<std::streamsize>(cs));
   printf("code object %zu bytes -> %s.co\n", cs, prefix.c_str());
+  // the specialised merge of the same plan
+  AggSpec agg = make_agg_spec(AGGR_SUM_FLOAT, 8);
+  hr::Widen w{1, K_F32, Float64};
+  const std::string msrc = rtc_merge_source(p, 4, 9, agg, w);
+  if (msrc.empty()) { puts("merge: unsupported plan"); return 5; }
+  std::ofstream(prefix + "_merge.hip") << msrc;
+  hiprtcProgram mp;
+  if (hiprtcCreateProgram(&mp, msrc.c_str(), "hr_merge_rtc.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return 6;
+  const hiprtcResult mrc = hiprtcCompileProgram(mp, 4, opts);
+  n = 0; hiprtcGetProgramLogSize(mp, &n);
+  std::string mlog(n, 0); if (n) hiprtcGetProgramLog(mp, &mlog[0]);
+  printf("merge compile rc %d\n%s\n", static_cast<int>(mrc), mlog.c_str());
+  if (mrc != HIPRTC_SUCCESS) return 7;
+  hiprtcGetCodeSize(mp, &cs);
+  std::vector<char> mcode(cs); hiprtcGetCode(mp, mcode.data());
+  std::ofstream(prefix + "_merge.co", std::ios::binary).write(mcode.data(), static_cast<std::streamsize>(cs));
+  printf("merge code object %zu bytes\n", cs);
   return 0;
 }

@@ -14,7 +14,11 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
+#include <map>
+#include <mutex>
+#include <thread>
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
@@ -62,6 +66,7 @@ struct AbiLibrary {
   decltype(&::WriteGeoShapeDim) WriteGeoShapeDim;
   decltype(&::AsyncCopyDeviceToDevice) AsyncCopyDeviceToDevice;
   decltype(&::AsyncCopyDeviceToHost) AsyncCopyDeviceToHost;
+  decltype(&::AsyncCopyHostToDevice) AsyncCopyHostToDevice;
 
   template <typename F>
   void bind(void *handle, const char *name, F &fn) {
@@ -92,6 +97,7 @@ struct AbiLibrary {
     bind(memHandle, "WaitForCudaStream", WaitForCudaStream);
     bind(memHandle, "AsyncCopyDeviceToDevice", AsyncCopyDeviceToDevice);
     bind(memHandle, "AsyncCopyDeviceToHost", AsyncCopyDeviceToHost);
+    bind(memHandle, "AsyncCopyHostToDevice", AsyncCopyHostToDevice);
   }
   ~AbiLibrary() {
     if (algoHandle) dlclose(algoHandle);
@@ -694,6 +700,8 @@ struct AresQuery {
     }
     resultSize = static_cast<int>(check(h));
     wait();
+    for (void *p : ownedColumns) release(p);  // the batch's input columns (query/aql_processor.go:695-699)
+    ownedColumns.clear();
     swapResultBuffers();
     fusedBatches++;
     return true;
@@ -832,6 +840,345 @@ void AresQueryDestroy(AresQuery *q) {
   } catch (...) {
   }
   delete q;
+}
+
+}  // extern "C"
+
+// ---- shards across devices -----------------------------------------------------------------------------
+struct AresComm {
+  int rank = 0, nranks = 1;
+  AresAllGatherFn allGather = nullptr;
+  void *user = nullptr;
+  // RCCL binding (AresCommCreateRccl)
+  void *rcclHandle = nullptr, *rcclComm = nullptr;
+  int (*ncclAllGather)(const void *, void *, size_t, int, void *, void *) = nullptr;
+  int (*ncclCommDestroy)(void *) = nullptr;
+  const char *(*ncclGetErrorString)(int) = nullptr;
+};
+
+namespace {
+struct NcclUniqueId { char internal[128]; };
+
+int rccl_all_gather(void *user, const void *send, void *recv, size_t bytesPerRank, void *stream) {
+  AresComm *c = static_cast<AresComm *>(user);
+  return c->ncclAllGather(send, recv, bytesPerRank, /*ncclUint8*/ 1, c->rcclComm, stream);
+}
+
+void *open_rccl(std::string *why) {
+  for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+    if (void *h = dlopen(name, RTLD_NOW | RTLD_LOCAL)) return h;
+  }
+  *why = std::string("cannot load librccl.so: ") + dlerror();
+  return nullptr;
+}
+
+bool select_device(int device, std::string *why) {
+  void *hip = dlopen("libamdhip64.so", RTLD_NOW | RTLD_GLOBAL);
+  auto set = hip ? reinterpret_cast<int (*)(int)>(dlsym(hip, "hipSetDevice")) : nullptr;
+  if (!set || set(device) != 0) {
+    *why = "hipSetDevice failed";
+    return false;
+  }
+  return true;
+}
+
+// all_gather of `bytes` host bytes per rank through device staging buffers of the query's allocator
+void gather_words(AresQuery *q, AresComm *c, const void *mine, void *all, size_t bytes) {
+  uint8_t *send = q->alloc(bytes), *recv = q->alloc(bytes * c->nranks);
+  check(q->lib->AsyncCopyHostToDevice(send, const_cast<void *>(mine), bytes, q->stream, q->device));
+  if (c->allGather(c->user, send, recv, bytes, q->stream) != 0) throw AbiError("all-gather of the partial sizes failed");
+  check(q->lib->AsyncCopyDeviceToHost(all, recv, bytes * c->nranks, q->stream, q->device));
+  q->wait();
+  q->release(send);
+  q->release(recv);
+}
+}  // namespace
+
+extern "C" {
+
+AresComm *AresCommCreate(int rank, int nranks, AresAllGatherFn allGather, void *user) {
+  if (!allGather || nranks < 1 || rank < 0 || rank >= nranks) return nullptr;
+  AresComm *c = new AresComm;
+  c->rank = rank;
+  c->nranks = nranks;
+  c->allGather = allGather;
+  c->user = user;
+  return c;
+}
+
+int AresCommRcclUniqueId(uint8_t id[128], char *err, int errLen) {
+  std::string why;
+  void *h = open_rccl(&why);
+  auto get = h ? reinterpret_cast<int (*)(NcclUniqueId *)>(dlsym(h, "ncclGetUniqueId")) : nullptr;
+  NcclUniqueId u;
+  if (!get || get(&u) != 0) {
+    set_err(err, errLen, h ? "ncclGetUniqueId failed" : why.c_str());
+    return -1;
+  }
+  memcpy(id, u.internal, 128);
+  return 0;
+}
+
+AresComm *AresCommCreateRccl(const uint8_t id[128], int rank, int nranks, int device, char *err, int errLen) {
+  std::string why;
+  void *h = open_rccl(&why);
+  if (!h || !select_device(device, &why)) {
+    set_err(err, errLen, why.c_str());
+    return nullptr;
+  }
+  auto init = reinterpret_cast<int (*)(void **, int, NcclUniqueId, int)>(dlsym(h, "ncclCommInitRank"));
+  AresComm *c = new AresComm;
+  c->rank = rank;
+  c->nranks = nranks;
+  c->rcclHandle = h;
+  c->ncclAllGather = reinterpret_cast<decltype(c->ncclAllGather)>(dlsym(h, "ncclAllGather"));
+  c->ncclCommDestroy = reinterpret_cast<decltype(c->ncclCommDestroy)>(dlsym(h, "ncclCommDestroy"));
+  c->ncclGetErrorString = reinterpret_cast<decltype(c->ncclGetErrorString)>(dlsym(h, "ncclGetErrorString"));
+  NcclUniqueId u;
+  memcpy(u.internal, id, 128);
+  int rc = -1;
+  if (!init || !c->ncclAllGather || !c->ncclCommDestroy || (rc = init(&c->rcclComm, nranks, u, rank)) != 0) {
+    set_err(err, errLen, (std::string("ncclCommInitRank failed: ") +
+                          (c->ncclGetErrorString && rc > 0 ? c->ncclGetErrorString(rc) : "missing symbol")).c_str());
+    delete c;
+    return nullptr;
+  }
+  c->allGather = &rccl_all_gather;
+  c->user = c;
+  return c;
+}
+
+void AresCommDestroy(AresComm *c) {
+  if (!c) return;
+  if (c->rcclComm && c->ncclCommDestroy) c->ncclCommDestroy(c->rcclComm);
+  delete c;
+}
+
+int AresQueryMergeShards(AresQuery *q, AresComm *c, char *err, int errLen) {
+  try {
+    if (!c || !c->allGather) throw AbiError("no communicator");
+    if (q->plan.isHLL()) throw AbiError("HyperLogLog results are merged on the host (query/hll.go), not here");
+    std::vector<int> widths;
+    for (int k = 0; k < NUM_DIM_WIDTH; k++)
+      for (int j = 0; j < q->ndw[k]; j++) widths.push_back(kDimWidths[k]);
+    const int nd = static_cast<int>(widths.size()), mb = q->plan.measureBytes(), world = c->nranks;
+    int64_t valueBytes = 0;
+    for (int w : widths) valueBytes += w;
+    const int64_t rowBytes = valueBytes + nd + mb;
+    // 1. sizes
+    std::vector<int64_t> sizes(world, 0);
+    const int64_t mine = q->resultSize;
+    gather_words(q, c, &mine, sizes.data(), sizeof(int64_t));
+    int64_t gmax = 1, total = 0;
+    for (int64_t sz : sizes) {
+      gmax = std::max(gmax, sz);
+      total += sz;
+    }
+    if (total > INT32_MAX) throw AbiError("merged result exceeds 2^31 rows");
+    // 2. columnar partial, padded to gmax rows: [dim values...][dim validity...][measures]
+    std::vector<int64_t> sect;
+    int64_t off = 0;
+    for (int w : widths) { sect.push_back(off); off += gmax * w; }
+    for (int d = 0; d < nd; d++) { sect.push_back(off); off += gmax; }
+    sect.push_back(off);
+    const size_t packedBytes = static_cast<size_t>(gmax * rowBytes);
+    uint8_t *packed = q->alloc(packedBytes), *gathered = q->alloc(packedBytes * world);
+    const int64_t g = q->resultSize;
+    for (int d = 0; d < nd && g; d++) {
+      int64_t vo, no;
+      dimension_start_offsets(q->ndw, d, q->resultCapacity, &vo, &no);
+      q->d2d(packed + sect[d], q->dimVec[0] + vo, static_cast<size_t>(g) * widths[d]);
+      q->d2d(packed + sect[nd + d], q->dimVec[0] + no, static_cast<size_t>(g));
+    }
+    if (g) q->d2d(packed + sect[2 * nd], q->measureVec[0], static_cast<size_t>(g) * mb);
+    // 3. one exchange
+    if (c->allGather(c->user, packed, gathered, packedBytes, q->stream) != 0) throw AbiError("all-gather of the partial group tables failed");
+    // 4. append every rank's partial into fresh result vectors and re-reduce
+    q->wait();
+    q->releaseAll();
+    q->resultSize = 0;
+    q->size = static_cast<int>(total);
+    q->prepareForDimAndMeasureEval();  // capacity total + 12.5 %, both buffers of every vector
+    int64_t base = 0;
+    for (int r = 0; r < world; r++) {
+      const uint8_t *src = gathered + packedBytes * r;
+      for (int d = 0; d < nd && sizes[r]; d++) {
+        int64_t vo, no;
+        dimension_start_offsets(q->ndw, d, q->resultCapacity, &vo, &no);
+        q->d2d(q->dimVec[0] + vo + base * widths[d], const_cast<uint8_t *>(src) + sect[d], static_cast<size_t>(sizes[r]) * widths[d]);
+        q->d2d(q->dimVec[0] + no + base, const_cast<uint8_t *>(src) + sect[nd + d], static_cast<size_t>(sizes[r]));
+      }
+      if (sizes[r]) q->d2d(q->measureVec[0] + base * mb, const_cast<uint8_t *>(src) + sect[2 * nd], static_cast<size_t>(sizes[r]) * mb);
+      base += sizes[r];
+    }
+    q->wait();
+    q->release(packed);
+    q->release(gathered);
+    if (total > 0) {
+      q->reduce();  // HashReduce or InitIndexVector + Sort + Reduce over rows [0, size) of vector [0] into [1]
+      q->postExec();
+    } else {
+      q->size = 0;
+    }
+    return 0;
+  } catch (std::exception &e) {
+    set_err(err, errLen, e.what());
+    return -1;
+  }
+}
+
+// ---- host batches: transfer pipeline + device-resident column cache -------------------------------------
+}  // extern "C"
+
+struct AresColumnCache {
+  AbiLibrary *lib;
+  int device;
+  size_t budget, bytes = 0;
+  uint64_t clock = 0;
+  struct Entry {
+    void *ptr;
+    size_t bytes;
+    uint64_t lastUse;
+    int pins;
+  };
+  std::map<uint64_t, Entry> entries;
+  std::mutex mu;
+
+  // a resident column (pinned until unpin) or nullptr
+  void *find(uint64_t key) {
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = entries.find(key);
+    if (it == entries.end()) return nullptr;
+    it->second.lastUse = ++clock;
+    it->second.pins++;
+    return it->second.ptr;
+  }
+  // takes ownership of `ptr` (an uploaded column) if the budget allows, evicting the least recently used
+  // unpinned entries; returns false when the caller keeps ownership
+  bool insert(uint64_t key, void *ptr, size_t n) {
+    std::vector<void *> evicted;
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      if (n > budget || entries.count(key)) return false;
+      while (bytes + n > budget) {
+        auto victim = entries.end();
+        for (auto it = entries.begin(); it != entries.end(); ++it)
+          if (it->second.pins == 0 && (victim == entries.end() || it->second.lastUse < victim->second.lastUse)) victim = it;
+        if (victim == entries.end()) return false;
+        bytes -= victim->second.bytes;
+        evicted.push_back(victim->second.ptr);
+        entries.erase(victim);
+      }
+      entries[key] = Entry{ptr, n, ++clock, 1};
+      bytes += n;
+    }
+    for (void *p : evicted) check(lib->DeviceFree(p, device));
+    return true;
+  }
+  void unpin(uint64_t key) {
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = entries.find(key);
+    if (it != entries.end() && it->second.pins > 0) it->second.pins--;
+  }
+};
+
+extern "C" {
+
+AresColumnCache *AresColumnCacheCreate(void *driver, int device, size_t budgetBytes) {
+  AresColumnCache *c = new AresColumnCache;
+  c->lib = static_cast<AbiLibrary *>(driver);
+  c->device = device;
+  c->budget = budgetBytes;
+  return c;
+}
+
+void AresColumnCacheDestroy(AresColumnCache *c) {
+  if (!c) return;
+  for (auto &kv : c->entries) {
+    try {
+      check(c->lib->DeviceFree(kv.second.ptr, c->device));
+    } catch (...) {
+    }
+  }
+  delete c;
+}
+
+int AresQueryRunHostBatches(AresQuery *q, const AresHostColumn *columns, int numColumns, const int *batchSizes, int numBatches,
+                            AresColumnCache *cache, uint64_t stats[4], char *err, int errLen) {
+  uint64_t uploadedBytes = 0, uploads = 0, hits = 0;
+  struct Staged {
+    std::vector<VectorPartySlice> slices;
+    std::vector<void *> owned;
+    std::vector<uint64_t> pinned;
+    int size = 0;
+  };
+  std::string workerError;
+  auto run_staged = [&](Staged *b) {  // the executor of one batch, on the stream its transfer used
+    try {
+      q->ownedColumns = b->owned;
+      q->runBatch(b->slices.data(), static_cast<int>(b->slices.size()), b->size, nullptr, 0);
+    } catch (std::exception &e) {
+      workerError = e.what();
+      try {
+        q->cleanupBeforeAggregation();
+      } catch (...) {
+      }
+    }
+    if (cache)
+      for (uint64_t k : b->pinned) cache->unpin(k);
+  };
+  try {
+    Staged prev, cur;
+    bool havePrev = false;
+    for (int k = 0; k < numBatches; k++) {
+      // (query/aql_processor.go:850-881) async transfer of batch k ...
+      void *xfer = havePrev && q->otherStream ? q->otherStream : q->stream;
+      cur = Staged();
+      cur.size = batchSizes[k];
+      std::thread worker;
+      if (havePrev) worker = std::thread(run_staged, &prev);  // ... while batch k-1 executes
+      try {
+        for (int c = 0; c < numColumns; c++) {
+          const AresHostColumn &hc = columns[static_cast<size_t>(k) * numColumns + c];
+          void *dev = (cache && hc.cacheKey) ? cache->find(hc.cacheKey) : nullptr;
+          if (dev) {
+            hits++;
+            cur.pinned.push_back(hc.cacheKey);
+          } else {
+            dev = reinterpret_cast<void *>(check(q->lib->DeviceAllocate(hc.bytes ? hc.bytes : 1, q->device)));
+            check(q->lib->AsyncCopyHostToDevice(dev, const_cast<void *>(hc.host), hc.bytes, xfer, q->device));
+            uploadedBytes += hc.bytes;
+            uploads++;
+            if (cache && hc.cacheKey && cache->insert(hc.cacheKey, dev, hc.bytes)) cur.pinned.push_back(hc.cacheKey);
+            else cur.owned.push_back(dev);
+          }
+          VectorPartySlice vp = hc.slice;
+          vp.BasePtr = static_cast<uint8_t *>(dev) + reinterpret_cast<uintptr_t>(hc.slice.BasePtr);
+          cur.slices.push_back(vp);
+        }
+        check(q->lib->WaitForCudaStream(xfer, q->device));  // wait for the data transfer of the current batch
+      } catch (...) {
+        if (worker.joinable()) worker.join();
+        throw;
+      }
+      if (worker.joinable()) worker.join();
+      if (!workerError.empty()) throw AbiError(workerError);
+      prev = cur;
+      havePrev = true;
+    }
+    if (havePrev) run_staged(&prev);
+    if (!workerError.empty()) throw AbiError(workerError);
+    if (stats) {
+      stats[0] = uploadedBytes;
+      stats[1] = uploads;
+      stats[2] = hits;
+      stats[3] = cache ? cache->bytes : 0;
+    }
+    return 0;
+  } catch (std::exception &e) {
+    set_err(err, errLen, e.what());
+    return -1;
+  }
 }
 
 }  // extern "C"

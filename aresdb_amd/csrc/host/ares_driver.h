@@ -112,6 +112,50 @@ int64_t AresQueryHLLVectorSize(const AresQuery *q);
 int AresQueryFetchHLL(AresQuery *q, uint16_t *regCounts, uint8_t *hllVector, char *err, int errLen);
 void AresQueryDestroy(AresQuery *q);
 
+/* ---- shards across devices ------------------------------------------------------------
+ * One process per GPU, one shard per process.  The only exchange is the merge of the per-shard group
+ * tables: all-gather of their sizes, all-gather of the padded columnar partials, then every rank appends
+ * them and re-reduces with the library's own HashReduce / Sort+Reduce — the reference's "previous
+ * results + re-reduce" contract (query/aql_batchexecutor.go:236-251) with the aggregate's own combine
+ * rule (broker/result_merge.go:77-94).  Key sets differ per shard: there is no element-wise all-reduce.
+ *
+ * The collective is pluggable: AresCommCreateRccl binds RCCL (librccl.so is dlopen()ed; the all-gathers
+ * run on the query's stream, over xGMI between the GPUs of a node); AresCommCreate takes any all-gather
+ * function — the multi-process CPU tests pass one built on torch.distributed / gloo, so the same C++
+ * merge runs there on host memory. */
+typedef int (*AresAllGatherFn)(void *user, const void *send, void *recv, size_t bytesPerRank, void *stream);
+typedef struct AresComm AresComm;
+AresComm *AresCommCreate(int rank, int nranks, AresAllGatherFn allGather, void *user);
+/* RCCL: rank 0 obtains an id with AresCommRcclUniqueId and hands its 128 bytes to every rank (any
+ * side channel: torch.distributed broadcast, a file, MPI).  NULL + message on failure. */
+int AresCommRcclUniqueId(uint8_t id[128], char *err, int errLen);
+AresComm *AresCommCreateRccl(const uint8_t id[128], int rank, int nranks, int device, char *err, int errLen);
+void AresCommDestroy(AresComm *c);
+/* Replaces q's result by the merged result of all ranks (every rank ends with the whole table).
+ * Hash-reduction and sort-reduction queries; not HyperLogLog.  0, or -1 + message. */
+int AresQueryMergeShards(AresQuery *q, AresComm *c, char *err, int errLen);
+
+/* ---- host batches: transfer pipeline + device-resident column cache --------------------
+ * The Go host uploads every batch's columns for every query (query/aql_processor.go:513-540,
+ * :1345-1431) and overlaps the upload of batch k+1 with the execution of batch k on its second stream
+ * (:850-881).  AresQueryRunHostBatches does the same from pinned host memory (HostAlloc): one
+ * DeviceAllocate + AsyncCopyHostToDevice per column on the transfer stream, the previous batch executed
+ * on a worker thread meanwhile, columns freed by the executor before its aggregation stage.
+ * With a cache (AresColumnCacheCreate) columns stay in HBM under (table, batch, column) keys up to a
+ * byte budget, least recently used first out: a query whose batches are cached uploads nothing —
+ * MI355X's 288 GB hold hot batches resident.  stats: {bytes uploaded, uploads, cache hits, cache bytes}. */
+typedef struct {
+  const void *host;  /* pinned host image of the column allocation: [counts][validity][values] */
+  size_t bytes;
+  VectorPartySlice slice; /* BasePtr is ignored: offsets are relative to the allocation */
+  uint64_t cacheKey;      /* identifies (table, batch, column) in the cache; 0 = never cache */
+} AresHostColumn;
+typedef struct AresColumnCache AresColumnCache;
+AresColumnCache *AresColumnCacheCreate(void *driver, int device, size_t budgetBytes);
+void AresColumnCacheDestroy(AresColumnCache *c);
+int AresQueryRunHostBatches(AresQuery *q, const AresHostColumn *columns, int numColumns, const int *batchSizes,
+                            int numBatches, AresColumnCache *cache, uint64_t stats[4], char *err, int errLen);
+
 #ifdef __cplusplus
 }
 #endif

@@ -317,6 +317,33 @@ void AresMemSetDeferralHooks(const AresDeferralHooks *hooks) {
 
 void AresMemSetAuxHooks(const AresMemAuxHooks *hooks) { g_aux.store(hooks, std::memory_order_release); }
 
+// What the host currently owns on `device` (the Go host keeps the same books itself and asserts they
+// return to zero after every query, query/aql_processor_test.go:230-231): bytes of live DeviceAllocate /
+// deviceMalloc blocks (rounded to their size bins), blocks kept aside for deferred work, bytes parked
+// in the cache.
+void AresMemStats(int device, size_t *liveBytes, size_t *liveBlocks, size_t *heldBlocks, size_t *parkedBytes) {
+  size_t lb = 0, ln = 0, hn = 0, pb = 0;
+  if (device >= 0 && device < kMaxDevices) {
+    DeviceState *st = &g_devices[device];
+    std::lock_guard<std::mutex> lock(st->mu);
+    for (auto &kv : st->live) lb += kv.second;
+    ln = st->live.size();
+    hn = st->held.size();
+    for (auto &h : st->held) {  // freed by the host, kept aside: not the host's any more
+      auto it = st->live.find(h.first);
+      if (it != st->live.end()) {
+        lb -= it->second;
+        ln--;
+      }
+    }
+    pb = st->parkedBytes;
+  }
+  if (liveBytes) *liveBytes = lb;
+  if (liveBlocks) *liveBlocks = ln;
+  if (heldBlocks) *heldBlocks = hn;
+  if (parkedBytes) *parkedBytes = pb;
+}
+
 void AresMemTrimCache(int device) {
   if (device < 0 || device >= kMaxDevices) return;
   DeviceState *st = &g_devices[device];

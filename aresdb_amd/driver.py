@@ -44,6 +44,13 @@ class QueryPlanC(C.Structure):
                 ("useFusedExtension", C.c_int), ("geo", C.POINTER(GeoIntersectionC))]
 
 
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+class HostColumnC(C.Structure):
+    _fields_ = [("host", C.c_void_p), ("bytes", C.c_size_t), ("slice", abi.VectorPartySlice), ("cacheKey", C.c_uint64)]
+
+
 _lib = None
 
 
@@ -72,6 +79,17 @@ def _driver():
         lib.AresQuerySetLastBatch.argtypes = [C.c_void_p, C.c_int]
         lib.AresQuerySetSecondStream.argtypes = [C.c_void_p, C.c_void_p]
         lib.AresQueryAdoptColumns.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int]
+        lib.AresCommCreate.argtypes, lib.AresCommCreate.restype = [C.c_int, C.c_int, ALLGATHER_FN, C.c_void_p], C.c_void_p
+        lib.AresCommRcclUniqueId.argtypes, lib.AresCommRcclUniqueId.restype = [C.c_void_p, C.c_char_p, C.c_int], C.c_int
+        lib.AresCommCreateRccl.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]
+        lib.AresCommCreateRccl.restype = C.c_void_p
+        lib.AresCommDestroy.argtypes = [C.c_void_p]
+        lib.AresQueryMergeShards.argtypes, lib.AresQueryMergeShards.restype = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int], C.c_int
+        lib.AresColumnCacheCreate.argtypes, lib.AresColumnCacheCreate.restype = [C.c_void_p, C.c_int, C.c_size_t], C.c_void_p
+        lib.AresColumnCacheDestroy.argtypes = [C.c_void_p]
+        lib.AresQueryRunHostBatches.argtypes = [C.c_void_p, C.POINTER(HostColumnC), C.c_int, C.POINTER(C.c_int), C.c_int,
+                                                C.c_void_p, C.POINTER(C.c_uint64), C.c_char_p, C.c_int]
+        lib.AresQueryRunHostBatches.restype = C.c_int
         lib.AresQueryHLLVectorSize.argtypes, lib.AresQueryHLLVectorSize.restype = [C.c_void_p], C.c_int64
         lib.AresQueryFetchHLL.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
         lib.AresQueryFetchHLL.restype = C.c_int
@@ -270,6 +288,32 @@ class NativeQuery:
         size = _driver().AresQueryHLLVectorSize(self._q) if n else 0
         return dims, valids, counts[:n].copy(), vec[:size].copy()
 
+    def merge_shards(self, comm):
+        """Replaces this query's result by the merged result of every rank of `comm` (all-gather of
+        the partial group tables + re-reduce, inside libaresdriver.so)."""
+        rc = _driver().AresQueryMergeShards(self._q, comm.handle, self._err, 1024)
+        if rc != 0:
+            raise abi.AresError(self._err.value.decode().strip())
+
+    def run_host_batches(self, batches, cache=None):
+        """batches: [(list of HostColumn in column order, rows)] living in pinned host memory; the
+        driver uploads batch k+1 while batch k executes.  Returns {uploaded_bytes, uploads, cache_hits,
+        cache_bytes}."""
+        ncol = len(self.column_names)
+        flat = (HostColumnC * (ncol * len(batches)))()
+        sizes = (C.c_int * len(batches))()
+        for b, (cols, n) in enumerate(batches):
+            sizes[b] = n
+            for c, hc in enumerate(cols):
+                e = flat[b * ncol + c]
+                e.host, e.bytes, e.slice, e.cacheKey = hc.host_ptr, hc.nbytes, hc.slice, hc.cache_key
+        stats = (C.c_uint64 * 4)()
+        rc = _driver().AresQueryRunHostBatches(self._q, flat, ncol, sizes, len(batches), cache.handle if cache else None,
+                                               stats, self._err, 1024)
+        if rc != 0:
+            raise abi.AresError(self._err.value.decode().strip())
+        return {"uploaded_bytes": stats[0], "uploads": stats[1], "cache_hits": stats[2], "cache_bytes": stats[3]}
+
     def release(self):
         if self._q:
             _driver().AresQueryDestroy(self._q)
@@ -280,3 +324,91 @@ class NativeQuery:
             self.release()
         except Exception:  # noqa: BLE001
             pass
+
+
+class NativeComm:
+    """Communicator of libaresdriver.so's shard merge.  `rccl`: ranks on GPUs (the 128-byte id of rank
+    0 reaches the others through `broadcast`, e.g. torch.distributed); `torch_group`: any
+    torch.distributed group on host memory (gloo) — what the multi-process CPU tests use."""
+
+    def __init__(self, handle, keep=None):
+        self.handle, self._keep = handle, keep
+
+    @classmethod
+    def rccl(cls, rank, world, device, broadcast):
+        lib = _driver()
+        ident = (C.c_uint8 * 128)()
+        err = C.create_string_buffer(512)
+        if rank == 0 and lib.AresCommRcclUniqueId(ident, err, 512) != 0:
+            raise abi.AresError(err.value.decode())
+        raw = broadcast(bytes(ident))
+        ident = (C.c_uint8 * 128).from_buffer_copy(raw)
+        h = lib.AresCommCreateRccl(ident, rank, world, device, err, 512)
+        if not h:
+            raise abi.AresError(err.value.decode())
+        return cls(h)
+
+    @classmethod
+    def torch_group(cls, group=None):
+        import torch
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+
+        def all_gather(user, send, recv, nbytes, stream):
+            try:
+                mine = torch.frombuffer((C.c_uint8 * nbytes).from_address(send), dtype=torch.uint8).clone()
+                out = torch.empty(world * nbytes, dtype=torch.uint8)
+                dist.all_gather_into_tensor(out, mine, group=group)
+                C.memmove(recv, out.data_ptr(), world * nbytes)
+                return 0
+            except Exception:  # noqa: BLE001
+                return 1
+        cb = ALLGATHER_FN(all_gather)
+        return cls(_driver().AresCommCreate(rank, world, cb, None), keep=cb)
+
+    def destroy(self):
+        if self.handle:
+            _driver().AresCommDestroy(self.handle)
+            self.handle = None
+
+
+class HostColumn:
+    """One column of one batch in pinned host memory (HostAlloc), laid out like the device allocation
+    the Go host uploads: [validity bitmap, 64-byte padded][values] (query/aql_processor.go:1415-1429)."""
+
+    def __init__(self, be, data_type, values, valid=None, cache_key=0):
+        import numpy as np
+        values = np.ascontiguousarray(values)
+        vbytes = values.view(np.uint8).reshape(-1)
+        nb = np.zeros(0, np.uint8) if valid is None else np.packbits(np.asarray(valid, bool), bitorder="little")
+        vo = (len(nb) + 63) // 64 * 64
+        self.nbytes = vo + (len(vbytes) + 63) // 64 * 64
+        self.be = be
+        self.host_ptr = be.call("HostAlloc", self.nbytes)
+        buf = np.frombuffer((C.c_uint8 * self.nbytes).from_address(self.host_ptr), np.uint8)
+        buf[:len(nb)] = nb
+        buf[vo:vo + len(vbytes)] = vbytes
+        vp = abi.VectorPartySlice()
+        vp.DataType, vp.Length, vp.StartingIndex = data_type, len(values), 0
+        if valid is not None:
+            vp.BasePtr, vp.NullsOffset, vp.ValuesOffset = 0, 0, vo
+        else:
+            vp.BasePtr, vp.NullsOffset, vp.ValuesOffset = vo, 0, 0  # BasePtr = byte offset inside the allocation
+        self.slice, self.cache_key = vp, cache_key
+
+    def free(self):
+        if self.host_ptr:
+            self.be.call("HostFree", self.host_ptr)
+            self.host_ptr = 0
+
+
+class ColumnCache:
+    """Device-resident column cache of libaresdriver.so (least recently used out, byte budget)."""
+
+    def __init__(self, be, device=0, budget_bytes=1 << 30):
+        self.handle = _driver().AresColumnCacheCreate(_open(be), device, budget_bytes)
+
+    def destroy(self):
+        if self.handle:
+            _driver().AresColumnCacheDestroy(self.handle)
+            self.handle = None

@@ -46,11 +46,14 @@ def run_query(be, plan, batches):
     return out, calls
 
 
-def run_query_native(be, plan, batches, stream=None):
-    """The same query through the C++ host driver (libaresdriver.so) instead of the Python mirror."""
+def run_query_native(be, plan, batches, stream=None, streams=None):
+    """The same query through the C++ host driver (libaresdriver.so) instead of the Python mirror.
+    streams: two handles -> batches alternate between them like the Go host (query/aql_processor.go:218)."""
     from .driver import NativeQuery
     names = list(batches[0][0].keys())
-    q = NativeQuery(be, plan, names, stream=stream)
+    q = NativeQuery(be, plan, names, stream=stream, streams=streams)
+    if streams:
+        stream = streams[0]
     for cols, valid in batches:
         dev = {k: DeviceColumn(be, t, v, valid=valid[k], stream=stream) for k, (t, v) in cols.items()}
         n = len(next(iter(cols.values()))[1])

@@ -212,9 +212,24 @@ def main(argv=None, backend=None, tensor_device=None):
         if distributed:
             dist.barrier()
 
+    # N > 1: the per-shard group tables meet in ONE exchange inside libaresdriver.so — all-gather of the
+    # padded columnar partials (RCCL on the query's stream over xGMI; gloo in the CPU test of this file)
+    # and a re-reduce with the library's own HashReduce; aresdb_amd/shard_merge.py is its test mirror
+    comm = None
+    if distributed:
+        from aresdb_amd.driver import NativeComm
+        if on_gpu:
+            def bcast(raw):
+                t = torch.tensor(list(raw), dtype=torch.uint8, device=tdev)
+                dist.broadcast(t, 0)
+                return bytes(t.cpu().tolist())
+            comm = NativeComm.rccl(rank, world, device_index, bcast)
+        else:
+            comm = NativeComm.torch_group()
+
     def merge(ctx):
-        from aresdb_amd.shard_merge import merge_shard_results
-        return merge_shard_results(ctx, tdev)
+        ctx.merge_shards(comm)
+        return ctx.result_size
 
     # ---- the timed region: W warm-up steps, then exactly K steps between barrier + synchronize ----
     for _ in range(args.warmup):
@@ -259,19 +274,21 @@ def main(argv=None, backend=None, tensor_device=None):
     ctx = last
 
     # ---- outside the timed region: key-level verification of this rank's final group table ----
+    merged_groups = merged_check = None
+    if distributed:  # `ctx` holds the merged table of all shards: check it, then redo the shard alone
+        merged_groups = int(merged)
+        if args.verify_merged and rank == 0:
+            every = []
+            for r in range(world):
+                every += workload.c3_shard(rows, batch_rows, seed=1 + r, device=tdev, null_fraction=args.null_fraction)
+            merged_check = check.compare_result(ctx.fetch(), check.exact_groups(every), hash_identity=True)
+        ctx.release()
+        ctx = run_shard(be, plan, vps, device_index, streams)
     report = check.compare_result(ctx.fetch(), check.exact_groups(batches), hash_identity=True)
     groups = ctx.result_size
     ok = report["status"] == "ok" and report["groups"] == groups
-    merged_groups = int(merged.size) if merged is not None else None
-    merged_check = None
-    if merged is not None and args.verify_merged and rank == 0:
-        every = []
-        for r in range(world):
-            every += workload.c3_shard(rows, batch_rows, seed=1 + r, device=tdev, null_fraction=args.null_fraction)
-        fetched = check.fetched_from_columnar(merged.dims.cpu().numpy(), merged.measures.cpu().numpy(), merged.size,
-                                              merged.capacity)
-        merged_check = check.compare_result(fetched, check.exact_groups(every), hash_identity=True)
-        ok = ok and merged_check["status"] == "ok"
+    if merged_check is not None:
+        ok = ok and merged_check["status"] == "ok" and merged_check["groups"] == merged_groups
     ctx.release()
 
     bytes_per_row = 5 * 4 + (5 / 8 if args.null_fraction > 0 else 0)
@@ -348,7 +365,7 @@ def main(argv=None, backend=None, tensor_device=None):
                        "rows_per_gpu": rows, "batch_rows": batch_rows, "batches": len(batches),
                        "streams_per_query": n_streams,
                        "groups_per_shard": groups, "merged_groups": merged_groups,
-                       "parallelism": f"{world} shard(s), one per GPU" + (", all_gather + re-reduce merge" if distributed else "")},
+                       "parallelism": f"{world} shard(s), one per GPU" + (", all-gather + re-reduce merge in libaresdriver.so" if distributed else "")},
             "rows_per_sec_per_gpu": value / world,
             "algorithmic_GBps_end_to_end": value / world * bytes_per_row / 1e9,
             "check_groups": report, "check_merged_groups": merged_check, "reference_host_check": ref_check,
@@ -361,6 +378,8 @@ def main(argv=None, backend=None, tensor_device=None):
         okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=tdev)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         ok = bool(int(okt))
+        if comm is not None:
+            comm.destroy()
         if backend is None:
             dist.destroy_process_group()
     for s in streams:

@@ -84,6 +84,10 @@ typedef struct {
 } AresMemAuxHooks;
 void AresMemSetAuxHooks(const AresMemAuxHooks *hooks); /* exported by libmem.so */
 void AresMemTrimCache(int device);                     /* exported by libmem.so */
+/* Books of libmem.so for one device: bytes / number of blocks the host holds (DeviceAllocate, deviceMalloc;
+ * held blocks were freed by the host but are kept aside for deferred work and are NOT counted as live),
+ * blocks kept aside, bytes parked in the cache.  Any pointer may be NULL. */
+void AresMemStats(int device, size_t *liveBytes, size_t *liveBlocks, size_t *heldBlocks, size_t *parkedBytes);
 
 /* Fused batch execution: filter -> dimension / measure projection -> hash reduction of ONE batch in
  * a single pass over the source columns, without the index / predicate / dimension vectors the

@@ -47,6 +47,59 @@ def _single_process_result(be, plan, all_batches):
     return out
 
 
+def _native_worker(rank, world, port, use_hash, q):
+    """The merge inside libaresdriver.so (C++), the collective supplied by torch.distributed / gloo."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import harness as H
+    from aresdb_amd import workload
+    from aresdb_amd.driver import NativeComm, NativeQuery
+    from aresdb_amd.queries import c3_plan
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        be = H.oracle_backend()
+        plan = c3_plan(use_hash_reduction=use_hash)
+        names = [n for n, _ in workload.C3_COLUMNS]
+        shards = [workload.c3_shard(5000 + 700 * r, 2048, seed=11 + r, device="cpu") for r in range(world)]
+        ctx = NativeQuery(be, plan, names)
+        for b in shards[rank]:
+            ctx.run({k: rc.vp for k, rc in b.items()}, next(iter(b.values())).length)
+        comm = NativeComm.torch_group()
+        ctx.merge_shards(comm)
+        dims, valids, meas = ctx.fetch()
+        n = ctx.result_size
+        m = meas.view(np.float64)
+        got = {tuple((bytes(d[r * len(d) // n:(r + 1) * len(d) // n]), int(v[r])) for d, v in zip(dims, valids)): m[r]
+               for r in range(n)}
+        want = _single_process_result(be, plan, [b for s in shards for b in s])
+        assert got.keys() == want.keys(), (len(got), len(want))
+        for k, v in want.items():
+            assert abs(got[k] - v) <= 1e-9 * max(1.0, abs(v)), (k, got[k], v)
+        comm.destroy()
+        ctx.release()
+        q.put((rank, "ok", len(got)))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, f"{type(e).__name__}: {e}", 0))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("use_hash", [True, False], ids=["hash_reduce", "sort_reduce"])
+def test_native_shard_merge_gloo(use_hash, world):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_native_worker, args=(r, world, port, use_hash, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in results), results
+    assert len({r[2] for r in results}) == 1 and results[0][2] > 0
+
+
 def _worker(rank, world, port, use_hash, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -123,6 +176,22 @@ def _gpu_worker(port, use_hash, q):
         assert got.keys() == want.keys(), (len(got), len(want))
         for k, v in want.items():
             assert abs(got[k] - v) <= 1e-9 * max(1.0, abs(v)), (k, got[k], v)
+        # the same merge inside libaresdriver.so: ncclAllGather on the query's stream, re-reduce, fetch
+        from aresdb_amd.driver import NativeComm
+
+        def bcast(raw):
+            t = torch.tensor(list(raw), dtype=torch.uint8, device=dev)
+            dist.broadcast(t, 0)
+            return bytes(t.cpu().tolist())
+        comm = NativeComm.rccl(0, 1, 0, bcast)
+        ctx.merge_shards(comm)
+        dims, valids, meas = ctx.fetch()
+        n2 = ctx.result_size
+        m2 = meas.view(np.float64)
+        got2 = {tuple((bytes(d[r * len(d) // n2:(r + 1) * len(d) // n2]), int(v[r])) for d, v in zip(dims, valids)): m2[r]
+                for r in range(n2)}
+        assert got2.keys() == want.keys() and all(abs(got2[k] - v) <= 1e-9 * max(1.0, abs(v)) for k, v in want.items())
+        comm.destroy()
         ctx.release()
         dist.destroy_process_group()
         q.put(("ok", len(got)))

@@ -311,6 +311,9 @@ int hash_reduce_lds(int device, const DimensionVector &inputKeys, const uint8_t 
 #undef ARES_HR_MERGE_ND
 #undef ARES_HR_MERGE
     res = read_result(ws, stream);
+    if (getenv("ARES_HR_TRACE"))
+      fprintf(stderr, "hash_reduce_lds: length %d start %d rows %d streams %d capA %llu capB %u partBits %d -> groups %u overflow %u stale %u\n",
+              length, start, rows, streams, static_cast<unsigned long long>(ws.capA), ws.capB, partBits, res.groups, res.overflow, res.stale);
     if (grouped && res.stale) {  // the input vectors are not what the previous merge wrote: the long way
       grouped_note_write(device, inputKeys.DimValues, static_cast<size_t>(L.rowBytes) * capacity);
       grouped = false;
@@ -319,6 +322,11 @@ int hash_reduce_lds(int device, const DimensionVector &inputKeys, const uint8_t 
     break;
   }
   if (res.overflow) {
+    static bool told = false;
+    if (!told) {
+      told = true;
+      fprintf(stderr, "libalgorithm: a hash-partition region overflowed (skewed hashes?): HashReduce falls back to the global table\n");
+    }
     give_ranges(device, outRanges);
     return -1;
   }

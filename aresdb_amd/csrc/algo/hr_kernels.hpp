@@ -587,7 +587,20 @@ __device__ __forceinline__ void partition_body(Source &src, const AggSpec &a, in
     }
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      if (rank[j] < capB) {  // (a full stream is reported once, by the epilogue)
+      if (((alive >> j) & 1u) && rank[j] >= capB) {
+        // The private stream is full: rows that arrive clustered by partition (previous results fed back
+        // without their grouping being known) overrun it by design.  Such records go to the shared
+        // region A instead — one global cursor reservation each, the slow but unbounded path.
+        const uint32_t p = pb ? h[j] >> (32 - pb) : 0u;
+        const uint64_t at = atomicAdd(ws.cursorsA + p, 1u);
+        const uint64_t v = src.final_bits(ws, c[j]);
+        if (at < ws.capA)
+          ws.recA[static_cast<uint64_t>(p) * ws.capA + at] =
+              make_uint4(src.row_id(i0 + j), h[j], static_cast<uint32_t>(v), static_cast<uint32_t>(v >> 32));
+        else
+          *ws_overflow(ws) = 1u;
+      }
+      if (rank[j] < capB) {
         const uint32_t p = pb ? h[j] >> (32 - pb) : 0u;
         uint32_t *dst = myB + (p * capB + rank[j]) * RW;
         if constexpr (RW == 4) {
@@ -610,10 +623,7 @@ __device__ __forceinline__ void partition_body(Source &src, const AggSpec &a, in
     __syncthreads();
     for (int p = threadIdx.x; p < numParts; p += kThreads) {
       uint32_t cnt = direct ? sPartCount[p] : 0u;
-      if (cnt > capB) {
-        *ws_overflow(ws) = 1u;
-        cnt = capB;
-      }
+      if (cnt > capB) cnt = capB;  // the rest went to region A
       ws.countsB[static_cast<uint64_t>(blockIdx.x) * numParts + p] = cnt;
     }
   }

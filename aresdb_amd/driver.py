@@ -396,6 +396,24 @@ class HostColumn:
             vp.BasePtr, vp.NullsOffset, vp.ValuesOffset = vo, 0, 0  # BasePtr = byte offset inside the allocation
         self.slice, self.cache_key = vp, cache_key
 
+    @classmethod
+    def from_blob(cls, be, data_type, blob, values_off, length, has_nulls, cache_key=0):
+        """From an allocation image that already has the upload layout (aresdb_amd.workload.ResidentColumn)."""
+        import numpy as np
+        self = cls.__new__(cls)
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        self.be, self.nbytes = be, len(blob)
+        self.host_ptr = be.call("HostAlloc", self.nbytes)
+        np.frombuffer((C.c_uint8 * self.nbytes).from_address(self.host_ptr), np.uint8)[:] = blob
+        vp = abi.VectorPartySlice()
+        vp.DataType, vp.Length, vp.StartingIndex = data_type, length, 0
+        if has_nulls:
+            vp.BasePtr, vp.NullsOffset, vp.ValuesOffset = 0, 0, values_off
+        else:
+            vp.BasePtr, vp.NullsOffset, vp.ValuesOffset = values_off, 0, 0
+        self.slice, self.cache_key = vp, cache_key
+        return self
+
     def free(self):
         if self.host_ptr:
             self.be.call("HostFree", self.host_ptr)

@@ -97,6 +97,41 @@ def cpu_baseline(batch, plan_factory, budget_s=15.0):
     return report, fetched, rows
 
 
+def host_batch_leg(be, plan, batches, device, streams, max_batches=4):
+    """PCIe-inclusive secondary leg (never `value`): the first batches of the shard handed over as pinned
+    host buffers — upload of batch k+1 overlapped with the execution of batch k, like the Go host
+    (query/aql_processor.go:850-881) — then the same query again with the columns resident in the
+    driver's HBM column cache."""
+    from aresdb_amd.driver import ColumnCache, HostColumn
+    take = batches[:max_batches]
+    hb = []
+    for b, cols in enumerate(take):
+        hcs = [HostColumn.from_blob(be, cols[k].data_type, cols[k].blob.cpu().numpy(), cols[k].values_off, cols[k].length,
+                                    cols[k].has_nulls, cache_key=100 * (b + 1) + i + 1) for i, k in enumerate(COLUMN_NAMES)]
+        hb.append((hcs, cols[COLUMN_NAMES[0]].length))
+    rows = sum(n for _, n in hb)
+    total_bytes = sum(hc.nbytes for cols, _ in hb for hc in cols)
+    cache = ColumnCache(be, device, budget_bytes=2 * total_bytes)
+    out = {"rows": rows, "batches": len(hb)}
+    for name, use_cache in (("pcie_inclusive", None), ("cache_fill", cache), ("cache_resident", cache)):
+        ctx = NativeQuery(be, plan, COLUMN_NAMES, device=device, streams=streams)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        stats = ctx.run_host_batches(hb, use_cache)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        rep = check.compare_result(ctx.fetch(), check.exact_groups(take), hash_identity=True)
+        ctx.release()
+        out[name] = {"rows_per_sec": rows / dt, "ms": dt * 1e3, "uploaded_GB": stats["uploaded_bytes"] / 1e9,
+                     "h2d_GBps": stats["uploaded_bytes"] / dt / 1e9, "cache_hits": stats["cache_hits"],
+                     "check_groups": rep["status"]}
+    cache.destroy()
+    for cols, _ in hb:
+        for hc in cols:
+            hc.free()
+    return out
+
+
 def library_sha():
     h = hashlib.sha256()
     with open(abi.hip_library_paths()[0], "rb") as f:
@@ -351,6 +386,10 @@ def main(argv=None, backend=None, tensor_device=None):
             legs["eager_abi_ARES_DEFER=0"] = run_leg({"ARES_DEFER": "0"}, big)
             legs["fused_extension"] = run_leg({}, big + ["--fused-extension"])
             legs[f"live_batches_{LIVE_BATCH_ROWS}_rows"] = run_leg({}, common + ["--batch-rows", str(LIVE_BATCH_ROWS)])
+            try:
+                legs["host_batches"] = host_batch_leg(be, plan, batches, device_index, streams)
+            except Exception as e:  # noqa: BLE001
+                legs["host_batches"] = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         value = rows * world * args.steps / elapsed

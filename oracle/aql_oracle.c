@@ -825,9 +825,12 @@ static Kind sink_result_kind(const Sink *s) {
 /* ------------------------------------------------------------------------------------------
  * generic drivers
  * ---------------------------------------------------------------------------------------- */
+static const char *run_array(const InputVector *in, const InputVector *rhs, Sink *s, int n, int ft);
+
 static const char *run_unary(const InputVector *in, Sink *s, const uint32_t *idx, int n,
                              const uint32_t *baseCounts, uint32_t startCount, int ft) {
   Operand a;
+  if (in->Type == ArrayVectorPartyInput) return run_array(in, NULL, s, n, ft);
   const char *e = bind_operand(&a, in, idx, baseCounts, startCount, true);
   if (e) return e;
   Kind ok = sink_result_kind(s);
@@ -843,6 +846,7 @@ static const char *run_binary(const InputVector *l, const InputVector *r_, Sink 
                               const uint32_t *idx, int n, const uint32_t *baseCounts,
                               uint32_t startCount, int ft) {
   Operand a, b;
+  if (l->Type == ArrayVectorPartyInput) return run_array(l, r_, s, n, ft);
   const char *e = bind_operand(&a, l, idx, baseCounts, startCount, true);
   if (e) return e;
   e = bind_operand(&b, r_, idx, baseCounts, startCount, false);
@@ -862,6 +866,160 @@ static const char *run_binary(const InputVector *l, const InputVector *r_, Sink 
     Val r = binary_apply(ft, x, y, ok);
     sink_store(s, i, r);
   }
+  return NULL;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * array columns — query/iterator.hpp:377-451 (ArrayVectorPartyIterator), query/functor.hpp:468-640
+ * (ArrayLength / ArrayElementAt / ArrayContains), binding rules query/binder.hpp:385-426, :458-560.
+ * An array column is [offset u32, length u32] x Length followed by the values; one array value is
+ * [length u32][elements][validity bits].  The iterator is NOT zipped with the index vector: output
+ * position i reads array i (binder.hpp:392-394 binds the bare iterator).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+  const uint8_t *value; /* NULL: empty (valid) or null (invalid) array */
+  bool ok;
+} ArrayRef;
+
+static ArrayRef array_at(const ArrayVectorPartySlice *a, int i) {
+  const uint8_t *base = a->OffsetLengthVector;
+  const uint8_t *valuePtr = base + 8 * (size_t)a->Length - a->ValueOffsetAdj;
+  uint32_t offset, length;
+  memcpy(&offset, base + 8 * (size_t)i, 4);
+  memcpy(&length, base + 8 * (size_t)i + 4, 4);
+  ArrayRef r;
+  if (length == 0) { r.value = NULL; r.ok = offset != 0; return r; }
+  r.value = valuePtr + offset;
+  r.ok = true;
+  return r;
+}
+
+/* element j of an array value as a Val of the element's storage kind */
+static Val array_element(const uint8_t *elems, enum DataType t, int j) {
+  Val r;
+  memset(&r, 0, sizeof(r));
+  r.ok = true;
+  r.k = kind_of_datatype(t);
+  switch (t) {
+    case Bool: r.v.b = elems[j] != 0; break;
+    case Int8: r.v.i = (int8_t)elems[j]; break;
+    case Uint8: r.v.u = elems[j]; break;
+    case Int16: { int16_t x; memcpy(&x, elems + 2 * j, 2); r.v.i = x; break; }
+    case Uint16: { uint16_t x; memcpy(&x, elems + 2 * j, 2); r.v.u = x; break; }
+    case Int32: memcpy(&r.v.i, elems + 4 * j, 4); break;
+    case Uint32: memcpy(&r.v.u, elems + 4 * j, 4); break;
+    case Float32: memcpy(&r.v.f, elems + 4 * j, 4); break;
+    case Int64: memcpy(&r.v.l, elems + 8 * j, 8); break;
+    case UUID: memcpy(&r.v.uuid, elems + 16 * j, 16); break;
+    case GeoPoint: memcpy(&r.v.geo, elems + 8 * j, 8); break;
+    default: break;
+  }
+  return r;
+}
+
+static Val null_of(Kind k) {
+  Val r;
+  memset(&r, 0, sizeof(r));
+  r.k = k;
+  return r;
+}
+
+/* result of one array functor at position i; `ok_kind` = value type O of the sink's functor result;
+ * c = constant second operand (binary functors), NULL for ArrayLength */
+static Val array_apply(const ArrayVectorPartySlice *a, int i, int ft, bool binary, const ConstantVector *c, enum DataType odt) {
+  const Kind ok_kind = kind_of_datatype(odt) == K_NONE ? K_F32 : kind_of_datatype(odt); /* kind of a null result */
+  const enum DataType t = a->DataType;
+  const int w = step_in_bytes(t);
+  const Kind ek = kind_of_datatype(t);
+  ArrayRef ar = array_at(a, i);
+  if (!binary) { /* functor.hpp:700-723: only ArrayLength, and only into uint32 */
+    if (ft != ArrayLength || odt != Uint32) return null_of(ok_kind);
+    Val r = null_of(K_U32);
+    if (!ar.ok) return r;
+    r.ok = true;
+    if (ar.value) memcpy(&r.v.u, ar.value, 4);
+    return r;
+  }
+  const bool wide = ek == K_UUID || ek == K_GEO;
+  if (ft == ArrayContains) { /* functor.hpp:610-640: result type bool only */
+    if (odt != Bool) return null_of(ok_kind);
+    if (wide ? (ek == K_UUID ? c->DataType != ConstUUID : (c->DataType != ConstGeoPoint && c->DataType != ConstUUID))
+             : (c->DataType != ConstInt && c->DataType != ConstFloat))
+      return null_of(K_BOOL); /* (binder.hpp:483-558 lets ConstInt through for wide arrays: generic functor, null) */
+    Val r = null_of(K_BOOL);
+    if (!ar.ok) return r;
+    r.ok = true;
+    if (!ar.value) return r;
+    int32_t len;
+    memcpy(&len, ar.value, 4);
+    if (len <= 0) return r;
+    const uint8_t *elems = ar.value + 4, *valid = elems + ((size_t)w * 8 * len + 7) / 8;
+    for (int j = 0; j < len; j++) {
+      if (!get_bit(valid, (uint32_t)j)) continue;
+      Val e = array_element(elems, t, j);
+      bool eq;
+      if (ek == K_UUID) eq = e.v.uuid.p1 == c->Value.UUIDVal.p1 && e.v.uuid.p2 == c->Value.UUIDVal.p2;
+      else if (ek == K_GEO) /* the constant travels in the upper half of SimpleIterator<GeoPointT>'s 64-bit pointer
+                             * (iterator.hpp:484-516), which keeps its first 4 bytes only: Long arrives as 0 */
+        eq = e.v.geo.Lat == c->Value.GeoPointVal.Lat && e.v.geo.Long == 0.0f;
+      else { /* val = static_cast<input_type>(constant); equals(val, element) */
+        const bool cf = c->DataType == ConstFloat;
+        switch (t) {
+          case Bool: eq = (cf ? c->Value.FloatVal != 0.0f : c->Value.IntVal != 0) == e.v.b; break;
+          case Int8: eq = (cf ? (int8_t)c->Value.FloatVal : (int8_t)c->Value.IntVal) == (int8_t)e.v.i; break;
+          case Uint8: eq = (cf ? (uint8_t)c->Value.FloatVal : (uint8_t)c->Value.IntVal) == (uint8_t)e.v.u; break;
+          case Int16: eq = (cf ? (int16_t)c->Value.FloatVal : (int16_t)c->Value.IntVal) == (int16_t)e.v.i; break;
+          case Uint16: eq = (cf ? (uint16_t)c->Value.FloatVal : (uint16_t)c->Value.IntVal) == (uint16_t)e.v.u; break;
+          case Int32: eq = (cf ? (int32_t)c->Value.FloatVal : c->Value.IntVal) == e.v.i; break;
+          case Uint32: eq = (cf ? (uint32_t)c->Value.FloatVal : (uint32_t)c->Value.IntVal) == e.v.u; break;
+          case Float32: eq = (cf ? c->Value.FloatVal : (float)c->Value.IntVal) == e.v.f; break;
+          case Int64: eq = (cf ? (int64_t)c->Value.FloatVal : (int64_t)c->Value.IntVal) == e.v.l; break;
+          default: eq = false; break;
+        }
+      }
+      if (eq) { r.v.b = true; return r; }
+    }
+    return r;
+  }
+  if (ft == ArrayElementAt) { /* functor.hpp:515-571: index must be ConstInt; UUID / GeoPoint only into themselves */
+    if (c->DataType != ConstInt) return null_of(ok_kind);
+    if ((ek == K_UUID) != (odt == UUID) || (ek == K_GEO) != (odt == GeoPoint)) return null_of(ok_kind);
+    Val zero = null_of(wide ? ek : ok_kind);
+    if (!ar.ok || !ar.value) return zero;
+    uint32_t ulen;
+    memcpy(&ulen, ar.value, 4);
+    int index = c->Value.IntVal;
+    if ((index >= 0 && ulen <= (uint32_t)index) || (index < 0 && ulen < (uint32_t)(-index))) return zero;
+    const int len = (int)ulen;
+    if (index < 0) index = len + index;
+    if (len == 0 || index >= len || index < 0) return zero;
+    const uint8_t *elems = ar.value + 4, *valid = elems + ((size_t)w * 8 * len + 7) / 8;
+    if (!get_bit(valid, (uint32_t)index)) return zero;
+    return array_element(elems, t, index); /* the sink applies static_cast<O>(element) */
+  }
+  return null_of(ok_kind);
+}
+
+static const char *run_array(const InputVector *in, const InputVector *rhs, Sink *s, int n, int ft) {
+  const ArrayVectorPartySlice *a = &in->Vector.ArrayVP;
+  if (kind_of_datatype(a->DataType) == K_NONE) return "Unsupported data type for ArrayVectorPartyInput";
+  if (rhs && rhs->Type != ConstantInput)
+    return "Unsupported data type when value type of first input iterator is ArrayVP Iterator";
+  if (rhs) { /* binder.hpp:469-558: which constants an array of this element type binds with */
+    const Kind ek = kind_of_datatype(a->DataType);
+    const int ct = (int)rhs->Vector.Constant.DataType;
+    bool okc = ek == K_UUID ? (ct == ConstInt || ct == ConstUUID)
+               : ek == K_GEO ? (ct == ConstInt || ct == ConstGeoPoint || ct == ConstUUID)
+                             : (ct == ConstInt || ct == ConstFloat);
+    if (!okc) return "Unsupported data type when value type of first input iterator is ArrayVP Iterator";
+  }
+  /* O = value type of the sink's iterator: the stored data type (bool for a filter's predicate) */
+  enum DataType odt = Bool;
+  if (s->out)
+    odt = s->out->Type == ScratchSpaceOutput ? s->out->Vector.ScratchSpace.DataType
+          : s->out->Type == DimensionOutput ? s->out->Vector.Dimension.DataType : s->out->Vector.Measure.DataType;
+  for (int i = 0; i < n; i++)
+    sink_store(s, i, array_apply(a, i, ft, rhs != NULL, rhs ? &rhs->Vector.Constant : NULL, odt));
   return NULL;
 }
 

@@ -156,7 +156,8 @@ inline void bind_operand(const InputVector &in, bool first, hipStream_t stream, 
       return;
     }
     default:
-      throw std::invalid_argument("Array columns are not supported by this build (SURVEY.md 8: out of scope)");
+      // array columns bind as the FIRST operand only, through bind_array (binder.hpp:385-426)
+      throw std::invalid_argument("Unsupported input vector type for this operand");
   }
 }
 

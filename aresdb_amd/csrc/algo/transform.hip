@@ -263,6 +263,119 @@ __global__ __launch_bounds__(kBlock) void transform_wide_kernel(EvalParams p, Si
 }
 
 // ---------------------------------------------------------------------------------------------
+// array columns: ArrayLength / ArrayContains / ArrayElementAt (query/iterator.hpp:377-451,
+// query/functor.hpp:468-640).  An array column is [offset u32, length u32] x Length followed by the
+// array values [length u32][elements][validity bits]; output position i reads array i — the
+// reference binds the bare iterator, not one zipped with the index vector (binder.hpp:385-426).
+// One lane per array: the descriptors load coalesced, the element walks are short and divergent.
+// ---------------------------------------------------------------------------------------------
+struct ArrayD {
+  const uint8_t *descriptors;  // OffsetLengthVector
+  const uint8_t *values;       // descriptors + 8 * Length - ValueOffsetAdj
+  int dtype, kind, width;      // element type
+  int functor;                 // ArrayLength / ArrayContains / ArrayElementAt
+  int enabled;                 // 0: the functor / sink / constant combination yields null everywhere
+  int index;                   // ArrayElementAt
+  uint64_t c[2];               // ArrayContains: the constant, already cast to the element type
+  const uint32_t *idx;         // rows for a measure sink's run lengths
+};
+
+__device__ __forceinline__ bool array_elem_equals(const ArrayD &a, const uint8_t *e) {
+  switch (a.dtype) {
+    case Bool: return (*e != 0) == (a.c[0] != 0);
+    case Int8: case Uint8: return *e == static_cast<uint8_t>(a.c[0]);
+    case Int16: case Uint16: return *reinterpret_cast<const uint16_t *>(e) == static_cast<uint16_t>(a.c[0]);
+    case Int32: case Uint32: return *reinterpret_cast<const uint32_t *>(e) == static_cast<uint32_t>(a.c[0]);
+    case Float32: return bits_f(*reinterpret_cast<const uint32_t *>(e)) == bits_f(static_cast<uint32_t>(a.c[0]));
+    case Int64: {  // elements start 4 bytes into an 8-byte aligned value: read words
+      const uint32_t *w = reinterpret_cast<const uint32_t *>(e);
+      return w[0] == static_cast<uint32_t>(a.c[0]) && w[1] == static_cast<uint32_t>(a.c[0] >> 32);
+    }
+    case GeoPoint: {
+      const uint32_t *w = reinterpret_cast<const uint32_t *>(e);
+      return bits_f(w[0]) == bits_f(static_cast<uint32_t>(a.c[0])) && bits_f(w[1]) == bits_f(static_cast<uint32_t>(a.c[0] >> 32));
+    }
+    default: {  // UUID
+      const uint32_t *w = reinterpret_cast<const uint32_t *>(e);
+      return w[0] == static_cast<uint32_t>(a.c[0]) && w[1] == static_cast<uint32_t>(a.c[0] >> 32) &&
+             w[2] == static_cast<uint32_t>(a.c[1]) && w[3] == static_cast<uint32_t>(a.c[1] >> 32);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void array_transform_kernel(ArrayD a, SinkD s, int n) {
+  const bool sinkWide = s.type != SINK_PRED && s.type != SINK_MEASURE && (s.dtype == UUID || s.dtype == GeoPoint);
+  for (int64_t i64 = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i64 < n;
+       i64 += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const uint32_t i = static_cast<uint32_t>(i64);
+    const uint32_t row = a.idx ? a.idx[i] : i;
+    DVal r;
+    r.bits = 0;
+    r.ok = 0;
+    int rk = K_U32;
+    if (a.enabled) {
+      const uint2 d = *reinterpret_cast<const uint2 *>(a.descriptors + 8ull * i);  // {offset, length}
+      const uint8_t *value = d.y ? a.values + d.x : nullptr;
+      const bool present = d.y != 0 || d.x != 0;  // (0, 0) is a null array, (x, 0) an empty one
+      if (a.functor == ArrayLength) {
+        r.ok = present;
+        if (value) r.bits = *reinterpret_cast<const uint32_t *>(value);
+      } else if (a.functor == ArrayContains) {
+        rk = K_BOOL;
+        r.ok = present;
+        const int len = value ? static_cast<int>(*reinterpret_cast<const uint32_t *>(value)) : 0;
+        if (len > 0) {
+          const uint8_t *elems = value + 4, *valid = elems + static_cast<size_t>(a.width) * static_cast<uint32_t>(len);
+          for (int j = 0; j < len; j++)
+            if (((valid[j >> 3] >> (j & 7)) & 1) && array_elem_equals(a, elems + static_cast<size_t>(a.width) * j)) {
+              r.bits = 1;
+              break;
+            }
+        }
+      } else if (value) {  // ArrayElementAt (functor.hpp:536-571): a negative index counts from the end
+        const uint32_t ulen = *reinterpret_cast<const uint32_t *>(value);
+        int index = a.index;
+        const bool out = (index >= 0 && ulen <= static_cast<uint32_t>(index)) || (index < 0 && ulen < static_cast<uint32_t>(-index));
+        const int len = static_cast<int>(ulen);
+        if (index < 0) index = len + index;
+        const uint8_t *elems = value + 4, *valid = elems + static_cast<size_t>(a.width) * ulen;
+        if (!out && len != 0 && index < len && index >= 0 && ((valid[index >> 3] >> (index & 7)) & 1)) {
+          const uint8_t *e = elems + static_cast<size_t>(a.width) * index;
+          if (a.kind == K_UUID || a.kind == K_GEO) {  // only into a sink of its own type (checked on the host)
+            uint8_t *dst = s.values + static_cast<size_t>(s.width) * i;
+            const uint32_t *w = reinterpret_cast<const uint32_t *>(e);
+            for (int k = 0; k < a.width / 4; k++) reinterpret_cast<uint32_t *>(dst)[k] = w[k];
+            s.nulls[i] = 1;
+            continue;
+          }
+          if (a.kind == K_I64) {
+            const uint32_t *w = reinterpret_cast<const uint32_t *>(e);
+            const int64_t v = static_cast<int64_t>(static_cast<uint64_t>(w[0]) | (static_cast<uint64_t>(w[1]) << 32));
+            if (sinkWide) {
+              sink_store32(s, i, row, r, rk);
+            } else {
+              store_from_i64(s, i, row, v, 1u);
+            }
+            continue;
+          }
+          r.ok = 1;
+          rk = a.kind;
+          switch (a.dtype) {
+            case Bool: r.bits = *e != 0; break;
+            case Int8: r.bits = static_cast<uint32_t>(static_cast<int32_t>(*reinterpret_cast<const int8_t *>(e))); break;
+            case Uint8: r.bits = *e; break;
+            case Int16: r.bits = static_cast<uint32_t>(static_cast<int32_t>(*reinterpret_cast<const int16_t *>(e))); break;
+            case Uint16: r.bits = *reinterpret_cast<const uint16_t *>(e); break;
+            default: r.bits = *reinterpret_cast<const uint32_t *>(e); break;
+          }
+        }
+      }
+    }
+    sink_store32(s, i, row, r, rk);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // filter: fused predicate + stable in-place compaction (decoupled look-back)
 // ---------------------------------------------------------------------------------------------
 constexpr int kFilterItems = 8;
@@ -1448,11 +1561,91 @@ static bool fast_sink(const SinkD &s) {
   return (s.type == SINK_DIM || s.type == SINK_SCRATCH) && four;
 }
 
+// Binds an array column and its functor (query/binder.hpp:385-426, :458-560): the second operand
+// of a binary array functor is a constant whose type fits the element type; `odt` is the value type
+// of the sink (Bool for a filter's predicate).  Combinations the reference resolves to its generic
+// "null" functor (functor.hpp:468-513, :573-590, :700-723) run with enabled = 0.
+static void bind_array(const InputVector *ins, int arity, int functor, int odt, ArrayD &a) {
+  const ArrayVectorPartySlice &vp = ins[0].Vector.ArrayVP;
+  memset(&a, 0, sizeof(a));
+  a.kind = kind_of_datatype(vp.DataType);
+  if (a.kind == K_NONE) throw std::invalid_argument("Unsupported data type for ArrayVectorPartyInput");
+  a.dtype = vp.DataType;
+  a.width = step_in_bytes(vp.DataType);
+  a.descriptors = vp.OffsetLengthVector;
+  a.values = vp.OffsetLengthVector + 8ull * vp.Length - vp.ValueOffsetAdj;
+  a.functor = functor;
+  const char *badOperand = "Unsupported data type when value type of first input iterator is ArrayVP Iterator";
+  if (arity == 1) {
+    a.enabled = functor == ArrayLength && odt == Uint32;
+    return;
+  }
+  if (ins[1].Type != ConstantInput) throw std::invalid_argument(badOperand);
+  const ConstantVector &c = ins[1].Vector.Constant;
+  const int ct = c.DataType;
+  const bool fits = a.kind == K_UUID ? (ct == ConstInt || ct == ConstUUID)
+                    : a.kind == K_GEO ? (ct == ConstInt || ct == ConstGeoPoint || ct == ConstUUID)
+                                      : (ct == ConstInt || ct == ConstFloat);
+  if (!fits) throw std::invalid_argument(badOperand);
+  if (functor == ArrayElementAt) {
+    a.index = c.Value.IntVal;
+    a.enabled = ct == ConstInt && (a.kind == K_UUID) == (odt == UUID) && (a.kind == K_GEO) == (odt == GeoPoint);
+    return;
+  }
+  if (functor != ArrayContains || odt != Bool) return;
+  if (a.kind == K_UUID) {
+    a.enabled = ct == ConstUUID;
+    memcpy(a.c, &c.Value.UUIDVal, 16);
+    return;
+  }
+  if (a.kind == K_GEO) {
+    // the reference carries this constant in the upper half of a 64-bit pointer
+    // (iterator.hpp:484-516, SimpleIterator<GeoPointT>): only its first four bytes survive, Long is 0
+    a.enabled = ct != ConstInt;
+    memcpy(a.c, &c.Value.GeoPointVal, 4);
+    return;
+  }
+  a.enabled = 1;  // val = static_cast<element type>(constant) (functor.hpp:655)
+  const bool cf = ct == ConstFloat;
+  const float fv = c.Value.FloatVal;
+  const int32_t iv = c.Value.IntVal;
+  switch (vp.DataType) {
+    case Bool: a.c[0] = cf ? fv != 0.0f : iv != 0; break;
+    case Int8: a.c[0] = static_cast<uint8_t>(cf ? static_cast<int8_t>(fv) : static_cast<int8_t>(iv)); break;
+    case Uint8: a.c[0] = cf ? static_cast<uint8_t>(fv) : static_cast<uint8_t>(iv); break;
+    case Int16: a.c[0] = static_cast<uint16_t>(cf ? static_cast<int16_t>(fv) : static_cast<int16_t>(iv)); break;
+    case Uint16: a.c[0] = cf ? static_cast<uint16_t>(fv) : static_cast<uint16_t>(iv); break;
+    case Int32: a.c[0] = static_cast<uint32_t>(cf ? static_cast<int32_t>(fv) : iv); break;
+    case Uint32: a.c[0] = cf ? static_cast<uint32_t>(fv) : static_cast<uint32_t>(iv); break;
+    case Float32: { const float x = cf ? fv : static_cast<float>(iv); uint32_t b; memcpy(&b, &x, 4); a.c[0] = b; break; }
+    default: a.c[0] = static_cast<uint64_t>(cf ? static_cast<int64_t>(fv) : static_cast<int64_t>(iv)); break;  // Int64
+  }
+}
+
+static void launch_array(const ArrayD &a, const SinkD &s, int n, hipStream_t stream) {
+  const int grid = capped_grid((static_cast<int64_t>(n) + kBlock - 1) / kBlock);
+  ARES_LAUNCH("array_transform_kernel", array_transform_kernel, grid, kBlock, stream, a, s, n);
+}
+
 static int run_transform(const InputVector *ins, int arity, const OutputVector &output, uint32_t *indexVector,
                          int n, uint32_t *baseCounts, uint32_t startCount, int functor, hipStream_t stream, int device) {
   if (n <= 0) {
     flush_deferred(device);
     return n < 0 ? 0 : n;
+  }
+  if (ins[0].Type == ArrayVectorPartyInput) {
+    SinkD s;
+    bind_sink(output, baseCounts, s);
+    ArrayD a;
+    bind_array(ins, arity, functor, s.dtype, a);
+    if (s.type == SINK_MEASURE && s.baseCounts) a.idx = indexVector;
+    if (s.type == SINK_DIM || s.type == SINK_MEASURE) {
+      grouped_note_write(device, s.values, static_cast<size_t>(s.width) * n);
+      if (s.nulls) grouped_note_write(device, s.nulls, static_cast<size_t>(n));
+    }
+    flush_deferred(device);
+    launch_array(a, s, n, stream);
+    return n;
   }
   EvalParams p;
   SinkD s;
@@ -1497,7 +1690,15 @@ static int run_filter(const InputVector *ins, int arity, uint32_t *indexVector, 
   }
   EvalParams p;
   CallTemps temps;
-  build_params(ins, arity, stream, indexVector, baseCounts, startCount, functor, p, temps);
+  const bool isArray = ins[0].Type == ArrayVectorPartyInput;
+  ArrayD arr;
+  if (isArray) {
+    bind_array(ins, arity, functor, Bool, arr);
+    memset(&p, 0, sizeof(p));
+    p.a.kind = K_UUID;  // routed like a wide operand: predicate first, then compaction by predicate
+  } else {
+    build_params(ins, arity, stream, indexVector, baseCounts, startCount, functor, p, temps);
+  }
   p.needRow = 1;
   // a filter of the hot shape consumes a not-yet-written iota index vector directly; everything
   // else that is pending on the device is launched first
@@ -1514,7 +1715,10 @@ static int run_filter(const InputVector *ins, int arity, uint32_t *indexVector, 
     bind_pred_sink(pred, s);
     p.needRow = indexVector != nullptr;
     const int grid = capped_grid((static_cast<int64_t>(n) + kBlock - 1) / kBlock);
-    ARES_LAUNCH("transform_wide_kernel", transform_wide_kernel, grid, kBlock, stream, p, s, n);
+    if (isArray)
+      launch_array(arr, s, n, stream);
+    else
+      ARES_LAUNCH("transform_wide_kernel", transform_wide_kernel, grid, kBlock, stream, p, s, n);
   }
   FastOperands f;
   const bool fast = !is_wide(p.a.kind) && indexVector != nullptr && fast_operands(p, f, true);

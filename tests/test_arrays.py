@@ -153,7 +153,8 @@ def _run_array_ops(be, seed):
         out["element_wide"] = (s.buf.read(np.uint8, w * n).tobytes(), s.valid().tobytes())
         s.free()
     else:
-        for ot in (abi.Uint32, abi.Int32, abi.Float32):   # static_cast<O>(element)
+        # static_cast<O>(element); a negative float into uint32 is undefined in C++ (x86 and the GPU differ)
+        for ot in ((abi.Int32, abi.Float32) if dtype == abi.Float32 else (abi.Uint32, abi.Int32, abi.Float32)):
             s = H.Scratch(be, n, ot)
             be.call("BinaryTransform", inp, index, s.output(), None, n, None, 0, abi.ArrayElementAt, None, 0)
             be.wait()

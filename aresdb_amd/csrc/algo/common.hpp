@@ -39,7 +39,7 @@ void flush_deferred(int device);
 bool fuse_pending_into_hash_reduce(int device, hipStream_t stream, const DimensionVector &in, const uint8_t *inValues,
                                    const DimensionVector &out, uint8_t *outValues, int valueBytes, int length, int aggFunc,
                                    int *groups);
-void invalidate_filter_journal(const uint32_t *indexVector);
+void invalidate_filter_journal(int device, const uint32_t *indexVector);
 // true when the sibling libmem.so reports waits, frees and copies to this library (transform.hip)
 bool deferral_hooks_active();
 // something writes (or frees) [ptr, ptr + bytes): partition-grouped results that overlap are no longer

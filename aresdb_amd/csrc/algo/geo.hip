@@ -279,7 +279,7 @@ __global__ __launch_bounds__(kBlock) void geo_shape_dim_kernel(GeoDimParams p) {
 
 int geo_batch_intersects(const GeoShapeBatch &shapes, const InputVector &points, uint32_t *indexVector, int n,
                          RecordID **recordIDVectors, int numForeignTables, uint32_t *outputPredicate, bool inOrOut,
-                         hipStream_t stream) {
+                         hipStream_t stream, int device) {
   GeoPointsD P;
   memset(&P, 0, sizeof(P));
   std::vector<ForeignBatchD> hostBatches;
@@ -321,7 +321,7 @@ int geo_batch_intersects(const GeoShapeBatch &shapes, const InputVector &points,
     throw std::invalid_argument("Unsupported data type for geo intersection contexts");
   }
   if (numForeignTables < 0 || numForeignTables > 8) throw std::invalid_argument("only support up to 8 foreign tables");
-  invalidate_filter_journal(indexVector);  // the index vector is compacted by something a fused scan cannot replay
+  invalidate_filter_journal(device, indexVector);  // the index vector is compacted by something a fused scan cannot replay
   if (n <= 0) return 0;
   const int N = shapes.TotalNumPoints, W = shapes.TotalWords;
   if (W > 8) throw std::invalid_argument("geo intersection supports up to 256 shapes");
@@ -380,7 +380,7 @@ CGoCallResHandle GeoBatchIntersects(GeoShapeBatch geoShapeBatch, InputVector poi
   (void)startCount;  // geo columns are never run-length decoded (query/geo_intersects.cu:160-163)
   resHandle.res = int_result(geo_batch_intersects(geoShapeBatch, points, indexVector, indexVectorLength, recordIDVectors,
                                                   numForeignTables, outputPredicate, inOrOut,
-                                                  reinterpret_cast<hipStream_t>(cudaStream)));
+                                                  reinterpret_cast<hipStream_t>(cudaStream), device));
   ARES_ABI_END("GeoBatchIntersects")
 }
 

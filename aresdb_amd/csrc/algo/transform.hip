@@ -1091,16 +1091,25 @@ struct PendingQueue {
   // restore "the stream is idle" before anybody looks
   bool overWait = false;
 };
-std::mutex g_deferMutex;
-// Stream synchronisations that work done under g_deferMutex asks for (a queue the host has already
+struct DeferState;
+DeferState &state_of(int device);
+// The deferral state is per device: queries on different GPUs of one process never contend, and the
+// work done under a device's mutex is bookkeeping and kernel launches only (synchronisations run after
+// the unlock, see below).  DeferLock selects the state its holder works on; the helpers marked
+// "caller holds the device's DeferLock" reach it through t_state.
+thread_local DeferState *t_state = nullptr;
+// Stream synchronisations that work done under a DeferLock asks for (a queue the host has already
 // waited for was launched late; a copy is about to read what a late launch writes): they run after
 // the mutex is released, so one query's late launch never stalls the other streams of the device.
 thread_local std::vector<hipStream_t> t_syncAfterUnlock;
 struct DeferLock {
   std::unique_lock<std::mutex> lock;
-  DeferLock() : lock(g_deferMutex) {}
+  explicit DeferLock(int device);
   void unlock() {
-    if (lock.owns_lock()) lock.unlock();
+    if (lock.owns_lock()) {
+      t_state = nullptr;
+      lock.unlock();
+    }
     drain();
   }
   static void drain() {
@@ -1113,12 +1122,14 @@ struct DeferLock {
     }
   }
   ~DeferLock() noexcept(false) {
-    if (lock.owns_lock()) lock.unlock();
+    if (lock.owns_lock()) {
+      t_state = nullptr;
+      lock.unlock();
+    }
     if (std::uncaught_exceptions() == 0) drain();
     else t_syncAfterUnlock.clear();
   }
 };
-std::map<std::pair<int, hipStream_t>, PendingQueue> g_pending;
 
 // Filters of the hot shape that have compacted an index vector since its InitIndexVector: with them
 // HashReduce can re-derive the survivors from the source columns instead of reading index, dimension
@@ -1132,12 +1143,10 @@ struct FilterJournal {
   std::vector<FastOperands> filters;
   std::vector<uint32_t> colRows;
 };
-std::map<const uint32_t *, FilterJournal> g_journals;
 
 // Queues that a HashReduce consumed on the fly: their outputs were never written.  They stay
 // launchable (their inputs are held by libmem.so) until the stream starts its next batch or the
 // outputs are freed; a copy that touches an output launches them first.
-std::map<std::pair<int, hipStream_t>, PendingQueue> g_limbo;
 void (*g_releaseHeld)(int, uintptr_t) = nullptr;  // AresMemReleaseHeld of the sibling libmem.so
 // Blocks are held on behalf of ONE stream's pending work: the tag names that stream, so that one
 // query's progress never releases what another query's not-yet-launched kernels still read.
@@ -1166,7 +1175,6 @@ struct PendingCompact {
   unsigned int *ticket;
   uint32_t *error, *tileOffsets, *loaded;
 };
-std::map<const uint32_t *, PendingCompact> g_compactions;
 
 // Index vectors that InitIndexVector has defined but not written yet ("virtual iota"): the fast
 // filter and transform kernels that consume them compute rows = position instead of loading 4 bytes
@@ -1177,7 +1185,6 @@ struct PendingIota {
   uint32_t start;
   int n;
 };
-std::map<uint32_t *, PendingIota> g_iotas;
 
 void hook_on_wait(int device, void *stream);
 uintptr_t hook_on_free(int device, void *ptr, size_t bytes);
@@ -1235,18 +1242,34 @@ struct ErrorCheck {
   uint32_t *pinned;
   std::shared_ptr<StreamBuffer> ws;  // keeps the error word alive until the copy has run
 };
-std::vector<ErrorCheck> g_errorChecks;
-std::vector<std::pair<hipEvent_t, uint32_t *>> g_errorSlots;  // recycled (event, pinned word) pairs
 
-// caller holds g_deferMutex
+struct DeferState {
+  std::mutex mutex;
+  std::map<std::pair<int, hipStream_t>, PendingQueue> pending;  // root transforms queued per (device, stream)
+  std::map<std::pair<int, hipStream_t>, PendingQueue> limbo;    // queues a HashReduce consumed on the fly
+  std::map<const uint32_t *, FilterJournal> journals;
+  std::map<const uint32_t *, PendingCompact> compactions;
+  std::map<uint32_t *, PendingIota> iotas;
+  std::vector<ErrorCheck> errorChecks;
+  std::vector<std::pair<hipEvent_t, uint32_t *>> errorSlots;  // recycled (event, pinned word) pairs
+};
+constexpr int kMaxDevices = 64;
+DeferState &state_of(int device) {
+  static DeferState states[kMaxDevices];
+  if (device < 0 || device >= kMaxDevices) throw std::invalid_argument("device index out of range");
+  return states[device];
+}
+DeferLock::DeferLock(int device) : lock(state_of(device).mutex) { t_state = &state_of(device); }
+
+// caller holds the device's DeferLock
 void watch_error_word(int device, hipStream_t stream, const uint32_t *errorDev, std::shared_ptr<StreamBuffer> ws) {
   ErrorCheck c;
   c.device = device;
   c.ws = std::move(ws);
-  if (!g_errorSlots.empty()) {
-    c.done = g_errorSlots.back().first;
-    c.pinned = g_errorSlots.back().second;
-    g_errorSlots.pop_back();
+  if (!t_state->errorSlots.empty()) {
+    c.done = t_state->errorSlots.back().first;
+    c.pinned = t_state->errorSlots.back().second;
+    t_state->errorSlots.pop_back();
   } else {
     hip_check(hipEventCreateWithFlags(&c.done, hipEventDisableTiming), "hipEventCreate");
     hip_check(hipHostMalloc(reinterpret_cast<void **>(&c.pinned), sizeof(uint32_t), hipHostMallocPortable), "hipHostMalloc");
@@ -1254,19 +1277,19 @@ void watch_error_word(int device, hipStream_t stream, const uint32_t *errorDev, 
   *c.pinned = 0;
   hip_check(hipMemcpyAsync(c.pinned, errorDev, sizeof(uint32_t), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync");
   hip_check(hipEventRecord(c.done, stream), "hipEventRecord");
-  g_errorChecks.push_back(std::move(c));
+  t_state->errorChecks.push_back(std::move(c));
 }
 
-// caller holds g_deferMutex; throws when a finished lazy compaction reported a failure
+// caller holds the device's DeferLock; throws when a finished lazy compaction reported a failure
 void poll_error_words(int device) {
   bool failed = false;
-  for (size_t i = 0; i < g_errorChecks.size();) {
-    ErrorCheck &c = g_errorChecks[i];
+  for (size_t i = 0; i < t_state->errorChecks.size();) {
+    ErrorCheck &c = t_state->errorChecks[i];
     if (c.device == device && hipEventQuery(c.done) == hipSuccess) {
       failed = failed || *c.pinned != 0;
-      g_errorSlots.emplace_back(c.done, c.pinned);
-      g_errorChecks[i] = std::move(g_errorChecks.back());
-      g_errorChecks.pop_back();
+      t_state->errorSlots.emplace_back(c.done, c.pinned);
+      t_state->errorChecks[i] = std::move(t_state->errorChecks.back());
+      t_state->errorChecks.pop_back();
     } else {
       (void)hipGetLastError();
       i++;
@@ -1275,13 +1298,13 @@ void poll_error_words(int device) {
   if (failed) throw AlgorithmError("ERROR: filter: compaction wait timed out (reported by a deferred compaction)");
 }
 
-// caller holds g_deferMutex and has selected the device: runs the pending compaction of `idx` (if
+// caller holds the device's DeferLock and has selected the device: runs the pending compaction of `idx` (if
 // there is one) on the stream its filter ran on
 void run_compaction(const uint32_t *idx) {
-  auto it = g_compactions.find(idx);
-  if (it == g_compactions.end()) return;
+  auto it = t_state->compactions.find(idx);
+  if (it == t_state->compactions.end()) return;
   const PendingCompact c = it->second;
-  g_compactions.erase(it);
+  t_state->compactions.erase(it);
   CompactWorkspace cw;
   cw.ticket = c.ticket;
   cw.error = c.error;
@@ -1304,7 +1327,7 @@ bool compaction_touches(const PendingCompact &c, const ByteRange &r) {
   return ri.overlaps(r) || rp.overlaps(r);
 }
 
-// caller holds g_deferMutex and has selected the device.  inOrder: the launch is part of the
+// caller holds the device's DeferLock and has selected the device.  inOrder: the launch is part of the
 // stream's own call sequence (a later call on the same stream follows); otherwise a queue the host
 // has already waited for is synchronised after its late launch.
 void launch_queue(hipStream_t stream, PendingQueue &q, bool inOrder = false) {
@@ -1331,11 +1354,11 @@ void launch_queue(hipStream_t stream, PendingQueue &q, bool inOrder = false) {
   if (syncAfter) t_syncAfterUnlock.push_back(stream);  // (DeferLock: after the mutex is released)
 }
 
-// caller holds g_deferMutex.  Launches the skipped transforms of every limbo entry of the device
+// caller holds the device's DeferLock.  Launches the skipped transforms of every limbo entry of the device
 // (all = true) or of those whose outputs overlap `range`, and forgets the entries.
 bool materialize_limbo(int device, const ByteRange *range, ReleaseSet *released) {
   bool any = false;
-  for (auto it = g_limbo.begin(); it != g_limbo.end();) {
+  for (auto it = t_state->limbo.begin(); it != t_state->limbo.end();) {
     bool hit = it->first.first == device;
     if (hit && range) {
       hit = false;
@@ -1345,7 +1368,7 @@ bool materialize_limbo(int device, const ByteRange *range, ReleaseSet *released)
       it->second.overWait = true;  // the host believes this work is long done
       launch_queue(it->first.second, it->second);
       if (released) released->add(it->first.second);
-      it = g_limbo.erase(it);
+      it = t_state->limbo.erase(it);
       any = true;
     } else {
       ++it;
@@ -1355,7 +1378,7 @@ bool materialize_limbo(int device, const ByteRange *range, ReleaseSet *released)
 }
 }  // namespace
 
-// caller holds g_deferMutex and has selected the device
+// caller holds the device's DeferLock and has selected the device
 static void launch_init_index(uint32_t *indexVector, uint32_t start, int n, hipStream_t stream) {
   if (n <= 0) return;
   const int64_t quads = (static_cast<int64_t>(n) + 3) / 4;
@@ -1366,12 +1389,12 @@ static void launch_init_index(uint32_t *indexVector, uint32_t start, int n, hipS
 // limboA/limboB: when given, only the skipped work whose outputs overlap these byte ranges is
 // launched (the caller reads nothing else); otherwise all of it
 static void flush_deferred_impl(int device, const ByteRange *limboA, const ByteRange *limboB) {
-  DeferLock lock;
+  DeferLock lock(device);
   poll_error_words(device);
-  for (auto it = g_iotas.begin(); it != g_iotas.end();) {
+  for (auto it = t_state->iotas.begin(); it != t_state->iotas.end();) {
     if (it->second.device == device) {
       launch_init_index(it->first, it->second.start, it->second.n, it->second.stream);
-      it = g_iotas.erase(it);
+      it = t_state->iotas.erase(it);
     } else {
       ++it;
     }
@@ -1381,18 +1404,18 @@ static void flush_deferred_impl(int device, const ByteRange *limboA, const ByteR
   // dormant with its skipped work and dies with it
   auto dormant = [&](const uint32_t *idx) {
     bool skipped = false, queued = false;
-    for (auto &kv : g_limbo) skipped = skipped || kv.second.idx == idx;
-    for (auto &kv : g_pending) queued = queued || (kv.second.jobs.count && kv.second.idx == idx);
+    for (auto &kv : t_state->limbo) skipped = skipped || kv.second.idx == idx;
+    for (auto &kv : t_state->pending) queued = queued || (kv.second.jobs.count && kv.second.idx == idx);
     return skipped && !queued;
   };
   for (;;) {
-    auto c = g_compactions.begin();
-    while (c != g_compactions.end() && (c->second.device != device || dormant(c->first))) ++c;
-    if (c == g_compactions.end()) break;
+    auto c = t_state->compactions.begin();
+    while (c != t_state->compactions.end() && (c->second.device != device || dormant(c->first))) ++c;
+    if (c == t_state->compactions.end()) break;
     run_compaction(c->first);
   }
   ReleaseSet released;
-  for (auto &kv : g_pending)
+  for (auto &kv : t_state->pending)
     if (kv.first.first == device) {
       if (kv.second.overWait && kv.second.jobs.count) released.add(kv.first.second);
       launch_queue(kv.first.second, kv.second);
@@ -1424,15 +1447,15 @@ void drop_skipped_outputs(int device, const void *a, size_t aBytes, const void *
   const ByteRange rb{static_cast<const uint8_t *>(b), static_cast<const uint8_t *>(b) + (bBytes ? bBytes : 1)};
   ReleaseSet released;
   {
-    DeferLock lock;
-    for (auto it = g_limbo.begin(); it != g_limbo.end();) {
+    DeferLock lock(device);
+    for (auto it = t_state->limbo.begin(); it != t_state->limbo.end();) {
       bool hit = false;
       if (it->first.first == device)
         for (const ByteRange &w : it->second.writes) hit = hit || w.overlaps(ra) || w.overlaps(rb);
       if (hit) {
-        if (it->second.idx) g_compactions.erase(it->second.idx);
+        if (it->second.idx) t_state->compactions.erase(it->second.idx);
         released.add(it->first.second);
-        it = g_limbo.erase(it);
+        it = t_state->limbo.erase(it);
       } else {
         ++it;
       }
@@ -1454,31 +1477,31 @@ static void begin_batch(int device, hipStream_t stream, const uint32_t *indexVec
   if (!fuse_available()) return;
   bool release = false;
   {
-    DeferLock lock;
-    auto lim = g_limbo.find({device, stream});
-    if (lim != g_limbo.end()) {  // the skipped work of the previous batch dies, and with it the compaction it would need
-      if (lim->second.idx) g_compactions.erase(lim->second.idx);
-      g_limbo.erase(lim);
+    DeferLock lock(device);
+    auto lim = t_state->limbo.find({device, stream});
+    if (lim != t_state->limbo.end()) {  // the skipped work of the previous batch dies, and with it the compaction it would need
+      if (lim->second.idx) t_state->compactions.erase(lim->second.idx);
+      t_state->limbo.erase(lim);
       release = true;
     }
-    g_compactions.erase(indexVector);  // the vector is redefined
+    t_state->compactions.erase(indexVector);  // the vector is redefined
     FilterJournal j;
     j.device = device;
     j.stream = stream;
     j.start = start;
     j.n0 = n;
     j.valid = true;
-    g_journals[indexVector] = j;
+    t_state->journals[indexVector] = j;
   }
   if (release) g_releaseHeld(device, hold_tag(stream));
 }
 
 // a fast filter has compacted `indexVector` (f == nullptr: something else has — forget the journal)
-static void journal_filter(const uint32_t *indexVector, const FastOperands *f, uint32_t colRows, int rowsBefore) {
+static void journal_filter(int device, const uint32_t *indexVector, const FastOperands *f, uint32_t colRows, int rowsBefore) {
   if (!fuse_available()) return;
-  DeferLock lock;
-  auto it = g_journals.find(indexVector);
-  if (it == g_journals.end()) return;
+  DeferLock lock(device);
+  auto it = t_state->journals.find(indexVector);
+  if (it == t_state->journals.end()) return;
   FilterJournal &j = it->second;
   if (!f || !j.valid || j.filters.size() >= static_cast<size_t>(kFusedFilters) ||
       (j.filters.empty() && rowsBefore != j.n0)) {
@@ -1492,44 +1515,44 @@ static void journal_filter(const uint32_t *indexVector, const FastOperands *f, u
   j.colRows.push_back(colRows);
 }
 
-void invalidate_filter_journal(const uint32_t *indexVector) { journal_filter(indexVector, nullptr, 0, 0); }
+void invalidate_filter_journal(int device, const uint32_t *indexVector) { journal_filter(device, indexVector, nullptr, 0, 0); }
 
-static bool journal_is_valid(const uint32_t *indexVector) {
+static bool journal_is_valid(int device, const uint32_t *indexVector) {
   if (!fuse_available()) return false;
   static const bool lazy = [] {
     const char *e = getenv("ARES_LAZY_COMPACT");
     return !(e && e[0] == '0');
   }();
   if (!lazy) return false;
-  DeferLock lock;
-  auto it = g_journals.find(indexVector);
-  return it != g_journals.end() && it->second.valid;
+  DeferLock lock(device);
+  auto it = t_state->journals.find(indexVector);
+  return it != t_state->journals.end() && it->second.valid;
 }
 
 // InitIndexVector: remember instead of writing (when the flush hook is in place)
 static bool defer_iota(int device, hipStream_t stream, uint32_t *indexVector, uint32_t start, int n) {
   if (!defer_available() || n <= 0) return false;
-  DeferLock lock;
-  g_iotas[indexVector] = PendingIota{device, stream, start, n};
+  DeferLock lock(device);
+  t_state->iotas[indexVector] = PendingIota{device, stream, start, n};
   return true;
 }
 
 // true when `indexVector` is a virtual iota(0) of exactly n rows on this device; `take` removes it
 // (the caller is about to give the vector real contents)
 static bool virtual_iota(int device, uint32_t *indexVector, int n, bool take) {
-  DeferLock lock;
-  auto it = g_iotas.find(indexVector);
-  if (it == g_iotas.end() || it->second.device != device || it->second.start != 0 || it->second.n != n) return false;
-  if (take) g_iotas.erase(it);
+  DeferLock lock(device);
+  auto it = t_state->iotas.find(indexVector);
+  if (it == t_state->iotas.end() || it->second.device != device || it->second.start != 0 || it->second.n != n) return false;
+  if (take) t_state->iotas.erase(it);
   return true;
 }
 
 // Queues one fast-path transform; returns false when deferral is unavailable (the caller launches it).
 static bool defer_transform(int device, hipStream_t stream, const FastOperands &f, const SinkD &s, int n, uint32_t colRows) {
   if (!defer_available()) return false;
-  DeferLock lock;
+  DeferLock lock(device);
   // everything pending on OTHER streams of the device is unrelated; only this stream's queue matters
-  PendingQueue &q = g_pending[{device, stream}];
+  PendingQueue &q = t_state->pending[{device, stream}];
   ByteRange rv{reinterpret_cast<const uint8_t *>(f.vals), reinterpret_cast<const uint8_t *>(f.vals) + 4ull * colRows};
   ByteRange rn{f.nulls, f.nulls ? f.nulls + (static_cast<uint64_t>(colRows) + f.bitOff + 7) / 8 + 2 : f.nulls};
   ByteRange ri{reinterpret_cast<const uint8_t *>(f.idx), reinterpret_cast<const uint8_t *>(f.idx) + (f.idx ? 4ull * n : 0)};
@@ -1727,9 +1750,9 @@ static int run_filter(const InputVector *ins, int arity, uint32_t *indexVector, 
     return e && strcmp(e, "onepass") == 0;
   }();
   if (fast && !onePass && numForeignTables == 0 && baseCounts == nullptr)
-    journal_filter(indexVector, &f, p.a.length, n);
+    journal_filter(device, indexVector, &f, p.a.length, n);
   else
-    journal_filter(indexVector, nullptr, 0, 0);
+    journal_filter(device, indexVector, nullptr, 0, 0);
   if (fast && !onePass) {
     // two-phase path: predicate + tile counts, scan, chain-free compaction of the index vector and
     // of every RecordID vector
@@ -1751,7 +1774,7 @@ static int run_filter(const InputVector *ins, int arity, uint32_t *indexVector, 
     if (virtualIdx) f.idx = nullptr;  // rows = position
     ARES_LAUNCH("filter_pred_kernel", filter_pred_kernel, capped_grid(tiles, 256 * 16), kBlock, stream, f, pred, tileCounts, n, tiles);
     ARES_LAUNCH("filter_scan_kernel", filter_scan_kernel, 1, 1024, stream, tileCounts, tileOffsets, tiles, total);
-    if (numForeignTables == 0 && journal_is_valid(indexVector)) {
+    if (numForeignTables == 0 && journal_is_valid(device, indexVector)) {
       // The count is known; the compaction waits until somebody needs the compacted vector — a
       // HashReduce that re-derives the survivors from the journal never does.
       uint32_t result[2] = {0, 0};
@@ -1770,8 +1793,8 @@ static int run_filter(const InputVector *ins, int arity, uint32_t *indexVector, 
       c.error = error;
       c.tileOffsets = tileOffsets;
       c.loaded = loaded;
-      DeferLock lock;
-      g_compactions[indexVector] = c;
+      DeferLock lock(device);
+      t_state->compactions[indexVector] = c;
       return static_cast<int>(result[0]);
     }
     const int cgrid = capped_grid((tiles + kTilesPerTicket - 1) / kTilesPerTicket, 256 * 8);
@@ -1798,7 +1821,7 @@ static int run_filter(const InputVector *ins, int arity, uint32_t *indexVector, 
     return static_cast<int>(result[0]);
   }
   if (virtualIdx) {  // the one-pass kernels read the index vector: write it now
-    DeferLock lock;
+    DeferLock lock(device);
     launch_init_index(indexVector, 0, n, stream);
   }
   int numTiles = static_cast<int>((static_cast<int64_t>(n) + kFilterTile - 1) / kFilterTile);
@@ -1886,23 +1909,23 @@ void hook_on_wait(int device, void *streamPtr) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(streamPtr);
   try {
     DeviceGuard guard(device);
-    DeferLock lock;
+    DeferLock lock(device);
     // a wait on one stream says nothing about the others: their pending work is left alone
-    for (auto it = g_iotas.begin(); it != g_iotas.end();) {
+    for (auto it = t_state->iotas.begin(); it != t_state->iotas.end();) {
       if (it->second.device == device && it->second.stream == stream) {
         launch_init_index(it->first, it->second.start, it->second.n, it->second.stream);
-        it = g_iotas.erase(it);
+        it = t_state->iotas.erase(it);
       } else {
         ++it;
       }
     }
-    for (auto &kv : g_pending) {
+    for (auto &kv : t_state->pending) {
       if (kv.first.first != device || kv.first.second != stream || kv.second.jobs.count == 0 || kv.second.overWait) continue;
       PendingQueue &q = kv.second;
       bool keep = true;
       if (q.idx) {  // the survivors must be re-derivable from the filter journal
-        auto j = g_journals.find(q.idx);
-        keep = j != g_journals.end() && j->second.valid && j->second.device == device && j->second.stream == stream &&
+        auto j = t_state->journals.find(q.idx);
+        keep = j != t_state->journals.end() && j->second.valid && j->second.device == device && j->second.stream == stream &&
                j->second.start == 0;
         if (keep)  // the filters' columns are inputs of the pending work from now on
           for (size_t k = 0; k < j->second.filters.size(); k++) {
@@ -1930,21 +1953,21 @@ uintptr_t hook_on_free(int device, void *ptr, size_t bytes) {
   ReleaseSet released;
   try {
     DeviceGuard guard(device);
-    DeferLock lock;
-    for (auto it = g_iotas.begin(); it != g_iotas.end();) {  // an index vector nobody has read yet
+    DeferLock lock(device);
+    for (auto it = t_state->iotas.begin(); it != t_state->iotas.end();) {  // an index vector nobody has read yet
       const ByteRange v = range_of(it->first, 4ull * it->second.n);
-      it = (it->second.device == device && v.overlaps(r)) ? g_iotas.erase(it) : std::next(it);
+      it = (it->second.device == device && v.overlaps(r)) ? t_state->iotas.erase(it) : std::next(it);
     }
-    for (auto it = g_journals.begin(); it != g_journals.end();) {
+    for (auto it = t_state->journals.begin(); it != t_state->journals.end();) {
       // a journal dies with its index vector or with a column its filters read — unless a queue the
       // host has already waited for still refers to it (then the block is held below, contents intact)
       const bool dead = it->second.device == device && journal_touched(it->first, it->second, r, nullptr);
       bool kept = false;
       if (dead)
-        for (auto &kv : g_pending) kept = kept || (kv.second.jobs.count && kv.second.overWait && kv.second.idx == it->first);
-      it = (dead && !kept) ? g_journals.erase(it) : std::next(it);
+        for (auto &kv : t_state->pending) kept = kept || (kv.second.jobs.count && kv.second.overWait && kv.second.idx == it->first);
+      it = (dead && !kept) ? t_state->journals.erase(it) : std::next(it);
     }
-    for (auto &kv : g_pending) {
+    for (auto &kv : t_state->pending) {
       if (kv.first.first != device || kv.second.jobs.count == 0) continue;
       if (touches(kv.second.writes, r)) {
         released.add(kv.first.second);
@@ -1958,7 +1981,7 @@ uintptr_t hook_on_free(int device, void *ptr, size_t bytes) {
         }
       }
     }
-    for (auto it = g_compactions.begin(); it != g_compactions.end();) {
+    for (auto it = t_state->compactions.begin(); it != t_state->compactions.end();) {
       if (it->second.device != device || !compaction_touches(it->second, r)) {
         ++it;
         continue;
@@ -1967,33 +1990,33 @@ uintptr_t hook_on_free(int device, void *ptr, size_t bytes) {
       const uint32_t *key = it->first;
       const hipStream_t owner = it->second.stream;
       bool waited = false, queued = false, skipped = false;
-      for (auto &kv : g_pending)
+      for (auto &kv : t_state->pending)
         if (kv.second.jobs.count && kv.second.idx == key) (kv.second.overWait ? waited : queued) = true;
-      for (auto &kv : g_limbo) skipped = skipped || kv.second.idx == key;
+      for (auto &kv : t_state->limbo) skipped = skipped || kv.second.idx == key;
       if (waited || skipped) {  // still needed if that work is launched after all: keep the block intact
         hold = hold_tag(owner);
         ++it;
       } else if (queued) {  // transforms the host has not even waited for: run everything now
-        for (auto &kv : g_pending)
+        for (auto &kv : t_state->pending)
           if (kv.second.jobs.count && kv.second.idx == key) {
             released.add(kv.first.second);
             launch_queue(kv.first.second, kv.second);
           }
-        it = g_compactions.begin();  // (launch_queue erased the entry)
+        it = t_state->compactions.begin();  // (launch_queue erased the entry)
       } else if (range_of(it->second.idx, 4ull * it->second.n).overlaps(r)) {
-        it = g_compactions.erase(it);  // the index vector itself goes: nobody will read the compacted vector
+        it = t_state->compactions.erase(it);  // the index vector itself goes: nobody will read the compacted vector
       } else {
         // only the predicate vector goes, the index vector stays live (a later transform, filter or
         // copy may read it): compact now — the free is fenced behind the launch
         run_compaction(key);
-        it = g_compactions.begin();
+        it = t_state->compactions.begin();
       }
     }
-    for (auto it = g_limbo.begin(); it != g_limbo.end();) {
+    for (auto it = t_state->limbo.begin(); it != t_state->limbo.end();) {
       if (it->first.first == device && touches(it->second.writes, r)) {  // the skipped outputs die unseen
-        if (it->second.idx) g_compactions.erase(it->second.idx);
+        if (it->second.idx) t_state->compactions.erase(it->second.idx);
         released.add(it->first.second);
-        it = g_limbo.erase(it);
+        it = t_state->limbo.erase(it);
       } else {
         if (it->first.first == device && touches(it->second.reads, r)) hold = hold_tag(it->first.second);
         ++it;
@@ -2012,18 +2035,18 @@ void hook_on_access(int device, const void *ptr, size_t bytes) {
   ReleaseSet released;
   try {
     DeviceGuard guard(device);
-    DeferLock lock;
-    for (auto it = g_iotas.begin(); it != g_iotas.end();) {
+    DeferLock lock(device);
+    for (auto it = t_state->iotas.begin(); it != t_state->iotas.end();) {
       const ByteRange v = range_of(it->first, 4ull * it->second.n);
       if (it->second.device == device && v.overlaps(r)) {
         launch_init_index(it->first, it->second.start, it->second.n, it->second.stream);
         t_syncAfterUnlock.push_back(it->second.stream);
-        it = g_iotas.erase(it);
+        it = t_state->iotas.erase(it);
       } else {
         ++it;
       }
     }
-    for (auto &kv : g_pending) {
+    for (auto &kv : t_state->pending) {
       if (kv.first.first != device || kv.second.jobs.count == 0) continue;
       if (touches(kv.second.writes, r) || touches(kv.second.reads, r)) {
         released.add(kv.first.second);
@@ -2031,20 +2054,20 @@ void hook_on_access(int device, const void *ptr, size_t bytes) {
       }
     }
     materialize_limbo(device, &r, &released);
-    for (auto it = g_compactions.begin(); it != g_compactions.end();) {
+    for (auto it = t_state->compactions.begin(); it != t_state->compactions.end();) {
       if (it->second.device == device && compaction_touches(it->second, r)) {
         const hipStream_t cs = it->second.stream;
         run_compaction(it->first);
         t_syncAfterUnlock.push_back(cs);
-        it = g_compactions.begin();
+        it = t_state->compactions.begin();
       } else {
         ++it;
       }
     }
     // a copy into an index vector or into a column a journalled filter has read: the survivors can
     // no longer be re-derived (queues that depended on the journal were launched above)
-    for (auto it = g_journals.begin(); it != g_journals.end();)
-      it = (it->second.device == device && journal_touched(it->first, it->second, r, nullptr)) ? g_journals.erase(it) : std::next(it);
+    for (auto it = t_state->journals.begin(); it != t_state->journals.end();)
+      it = (it->second.device == device && journal_touched(it->first, it->second, r, nullptr)) ? t_state->journals.erase(it) : std::next(it);
   } catch (std::exception &e) {
     fprintf(stderr, "Exception happened when handling a device copy: %s\n", e.what());
   }
@@ -2070,19 +2093,19 @@ void hook_on_stream_destroy(int device, void *streamPtr) {
   try {
     DeviceGuard guard(device);
     {
-      DeferLock lock;
-      g_pending.erase({device, stream});
-      auto lim = g_limbo.find({device, stream});
-      if (lim != g_limbo.end()) {
-        if (lim->second.idx) g_compactions.erase(lim->second.idx);
-        g_limbo.erase(lim);
+      DeferLock lock(device);
+      t_state->pending.erase({device, stream});
+      auto lim = t_state->limbo.find({device, stream});
+      if (lim != t_state->limbo.end()) {
+        if (lim->second.idx) t_state->compactions.erase(lim->second.idx);
+        t_state->limbo.erase(lim);
       }
-      for (auto it = g_journals.begin(); it != g_journals.end();)
-        it = (it->second.device == device && it->second.stream == stream) ? g_journals.erase(it) : std::next(it);
-      for (auto it = g_compactions.begin(); it != g_compactions.end();)
-        it = (it->second.device == device && it->second.stream == stream) ? g_compactions.erase(it) : std::next(it);
-      for (auto it = g_iotas.begin(); it != g_iotas.end();)
-        it = (it->second.device == device && it->second.stream == stream) ? g_iotas.erase(it) : std::next(it);
+      for (auto it = t_state->journals.begin(); it != t_state->journals.end();)
+        it = (it->second.device == device && it->second.stream == stream) ? t_state->journals.erase(it) : std::next(it);
+      for (auto it = t_state->compactions.begin(); it != t_state->compactions.end();)
+        it = (it->second.device == device && it->second.stream == stream) ? t_state->compactions.erase(it) : std::next(it);
+      for (auto it = t_state->iotas.begin(); it != t_state->iotas.end();)
+        it = (it->second.device == device && it->second.stream == stream) ? t_state->iotas.erase(it) : std::next(it);
     }
     if (g_releaseHeld) g_releaseHeld(device, hold_tag(stream));
     stream_cache_purge(device, stream);
@@ -2107,9 +2130,9 @@ bool fuse_pending_into_hash_reduce(int device, hipStream_t stream, const Dimensi
   int nd = 0, prev = 0, n0 = 0;
   AggSpec a;
   {
-    DeferLock lock;
-    auto it = g_pending.find({device, stream});
-    if (it == g_pending.end() || it->second.jobs.count == 0) return false;
+    DeferLock lock(device);
+    auto it = t_state->pending.find({device, stream});
+    if (it == t_state->pending.end() || it->second.jobs.count == 0) return false;
     PendingQueue &pq = it->second;
     bool ok = !(forced && strcmp(forced, "global") == 0);
     nd = in.NumDimsPerDimWidth[2];
@@ -2130,8 +2153,8 @@ bool fuse_pending_into_hash_reduce(int device, hipStream_t stream, const Dimensi
     const FilterJournal *journal = nullptr;
     n0 = pq.n;
     if (ok && pq.idx) {
-      auto j = g_journals.find(pq.idx);
-      ok = j != g_journals.end() && j->second.valid && j->second.start == 0 && j->second.device == device;
+      auto j = t_state->journals.find(pq.idx);
+      ok = j != t_state->journals.end() && j->second.valid && j->second.start == 0 && j->second.device == device;
       if (ok) {
         journal = &j->second;
         n0 = journal->n0;
@@ -2213,18 +2236,18 @@ bool fuse_pending_into_hash_reduce(int device, hipStream_t stream, const Dimensi
     pq.reads.clear();
     pq.writes.clear();
     pq.overWait = false;
-    if (q.idx) g_journals.erase(q.idx);
+    if (q.idx) t_state->journals.erase(q.idx);
   }
   DimensionVector prevKeys = in;
   const int result = fused_hash_reduce_run(device, plan, n0, prevKeys, inValues, prev, out, outValues, a, stream);
-  DeferLock lock;
+  DeferLock lock(device);
   if (result < 0) {  // a partition region overflowed: materialise the inputs after all
     launch_queue(stream, q, /*inOrder=*/true);
     lock.unlock();
     g_releaseHeld(device, hold_tag(stream));
     return false;
   }
-  g_limbo[{device, stream}] = q;  // launchable until the next batch begins (begin_batch)
+  t_state->limbo[{device, stream}] = q;  // launchable until the next batch begins (begin_batch)
   *groups = result;
   return true;
 }
@@ -2323,7 +2346,7 @@ CGoCallResHandle InitIndexVector(uint32_t *indexVector, uint32_t start, int inde
   begin_batch(device, stream, indexVector, start, indexVectorLength);
   if (!defer_iota(device, stream, indexVector, start, indexVectorLength)) {
     flush_deferred(device);
-    DeferLock lock;
+    DeferLock lock(device);
     launch_init_index(indexVector, start, indexVectorLength, stream);
   }
   ARES_ABI_END("InitIndexVector")

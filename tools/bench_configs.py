@@ -82,6 +82,81 @@ def c4(be, dev, rows, nkeys):
              "ms": dt * 1e3, "rows_per_s": rows / dt, "kernels": {n: round(ms / c, 4) for n, (c, ms) in k.items()}}]
 
 
+def c4_spec(be, dev, rows, nkeys, batch_rows=1 << 26):
+    """C4 at BASELINE's stated size: `rows` fact rows in batches of `batch_rows`, an `nkeys`-key cuckoo index
+    (every probe an HBM access), one group per key, Sort + Reduce with the previous result merged per batch.
+    Every (fk, attr) -> sum is checked against a torch bincount of the same rows."""
+    import harness as H
+    from test_scale_parity import build_cuckoo_u32
+    rng = np.random.default_rng(6)
+    per_batch = 1 << 20
+    t0 = time.perf_counter()
+    keys = rng.permutation(np.arange(1, 4 * nkeys + 1, 4, dtype=np.uint32))[:nkeys]
+    attr = (keys * np.uint32(2654435761) >> np.uint32(20)).astype(np.uint32)
+    seeds = [int(x) for x in rng.integers(0, 1 << 32, 4)]
+    num_buckets = nkeys // 5
+    table, placed = build_cuckoo_u32(keys, num_buckets, seeds, per_batch)
+    usable = np.nonzero(placed)[0]
+    build_s = time.perf_counter() - t0
+    nb = (nkeys + per_batch - 1) // per_batch
+    tb = H.Buf(be, table)
+    idx = abi.CuckooHashIndex(); idx.buckets = tb.ptr
+    for i, s in enumerate(seeds): idx.seeds[i] = s
+    idx.keyBytes, idx.numHashes, idx.numBuckets = 4, 4, num_buckets
+    dcols = [H.Column(be, abi.Uint32, attr[b * per_batch:(b + 1) * per_batch]) for b in range(nb)]
+    ft = ForeignTable(join_column="fk", index=idx, batches={"attr": [c.vp for c in dcols]}, data_types={"attr": abi.Uint32},
+                      base_batch_id=1, num_records_in_last_batch=nkeys - (nb - 1) * per_batch)
+    plan = QueryPlan(filters=[], foreign_tables=[ft], foreign_filters=[],
+                     dimensions=[DimensionSpec(Col("fk"), abi.Uint32), DimensionSpec(Col("attr", table=1), abi.Uint32)],
+                     measure=Col("amount"), agg=abi.AGGR_SUM_UNSIGNED, measure_type=abi.Uint32, use_hash_reduction=False)
+    g = torch.Generator(device=dev); g.manual_seed(2)
+    keys_d = torch.from_numpy(keys[usable].astype(np.int64)).to(dev)
+    sums = torch.zeros(len(usable), dtype=torch.float64, device=dev)
+    nbatches = (rows + batch_rows - 1) // batch_rows
+    q = NativeQuery(be, plan, ["fk", "amount"])
+    kernels, busy = {}, 0.0
+    for b in range(nbatches):
+        n = min(batch_rows, rows - b * batch_rows)
+        # the first batches walk the keys in order so that every key occurs; the rest draw at random
+        pick = (torch.arange(b * batch_rows, b * batch_rows + n, device=dev) % len(usable)) if (b + 1) * batch_rows <= len(usable) + batch_rows \
+            else torch.randint(0, len(usable), (n,), device=dev, generator=g)
+        amount = torch.randint(0, 100, (n,), dtype=torch.int32, device=dev, generator=g)
+        sums += torch.bincount(pick, weights=amount.to(torch.float64), minlength=len(usable))
+        cf, ca = workload._pack_column(keys_d[pick].to(torch.int32), None, abi.Uint32), workload._pack_column(amount, None, abi.Uint32)
+        del pick, amount
+        be.profiler_enable(True); torch.cuda.synchronize(); t0 = time.perf_counter()
+        q.run({"fk": cf.vp, "amount": ca.vp}, n)
+        torch.cuda.synchronize(); busy += time.perf_counter() - t0
+        for name, (c, ms) in be.profiler_report().items():
+            c0, m0 = kernels.get(name, (0, 0.0)); kernels[name] = (c0 + c, m0 + ms)
+        be.profiler_enable(False)
+        del cf, ca
+    groups = q.result_size
+    dims, valids, meas = q.fetch()
+    got_fk, got_attr, got_sum = dims[0].view(np.uint32), dims[1].view(np.uint32), meas.view(np.uint32)
+    order = np.argsort(got_fk)
+    korder = usable[np.argsort(keys[usable])]
+    present = (sums > 0).cpu().numpy()[np.argsort(keys[usable])]
+    want_sum = sums.cpu().numpy()[np.argsort(keys[usable])]
+    ok = (groups == int(present.sum()) and np.array_equal(got_fk[order], keys[korder][present])
+          and np.array_equal(got_attr[order], attr[korder][present])
+          and np.array_equal(got_sum[order].astype(np.int64), want_sum[present].astype(np.int64)))
+    q.release()
+    for x in [tb] + dcols: x.free()
+    # HashLookup: one 104-byte bucket probe per row and hash function tried, sector-granular: >= 128 B / row
+    look = kernels.get("hash_lookup_kernel")
+    out = {"config": "C4-spec", "rows": rows, "batches": nbatches, "batch_rows": batch_rows, "keys": int(len(usable)),
+           "cuckoo_table_MB": len(table) / 1e6, "cuckoo_build_s": build_s, "groups": groups, "key_level_check": "ok" if ok else "MISMATCH",
+           "ms": busy * 1e3, "rows_per_s": rows / busy,
+           "kernels": {n: {"launches": c, "avg_ms": ms / c, "total_ms": ms} for n, (c, ms) in sorted(kernels.items(), key=lambda kv: -kv[1][1])}}
+    if look:
+        per_launch_rows = rows / look[0]
+        out["hash_lookup_roofline"] = {"bound": "hbm", "unit": "GB/s", "peak": 8000.0, "bytes_per_row": 128 + 4 + 8,
+                                       "achieved": per_launch_rows * 140 / (look[1] / look[0] * 1e-3) / 1e9}
+        out["hash_lookup_roofline"]["frac"] = out["hash_lookup_roofline"]["achieved"] / 8000.0
+    return [out]
+
+
 def hll(be, dev, rows, groups, users, batches=2):
     """countdistincthll(user) group by g: `batches` batches of `rows` rows through the C++ driver."""
     from aresdb_amd.executor import Unary
@@ -144,10 +219,11 @@ def main():
     res = []
     if "c2" in which: res += c2(be, dev, 100_000_000)
     if "c4" in which: res += c4(be, dev, 1 << 26, 200_000)
+    if "c4spec" in which: res += c4_spec(be, dev, int(float(os.environ.get("C4_ROWS", "1e9"))), int(float(os.environ.get("C4_KEYS", "5e7"))))
     if "hll" in which:
         res += hll(be, dev, 1 << 25, 1000, 5_000_000) + hll(be, dev, 1 << 25, 4, 50_000_000)
     if "geo" in which: res += geo(be, dev, 1 << 24, 100, 20) + geo(be, dev, 1 << 22, 250, 400)
     for r in res: print(json.dumps(r), flush=True)
     os.makedirs("gpurun_out", exist_ok=True)
-    json.dump(res, open("gpurun_out/bench_configs.json", "w"), indent=1)
+    json.dump(res, open("gpurun_out/bench_configs_%s.json" % "_".join(which), "w"), indent=1)
 main()

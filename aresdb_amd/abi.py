@@ -287,5 +287,8 @@ def hip_library_paths():
 
 def load_hip_backend():
     """The product: hand-written HIP libalgorithm.so + libmem.so.  No fallback of any kind."""
+    # One HIP runtime per process: torch bundles its own libamdhip64 and must be the first to load it —
+    # loaded after ours (which resolves to /opt/rocm), torch finds "no ROCm-capable device".
+    import torch  # noqa: F401
     algo, mem = hip_library_paths()
     return Backend("hip", algo, mem, device_memory=True)

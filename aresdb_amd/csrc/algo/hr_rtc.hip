@@ -393,7 +393,16 @@ struct RtcMergeArgs {  // mirrors `struct MArgs` of the generated source
   uint64_t prevCapacity, outCapacity;
   uint32_t bitOff[kFusedCols];
   uint32_t capB, streams, prevSize, pad;
+  uint64_t *phases;  // ARES_HR_PHASES=1: per-partition time stamps (diagnostics)
 };
+
+static bool merge_phases_enabled() {
+  static const bool on = [] {
+    const char *e = getenv("ARES_HR_PHASES");
+    return e && e[0] == '1';
+  }();
+  return on;
+}
 
 std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w) {
   if (nd < 1 || nd > kFusedDims) return "";
@@ -401,7 +410,7 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
   o << "typedef unsigned int u32; typedef unsigned long long u64; typedef unsigned char u8; typedef int i32; typedef long long i64;\n"
        "struct MArgs { const u32 *vals[" << kFusedCols << "]; const u8 *nulls[" << kFusedCols << "]; const u32 *recB; const u32 *countsB;\n"
        "  const u32 *prevRanges; const u8 *prevDims; const u8 *prevValues; u8 *dimOut; u8 *outValues; u32 *outCount; u32 *outRanges;\n"
-       "  u64 prevCapacity, outCapacity; u32 bitOff[" << kFusedCols << "]; u32 capB, streams, prevSize, pad; };\n"
+       "  u64 prevCapacity, outCapacity; u32 bitOff[" << kFusedCols << "]; u32 capB, streams, prevSize, pad; u64 *phases; };\n"
        "#define ND " << nd << "\n#define PB " << partBits << "\n#define NP " << (1 << partBits) << "\n"
        "#define SLOTS " << hr::kSlots << "\n#define LIMIT " << hr::kMergeLimit << "u\n#define RANGEWORDS " << hr::kRangeWords
     << "\n#define MAXRANGES " << hr::kMaxRanges << "u\n#define EMPTY 0xFFFFFFFFFFFFFFFFull\n"
@@ -437,6 +446,10 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
   char ident[32];
   snprintf(ident, sizeof(ident), "0x%016llxull", static_cast<unsigned long long>(a.identity));
   o << "#define IDENT " << ident << "\n";
+  if (merge_phases_enabled())
+    o << "#define STAMP(k) if (threadIdx.x == 0u) a.phases[(u64)blockIdx.x * 8u + (k)] = __builtin_amdgcn_s_memrealtime();\n";
+  else
+    o << "#define STAMP(k)\n";
   // The table is probed by buckets of four keys (32 bytes, two LDS reads): a record meets its group in
   // its home bucket ~93 % of the time at this load, so a wavefront rarely takes more than two or three
   // rounds — with one key per probe the longest probe sequence among 64 lanes paced every wave.  A
@@ -482,27 +495,29 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
        "  if (q.done) finish(sKeys, sVals, q, mine, value);\n"
        "  else __hip_atomic_store(sOverflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"  // table full: the round is void anyway
        "}\n";
-  o << "struct Chunk { const uint4 *ptr; u32 rem; };\n"
-       "struct Stage { uint4 r[4]; };\n"
-       "__device__ __forceinline__ void load_chunk(Stage &s, const Chunk &c, u32 lane) {\n"
-       "  const u32 last = c.rem ? c.rem - 1u : 0u;\n"
-       "#pragma unroll\n"
-       "  for (int k = 0; k < 4; k++) { const u32 i = (u32)k * 64u + lane; s.r[k] = c.ptr[i < last ? i : last]; }\n"
+  // Records arrive in segments of up to 64 (one per lane), four segments per register stage — of one long
+  // run or of four short ones (small batches leave ~16 records per run: a stage per run would make the
+  // merge a chain of dependent loads).  Round one looks at every record's home bucket with straight-line
+  // code (no claim, no advance): a record whose group sits there — ~93 % once the groups exist — costs one
+  // LDS atomic more.  The rest (the group lives further on, or is new) is queued per wavefront in LDS and
+  // taken through the general probe loop 64 at a time, every lane busy: run per record where it occurs,
+  // that loop would execute for a handful of lanes after nearly every segment.
+  o << "#define QCAP 128u\n"
+       "struct Seg { const uint4 *ptr; u32 n; };\n"
+       "struct Stage { uint4 r[4]; u32 n[4]; };\n"
+       "__device__ __forceinline__ void drain(u32 *queue, u32 first, u32 count, u32 lane, u64 *sKeys, u64 *sVals, u32 *sClaimed, u32 *sOverflow) {\n"
+       "  asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");\n"
+       "  if (lane < count) {\n"
+       "    const u32 e = 3u * (first + lane);\n"
+       "    const u32 row = queue[e], h = queue[e + 1u], z = queue[e + 2u];\n"
+       "    insert(sKeys, sVals, sClaimed, sOverflow, row, h, widen(z));\n"
+       "  }\n"
+       "  asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");\n"
        "}\n"
-       // A stage = four records per lane.  Round one looks at every record's home bucket with straight-line
-       // code (no claim, no advance): a record whose group sits there — ~93 % once the groups exist — costs
-       // one LDS atomic more.  What is left (the group lives further on, or is new) goes through the general
-       // probe loop one record per lane at a time: lanes with nothing pending drop out at once.
-       // A stage = four records per lane.  Round one looks at every record's home bucket with straight-line
-       // code (no claim, no advance): a record whose group sits there — ~93 % once the groups exist — costs
-       // one LDS atomic more.  The rest (the group lives further on, or is new) takes the general probe loop.
-       "__device__ __forceinline__ void consume(const Stage &s, const Chunk &c, u32 lane, u64 *sKeys, u64 *sVals, u32 *sClaimed, u32 *sOverflow) {\n"
-       "  const u32 take = c.rem < 256u ? c.rem : 256u;\n"
-       "  bool pend[4];\n"
+       "__device__ __forceinline__ void consume(const Stage &s, u32 lane, u64 *sKeys, u64 *sVals, u32 *sClaimed, u32 *sOverflow, u32 *queue, u32 &qn) {\n"
        "#pragma unroll\n"
        "  for (int k = 0; k < 4; k++) {\n"
-       "    const u32 i = (u32)k * 64u + lane;\n"
-       "    const bool valid = i < take && s.r[k].x != 0xFFFFFFFFu;\n"  // not past the run / padding of its last line
+       "    const bool valid = lane < s.n[k] && s.r[k].x != 0xFFFFFFFFu;\n"  // not past the segment / padding of the run's last line
        "    const u32 h = s.r[k].y, b = h & (BUCKETS - 1u);\n"
        "    const U64x2 lo = *reinterpret_cast<const U64x2 *>(sKeys + 4u * b), hi = *reinterpret_cast<const U64x2 *>(sKeys + 4u * b + 2u);\n"
        "    const bool m0 = (u32)(lo.x >> 32) == h && lo.x != EMPTY, m1 = (u32)(lo.y >> 32) == h && lo.y != EMPTY;\n"
@@ -514,11 +529,17 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
        "      if (s.r[k].x < seenRow) __hip_atomic_fetch_min(sKeys + 4u * b + mi, ((u64)h << 32) | s.r[k].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
        "      agg(sVals + 4u * b + mi, widen(s.r[k].z));\n"
        "    }\n"
-       "    pend[k] = valid && !hit;\n"
+       "    const bool pend = valid && !hit;\n"
+       "    const u64 m = __ballot(pend);\n"
+       "    if (m) {\n"
+       "      if (pend) {\n"
+       "        const u32 e = 3u * (qn + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)));\n"
+       "        queue[e] = s.r[k].x; queue[e + 1u] = s.r[k].y; queue[e + 2u] = s.r[k].z;\n"
+       "      }\n"
+       "      qn += (u32)__popcll(m);\n"
+       "      if (qn >= 64u) { qn -= 64u; drain(queue, qn, 64u, lane, sKeys, sVals, sClaimed, sOverflow); }\n"
+       "    }\n"
        "  }\n"
-       "#pragma unroll\n"
-       "  for (int k = 0; k < 4; k++)\n"
-       "    if (pend[k]) insert(sKeys, sVals, sClaimed, sOverflow, s.r[k].x, s.r[k].y, widen(s.r[k].z));\n"
        "}\n";
   // dimensions of a source row (hr::fused_eval_row), for groups that are new in this batch
   o << "__device__ __forceinline__ void eval_row(const MArgs &a, u32 row, u32 (&bits)[ND], u32 (&ok)[ND]) {\n";
@@ -539,8 +560,10 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
        "  __shared__ u64 sKeys[SLOTS];\n"
        "  __shared__ u64 sVals[SLOTS];\n"
        "  __shared__ u32 sRunCount[256];\n"
+       "  __shared__ u32 sQueue[16u * QCAP * 3u];\n"
        "  __shared__ u32 sClaimed, sOverflow, sCount, sBase, sEmit;\n"
        "  const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, p = blockIdx.x;\n"
+       "  STAMP(0)\n"
        "  for (u32 s = tid; s < SLOTS; s += 1024u) { sKeys[s] = EMPTY; sVals[s] = IDENT; }\n"
        "  if (tid == 0u) { sClaimed = 0u; sOverflow = 0u; sCount = 0u; sEmit = 0u; }\n"
        "  const u32 G = a.streams;\n"
@@ -549,62 +572,87 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
        "  u32 nRanges = ranges ? ranges[0] : 0u;\n"
        "  if (nRanges > MAXRANGES) { if (tid == 0u) a.outCount[2] = 1u; nRanges = 0u; }\n"
        "  __syncthreads();\n"
+       "  STAMP(1)\n"
        // previous groups of this partition (always the lowest row indices: they stay the representatives)
        "  {\n"
        "    const u8 *nullsIn = a.prevDims + (u64)(4 * ND) * a.prevCapacity;\n"
        "    for (u32 r = 0u; r < nRanges; r++) {\n"
        "      const u32 start = ranges[1u + 2u * r], cnt = ranges[2u + 2u * r];\n"
-       "      for (u32 i = tid; i < cnt; i += 1024u) {\n"
-       "        const u32 row = start + i;\n"
-       "        u32 h = 0u, okbytes = 0u;\n"
+       "      for (u32 i0 = 0u; i0 < cnt; i0 += 4096u) {\n"  // four groups per lane: their loads are in flight together
+       "        u32 hh[4], rr[4]; u64 vv[4]; bool okk[4];\n"
        "#pragma unroll\n"
-       "        for (int d = 0; d < ND; d++) {\n"
-       "          h = mix(h, *reinterpret_cast<const u32 *>(a.prevDims + (u64)(4 * d) * a.prevCapacity + 4ull * row));\n"
-       "          okbytes |= (u32)nullsIn[(u64)d * a.prevCapacity + row] << (8 * d);\n"
-       "        }\n";
-  if (nd == 4) o << "        h = mix(h, okbytes);\n";
-  else o << "        { u32 k = okbytes * 0xcc9e2d51u; k = rotl(k, 15) * 0x1b873593u; h ^= k; }\n";
-  o << "        h ^= " << 5 * nd << "u; h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;\n"
-       "        if (row >= a.prevSize || (PB && (h >> (32 - (PB ? PB : 1))) != p)) { a.outCount[2] = 1u; continue; }\n"
-    << (wide ? "        const u64 val = reinterpret_cast<const u64 *>(a.prevValues)[row];\n"
-             : "        const u64 val = reinterpret_cast<const u32 *>(a.prevValues)[row];\n")
-    << "        insert(sKeys, sVals, &sClaimed, &sOverflow, row, h, val);\n"
+       "        for (int k = 0; k < 4; k++) {\n"
+       "          const u32 i = i0 + (u32)k * 1024u + tid;\n"
+       "          okk[k] = i < cnt;\n"
+       "          const u32 row = start + (okk[k] ? i : 0u);\n"
+       "          rr[k] = row;\n"
+       "          okk[k] = okk[k] && row < a.prevSize;\n"
+       "          const u32 safe = row < a.prevSize ? row : 0u;\n"
+       "          u32 h = 0u, okbytes = 0u;\n"
+       "#pragma unroll\n"
+       "          for (int d = 0; d < ND; d++) {\n"
+       "            h = mix(h, *reinterpret_cast<const u32 *>(a.prevDims + (u64)(4 * d) * a.prevCapacity + 4ull * safe));\n"
+       "            okbytes |= (u32)nullsIn[(u64)d * a.prevCapacity + safe] << (8 * d);\n"
+       "          }\n";
+  if (nd == 4) o << "          h = mix(h, okbytes);\n";
+  else o << "          { u32 kk = okbytes * 0xcc9e2d51u; kk = rotl(kk, 15) * 0x1b873593u; h ^= kk; }\n";
+  o << "          h ^= " << 5 * nd << "u; h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;\n"
+       "          hh[k] = h;\n"
+    << (wide ? "          vv[k] = reinterpret_cast<const u64 *>(a.prevValues)[safe];\n"
+             : "          vv[k] = reinterpret_cast<const u32 *>(a.prevValues)[safe];\n")
+    << "        }\n"
+       "#pragma unroll\n"
+       "        for (int k = 0; k < 4; k++) {\n"
+       "          const u32 i = i0 + (u32)k * 1024u + tid;\n"
+       "          if (i >= cnt) continue;\n"
+       "          if (!okk[k] || (PB && (hh[k] >> (32 - (PB ? PB : 1))) != p)) { a.outCount[2] = 1u; continue; }\n"
+       "          insert(sKeys, sVals, &sClaimed, &sOverflow, rr[k], hh[k], vv[k]);\n"
+       "        }\n"
        "      }\n"
        "    }\n"
        "  }\n"
        "  __syncthreads();\n"
+       "  STAMP(2)\n"
        // the partition's runs: every wavefront streams whole runs, two register stages
        "  if (G > 0u) {\n"
        "    const uint4 *dummy = reinterpret_cast<const uint4 *>(a.recB);\n"
-       "    u32 g = wave, off = 0u;\n"
-       "    auto next = [&]() -> Chunk {\n"
-       "      Chunk c{dummy, 0u};\n"
+       "    u32 g = wave, off = 0u, qn = 0u;\n"
+       "    u32 *queue = sQueue + wave * (QCAP * 3u);\n"
+       "    auto next = [&]() -> Seg {\n"
+       "      Seg c{dummy, 0u};\n"
        "      while (g < G) {\n"
        "        const u32 cnt = (u32)__builtin_amdgcn_readfirstlane((int)sRunCount[g]);\n"
        "        if (off < cnt) {\n"
        "          c.ptr = reinterpret_cast<const uint4 *>(a.recB) + ((u64)g * NP + p) * a.capB + off;\n"
-       "          c.rem = cnt - off;\n"
-       "          off += 256u;\n"
+       "          c.n = cnt - off < 64u ? cnt - off : 64u;\n"
+       "          off += 64u;\n"
        "          break;\n"
        "        }\n"
        "        g += 16u; off = 0u;\n"
        "      }\n"
        "      return c;\n"
        "    };\n"
+       "    auto load = [&](Stage &s) {\n"
+       "#pragma unroll\n"
+       "      for (int k = 0; k < 4; k++) {\n"
+       "        const Seg c = next();\n"
+       "        s.n[k] = c.n;\n"
+       "        s.r[k] = c.ptr[lane < c.n ? lane : (c.n ? c.n - 1u : 0u)];\n"
+       "      }\n"
+       "    };\n"
        "    Stage sa, sb;\n"
-       "    Chunk ca = next();\n"
-       "    load_chunk(sa, ca, lane);\n"
-       "    while (ca.rem) {\n"
-       "      Chunk cb = next();\n"
-       "      load_chunk(sb, cb, lane);\n"
-       "      consume(sa, ca, lane, sKeys, sVals, &sClaimed, &sOverflow);\n"
-       "      if (!cb.rem) break;\n"
-       "      ca = next();\n"
-       "      load_chunk(sa, ca, lane);\n"
-       "      consume(sb, cb, lane, sKeys, sVals, &sClaimed, &sOverflow);\n"
+       "    load(sa);\n"
+       "    while (sa.n[0]) {\n"
+       "      load(sb);\n"
+       "      consume(sa, lane, sKeys, sVals, &sClaimed, &sOverflow, queue, qn);\n"
+       "      if (!sb.n[0]) break;\n"
+       "      load(sa);\n"
+       "      consume(sb, lane, sKeys, sVals, &sClaimed, &sOverflow, queue, qn);\n"
        "    }\n"
+       "    if (qn) drain(queue, 0u, qn, lane, sKeys, sVals, &sClaimed, &sOverflow);\n"
        "  }\n"
        "  __syncthreads();\n"
+       "  STAMP(3)\n"
        "  if (sOverflow) { if (tid == 0u) a.outCount[3] = 1u; return; }\n"  // more groups than one table: the generic merge takes over
        // emit: count occupied slots, reserve output rows once, then copy (as hr::merge_body)
        "  u32 mineCount = 0u;\n"
@@ -620,6 +668,7 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
        "    if (a.outRanges) { u32 *o = a.outRanges + (u64)p * RANGEWORDS; o[0] = total ? 1u : 0u; o[1] = base; o[2] = total; }\n"
        "  }\n"
        "  __syncthreads();\n"
+       "  STAMP(4)\n"
        "  if (!total) return;\n"
        "  const u8 *nullsIn = a.prevDims + (u64)(4 * ND) * a.prevCapacity;\n"
        "  u8 *nullsOut = a.dimOut + (u64)(4 * ND) * a.outCapacity;\n"
@@ -658,6 +707,7 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
              : "      reinterpret_cast<u32 *>(a.outValues)[at[kk]] = (u32)sVals[s];\n")
     << "    }\n"
        "  }\n"
+       "  STAMP(5)\n"
        "}\n";
   return o.str();
 }
@@ -776,9 +826,37 @@ void rtc_merge_launch(void *kernel, const FusedPlanD &plan, const uint8_t *prevD
   args.prevSize = prevSize;
   size_t size = sizeof(args);
   void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-  KernelTimer timer("hr_merge_rtc", stream);
-  hip_check(hipModuleLaunchKernel(fn, 1u << ws.partBits, 1, 1, hr::kThreads, 1, 1, 0, stream, nullptr, config),
-            "hipModuleLaunchKernel");
+  static uint64_t *phases = nullptr;
+  if (merge_phases_enabled()) {
+    if (!phases) hip_check(hipMalloc(reinterpret_cast<void **>(&phases), sizeof(uint64_t) * 8 * hr::kMaxPartitions), "hipMalloc");
+    hip_check(hipMemsetAsync(phases, 0, sizeof(uint64_t) * 8 * hr::kMaxPartitions, stream), "hipMemsetAsync");
+    args.phases = phases;
+  }
+  {
+    KernelTimer timer("hr_merge_rtc", stream);
+    hip_check(hipModuleLaunchKernel(fn, 1u << ws.partBits, 1, 1, hr::kThreads, 1, 1, 0, stream, nullptr, config),
+              "hipModuleLaunchKernel");
+  }
+  if (merge_phases_enabled()) {  // diagnostics: where a partition's time goes (100 MHz constant clock)
+    static int launches = 0;
+    const int np = 1 << ws.partBits;
+    std::vector<uint64_t> h(static_cast<size_t>(8) * np);
+    hip_check(hipMemcpyAsync(h.data(), phases, sizeof(uint64_t) * h.size(), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync");
+    hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    if (++launches <= 3 || launches % 64 == 0) {
+      uint64_t first = ~0ull, last = 0;
+      double sum[5] = {0, 0, 0, 0, 0}, whole = 0;
+      for (int p = 0; p < np; p++) {
+        const uint64_t *t = &h[static_cast<size_t>(8) * p];
+        if (t[0] < first) first = t[0];
+        if (t[5] > last) last = t[5];
+        for (int k = 0; k < 5; k++) sum[k] += static_cast<double>(t[k + 1] - t[k]) * 0.01;
+        whole += static_cast<double>(t[5] - t[0]) * 0.01;
+      }
+      fprintf(stderr, "hr_merge_rtc phases (launch %d, %d partitions, prev %u): span %.1f us; per partition avg %.1f us = init %.1f + prev %.1f + records %.1f + count %.1f + emit %.1f\n",
+              launches, np, prevSize, static_cast<double>(last - first) * 0.01, whole / np, sum[0] / np, sum[1] / np, sum[2] / np, sum[3] / np, sum[4] / np);
+    }
+  }
 }
 
 std::string rtc_merge_source(const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w) {

@@ -135,13 +135,17 @@ bool use_pool() {
 // Design: blocks come from hipMalloc and are cached per device in size bins (1/8-octave steps).
 // DeviceFree records one event on every stream the host uses on that device (the streams made by
 // CreateCudaStream plus the null stream) and parks the block with that fence; DeviceAllocate reuses
-// a parked block of the bin only once its whole fence has completed, zero-fills it on a private
-// stream and waits for the fill.  No driver allocation after warm-up, no device-wide
+// a parked block of the bin only once its whole fence has completed.  The zero fill DeviceAllocate
+// promises happens when the block is PARKED: the private stream waits for the fence, clears the block
+// and records one more event that joins the fence — so an allocation from the cache costs no fill, no
+// launch and no host wait (only a block that comes fresh from hipMalloc is cleared synchronously).
+// No driver allocation after warm-up, no device-wide
 // synchronisation ever, and no reliance on cross-stream reuse inside HIP's own stream-ordered pool
 // (which libalgorithm.so uses for its stream-local temporaries only).
 struct ParkedBlock {
   void *ptr;
   std::vector<hipEvent_t> fence;
+  bool zeroed = false;  // the block was cleared behind its fence (the last event of the fence covers the fill)
 };
 
 struct DeviceState {
@@ -222,6 +226,7 @@ hipError_t pool_alloc(DeviceState *st, void **p, size_t bytes, bool zero) {
   }
   const size_t rounded = bin_size(bytes);
   void *ptr = nullptr;
+  bool cleared = false;
   {
     std::lock_guard<std::mutex> lock(st->mu);
     auto it = st->bins.find(rounded);
@@ -230,6 +235,7 @@ hipError_t pool_alloc(DeviceState *st, void **p, size_t bytes, bool zero) {
       for (size_t i = 0; i < vec.size(); i++) {
         if (fence_done(vec[i])) {
           ptr = vec[i].ptr;
+          cleared = vec[i].zeroed;
           recycle_events(st, vec[i]);
           vec[i] = vec.back();
           vec.pop_back();
@@ -258,7 +264,7 @@ hipError_t pool_alloc(DeviceState *st, void **p, size_t bytes, bool zero) {
     st->live[ptr] = rounded;
   }
   *p = ptr;
-  if (zero) {
+  if (zero && !cleared) {
     hipError_t e = hipMemsetAsync(ptr, 0, bytes, st->allocStream);
     if (e != hipSuccess) return e;
     return hipStreamSynchronize(st->allocStream);
@@ -296,6 +302,13 @@ hipError_t pool_free(DeviceState *st, void *p) {
     (void)hipGetLastError();
     recycle_events(st, b);
     return hipFree(p);
+  }
+  {  // clear the block behind its fence, off every query's critical path
+    bool okFill = true;
+    for (hipEvent_t e : b.fence) okFill = okFill && hipStreamWaitEvent(st->allocStream, e, 0) == hipSuccess;
+    okFill = okFill && hipMemsetAsync(p, 0, rounded, st->allocStream) == hipSuccess;
+    if (okFill && fence_on(st->allocStream) == hipSuccess) b.zeroed = true;
+    else (void)hipGetLastError();
   }
   st->bins[rounded].push_back(b);
   st->parkedBytes += rounded;

@@ -185,11 +185,11 @@ void make_regions(Regions &r, int partBits, int64_t rowsA, int64_t rowsB, int st
   // merge workgroups, which stream their regions in lockstep, do not camp on the same HBM channels
   ws.capA = ((2ull * (static_cast<uint64_t>(rowsA) / numParts) + 2 * kSlots) | 63ull) + 18;
   ws.capB = 0;
-  ws.lineRecords = lines ? 8 : 0;
+  ws.lineRecords = lines ? static_cast<int>(kLineRecords) : 0;
   if (streams > 0) {
     const uint64_t mean = static_cast<uint64_t>(rowsB) / (static_cast<uint64_t>(numParts) * streams);
-    if (lines)  // whole 128-byte lines of 8 records; an odd number of lines per stream keeps the strides off powers of two
-      ws.capB = static_cast<uint32_t>(((2 * mean + 64 + 7) / 8 * 8) | 8ull);
+    if (lines)  // capB counts whole 128-byte lines of 10 records; an odd number keeps the strides off powers of two
+      ws.capB = static_cast<uint32_t>(((2 * mean + 64) / kLineRecords + 1) | 1ull);
     else
       ws.capB = static_cast<uint32_t>(((2 * mean + 64) | 15ull) + 6);
   }
@@ -370,7 +370,7 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
   for (;;) {
     const int streams = batchRows > 0 ? (lean ? rtc_scan_grid(batchRows) : grid_for(batchRows)) : 0;
     Regions r;
-    make_regions(r, partBits, length, batchRows, streams, lean ? 4 : 3, stream, lean != nullptr);
+    make_regions(r, partBits, length, batchRows, streams, lean ? 32 : 3, stream, lean != nullptr);  // 32 words per line
     Workspace &ws = r.ws;
     ws.widen.mode = mw == 8 ? 1 : 0;
     ws.widen.rk = plan.measure.f.rk;

@@ -685,9 +685,11 @@ constexpr int kMergeBatch = 4;                      // records per lane per pipe
 constexpr uint32_t kChunk = 64 * kMergeBatch;       // records per wavefront per stage
 
 struct Chunk {
-  const uint32_t *ptr;  // first record
+  const uint32_t *ptr;  // first record (line records: start of the run)
   uint32_t rem;         // records from ptr to the end of the run (0 = no chunk)
+  uint32_t first = 0;   // line records: slot of the chunk's first record inside the run
 };
+constexpr uint32_t kLineRecords = 10;  // 12-byte records per 128-byte line of the specialised scan (hr_rtc.hip)
 
 template <int RW>
 struct RecStage {
@@ -711,6 +713,18 @@ __device__ __forceinline__ void load_chunk(RecStage<RW> &s, const Chunk &c, int 
       const Rec3 r = *reinterpret_cast<const Rec3 *>(p);
       s.w[k][0] = r.row; s.w[k][1] = r.hash; s.w[k][2] = r.val;
     }
+  }
+}
+
+// the same for a run of whole lines: slot s sits at word (s / 10) * 32 + (s % 10) * 3
+__device__ __forceinline__ void load_chunk_lines(RecStage<4> &s, const Chunk &c, int lane) {
+  const uint32_t last = c.rem ? c.rem - 1 : 0u;
+#pragma unroll
+  for (int k = 0; k < kMergeBatch; k++) {
+    const uint32_t i = static_cast<uint32_t>(k) * 64u + lane;
+    const uint32_t slot = c.first + (i < last ? i : last);
+    const Rec3 r = *reinterpret_cast<const Rec3 *>(c.ptr + static_cast<uint64_t>(slot / kLineRecords) * 32u + (slot % kLineRecords) * 3u);
+    s.w[k][0] = r.row; s.w[k][1] = r.hash; s.w[k][2] = r.val; s.w[k][3] = 0u;
   }
 }
 
@@ -845,7 +859,12 @@ __device__ __forceinline__ void merge_body(const uint8_t *__restrict__ dimIn, si
         while (g < G) {
           const uint32_t cnt = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(sRunCount[g])));
           if (offB < cnt) {
-            c.ptr = ws.recB + ((static_cast<uint64_t>(g) * (1u << pb) + p) * capB + offB) * RWB;
+            if (RWB == 4 && ws.lineRecords) {  // capB counts lines
+              c.ptr = ws.recB + (static_cast<uint64_t>(g) * (1u << pb) + p) * capB * 32u;
+              c.first = offB;
+            } else {
+              c.ptr = ws.recB + ((static_cast<uint64_t>(g) * (1u << pb) + p) * capB + offB) * RWB;
+            }
             c.rem = cnt - offB;
             offB += kChunk;
             break;
@@ -877,16 +896,25 @@ __device__ __forceinline__ void merge_body(const uint8_t *__restrict__ dimIn, si
         }
         processed += take;
       };
+      auto load = [&](RecStage<RWB> &s, const Chunk &c) {
+        if constexpr (RWB == 4) {
+          if (ws.lineRecords) {
+            load_chunk_lines(s, c, lane);
+            return;
+          }
+        }
+        load_chunk<RWB>(s, c, lane);
+      };
       RecStage<RWB> sa, sb;
       Chunk ca = next();
-      load_chunk<RWB>(sa, ca, lane);
+      load(sa, ca);
       while (ca.rem) {
         Chunk cb = next();
-        load_chunk<RWB>(sb, cb, lane);
+        load(sb, cb);
         consume(sa, ca);
         if (!cb.rem || __hip_atomic_load(&sOverflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
         ca = next();
-        load_chunk<RWB>(sa, ca, lane);
+        load(sa, ca);
         consume(sb, cb);
         if (__hip_atomic_load(&sOverflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
       }

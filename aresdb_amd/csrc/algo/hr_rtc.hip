@@ -14,7 +14,7 @@
 // write path is what matters (tools/ubench_scatter.hip, profiles/r2_ubench_write_path*.txt): reading
 // and hashing the columns runs at 6 TB/s, but a CU retires only one scattered small store per ~4.5
 // cycles and HBM write time follows the number of 64-byte write requests, so records are counting-
-// sorted by partition in LDS and leave the CU only as whole aligned 128-byte lines of 8 records.
+// sorted by partition in LDS and leave the CU only as whole aligned 128-byte lines of ten 12-byte records.
 // The matching merge (generate_merge below) is specialised the same way.
 //
 // Supported shapes (everything else: generic kernel) — exactly the fast paths of eval_quad /
@@ -158,12 +158,23 @@ bool gen_compare(const FastOperands &f, std::ostringstream &o, const char *v, co
 
 bool plain_store(int rk, int outKind) { return rk == outKind || (rk != K_F32 && outKind != K_F32 && rk != K_BOOL); }
 
+// ARES_HR_PHASES=1: the generated kernels time-stamp their phases (diagnostics; a different source text, so
+// a separate cache entry)
+static bool phases_enabled() {
+  static const bool on = [] {
+    const char *e = getenv("ARES_HR_PHASES");
+    return e && e[0] == '1';
+  }();
+  return on;
+}
+
 struct RtcArgs {  // mirrors `struct Args` of the generated source (pointers first, then 4-byte fields)
   const uint32_t *vals[kFusedCols];
   const uint8_t *nulls[kFusedCols];
   uint32_t *recB;
   uint32_t *countsB;
   uint32_t *overflow;
+  uint64_t *phases;
   uint32_t bitOff[kFusedCols];
   uint32_t rowBase;
   int length;
@@ -180,7 +191,7 @@ std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t null
        "struct __attribute__((packed, aligned(1))) PU32x4 { u32 v[4]; };\n"
        "struct __attribute__((packed, aligned(1))) PU16 { u16 v; };\n"
        "struct __attribute__((packed, aligned(4))) Rec3 { u32 row, hash, val; };\n"
-       "struct Args { const u32 *vals[" << kFusedCols << "]; const u8 *nulls[" << kFusedCols << "]; u32 *recB; u32 *countsB; u32 *overflow;\n"
+       "struct Args { const u32 *vals[" << kFusedCols << "]; const u8 *nulls[" << kFusedCols << "]; u32 *recB; u32 *countsB; u32 *overflow; u64 *phases;\n"
        "              u32 bitOff[" << kFusedCols << "]; u32 rowBase; int length; u32 capB; u32 pad; };\n"
        "#define NC " << nc << "\n#define ND " << nd << "\n#define PB " << partBits << "\n#define NP " << (1 << partBits) << "\n"
        "__device__ __forceinline__ u32 rotl(u32 x, int r) { return (x << r) | (x >> (32 - r)); }\n"
@@ -256,27 +267,35 @@ std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t null
   // ---- the kernel.  One 1024-lane workgroup per CU walks 4096-row tiles.  The write path is what
   // bounds this kernel (tools/ubench_scatter.hip): a CU retires one scattered small store per ~4.5
   // cycles, and HBM write time follows the number of 64-byte write requests — whole aligned 128-byte
-  // lines cost half of anything partial.  So records (16 bytes: row, hash, 4-byte measure, 0) are
-  // counting-sorted by partition in LDS and ONLY whole lines of 8 records leave the CU, each written
-  // by 8 adjacent lanes with one store; the < 8 records a partition has left over stay in LDS and go
-  // first in the next tile's lines.  Streams are private to the workgroup: no global atomics.
-  o << "#define T 4096u\n#define SR (T + NP * 7u)\n"
+  // lines cost half of anything partial.  So records (12 bytes: row, hash, 4-byte measure) are
+  // counting-sorted by partition in LDS and ONLY whole lines leave the CU: ten records and eight bytes of
+  // padding per 128-byte line, each line written by 8 adjacent lanes with one 16-byte store per lane; the
+  // < 10 records a partition has left over stay in LDS and go first in the next tile's lines.  Streams
+  // are private to the workgroup: no global atomics.  capB counts LINES per (workgroup, partition).
+  if (phases_enabled())
+    o << "#define PH_DECL u64 phT[8] = {0, 0, 0, 0, 0, 0, 0, 0}; u64 phLast = __builtin_readcyclecounter();\n"
+         "#define PH(k) { const u64 now = __builtin_readcyclecounter(); phT[k] += now - phLast; phLast = now; }\n"
+         "#define PH_OUT if (threadIdx.x == 0u) for (int k = 0; k < 8; k++) a.phases[(u64)blockIdx.x * 8u + k] = phT[k];\n";
+  else
+    o << "#define PH_DECL\n#define PH(k)\n#define PH_OUT\n";
+  o << "#define T 4096u\n#define LR 10u\n#define LEFTW 27u\n"
        "__device__ __forceinline__ u32 lane_up(u32 v, u32 lane, u32 off) { return (u32)__builtin_amdgcn_ds_bpermute((int)((lane - off) << 2), (int)v); }\n"
        "extern \"C\" __global__ void __launch_bounds__(1024) hr_scan_rtc(Args a) {\n"
-       "  __shared__ u32 sRow[SR], sHash[SR], sVal[SR];\n"
-       "  __shared__ u32 sLeft[NP * 21];\n"
+       "  __shared__ u32 sRec[T * 3u];\n"          // the tile's records, sorted by partition: row, hash, value
+       "  __shared__ u32 sLeft[NP * LEFTW];\n"     // up to 9 records per partition waiting for a full line
        "  __shared__ u32 sCount[2][NP];\n"
        "  __shared__ u32 sStart[NP], sLeftN[NP], sCursor[NP];\n"
-       "  __shared__ u32 sLines[SR / 8u + 1u];\n"
+       "  __shared__ u32 sLines[(T + NP * 9u) / LR + 1u];\n"
        "  __shared__ u32 sWave[16];\n"
        "  __shared__ u32 sTotalLines;\n"
        "  const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;\n"
        "  for (u32 p = tid; p < NP; p += 1024u) { sCount[0][p] = 0u; sCount[1][p] = 0u; sLeftN[p] = 0u; sCursor[p] = 0u; }\n"
        "  __syncthreads();\n"
-       "  u32 *myB = a.recB + (u64)blockIdx.x * NP * a.capB * 4u;\n"
+       "  u32 *myB = a.recB + (u64)blockIdx.x * NP * a.capB * 32u;\n"
        "  const u32 numTiles = ((u32)a.length + T - 1u) / T, fullTiles = (u32)a.length / T;\n"
        "  u32 tile = blockIdx.x, par = 0u;\n"
        "  Raw R;\n"
+       "  PH_DECL\n"
        "  if (tile < fullTiles) load_full(R, a, tile * T + tid * 4u);\n"
        "  else if (tile < numTiles) load_tail(R, a, tile * T + tid * 4u);\n"
        "  while (tile < numTiles) {\n"
@@ -293,10 +312,11 @@ std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t null
        "      if (alive[j]) rank[j] = __hip_atomic_fetch_add(&cnt[PB ? hh[j] >> (32 - (PB ? PB : 1)) : 0u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
        "    }\n"
        "    __syncthreads();\n"
+       "    PH(0)\n"
        // exclusive scans of (new records, whole lines) per partition, packed in one word
        "    u32 myCount = 0u, myLeft = 0u;\n"
        "    if (tid < NP) { myCount = cnt[tid]; myLeft = sLeftN[tid]; }\n"
-       "    const u32 myHave = myCount + myLeft, myLines = myHave >> 3;\n"
+       "    const u32 myHave = myCount + myLeft, myLines = myHave / LR;\n"
        "    const u32 packed = (myCount << 16) | myLines;\n"
        "    u32 incl = packed;\n"
        "#pragma unroll\n"
@@ -304,7 +324,8 @@ std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t null
        "    if (lane == 63u) sWave[wave] = incl;\n"
        "    __syncthreads();\n"
        "    u32 before = 0u;\n"
-       "    for (u32 w = 0u; w < wave; w++) before += sWave[w];\n"
+       "#pragma unroll\n"
+       "    for (u32 w = 0u; w < (NP + 63u) / 64u; w++) { const u32 t = sWave[w]; before += w < wave ? t : 0u; }\n"
        "    const u32 excl = before + incl - packed;\n"
        "    const u32 myStart = excl >> 16, myLineStart = excl & 0xFFFFu;\n"
        "    if (tid < NP) {\n"
@@ -313,56 +334,93 @@ std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t null
        "      if (tid == NP - 1u) sTotalLines = myLineStart + myLines;\n"
        "    }\n"
        "    __syncthreads();\n"
+       "    PH(1)\n"
        "#pragma unroll\n"
        "    for (int j = 0; j < 4; j++) {\n"
        "      if (alive[j]) {\n"
-       "        const u32 pos = sStart[PB ? hh[j] >> (32 - (PB ? PB : 1)) : 0u] + rank[j];\n"
-       "        sRow[pos] = a.rowBase + i0 + j; sHash[pos] = hh[j]; sVal[pos] = cv[j];\n"
+       "        u32 *d = sRec + (sStart[PB ? hh[j] >> (32 - (PB ? PB : 1)) : 0u] + rank[j]) * 3u;\n"
+       "        d[0] = a.rowBase + i0 + j; d[1] = hh[j]; d[2] = cv[j];\n"
        "      }\n"
        "    }\n"
        "    __syncthreads();\n"
-       // whole lines: 8 adjacent lanes write the 8 records of one aligned 128-byte line with one store
+       "    PH(2)\n"
+       // whole lines: lane q of 8 writes words 4q .. 4q+3 of the line — the partition's pending records
+       // (its remainder first, then this tile's) are one run of words apart from that seam
        "    const u32 totalLines = sTotalLines;\n"
-       "    for (u32 L = tid >> 3; L < totalLines; L += 128u) {\n"
-       "      const u32 e = sLines[L], p = e & 511u, idx = (e >> 9) * 8u + (tid & 7u);\n"
-       "      const u32 left = sLeftN[p];\n"
-       "      u32 r0, r1, r2;\n"
-       "      if (idx < left) { const u32 *s = sLeft + (p * 7u + idx) * 3u; r0 = s[0]; r1 = s[1]; r2 = s[2]; }\n"
-       "      else { const u32 k = sStart[p] + idx - left; r0 = sRow[k]; r1 = sHash[k]; r2 = sVal[k]; }\n"
-       "      const u32 at = sCursor[p] + idx;\n"
-       "      if (at < a.capB) *reinterpret_cast<uint4 *>(myB + ((u64)p * a.capB + at) * 4u) = make_uint4(r0, r1, r2, 0u);\n"
+       "    for (u32 L0 = tid >> 3; L0 < totalLines; L0 += 512u) {\n"  // four lines per lane in flight
+       "      const u32 q = tid & 7u;\n"
+       "      u32 e[4], lw[4], st[4], cu[4];\n"
+       "#pragma unroll\n"
+       "      for (u32 j = 0u; j < 4u; j++) { const u32 L = L0 + j * 128u; e[j] = L < totalLines ? sLines[L] : 0u; }\n"
+       "#pragma unroll\n"
+       "      for (u32 j = 0u; j < 4u; j++) { const u32 p = e[j] & 511u; lw[j] = sLeftN[p] * 3u; st[j] = sStart[p]; cu[j] = sCursor[p]; }\n"
+       "      u32 w[4][4];\n"
+       "#pragma unroll\n"
+       "      for (u32 j = 0u; j < 4u; j++) {\n"
+       "        const u32 p = e[j] & 511u, c = e[j] >> 9;\n"
+       "        const u32 base = (st[j] + c * LR) * 3u - lw[j];\n"  // (mod 2^32: the sum below is in range)
+       "#pragma unroll\n"
+       "        for (u32 k = 0u; k < 4u; k++) {\n"
+       "          const u32 i = 4u * q + k;\n"
+       "          const u32 *src = (c == 0u && i < lw[j]) ? sLeft + p * LEFTW + i : sRec + (base + i);\n"
+       "          w[j][k] = i >= 3u * LR ? 0u : *src;\n"
+       "        }\n"
+       "      }\n"
+       "#pragma unroll\n"
+       "      for (u32 j = 0u; j < 4u; j++) {\n"
+       "        const u32 p = e[j] & 511u, c = e[j] >> 9;\n"
+       "        const u32 at = cu[j] + c;\n"
+       "        if (L0 + j * 128u < totalLines && at < a.capB)\n"
+       "          *reinterpret_cast<uint4 *>(myB + ((u64)p * a.capB + at) * 32u + 4u * q) = make_uint4(w[j][0], w[j][1], w[j][2], w[j][3]);\n"
+       "      }\n"
        "    }\n"
        "    __syncthreads();\n"
-       // what is left of each partition (< 8 records) moves to its LDS remainder; cursors advance
+       "    PH(3)\n"
+       // what is left of each partition (< 10 records) moves to its LDS remainder; cursors advance
        "    if (tid < NP) {\n"
-       "      const u32 rem = myHave & 7u;\n"
-       "      if (myLines) {\n"
-       "        for (u32 k = 0u; k < rem; k++) { const u32 src = myStart + myLines * 8u + k - myLeft; u32 *d = sLeft + (tid * 7u + k) * 3u; d[0] = sRow[src]; d[1] = sHash[src]; d[2] = sVal[src]; }\n"
-       "      } else {\n"
-       "        for (u32 k = 0u; k < myCount; k++) { const u32 src = myStart + k; u32 *d = sLeft + (tid * 7u + myLeft + k) * 3u; d[0] = sRow[src]; d[1] = sHash[src]; d[2] = sVal[src]; }\n"
+       "      const u32 rem = myHave - myLines * LR;\n"
+       "      const u32 n = myLines ? rem * 3u : myCount * 3u;\n"
+       "      const u32 *src = sRec + (myLines ? (myStart + myLines * LR - myLeft) * 3u : myStart * 3u);\n"
+       "      u32 *dst = sLeft + tid * LEFTW + (myLines ? 0u : myLeft * 3u);\n"
+       "#pragma unroll\n"
+       "      for (u32 h0 = 0u; h0 < 28u; h0 += 14u) {\n"  // loads first, then stores: one LDS round trip per half
+       "        u32 t[14];\n"
+       "#pragma unroll\n"
+       "        for (u32 k = 0u; k < 14u; k++) t[k] = h0 + k < n ? src[h0 + k] : 0u;\n"
+       "#pragma unroll\n"
+       "        for (u32 k = 0u; k < 14u; k++) if (h0 + k < n) dst[h0 + k] = t[k];\n"
        "      }\n"
        "      sLeftN[tid] = rem;\n"
-       "      u32 cur = sCursor[tid] + myLines * 8u;\n"
+       "      u32 cur = sCursor[tid] + myLines;\n"
        "      if (cur > a.capB) { *a.overflow = 1u; cur = a.capB; }\n"
        "      sCursor[tid] = cur;\n"
        "      cnt[tid] = 0u;\n"  // this counter set is used again two tiles from now
        "    }\n"
        "    par ^= 1u;\n"
        "    tile = next;\n"
+       "    PH(4)\n"
        "  }\n"
        "  __syncthreads();\n"
-       // the remainders go out as one last line each, padded with null records (row = ~0) the merge skips
+       "  PH(5)\n"
+       // the remainders go out as one last line each, padded with null records (row = ~0) the merge skips;
+       // countsB = record slots of the run (10 per line)
        "  for (u32 p = tid >> 3; p < NP; p += 128u) {\n"
-       "    const u32 left = sLeftN[p], j = tid & 7u, cur = sCursor[p];\n"
-       "    const bool fits = cur + 8u <= a.capB;\n"
+       "    const u32 left = sLeftN[p], q = tid & 7u, cur = sCursor[p];\n"
+       "    const bool fits = cur < a.capB;\n"
        "    if (left && fits) {\n"
-       "      uint4 rec = make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);\n"
-       "      if (j < left) { const u32 *s = sLeft + (p * 7u + j) * 3u; rec = make_uint4(s[0], s[1], s[2], 0u); }\n"
-       "      *reinterpret_cast<uint4 *>(myB + ((u64)p * a.capB + cur + j) * 4u) = rec;\n"
+       "      u32 w[4];\n"
+       "#pragma unroll\n"
+       "      for (u32 k = 0u; k < 4u; k++) {\n"
+       "        const u32 i = 4u * q + k;\n"
+       "        w[k] = i < left * 3u ? sLeft[p * LEFTW + i] : (i < 3u * LR && i % 3u == 0u) ? 0xFFFFFFFFu : 0u;\n"
+       "      }\n"
+       "      *reinterpret_cast<uint4 *>(myB + ((u64)p * a.capB + cur) * 32u + 4u * q) = make_uint4(w[0], w[1], w[2], w[3]);\n"
        "    }\n"
        "    if (left && !fits) *a.overflow = 1u;\n"
-       "    if (j == 0u) a.countsB[(u64)blockIdx.x * NP + p] = (left && fits) ? cur + 8u : cur;\n"
+       "    if (q == 0u) a.countsB[(u64)blockIdx.x * NP + p] = ((left && fits) ? cur + 1u : cur) * LR;\n"
        "  }\n"
+       "  PH(6)\n"
+       "  PH_OUT\n"
        "}\n";
   return o.str();
 }
@@ -370,7 +428,7 @@ std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t null
 
 // ---- specialised merge ------------------------------------------------------------------------------
 // One workgroup per partition, like merge_body<ND, true, 4> (hr_kernels.hpp) for the case the
-// specialised scan produces: 16-byte line records in region B only, previous groups (if any) read
+// specialised scan produces: 12-byte line records in region B only, previous groups (if any) read
 // from their partition-grouped ranges, the whole hash range in one round.  What changes is the cost
 // per record: the aggregate, the widening of the carried measure and the dimension expressions are
 // literals (the generic kernel spends ~90 VALU + ~120 SALU instructions per record on dispatch), and
@@ -395,14 +453,6 @@ struct RtcMergeArgs {  // mirrors `struct MArgs` of the generated source
   uint32_t capB, streams, prevSize, pad;
   uint64_t *phases;  // ARES_HR_PHASES=1: per-partition time stamps (diagnostics)
 };
-
-static bool merge_phases_enabled() {
-  static const bool on = [] {
-    const char *e = getenv("ARES_HR_PHASES");
-    return e && e[0] == '1';
-  }();
-  return on;
-}
 
 std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w) {
   if (nd < 1 || nd > kFusedDims) return "";
@@ -446,7 +496,7 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
   char ident[32];
   snprintf(ident, sizeof(ident), "0x%016llxull", static_cast<unsigned long long>(a.identity));
   o << "#define IDENT " << ident << "\n";
-  if (merge_phases_enabled())
+  if (phases_enabled())
     o << "#define STAMP(k) if (threadIdx.x == 0u) a.phases[(u64)blockIdx.x * 8u + (k)] = __builtin_amdgcn_s_memrealtime();\n";
   else
     o << "#define STAMP(k)\n";
@@ -495,7 +545,7 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
        "  if (q.done) finish(sKeys, sVals, q, mine, value);\n"
        "  else __hip_atomic_store(sOverflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"  // table full: the round is void anyway
        "}\n";
-  // Records arrive in segments of up to 64 (one per lane), four segments per register stage — of one long
+  // Records arrive in segments of up to 60 (six lines, one record per lane), four segments per register stage — of one long
   // run or of four short ones (small batches leave ~16 records per run: a stage per run would make the
   // merge a chain of dependent loads).  Round one looks at every record's home bucket with straight-line
   // code (no claim, no advance): a record whose group sits there — ~93 % once the groups exist — costs one
@@ -503,8 +553,9 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
   // taken through the general probe loop 64 at a time, every lane busy: run per record where it occurs,
   // that loop would execute for a handful of lanes after nearly every segment.
   o << "#define QCAP 128u\n"
-       "struct Seg { const uint4 *ptr; u32 n; };\n"
-       "struct Stage { uint4 r[4]; u32 n[4]; };\n"
+       "struct __attribute__((packed, aligned(4))) R3 { u32 x, y, z; };\n"
+       "struct Seg { const u32 *ptr; u32 n; };\n"   // up to 60 record slots: six 128-byte lines of ten 12-byte records
+       "struct Stage { R3 r[4]; u32 n[4]; };\n"
        "__device__ __forceinline__ void drain(u32 *queue, u32 first, u32 count, u32 lane, u64 *sKeys, u64 *sVals, u32 *sClaimed, u32 *sOverflow) {\n"
        "  asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");\n"
        "  if (lane < count) {\n"
@@ -615,20 +666,24 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
        "  STAMP(2)\n"
        // the partition's runs: every wavefront streams whole runs, two register stages
        "  if (G > 0u) {\n"
-       "    const uint4 *dummy = reinterpret_cast<const uint4 *>(a.recB);\n"
-       "    u32 g = wave, off = 0u, qn = 0u;\n"
+       "    const u32 *dummy = a.recB;\n"
+       "    u32 j = 0u, off = 0u, qn = 0u;\n"
        "    u32 *queue = sQueue + wave * (QCAP * 3u);\n"
+       // this wavefront's runs are wave, wave + 16, ...: lane i keeps the length of the i-th of them, so that
+       // walking the runs costs no LDS round trip per segment
+       "    const u32 myRuns = (G + 15u - wave) / 16u;\n"
+       "    const u32 myCnt = lane < myRuns ? sRunCount[wave + 16u * lane] : 0u;\n"
        "    auto next = [&]() -> Seg {\n"
        "      Seg c{dummy, 0u};\n"
-       "      while (g < G) {\n"
-       "        const u32 cnt = (u32)__builtin_amdgcn_readfirstlane((int)sRunCount[g]);\n"
+       "      while (j < myRuns) {\n"
+       "        const u32 cnt = (u32)__builtin_amdgcn_readlane((int)myCnt, (int)j);\n"
        "        if (off < cnt) {\n"
-       "          c.ptr = reinterpret_cast<const uint4 *>(a.recB) + ((u64)g * NP + p) * a.capB + off;\n"
-       "          c.n = cnt - off < 64u ? cnt - off : 64u;\n"
-       "          off += 64u;\n"
+       "          c.ptr = a.recB + (((u64)(wave + 16u * j) * NP + p) * a.capB + off / 10u) * 32u;\n"
+       "          c.n = cnt - off < 60u ? cnt - off : 60u;\n"
+       "          off += 60u;\n"
        "          break;\n"
        "        }\n"
-       "        g += 16u; off = 0u;\n"
+       "        j++; off = 0u;\n"
        "      }\n"
        "      return c;\n"
        "    };\n"
@@ -637,17 +692,24 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
        "      for (int k = 0; k < 4; k++) {\n"
        "        const Seg c = next();\n"
        "        s.n[k] = c.n;\n"
-       "        s.r[k] = c.ptr[lane < c.n ? lane : (c.n ? c.n - 1u : 0u)];\n"
+       "        const u32 i = lane < c.n ? lane : (c.n ? c.n - 1u : 0u);\n"
+       "        s.r[k] = *reinterpret_cast<const R3 *>(c.ptr + (i / 10u) * 32u + (i % 10u) * 3u);\n"
        "      }\n"
        "    };\n"
-       "    Stage sa, sb;\n"
-       "    load(sa);\n"
-       "    while (sa.n[0]) {\n"
-       "      load(sb);\n"
-       "      consume(sa, lane, sKeys, sVals, &sClaimed, &sOverflow, queue, qn);\n"
-       "      if (!sb.n[0]) break;\n"
-       "      load(sa);\n"
-       "      consume(sb, lane, sKeys, sVals, &sClaimed, &sOverflow, queue, qn);\n"
+       // three register stages: two stages of loads are always in flight behind the one being consumed
+       "    Stage s0, s1, s2;\n"
+       "    load(s0);\n"
+       "    load(s1);\n"
+       "    for (;;) {\n"
+       "      load(s2);\n"
+       "      if (!s0.n[0]) break;\n"
+       "      consume(s0, lane, sKeys, sVals, &sClaimed, &sOverflow, queue, qn);\n"
+       "      load(s0);\n"
+       "      if (!s1.n[0]) break;\n"
+       "      consume(s1, lane, sKeys, sVals, &sClaimed, &sOverflow, queue, qn);\n"
+       "      load(s1);\n"
+       "      if (!s2.n[0]) break;\n"
+       "      consume(s2, lane, sKeys, sVals, &sClaimed, &sOverflow, queue, qn);\n"
        "    }\n"
        "    if (qn) drain(queue, 0u, qn, lane, sKeys, sVals, &sClaimed, &sOverflow);\n"
        "  }\n"
@@ -786,9 +848,30 @@ void rtc_scan_launch(void *kernel, const FusedPlanD &plan, uint32_t rowBase, int
   args.capB = ws.capB;
   size_t size = sizeof(args);
   void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-  KernelTimer timer("hr_scan_rtc", stream);
-  hip_check(hipModuleLaunchKernel(fn, static_cast<unsigned>(ws.streams), 1, 1, hr::kThreads, 1, 1, 0, stream, nullptr, config),
-            "hipModuleLaunchKernel");
+  static uint64_t *phases = nullptr;
+  if (phases_enabled()) {
+    if (!phases) hip_check(hipMalloc(reinterpret_cast<void **>(&phases), sizeof(uint64_t) * 8 * hr::kMaxStreams), "hipMalloc");
+    args.phases = phases;
+  }
+  {
+    KernelTimer timer("hr_scan_rtc", stream);
+    hip_check(hipModuleLaunchKernel(fn, static_cast<unsigned>(ws.streams), 1, 1, hr::kThreads, 1, 1, 0, stream, nullptr, config),
+              "hipModuleLaunchKernel");
+  }
+  if (phases_enabled()) {  // diagnostics: core-clock cycles lane 0 of each workgroup spent per phase
+    static int launches = 0;
+    std::vector<uint64_t> h(static_cast<size_t>(8) * ws.streams);
+    hip_check(hipMemcpyAsync(h.data(), phases, sizeof(uint64_t) * h.size(), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync");
+    hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    if (++launches <= 3 || launches % 64 == 0) {
+      double sum[7] = {0, 0, 0, 0, 0, 0, 0};
+      for (int g = 0; g < ws.streams; g++)
+        for (int k = 0; k < 7; k++) sum[k] += static_cast<double>(h[static_cast<size_t>(8) * g + k]);
+      const double n = ws.streams * 1e3;
+      fprintf(stderr, "hr_scan_rtc phases (launch %d, %d workgroups, %d rows): kcycles per workgroup: eval+count %.1f, scan %.1f, scatter %.1f, lines %.1f, leftovers %.1f, drain %.1f, last lines %.1f\n",
+              launches, ws.streams, length, sum[0] / n, sum[1] / n, sum[2] / n, sum[3] / n, sum[4] / n, sum[5] / n, sum[6] / n);
+    }
+  }
 }
 
 
@@ -827,7 +910,7 @@ void rtc_merge_launch(void *kernel, const FusedPlanD &plan, const uint8_t *prevD
   size_t size = sizeof(args);
   void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
   static uint64_t *phases = nullptr;
-  if (merge_phases_enabled()) {
+  if (phases_enabled()) {
     if (!phases) hip_check(hipMalloc(reinterpret_cast<void **>(&phases), sizeof(uint64_t) * 8 * hr::kMaxPartitions), "hipMalloc");
     hip_check(hipMemsetAsync(phases, 0, sizeof(uint64_t) * 8 * hr::kMaxPartitions, stream), "hipMemsetAsync");
     args.phases = phases;
@@ -837,7 +920,7 @@ void rtc_merge_launch(void *kernel, const FusedPlanD &plan, const uint8_t *prevD
     hip_check(hipModuleLaunchKernel(fn, 1u << ws.partBits, 1, 1, hr::kThreads, 1, 1, 0, stream, nullptr, config),
               "hipModuleLaunchKernel");
   }
-  if (merge_phases_enabled()) {  // diagnostics: where a partition's time goes (100 MHz constant clock)
+  if (phases_enabled()) {  // diagnostics: where a partition's time goes (100 MHz constant clock)
     static int launches = 0;
     const int np = 1 << ws.partBits;
     std::vector<uint64_t> h(static_cast<size_t>(8) * np);

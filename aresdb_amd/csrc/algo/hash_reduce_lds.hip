@@ -1,6 +1,11 @@
 // HashReduce, partitioned: kernels and host side (device code: hr_kernels.hpp).
 #include <hip/hip_runtime.h>
 
+#include <functional>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+
 #include <memory>
 #include <mutex>
 #include <vector>
@@ -161,6 +166,10 @@ int lean_min_groups() {
   return v;
 }
 
+// groups the first batch of a plan shape produced the last time (cardinality feedback for first batches)
+std::mutex g_shapeMutex;
+std::unordered_map<size_t, int> g_firstBatchGroups;
+
 int part_bits_for(int64_t length) {
   int partBits = 0;
   while ((8192ll << partBits) < length && (1 << partBits) < kMaxPartitions) partBits++;
@@ -185,11 +194,11 @@ void make_regions(Regions &r, int partBits, int64_t rowsA, int64_t rowsB, int st
   // merge workgroups, which stream their regions in lockstep, do not camp on the same HBM channels
   ws.capA = ((2ull * (static_cast<uint64_t>(rowsA) / numParts) + 2 * kSlots) | 63ull) + 18;
   ws.capB = 0;
-  ws.lineRecords = lines ? static_cast<int>(kLineRecords) : 0;
+  ws.lineRecords = lines ? 8 : 0;
   if (streams > 0) {
     const uint64_t mean = static_cast<uint64_t>(rowsB) / (static_cast<uint64_t>(numParts) * streams);
-    if (lines)  // capB counts whole 128-byte lines of 10 records; an odd number keeps the strides off powers of two
-      ws.capB = static_cast<uint32_t>(((2 * mean + 64) / kLineRecords + 1) | 1ull);
+    if (lines)  // whole 128-byte lines of 8 records; an odd number of lines per stream keeps the strides off powers of two
+      ws.capB = static_cast<uint32_t>(((2 * mean + 64 + 7) / 8 * 8) | 8ull);
     else
       ws.capB = static_cast<uint32_t>(((2 * mean + 64) | 15ull) + 6);
   }
@@ -365,12 +374,22 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
   // A query that already has more groups than an LDS table holds goes straight to DIRECT mode, with the
   // scan kernel compiled for this plan (hr_rtc.hip); the adaptive generic kernel takes the first batch
   // (nothing known yet), low-cardinality queries and every plan the generator does not cover.
+  // The first batch of a query has no previous groups to judge by: it goes by what the first batch of
+  // the same plan shape (expressions and constants, not columns) produced the last time it ran.
   void *lean = nullptr;
-  if (batchRows > 0 && prevSize >= lean_min_groups() && rtc_scan_available()) lean = rtc_scan_lookup(device, plan, nd, partBits);
+  size_t shape = 0;
+  int expected = prevSize;
+  if (batchRows > 0 && prevSize == 0 && rtc_scan_available()) {
+    shape = std::hash<std::string>()(rtc_scan_source(plan, nd, 0));
+    std::lock_guard<std::mutex> lock(g_shapeMutex);
+    auto it = g_firstBatchGroups.find(shape);
+    if (it != g_firstBatchGroups.end()) expected = it->second;
+  }
+  if (batchRows > 0 && expected >= lean_min_groups() && rtc_scan_available()) lean = rtc_scan_lookup(device, plan, nd, partBits);
   for (;;) {
     const int streams = batchRows > 0 ? (lean ? rtc_scan_grid(batchRows) : grid_for(batchRows)) : 0;
     Regions r;
-    make_regions(r, partBits, length, batchRows, streams, lean ? 32 : 3, stream, lean != nullptr);  // 32 words per line
+    make_regions(r, partBits, length, batchRows, streams, lean ? 4 : 3, stream, lean != nullptr);
     Workspace &ws = r.ws;
     ws.widen.mode = mw == 8 ? 1 : 0;
     ws.widen.rk = plan.measure.f.rk;
@@ -440,6 +459,11 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
   if (res.overflow) {
     give_ranges(device, outRanges);
     return -1;
+  }
+  if (shape) {
+    std::lock_guard<std::mutex> lock(g_shapeMutex);
+    if (g_firstBatchGroups.size() > 4096) g_firstBatchGroups.clear();
+    g_firstBatchGroups[shape] = static_cast<int>(res.groups);
   }
   if (outRanges) {
     GroupedState s{device, outKeys.DimValues, outValues, outCapacity, nd, mw, static_cast<int>(res.groups), partBits, outRanges};

@@ -689,7 +689,8 @@ struct Chunk {
   uint32_t rem;         // records from ptr to the end of the run (0 = no chunk)
   uint32_t first = 0;   // line records: slot of the chunk's first record inside the run
 };
-constexpr uint32_t kLineRecords = 10;  // 12-byte records per 128-byte line of the specialised scan (hr_rtc.hip)
+constexpr uint32_t kLineRecords = 10;  // lineRecords == 10: 12-byte records, ten per 128-byte line (a format the scan can be
+                                       // generated for; 8 = 16-byte records, which is what it produces — see hr_rtc.hip)
 
 template <int RW>
 struct RecStage {
@@ -859,7 +860,7 @@ __device__ __forceinline__ void merge_body(const uint8_t *__restrict__ dimIn, si
         while (g < G) {
           const uint32_t cnt = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(sRunCount[g])));
           if (offB < cnt) {
-            if (RWB == 4 && ws.lineRecords) {  // capB counts lines
+            if (RWB == 4 && ws.lineRecords == static_cast<int>(kLineRecords)) {  // 12-byte line records: capB counts lines
               c.ptr = ws.recB + (static_cast<uint64_t>(g) * (1u << pb) + p) * capB * 32u;
               c.first = offB;
             } else {
@@ -898,7 +899,7 @@ __device__ __forceinline__ void merge_body(const uint8_t *__restrict__ dimIn, si
       };
       auto load = [&](RecStage<RWB> &s, const Chunk &c) {
         if constexpr (RWB == 4) {
-          if (ws.lineRecords) {
+          if (ws.lineRecords == static_cast<int>(kLineRecords)) {
             load_chunk_lines(s, c, lane);
             return;
           }

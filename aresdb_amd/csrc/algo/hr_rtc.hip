@@ -14,7 +14,7 @@
 // write path is what matters (tools/ubench_scatter.hip, profiles/r2_ubench_write_path*.txt): reading
 // and hashing the columns runs at 6 TB/s, but a CU retires only one scattered small store per ~4.5
 // cycles and HBM write time follows the number of 64-byte write requests, so records are counting-
-// sorted by partition in LDS and leave the CU only as whole aligned 128-byte lines of ten 12-byte records.
+// sorted by partition in LDS and leave the CU only as whole aligned 128-byte lines of 8 records.
 // The matching merge (generate_merge below) is specialised the same way.
 //
 // Supported shapes (everything else: generic kernel) — exactly the fast paths of eval_quad /
@@ -265,33 +265,36 @@ std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t null
     o << "    }\n  }\n}\n";
   }
   // ---- the kernel.  One 1024-lane workgroup per CU walks 4096-row tiles.  The write path is what
-  // bounds this kernel (tools/ubench_scatter.hip): a CU retires one scattered small store per ~4.5
-  // cycles, and HBM write time follows the number of 64-byte write requests — whole aligned 128-byte
-  // lines cost half of anything partial.  So records (12 bytes: row, hash, 4-byte measure) are
-  // counting-sorted by partition in LDS and ONLY whole lines leave the CU: ten records and eight bytes of
-  // padding per 128-byte line, each line written by 8 adjacent lanes with one 16-byte store per lane; the
-  // < 10 records a partition has left over stay in LDS and go first in the next tile's lines.  Streams
-  // are private to the workgroup: no global atomics.  capB counts LINES per (workgroup, partition).
+  // bounds the memory side of this kernel (tools/ubench_scatter.hip): a CU retires one scattered small
+  // store per ~4.5 cycles, and HBM write time follows the number of 64-byte write requests — whole
+  // aligned 128-byte lines cost half of anything partial.  So records (16 bytes: row, hash, 4-byte
+  // measure, 0) are counting-sorted by partition in LDS and ONLY whole lines of 8 records leave the CU,
+  // each written by 8 adjacent lanes with one store; the < 8 records a partition has left over stay in
+  // LDS and go first in the next tile's lines.  Streams are private to the workgroup: no global atomics.
+  // The other bound is instruction issue (ARES_HR_PHASES=1: ~3/4 of a tile's critical path is VALU/LDS
+  // issue): records are 16-byte units in LDS too, so that sorting, line building and the remainder copy
+  // move one record per LDS instruction — a 12-byte record format (10 per line, -20 % traffic) was
+  // measured slower for exactly that reason.
   if (phases_enabled())
     o << "#define PH_DECL u64 phT[8] = {0, 0, 0, 0, 0, 0, 0, 0}; u64 phLast = __builtin_readcyclecounter();\n"
          "#define PH(k) { const u64 now = __builtin_readcyclecounter(); phT[k] += now - phLast; phLast = now; }\n"
          "#define PH_OUT if (threadIdx.x == 0u) for (int k = 0; k < 8; k++) a.phases[(u64)blockIdx.x * 8u + k] = phT[k];\n";
   else
     o << "#define PH_DECL\n#define PH(k)\n#define PH_OUT\n";
-  o << "#define T 4096u\n#define LR 10u\n#define LEFTW 27u\n"
+  o << "#define T 4096u\n"
        "__device__ __forceinline__ u32 lane_up(u32 v, u32 lane, u32 off) { return (u32)__builtin_amdgcn_ds_bpermute((int)((lane - off) << 2), (int)v); }\n"
        "extern \"C\" __global__ void __launch_bounds__(1024) hr_scan_rtc(Args a) {\n"
-       "  __shared__ u32 sRec[T * 3u];\n"          // the tile's records, sorted by partition: row, hash, value
-       "  __shared__ u32 sLeft[NP * LEFTW];\n"     // up to 9 records per partition waiting for a full line
+       "  __shared__ uint4 sRec[T];\n"            // the tile's records, sorted by partition
+       "  __shared__ uint4 sLeft[NP * 7u];\n"     // up to 7 records per partition waiting for a full line
        "  __shared__ u32 sCount[2][NP];\n"
        "  __shared__ u32 sStart[NP], sLeftN[NP], sCursor[NP];\n"
-       "  __shared__ u32 sLines[(T + NP * 9u) / LR + 1u];\n"
+       "  __shared__ u32 sLines[(T + NP * 7u) / 8u + 1u];\n"
        "  __shared__ u32 sWave[16];\n"
        "  __shared__ u32 sTotalLines;\n"
        "  const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;\n"
        "  for (u32 p = tid; p < NP; p += 1024u) { sCount[0][p] = 0u; sCount[1][p] = 0u; sLeftN[p] = 0u; sCursor[p] = 0u; }\n"
        "  __syncthreads();\n"
-       "  u32 *myB = a.recB + (u64)blockIdx.x * NP * a.capB * 32u;\n"
+       "  uint4 *myB = reinterpret_cast<uint4 *>(a.recB) + (u64)blockIdx.x * NP * a.capB;\n"
        "  const u32 numTiles = ((u32)a.length + T - 1u) / T, fullTiles = (u32)a.length / T;\n"
        "  u32 tile = blockIdx.x, par = 0u;\n"
        "  Raw R;\n"
@@ -316,7 +319,7 @@ std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t null
        // exclusive scans of (new records, whole lines) per partition, packed in one word
        "    u32 myCount = 0u, myLeft = 0u;\n"
        "    if (tid < NP) { myCount = cnt[tid]; myLeft = sLeftN[tid]; }\n"
-       "    const u32 myHave = myCount + myLeft, myLines = myHave / LR;\n"
+       "    const u32 myHave = myCount + myLeft, myLines = myHave >> 3;\n"
        "    const u32 packed = (myCount << 16) | myLines;\n"
        "    u32 incl = packed;\n"
        "#pragma unroll\n"
@@ -336,62 +339,48 @@ std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t null
        "    __syncthreads();\n"
        "    PH(1)\n"
        "#pragma unroll\n"
-       "    for (int j = 0; j < 4; j++) {\n"
-       "      if (alive[j]) {\n"
-       "        u32 *d = sRec + (sStart[PB ? hh[j] >> (32 - (PB ? PB : 1)) : 0u] + rank[j]) * 3u;\n"
-       "        d[0] = a.rowBase + i0 + j; d[1] = hh[j]; d[2] = cv[j];\n"
-       "      }\n"
-       "    }\n"
+       "    for (int j = 0; j < 4; j++)\n"
+       "      if (alive[j]) sRec[sStart[PB ? hh[j] >> (32 - (PB ? PB : 1)) : 0u] + rank[j]] = make_uint4(a.rowBase + i0 + j, hh[j], cv[j], 0u);\n"
        "    __syncthreads();\n"
        "    PH(2)\n"
-       // whole lines: lane q of 8 writes words 4q .. 4q+3 of the line — the partition's pending records
-       // (its remainder first, then this tile's) are one run of words apart from that seam
+       // whole lines: 8 adjacent lanes write the 8 records of one aligned 128-byte line with one store;
+       // four lines per lane are in flight (the LDS look-ups of a line depend on one another)
        "    const u32 totalLines = sTotalLines;\n"
-       "    for (u32 L0 = tid >> 3; L0 < totalLines; L0 += 512u) {\n"  // four lines per lane in flight
+       "    for (u32 L0 = tid >> 3; L0 < totalLines; L0 += 512u) {\n"
        "      const u32 q = tid & 7u;\n"
-       "      u32 e[4], lw[4], st[4], cu[4];\n"
+       "      u32 e[4], lf[4], st[4], cu[4];\n"
        "#pragma unroll\n"
        "      for (u32 j = 0u; j < 4u; j++) { const u32 L = L0 + j * 128u; e[j] = L < totalLines ? sLines[L] : 0u; }\n"
        "#pragma unroll\n"
-       "      for (u32 j = 0u; j < 4u; j++) { const u32 p = e[j] & 511u; lw[j] = sLeftN[p] * 3u; st[j] = sStart[p]; cu[j] = sCursor[p]; }\n"
-       "      u32 w[4][4];\n"
+       "      for (u32 j = 0u; j < 4u; j++) { const u32 p = e[j] & 511u; lf[j] = sLeftN[p]; st[j] = sStart[p]; cu[j] = sCursor[p]; }\n"
+       "      uint4 rec[4];\n"
        "#pragma unroll\n"
        "      for (u32 j = 0u; j < 4u; j++) {\n"
-       "        const u32 p = e[j] & 511u, c = e[j] >> 9;\n"
-       "        const u32 base = (st[j] + c * LR) * 3u - lw[j];\n"  // (mod 2^32: the sum below is in range)
-       "#pragma unroll\n"
-       "        for (u32 k = 0u; k < 4u; k++) {\n"
-       "          const u32 i = 4u * q + k;\n"
-       "          const u32 *src = (c == 0u && i < lw[j]) ? sLeft + p * LEFTW + i : sRec + (base + i);\n"
-       "          w[j][k] = i >= 3u * LR ? 0u : *src;\n"
-       "        }\n"
+       "        const u32 p = e[j] & 511u, idx = (e[j] >> 9) * 8u + q;\n"
+       "        const uint4 *src = idx < lf[j] ? sLeft + p * 7u + idx : sRec + ((st[j] + idx - lf[j]) & (T - 1u));\n"
+       "        rec[j] = *src;\n"
        "      }\n"
        "#pragma unroll\n"
        "      for (u32 j = 0u; j < 4u; j++) {\n"
-       "        const u32 p = e[j] & 511u, c = e[j] >> 9;\n"
-       "        const u32 at = cu[j] + c;\n"
-       "        if (L0 + j * 128u < totalLines && at < a.capB)\n"
-       "          *reinterpret_cast<uint4 *>(myB + ((u64)p * a.capB + at) * 32u + 4u * q) = make_uint4(w[j][0], w[j][1], w[j][2], w[j][3]);\n"
+       "        const u32 p = e[j] & 511u, at = cu[j] + (e[j] >> 9) * 8u + q;\n"
+       "        if (L0 + j * 128u < totalLines && at < a.capB) myB[(u64)p * a.capB + at] = rec[j];\n"
        "      }\n"
        "    }\n"
        "    __syncthreads();\n"
        "    PH(3)\n"
-       // what is left of each partition (< 10 records) moves to its LDS remainder; cursors advance
+       // what is left of each partition (< 8 records) moves to its LDS remainder; cursors advance
        "    if (tid < NP) {\n"
-       "      const u32 rem = myHave - myLines * LR;\n"
-       "      const u32 n = myLines ? rem * 3u : myCount * 3u;\n"
-       "      const u32 *src = sRec + (myLines ? (myStart + myLines * LR - myLeft) * 3u : myStart * 3u);\n"
-       "      u32 *dst = sLeft + tid * LEFTW + (myLines ? 0u : myLeft * 3u);\n"
+       "      const u32 rem = myHave & 7u;\n"
+       "      const u32 n = myLines ? rem : myCount;\n"
+       "      const uint4 *src = sRec + (myLines ? myStart + myLines * 8u - myLeft : myStart);\n"
+       "      uint4 *dst = sLeft + tid * 7u + (myLines ? 0u : myLeft);\n"
+       "      uint4 t[7];\n"
        "#pragma unroll\n"
-       "      for (u32 h0 = 0u; h0 < 28u; h0 += 14u) {\n"  // loads first, then stores: one LDS round trip per half
-       "        u32 t[14];\n"
+       "      for (u32 k = 0u; k < 7u; k++) t[k] = src[k < n ? k : 0u];\n"  // loads first, then stores: one LDS round trip
        "#pragma unroll\n"
-       "        for (u32 k = 0u; k < 14u; k++) t[k] = h0 + k < n ? src[h0 + k] : 0u;\n"
-       "#pragma unroll\n"
-       "        for (u32 k = 0u; k < 14u; k++) if (h0 + k < n) dst[h0 + k] = t[k];\n"
-       "      }\n"
+       "      for (u32 k = 0u; k < 7u; k++) if (k < n) dst[k] = t[k];\n"
        "      sLeftN[tid] = rem;\n"
-       "      u32 cur = sCursor[tid] + myLines;\n"
+       "      u32 cur = sCursor[tid] + myLines * 8u;\n"
        "      if (cur > a.capB) { *a.overflow = 1u; cur = a.capB; }\n"
        "      sCursor[tid] = cur;\n"
        "      cnt[tid] = 0u;\n"  // this counter set is used again two tiles from now
@@ -402,22 +391,13 @@ std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t null
        "  }\n"
        "  __syncthreads();\n"
        "  PH(5)\n"
-       // the remainders go out as one last line each, padded with null records (row = ~0) the merge skips;
-       // countsB = record slots of the run (10 per line)
+       // the remainders go out as one last line each, padded with null records (row = ~0) the merge skips
        "  for (u32 p = tid >> 3; p < NP; p += 128u) {\n"
-       "    const u32 left = sLeftN[p], q = tid & 7u, cur = sCursor[p];\n"
-       "    const bool fits = cur < a.capB;\n"
-       "    if (left && fits) {\n"
-       "      u32 w[4];\n"
-       "#pragma unroll\n"
-       "      for (u32 k = 0u; k < 4u; k++) {\n"
-       "        const u32 i = 4u * q + k;\n"
-       "        w[k] = i < left * 3u ? sLeft[p * LEFTW + i] : (i < 3u * LR && i % 3u == 0u) ? 0xFFFFFFFFu : 0u;\n"
-       "      }\n"
-       "      *reinterpret_cast<uint4 *>(myB + ((u64)p * a.capB + cur) * 32u + 4u * q) = make_uint4(w[0], w[1], w[2], w[3]);\n"
-       "    }\n"
+       "    const u32 left = sLeftN[p], j = tid & 7u, cur = sCursor[p];\n"
+       "    const bool fits = cur + 8u <= a.capB;\n"
+       "    if (left && fits) myB[(u64)p * a.capB + cur + j] = j < left ? sLeft[p * 7u + j] : make_uint4(0xFFFFFFFFu, 0u, 0u, 0u);\n"
        "    if (left && !fits) *a.overflow = 1u;\n"
-       "    if (q == 0u) a.countsB[(u64)blockIdx.x * NP + p] = ((left && fits) ? cur + 1u : cur) * LR;\n"
+       "    if (j == 0u) a.countsB[(u64)blockIdx.x * NP + p] = (left && fits) ? cur + 8u : cur;\n"
        "  }\n"
        "  PH(6)\n"
        "  PH_OUT\n"
@@ -428,7 +408,7 @@ std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t null
 
 // ---- specialised merge ------------------------------------------------------------------------------
 // One workgroup per partition, like merge_body<ND, true, 4> (hr_kernels.hpp) for the case the
-// specialised scan produces: 12-byte line records in region B only, previous groups (if any) read
+// specialised scan produces: 16-byte line records in region B only, previous groups (if any) read
 // from their partition-grouped ranges, the whole hash range in one round.  What changes is the cost
 // per record: the aggregate, the widening of the carried measure and the dimension expressions are
 // literals (the generic kernel spends ~90 VALU + ~120 SALU instructions per record on dispatch), and
@@ -545,7 +525,7 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
        "  if (q.done) finish(sKeys, sVals, q, mine, value);\n"
        "  else __hip_atomic_store(sOverflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"  // table full: the round is void anyway
        "}\n";
-  // Records arrive in segments of up to 60 (six lines, one record per lane), four segments per register stage — of one long
+  // Records arrive in segments of up to 64 (one per lane), four segments per register stage — of one long
   // run or of four short ones (small batches leave ~16 records per run: a stage per run would make the
   // merge a chain of dependent loads).  Round one looks at every record's home bucket with straight-line
   // code (no claim, no advance): a record whose group sits there — ~93 % once the groups exist — costs one
@@ -553,9 +533,8 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
   // taken through the general probe loop 64 at a time, every lane busy: run per record where it occurs,
   // that loop would execute for a handful of lanes after nearly every segment.
   o << "#define QCAP 128u\n"
-       "struct __attribute__((packed, aligned(4))) R3 { u32 x, y, z; };\n"
-       "struct Seg { const u32 *ptr; u32 n; };\n"   // up to 60 record slots: six 128-byte lines of ten 12-byte records
-       "struct Stage { R3 r[4]; u32 n[4]; };\n"
+       "struct Seg { const uint4 *ptr; u32 n; };\n"
+       "struct Stage { uint4 r[4]; u32 n[4]; };\n"
        "__device__ __forceinline__ void drain(u32 *queue, u32 first, u32 count, u32 lane, u64 *sKeys, u64 *sVals, u32 *sClaimed, u32 *sOverflow) {\n"
        "  asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");\n"
        "  if (lane < count) {\n"
@@ -666,7 +645,7 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
        "  STAMP(2)\n"
        // the partition's runs: every wavefront streams whole runs, two register stages
        "  if (G > 0u) {\n"
-       "    const u32 *dummy = a.recB;\n"
+       "    const uint4 *dummy = reinterpret_cast<const uint4 *>(a.recB);\n"
        "    u32 j = 0u, off = 0u, qn = 0u;\n"
        "    u32 *queue = sQueue + wave * (QCAP * 3u);\n"
        // this wavefront's runs are wave, wave + 16, ...: lane i keeps the length of the i-th of them, so that
@@ -678,9 +657,9 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
        "      while (j < myRuns) {\n"
        "        const u32 cnt = (u32)__builtin_amdgcn_readlane((int)myCnt, (int)j);\n"
        "        if (off < cnt) {\n"
-       "          c.ptr = a.recB + (((u64)(wave + 16u * j) * NP + p) * a.capB + off / 10u) * 32u;\n"
-       "          c.n = cnt - off < 60u ? cnt - off : 60u;\n"
-       "          off += 60u;\n"
+       "          c.ptr = reinterpret_cast<const uint4 *>(a.recB) + ((u64)(wave + 16u * j) * NP + p) * a.capB + off;\n"
+       "          c.n = cnt - off < 64u ? cnt - off : 64u;\n"
+       "          off += 64u;\n"
        "          break;\n"
        "        }\n"
        "        j++; off = 0u;\n"
@@ -692,8 +671,7 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
        "      for (int k = 0; k < 4; k++) {\n"
        "        const Seg c = next();\n"
        "        s.n[k] = c.n;\n"
-       "        const u32 i = lane < c.n ? lane : (c.n ? c.n - 1u : 0u);\n"
-       "        s.r[k] = *reinterpret_cast<const R3 *>(c.ptr + (i / 10u) * 32u + (i % 10u) * 3u);\n"
+       "        s.r[k] = c.ptr[lane < c.n ? lane : (c.n ? c.n - 1u : 0u)];\n"
        "      }\n"
        "    };\n"
        // three register stages: two stages of loads are always in flight behind the one being consumed

@@ -465,6 +465,15 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
     if (g_firstBatchGroups.size() > 4096) g_firstBatchGroups.clear();
     g_firstBatchGroups[shape] = static_cast<int>(res.groups);
   }
+  if (shape && !lean && static_cast<int>(res.groups) >= lean_min_groups()) {
+    // the next first batch of this shape takes the specialised kernels: compile them now, with the other
+    // first-time costs of the shape, not inside that query
+    hr::Widen w;
+    w.mode = mw == 8 ? 1 : 0;
+    w.rk = plan.measure.f.rk;
+    w.dtype = plan.measureDtype;
+    if (rtc_scan_lookup(device, plan, nd, partBits)) (void)rtc_merge_lookup(device, plan, nd, partBits, a, w);
+  }
   if (outRanges) {
     GroupedState s{device, outKeys.DimValues, outValues, outCapacity, nd, mw, static_cast<int>(res.groups), partBits, outRanges};
     if (res.groups > 0) grouped_register(s);

@@ -268,8 +268,11 @@ inline bool fast_operands(const EvalParams &p, FastOperands &f, bool compareOnly
   f.bok = p.b.cok;
   f.idx = p.needRow ? p.idx : nullptr;
   f.divLike = p.arity == 2 && (p.I == K_I32 || p.I == K_U32) && (p.functor == Divide || p.functor == Mod || p.functor == Floor);
-  const char *dbg = getenv("ARES_F_DEBUG");
-  f.debug = dbg ? atoi(dbg) : 0;
+  static const int debug = [] {  // kernel-variant switch of the filter experiments (tools/)
+    const char *dbg = getenv("ARES_F_DEBUG");
+    return dbg ? atoi(dbg) : 0;
+  }();
+  f.debug = debug;
   return true;
 }
 

@@ -126,8 +126,11 @@ using namespace ares;
 
 // ARES_HASH_REDUCE=global pins the global-table path (tests exercise both implementations).
 static bool global_table_forced() {
-  const char *e = getenv("ARES_HASH_REDUCE");
-  return e && strcmp(e, "global") == 0;
+  static const bool forced = [] {
+    const char *e = getenv("ARES_HASH_REDUCE");
+    return e && strcmp(e, "global") == 0;
+  }();
+  return forced;
 }
 
 extern "C" CGoCallResHandle HashReduce(DimensionVector inputKeys, uint8_t *inputValues, DimensionVector outputKeys,

@@ -274,15 +274,24 @@ int hash_reduce_lds(int device, const DimensionVector &inputKeys, const uint8_t 
   for (;;) {
     const int start = grouped ? prev.size : 0;
     const int rows = length - start;
-    const int streams = (all4 && rows > 0) ? grid_for(rows) : 0;
-    const int rwB = a.width == 8 ? 4 : 3;
+    // a query that already has more groups than an LDS table holds: the write-combining scan, generated
+    // for this vector shape (hr_rtc.hip), instead of the adaptive kernel's scattered DIRECT-mode stores
+    void *lean = nullptr;
+    if (all4 && grouped && rows > 0 && start >= lean_min_groups() && (a.width == 4 || a.width == 8) && rtc_scan_available())
+      lean = rtc_vector_scan_lookup(device, L.numDims, a.width, partBits);
+    const int streams = (all4 && rows > 0) ? (lean ? rtc_scan_grid(rows) : grid_for(rows)) : 0;
+    const int rwB = (a.width == 8 || lean) ? 4 : 3;
     Regions r;
-    make_regions(r, partBits, rows, rows, streams, rwB, stream);
+    make_regions(r, partBits, rows, rows, streams, rwB, stream, lean != nullptr);
     Workspace &ws = r.ws;
+    if (lean && a.width == 8) ws.widen.mode = 2;  // line records carry the whole 8-byte value
     ws.prevRanges = grouped ? prev.ranges : nullptr;
     ws.outRanges = outRanges;
     if (outRanges) hip_check(hipMemsetAsync(outRanges, 0, kRangesBytes, stream), "hipMemsetAsync");
-    if (all4) {
+    if (lean) {
+      rtc_vector_scan_launch(lean, inputKeys.DimValues, capacity, inputValues, L.numDims, a.width, static_cast<uint32_t>(start), rows,
+                             ws, stream);
+    } else if (all4) {
       if (rows > 0) {
 #define ARES_HR_CASE(ND)                                                                                             \
   case ND:                                                                                                           \
@@ -308,7 +317,7 @@ int hash_reduce_lds(int device, const DimensionVector &inputKeys, const uint8_t 
   ARES_LAUNCH("hr_merge_kernel", (hr_merge_kernel<ND, RWB>), numParts, kThreads, stream, inputKeys.DimValues, inputValues, \
               outputKeys.DimValues, L, capacity, outputValues, a, ws, static_cast<uint32_t>(start))
 #define ARES_HR_MERGE_ND(ND)                       \
-  if (a.width == 8) ARES_HR_MERGE(ND, 4);          \
+  if (rwB == 4) ARES_HR_MERGE(ND, 4);              \
   else ARES_HR_MERGE(ND, 3);
     switch (all4 ? L.numDims : 0) {
       case 1: ARES_HR_MERGE_ND(1) break;
@@ -320,7 +329,8 @@ int hash_reduce_lds(int device, const DimensionVector &inputKeys, const uint8_t 
 #undef ARES_HR_MERGE_ND
 #undef ARES_HR_MERGE
     res = read_result(ws, stream);
-    if (getenv("ARES_HR_TRACE"))
+    static const bool trace = getenv("ARES_HR_TRACE") != nullptr;  // diagnostics
+    if (trace)
       fprintf(stderr, "hash_reduce_lds: length %d start %d rows %d streams %d capA %llu capB %u partBits %d -> groups %u overflow %u stale %u\n",
               length, start, rows, streams, static_cast<unsigned long long>(ws.capA), ws.capB, partBits, res.groups, res.overflow, res.stale);
     if (grouped && res.stale) {  // the input vectors are not what the previous merge wrote: the long way

@@ -885,7 +885,8 @@ __device__ __forceinline__ void merge_body(const uint8_t *__restrict__ dimIn, si
             if constexpr (RWB == 4) {
               if (ws.lineRecords) {
                 if (s.w[k][0] == 0xFFFFFFFFu) continue;  // padding of a stream's last line
-                v = widen_value(ws.widen, s.w[k][2]);
+                v = ws.widen.mode == 2 ? (static_cast<uint64_t>(s.w[k][3]) << 32) | s.w[k][2]  // the whole value travels
+                                       : widen_value(ws.widen, s.w[k][2]);
               } else {
                 v = (static_cast<uint64_t>(s.w[k][3]) << 32) | s.w[k][2];
               }

@@ -182,88 +182,9 @@ struct RtcArgs {  // mirrors `struct Args` of the generated source (pointers fir
   uint32_t pad;
 };
 
-// the whole kernel source for `plan`; empty when the plan is outside the supported shapes
-std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t nullMask) {
-  if (nd < 1 || nd > kFusedDims || plan.numCols > kFusedCols) return "";
-  std::ostringstream o;
-  const int nc = plan.numCols;
-  o << "typedef unsigned int u32; typedef unsigned long long u64; typedef unsigned char u8; typedef unsigned short u16; typedef int i32;\n"
-       "struct __attribute__((packed, aligned(1))) PU32x4 { u32 v[4]; };\n"
-       "struct __attribute__((packed, aligned(1))) PU16 { u16 v; };\n"
-       "struct __attribute__((packed, aligned(4))) Rec3 { u32 row, hash, val; };\n"
-       "struct Args { const u32 *vals[" << kFusedCols << "]; const u8 *nulls[" << kFusedCols << "]; u32 *recB; u32 *countsB; u32 *overflow; u64 *phases;\n"
-       "              u32 bitOff[" << kFusedCols << "]; u32 rowBase; int length; u32 capB; u32 pad; };\n"
-       "#define NC " << nc << "\n#define ND " << nd << "\n#define PB " << partBits << "\n#define NP " << (1 << partBits) << "\n"
-       "__device__ __forceinline__ u32 rotl(u32 x, int r) { return (x << r) | (x >> (32 - r)); }\n"
-       "__device__ __forceinline__ u32 mix(u32 h, u32 k) { k *= 0xcc9e2d51u; k = rotl(k, 15) * 0x1b873593u; h ^= k; return rotl(h, 13) * 5u + 0xe6546b64u; }\n"
-       "struct Raw { u32 v[NC][4]; u32 win[NC]; };\n";
-  // ---- loads of a full quad (all four rows exist) ----
-  o << "__device__ __forceinline__ void load_full(Raw &r, const Args &a, u32 i0) {\n";
-  for (int c = 0; c < nc; c++) {
-    o << "  { const PU32x4 t = *reinterpret_cast<const PU32x4 *>(a.vals[" << c << "] + i0); r.v[" << c << "][0] = t.v[0]; r.v[" << c
-      << "][1] = t.v[1]; r.v[" << c << "][2] = t.v[2]; r.v[" << c << "][3] = t.v[3]; }\n";
-    if (nullMask & (1u << c))
-      o << "  r.win[" << c << "] = reinterpret_cast<const PU16 *>(a.nulls[" << c << "] + ((i0 + a.bitOff[" << c << "]) >> 3))->v;\n";
-    else
-      o << "  r.win[" << c << "] = 0xFFFFu;\n";
-  }
-  o << "}\n";
-  // ---- guarded loads of the shard's last, partial tile ----
-  o << "__device__ __forceinline__ void load_tail(Raw &r, const Args &a, u32 i0) {\n";
-  for (int c = 0; c < nc; c++) {
-    o << "  for (int j = 0; j < 4; j++) r.v[" << c << "][j] = (int)(i0 + j) < a.length ? a.vals[" << c << "][i0 + j] : 0u;\n";
-    if (nullMask & (1u << c))
-      o << "  r.win[" << c << "] = (int)i0 < a.length ? (u32)reinterpret_cast<const PU16 *>(a.nulls[" << c << "] + ((i0 + a.bitOff[" << c
-        << "]) >> 3))->v : 0u;\n";
-    else
-      o << "  r.win[" << c << "] = 0xFFFFu;\n";
-  }
-  o << "}\n";
-  // ---- evaluate + hash one quad: hash, carried measure bits and "takes part" of its four rows ----
-  o << "__device__ __forceinline__ void eval4(const Raw &r, const Args &a, u32 i0, u32 (&hh)[4], u32 (&cv)[4], u32 (&alive)[4]) {\n"
-       "  u32 okc[NC];\n";
-  for (int c = 0; c < nc; c++) {
-    if (nullMask & (1u << c)) o << "  okc[" << c << "] = (r.win[" << c << "] >> ((i0 + a.bitOff[" << c << "]) & 7u)) & 0xFu;\n";
-    else o << "  okc[" << c << "] = 0xFu;\n";
-  }
-  o << "#pragma unroll\n"
-       "  for (int j = 0; j < 4; j++) {\n"
-       "    u32 keep = (int)(i0 + j) < a.length ? 1u : 0u;\n";
-  for (int k = 0; k < plan.numFilters; k++) {
-    const FusedExpr &e = plan.filters[k];
-    o << "    {\n      const u32 v = r.v[" << e.col << "][j]; const u32 okb = (okc[" << e.col << "] >> j) & 1u;\n";
-    if (!gen_compare(e.f, o, "v", "okb", "keep")) return "";
-    o << "    }\n";
-  }
-  o << "    alive[j] = keep;\n    u32 h = 0u, okbytes = 0u;\n";
-  for (int d = 0; d < nd; d++) {
-    const FusedExpr &e = plan.dims[d];
-    if (e.col != d || !plain_store(e.f.rk, e.outKind)) return "";
-    o << "    {\n      const u32 v = r.v[" << d << "][j]; const u32 okb = (okc[" << d << "] >> j) & 1u; u32 x;\n";
-    if (!gen_value(e.f, o, "v", "okb", "x")) return "";
-    o << "      h = mix(h, x); okbytes |= okb << " << 8 * d << ";\n    }\n";
-  }
-  // Murmur32Stream (dim_layout.hpp): the validity bytes are one more block when there are four of them,
-  // otherwise the tail
-  if (nd == 4) o << "    h = mix(h, okbytes);\n";
-  else o << "    { u32 k = okbytes * 0xcc9e2d51u; k = rotl(k, 15) * 0x1b873593u; h ^= k; }\n";
-  o << "    h ^= " << 5 * nd << "u; h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;\n"
-       "    hh[j] = h;\n";
-  {  // measure: fused_carry
-    const FusedExpr &e = plan.measure;
-    if (e.col != nd) return "";
-    o << "    {\n      const u32 v = r.v[" << nd << "][j]; const u32 okb = (okc[" << nd << "] >> j) & 1u; u32 x;\n";
-    if (!gen_value(e.f, o, "v", "okb", "x")) return "";
-    if (plan.measureWidth == 8) {
-      if (plan.identity != 0) return "";
-      o << "      cv[j] = okb ? x : 0u;\n";
-    } else {
-      const int target = plan.measureDtype == Int32 ? K_I32 : plan.measureDtype == Uint32 ? K_U32 : K_F32;
-      if (!plain_store(e.f.rk, target)) return "";
-      o << "      cv[j] = okb ? x : " << hex(static_cast<uint32_t>(plan.identity)) << ";\n";
-    }
-    o << "    }\n  }\n}\n";
-  }
+// The kernel proper, shared by the plan-sourced and the vector-sourced scan: `Raw`, `load_full`, `load_tail`
+// and `eval4(R, a, i0, hh, cv, cw, alive)` are already in `o`; `fourth` is the record's fourth word.
+static void kernel_body(std::ostringstream &o, const char *fourth) {
   // ---- the kernel.  One 1024-lane workgroup per CU walks 4096-row tiles.  The write path is what
   // bounds the memory side of this kernel (tools/ubench_scatter.hip): a CU retires one scattered small
   // store per ~4.5 cycles, and HBM write time follows the number of 64-byte write requests — whole
@@ -303,8 +224,8 @@ std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t null
        "  else if (tile < numTiles) load_tail(R, a, tile * T + tid * 4u);\n"
        "  while (tile < numTiles) {\n"
        "    const u32 i0 = tile * T + tid * 4u;\n"
-       "    u32 hh[4], cv[4], alive[4], rank[4];\n"
-       "    eval4(R, a, i0, hh, cv, alive);\n"
+       "    u32 hh[4], cv[4], cw[4], alive[4], rank[4];\n"
+       "    eval4(R, a, i0, hh, cv, cw, alive);\n"
        "    const u32 next = tile + gridDim.x;\n"
        "    if (next < fullTiles) load_full(R, a, next * T + tid * 4u);\n"  // in flight during the sort below
        "    else if (next < numTiles) load_tail(R, a, next * T + tid * 4u);\n"
@@ -340,7 +261,7 @@ std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t null
        "    PH(1)\n"
        "#pragma unroll\n"
        "    for (int j = 0; j < 4; j++)\n"
-       "      if (alive[j]) sRec[sStart[PB ? hh[j] >> (32 - (PB ? PB : 1)) : 0u] + rank[j]] = make_uint4(a.rowBase + i0 + j, hh[j], cv[j], 0u);\n"
+       "      if (alive[j]) sRec[sStart[PB ? hh[j] >> (32 - (PB ? PB : 1)) : 0u] + rank[j]] = make_uint4(a.rowBase + i0 + j, hh[j], cv[j], " << fourth << ");\n"
        "    __syncthreads();\n"
        "    PH(2)\n"
        // whole lines: 8 adjacent lanes write the 8 records of one aligned 128-byte line with one store;
@@ -402,6 +323,157 @@ std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t null
        "  PH(6)\n"
        "  PH_OUT\n"
        "}\n";
+}
+
+// the whole kernel source for `plan`; empty when the plan is outside the supported shapes
+std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t nullMask) {
+  if (nd < 1 || nd > kFusedDims || plan.numCols > kFusedCols) return "";
+  std::ostringstream o;
+  const int nc = plan.numCols;
+  o << "typedef unsigned int u32; typedef unsigned long long u64; typedef unsigned char u8; typedef unsigned short u16; typedef int i32;\n"
+       "struct __attribute__((packed, aligned(1))) PU32x4 { u32 v[4]; };\n"
+       "struct __attribute__((packed, aligned(1))) PU16 { u16 v; };\n"
+       "struct __attribute__((packed, aligned(4))) Rec3 { u32 row, hash, val; };\n"
+       "struct Args { const u32 *vals[" << kFusedCols << "]; const u8 *nulls[" << kFusedCols << "]; u32 *recB; u32 *countsB; u32 *overflow; u64 *phases;\n"
+       "              u32 bitOff[" << kFusedCols << "]; u32 rowBase; int length; u32 capB; u32 pad; };\n"
+       "#define NC " << nc << "\n#define ND " << nd << "\n#define PB " << partBits << "\n#define NP " << (1 << partBits) << "\n"
+       "__device__ __forceinline__ u32 rotl(u32 x, int r) { return (x << r) | (x >> (32 - r)); }\n"
+       "__device__ __forceinline__ u32 mix(u32 h, u32 k) { k *= 0xcc9e2d51u; k = rotl(k, 15) * 0x1b873593u; h ^= k; return rotl(h, 13) * 5u + 0xe6546b64u; }\n"
+       "struct Raw { u32 v[NC][4]; u32 win[NC]; };\n";
+  // ---- loads of a full quad (all four rows exist) ----
+  o << "__device__ __forceinline__ void load_full(Raw &r, const Args &a, u32 i0) {\n";
+  for (int c = 0; c < nc; c++) {
+    o << "  { const PU32x4 t = *reinterpret_cast<const PU32x4 *>(a.vals[" << c << "] + i0); r.v[" << c << "][0] = t.v[0]; r.v[" << c
+      << "][1] = t.v[1]; r.v[" << c << "][2] = t.v[2]; r.v[" << c << "][3] = t.v[3]; }\n";
+    if (nullMask & (1u << c))
+      o << "  r.win[" << c << "] = reinterpret_cast<const PU16 *>(a.nulls[" << c << "] + ((i0 + a.bitOff[" << c << "]) >> 3))->v;\n";
+    else
+      o << "  r.win[" << c << "] = 0xFFFFu;\n";
+  }
+  o << "}\n";
+  // ---- guarded loads of the shard's last, partial tile ----
+  o << "__device__ __forceinline__ void load_tail(Raw &r, const Args &a, u32 i0) {\n";
+  for (int c = 0; c < nc; c++) {
+    o << "  for (int j = 0; j < 4; j++) r.v[" << c << "][j] = (int)(i0 + j) < a.length ? a.vals[" << c << "][i0 + j] : 0u;\n";
+    if (nullMask & (1u << c))
+      o << "  r.win[" << c << "] = (int)i0 < a.length ? (u32)reinterpret_cast<const PU16 *>(a.nulls[" << c << "] + ((i0 + a.bitOff[" << c
+        << "]) >> 3))->v : 0u;\n";
+    else
+      o << "  r.win[" << c << "] = 0xFFFFu;\n";
+  }
+  o << "}\n";
+  // ---- evaluate + hash one quad: hash, carried measure bits and "takes part" of its four rows ----
+  o << "__device__ __forceinline__ void eval4(const Raw &r, const Args &a, u32 i0, u32 (&hh)[4], u32 (&cv)[4], u32 (&cw)[4], u32 (&alive)[4]) {\n"
+       "  u32 okc[NC];\n"
+       "  cw[0] = cw[1] = cw[2] = cw[3] = 0u;\n";
+  for (int c = 0; c < nc; c++) {
+    if (nullMask & (1u << c)) o << "  okc[" << c << "] = (r.win[" << c << "] >> ((i0 + a.bitOff[" << c << "]) & 7u)) & 0xFu;\n";
+    else o << "  okc[" << c << "] = 0xFu;\n";
+  }
+  o << "#pragma unroll\n"
+       "  for (int j = 0; j < 4; j++) {\n"
+       "    u32 keep = (int)(i0 + j) < a.length ? 1u : 0u;\n";
+  for (int k = 0; k < plan.numFilters; k++) {
+    const FusedExpr &e = plan.filters[k];
+    o << "    {\n      const u32 v = r.v[" << e.col << "][j]; const u32 okb = (okc[" << e.col << "] >> j) & 1u;\n";
+    if (!gen_compare(e.f, o, "v", "okb", "keep")) return "";
+    o << "    }\n";
+  }
+  o << "    alive[j] = keep;\n    u32 h = 0u, okbytes = 0u;\n";
+  for (int d = 0; d < nd; d++) {
+    const FusedExpr &e = plan.dims[d];
+    if (e.col != d || !plain_store(e.f.rk, e.outKind)) return "";
+    o << "    {\n      const u32 v = r.v[" << d << "][j]; const u32 okb = (okc[" << d << "] >> j) & 1u; u32 x;\n";
+    if (!gen_value(e.f, o, "v", "okb", "x")) return "";
+    o << "      h = mix(h, x); okbytes |= okb << " << 8 * d << ";\n    }\n";
+  }
+  // Murmur32Stream (dim_layout.hpp): the validity bytes are one more block when there are four of them,
+  // otherwise the tail
+  if (nd == 4) o << "    h = mix(h, okbytes);\n";
+  else o << "    { u32 k = okbytes * 0xcc9e2d51u; k = rotl(k, 15) * 0x1b873593u; h ^= k; }\n";
+  o << "    h ^= " << 5 * nd << "u; h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;\n"
+       "    hh[j] = h;\n";
+  {  // measure: fused_carry
+    const FusedExpr &e = plan.measure;
+    if (e.col != nd) return "";
+    o << "    {\n      const u32 v = r.v[" << nd << "][j]; const u32 okb = (okc[" << nd << "] >> j) & 1u; u32 x;\n";
+    if (!gen_value(e.f, o, "v", "okb", "x")) return "";
+    if (plan.measureWidth == 8) {
+      if (plan.identity != 0) return "";
+      o << "      cv[j] = okb ? x : 0u;\n";
+    } else {
+      const int target = plan.measureDtype == Int32 ? K_I32 : plan.measureDtype == Uint32 ? K_U32 : K_F32;
+      if (!plain_store(e.f.rk, target)) return "";
+      o << "      cv[j] = okb ? x : " << hex(static_cast<uint32_t>(plan.identity)) << ";\n";
+    }
+    o << "    }\n  }\n}\n";
+  }
+  kernel_body(o, "0u");
+  return o.str();
+}
+
+// The same kernel over rows [rowBase, rowBase + length) of a dimension vector of `nd` 4-byte dimensions
+// (values per dimension, then one validity byte per row and dimension) and a measure vector of `vw`-byte
+// values — what HashReduce is handed when the batch's transforms were launched (ARES_FUSE=0, plans the
+// fused scan does not cover).  Args: vals[d] / nulls[d] = dimension d's values / validity bytes at
+// rowBase, vals[nd] = the measures at rowBase.  Records carry the whole value: {row, hash, lo, hi}.
+std::string generate_vector(int nd, int vw, int partBits) {
+  if (nd < 1 || nd > kFusedDims || (vw != 4 && vw != 8)) return "";
+  std::ostringstream o;
+  const int mq = vw / 4;
+  o << "typedef unsigned int u32; typedef unsigned long long u64; typedef unsigned char u8; typedef unsigned short u16; typedef int i32;\n"
+       "struct __attribute__((packed, aligned(1))) PU32x4 { u32 v[4]; };\n"
+       "struct __attribute__((packed, aligned(1))) PU32 { u32 v; };\n"
+       "struct Args { const u32 *vals[" << kFusedCols << "]; const u8 *nulls[" << kFusedCols << "]; u32 *recB; u32 *countsB; u32 *overflow; u64 *phases;\n"
+       "              u32 bitOff[" << kFusedCols << "]; u32 rowBase; int length; u32 capB; u32 pad; };\n"
+       "#define ND " << nd << "\n#define MQ " << mq << "\n#define PB " << partBits << "\n#define NP " << (1 << partBits) << "\n"
+       "__device__ __forceinline__ u32 rotl(u32 x, int r) { return (x << r) | (x >> (32 - r)); }\n"
+       "__device__ __forceinline__ u32 mix(u32 h, u32 k) { k *= 0xcc9e2d51u; k = rotl(k, 15) * 0x1b873593u; h ^= k; return rotl(h, 13) * 5u + 0xe6546b64u; }\n"
+       "struct Raw { u32 v[ND][4]; u32 ok[ND]; u32 m[MQ * 4]; };\n"
+       "__device__ __forceinline__ void load_full(Raw &r, const Args &a, u32 i0) {\n"
+       "#pragma unroll\n"
+       "  for (int d = 0; d < ND; d++) {\n"
+       "    const PU32x4 t = *reinterpret_cast<const PU32x4 *>(a.vals[d] + i0);\n"
+       "    r.v[d][0] = t.v[0]; r.v[d][1] = t.v[1]; r.v[d][2] = t.v[2]; r.v[d][3] = t.v[3];\n"
+       "    r.ok[d] = reinterpret_cast<const PU32 *>(a.nulls[d] + i0)->v;\n"
+       "  }\n"
+       "#pragma unroll\n"
+       "  for (int q = 0; q < MQ; q++) {\n"
+       "    const PU32x4 t = *reinterpret_cast<const PU32x4 *>(a.vals[ND] + (u64)i0 * MQ + 4 * q);\n"
+       "    r.m[4 * q] = t.v[0]; r.m[4 * q + 1] = t.v[1]; r.m[4 * q + 2] = t.v[2]; r.m[4 * q + 3] = t.v[3];\n"
+       "  }\n"
+       "}\n"
+       "__device__ __forceinline__ void load_tail(Raw &r, const Args &a, u32 i0) {\n"
+       "#pragma unroll\n"
+       "  for (int d = 0; d < ND; d++) {\n"
+       "    r.ok[d] = 0u;\n"
+       "    for (int j = 0; j < 4; j++) {\n"
+       "      const bool in = (int)(i0 + j) < a.length;\n"
+       "      r.v[d][j] = in ? a.vals[d][i0 + j] : 0u;\n"
+       "      r.ok[d] |= in ? (u32)a.nulls[d][i0 + j] << (8 * j) : 0u;\n"
+       "    }\n"
+       "  }\n"
+       "  for (int j = 0; j < 4; j++)\n"
+       "    for (int q = 0; q < MQ; q++) r.m[j * MQ + q] = (int)(i0 + j) < a.length ? a.vals[ND][(u64)(i0 + j) * MQ + q] : 0u;\n"
+       "}\n"
+       // Murmur32Stream over the packed row (dim_layout.hpp): values, then the validity bytes — one more block
+       // when there are four of them, otherwise the tail
+       "__device__ __forceinline__ void eval4(const Raw &r, const Args &a, u32 i0, u32 (&hh)[4], u32 (&cv)[4], u32 (&cw)[4], u32 (&alive)[4]) {\n"
+       "#pragma unroll\n"
+       "  for (int j = 0; j < 4; j++) {\n"
+       "    alive[j] = (int)(i0 + j) < a.length ? 1u : 0u;\n"
+       "    u32 h = 0u, okbytes = 0u;\n"
+       "#pragma unroll\n"
+       "    for (int d = 0; d < ND; d++) { h = mix(h, r.v[d][j]); okbytes |= ((r.ok[d] >> (8 * j)) & 0xFFu) << (8 * d); }\n";
+  if (nd == 4) o << "    h = mix(h, okbytes);\n";
+  else o << "    { u32 k = okbytes * 0xcc9e2d51u; k = rotl(k, 15) * 0x1b873593u; h ^= k; }\n";
+  o << "    h ^= " << 5 * nd << "u; h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;\n"
+       "    hh[j] = h;\n"
+       "    cv[j] = r.m[j * MQ];\n"
+       "    cw[j] = MQ == 2 ? r.m[j * MQ + MQ - 1] : 0u;\n"
+       "  }\n"
+       "}\n";
+  kernel_body(o, "cw[j]");
   return o.str();
 }
 
@@ -851,6 +923,29 @@ void rtc_scan_launch(void *kernel, const FusedPlanD &plan, uint32_t rowBase, int
     }
   }
 }
+
+void *rtc_vector_scan_lookup(int device, int nd, int vw, int partBits) {
+  if (!rtc_api().ok) return nullptr;
+  const std::string source = generate_vector(nd, vw, partBits);
+  if (source.empty()) return nullptr;
+  return compiled_kernel(device, source, "hr_scan_rtc");
+}
+
+void rtc_vector_scan_launch(void *kernel, const uint8_t *dimValues, size_t capacity, const uint8_t *values, int nd, int vw,
+                            uint32_t rowBase, int length, const hr::Workspace &ws, hipStream_t stream) {
+  FusedPlanD plan;
+  memset(&plan, 0, sizeof(plan));
+  plan.numCols = nd + 1;
+  for (int d = 0; d < nd; d++) {
+    plan.cols[d].vals = reinterpret_cast<const uint32_t *>(dimValues + 4ull * d * capacity) + rowBase;
+    plan.cols[d].nulls = dimValues + 4ull * nd * capacity + static_cast<size_t>(d) * capacity + rowBase;
+  }
+  plan.cols[nd].vals = reinterpret_cast<const uint32_t *>(values + static_cast<size_t>(vw) * rowBase);
+  rtc_scan_launch(kernel, plan, rowBase, length, ws, stream);
+}
+
+std::string rtc_vector_scan_source(int nd, int vw, int partBits) { return generate_vector(nd, vw, partBits); }
+
 
 
 void *rtc_merge_lookup(int device, const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w) {

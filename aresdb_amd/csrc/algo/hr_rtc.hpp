@@ -27,6 +27,12 @@ void *rtc_scan_lookup(int device, const FusedPlanD &plan, int nd, int partBits);
 // (ws.streams workgroups; 16-byte records in whole 128-byte lines, ws.capB a multiple of 8).
 void rtc_scan_launch(void *kernel, const FusedPlanD &plan, uint32_t rowBase, int length, const hr::Workspace &ws,
                      hipStream_t stream);
+// The same scan over rows [rowBase, rowBase + length) of a dimension vector of `nd` 4-byte dimensions and a
+// measure vector of `vw`-byte values (HashReduce on materialised vectors); records carry the whole value.
+void *rtc_vector_scan_lookup(int device, int nd, int vw, int partBits);
+void rtc_vector_scan_launch(void *kernel, const uint8_t *dimValues, size_t capacity, const uint8_t *values, int nd, int vw,
+                            uint32_t rowBase, int length, const hr::Workspace &ws, hipStream_t stream);
+std::string rtc_vector_scan_source(int nd, int vw, int partBits);
 // The specialised merge for what that scan produces (line records in region B, previous groups in their
 // partition-grouped ranges or none, one round over the whole hash range).  It raises outCount[3] when a
 // partition holds more groups than one LDS table: the caller then runs the generic merge.

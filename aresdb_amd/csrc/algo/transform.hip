@@ -1148,6 +1148,7 @@ struct FilterJournal {
 // launchable (their inputs are held by libmem.so) until the stream starts its next batch or the
 // outputs are freed; a copy that touches an output launches them first.
 void (*g_releaseHeld)(int, uintptr_t) = nullptr;  // AresMemReleaseHeld of the sibling libmem.so
+bool g_fuseEnabled = true;
 // Blocks are held on behalf of ONE stream's pending work: the tag names that stream, so that one
 // query's progress never releases what another query's not-yet-launched kernels still read.
 uintptr_t hold_tag(hipStream_t stream) { return reinterpret_cast<uintptr_t>(stream) + 1; }
@@ -1212,7 +1213,8 @@ bool defer_available() {
     const char *fuse = getenv("ARES_FUSE");
     auto setHooks = reinterpret_cast<void (*)(const AresDeferralHooks *)>(dlsym(h, "AresMemSetDeferralHooks"));
     auto release = reinterpret_cast<void (*)(int, uintptr_t)>(dlsym(h, "AresMemReleaseHeld"));
-    if (setHooks && release && !(fuse && fuse[0] == '0')) {
+    g_fuseEnabled = !(fuse && fuse[0] == '0');
+    if (setHooks && release) {  // the hooks also tell HashReduce whether its previous results are untouched
       static const AresDeferralHooks hooks = {&AresFlushDeferred, &hook_on_wait, &hook_on_free, &hook_on_access};
       g_releaseHeld = release;
       setHooks(&hooks);
@@ -1227,9 +1229,11 @@ bool defer_available() {
   }();
   return ok;
 }
-bool fuse_available() { return defer_available() && g_releaseHeld != nullptr; }
+// second-stage fusion (HashReduce consumes pending transforms, lazy compaction): ARES_FUSE=0 switches it
+// off; the hooks stay in place
+bool fuse_available() { return defer_available() && g_releaseHeld != nullptr && g_fuseEnabled; }
 }  // namespace
-bool deferral_hooks_active() { return fuse_available(); }
+bool deferral_hooks_active() { return defer_available() && g_releaseHeld != nullptr; }
 namespace {
 
 // The error word of a lazily launched compaction (a bounded wait inside filter_compact_kernel timed
@@ -1922,8 +1926,8 @@ void hook_on_wait(int device, void *streamPtr) {
     for (auto &kv : t_state->pending) {
       if (kv.first.first != device || kv.first.second != stream || kv.second.jobs.count == 0 || kv.second.overWait) continue;
       PendingQueue &q = kv.second;
-      bool keep = true;
-      if (q.idx) {  // the survivors must be re-derivable from the filter journal
+      bool keep = g_fuseEnabled;  // nobody will consume the queue otherwise
+      if (keep && q.idx) {  // the survivors must be re-derivable from the filter journal
         auto j = t_state->journals.find(q.idx);
         keep = j != t_state->journals.end() && j->second.valid && j->second.device == device && j->second.stream == stream &&
                j->second.start == 0;
@@ -2123,7 +2127,7 @@ bool fuse_pending_into_hash_reduce(int device, hipStream_t stream, const Dimensi
                                    const DimensionVector &out, uint8_t *outValues, int valueBytes, int length, int aggFunc,
                                    int *groups) {
   if (!fuse_available()) return false;
-  const char *forced = getenv("ARES_HASH_REDUCE");
+  static const char *const forced = getenv("ARES_HASH_REDUCE");
   PendingQueue q;
   FusedPlanD plan;
   memset(&plan, 0, sizeof(plan));

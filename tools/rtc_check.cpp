@@ -69,5 +69,24 @@ int main(int argc, char **argv) {
   std::vector<char> mcode(cs); hiprtcGetCode(mp, mcode.data());
   std::ofstream(prefix + "_merge.co", std::ios::binary).write(mcode.data(), static_cast<std::streamsize>(cs));
   printf("merge code object %zu bytes\n", cs);
+  // the vector-sourced scan (HashReduce on materialised dimension / measure vectors)
+  for (int vw = 4; vw <= 8; vw += 4)
+    for (int nd = 1; nd <= 4; nd += 3) {
+      const std::string vsrc = rtc_vector_scan_source(nd, vw, 9);
+      if (vsrc.empty()) { puts("vector scan: unsupported"); return 8; }
+      if (nd == 4 && vw == 8) std::ofstream(prefix + "_vector.hip") << vsrc;
+      hiprtcProgram vp;
+      if (hiprtcCreateProgram(&vp, vsrc.c_str(), "hr_vscan_rtc.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return 9;
+      const hiprtcResult vrc = hiprtcCompileProgram(vp, 4, opts);
+      n = 0; hiprtcGetProgramLogSize(vp, &n);
+      std::string vlog(n, 0); if (n) hiprtcGetProgramLog(vp, &vlog[0]);
+      printf("vector scan nd %d vw %d compile rc %d\n%s\n", nd, vw, static_cast<int>(vrc), vlog.c_str());
+      if (vrc != HIPRTC_SUCCESS) return 10;
+      if (nd == 4 && vw == 8) {
+        hiprtcGetCodeSize(vp, &cs);
+        std::vector<char> vcode(cs); hiprtcGetCode(vp, vcode.data());
+        std::ofstream(prefix + "_vector.co", std::ios::binary).write(vcode.data(), static_cast<std::streamsize>(cs));
+      }
+    }
   return 0;
 }

@@ -406,11 +406,12 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
     ws.widen.dtype = plan.measureDtype;
     ws.prevRanges = grouped ? prev.ranges : nullptr;
     ws.outRanges = outRanges;
-    if (outRanges) hip_check(hipMemsetAsync(outRanges, 0, kRangesBytes, stream), "hipMemsetAsync");
     Workspace wsPrev = ws;  // previous groups that are not grouped by partition: TABLE-mode pass into region A
     wsPrev.streams = 0;
     // the specialised merge reads region B and grouped previous results only
     void *leanMerge = (lean && (prevSize == 0 || grouped)) ? rtc_merge_lookup(device, plan, nd, partBits, a, ws.widen) : nullptr;
+    // (the specialised merge writes every partition's range entry itself)
+    if (outRanges && !leanMerge) hip_check(hipMemsetAsync(outRanges, 0, kRangesBytes, stream), "hipMemsetAsync");
 #define ARES_FUSED_CASE(ND)                                                                                            \
   case ND:                                                                                                             \
     if (prevSize > 0 && !grouped) {                                                                                    \

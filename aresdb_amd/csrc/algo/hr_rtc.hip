@@ -515,7 +515,12 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
        "  u64 prevCapacity, outCapacity; u32 bitOff[" << kFusedCols << "]; u32 capB, streams, prevSize, pad; u64 *phases; };\n"
        "#define ND " << nd << "\n#define PB " << partBits << "\n#define NP " << (1 << partBits) << "\n"
        "#define SLOTS " << hr::kSlots << "\n#define LIMIT " << hr::kMergeLimit << "u\n#define RANGEWORDS " << hr::kRangeWords
-    << "\n#define MAXRANGES " << hr::kMaxRanges << "u\n#define EMPTY 0xFFFFFFFFFFFFFFFFull\n"
+    << "\n#define MAXRANGES " << hr::kMaxRanges << "u\n"
+       // An empty slot holds a key no record of this partition can have: its hash field carries the
+       // NEIGHBOUR partition's number in the partition bits (PB > 0), so "hash field == h" alone identifies a
+       // hit — no separate "slot is not empty" test in the straight-line path.
+       "#if PB > 0\n#define EMPTY ((((u64)((blockIdx.x ^ 1u) << (32 - PB))) << 32) | 0xFFFFFFFFull)\n#define OCC(k) true\n"
+       "#else\n#define EMPTY 0xFFFFFFFFFFFFFFFFull\n#define OCC(k) ((k) != EMPTY)\n#endif\n"
        "__device__ __forceinline__ u32 rotl(u32 x, int r) { return (x << r) | (x >> (32 - r)); }\n"
        "__device__ __forceinline__ u32 mix(u32 h, u32 k) { k *= 0xcc9e2d51u; k = rotl(k, 15) * 0x1b873593u; h ^= k; return rotl(h, 13) * 5u + 0xe6546b64u; }\n";
   // value of a carried measure (hr::widen_value)
@@ -622,8 +627,8 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
        "    const bool valid = lane < s.n[k] && s.r[k].x != 0xFFFFFFFFu;\n"  // not past the segment / padding of the run's last line
        "    const u32 h = s.r[k].y, b = h & (BUCKETS - 1u);\n"
        "    const U64x2 lo = *reinterpret_cast<const U64x2 *>(sKeys + 4u * b), hi = *reinterpret_cast<const U64x2 *>(sKeys + 4u * b + 2u);\n"
-       "    const bool m0 = (u32)(lo.x >> 32) == h && lo.x != EMPTY, m1 = (u32)(lo.y >> 32) == h && lo.y != EMPTY;\n"
-       "    const bool m2 = (u32)(hi.x >> 32) == h && hi.x != EMPTY, m3 = (u32)(hi.y >> 32) == h && hi.y != EMPTY;\n"
+       "    const bool m0 = (u32)(lo.x >> 32) == h && OCC(lo.x), m1 = (u32)(lo.y >> 32) == h && OCC(lo.y);\n"
+       "    const bool m2 = (u32)(hi.x >> 32) == h && OCC(hi.x), m3 = (u32)(hi.y >> 32) == h && OCC(hi.y);\n"
        "    const bool hit = valid && (m0 || m1 || m2 || m3);\n"
        "    if (hit) {\n"
        "      const u32 mi = m0 ? 0u : m1 ? 1u : m2 ? 2u : 3u;\n"

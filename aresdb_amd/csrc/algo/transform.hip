@@ -1772,9 +1772,7 @@ static int run_filter(const InputVector *ins, int arity, uint32_t *indexVector, 
     uint32_t *total = w, *error = w + 1;
     unsigned int *tickets = w + 2;
     uint32_t *tileCounts = w + 16, *tileOffsets = tileCounts + tiles, *loaded = tileOffsets + tiles + 1;
-    hip_check(hipMemsetAsync(w, 0, head, stream), "hipMemsetAsync");
-    hip_check(hipMemsetAsync(tileCounts, 0, 4 * static_cast<size_t>(tiles), stream), "hipMemsetAsync");
-    hip_check(hipMemsetAsync(loaded, 0, 4 * static_cast<size_t>(tiles) * passes, stream), "hipMemsetAsync");
+    hip_check(hipMemsetAsync(w, 0, head + 4 * words, stream), "hipMemsetAsync");  // one fill: head, counts, flags
     if (virtualIdx) f.idx = nullptr;  // rows = position
     ARES_LAUNCH("filter_pred_kernel", filter_pred_kernel, capped_grid(tiles, 256 * 16), kBlock, stream, f, pred, tileCounts, n, tiles);
     ARES_LAUNCH("filter_scan_kernel", filter_scan_kernel, 1, 1024, stream, tileCounts, tileOffsets, tiles, total);

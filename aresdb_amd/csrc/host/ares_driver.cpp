@@ -852,6 +852,11 @@ struct AresComm {
   // RCCL binding (AresCommCreateRccl)
   void *rcclHandle = nullptr, *rcclComm = nullptr;
   int (*ncclAllGather)(const void *, void *, size_t, int, void *, void *) = nullptr;
+  int (*ncclSend)(const void *, size_t, int, int, void *, void *) = nullptr;
+  int (*ncclRecv)(void *, size_t, int, int, void *, void *) = nullptr;
+  int (*ncclGroupStart)() = nullptr;
+  int (*ncclGroupEnd)() = nullptr;
+  AresAllToAllFn allToAll = nullptr;  // optional: without it blocks travel by padded all-gathers
   int (*ncclCommDestroy)(void *) = nullptr;
   const char *(*ncclGetErrorString)(int) = nullptr;
 };
@@ -862,6 +867,19 @@ struct NcclUniqueId { char internal[128]; };
 int rccl_all_gather(void *user, const void *send, void *recv, size_t bytesPerRank, void *stream) {
   AresComm *c = static_cast<AresComm *>(user);
   return c->ncclAllGather(send, recv, bytesPerRank, /*ncclUint8*/ 1, c->rcclComm, stream);
+}
+
+// all-to-all of byte blocks over RCCL: one grouped send / receive pair per peer
+int rccl_all_to_all(void *user, const void *send, const size_t *sendBytes, const size_t *sendOffsets, void *recv,
+                    const size_t *recvBytes, const size_t *recvOffsets, void *stream) {
+  AresComm *c = static_cast<AresComm *>(user);
+  int rc = c->ncclGroupStart();
+  for (int r = 0; r < c->nranks && rc == 0; r++) {
+    if (sendBytes[r]) rc = c->ncclSend(static_cast<const uint8_t *>(send) + sendOffsets[r], sendBytes[r], /*ncclUint8*/ 1, r, c->rcclComm, stream);
+    if (rc == 0 && recvBytes[r]) rc = c->ncclRecv(static_cast<uint8_t *>(recv) + recvOffsets[r], recvBytes[r], 1, r, c->rcclComm, stream);
+  }
+  const int end = c->ncclGroupEnd();
+  return rc ? rc : end;
 }
 
 void *open_rccl(std::string *why) {
@@ -945,7 +963,16 @@ AresComm *AresCommCreateRccl(const uint8_t id[128], int rank, int nranks, int de
   }
   c->allGather = &rccl_all_gather;
   c->user = c;
+  c->ncclSend = reinterpret_cast<decltype(c->ncclSend)>(dlsym(h, "ncclSend"));
+  c->ncclRecv = reinterpret_cast<decltype(c->ncclRecv)>(dlsym(h, "ncclRecv"));
+  c->ncclGroupStart = reinterpret_cast<decltype(c->ncclGroupStart)>(dlsym(h, "ncclGroupStart"));
+  c->ncclGroupEnd = reinterpret_cast<decltype(c->ncclGroupEnd)>(dlsym(h, "ncclGroupEnd"));
+  if (c->ncclSend && c->ncclRecv && c->ncclGroupStart && c->ncclGroupEnd) c->allToAll = &rccl_all_to_all;
   return c;
+}
+
+void AresCommSetAllToAll(AresComm *c, AresAllToAllFn allToAll) {
+  if (c) c->allToAll = allToAll;
 }
 
 void AresCommDestroy(AresComm *c) {
@@ -1020,6 +1047,175 @@ int AresQueryMergeShards(AresQuery *q, AresComm *c, char *err, int errLen) {
     } else {
       q->size = 0;
     }
+    return 0;
+  } catch (std::exception &e) {
+    set_err(err, errLen, e.what());
+    return -1;
+  }
+}
+
+// Option (B) of SURVEY.md 8e: every rank ends with the groups whose 64-bit row hash falls into its share
+// of the hash range, so no rank ever holds the whole table.  Built from the library's own entry points:
+// Sort gives the row hashes and the order, Reduce lays the table out in that order (a shard's rows are
+// distinct, so it only gathers), the slice for rank r is then contiguous; blocks travel by one
+// all-to-all (or padded all-gathers when the communicator has none) and the receiver re-reduces what
+// arrived with the query's own reduction.
+int AresQueryMergeShardsPartitioned(AresQuery *q, AresComm *c, int64_t *totalGroups, char *err, int errLen) {
+  try {
+    if (!c || !c->allGather) throw AbiError("no communicator");
+    if (q->plan.isHLL()) throw AbiError("HyperLogLog results are merged on the host (query/hll.go), not here");
+    std::vector<int> widths;
+    for (int k = 0; k < NUM_DIM_WIDTH; k++)
+      for (int j = 0; j < q->ndw[k]; j++) widths.push_back(kDimWidths[k]);
+    const int nd = static_cast<int>(widths.size()), mb = q->plan.measureBytes(), world = c->nranks;
+    int64_t valueBytes = 0;
+    for (int w : widths) valueBytes += w;
+    const int64_t rowBytes = valueBytes + nd + mb;
+    const int n = q->resultSize;
+    // 1. the local table in hash order: Sort (hashes + order) and Reduce (gather) of vector [0] into [1]
+    std::vector<int64_t> split(world + 1, 0);
+    if (n > 0) {
+      const int64_t cap = q->resultCapacity;
+      const bool ownVectors = q->hashVec[0] == nullptr;
+      if (ownVectors) {
+        for (int i = 0; i < 2; i++) {
+          q->hashVec[i] = q->alloc<uint64_t>(static_cast<size_t>(cap) * 8);
+          q->dimIndexVec[i] = q->alloc<uint32_t>(static_cast<size_t>(cap) * 4);
+        }
+      }
+      check(q->lib->InitIndexVector(q->dimIndexVec[0], 0, n, q->stream, q->device));
+      check(q->lib->Sort(q->dimensionVector(0), n, q->stream, q->device));
+      const int kept = static_cast<int>(check(q->lib->Reduce(q->dimensionVector(0), q->measureVec[0], q->dimensionVector(1),
+                                                             q->measureVec[1], mb, n, static_cast<AggregateFunction>(q->plan.aggFunc),
+                                                             q->stream, q->device)));
+      if (kept != n) throw AbiError("the shard's group table holds rows with equal 64-bit hashes");
+      // 2. rank r takes hashes in [r * 2^64 / world, (r + 1) * 2^64 / world): binary searches in the sorted hashes
+      auto hashAt = [&](int64_t i) {
+        uint64_t h = 0;
+        check(q->lib->AsyncCopyDeviceToHost(&h, q->hashVec[0] + i, 8, q->stream, q->device));
+        q->wait();
+        return h;
+      };
+      for (int r = 1; r < world; r++) {
+        const uint64_t bound = static_cast<uint64_t>((static_cast<unsigned __int128>(r) << 64) / static_cast<unsigned>(world));
+        int64_t lo = split[r - 1], hi = n;  // first position with hash >= bound
+        while (lo < hi) {
+          const int64_t mid = (lo + hi) / 2;
+          if (hashAt(mid) < bound) lo = mid + 1;
+          else hi = mid;
+        }
+        split[r] = lo;
+      }
+      split[world] = n;
+      q->wait();
+      q->swapResultBuffers();  // vector [0] is the table in hash order now
+      q->size = 0;
+      if (ownVectors) {
+        for (int i = 0; i < 2; i++) {
+          q->release(q->hashVec[i]); q->release(q->dimIndexVec[i]);
+          q->hashVec[i] = nullptr; q->dimIndexVec[i] = nullptr;
+        }
+      }
+    }
+    // 3. who sends how much to whom
+    std::vector<int64_t> mine(world), all(static_cast<size_t>(world) * world);
+    for (int r = 0; r < world; r++) mine[r] = split[r + 1] - split[r];
+    gather_words(q, c, mine.data(), all.data(), sizeof(int64_t) * world);
+    std::vector<int64_t> recvRows(world);
+    int64_t total = 0, grand = 0, maxBlock = 1;
+    for (int src = 0; src < world; src++) {
+      recvRows[src] = all[static_cast<size_t>(src) * world + c->rank];
+      total += recvRows[src];
+      for (int dst = 0; dst < world; dst++) {
+        grand += all[static_cast<size_t>(src) * world + dst];
+        maxBlock = std::max(maxBlock, all[static_cast<size_t>(src) * world + dst]);
+      }
+    }
+    if (total > INT32_MAX) throw AbiError("a rank's share of the merged result exceeds 2^31 rows");
+    // 4. pack one block per destination: [dim values...][dim validity...][measures] of its rows
+    auto sections = [&](int64_t rows, std::vector<int64_t> &sect) {
+      sect.clear();
+      int64_t off = 0;
+      for (int w : widths) { sect.push_back(off); off += rows * w; }
+      for (int d = 0; d < nd; d++) { sect.push_back(off); off += rows; }
+      sect.push_back(off);
+    };
+    std::vector<size_t> sendBytes(world), sendOff(world), recvBytes(world), recvOff(world);
+    size_t sendTotal = 0, recvTotal = 0;
+    for (int r = 0; r < world; r++) {
+      sendBytes[r] = static_cast<size_t>(mine[r] * rowBytes); sendOff[r] = sendTotal; sendTotal += sendBytes[r];
+      recvBytes[r] = static_cast<size_t>(recvRows[r] * rowBytes); recvOff[r] = recvTotal; recvTotal += recvBytes[r];
+    }
+    uint8_t *packed = q->alloc(sendTotal), *arrived = q->alloc(recvTotal);
+    std::vector<int64_t> sect;
+    for (int r = 0; r < world; r++) {
+      if (!mine[r]) continue;
+      sections(mine[r], sect);
+      uint8_t *block = packed + sendOff[r];
+      for (int d = 0; d < nd; d++) {
+        int64_t vo, no;
+        dimension_start_offsets(q->ndw, d, q->resultCapacity, &vo, &no);
+        q->d2d(block + sect[d], q->dimVec[0] + vo + split[r] * widths[d], static_cast<size_t>(mine[r]) * widths[d]);
+        q->d2d(block + sect[nd + d], q->dimVec[0] + no + split[r], static_cast<size_t>(mine[r]));
+      }
+      q->d2d(block + sect[2 * nd], q->measureVec[0] + split[r] * mb, static_cast<size_t>(mine[r]) * mb);
+    }
+    // 5. the exchange
+    if (c->allToAll) {
+      if (c->allToAll(c->user, packed, sendBytes.data(), sendOff.data(), arrived, recvBytes.data(), recvOff.data(), q->stream) != 0)
+        throw AbiError("all-to-all of the group table blocks failed");
+    } else {  // destination by destination: everybody contributes its block for rank r, rank r keeps them
+      const size_t pad = static_cast<size_t>(maxBlock * rowBytes);
+      uint8_t *one = q->alloc(pad), *every = q->alloc(pad * world);
+      for (int r = 0; r < world; r++) {
+        if (sendBytes[r]) q->d2d(one, packed + sendOff[r], sendBytes[r]);
+        if (c->allGather(c->user, one, every, pad, q->stream) != 0) throw AbiError("all-gather of the group table blocks failed");
+        if (r == c->rank)
+          for (int src = 0; src < world; src++)
+            if (recvBytes[src]) q->d2d(arrived + recvOff[src], every + pad * src, recvBytes[src]);
+        q->wait();  // `one` is refilled for the next destination
+      }
+      q->release(one);
+      q->release(every);
+    }
+    // 6. append what arrived into fresh result vectors and re-reduce
+    q->wait();
+    q->releaseAll();
+    q->resultSize = 0;
+    q->size = static_cast<int>(total);
+    if (total > 0) q->prepareForDimAndMeasureEval();
+    int64_t base = 0;
+    for (int src = 0; src < world; src++) {
+      if (!recvRows[src]) continue;
+      sections(recvRows[src], sect);
+      const uint8_t *block = arrived + recvOff[src];
+      for (int d = 0; d < nd; d++) {
+        int64_t vo, no;
+        dimension_start_offsets(q->ndw, d, q->resultCapacity, &vo, &no);
+        q->d2d(q->dimVec[0] + vo + base * widths[d], const_cast<uint8_t *>(block) + sect[d], static_cast<size_t>(recvRows[src]) * widths[d]);
+        q->d2d(q->dimVec[0] + no + base, const_cast<uint8_t *>(block) + sect[nd + d], static_cast<size_t>(recvRows[src]));
+      }
+      q->d2d(q->measureVec[0] + base * mb, const_cast<uint8_t *>(block) + sect[2 * nd], static_cast<size_t>(recvRows[src]) * mb);
+      base += recvRows[src];
+    }
+    q->wait();
+    q->release(packed);
+    q->release(arrived);
+    if (total > 0) {
+      q->reduce();
+      q->postExec();
+    } else {
+      q->size = 0;
+    }
+    // 7. the size of the whole result: every rank's share
+    if (totalGroups) {
+      std::vector<int64_t> shares(world, 0);
+      const int64_t share = q->resultSize;
+      gather_words(q, c, &share, shares.data(), sizeof(int64_t));
+      *totalGroups = 0;
+      for (int64_t v : shares) *totalGroups += v;
+    }
+    (void)grand;
     return 0;
   } catch (std::exception &e) {
     set_err(err, errLen, e.what());

@@ -135,6 +135,16 @@ void AresCommDestroy(AresComm *c);
  * Hash-reduction and sort-reduction queries; not HyperLogLog.  0, or -1 + message. */
 int AresQueryMergeShards(AresQuery *q, AresComm *c, char *err, int errLen);
 
+/* Option (B), for group tables too large to replicate: every rank ends with the groups whose 64-bit row
+ * hash falls into its 1/nranks share of the hash range (q's result becomes that share; *totalGroups = the
+ * size of the whole result).  Blocks travel by one all-to-all — ncclSend / ncclRecv pairs on the query's
+ * stream for an RCCL communicator, AresCommSetAllToAll for any other — or, without one, by nranks padded
+ * all-gathers.  0, or -1 + message. */
+typedef int (*AresAllToAllFn)(void *user, const void *send, const size_t *sendBytes, const size_t *sendOffsets, void *recv,
+                              const size_t *recvBytes, const size_t *recvOffsets, void *stream);
+void AresCommSetAllToAll(AresComm *c, AresAllToAllFn allToAll);
+int AresQueryMergeShardsPartitioned(AresQuery *q, AresComm *c, int64_t *totalGroups, char *err, int errLen);
+
 /* ---- host batches: transfer pipeline + device-resident column cache --------------------
  * The Go host uploads every batch's columns for every query (query/aql_processor.go:513-540,
  * :1345-1431) and overlaps the upload of batch k+1 with the execution of batch k on its second stream

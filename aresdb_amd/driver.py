@@ -45,6 +45,8 @@ class QueryPlanC(C.Structure):
 
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+ALLTOALL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_void_p,
+                          C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_void_p)
 
 
 class HostColumnC(C.Structure):
@@ -85,6 +87,9 @@ def _driver():
         lib.AresCommCreateRccl.restype = C.c_void_p
         lib.AresCommDestroy.argtypes = [C.c_void_p]
         lib.AresQueryMergeShards.argtypes, lib.AresQueryMergeShards.restype = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int], C.c_int
+        lib.AresQueryMergeShardsPartitioned.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_char_p, C.c_int]
+        lib.AresQueryMergeShardsPartitioned.restype = C.c_int
+        lib.AresCommSetAllToAll.argtypes, lib.AresCommSetAllToAll.restype = [C.c_void_p, ALLTOALL_FN], None
         lib.AresColumnCacheCreate.argtypes, lib.AresColumnCacheCreate.restype = [C.c_void_p, C.c_int, C.c_size_t], C.c_void_p
         lib.AresColumnCacheDestroy.argtypes = [C.c_void_p]
         lib.AresQueryRunHostBatches.argtypes = [C.c_void_p, C.POINTER(HostColumnC), C.c_int, C.POINTER(C.c_int), C.c_int,
@@ -295,6 +300,16 @@ class NativeQuery:
         if rc != 0:
             raise abi.AresError(self._err.value.decode().strip())
 
+    def merge_shards_partitioned(self, comm):
+        """Hash-partitioned merge: this query's result becomes the groups whose 64-bit row hash falls into
+        this rank's share of the hash range (no rank holds the whole table).  Returns the size of the whole
+        result over all ranks."""
+        total = C.c_int64(0)
+        rc = _driver().AresQueryMergeShardsPartitioned(self._q, comm.handle, C.byref(total), self._err, 1024)
+        if rc != 0:
+            raise abi.AresError(self._err.value.decode().strip())
+        return total.value
+
     def run_host_batches(self, batches, cache=None):
         """batches: [(list of HostColumn in column order, rows)] living in pinned host memory; the
         driver uploads batch k+1 while batch k executes.  Returns {uploaded_bytes, uploads, cache_hits,
@@ -349,7 +364,7 @@ class NativeComm:
         return cls(h)
 
     @classmethod
-    def torch_group(cls, group=None):
+    def torch_group(cls, group=None, all_to_all=False):
         import torch
         import torch.distributed as dist
         world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -364,7 +379,34 @@ class NativeComm:
             except Exception:  # noqa: BLE001
                 return 1
         cb = ALLGATHER_FN(all_gather)
-        return cls(_driver().AresCommCreate(rank, world, cb, None), keep=cb)
+        handle = _driver().AresCommCreate(rank, world, cb, None)
+        keep = [cb]
+        if all_to_all:
+            def exchange(user, send, send_bytes, send_off, recv, recv_bytes, recv_off, stream):
+                try:
+                    outs = [torch.frombuffer((C.c_uint8 * max(send_bytes[r], 1)).from_address(send + send_off[r]),
+                                             dtype=torch.uint8)[:send_bytes[r]].clone() for r in range(world)]
+                    ins = [torch.empty(recv_bytes[r], dtype=torch.uint8) for r in range(world)]
+                    # gloo has no all_to_all: pairwise exchanges, lower rank sends first
+                    for peer in range(world):
+                        if peer == rank:
+                            ins[peer].copy_(outs[peer])
+                        elif rank < peer:
+                            dist.send(outs[peer], peer, group=group)
+                            dist.recv(ins[peer], peer, group=group)
+                        else:
+                            dist.recv(ins[peer], peer, group=group)
+                            dist.send(outs[peer], peer, group=group)
+                    for r in range(world):
+                        if recv_bytes[r]:
+                            C.memmove(recv + recv_off[r], ins[r].data_ptr(), recv_bytes[r])
+                    return 0
+                except Exception:  # noqa: BLE001
+                    return 1
+            a2a = ALLTOALL_FN(exchange)
+            _driver().AresCommSetAllToAll(handle, a2a)
+            keep.append(a2a)
+        return cls(handle, keep=keep)
 
     def destroy(self):
         if self.handle:

@@ -84,6 +84,71 @@ def _native_worker(rank, world, port, use_hash, q):
         dist.destroy_process_group()
 
 
+def _partitioned_worker(rank, world, port, use_hash, all_to_all, q):
+    """Hash-partitioned merge inside libaresdriver.so: the ranks' shares are disjoint, their union equals
+    one process reducing every shard."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import harness as H
+    from aresdb_amd import workload
+    from aresdb_amd.driver import NativeComm, NativeQuery
+    from aresdb_amd.queries import c3_plan
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        be = H.oracle_backend()
+        plan = c3_plan(use_hash_reduction=use_hash)
+        names = [n for n, _ in workload.C3_COLUMNS]
+        # the last rank's shard is empty when there are three: a rank with nothing to send
+        rows = [5000 + 700 * r if (world < 3 or r < world - 1) else 0 for r in range(world)]
+        shards = [workload.c3_shard(rows[r], 2048, seed=11 + r, device="cpu") if rows[r] else [] for r in range(world)]
+        ctx = NativeQuery(be, plan, names)
+        for b in shards[rank]:
+            ctx.run({k: rc.vp for k, rc in b.items()}, next(iter(b.values())).length)
+        comm = NativeComm.torch_group(all_to_all=all_to_all)
+        total = ctx.merge_shards_partitioned(comm)
+        n = ctx.result_size
+        got = {}
+        if n:
+            dims, valids, meas = ctx.fetch()
+            m = meas.view(np.float64)
+            got = {tuple((bytes(d[r * len(d) // n:(r + 1) * len(d) // n]), int(v[r])) for d, v in zip(dims, valids)): m[r]
+                   for r in range(n)}
+        everyone = [None] * world
+        dist.all_gather_object(everyone, got)
+        union = {}
+        for part in everyone:
+            assert not (union.keys() & part.keys()), "two ranks hold the same group"
+            union.update(part)
+        want = _single_process_result(be, plan, [b for s in shards for b in s])
+        assert total == len(want) == len(union), (total, len(want), len(union))
+        assert union.keys() == want.keys()
+        for k, v in want.items():
+            assert abs(union[k] - v) <= 1e-9 * max(1.0, abs(v)), (k, union[k], v)
+        comm.destroy()
+        ctx.release()
+        q.put((rank, "ok", n))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, f"{type(e).__name__}: {e}", 0))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,all_to_all", [(2, True), (3, True), (3, False)], ids=["2_all_to_all", "3_all_to_all", "3_all_gathers"])
+@pytest.mark.parametrize("use_hash", [True, False], ids=["hash_reduce", "sort_reduce"])
+def test_hash_partitioned_shard_merge_gloo(use_hash, world, all_to_all):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_partitioned_worker, args=(r, world, port, use_hash, all_to_all, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in results), results
+    assert sum(r[2] for r in results) > 0 and all(r[2] > 0 for r in results)  # every rank owns a share
+
+
 @pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("use_hash", [True, False], ids=["hash_reduce", "sort_reduce"])
 def test_native_shard_merge_gloo(use_hash, world):
@@ -191,6 +256,15 @@ def _gpu_worker(port, use_hash, q):
         got2 = {tuple((bytes(d[r * len(d) // n2:(r + 1) * len(d) // n2]), int(v[r])) for d, v in zip(dims, valids)): m2[r]
                 for r in range(n2)}
         assert got2.keys() == want.keys() and all(abs(got2[k] - v) <= 1e-9 * max(1.0, abs(v)) for k, v in want.items())
+        # ... and the hash-partitioned merge: Sort + Reduce of the table, one ncclSend / ncclRecv pair (to itself)
+        total = ctx.merge_shards_partitioned(comm)
+        dims, valids, meas = ctx.fetch()
+        n3 = ctx.result_size
+        m3 = meas.view(np.float64)
+        got3 = {tuple((bytes(d[r * len(d) // n3:(r + 1) * len(d) // n3]), int(v[r])) for d, v in zip(dims, valids)): m3[r]
+                for r in range(n3)}
+        assert total == n3 == len(want)
+        assert got3.keys() == want.keys() and all(abs(got3[k] - v) <= 1e-9 * max(1.0, abs(v)) for k, v in want.items())
         comm.destroy()
         ctx.release()
         dist.destroy_process_group()

@@ -166,7 +166,18 @@ DeviceState g_devices[kMaxDevices];
 hipError_t device_state(int device, DeviceState **out) {
   if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
   DeviceState &st = g_devices[device];
-  std::call_once(st.once, [&] { st.initError = hipStreamCreateWithFlags(&st.allocStream, hipStreamNonBlocking); });
+  std::call_once(st.once, [&] {
+    // lowest priority: the fills of parked blocks should take the gaps between a query's kernels, not
+    // bandwidth from them
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) {
+      (void)hipGetLastError();
+      least = 0;
+    }
+    if (const char *e = getenv("ARES_MEM_FILL_PRIORITY"))  // "normal": diagnostics
+      if (strcmp(e, "normal") == 0) least = 0;
+    st.initError = hipStreamCreateWithPriority(&st.allocStream, hipStreamNonBlocking, least);
+  });
   *out = &st;
   return st.initError;
 }
@@ -217,6 +228,22 @@ void trim(DeviceState *st, size_t keepBytes) {
   }
 }
 
+// ARES_MEM_DEBUG=1: driver allocations the cache could not avoid, reported at exit (diagnostics)
+void count_driver_allocation(size_t bytes) {
+  static const bool on = [] {
+    const char *e = getenv("ARES_MEM_DEBUG");
+    return e && e[0] == '1';
+  }();
+  if (!on) return;
+  static std::atomic<long> calls{0}, total{0};
+  static const int registered = atexit([] {
+    fprintf(stderr, "libmem: %ld hipMalloc calls, %.1f MB in total\n", calls.load(), static_cast<double>(total.load()) / 1e6);
+  });
+  (void)registered;
+  calls++;
+  total += static_cast<long>(bytes);
+}
+
 hipError_t pool_alloc(DeviceState *st, void **p, size_t bytes, bool zero) {
   if (bytes == 0) bytes = 1;
   if (!use_pool()) {
@@ -246,6 +273,7 @@ hipError_t pool_alloc(DeviceState *st, void **p, size_t bytes, bool zero) {
     }
   }
   if (!ptr) {
+    count_driver_allocation(rounded);
     hipError_t e = hipMalloc(&ptr, rounded);
     if (e != hipSuccess) {  // out of memory: give both libraries' caches back and retry once
       (void)hipGetLastError();

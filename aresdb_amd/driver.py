@@ -354,9 +354,10 @@ class NativeComm:
         lib = _driver()
         ident = (C.c_uint8 * 128)()
         err = C.create_string_buffer(512)
-        if rank == 0 and lib.AresCommRcclUniqueId(ident, err, 512) != 0:
-            raise abi.AresError(err.value.decode())
-        raw = broadcast(bytes(ident))
+        failed = rank == 0 and lib.AresCommRcclUniqueId(ident, err, 512) != 0
+        raw = broadcast(bytes(128) if failed else bytes(ident))  # every rank takes part, whatever rank 0 found
+        if raw == bytes(128):
+            raise abi.AresError("rank 0 could not obtain an RCCL id: " + err.value.decode())
         ident = (C.c_uint8 * 128).from_buffer_copy(raw)
         h = lib.AresCommCreateRccl(ident, rank, world, device, err, 512)
         if not h:
@@ -364,17 +365,29 @@ class NativeComm:
         return cls(h)
 
     @classmethod
-    def torch_group(cls, group=None, all_to_all=False):
+    def torch_group(cls, group=None, all_to_all=False, device_backend=None, device=0):
+        """`group`: a torch.distributed group for host tensors (gloo).  With `device_backend` (an abi.Backend
+        whose memory is device memory) the buffers are staged through host memory with its copy entry
+        points — the transport of last resort for ranks on GPUs when RCCL cannot be bound directly."""
         import torch
         import torch.distributed as dist
         world, rank = dist.get_world_size(group), dist.get_rank(group)
 
         def all_gather(user, send, recv, nbytes, stream):
             try:
-                mine = torch.frombuffer((C.c_uint8 * nbytes).from_address(send), dtype=torch.uint8).clone()
+                if device_backend is not None:
+                    mine = torch.empty(nbytes, dtype=torch.uint8)
+                    device_backend.call("AsyncCopyDeviceToHost", mine.data_ptr(), send, nbytes, stream, device)
+                    device_backend.call("WaitForCudaStream", stream, device)
+                else:
+                    mine = torch.frombuffer((C.c_uint8 * nbytes).from_address(send), dtype=torch.uint8).clone()
                 out = torch.empty(world * nbytes, dtype=torch.uint8)
                 dist.all_gather_into_tensor(out, mine, group=group)
-                C.memmove(recv, out.data_ptr(), world * nbytes)
+                if device_backend is not None:
+                    device_backend.call("AsyncCopyHostToDevice", recv, out.data_ptr(), world * nbytes, stream, device)
+                    device_backend.call("WaitForCudaStream", stream, device)
+                else:
+                    C.memmove(recv, out.data_ptr(), world * nbytes)
                 return 0
             except Exception:  # noqa: BLE001
                 return 1

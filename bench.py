@@ -250,7 +250,7 @@ def main(argv=None, backend=None, tensor_device=None):
     # N > 1: the per-shard group tables meet in ONE exchange inside libaresdriver.so — all-gather of the
     # padded columnar partials (RCCL on the query's stream over xGMI; gloo in the CPU test of this file)
     # and a re-reduce with the library's own HashReduce; aresdb_amd/shard_merge.py is its test mirror
-    comm = None
+    comm, merge_transport = None, None
     if distributed:
         from aresdb_amd.driver import NativeComm
         if on_gpu:
@@ -258,9 +258,27 @@ def main(argv=None, backend=None, tensor_device=None):
                 t = torch.tensor(list(raw), dtype=torch.uint8, device=tdev)
                 dist.broadcast(t, 0)
                 return bytes(t.cpu().tolist())
-            comm = NativeComm.rccl(rank, world, device_index, bcast)
+            host_group = dist.new_group(backend="gloo")  # collective: made whether or not it is needed
+            why = ""
+            try:
+                if os.environ.get("ARES_BENCH_NO_RCCL") == "1":  # exercise the fallback
+                    raise RuntimeError("ARES_BENCH_NO_RCCL=1")
+                comm = NativeComm.rccl(rank, world, device_index, bcast)
+            except Exception as e:  # noqa: BLE001
+                why = f"{type(e).__name__}: {e}"
+            everyone = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=tdev)
+            dist.all_reduce(everyone, op=dist.ReduceOp.MIN)
+            merge_transport = "ncclAllGather on the query stream (librccl bound by libaresdriver.so)"
+            if int(everyone.item()) == 0:  # some rank could not bind RCCL: the same merge over host-staged gloo
+                if comm is not None:
+                    comm.destroy()
+                print(f"[rank {rank}] RCCL communicator unavailable ({why or 'on another rank'}): shard merge staged through "
+                      "host memory", file=sys.stderr, flush=True)
+                comm = NativeComm.torch_group(host_group, device_backend=be, device=device_index)
+                merge_transport = "gloo all-gather staged through host memory (RCCL could not be bound)"
         else:
             comm = NativeComm.torch_group()
+            merge_transport = "gloo all-gather (CPU test)"
 
     def merge(ctx):
         ctx.merge_shards(comm)
@@ -403,7 +421,7 @@ def main(argv=None, backend=None, tensor_device=None):
                                    f"{args.null_fraction:.0%} nulls, shard resident in HBM",
                        "rows_per_gpu": rows, "batch_rows": batch_rows, "batches": len(batches),
                        "streams_per_query": n_streams,
-                       "groups_per_shard": groups, "merged_groups": merged_groups,
+                       "groups_per_shard": groups, "merged_groups": merged_groups, "merge_transport": merge_transport,
                        "parallelism": f"{world} shard(s), one per GPU" + (", all-gather + re-reduce merge in libaresdriver.so" if distributed else "")},
             "rows_per_sec_per_gpu": value / world,
             "algorithmic_GBps_end_to_end": value / world * bytes_per_row / 1e9,

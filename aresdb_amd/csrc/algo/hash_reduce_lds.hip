@@ -287,7 +287,9 @@ int hash_reduce_lds(int device, const DimensionVector &inputKeys, const uint8_t 
     if (lean && a.width == 8) ws.widen.mode = 2;  // line records carry the whole 8-byte value
     ws.prevRanges = grouped ? prev.ranges : nullptr;
     ws.outRanges = outRanges;
-    if (outRanges) hip_check(hipMemsetAsync(outRanges, 0, kRangesBytes, stream), "hipMemsetAsync");
+    // the specialised merge for these records (it writes every partition's range entry itself)
+    void *leanMerge = lean ? rtc_vector_merge_lookup(device, L.numDims, a.width, partBits, a) : nullptr;
+    if (outRanges && !leanMerge) hip_check(hipMemsetAsync(outRanges, 0, kRangesBytes, stream), "hipMemsetAsync");
     if (lean) {
       rtc_vector_scan_launch(lean, inputKeys.DimValues, capacity, inputValues, L.numDims, a.width, static_cast<uint32_t>(start), rows,
                              ws, stream);
@@ -319,16 +321,33 @@ int hash_reduce_lds(int device, const DimensionVector &inputKeys, const uint8_t 
 #define ARES_HR_MERGE_ND(ND)                       \
   if (rwB == 4) ARES_HR_MERGE(ND, 4);              \
   else ARES_HR_MERGE(ND, 3);
-    switch (all4 ? L.numDims : 0) {
-      case 1: ARES_HR_MERGE_ND(1) break;
-      case 2: ARES_HR_MERGE_ND(2) break;
-      case 3: ARES_HR_MERGE_ND(3) break;
-      case 4: ARES_HR_MERGE_ND(4) break;
-      default: ARES_HR_MERGE(0, 3); break;
+    auto generic_merge = [&] {
+      switch (all4 ? L.numDims : 0) {
+        case 1: ARES_HR_MERGE_ND(1) break;
+        case 2: ARES_HR_MERGE_ND(2) break;
+        case 3: ARES_HR_MERGE_ND(3) break;
+        case 4: ARES_HR_MERGE_ND(4) break;
+        default: ARES_HR_MERGE(0, 3); break;
+      }
+    };
+    if (leanMerge) {
+      FusedPlanD none;
+      memset(&none, 0, sizeof(none));
+      rtc_merge_launch(leanMerge, none, inputKeys.DimValues, capacity, inputValues, static_cast<uint32_t>(start), outputKeys.DimValues,
+                       capacity, outputValues, ws, stream);
+    } else {
+      generic_merge();
+    }
+    res = read_result(ws, stream);
+    if (leanMerge && res.needGeneric && !res.overflow && !(grouped && res.stale)) {
+      // a partition holds more groups than one LDS table: the generic multi-round merge over the same records
+      hip_check(hipMemsetAsync(ws.outCount, 0, 4 * sizeof(uint32_t), stream), "hipMemsetAsync");
+      if (outRanges) hip_check(hipMemsetAsync(outRanges, 0, kRangesBytes, stream), "hipMemsetAsync");
+      generic_merge();
+      res = read_result(ws, stream);
     }
 #undef ARES_HR_MERGE_ND
 #undef ARES_HR_MERGE
-    res = read_result(ws, stream);
     static const bool trace = getenv("ARES_HR_TRACE") != nullptr;  // diagnostics
     if (trace)
       fprintf(stderr, "hash_reduce_lds: length %d start %d rows %d streams %d capA %llu capB %u partBits %d -> groups %u overflow %u stale %u\n",

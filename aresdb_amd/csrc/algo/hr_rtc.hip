@@ -506,7 +506,10 @@ struct RtcMergeArgs {  // mirrors `struct MArgs` of the generated source
   uint64_t *phases;  // ARES_HR_PHASES=1: per-partition time stamps (diagnostics)
 };
 
-std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w) {
+// vectorVW = 0: records of the plan-sourced scan (4-byte carried measure, widened here; rows >= prevSize are
+// source rows whose dimensions are re-evaluated from the plan's columns).  vectorVW = 4 / 8: records of the
+// vector-sourced scan (the whole value travels; every row, old or new, is a row of the input vectors).
+std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w, int vectorVW = 0) {
   if (nd < 1 || nd > kFusedDims) return "";
   std::ostringstream o;
   o << "typedef unsigned int u32; typedef unsigned long long u64; typedef unsigned char u8; typedef int i32; typedef long long i64;\n"
@@ -609,15 +612,20 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
   // LDS atomic more.  The rest (the group lives further on, or is new) is queued per wavefront in LDS and
   // taken through the general probe loop 64 at a time, every lane busy: run per record where it occurs,
   // that loop would execute for a handful of lanes after nearly every segment.
-  o << "#define QCAP 128u\n"
-       "struct Seg { const uint4 *ptr; u32 n; };\n"
+  if (vectorVW == 8)  // four words per queued record: a smaller queue, drained from 32 entries on (LDS is full)
+    o << "#define QCAP 96u\n#define QW 4u\n#define QDRAIN 32u\n#define VAL(r) ((((u64)(r).w) << 32) | (r).z)\n#define VALQ(z, w) ((((u64)(w)) << 32) | (z))\n";
+  else if (vectorVW == 4)
+    o << "#define QCAP 128u\n#define QW 3u\n#define QDRAIN 64u\n#define VAL(r) ((u64)(r).z)\n#define VALQ(z, w) ((u64)(z))\n";
+  else
+    o << "#define QCAP 128u\n#define QW 3u\n#define QDRAIN 64u\n#define VAL(r) widen((r).z)\n#define VALQ(z, w) widen(z)\n";
+  o << "struct Seg { const uint4 *ptr; u32 n; };\n"
        "struct Stage { uint4 r[4]; u32 n[4]; };\n"
        "__device__ __forceinline__ void drain(u32 *queue, u32 first, u32 count, u32 lane, u64 *sKeys, u64 *sVals, u32 *sClaimed, u32 *sOverflow) {\n"
        "  asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");\n"
        "  if (lane < count) {\n"
-       "    const u32 e = 3u * (first + lane);\n"
-       "    const u32 row = queue[e], h = queue[e + 1u], z = queue[e + 2u];\n"
-       "    insert(sKeys, sVals, sClaimed, sOverflow, row, h, widen(z));\n"
+       "    const u32 e = QW * (first + lane);\n"
+       "    const u32 row = queue[e], h = queue[e + 1u], z = queue[e + 2u], w = QW == 4u ? queue[e + QW - 1u] : 0u;\n"
+       "    insert(sKeys, sVals, sClaimed, sOverflow, row, h, VALQ(z, w));\n"
        "  }\n"
        "  asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");\n"
        "}\n"
@@ -634,23 +642,24 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
        "      const u32 mi = m0 ? 0u : m1 ? 1u : m2 ? 2u : 3u;\n"
        "      const u32 seenRow = m0 ? (u32)lo.x : m1 ? (u32)lo.y : m2 ? (u32)hi.x : (u32)hi.y;\n"
        "      if (s.r[k].x < seenRow) __hip_atomic_fetch_min(sKeys + 4u * b + mi, ((u64)h << 32) | s.r[k].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
-       "      agg(sVals + 4u * b + mi, widen(s.r[k].z));\n"
+       "      agg(sVals + 4u * b + mi, VAL(s.r[k]));\n"
        "    }\n"
        "    const bool pend = valid && !hit;\n"
        "    const u64 m = __ballot(pend);\n"
        "    if (m) {\n"
        "      if (pend) {\n"
-       "        const u32 e = 3u * (qn + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)));\n"
+       "        const u32 e = QW * (qn + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)));\n"
        "        queue[e] = s.r[k].x; queue[e + 1u] = s.r[k].y; queue[e + 2u] = s.r[k].z;\n"
+       "        if (QW == 4u) queue[e + QW - 1u] = s.r[k].w;\n"
        "      }\n"
        "      qn += (u32)__popcll(m);\n"
-       "      if (qn >= 64u) { qn -= 64u; drain(queue, qn, 64u, lane, sKeys, sVals, sClaimed, sOverflow); }\n"
+       "      if (qn >= QDRAIN) { const u32 take = qn < 64u ? qn : 64u; qn -= take; drain(queue, qn, take, lane, sKeys, sVals, sClaimed, sOverflow); }\n"
        "    }\n"
        "  }\n"
        "}\n";
   // dimensions of a source row (hr::fused_eval_row), for groups that are new in this batch
-  o << "__device__ __forceinline__ void eval_row(const MArgs &a, u32 row, u32 (&bits)[ND], u32 (&ok)[ND]) {\n";
-  for (int d = 0; d < nd; d++) {
+  if (!vectorVW) o << "__device__ __forceinline__ void eval_row(const MArgs &a, u32 row, u32 (&bits)[ND], u32 (&ok)[ND]) {\n";
+  for (int d = 0; d < nd && !vectorVW; d++) {
     const FusedExpr &e = plan.dims[d];
     if (!plain_store(e.f.rk, e.outKind)) return "";
     const int c = e.col;
@@ -661,13 +670,13 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
     if (!gen_value(e.f, o, "v", "okb", "x")) return "";
     o << "    bits[" << d << "] = x; ok[" << d << "] = okb;\n  }\n";
   }
-  o << "}\n";
+  if (!vectorVW) o << "}\n";
   const bool wide = a.width == 8;
   o << "extern \"C\" __global__ void __launch_bounds__(1024) hr_merge_rtc(MArgs a) {\n"
        "  __shared__ u64 sKeys[SLOTS];\n"
        "  __shared__ u64 sVals[SLOTS];\n"
        "  __shared__ u32 sRunCount[256];\n"
-       "  __shared__ u32 sQueue[16u * QCAP * 3u];\n"
+       "  __shared__ u32 sQueue[16u * QCAP * QW];\n"
        "  __shared__ u32 sClaimed, sOverflow, sCount, sBase, sEmit;\n"
        "  const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, p = blockIdx.x;\n"
        "  STAMP(0)\n"
@@ -724,7 +733,7 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
        "  if (G > 0u) {\n"
        "    const uint4 *dummy = reinterpret_cast<const uint4 *>(a.recB);\n"
        "    u32 j = 0u, off = 0u, qn = 0u;\n"
-       "    u32 *queue = sQueue + wave * (QCAP * 3u);\n"
+       "    u32 *queue = sQueue + wave * (QCAP * QW);\n"
        // this wavefront's runs are wave, wave + 16, ...: lane i keeps the length of the i-th of them, so that
        // walking the runs costs no LDS round trip per segment
        "    const u32 myRuns = (G + 15u - wave) / 16u;\n"
@@ -804,8 +813,8 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
        "      at[kk] = sBase + waveBase + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));\n"
        "      if (!has[kk]) continue;\n"
        "      const u32 row = (u32)key;\n"
-       "      if (row >= a.prevSize) { eval_row(a, row - a.prevSize, dv[kk], nv[kk]); continue; }\n"
-       "#pragma unroll\n"
+    << (vectorVW ? "" : "      if (row >= a.prevSize) { eval_row(a, row - a.prevSize, dv[kk], nv[kk]); continue; }\n")
+    << "#pragma unroll\n"
        "      for (int d = 0; d < ND; d++) {\n"
        "        dv[kk][d] = *reinterpret_cast<const u32 *>(a.prevDims + (u64)(4 * d) * a.prevCapacity + 4ull * row);\n"
        "        nv[kk][d] = nullsIn[(u64)d * a.prevCapacity + row];\n"
@@ -952,6 +961,21 @@ void rtc_vector_scan_launch(void *kernel, const uint8_t *dimValues, size_t capac
 std::string rtc_vector_scan_source(int nd, int vw, int partBits) { return generate_vector(nd, vw, partBits); }
 
 
+
+void *rtc_vector_merge_lookup(int device, int nd, int vw, int partBits, const AggSpec &a) {
+  if (!rtc_api().ok) return nullptr;
+  FusedPlanD none;
+  memset(&none, 0, sizeof(none));
+  const std::string source = generate_merge(none, nd, partBits, a, hr::Widen{0, 0, 0}, vw);
+  if (source.empty()) return nullptr;
+  return compiled_kernel(device, source, "hr_merge_rtc");
+}
+
+std::string rtc_vector_merge_source(int nd, int vw, int partBits, const AggSpec &a) {
+  FusedPlanD none;
+  memset(&none, 0, sizeof(none));
+  return generate_merge(none, nd, partBits, a, hr::Widen{0, 0, 0}, vw);
+}
 
 void *rtc_merge_lookup(int device, const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w) {
   if (!rtc_api().ok) return nullptr;

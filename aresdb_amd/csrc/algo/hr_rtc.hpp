@@ -41,6 +41,10 @@ void rtc_merge_launch(void *kernel, const FusedPlanD &plan, const uint8_t *prevD
                       uint32_t prevSize, uint8_t *dimOut, size_t outCapacity, uint8_t *outValues, const hr::Workspace &ws,
                       hipStream_t stream);
 std::string rtc_merge_source(const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w);
+// ... and for what the vector-sourced scan produces (launched with rtc_merge_launch and an empty plan: every
+// row, old or new, is a row of the input vectors passed as prevDims / prevValues)
+void *rtc_vector_merge_lookup(int device, int nd, int vw, int partBits, const AggSpec &a);
+std::string rtc_vector_merge_source(int nd, int vw, int partBits, const AggSpec &a);
 // the generated source (empty = unsupported shape); for tools and tests
 std::string rtc_scan_source(const FusedPlanD &plan, int nd, int partBits);
 

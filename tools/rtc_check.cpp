@@ -82,6 +82,24 @@ int main(int argc, char **argv) {
       std::string vlog(n, 0); if (n) hiprtcGetProgramLog(vp, &vlog[0]);
       printf("vector scan nd %d vw %d compile rc %d\n%s\n", nd, vw, static_cast<int>(vrc), vlog.c_str());
       if (vrc != HIPRTC_SUCCESS) return 10;
+      {
+        const AggSpec va = make_agg_spec(vw == 8 ? AGGR_SUM_FLOAT : AGGR_SUM_UNSIGNED, vw);
+        const std::string vm = rtc_vector_merge_source(nd, vw, 9, va);
+        if (vm.empty()) { puts("vector merge: unsupported"); return 11; }
+        if (nd == 4 && vw == 8) std::ofstream(prefix + "_vmerge.hip") << vm;
+        hiprtcProgram vq;
+        if (hiprtcCreateProgram(&vq, vm.c_str(), "hr_vmerge_rtc.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return 12;
+        const hiprtcResult qrc = hiprtcCompileProgram(vq, 4, opts);
+        n = 0; hiprtcGetProgramLogSize(vq, &n);
+        std::string qlog(n, 0); if (n) hiprtcGetProgramLog(vq, &qlog[0]);
+        printf("vector merge nd %d vw %d compile rc %d\n%s\n", nd, vw, static_cast<int>(qrc), qlog.c_str());
+        if (qrc != HIPRTC_SUCCESS) return 13;
+        if (nd == 4 && vw == 8) {
+          hiprtcGetCodeSize(vq, &cs);
+          std::vector<char> qcode(cs); hiprtcGetCode(vq, qcode.data());
+          std::ofstream(prefix + "_vmerge.co", std::ios::binary).write(qcode.data(), static_cast<std::streamsize>(cs));
+        }
+      }
       if (nd == 4 && vw == 8) {
         hiprtcGetCodeSize(vp, &cs);
         std::vector<char> vcode(cs); hiprtcGetCode(vp, vcode.data());

@@ -167,16 +167,17 @@ hipError_t device_state(int device, DeviceState **out) {
   if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
   DeviceState &st = g_devices[device];
   std::call_once(st.once, [&] {
-    // lowest priority: the fills of parked blocks should take the gaps between a query's kernels, not
-    // bandwidth from them
-    int least = 0, greatest = 0;
-    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) {
-      (void)hipGetLastError();
-      least = 0;
+    // ARES_MEM_FILL_PRIORITY=low puts the fills of parked blocks on a lowest-priority stream.  Measured:
+    // the scan kernel gains 0-3 %, but the first process on a box now and then takes twice as long per
+    // step with it (3 of 5 fresh boxes) — so the default is an ordinary stream.
+    int priority = 0;
+    const char *e = getenv("ARES_MEM_FILL_PRIORITY");
+    if (e && strcmp(e, "low") == 0) {
+      int least = 0, greatest = 0;
+      if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess) priority = least;
+      else (void)hipGetLastError();
     }
-    if (const char *e = getenv("ARES_MEM_FILL_PRIORITY"))  // "normal": diagnostics
-      if (strcmp(e, "normal") == 0) least = 0;
-    st.initError = hipStreamCreateWithPriority(&st.allocStream, hipStreamNonBlocking, least);
+    st.initError = hipStreamCreateWithPriority(&st.allocStream, hipStreamNonBlocking, priority);
   });
   *out = &st;
   return st.initError;

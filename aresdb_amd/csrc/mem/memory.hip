@@ -148,6 +148,8 @@ struct ParkedBlock {
   bool zeroed = false;  // the block was cleared behind its fence (the last event of the fence covers the fill)
 };
 
+constexpr size_t kWaitForParkedFrom = size_t(16) << 20;  // bytes; see pool_alloc
+
 struct DeviceState {
   std::once_flag once;
   hipStream_t allocStream = nullptr;
@@ -255,6 +257,8 @@ hipError_t pool_alloc(DeviceState *st, void **p, size_t bytes, bool zero) {
   const size_t rounded = bin_size(bytes);
   void *ptr = nullptr;
   bool cleared = false;
+  ParkedBlock waitFor;
+  waitFor.ptr = nullptr;
   {
     std::lock_guard<std::mutex> lock(st->mu);
     auto it = st->bins.find(rounded);
@@ -271,7 +275,24 @@ hipError_t pool_alloc(DeviceState *st, void **p, size_t bytes, bool zero) {
           break;
         }
       }
+      // Nothing ready, but blocks of this size are parked: for a large block, waiting for the oldest one's
+      // fence and fill (bounded by the work enqueued before its free, typically well under a millisecond)
+      // beats asking the driver for another multi-hundred-megabyte allocation — which costs milliseconds
+      // (tens of them in a fresh process) and grows the footprint.
+      if (!ptr && !vec.empty() && rounded >= kWaitForParkedFrom) {
+        ParkedBlock b = vec.front();
+        vec.erase(vec.begin());
+        st->parkedBytes -= rounded;
+        waitFor = b;
+      }
     }
+  }
+  if (waitFor.ptr) {  // (outside the lock: frees and allocations of other threads go on)
+    for (hipEvent_t e : waitFor.fence) (void)hipEventSynchronize(e);
+    ptr = waitFor.ptr;
+    cleared = waitFor.zeroed;
+    std::lock_guard<std::mutex> lock(st->mu);
+    recycle_events(st, waitFor);
   }
   if (!ptr) {
     count_driver_allocation(rounded);

@@ -296,11 +296,13 @@ def main(argv=None, backend=None, tensor_device=None):
     shard_s = merge_s = 0.0
     t0 = time.perf_counter()
     last = merged = None
+    step_ms = []
     for _ in range(args.steps):
         if last is not None:
             last.release()
         t1 = time.perf_counter()
         last = run_shard(be, plan, vps, device_index, streams)
+        step_ms.append((time.perf_counter() - t1) * 1e3)  # host view of the step (no device sync: diagnostics only)
         if distributed:
             if on_gpu:
                 torch.cuda.synchronize()
@@ -422,6 +424,7 @@ def main(argv=None, backend=None, tensor_device=None):
                        "rows_per_gpu": rows, "batch_rows": batch_rows, "batches": len(batches),
                        "streams_per_query": n_streams,
                        "groups_per_shard": groups, "merged_groups": merged_groups, "merge_transport": merge_transport,
+                       "host_ms_of_each_step": [round(x, 2) for x in step_ms],
                        "parallelism": f"{world} shard(s), one per GPU" + (", all-gather + re-reduce merge in libaresdriver.so" if distributed else "")},
             "rows_per_sec_per_gpu": value / world,
             "algorithmic_GBps_end_to_end": value / world * bytes_per_row / 1e9,

@@ -74,6 +74,34 @@ void drop_all_cached() {
 }
 }  // namespace
 
+void (*g_memNoteWrite)(int, const void *, size_t) = nullptr;  // AresMemNoteWrite of the sibling libmem.so (transform.hip resolves it)
+int current_device() {
+  int device = 0;
+  (void)hipGetDevice(&device);
+  return device;
+}
+void mem_note_dim_rows(int device, const DimensionVector &v, size_t firstRow, size_t rows) {
+  if (!g_memNoteWrite || !v.DimValues || rows == 0 || v.VectorCapacity <= 0) return;
+  const size_t cap = static_cast<size_t>(v.VectorCapacity);
+  size_t off = 0;
+  int nd = 0;
+  for (int w = 0; w < NUM_DIM_WIDTH; w++) {
+    const size_t width = static_cast<size_t>(1) << (NUM_DIM_WIDTH - 1 - w);
+    for (int k = 0; k < v.NumDimsPerDimWidth[w]; k++) {
+      g_memNoteWrite(device, v.DimValues + off + width * firstRow, width * rows);
+      off += width * cap;
+      nd++;
+    }
+  }
+  for (int d = 0; d < nd; d++) g_memNoteWrite(device, v.DimValues + off + static_cast<size_t>(d) * cap + firstRow, rows);
+}
+void mem_note_vector_all(int device, const DimensionVector &v) {
+  if (!g_memNoteWrite || v.VectorCapacity <= 0) return;
+  const size_t cap = static_cast<size_t>(v.VectorCapacity);
+  mem_note_dim_rows(device, v, 0, cap);
+  if (v.HashValues) g_memNoteWrite(device, v.HashValues, 8 * cap);
+  if (v.IndexVector) g_memNoteWrite(device, v.IndexVector, 4 * cap);
+}
 void (*g_memTrimCache)(int) = nullptr;  // AresMemTrimCache of the sibling libmem.so (transform.hip resolves it)
 
 // A stream is being destroyed (the host has synchronised it): its cached temporaries go back to the

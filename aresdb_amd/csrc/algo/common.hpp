@@ -81,6 +81,19 @@ void *stream_alloc(size_t bytes, hipStream_t stream);
 void stream_release(void *ptr, hipStream_t stream);
 void stream_cache_purge(int device, hipStream_t stream);  // the stream is being destroyed
 void stream_cache_trim(int device);                       // out of memory elsewhere: give everything back
+// Write reports towards the sibling libmem.so (AresMemNoteWrite, include/ares_extensions.h): it clears a freed
+// block only where something wrote.  Every entry point reports the outputs of its kernels; the three things
+// that may never be written — a deferred InitIndexVector, a lazily compacted index vector, transforms that
+// HashReduce consumed — report when (if) they are materialised.
+extern void (*g_memNoteWrite)(int device, const void *ptr, size_t bytes);
+inline void mem_note_write(int device, const void *ptr, size_t bytes) {
+  if (g_memNoteWrite && ptr && bytes) g_memNoteWrite(device, ptr, bytes);
+}
+int current_device();
+// rows [firstRow, firstRow + rows) of every dimension (values + validity byte) of a dimension vector
+void mem_note_dim_rows(int device, const DimensionVector &v, size_t firstRow, size_t rows);
+// everything a dimension vector owns, to its capacity: dimension values + validity, hash vector, index vector
+void mem_note_vector_all(int device, const DimensionVector &v);
 extern void (*g_memTrimCache)(int device);                // sibling libmem.so's AresMemTrimCache, when present
 
 class StreamBuffer {

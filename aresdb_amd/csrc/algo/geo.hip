@@ -378,6 +378,12 @@ CGoCallResHandle GeoBatchIntersects(GeoShapeBatch geoShapeBatch, InputVector poi
                                     int device) {
   ARES_ABI_BEGIN(device)
   (void)startCount;  // geo columns are never run-length decoded (query/geo_intersects.cu:160-163)
+  if (indexVectorLength > 0) {
+    const size_t n = static_cast<size_t>(indexVectorLength);
+    mem_note_write(device, outputPredicate, 4 * n * (geoShapeBatch.TotalWords ? geoShapeBatch.TotalWords : 1));
+    mem_note_write(device, indexVector, 4 * n);
+    for (int t = 0; t < numForeignTables && t < 8; t++) mem_note_write(device, recordIDVectors[t], sizeof(RecordID) * n);
+  }
   resHandle.res = int_result(geo_batch_intersects(geoShapeBatch, points, indexVector, indexVectorLength, recordIDVectors,
                                                   numForeignTables, outputPredicate, inOrOut,
                                                   reinterpret_cast<hipStream_t>(cudaStream), device));
@@ -388,6 +394,10 @@ CGoCallResHandle WriteGeoShapeDim(int shapeTotalWords, DimensionOutputVector dim
                                   uint32_t *outputPredicate, void *cudaStream, int device) {
   ARES_ABI_BEGIN(device)
   grouped_note_write(device, dimOut.DimValues, static_cast<size_t>(indexVectorLengthBeforeGeo > 0 ? indexVectorLengthBeforeGeo : 1));
+  if (indexVectorLengthBeforeGeo > 0) {
+    mem_note_write(device, dimOut.DimValues, static_cast<size_t>(indexVectorLengthBeforeGeo));
+    mem_note_write(device, dimOut.DimNulls, static_cast<size_t>(indexVectorLengthBeforeGeo));
+  }
   write_geo_shape_dim(shapeTotalWords, dimOut, indexVectorLengthBeforeGeo, outputPredicate,
                       reinterpret_cast<hipStream_t>(cudaStream));
   ARES_ABI_END("WriteGeoShapeDim")

@@ -154,6 +154,7 @@ extern "C" CGoCallResHandle HashLookup(InputVector input, RecordID *output, uint
     p.numBuckets = static_cast<uint32_t>(hashIndex.numBuckets);
     p.bucketBytes = HASH_BUCKET_SIZE * (8 + 1 + hashIndex.keyBytes);
     const int grid = capped_grid((static_cast<int64_t>(indexVectorLength) + kBlock - 1) / kBlock, 256 * 16);
+    mem_note_write(device, output, sizeof(RecordID) * static_cast<size_t>(indexVectorLength));
     ARES_LAUNCH("hash_lookup_kernel", hash_lookup_kernel, grid, kBlock, stream, p, output, indexVectorLength);
   }
   resHandle.res = int_result(indexVectorLength);

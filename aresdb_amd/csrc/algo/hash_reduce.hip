@@ -183,6 +183,8 @@ extern "C" CGoCallResHandle HashReduce(DimensionVector inputKeys, uint8_t *input
                        static_cast<size_t>(inputKeys.VectorCapacity), outputValues, a, counter.as<uint32_t>());
     uint32_t groups = 0;
     read_back_u32(counter.as<uint32_t>(), &groups, 1, stream);
+    mem_note_dim_rows(device, outputKeys, 0, groups);
+    mem_note_write(device, outputValues, static_cast<size_t>(a.width) * groups);
     resHandle.res = int_result(groups);
   }
   ARES_ABI_END("HashReduce")

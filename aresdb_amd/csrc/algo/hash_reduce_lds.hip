@@ -339,12 +339,16 @@ int hash_reduce_lds(int device, const DimensionVector &inputKeys, const uint8_t 
       generic_merge();
     }
     res = read_result(ws, stream);
+    mem_note_dim_rows(device, outputKeys, 0, res.groups);  // what this attempt emitted
+    mem_note_write(device, outputValues, static_cast<size_t>(a.width) * res.groups);
     if (leanMerge && res.needGeneric && !res.overflow && !(grouped && res.stale)) {
       // a partition holds more groups than one LDS table: the generic multi-round merge over the same records
       hip_check(hipMemsetAsync(ws.outCount, 0, 4 * sizeof(uint32_t), stream), "hipMemsetAsync");
       if (outRanges) hip_check(hipMemsetAsync(outRanges, 0, kRangesBytes, stream), "hipMemsetAsync");
       generic_merge();
       res = read_result(ws, stream);
+      mem_note_dim_rows(device, outputKeys, 0, res.groups);  // what this attempt emitted
+      mem_note_write(device, outputValues, static_cast<size_t>(a.width) * res.groups);
     }
 #undef ARES_HR_MERGE_ND
 #undef ARES_HR_MERGE
@@ -462,6 +466,8 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
       ARES_FUSED_CASE(1) ARES_FUSED_CASE(2) ARES_FUSED_CASE(3) ARES_FUSED_CASE(4)
     }
     res = read_result(ws, stream);
+    mem_note_dim_rows(device, outKeys, 0, res.groups);  // what this attempt emitted
+    mem_note_write(device, outValues, static_cast<size_t>(mw) * res.groups);
     if (leanMerge && res.needGeneric && !res.overflow && !(grouped && res.stale)) {
       // a partition holds more groups than one LDS table: the generic multi-round merge over the same records
       hip_check(hipMemsetAsync(ws.outCount, 0, 4 * sizeof(uint32_t), stream), "hipMemsetAsync");
@@ -477,6 +483,8 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
 #undef ARES_FUSED_REMERGE
       }
       res = read_result(ws, stream);
+      mem_note_dim_rows(device, outKeys, 0, res.groups);  // what this attempt emitted
+      mem_note_write(device, outValues, static_cast<size_t>(mw) * res.groups);
     }
 #undef ARES_FUSED_CASE
     if (grouped && res.stale) {

@@ -453,6 +453,14 @@ extern "C" CGoCallResHandle HyperLogLog(DimensionVector prevDimOut, DimensionVec
   flush_deferred_for_vector(device, curDimOut, nullptr, 0);
   grouped_note_write(device, prevDimOut);
   grouped_note_write(device, curDimOut);
+  {  // the sort / run-max / merge stages rewrite both vectors, their hash and index vectors and both value vectors
+    mem_note_vector_all(device, prevDimOut);
+    mem_note_vector_all(device, curDimOut);
+    const size_t cap = static_cast<size_t>(prevDimOut.VectorCapacity > curDimOut.VectorCapacity ? prevDimOut.VectorCapacity
+                                                                                                    : curDimOut.VectorCapacity);
+    mem_note_write(device, prevValuesOut, 4 * cap);
+    mem_note_write(device, curValuesOut, 4 * cap);
+  }
   resHandle.res = reinterpret_cast<void *>(static_cast<intptr_t>(
       hyperloglog(prevDimOut, curDimOut, prevValuesOut, curValuesOut, prevResultSize, curBatchSize, isLastBatch,
                   hllVectorPtr, hllVectorSizePtr, hllDimRegIDCountPtr, reinterpret_cast<hipStream_t>(cudaStream))));

@@ -656,6 +656,10 @@ extern "C" {
 CGoCallResHandle Sort(DimensionVector keys, int length, void *cudaStream, int device) {
   ARES_ABI_BEGIN(device)
   flush_deferred_for_vector(device, keys, nullptr, 0);  // rows a HashReduce skipped, should a host sort them after all
+  if (length > 0) {
+    mem_note_write(device, keys.HashValues, 8ull * static_cast<size_t>(length));
+    mem_note_write(device, keys.IndexVector, 4ull * static_cast<size_t>(length));
+  }
   sort_impl(keys, length, reinterpret_cast<hipStream_t>(cudaStream));
   ARES_ABI_END("Sort")
 }
@@ -668,6 +672,11 @@ CGoCallResHandle Reduce(DimensionVector inputKeys, uint8_t *inputValues, Dimensi
   grouped_note_write(device, outputKeys);
   grouped_note_write(device, outputValues, static_cast<size_t>(valueBytes) * (length > 0 ? length : 0));
   drop_skipped_outputs(device, outputKeys.DimValues, 1, outputValues, static_cast<size_t>(valueBytes) * (length > 0 ? length : 0));
+  if (length > 0) {  // (at most `length` groups; the identity fill covers `length` values)
+    mem_note_dim_rows(device, outputKeys, 0, static_cast<size_t>(length));
+    mem_note_write(device, outputKeys.IndexVector, 4ull * static_cast<size_t>(length));
+    mem_note_write(device, outputValues, static_cast<size_t>(valueBytes) * static_cast<size_t>(length));
+  }
   resHandle.res = int_result(reduce_impl(inputKeys, inputValues, outputKeys, outputValues, valueBytes, length, aggFunc,
                                          reinterpret_cast<hipStream_t>(cudaStream)));
   ARES_ABI_END("Reduce")
@@ -678,6 +687,7 @@ CGoCallResHandle Expand(DimensionVector inputKeys, DimensionVector outputKeys, u
   ARES_ABI_BEGIN(device)
   flush_deferred_for_vector(device, inputKeys, nullptr, 0);
   grouped_note_write(device, outputKeys);
+  mem_note_vector_all(device, outputKeys);
   resHandle.res = int_result(expand_impl(inputKeys, outputKeys, baseCounts, indexVector, indexVectorLen,
                                          outputOccupiedLen, reinterpret_cast<hipStream_t>(cudaStream)));
   ARES_ABI_END("Expand")

@@ -1225,6 +1225,10 @@ bool defer_available() {
       setAux(&aux);
     }
     g_memTrimCache = reinterpret_cast<void (*)(int)>(dlsym(h, "AresMemTrimCache"));
+    g_memNoteWrite = reinterpret_cast<void (*)(int, const void *, size_t)>(dlsym(h, "AresMemNoteWrite"));
+    auto track = reinterpret_cast<void (*)()>(dlsym(h, "AresMemEnableWriteTracking"));
+    if (g_memNoteWrite && track) track();  // from here on every kernel output is reported
+    else g_memNoteWrite = nullptr;
     return true;
   }();
   return ok;
@@ -1309,6 +1313,7 @@ void run_compaction(const uint32_t *idx) {
   if (it == t_state->compactions.end()) return;
   const PendingCompact c = it->second;
   t_state->compactions.erase(it);
+  mem_note_write(c.device, c.idx, 4ull * static_cast<size_t>(c.n));
   CompactWorkspace cw;
   cw.ticket = c.ticket;
   cw.error = c.error;
@@ -1352,6 +1357,10 @@ void launch_queue(hipStream_t stream, PendingQueue &q, bool inOrder = false) {
     ARES_LAUNCH("transform_multi_kernel", transform_multi_kernel, capped_grid(tiles, 256 * 16), kBlock, stream, q.jobs, q.idx,
                 q.n, numQuads);
   }
+  if (g_memNoteWrite) {
+    const int device = current_device();
+    for (const ByteRange &w : q.writes) mem_note_write(device, w.lo, static_cast<size_t>(w.hi - w.lo));
+  }
   q.jobs.count = 0;
   q.reads.clear();
   q.writes.clear();
@@ -1384,6 +1393,7 @@ bool materialize_limbo(int device, const ByteRange *range, ReleaseSet *released)
 
 // caller holds the device's DeferLock and has selected the device
 static void launch_init_index(uint32_t *indexVector, uint32_t start, int n, hipStream_t stream) {
+  if (n > 0) mem_note_write(current_device(), indexVector, 4ull * static_cast<size_t>(n));
   if (n <= 0) return;
   const int64_t quads = (static_cast<int64_t>(n) + 3) / 4;
   const int grid = capped_grid((quads + kBlock - 1) / kBlock, 256 * 16);
@@ -1654,6 +1664,13 @@ static void launch_array(const ArrayD &a, const SinkD &s, int n, hipStream_t str
   ARES_LAUNCH("array_transform_kernel", array_transform_kernel, grid, kBlock, stream, a, s, n);
 }
 
+// reports what a transform launched NOW writes (deferred ones report when their queue is launched)
+static void note_sink(int device, const SinkD &s, int n) {
+  if (n <= 0) return;
+  mem_note_write(device, s.values, static_cast<size_t>(s.width) * n);
+  if (s.nulls) mem_note_write(device, s.nulls, static_cast<size_t>(n));
+}
+
 static int run_transform(const InputVector *ins, int arity, const OutputVector &output, uint32_t *indexVector,
                          int n, uint32_t *baseCounts, uint32_t startCount, int functor, hipStream_t stream, int device) {
   if (n <= 0) {
@@ -1672,6 +1689,7 @@ static int run_transform(const InputVector *ins, int arity, const OutputVector &
     }
     flush_deferred(device);
     launch_array(a, s, n, stream);
+    note_sink(device, s, n);
     return n;
   }
   EvalParams p;
@@ -1690,6 +1708,7 @@ static int run_transform(const InputVector *ins, int arity, const OutputVector &
   // root outputs of the hot shape are held back and fused with their siblings (same index vector)
   if (fast && (s.type == SINK_DIM || s.type == SINK_MEASURE) && defer_transform(device, stream, f, s, n, p.a.length)) return n;
   flush_deferred(device);
+  note_sink(device, s, n);
   if (fast) {
     f.pad = s.type == SINK_MEASURE ? 0 : static_cast<int>(reinterpret_cast<uintptr_t>(s.nulls) & 3);
     const int64_t numQuads = (static_cast<int64_t>(n) + f.pad + 3) / 4;
@@ -1727,6 +1746,7 @@ static int run_filter(const InputVector *ins, int arity, uint32_t *indexVector, 
     build_params(ins, arity, stream, indexVector, baseCounts, startCount, functor, p, temps);
   }
   p.needRow = 1;
+  mem_note_write(device, pred, static_cast<size_t>(n));
   // a filter of the hot shape consumes a not-yet-written iota index vector directly; everything
   // else that is pending on the device is launched first
   bool virtualIdx = false;
@@ -1801,6 +1821,8 @@ static int run_filter(const InputVector *ins, int arity, uint32_t *indexVector, 
     }
     const int cgrid = capped_grid((tiles + kTilesPerTicket - 1) / kTilesPerTicket, 256 * 8);
     if (virtualIdx) f.idx = nullptr;
+    mem_note_write(device, indexVector, 4ull * static_cast<size_t>(n));
+    for (int t = 0; t < numForeignTables; t++) mem_note_write(device, recordIDVectors[t], 8ull * static_cast<size_t>(n));
     for (int pass = 0; pass < passes; pass++) {
       CompactWorkspace cw;
       cw.ticket = tickets + pass;
@@ -1826,6 +1848,8 @@ static int run_filter(const InputVector *ins, int arity, uint32_t *indexVector, 
     DeferLock lock(device);
     launch_init_index(indexVector, 0, n, stream);
   }
+  mem_note_write(device, indexVector, 4ull * static_cast<size_t>(n));
+  for (int t = 0; t < numForeignTables; t++) mem_note_write(device, recordIDVectors[t], 8ull * static_cast<size_t>(n));
   int numTiles = static_cast<int>((static_cast<int64_t>(n) + kFilterTile - 1) / kFilterTile);
   int fastTiles = 0;
   if (fast) {
@@ -2286,6 +2310,11 @@ __global__ __launch_bounds__(kBlock) void pred_count_kernel(const uint8_t *pred,
 int compact_by_predicate(const uint8_t *pred, uint32_t *indexVector, RecordID **recordIDVectors, int numForeignTables,
                          int n, hipStream_t stream) {
   if (n <= 0) return 0;
+  {
+    const int device = current_device();
+    mem_note_write(device, indexVector, 4ull * static_cast<size_t>(n));
+    for (int t = 0; t < numForeignTables; t++) mem_note_write(device, recordIDVectors[t], 8ull * static_cast<size_t>(n));
+  }
   const int pad = static_cast<int>(reinterpret_cast<uintptr_t>(pred) & 3);
   const int64_t numQuads = (static_cast<int64_t>(n) + pad + 3) / 4;
   const int tiles = static_cast<int>((numQuads + kBlock * kPQ - 1) / (kBlock * kPQ));

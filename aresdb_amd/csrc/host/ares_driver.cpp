@@ -67,6 +67,12 @@ struct AbiLibrary {
   decltype(&::AsyncCopyDeviceToDevice) AsyncCopyDeviceToDevice;
   decltype(&::AsyncCopyDeviceToHost) AsyncCopyDeviceToHost;
   decltype(&::AsyncCopyHostToDevice) AsyncCopyHostToDevice;
+  // optional (include/ares_extensions.h): libmem.so clears a freed block only where something wrote, so
+  // whatever writes DeviceAllocate memory behind its back — a collective receiving into it — says so
+  void (*NoteWrite)(int, const void *, size_t) = nullptr;
+  void noteWrite(int device, const void *p, size_t bytes) const {
+    if (NoteWrite) NoteWrite(device, p, bytes);
+  }
 
   template <typename F>
   void bind(void *handle, const char *name, F &fn) {
@@ -98,6 +104,7 @@ struct AbiLibrary {
     bind(memHandle, "AsyncCopyDeviceToDevice", AsyncCopyDeviceToDevice);
     bind(memHandle, "AsyncCopyDeviceToHost", AsyncCopyDeviceToHost);
     bind(memHandle, "AsyncCopyHostToDevice", AsyncCopyHostToDevice);
+    NoteWrite = reinterpret_cast<decltype(NoteWrite)>(dlsym(memHandle, "AresMemNoteWrite"));
   }
   ~AbiLibrary() {
     if (algoHandle) dlclose(algoHandle);
@@ -904,6 +911,7 @@ bool select_device(int device, std::string *why) {
 void gather_words(AresQuery *q, AresComm *c, const void *mine, void *all, size_t bytes) {
   uint8_t *send = q->alloc(bytes), *recv = q->alloc(bytes * c->nranks);
   check(q->lib->AsyncCopyHostToDevice(send, const_cast<void *>(mine), bytes, q->stream, q->device));
+  q->lib->noteWrite(q->device, recv, bytes * c->nranks);
   if (c->allGather(c->user, send, recv, bytes, q->stream) != 0) throw AbiError("all-gather of the partial sizes failed");
   check(q->lib->AsyncCopyDeviceToHost(all, recv, bytes * c->nranks, q->stream, q->device));
   q->wait();
@@ -1019,6 +1027,7 @@ int AresQueryMergeShards(AresQuery *q, AresComm *c, char *err, int errLen) {
     }
     if (g) q->d2d(packed + sect[2 * nd], q->measureVec[0], static_cast<size_t>(g) * mb);
     // 3. one exchange
+    q->lib->noteWrite(q->device, gathered, packedBytes * world);
     if (c->allGather(c->user, packed, gathered, packedBytes, q->stream) != 0) throw AbiError("all-gather of the partial group tables failed");
     // 4. append every rank's partial into fresh result vectors and re-reduce
     q->wait();
@@ -1161,6 +1170,7 @@ int AresQueryMergeShardsPartitioned(AresQuery *q, AresComm *c, int64_t *totalGro
       q->d2d(block + sect[2 * nd], q->measureVec[0] + split[r] * mb, static_cast<size_t>(mine[r]) * mb);
     }
     // 5. the exchange
+    q->lib->noteWrite(q->device, arrived, recvTotal);
     if (c->allToAll) {
       if (c->allToAll(c->user, packed, sendBytes.data(), sendOff.data(), arrived, recvBytes.data(), recvOff.data(), q->stream) != 0)
         throw AbiError("all-to-all of the group table blocks failed");
@@ -1169,6 +1179,7 @@ int AresQueryMergeShardsPartitioned(AresQuery *q, AresComm *c, int64_t *totalGro
       uint8_t *one = q->alloc(pad), *every = q->alloc(pad * world);
       for (int r = 0; r < world; r++) {
         if (sendBytes[r]) q->d2d(one, packed + sendOff[r], sendBytes[r]);
+        q->lib->noteWrite(q->device, every, pad * world);
         if (c->allGather(c->user, one, every, pad, q->stream) != 0) throw AbiError("all-gather of the group table blocks failed");
         if (r == c->rank)
           for (int src = 0; src < world; src++)

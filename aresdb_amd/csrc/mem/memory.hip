@@ -99,7 +99,9 @@ inline uintptr_t notify_free(int device, void *ptr, size_t bytes) {
 }
 
 std::atomic<const AresMemAuxHooks *> g_aux{nullptr};
+void note_write(int device, const void *ptr, size_t bytes);  // below: the written ranges of live blocks
 inline void notify_write(int device, const void *ptr, size_t bytes) {
+  note_write(device, ptr, bytes);
   const AresMemAuxHooks *h = g_aux.load(std::memory_order_acquire);
   if (h && h->size >= offsetof(AresMemAuxHooks, on_write) + sizeof(h->on_write) && h->on_write) h->on_write(device, ptr, bytes);
 }
@@ -150,6 +152,21 @@ struct ParkedBlock {
 
 constexpr size_t kWaitForParkedFrom = size_t(16) << 20;  // bytes; see pool_alloc
 
+// Write tracking.  DeviceAllocate hands out cleared memory, and the clearing happens when a block is parked;
+// a block (or the part of one) that nothing wrote to since it was last cleared is still clear.  Every writer
+// reports what it writes — libmem's own copies and fills here, libalgorithm.so its kernels' outputs through
+// AresMemNoteWrite (it switches tracking on with AresMemEnableWriteTracking once it does; without that call a
+// freed block counts as written all over) — so parking a block clears only the ranges written: the Go host's
+// per-batch index vector that a fused batch never materialises, and the unused tails of a query's result
+// vectors (sized for "every row a new group"), are most of the 9 GB per 1 B-row step that were cleared before.
+constexpr size_t kMaxDirtyRanges = 24;
+struct LiveBlock {
+  size_t rounded = 0;
+  bool allDirty = false;
+  std::vector<std::pair<size_t, size_t>> dirty;  // [lo, hi) byte ranges, disjoint, sorted
+};
+std::atomic<bool> g_writeTracking{false};
+
 struct DeviceState {
   std::once_flag once;
   hipStream_t allocStream = nullptr;
@@ -157,7 +174,7 @@ struct DeviceState {
   std::mutex mu;
   std::vector<hipStream_t> streams;                      // streams created through CreateCudaStream
   std::map<size_t, std::vector<ParkedBlock>> bins;       // rounded size -> parked blocks
-  std::unordered_map<void *, size_t> live;               // allocation -> rounded size
+  std::map<uintptr_t, LiveBlock> live;                   // allocation -> rounded size + what was written to it
   std::vector<hipEvent_t> freeEvents;
   size_t parkedBytes = 0;
   // freed by the host while deferred work of one stream (the tag) still reads them (AresMemReleaseHeld)
@@ -247,6 +264,31 @@ void count_driver_allocation(size_t bytes) {
   total += static_cast<long>(bytes);
 }
 
+// ARES_MEM_VERIFY_CLEAN=1 (tests): every block taken from the cache as "cleared" is checked on the device —
+// a writer that did not report what it wrote shows up as an abort here instead of as stale data in a
+// DeviceAllocate result.
+__global__ void verify_clear_kernel(const uint32_t *p, size_t words, unsigned int *nonzero) {
+  unsigned int found = 0;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < words; i += static_cast<size_t>(gridDim.x) * blockDim.x)
+    found |= p[i] != 0u;
+  if (found) atomicOr(nonzero, 1u);
+}
+void verify_clear(DeviceState *st, void *ptr, size_t rounded) {
+  static const bool on = [] {
+    const char *e = getenv("ARES_MEM_VERIFY_CLEAN");
+    return e && e[0] == '1';
+  }();
+  if (!on) return;
+  static unsigned int *flag = nullptr;
+  if (!flag && hipHostMalloc(reinterpret_cast<void **>(&flag), sizeof(unsigned int), hipHostMallocMapped) != hipSuccess) return;
+  *flag = 0;
+  hipLaunchKernelGGL(verify_clear_kernel, dim3(1024), dim3(256), 0, st->allocStream, static_cast<const uint32_t *>(ptr), rounded / 4, flag);
+  if (hipStreamSynchronize(st->allocStream) != hipSuccess || *flag) {
+    fprintf(stderr, "libmem: a %zu-byte block handed out as cleared holds data (a writer did not report its writes)\n", rounded);
+    abort();
+  }
+}
+
 hipError_t pool_alloc(DeviceState *st, void **p, size_t bytes, bool zero) {
   if (bytes == 0) bytes = 1;
   if (!use_pool()) {
@@ -311,24 +353,65 @@ hipError_t pool_alloc(DeviceState *st, void **p, size_t bytes, bool zero) {
   }
   {
     std::lock_guard<std::mutex> lock(st->mu);
-    st->live[ptr] = rounded;
+    LiveBlock &b = st->live[reinterpret_cast<uintptr_t>(ptr)];
+    b.rounded = rounded;
+    b.dirty.clear();
+    b.allDirty = !zero;  // deviceMalloc: libalgorithm.so's own result buffers (HyperLogLog) — their writers do not report
   }
   *p = ptr;
-  if (zero && !cleared) {
-    hipError_t e = hipMemsetAsync(ptr, 0, bytes, st->allocStream);
+  if (zero && cleared) verify_clear(st, ptr, rounded);
+  if (zero && !cleared) {  // (the whole block: what lies behind `bytes` is handed out by a later, larger request)
+    hipError_t e = hipMemsetAsync(ptr, 0, rounded, st->allocStream);
     if (e != hipSuccess) return e;
     return hipStreamSynchronize(st->allocStream);
   }
   return hipSuccess;
 }
 
+// caller holds st->mu.  Records [ptr, ptr + bytes) as written in the live block that contains ptr.
+void note_write_locked(DeviceState *st, const void *ptr, size_t bytes) {
+  if (bytes == 0 || st->live.empty()) return;
+  const uintptr_t a = reinterpret_cast<uintptr_t>(ptr);
+  auto it = st->live.upper_bound(a);
+  if (it == st->live.begin()) return;
+  --it;
+  LiveBlock &b = it->second;
+  if (a >= it->first + b.rounded || b.allDirty) return;
+  size_t lo = a - it->first, hi = lo + bytes < b.rounded ? lo + bytes : b.rounded;
+  std::vector<std::pair<size_t, size_t>> &d = b.dirty;
+  size_t i = 0;
+  while (i < d.size() && d[i].second < lo) i++;
+  size_t j = i;
+  while (j < d.size() && d[j].first <= hi) {
+    lo = d[j].first < lo ? d[j].first : lo;
+    hi = d[j].second > hi ? d[j].second : hi;
+    j++;
+  }
+  d.erase(d.begin() + i, d.begin() + j);
+  d.insert(d.begin() + i, {lo, hi});
+  if (d.size() > kMaxDirtyRanges) {
+    b.allDirty = true;
+    d.clear();
+  }
+}
+
+void note_write(int device, const void *ptr, size_t bytes) {
+  if (device < 0 || device >= kMaxDevices || !use_pool()) return;
+  DeviceState *st = &g_devices[device];
+  std::lock_guard<std::mutex> lock(st->mu);
+  note_write_locked(st, ptr, bytes);
+}
+
 hipError_t pool_free(DeviceState *st, void *p) {
   if (p == nullptr) return hipSuccess;
   if (!use_pool()) return hipFree(p);
   std::lock_guard<std::mutex> lock(st->mu);
-  auto it = st->live.find(p);
+  auto it = st->live.find(reinterpret_cast<uintptr_t>(p));
   if (it == st->live.end()) return hipFree(p);  // not ours (allocated before the pool was switched on)
-  const size_t rounded = it->second;
+  const size_t rounded = it->second.rounded;
+  std::vector<std::pair<size_t, size_t>> written;
+  if (it->second.allDirty || !g_writeTracking.load(std::memory_order_acquire)) written.emplace_back(0, rounded);
+  else written.swap(it->second.dirty);
   st->live.erase(it);
   ParkedBlock b;
   b.ptr = p;
@@ -353,10 +436,13 @@ hipError_t pool_free(DeviceState *st, void *p) {
     recycle_events(st, b);
     return hipFree(p);
   }
-  {  // clear the block behind its fence, off every query's critical path
+  if (written.empty()) {
+    b.zeroed = true;  // nothing wrote to it since it was cleared
+  } else {  // clear what was written behind the block's fence, off every query's critical path
     bool okFill = true;
     for (hipEvent_t e : b.fence) okFill = okFill && hipStreamWaitEvent(st->allocStream, e, 0) == hipSuccess;
-    okFill = okFill && hipMemsetAsync(p, 0, rounded, st->allocStream) == hipSuccess;
+    for (const auto &r : written)
+      okFill = okFill && hipMemsetAsync(static_cast<uint8_t *>(p) + r.first, 0, r.second - r.first, st->allocStream) == hipSuccess;
     if (okFill && fence_on(st->allocStream) == hipSuccess) b.zeroed = true;
     else (void)hipGetLastError();
   }
@@ -380,6 +466,12 @@ void AresMemSetDeferralHooks(const AresDeferralHooks *hooks) {
 
 void AresMemSetAuxHooks(const AresMemAuxHooks *hooks) { g_aux.store(hooks, std::memory_order_release); }
 
+// Write tracking (see LiveBlock): libalgorithm.so reports what its kernels write; anything else that writes
+// device memory obtained from this library without going through its copy / fill entry points (a collective
+// library receiving into it, say) reports it the same way.
+void AresMemNoteWrite(int device, const void *ptr, size_t bytes) { note_write(device, ptr, bytes); }
+void AresMemEnableWriteTracking(void) { g_writeTracking.store(true, std::memory_order_release); }
+
 // What the host currently owns on `device` (the Go host keeps the same books itself and asserts they
 // return to zero after every query, query/aql_processor_test.go:230-231): bytes of live DeviceAllocate /
 // deviceMalloc blocks (rounded to their size bins), blocks kept aside for deferred work, bytes parked
@@ -389,13 +481,13 @@ void AresMemStats(int device, size_t *liveBytes, size_t *liveBlocks, size_t *hel
   if (device >= 0 && device < kMaxDevices) {
     DeviceState *st = &g_devices[device];
     std::lock_guard<std::mutex> lock(st->mu);
-    for (auto &kv : st->live) lb += kv.second;
+    for (auto &kv : st->live) lb += kv.second.rounded;
     ln = st->live.size();
     hn = st->held.size();
     for (auto &h : st->held) {  // freed by the host, kept aside: not the host's any more
-      auto it = st->live.find(h.first);
+      auto it = st->live.find(reinterpret_cast<uintptr_t>(h.first));
       if (it != st->live.end()) {
-        lb -= it->second;
+        lb -= it->second.rounded;
         ln--;
       }
     }
@@ -526,8 +618,8 @@ CGoCallResHandle DeviceAllocate(size_t bytes, int device) {
 size_t allocation_size(DeviceState *st, void *p) {
   if (use_pool()) {
     std::lock_guard<std::mutex> lock(st->mu);
-    auto it = st->live.find(p);
-    if (it != st->live.end()) return it->second;
+    auto it = st->live.find(reinterpret_cast<uintptr_t>(p));
+    if (it != st->live.end()) return it->second.rounded;
   }
   size_t bytes = 0;
   if (hipMemPtrGetInfo(p, &bytes) != hipSuccess) {

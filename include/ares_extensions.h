@@ -84,6 +84,15 @@ typedef struct {
 } AresMemAuxHooks;
 void AresMemSetAuxHooks(const AresMemAuxHooks *hooks); /* exported by libmem.so */
 void AresMemTrimCache(int device);                     /* exported by libmem.so */
+/* Write tracking.  DeviceAllocate hands out cleared memory; libmem.so clears a block when it is freed, and
+ * only the byte ranges written since the block was last cleared.  libmem.so sees its own copies and fills;
+ * libalgorithm.so reports the outputs of its kernels with AresMemNoteWrite and switches tracking on with
+ * AresMemEnableWriteTracking (never called: a freed block counts as written all over).  A host component
+ * that lets anything else write into DeviceAllocate memory (a collective library receiving into it) reports
+ * those writes with AresMemNoteWrite too. */
+void AresMemNoteWrite(int device, const void *ptr, size_t bytes);
+void AresMemEnableWriteTracking(void);
+
 /* Books of libmem.so for one device: bytes / number of blocks the host holds (DeviceAllocate, deviceMalloc;
  * held blocks were freed by the host but are kept aside for deferred work and are NOT counted as live),
  * blocks kept aside, bytes parked in the cache.  Any pointer may be NULL. */

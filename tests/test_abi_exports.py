@@ -72,7 +72,7 @@ def test_extension_symbols_are_exported_by_the_library_that_declares_them():
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     declared = set(re.findall(r"^(?:void|size_t|CGoCallResHandle)\s+(\w+)\s*\(", src, flags=re.M))
     in_mem = {"AresMemSetFlushHook", "AresMemSetDeferralHooks", "AresMemReleaseHeld", "AresMemSetAuxHooks",
-              "AresMemTrimCache", "AresMemStats"}
+              "AresMemTrimCache", "AresMemStats", "AresMemNoteWrite", "AresMemEnableWriteTracking"}
     assert in_mem <= declared and {"AresFlushDeferred", "AresProfilerEnable", "AresProfilerReport",
                                    "AresFusedFilterHashReduce"} <= declared
     la, lm = C.CDLL(algo, mode=os.RTLD_NOW | os.RTLD_LOCAL), C.CDLL(mem, mode=os.RTLD_NOW | os.RTLD_LOCAL)

@@ -199,3 +199,71 @@ def test_two_alternating_streams_without_filters_match_the_oracle():
         smoke.compare_results(got, want)
     for s in streams:
         be.call("DestroyCudaStream", s, 0)
+
+
+@pytest.mark.gpu
+def test_blocks_written_by_kernels_come_back_zeroed():
+    """Write tracking (include/ares_extensions.h, AresMemNoteWrite): libmem clears a freed block only where
+    something wrote, and libalgorithm's kernels write without libmem seeing it — every entry point reports
+    its outputs.  Blocks of unusual sizes (their own cache bins) are written by kernels only, freed, and the
+    same blocks must come back cleared: index vector (eager InitIndexVector, compaction), predicate vector,
+    scratch space, RecordIDs, Sort's hash / index vectors, Reduce's and HashReduce's output vectors."""
+    be = H.hip_backend()
+    n = 70001
+
+    def fresh(nbytes):
+        return be.device_alloc(nbytes)
+
+    def all_zero(nbytes, seen):
+        p = be.device_alloc(nbytes)
+        got = np.empty(nbytes, np.uint8)
+        be.d2h(got.ctypes.data_as(C.c_void_p), p, nbytes)
+        be.wait()
+        reused = p in seen
+        be.device_free(p)
+        return reused, not got.any()
+
+    sizes = {"idx": 4 * n + 13, "pred": n + 7, "scratch": 5 * n + 3, "rid": 8 * n + 5, "hash": 8 * n + 21, "idx2": 4 * n + 29,
+             "dims_in": 5 * n + 31, "dims_out": 5 * n + 37, "meas_in": 4 * n + 41, "meas_out": 4 * n + 43, "dims_h": 5 * n + 47,
+             "meas_h": 4 * n + 53}
+    blk = {k: fresh(v) for k, v in sizes.items()}
+    rng = np.random.default_rng(5)
+    col = H.Column(be, abi.Uint32, rng.integers(0, 50, n).astype(np.uint32))
+    # index vector written eagerly (a copy of it forces the deferred iota out), filter writes predicate + compacts
+    be.call("InitIndexVector", blk["idx"], 0, n, None, 0)
+    kept = be.call("BinaryFilter", col.input(), H.const_int(25), blk["idx"], blk["pred"], n, None, 0, None, 0, abi.LessThan, None, 0)
+    tmp = np.empty(4 * kept, np.uint8)
+    be.d2h(tmp.ctypes.data_as(C.c_void_p), blk["idx"], 4 * kept)  # reads the vector: the lazy compaction runs
+    # a transform into scratch space
+    sc = abi.OutputVector()
+    sc.Vector.ScratchSpace.Values, sc.Vector.ScratchSpace.NullsOffset, sc.Vector.ScratchSpace.DataType = blk["scratch"], 4 * n, abi.Uint32
+    sc.Type = abi.ScratchSpaceOutput
+    be.call("BinaryTransform", col.input(), H.const_int(3), sc, None, n, None, 0, abi.Plus, None, 0)
+    # dimension + measure vectors: transform into them, Sort + Reduce and HashReduce out of them
+    def dv(ptr, hashes=None, index=None):
+        v = abi.DimensionVector()
+        v.DimValues, v.HashValues, v.IndexVector, v.VectorCapacity = ptr, hashes, index, n
+        for i, c in enumerate((0, 0, 1, 0, 0)):
+            v.NumDimsPerDimWidth[i] = c
+        return v
+    be.call("UnaryTransform", col.input(), H.dimension_output(blk["dims_in"], blk["dims_in"] + 4 * n, abi.Uint32), None, n, None, 0,
+            abi.Noop, None, 0)
+    be.call("UnaryTransform", col.input(), H.measure_output(blk["meas_in"], abi.Uint32, abi.AGGR_SUM_UNSIGNED), None, n, None, 0,
+            abi.Noop, None, 0)
+    be.call("InitIndexVector", blk["idx2"], 0, n, None, 0)
+    be.call("Sort", dv(blk["dims_in"], blk["hash"], blk["idx2"]), n, None, 0)
+    g1 = be.call("Reduce", dv(blk["dims_in"], blk["hash"], blk["idx2"]), blk["meas_in"], dv(blk["dims_out"], None, blk["rid"]),
+                 blk["meas_out"], 4, n, abi.AGGR_SUM_UNSIGNED, None, 0)
+    g2 = be.call("HashReduce", dv(blk["dims_in"]), blk["meas_in"], dv(blk["dims_h"]), blk["meas_h"], 4, n, abi.AGGR_SUM_UNSIGNED, None, 0)
+    assert g1 == g2 == 50
+    be.wait()
+    seen = set(blk.values())
+    for p in blk.values():
+        be.device_free(p)
+    col.free()
+    reused = 0
+    for k, v in sizes.items():
+        r, clean = all_zero(v, seen)
+        assert clean, f"the block that served as {k} came back with data"
+        reused += r
+    assert reused >= len(sizes) // 2  # (the cache did hand the same blocks out again)

@@ -215,13 +215,22 @@ def test_blocks_written_by_kernels_come_back_zeroed():
         return be.device_alloc(nbytes)
 
     def all_zero(nbytes, seen):
-        p = be.device_alloc(nbytes)
-        got = np.empty(nbytes, np.uint8)
-        be.d2h(got.ctypes.data_as(C.c_void_p), p, nbytes)
-        be.wait()
-        reused = p in seen
-        be.device_free(p)
-        return reused, not got.any()
+        """allocates from the size's bin until one of OUR blocks comes back (other tests of the process may
+        have parked blocks of the same bin before): every block on the way must be cleared"""
+        taken, reused, clean = [], False, True
+        for _ in range(64):
+            p = be.device_alloc(nbytes)
+            taken.append(p)
+            got = np.empty(nbytes, np.uint8)
+            be.d2h(got.ctypes.data_as(C.c_void_p), p, nbytes)
+            be.wait()
+            clean = clean and not got.any()
+            if p in seen:
+                reused = True
+                break
+        for p in taken:
+            be.device_free(p)
+        return reused, clean
 
     sizes = {"idx": 4 * n + 13, "pred": n + 7, "scratch": 5 * n + 3, "rid": 8 * n + 5, "hash": 8 * n + 21, "idx2": 4 * n + 29,
              "dims_in": 5 * n + 31, "dims_out": 5 * n + 37, "meas_in": 4 * n + 41, "meas_out": 4 * n + 43, "dims_h": 5 * n + 47,
@@ -266,4 +275,4 @@ def test_blocks_written_by_kernels_come_back_zeroed():
         r, clean = all_zero(v, seen)
         assert clean, f"the block that served as {k} came back with data"
         reused += r
-    assert reused >= len(sizes) // 2  # (the cache did hand the same blocks out again)
+    assert reused >= len(sizes) // 2  # (the cache did hand our blocks out again)

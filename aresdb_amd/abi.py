@@ -246,6 +246,22 @@ class Backend:
     def call(self, sym, *args):
         return _check(getattr(self, "_" + sym)(*args))
 
+    def mem_driver_calls(self, device=0):
+        """{mallocs, frees, trims}: driver calls libmem.so's block cache could not avoid (None: not this libmem)."""
+        if not hasattr(self._mem, "AresMemDriverCalls"):
+            return None
+        m, f, t = C.c_size_t(0), C.c_size_t(0), C.c_size_t(0)
+        self._mem.AresMemDriverCalls.argtypes = [C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        self._mem.AresMemDriverCalls.restype = None
+        self._mem.AresMemDriverCalls(device, C.byref(m), C.byref(f), C.byref(t))
+        return {"mallocs": m.value, "frees": f.value, "trims": t.value}
+
+    def reload_env(self):
+        """The library's latched environment switches (ARES_HASH_REDUCE, ...) are read again on next use."""
+        if hasattr(self._algo, "AresReloadEnv"):
+            self._algo.AresReloadEnv.argtypes, self._algo.AresReloadEnv.restype = [], None
+            self._algo.AresReloadEnv()
+
     def flags(self):
         return self._mem.GetFlags()
 

@@ -8,6 +8,8 @@
 
 namespace ares {
 
+std::atomic<uint32_t> g_envGeneration{1};
+
 namespace {
 struct PinnedSlot {
   uint64_t *ptr = nullptr;
@@ -48,6 +50,10 @@ struct StreamCache {
 };
 std::mutex g_cacheMutex;
 std::map<std::pair<int, hipStream_t>, StreamCache> g_caches;
+// blocks of destroyed streams (DestroyCudaStream synchronised the stream first: nothing enqueued touches them any
+// more), per device: any stream of the device may take them.  The Go host makes and destroys two streams per
+// query — its temporaries carry over to the next query instead of going through hipFree / hipMalloc.
+std::map<int, StreamCache> g_orphans;
 std::map<void *, size_t> g_blockSize;  // every block handed out or cached -> rounded size
 size_t g_cachedBytes = 0;
 
@@ -61,15 +67,17 @@ size_t cache_bin(size_t bytes) {
 // frees every cached block (all streams of all devices); the caller holds g_cacheMutex.  hipFree
 // waits for outstanding work, so blocks still referenced by enqueued kernels stay valid until then.
 void drop_all_cached() {
-  for (auto &kv : g_caches) {
-    for (auto &bin : kv.second.bins)
+  auto drop = [](StreamCache &c) {
+    for (auto &bin : c.bins)
       for (void *p : bin.second) {
         (void)hipFree(p);
         g_blockSize.erase(p);
       }
-    kv.second.bins.clear();
-    kv.second.bytes = 0;
-  }
+    c.bins.clear();
+    c.bytes = 0;
+  };
+  for (auto &kv : g_caches) drop(kv.second);
+  for (auto &kv : g_orphans) drop(kv.second);
   g_cachedBytes = 0;
 }
 }  // namespace
@@ -104,24 +112,20 @@ void mem_note_vector_all(int device, const DimensionVector &v) {
 }
 void (*g_memTrimCache)(int) = nullptr;  // AresMemTrimCache of the sibling libmem.so (transform.hip resolves it)
 
-// A stream is being destroyed (the host has synchronised it): its cached temporaries go back to the
-// driver — the Go host creates and destroys two streams per query, blocks cached under dead handles
-// would only pile up.
+// A stream is being destroyed (the host has synchronised it): its cached temporaries become the device's —
+// the Go host creates and destroys two streams per query, blocks cached under dead handles would only pile up,
+// and giving them back to the driver costs a device-synchronising hipFree each plus a hipMalloc in the next query.
 void stream_cache_purge(int device, hipStream_t stream) {
-  std::vector<void *> blocks;
-  {
-    std::lock_guard<std::mutex> lock(g_cacheMutex);
-    auto it = g_caches.find({device, stream});
-    if (it == g_caches.end()) return;
-    for (auto &bin : it->second.bins)
-      for (void *p : bin.second) {
-        blocks.push_back(p);
-        g_blockSize.erase(p);
-      }
-    g_cachedBytes -= it->second.bytes;
-    g_caches.erase(it);
+  std::lock_guard<std::mutex> lock(g_cacheMutex);
+  auto it = g_caches.find({device, stream});
+  if (it == g_caches.end()) return;
+  StreamCache &o = g_orphans[device];
+  for (auto &bin : it->second.bins) {
+    std::vector<void *> &dst = o.bins[bin.first];
+    dst.insert(dst.end(), bin.second.begin(), bin.second.end());
   }
-  for (void *p : blocks) (void)hipFree(p);
+  o.bytes += it->second.bytes;
+  g_caches.erase(it);
 }
 
 // gives every cached block of the device back to the driver (the sibling library ran out of memory)
@@ -139,6 +143,16 @@ void stream_cache_trim(int device) {
       kv.second.bins.clear();
       g_cachedBytes -= kv.second.bytes;
       kv.second.bytes = 0;
+    }
+    auto o = g_orphans.find(device);
+    if (o != g_orphans.end()) {
+      for (auto &bin : o->second.bins)
+        for (void *p : bin.second) {
+          blocks.push_back(p);
+          g_blockSize.erase(p);
+        }
+      g_cachedBytes -= o->second.bytes;
+      g_orphans.erase(o);
     }
   }
   for (void *p : blocks) (void)hipFree(p);
@@ -158,6 +172,17 @@ void *stream_alloc(size_t bytes, hipStream_t stream) {
       c.bytes -= rounded;
       g_cachedBytes -= rounded;
       return p;
+    }
+    auto o = g_orphans.find(device);
+    if (o != g_orphans.end()) {
+      auto ob = o->second.bins.find(rounded);
+      if (ob != o->second.bins.end() && !ob->second.empty()) {
+        void *p = ob->second.back();
+        ob->second.pop_back();
+        o->second.bytes -= rounded;
+        g_cachedBytes -= rounded;
+        return p;
+      }
     }
   }
   void *p = nullptr;
@@ -191,8 +216,15 @@ void stream_release(void *ptr, hipStream_t stream) {
   c.bytes += rounded;
   g_cachedBytes += rounded;
   // keep the cache below an eighth of the device: drop everything when it outgrows that
-  size_t freeB = 0, totalB = 0;
-  if (g_cachedBytes > (1ull << 30) && hipMemGetInfo(&freeB, &totalB) == hipSuccess && g_cachedBytes > totalB / 8) drop_all_cached();
+  static const size_t cap = [] {
+    size_t freeB = 0, totalB = 0;
+    if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) {
+      (void)hipGetLastError();
+      return static_cast<size_t>(32) << 30;
+    }
+    return totalB / 8;
+  }();
+  if (g_cachedBytes > cap) drop_all_cached();
 }
 
 // ---- kernel timing -------------------------------------------------------------------------------
@@ -236,6 +268,8 @@ KernelTimer::~KernelTimer() {
 }  // namespace ares
 
 // Exported (not part of the reference ABI; declared in include/ares_extensions.h).
+extern "C" void AresReloadEnv(void) { ares::g_envGeneration.fetch_add(1, std::memory_order_acq_rel); }
+
 extern "C" void AresProfilerEnable(int on) {
   std::lock_guard<std::mutex> lock(ares::g_profMutex);
   ares::g_profEnabled.store(on ? 1 : 0);

@@ -7,6 +7,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -40,6 +41,8 @@ bool fuse_pending_into_hash_reduce(int device, hipStream_t stream, const Dimensi
                                    const DimensionVector &out, uint8_t *outValues, int valueBytes, int length, int aggFunc,
                                    int *groups);
 void invalidate_filter_journal(int device, const uint32_t *indexVector);
+// ARES_HASH_REDUCE=global: every HashReduce takes the global-table path (hash_reduce.hip)
+bool global_table_forced();
 // true when the sibling libmem.so reports waits, frees and copies to this library (transform.hip)
 bool deferral_hooks_active();
 // something writes (or frees) [ptr, ptr + bytes): partition-grouped results that overlap are no longer
@@ -56,7 +59,8 @@ void drop_skipped_outputs(int device, const void *a, size_t aBytes, const void *
 #define ARES_ABI_BEGIN_NOFLUSH(device)                 \
   CGoCallResHandle resHandle = {nullptr, nullptr};     \
   try {                                                \
-    ares::hip_check(hipSetDevice(device), "hipSetDevice");
+    ares::hip_check(hipSetDevice(device), "hipSetDevice");  \
+    (void)ares::deferral_hooks_active(); /* write tracking is on before this entry point's first kernel */
 
 #define ARES_ABI_BEGIN(device)     \
   ARES_ABI_BEGIN_NOFLUSH(device)   \
@@ -69,6 +73,30 @@ void drop_skipped_outputs(int device, const void *a, size_t aBytes, const void *
     resHandle.pStrErr = strdup(e.what());                             \
   }                                                                   \
   return resHandle;
+
+// Behaviour switches read from the environment (ARES_HASH_REDUCE, ARES_GROUPED, ...).  A switch latches the
+// value it parsed and re-reads it only after AresReloadEnv() (include/ares_extensions.h) was called: a
+// test that flips a variable inside one process says so, a server never pays for getenv on the query path.
+extern std::atomic<uint32_t> g_envGeneration;
+template <typename T>
+class EnvSwitch {
+ public:
+  EnvSwitch(const char *name, T (*parse)(const char *)) : name_(name), parse_(parse) {}
+  T get() {
+    const uint32_t g = g_envGeneration.load(std::memory_order_acquire);
+    if (gen_.load(std::memory_order_acquire) != g) {
+      value_.store(parse_(getenv(name_)), std::memory_order_relaxed);
+      gen_.store(g, std::memory_order_release);
+    }
+    return value_.load(std::memory_order_relaxed);
+  }
+
+ private:
+  const char *name_;
+  T (*parse_)(const char *);
+  std::atomic<uint32_t> gen_{0};  // g_envGeneration starts at 1
+  std::atomic<T> value_{};
+};
 
 inline void *int_result(int64_t v) { return reinterpret_cast<void *>(static_cast<intptr_t>(v)); }
 

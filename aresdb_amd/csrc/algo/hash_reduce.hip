@@ -125,13 +125,12 @@ __global__ __launch_bounds__(kBlock) void hash_extract_kernel(const uint64_t *ke
 using namespace ares;
 
 // ARES_HASH_REDUCE=global pins the global-table path (tests exercise both implementations).
-static bool global_table_forced() {
-  static const bool forced = [] {
-    const char *e = getenv("ARES_HASH_REDUCE");
-    return e && strcmp(e, "global") == 0;
-  }();
-  return forced;
+namespace ares {
+bool global_table_forced() {
+  static EnvSwitch<bool> forced("ARES_HASH_REDUCE", [](const char *e) { return e && strcmp(e, "global") == 0; });
+  return forced.get();
 }
+}  // namespace ares
 
 extern "C" CGoCallResHandle HashReduce(DimensionVector inputKeys, uint8_t *inputValues, DimensionVector outputKeys,
                                        uint8_t *outputValues, int valueBytes, int length,

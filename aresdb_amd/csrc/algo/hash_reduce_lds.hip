@@ -91,11 +91,8 @@ std::vector<std::pair<int, uint32_t *>> g_freeRanges;
 constexpr size_t kRangesBytes = sizeof(uint32_t) * kMaxPartitions * kRangeWords;
 
 bool grouped_enabled() {
-  static const bool on = [] {
-    const char *e = getenv("ARES_GROUPED");
-    return !(e && e[0] == '0');
-  }();
-  return on && deferral_hooks_active();
+  static EnvSwitch<bool> on("ARES_GROUPED", [](const char *e) { return !(e && e[0] == '0'); });
+  return on.get() && deferral_hooks_active();
 }
 
 uint32_t *take_ranges(int device) {
@@ -159,11 +156,8 @@ struct Regions {
 // previous groups from which a query is taken to be high-cardinality (ARES_LEAN_MIN_GROUPS overrides:
 // 0 sends every fusable batch to the specialised DIRECT-mode kernel — tests)
 int lean_min_groups() {
-  static const int v = [] {
-    const char *e = getenv("ARES_LEAN_MIN_GROUPS");
-    return e ? atoi(e) : 16384;
-  }();
-  return v;
+  static EnvSwitch<int> v("ARES_LEAN_MIN_GROUPS", [](const char *e) { return e ? atoi(e) : 16384; });
+  return v.get();
 }
 
 // groups the first batch of a plan shape produced the last time (cardinality feedback for first batches)

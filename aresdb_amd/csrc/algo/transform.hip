@@ -2149,7 +2149,7 @@ bool fuse_pending_into_hash_reduce(int device, hipStream_t stream, const Dimensi
                                    const DimensionVector &out, uint8_t *outValues, int valueBytes, int length, int aggFunc,
                                    int *groups) {
   if (!fuse_available()) return false;
-  static const char *const forced = getenv("ARES_HASH_REDUCE");
+  const bool forcedGlobal = global_table_forced();
   PendingQueue q;
   FusedPlanD plan;
   memset(&plan, 0, sizeof(plan));
@@ -2160,7 +2160,7 @@ bool fuse_pending_into_hash_reduce(int device, hipStream_t stream, const Dimensi
     auto it = t_state->pending.find({device, stream});
     if (it == t_state->pending.end() || it->second.jobs.count == 0) return false;
     PendingQueue &pq = it->second;
-    bool ok = !(forced && strcmp(forced, "global") == 0);
+    bool ok = !forcedGlobal;
     nd = in.NumDimsPerDimWidth[2];
     for (int k = 0; k < NUM_DIM_WIDTH; k++)
       ok = ok && in.NumDimsPerDimWidth[k] == (k == 2 ? nd : 0) && out.NumDimsPerDimWidth[k] == in.NumDimsPerDimWidth[k];

@@ -169,8 +169,12 @@ std::atomic<bool> g_writeTracking{false};
 
 struct DeviceState {
   std::once_flag once;
-  hipStream_t allocStream = nullptr;
+  hipStream_t allocStream = nullptr;  // fills of parked blocks, each behind the block's fence
+  hipStream_t freshStream = nullptr;  // the synchronous fill of a block that comes straight from hipMalloc: never queued
+                                      // behind other queries' fences (head-of-line blocking on allocStream)
   hipError_t initError = hipSuccess;
+  size_t cacheCapBytes = 0;           // parked bytes above which the cache is trimmed (a quarter of the device, read once)
+  size_t driverAllocs = 0, driverFrees = 0, trims = 0;  // driver calls the cache could not avoid (AresMemDriverCalls)
   std::mutex mu;
   std::vector<hipStream_t> streams;                      // streams created through CreateCudaStream
   std::map<size_t, std::vector<ParkedBlock>> bins;       // rounded size -> parked blocks
@@ -197,6 +201,11 @@ hipError_t device_state(int device, DeviceState **out) {
       else (void)hipGetLastError();
     }
     st.initError = hipStreamCreateWithPriority(&st.allocStream, hipStreamNonBlocking, priority);
+    if (st.initError == hipSuccess) st.initError = hipStreamCreateWithFlags(&st.freshStream, hipStreamNonBlocking);
+    size_t freeB = 0, totalB = 0;
+    if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) st.cacheCapBytes = totalB / 4;
+    else (void)hipGetLastError();
+    if (const char *cap = getenv("ARES_MEM_CACHE_MB")) st.cacheCapBytes = static_cast<size_t>(atoll(cap)) << 20;
   });
   *out = &st;
   return st.initError;
@@ -233,7 +242,17 @@ void recycle_events(DeviceState *st, ParkedBlock &b) {
 
 // Releases parked blocks (oldest bins first) until `need` more bytes fit under the cap or nothing
 // is left; used when hipMalloc fails or the cache grows past half of the device.
+bool mem_debug() {
+  static const bool on = [] {
+    const char *e = getenv("ARES_MEM_DEBUG");
+    return e && e[0] == '1';
+  }();
+  return on;
+}
+
 void trim(DeviceState *st, size_t keepBytes) {
+  st->trims++;
+  if (mem_debug()) fprintf(stderr, "libmem: trimming the block cache from %.1f MB to %.1f MB\n", st->parkedBytes / 1e6, keepBytes / 1e6);
   for (auto it = st->bins.begin(); it != st->bins.end() && st->parkedBytes > keepBytes;) {
     auto &vec = it->second;
     while (!vec.empty() && st->parkedBytes > keepBytes) {
@@ -242,6 +261,7 @@ void trim(DeviceState *st, size_t keepBytes) {
       for (hipEvent_t e : b.fence) (void)hipEventSynchronize(e);
       recycle_events(st, b);
       (void)hipFree(b.ptr);
+      st->driverFrees++;
       st->parkedBytes -= it->first;
     }
     it = vec.empty() ? st->bins.erase(it) : std::next(it);
@@ -250,11 +270,7 @@ void trim(DeviceState *st, size_t keepBytes) {
 
 // ARES_MEM_DEBUG=1: driver allocations the cache could not avoid, reported at exit (diagnostics)
 void count_driver_allocation(size_t bytes) {
-  static const bool on = [] {
-    const char *e = getenv("ARES_MEM_DEBUG");
-    return e && e[0] == '1';
-  }();
-  if (!on) return;
+  if (!mem_debug()) return;
   static std::atomic<long> calls{0}, total{0};
   static const int registered = atexit([] {
     fprintf(stderr, "libmem: %ld hipMalloc calls, %.1f MB in total\n", calls.load(), static_cast<double>(total.load()) / 1e6);
@@ -338,6 +354,10 @@ hipError_t pool_alloc(DeviceState *st, void **p, size_t bytes, bool zero) {
   }
   if (!ptr) {
     count_driver_allocation(rounded);
+    {
+      std::lock_guard<std::mutex> lock(st->mu);
+      st->driverAllocs++;
+    }
     hipError_t e = hipMalloc(&ptr, rounded);
     if (e != hipSuccess) {  // out of memory: give both libraries' caches back and retry once
       (void)hipGetLastError();
@@ -361,9 +381,9 @@ hipError_t pool_alloc(DeviceState *st, void **p, size_t bytes, bool zero) {
   *p = ptr;
   if (zero && cleared) verify_clear(st, ptr, rounded);
   if (zero && !cleared) {  // (the whole block: what lies behind `bytes` is handed out by a later, larger request)
-    hipError_t e = hipMemsetAsync(ptr, 0, rounded, st->allocStream);
+    hipError_t e = hipMemsetAsync(ptr, 0, rounded, st->freshStream);
     if (e != hipSuccess) return e;
-    return hipStreamSynchronize(st->allocStream);
+    return hipStreamSynchronize(st->freshStream);
   }
   return hipSuccess;
 }
@@ -443,13 +463,19 @@ hipError_t pool_free(DeviceState *st, void *p) {
     for (hipEvent_t e : b.fence) okFill = okFill && hipStreamWaitEvent(st->allocStream, e, 0) == hipSuccess;
     for (const auto &r : written)
       okFill = okFill && hipMemsetAsync(static_cast<uint8_t *>(p) + r.first, 0, r.second - r.first, st->allocStream) == hipSuccess;
-    if (okFill && fence_on(st->allocStream) == hipSuccess) b.zeroed = true;
-    else (void)hipGetLastError();
+    if (okFill && fence_on(st->allocStream) == hipSuccess) {
+      b.zeroed = true;
+    } else {  // a fill may be in flight without a fence behind it: the block must not be handed out again
+      (void)hipGetLastError();
+      recycle_events(st, b);
+      st->driverFrees++;
+      return hipFree(p);  // (synchronises the device: whatever was enqueued has run)
+    }
   }
   st->bins[rounded].push_back(b);
   st->parkedBytes += rounded;
-  size_t freeB = 0, totalB = 0;
-  if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && st->parkedBytes > totalB / 4) trim(st, totalB / 8);
+  // the cache stays below a quarter of the device (the figure is read once per device, not per free)
+  if (st->cacheCapBytes && st->parkedBytes > st->cacheCapBytes) trim(st, st->cacheCapBytes / 2);
   return hipSuccess;
 }
 
@@ -497,6 +523,22 @@ void AresMemStats(int device, size_t *liveBytes, size_t *liveBlocks, size_t *hel
   if (liveBlocks) *liveBlocks = ln;
   if (heldBlocks) *heldBlocks = hn;
   if (parkedBytes) *parkedBytes = pb;
+}
+
+// Driver calls the block cache could not avoid on `device` since the process started: hipMalloc calls,
+// hipFree calls, cache trims (diagnostics: after warm-up a steady workload adds none).
+void AresMemDriverCalls(int device, size_t *mallocs, size_t *frees, size_t *trims) {
+  size_t m = 0, f = 0, t = 0;
+  if (device >= 0 && device < kMaxDevices) {
+    DeviceState *st = &g_devices[device];
+    std::lock_guard<std::mutex> lock(st->mu);
+    m = st->driverAllocs;
+    f = st->driverFrees;
+    t = st->trims;
+  }
+  if (mallocs) *mallocs = m;
+  if (frees) *frees = f;
+  if (trims) *trims = t;
 }
 
 void AresMemTrimCache(int device) {
@@ -615,7 +657,7 @@ CGoCallResHandle DeviceAllocate(size_t bytes, int device) {
 }
 
 // size of a live allocation (0 = unknown)
-size_t allocation_size(DeviceState *st, void *p) {
+static size_t allocation_size(DeviceState *st, void *p) {
   if (use_pool()) {
     std::lock_guard<std::mutex> lock(st->mu);
     auto it = st->live.find(reinterpret_cast<uintptr_t>(p));
@@ -629,7 +671,7 @@ size_t allocation_size(DeviceState *st, void *p) {
   return bytes;
 }
 
-hipError_t free_or_hold(DeviceState *st, void *p, int device) {
+static hipError_t free_or_hold(DeviceState *st, void *p, int device) {
   if (p == nullptr) return hipSuccess;
   if (const uintptr_t tag = notify_free(device, p, allocation_size(st, p))) {
     std::lock_guard<std::mutex> lock(st->mu);

@@ -21,6 +21,11 @@ extern "C" {
 void AresProfilerEnable(int on);
 size_t AresProfilerReport(char *buf, size_t len);
 
+/* Behaviour switches of libalgorithm.so that are read from the environment (ARES_HASH_REDUCE=global,
+ * ARES_GROUPED=0, ARES_LEAN_MIN_GROUPS=n) are parsed once and kept; AresReloadEnv() makes every one of them
+ * read its variable again on next use.  For tests that flip a switch inside one process. */
+void AresReloadEnv(void);
+
 /* Cross-call fusion inside the unchanged ABI.  Root transforms of the hot shape (a 4-byte column,
  * optionally combined with a constant, written to a dimension vector or a measure vector) are not
  * launched one by one: libalgorithm.so keeps up to 8 of them per (device, stream) and runs them as
@@ -97,6 +102,9 @@ void AresMemEnableWriteTracking(void);
  * held blocks were freed by the host but are kept aside for deferred work and are NOT counted as live),
  * blocks kept aside, bytes parked in the cache.  Any pointer may be NULL. */
 void AresMemStats(int device, size_t *liveBytes, size_t *liveBlocks, size_t *heldBlocks, size_t *parkedBytes);
+/* Driver calls libmem.so's block cache could not avoid on `device` since the process started (hipMalloc, hipFree,
+ * cache trims): after warm-up a steady workload adds none.  Any pointer may be NULL. */
+void AresMemDriverCalls(int device, size_t *mallocs, size_t *frees, size_t *trims);
 
 /* Fused batch execution: filter -> dimension / measure projection -> hash reduction of ONE batch in
  * a single pass over the source columns, without the index / predicate / dimension vectors the

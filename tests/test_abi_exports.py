@@ -71,13 +71,29 @@ def test_extension_symbols_are_exported_by_the_library_that_declares_them():
     src = open(os.path.join(ROOT, "include", "ares_extensions.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     declared = set(re.findall(r"^(?:void|size_t|CGoCallResHandle)\s+(\w+)\s*\(", src, flags=re.M))
-    in_mem = {"AresMemSetFlushHook", "AresMemSetDeferralHooks", "AresMemReleaseHeld", "AresMemSetAuxHooks",
-              "AresMemTrimCache", "AresMemStats", "AresMemNoteWrite", "AresMemEnableWriteTracking"}
-    assert in_mem <= declared and {"AresFlushDeferred", "AresProfilerEnable", "AresProfilerReport",
-                                   "AresFusedFilterHashReduce"} <= declared
+    in_mem = {n for n in declared if n.startswith("AresMem")}
+    assert {"AresMemSetFlushHook", "AresMemSetDeferralHooks", "AresMemReleaseHeld", "AresMemSetAuxHooks",
+            "AresMemTrimCache", "AresMemStats", "AresMemNoteWrite", "AresMemEnableWriteTracking",
+            "AresMemDriverCalls"} <= in_mem
+    assert {"AresFlushDeferred", "AresProfilerEnable", "AresProfilerReport", "AresReloadEnv",
+            "AresFusedFilterHashReduce"} <= declared
     la, lm = C.CDLL(algo, mode=os.RTLD_NOW | os.RTLD_LOCAL), C.CDLL(mem, mode=os.RTLD_NOW | os.RTLD_LOCAL)
     for n in declared:
         assert getattr(lm if n in in_mem else la, n) is not None
+
+
+def test_libmem_exports_nothing_but_the_abi_and_its_declared_extensions():
+    """The reference's libmem has 23 symbols (cgoutils/memory.h); ours adds the AresMem* extensions of
+    include/ares_extensions.h and no stray internals."""
+    _, mem = _built()
+    out = subprocess.check_output(["nm", "-D", "--defined-only", mem], text=True)
+    exported = {ln.split()[-1] for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] in "TW"}
+    exported = {n for n in exported if not n.startswith("_")}  # (_init/_fini, C++ runtime weak symbols)
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "ares_extensions.h")).read(), flags=re.S)
+    ext = {n for n in re.findall(r"^(?:void|size_t|CGoCallResHandle)\s+(\w+)\s*\(", src, flags=re.M) if n.startswith("AresMem")}
+    abi_names = set(_declared("ares_memory.h"))
+    assert len(abi_names) == 23
+    assert exported == abi_names | ext, (sorted(exported - abi_names - ext), sorted((abi_names | ext) - exported))
 
 
 def test_libalgorithm_does_not_depend_on_libmem_or_oracle():

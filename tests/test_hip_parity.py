@@ -4,6 +4,8 @@ Integer / byte / index outputs must be bit-identical.  Floating-point SUM/AVG re
 order-dependent (the reference's own DEVICE build is non-deterministic there, SURVEY.md 8a quirk 9);
 they are compared with relative tolerance 1e-6 for float64 accumulators (the north-star bound)
 and 1e-4 for float32 accumulators."""
+import os
+
 import numpy as np
 import pytest
 
@@ -98,14 +100,35 @@ def test_sort_reduce(seed):
 
 
 @pytest.fixture(params=["lds", "global"])
-def hash_path(request, monkeypatch):
+def hash_path(request):
     """Both HashReduce implementations: the partitioned LDS path (default) and the global-table path
-    (taken for AVG / float min-max, and as overflow fallback)."""
+    (taken for AVG / float min-max, and as overflow fallback).  The library latches ARES_HASH_REDUCE;
+    AresReloadEnv makes it read the variable again, and the kernel log proves which path ran."""
+    be = hip()
+    saved = os.environ.get("ARES_HASH_REDUCE")
     if request.param == "global":
-        monkeypatch.setenv("ARES_HASH_REDUCE", "global")
+        os.environ["ARES_HASH_REDUCE"] = "global"
     else:
-        monkeypatch.delenv("ARES_HASH_REDUCE", raising=False)
-    return request.param
+        os.environ.pop("ARES_HASH_REDUCE", None)
+    be.reload_env()
+    be.profiler_enable(True)
+    try:
+        yield request.param
+        be.call("WaitForCudaStream", None, 0)
+        ran = set(k.split("<")[0] for k in be.profiler_report())
+        partitioned = {k for k in ran if k.startswith("hr_")}
+        if request.param == "global":
+            assert "hash_insert_kernel" in ran and not partitioned, ran
+        else:
+            # (AVG and float min/max take the global table on both settings)
+            assert partitioned or "hash_insert_kernel" in ran, ran
+    finally:
+        be.profiler_enable(False)
+        if saved is None:
+            os.environ.pop("ARES_HASH_REDUCE", None)
+        else:
+            os.environ["ARES_HASH_REDUCE"] = saved
+        be.reload_env()
 
 
 def _hash_reduce_same(c, what):

@@ -256,6 +256,15 @@ class Backend:
         self._mem.AresMemDriverCalls(device, C.byref(m), C.byref(f), C.byref(t))
         return {"mallocs": m.value, "frees": f.value, "trims": t.value}
 
+    def rtc_wait(self):
+        """Blocks until no kernel is being compiled in the background; {kernels, compiles, disk_hits, evictions}."""
+        if not hasattr(self._algo, "AresRtcWait"):
+            return None
+        c = (C.c_long * 3)()
+        self._algo.AresRtcWait.argtypes, self._algo.AresRtcWait.restype = [C.POINTER(C.c_long)], C.c_size_t
+        n = self._algo.AresRtcWait(c)
+        return {"kernels": int(n), "compiles": int(c[0]), "disk_hits": int(c[1]), "evictions": int(c[2])}
+
     def reload_env(self):
         """The library's latched environment switches (ARES_HASH_REDUCE, ...) are read again on next use."""
         if hasattr(self._algo, "AresReloadEnv"):

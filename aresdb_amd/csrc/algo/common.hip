@@ -116,6 +116,27 @@ void (*g_memTrimCache)(int) = nullptr;  // AresMemTrimCache of the sibling libme
 // the Go host creates and destroys two streams per query, blocks cached under dead handles would only pile up,
 // and giving them back to the driver costs a device-synchronising hipFree each plus a hipMalloc in the next query.
 void stream_cache_purge(int device, hipStream_t stream) {
+  static const bool keep = [] {  // ARES_TEMP_ORPHANS=0: give the blocks back to the driver instead (hipFree synchronises the device)
+    const char *e = getenv("ARES_TEMP_ORPHANS");
+    return !(e && e[0] == '0');
+  }();
+  if (!keep) {
+    std::vector<void *> blocks;
+    {
+      std::lock_guard<std::mutex> lock(g_cacheMutex);
+      auto it = g_caches.find({device, stream});
+      if (it == g_caches.end()) return;
+      for (auto &bin : it->second.bins)
+        for (void *p : bin.second) {
+          blocks.push_back(p);
+          g_blockSize.erase(p);
+        }
+      g_cachedBytes -= it->second.bytes;
+      g_caches.erase(it);
+    }
+    for (void *p : blocks) (void)hipFree(p);
+    return;
+  }
   std::lock_guard<std::mutex> lock(g_cacheMutex);
   auto it = g_caches.find({device, stream});
   if (it == g_caches.end()) return;

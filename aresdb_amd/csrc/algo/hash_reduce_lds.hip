@@ -153,10 +153,11 @@ struct Regions {
   size_t headBytes;
 };
 
-// previous groups from which a query is taken to be high-cardinality (ARES_LEAN_MIN_GROUPS overrides:
-// 0 sends every fusable batch to the specialised DIRECT-mode kernel — tests)
+// previous groups from which a query is taken to be high-cardinality: beyond ~3/4 of an LDS table (8192 slots) a
+// workgroup's table no longer holds the query's groups and rows would spill one by one (ARES_LEAN_MIN_GROUPS
+// overrides: 0 sends every fusable batch to the specialised DIRECT-mode kernels — tests)
 int lean_min_groups() {
-  static EnvSwitch<int> v("ARES_LEAN_MIN_GROUPS", [](const char *e) { return e ? atoi(e) : 16384; });
+  static EnvSwitch<int> v("ARES_LEAN_MIN_GROUPS", [](const char *e) { return e ? atoi(e) : 6000; });
   return v.get();
 }
 
@@ -175,10 +176,18 @@ int grid_for(int64_t rows) {
   return static_cast<int>(tiles < kMaxStreams ? (tiles < 1 ? 1 : tiles) : kMaxStreams);
 }
 
+// compact lines (8-byte records, hr::Workspace::lineRecords == 14) for the plan-sourced DIRECT scan; ARES_COMPACT=0:
+// 16-byte records everywhere
+bool compact_enabled() {
+  static EnvSwitch<bool> on("ARES_COMPACT", [](const char *e) { return !(e && e[0] == '0'); });
+  return on.get();
+}
+
 // rowsA: rows that may end up as region-A records (TABLE-mode flushes, ungrouped previous groups);
-// rowsB / streams / rwB: rows, workgroups and record width of the launch that may write region B
+// rowsB / streams / rwB: rows, workgroups and record width (words) of the launch that may write region B;
+// lineRecords: 0 = scattered records, 8 = 16-byte records in whole lines, 14 = compact lines (capB counts lines)
 void make_regions(Regions &r, int partBits, int64_t rowsA, int64_t rowsB, int streams, int rwB, hipStream_t stream,
-                  bool lines = false) {
+                  int lineRecords = 0) {
   const int numParts = 1 << partBits;
   Workspace &ws = r.ws;
   memset(&ws, 0, sizeof(ws));
@@ -188,18 +197,25 @@ void make_regions(Regions &r, int partBits, int64_t rowsA, int64_t rowsB, int st
   // merge workgroups, which stream their regions in lockstep, do not camp on the same HBM channels
   ws.capA = ((2ull * (static_cast<uint64_t>(rowsA) / numParts) + 2 * kSlots) | 63ull) + 18;
   ws.capB = 0;
-  ws.lineRecords = lines ? 8 : 0;
+  ws.lineRecords = lineRecords;
+  size_t bBytes = 0;
   if (streams > 0) {
     const uint64_t mean = static_cast<uint64_t>(rowsB) / (static_cast<uint64_t>(numParts) * streams);
-    if (lines)  // whole 128-byte lines of 8 records; an odd number of lines per stream keeps the strides off powers of two
+    if (lineRecords == static_cast<int>(kCompactLineRecords)) {  // whole 128-byte lines of 14 records; an odd number of lines per stream
+      ws.capB = static_cast<uint32_t>(((2 * mean + 64) / kCompactLineRecords + 2) | 1ull);
+      bBytes = 128ull * ws.capB * numParts * streams;
+    } else if (lineRecords) {  // whole 128-byte lines of 8 records; an odd number of lines per stream keeps the strides off powers of two
       ws.capB = static_cast<uint32_t>(((2 * mean + 64 + 7) / 8 * 8) | 8ull);
-    else
+      bBytes = sizeof(uint32_t) * rwB * static_cast<size_t>(ws.capB) * numParts * streams;
+    } else {
       ws.capB = static_cast<uint32_t>(((2 * mean + 64) | 15ull) + 6);
+      bBytes = sizeof(uint32_t) * rwB * static_cast<size_t>(ws.capB) * numParts * streams;
+    }
   }
+  bBytes = (bBytes + 255) / 256 * 256;
   const size_t headBytes = (sizeof(uint32_t) * (numParts + 4) + 255) / 256 * 256;
   const size_t countsBytes = (sizeof(uint32_t) * static_cast<size_t>(numParts) * (streams > 0 ? streams : 1) + 255) / 256 * 256;
   const size_t aBytes = (sizeof(uint4) * ws.capA * numParts + 255) / 256 * 256;
-  const size_t bBytes = (sizeof(uint32_t) * rwB * static_cast<size_t>(ws.capB) * numParts * (streams > 0 ? streams : 0) + 255) / 256 * 256;
   r.buf.reset(new StreamBuffer(headBytes + countsBytes + aBytes + bBytes + 256, stream));
   uint8_t *base = r.buf->as<uint8_t>();
   ws.cursorsA = reinterpret_cast<uint32_t *>(base);
@@ -270,19 +286,19 @@ int hash_reduce_lds(int device, const DimensionVector &inputKeys, const uint8_t 
     const int rows = length - start;
     // a query that already has more groups than an LDS table holds: the write-combining scan, generated
     // for this vector shape (hr_rtc.hip), instead of the adaptive kernel's scattered DIRECT-mode stores
-    void *lean = nullptr;
+    RtcKernel lean;
     if (all4 && grouped && rows > 0 && start >= lean_min_groups() && (a.width == 4 || a.width == 8) && rtc_scan_available())
       lean = rtc_vector_scan_lookup(device, L.numDims, a.width, partBits);
     const int streams = (all4 && rows > 0) ? (lean ? rtc_scan_grid(rows) : grid_for(rows)) : 0;
     const int rwB = (a.width == 8 || lean) ? 4 : 3;
     Regions r;
-    make_regions(r, partBits, rows, rows, streams, rwB, stream, lean != nullptr);
+    make_regions(r, partBits, rows, rows, streams, rwB, stream, lean ? 8 : 0);
     Workspace &ws = r.ws;
     if (lean && a.width == 8) ws.widen.mode = 2;  // line records carry the whole 8-byte value
     ws.prevRanges = grouped ? prev.ranges : nullptr;
     ws.outRanges = outRanges;
     // the specialised merge for these records (it writes every partition's range entry itself)
-    void *leanMerge = lean ? rtc_vector_merge_lookup(device, L.numDims, a.width, partBits, a) : nullptr;
+    RtcKernel leanMerge = lean ? rtc_vector_merge_lookup(device, L.numDims, a.width, partBits, a) : nullptr;
     if (outRanges && !leanMerge) hip_check(hipMemsetAsync(outRanges, 0, kRangesBytes, stream), "hipMemsetAsync");
     if (lean) {
       rtc_vector_scan_launch(lean, inputKeys.DimValues, capacity, inputValues, L.numDims, a.width, static_cast<uint32_t>(start), rows,
@@ -398,35 +414,52 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
                  prev.partBits == partBits && prev.size == prevSize;
   uint32_t *outRanges = grouped_enabled() ? take_ranges(device) : nullptr;
   MergeResult res{0, 0, 0, 0};
-  // A query that already has more groups than an LDS table holds goes straight to DIRECT mode, with the
-  // scan kernel compiled for this plan (hr_rtc.hip); the adaptive generic kernel takes the first batch
-  // (nothing known yet), low-cardinality queries and every plan the generator does not cover.
+  // Which scan.  A query that already has more groups than an LDS table serves well goes straight to DIRECT
+  // mode: every surviving row becomes a record (compact lines when the batch's chunks fit the row field), with
+  // scan and merge compiled for this plan's shape (hr_rtc.hip).  Fewer groups: the TABLE-mode scan compiled for
+  // the shape — LDS aggregation, one record per group and workgroup.  The adaptive generic kernel takes the first
+  // batch of a shape that was never seen (nothing known yet), every plan the generator does not cover, and every
+  // call whose specialised kernel is not loaded yet (it is compiled in the background, never inside a query).
   // The first batch of a query has no previous groups to judge by: it goes by what the first batch of
-  // the same plan shape (expressions and constants, not columns) produced the last time it ran.
-  void *lean = nullptr;
+  // the same plan shape (expressions and divisors, not columns or comparison constants) produced the last time.
+  hr::Widen widen;
+  widen.mode = mw == 8 ? 1 : 0;
+  widen.rk = plan.measure.f.rk;
+  widen.dtype = plan.measureDtype;
   size_t shape = 0;
   int expected = prevSize;
-  if (batchRows > 0 && prevSize == 0 && rtc_scan_available()) {
+  bool known = prevSize > 0;
+  const bool rtc = batchRows > 0 && rtc_scan_available();
+  if (rtc && prevSize == 0) {
     shape = std::hash<std::string>()(rtc_scan_source(plan, nd, 0));
     std::lock_guard<std::mutex> lock(g_shapeMutex);
     auto it = g_firstBatchGroups.find(shape);
-    if (it != g_firstBatchGroups.end()) expected = it->second;
+    if (it != g_firstBatchGroups.end()) {
+      expected = it->second;
+      known = true;
+    }
   }
-  if (batchRows > 0 && expected >= lean_min_groups() && rtc_scan_available()) lean = rtc_scan_lookup(device, plan, nd, partBits);
+  const int chunkTiles = compact_enabled() ? rtc_compact_chunk_tiles(batchRows, partBits) : 0;
+  const bool compact = chunkTiles > 0;
+  RtcKernel lean, table;
+  // (ARES_LEAN_MIN_GROUPS=0 — tests — sends every batch, known shape or not, to the DIRECT kernels)
+  if (rtc && expected >= lean_min_groups() && (known || lean_min_groups() <= 0)) lean = rtc_scan_lookup(device, plan, nd, partBits, compact);
+  else if (rtc && known) table = rtc_table_scan_lookup(device, plan, nd, partBits, a, widen);
   for (;;) {
-    const int streams = batchRows > 0 ? (lean ? rtc_scan_grid(batchRows) : grid_for(batchRows)) : 0;
+    const int streams = batchRows > 0 ? (lean ? rtc_scan_grid(batchRows) : table ? 0 : grid_for(batchRows)) : 0;
     Regions r;
-    make_regions(r, partBits, length, batchRows, streams, lean ? 4 : 3, stream, lean != nullptr);
+    make_regions(r, partBits, length, batchRows, streams, lean ? 4 : 3, stream,
+                 !lean ? 0 : compact ? static_cast<int>(kCompactLineRecords) : 8);
     Workspace &ws = r.ws;
-    ws.widen.mode = mw == 8 ? 1 : 0;
-    ws.widen.rk = plan.measure.f.rk;
-    ws.widen.dtype = plan.measureDtype;
+    ws.widen = widen;
+    ws.chunkRows = static_cast<uint32_t>(chunkTiles) * 4096u;
+    ws.rowBase = static_cast<uint32_t>(prevSize);
     ws.prevRanges = grouped ? prev.ranges : nullptr;
     ws.outRanges = outRanges;
     Workspace wsPrev = ws;  // previous groups that are not grouped by partition: TABLE-mode pass into region A
     wsPrev.streams = 0;
     // the specialised merge reads region B and grouped previous results only
-    void *leanMerge = (lean && (prevSize == 0 || grouped)) ? rtc_merge_lookup(device, plan, nd, partBits, a, ws.widen) : nullptr;
+    RtcKernel leanMerge = (lean && (prevSize == 0 || grouped)) ? rtc_merge_lookup(device, plan, nd, partBits, a, widen, compact) : nullptr;
     // (the specialised merge writes every partition's range entry itself)
     if (outRanges && !leanMerge) hip_check(hipMemsetAsync(outRanges, 0, kRangesBytes, stream), "hipMemsetAsync");
 #define ARES_FUSED_CASE(ND)                                                                                            \
@@ -441,6 +474,8 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
     }                                                                                                                  \
     if (batchRows > 0 && lean)                                                                                         \
       rtc_scan_launch(lean, plan, static_cast<uint32_t>(prevSize), batchRows, ws, stream);                             \
+    else if (batchRows > 0 && table)                                                                                   \
+      rtc_table_scan_launch(table, plan, static_cast<uint32_t>(prevSize), batchRows, ws, stream);                      \
     else if (batchRows > 0)                                                                                            \
       ARES_LAUNCH("hr_fused_scan_kernel", hr_fused_scan_kernel<ND>, streams, kThreads, stream, plan,                   \
                   static_cast<uint32_t>(prevSize), a, batchRows, ws);                                                  \
@@ -497,14 +532,14 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
     if (g_firstBatchGroups.size() > 4096) g_firstBatchGroups.clear();
     g_firstBatchGroups[shape] = static_cast<int>(res.groups);
   }
-  if (shape && !lean && static_cast<int>(res.groups) >= lean_min_groups()) {
-    // the next first batch of this shape takes the specialised kernels: compile them now, with the other
-    // first-time costs of the shape, not inside that query
-    hr::Widen w;
-    w.mode = mw == 8 ? 1 : 0;
-    w.rk = plan.measure.f.rk;
-    w.dtype = plan.measureDtype;
-    if (rtc_scan_lookup(device, plan, nd, partBits)) (void)rtc_merge_lookup(device, plan, nd, partBits, a, w);
+  if (shape && !lean && !table) {
+    // the next first batch of this shape takes the specialised kernels: have them built now (in the background)
+    if (static_cast<int>(res.groups) >= lean_min_groups()) {
+      (void)rtc_scan_lookup(device, plan, nd, partBits, compact);
+      (void)rtc_merge_lookup(device, plan, nd, partBits, a, widen, compact);
+    } else {
+      (void)rtc_table_scan_lookup(device, plan, nd, partBits, a, widen);
+    }
   }
   if (outRanges) {
     GroupedState s{device, outKeys.DimValues, outValues, outCapacity, nd, mw, static_cast<int>(res.groups), partBits, outRanges};

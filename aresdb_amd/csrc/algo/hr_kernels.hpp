@@ -87,9 +87,16 @@ struct Workspace {
   uint32_t *countsB;     // [workgroup][partition]
   uint32_t capB;
   int streams;           // workgroups of the partition launch that wrote B (0 = none)
-  // 16-byte B records {row, hash, 4-byte carried measure, 0} written in whole 128-byte lines by the
-  // run-time compiled scan (hr_rtc.hip); streams end with null records (row = ~0) that pad the last line
+  // B records written in whole 128-byte lines by the run-time compiled scans (hr_rtc.hip):
+  //   8  — 16-byte records {row, hash, 4-byte carried measure (or the low word of the value), 0 (or the high word)};
+  //        a stream ends with null records (row = ~0) that pad its last line;
+  //   14 — compact lines (kCompactLineRecords): two 64-byte halves of {header u64, 7 x record u64}; a record is
+  //        {lo: carried measure, hi: (hash << partBits) | (row within the workgroup's chunk >> 9)} — the partition
+  //        bits of the hash are implied by the stream — and the header holds the low 9 row bits of its 7 records
+  //        (9 bits each).  Workgroup g scans rows [g * chunkRows, (g + 1) * chunkRows) of the batch, so
+  //        row = rowBase + g * chunkRows + rowInChunk.  capB counts LINES, countsB records (no padding marker).
   int lineRecords;
+  uint32_t chunkRows, rowBase;
   uint32_t *outCount;    // groups emitted; [1] = a region overflowed; [2] = the grouped previous result is stale
   int partBits;
   Widen widen;
@@ -685,12 +692,12 @@ constexpr int kMergeBatch = 4;                      // records per lane per pipe
 constexpr uint32_t kChunk = 64 * kMergeBatch;       // records per wavefront per stage
 
 struct Chunk {
-  const uint32_t *ptr;  // first record (line records: start of the run)
+  const uint32_t *ptr;  // first record (compact lines: start of the run)
   uint32_t rem;         // records from ptr to the end of the run (0 = no chunk)
-  uint32_t first = 0;   // line records: slot of the chunk's first record inside the run
+  uint32_t first = 0;   // compact lines: index of the chunk's first record inside the run
+  uint32_t rowBase = 0; // compact lines: row of the first row of the scanning workgroup's chunk
 };
-constexpr uint32_t kLineRecords = 10;  // lineRecords == 10: 12-byte records, ten per 128-byte line (a format the scan can be
-                                       // generated for; 8 = 16-byte records, which is what it produces — see hr_rtc.hip)
+constexpr uint32_t kCompactLineRecords = 14;  // Workspace::lineRecords of the compact format
 
 template <int RW>
 struct RecStage {
@@ -717,15 +724,23 @@ __device__ __forceinline__ void load_chunk(RecStage<RW> &s, const Chunk &c, int 
   }
 }
 
-// the same for a run of whole lines: slot s sits at word (s / 10) * 32 + (s % 10) * 3
-__device__ __forceinline__ void load_chunk_lines(RecStage<4> &s, const Chunk &c, int lane) {
+// the same for a run of compact lines (Workspace::lineRecords == 14): record i of the run sits in line i / 14,
+// half (i % 14) / 7, behind that half's header; it is expanded to {row, hash, carried measure, 0}
+__device__ __forceinline__ void load_chunk_compact(RecStage<4> &s, const Chunk &c, int lane, int pb, uint32_t part) {
   const uint32_t last = c.rem ? c.rem - 1 : 0u;
 #pragma unroll
   for (int k = 0; k < kMergeBatch; k++) {
     const uint32_t i = static_cast<uint32_t>(k) * 64u + lane;
     const uint32_t slot = c.first + (i < last ? i : last);
-    const Rec3 r = *reinterpret_cast<const Rec3 *>(c.ptr + static_cast<uint64_t>(slot / kLineRecords) * 32u + (slot % kLineRecords) * 3u);
-    s.w[k][0] = r.row; s.w[k][1] = r.hash; s.w[k][2] = r.val; s.w[k][3] = 0u;
+    const uint32_t line = slot / kCompactLineRecords, r = slot % kCompactLineRecords;
+    const uint32_t half = r >= 7u ? 1u : 0u, k7 = r - 7u * half;
+    const uint64_t *L = reinterpret_cast<const uint64_t *>(c.ptr) + static_cast<uint64_t>(line) * 16u + 8u * half;
+    const uint64_t hdr = L[0], rec = L[1u + k7];
+    const uint32_t lo9 = static_cast<uint32_t>(hdr >> (9u * k7)) & 511u, hiw = static_cast<uint32_t>(rec >> 32);
+    s.w[k][0] = c.rowBase + (((hiw & ((1u << pb) - 1u)) << 9) | lo9);
+    s.w[k][1] = (pb ? part << (32 - pb) : 0u) | (hiw >> pb);
+    s.w[k][2] = static_cast<uint32_t>(rec);
+    s.w[k][3] = 0u;
   }
 }
 
@@ -860,9 +875,10 @@ __device__ __forceinline__ void merge_body(const uint8_t *__restrict__ dimIn, si
         while (g < G) {
           const uint32_t cnt = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(sRunCount[g])));
           if (offB < cnt) {
-            if (RWB == 4 && ws.lineRecords == static_cast<int>(kLineRecords)) {  // 12-byte line records: capB counts lines
+            if (RWB == 4 && ws.lineRecords == static_cast<int>(kCompactLineRecords)) {  // capB counts lines
               c.ptr = ws.recB + (static_cast<uint64_t>(g) * (1u << pb) + p) * capB * 32u;
               c.first = offB;
+              c.rowBase = ws.rowBase + static_cast<uint32_t>(g) * ws.chunkRows;
             } else {
               c.ptr = ws.recB + ((static_cast<uint64_t>(g) * (1u << pb) + p) * capB + offB) * RWB;
             }
@@ -884,7 +900,7 @@ __device__ __forceinline__ void merge_body(const uint8_t *__restrict__ dimIn, si
             uint64_t v;
             if constexpr (RWB == 4) {
               if (ws.lineRecords) {
-                if (s.w[k][0] == 0xFFFFFFFFu) continue;  // padding of a stream's last line
+                if (ws.lineRecords == 8 && s.w[k][0] == 0xFFFFFFFFu) continue;  // padding of a stream's last line
                 v = ws.widen.mode == 2 ? (static_cast<uint64_t>(s.w[k][3]) << 32) | s.w[k][2]  // the whole value travels
                                        : widen_value(ws.widen, s.w[k][2]);
               } else {
@@ -900,8 +916,8 @@ __device__ __forceinline__ void merge_body(const uint8_t *__restrict__ dimIn, si
       };
       auto load = [&](RecStage<RWB> &s, const Chunk &c) {
         if constexpr (RWB == 4) {
-          if (ws.lineRecords == static_cast<int>(kLineRecords)) {
-            load_chunk_lines(s, c, lane);
+          if (ws.lineRecords == static_cast<int>(kCompactLineRecords)) {
+            load_chunk_compact(s, c, lane, pb, static_cast<uint32_t>(p));
             return;
           }
         }

@@ -1,21 +1,39 @@
-// Per-plan specialised scan kernel of the fused HashReduce, compiled at run time with hiprtc.
+// Per-plan specialised scan / merge kernels of the fused HashReduce, compiled at run time with hiprtc.
 //
 // The generic hr_fused_scan_kernel (hr_kernels.hpp) interprets the plan: operation codes, kinds and
 // constants arrive as kernel arguments and every expression is dispatched per quad.  That costs
 // ~210 VALU + ~80 SALU instructions per row, 266 KB of code and several hundred spilled SGPRs — the
 // kernel is bound by instruction issue and instruction fetch, not by HBM.  Here the host writes the
-// plan out as straight-line code (constants as literals, so the compiler strength-reduces the time
-// bucket division itself), hiprtc compiles it for gfx950 (~0.5 s, cached per plan signature and
-// device for the life of the process) and the result is launched through the module API.
+// plan's SHAPE out as straight-line code and hiprtc compiles it for the device's architecture.
 //
-// The generated scan covers DIRECT mode only (every row becomes a record; see hr_kernels.hpp for the
-// modes): the host uses it when the query is known to have more groups than an LDS table holds;
-// otherwise, and for every plan outside the supported shapes, the generic adaptive kernel runs.  Its
-// write path is what matters (tools/ubench_scatter.hip, profiles/r2_ubench_write_path*.txt): reading
-// and hashing the columns runs at 6 TB/s, but a CU retires only one scattered small store per ~4.5
-// cycles and HBM write time follows the number of 64-byte write requests, so records are counting-
-// sorted by partition in LDS and leave the CU only as whole aligned 128-byte lines of 8 records.
-// The matching merge (generate_merge below) is specialised the same way.
+// What is a literal and what is an argument.  Literals (they select instructions): functors, kinds, null
+// mask, column slots, aggregate, widening, partition bits, record format — and DIVISORS (the time bucket
+// `Floor(ts, 3600)`: the compiler strength-reduces the division; DESIGN.md 3 measured that this is where the
+// gain of specialisation is).  Kernel ARGUMENTS: every comparison constant and every + / - / x constant
+// (`Args::k`).  AresDB queries carry per-query `from` / `to` time-filter constants
+// (query/common/time_filter.go:371-397): a new time range runs the kernel that is already loaded.
+//
+// Compilation never sits on a query's critical path: a kernel that is not loaded yet is compiled on a
+// background thread (ARES_RTC_ASYNC=0: inline) while the caller goes on with the generic kernels — which
+// stay the fallback at every step —, code objects are kept in an on-disk cache keyed on (architecture,
+// hiprtc version, source) so that a restarted process loads instead of compiling, and the in-memory cache is
+// bounded (least recently used shapes are unloaded).
+//
+// Three scans are generated:
+//   * DIRECT, compact lines — high-cardinality queries (more groups than an LDS table holds): every surviving
+//     row becomes an 8-byte record {carried measure, (hash << partBits) | row bits}, counting-sorted by
+//     partition in LDS; only whole aligned 128-byte lines of 14 records + two 8-byte headers (the low row
+//     bits) leave the CU.  9.14 bytes per record instead of 16: the record round trip is what bounds this
+//     query shape (the scan moved 1.72x its algorithmic bytes with 16-byte records).
+//   * DIRECT, 16-byte records {row, hash, value lo, value hi} in lines of 8 — the vector-sourced scan
+//     (HashReduce on materialised dimension / measure vectors, 8-byte values) and batches whose per-workgroup
+//     chunk does not fit the compact row field.
+//   * TABLE — low-cardinality queries: each workgroup aggregates its rows in an LDS hash table without a
+//     barrier in the loop and emits one record per group at the end (region A, read by the generic merge);
+//     rows that find the table full spill as single records.
+// Write path facts behind the DIRECT kernels (tools/ubench_scatter.hip, profiles/r2_ubench_write_path*.txt):
+// reading and hashing the columns runs at 6 TB/s, but a CU retires only one scattered small store per ~4.5
+// cycles and HBM write time follows the number of 64-byte write requests — hence the LDS sort and whole lines.
 //
 // Supported shapes (everything else: generic kernel) — exactly the fast paths of eval_quad /
 // compare_tile in fast_eval.hpp, so results are bit-identical:
@@ -27,11 +45,19 @@
 // hiprtc is loaded with dlopen: a host without it simply keeps the generic kernel.  ARES_RTC=0: off.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <sys/stat.h>
+#include <cerrno>
+#include <unistd.h>
 
-#include <map>
+#include <atomic>
+#include <condition_variable>
+#include <fstream>
+#include <memory>
 #include <mutex>
 #include <sstream>
 #include <string>
+#include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "common.hpp"
@@ -53,6 +79,7 @@ struct RtcApi {
   int (*codeSize)(RtcProgram, size_t *) = nullptr;
   int (*code)(RtcProgram, char *) = nullptr;
   int (*destroy)(RtcProgram *) = nullptr;
+  int (*version)(int *, int *) = nullptr;
   bool ok = false;
 };
 const RtcApi &rtc_api() {
@@ -71,6 +98,7 @@ const RtcApi &rtc_api() {
     a.codeSize = reinterpret_cast<decltype(a.codeSize)>(dlsym(h, "hiprtcGetCodeSize"));
     a.code = reinterpret_cast<decltype(a.code)>(dlsym(h, "hiprtcGetCode"));
     a.destroy = reinterpret_cast<decltype(a.destroy)>(dlsym(h, "hiprtcDestroyProgram"));
+    a.version = reinterpret_cast<decltype(a.version)>(dlsym(h, "hiprtcVersion"));
     a.ok = a.create && a.compile && a.logSize && a.log && a.codeSize && a.code && a.destroy;
     return a;
   }();
@@ -99,9 +127,17 @@ std::string hex(uint32_t v) {
   return b;
 }
 
+// slots of Args::k (run-time constants): filter f -> f, dimension d -> kFusedFilters + d, measure -> the last
+constexpr int kNumConsts = kFusedFilters + kFusedDims + 1;
+int const_slot_filter(int f) { return f; }
+int const_slot_dim(int d) { return kFusedFilters + d; }
+int const_slot_measure() { return kFusedFilters + kFusedDims; }
+std::string const_name(int slot) { return "a.k[" + std::to_string(slot) + "]"; }
+
 // value expression of one element: writes `r` (result bits) given `v` (stored bits) and `okb` (0/1);
-// returns false when the shape is outside the fast paths of eval_quad
-bool gen_value(const FastOperands &f, std::ostringstream &o, const char *v, const char *okb, const char *r) {
+// `kc` names the run-time constant of the expression.  Returns false when the shape is outside the fast
+// paths of eval_quad.
+bool gen_value(const FastOperands &f, std::ostringstream &o, const char *v, const char *okb, const char *r, const std::string &kc) {
   if (!col_kind(f.akind)) return false;
   const bool intKinds = f.akind != K_F32 && f.I != K_F32 && f.akind != K_BOOL;
   if (f.arity == 1) {
@@ -111,7 +147,7 @@ bool gen_value(const FastOperands &f, std::ostringstream &o, const char *v, cons
   }
   if (f.arity != 2 || !intKinds || !int_kind(f.I) || !int_kind(f.bkind) || !f.bok) return false;
   const uint32_t y = f.bbits;  // cvt32 between the integer kinds keeps the bits
-  if (f.divLike) {
+  if (f.divLike) {  // the divisor is a literal: the compiler turns the division into multiply + shift
     const bool sgn = f.I == K_I32;
     const uint32_t mag = (sgn && static_cast<int32_t>(y) < 0) ? 0u - y : y;
     const bool yneg = sgn && static_cast<int32_t>(y) < 0;
@@ -133,28 +169,30 @@ bool gen_value(const FastOperands &f, std::ostringstream &o, const char *v, cons
     return true;
   }
   if (f.functor == Plus || f.functor == Minus || f.functor == Multiply) {
-    o << "      " << r << " = " << okb << " ? (" << v << (f.functor == Plus ? " + " : f.functor == Minus ? " - " : " * ") << hex(y)
+    o << "      " << r << " = " << okb << " ? (" << v << (f.functor == Plus ? " + " : f.functor == Minus ? " - " : " * ") << kc
       << ") : 0u;\n";
     return true;
   }
   return false;
 }
+// what Args::k holds for a value expression
+uint32_t value_const(const FastOperands &f) { return f.bbits; }
 
-// keep bit of one element for one filter
-bool gen_compare(const FastOperands &f, std::ostringstream &o, const char *v, const char *okb, const char *keep) {
+// keep bit of one element for one filter; the constant (converted to the common kind by the host) is `kc`
+bool gen_compare(const FastOperands &f, std::ostringstream &o, const char *v, const char *okb, const char *keep, const std::string &kc) {
   if (!col_kind(f.akind) || f.arity != 2) return false;
   const bool sameBits = f.akind == f.I || (f.akind != K_F32 && f.I != K_F32 && f.akind != K_BOOL);
   if (!sameBits || !f.bok) return false;
   if (f.functor < Equal || f.functor > GreaterThanOrEqual) return false;
   if (!(f.I == K_F32 || f.I == K_I32 || f.I == K_U32)) return false;
-  const uint32_t y = host_cvt32(f.bbits, f.bkind, f.I);
   const char *op = f.functor == Equal ? "==" : f.functor == NotEqual ? "!=" : f.functor == LessThan ? "<"
                    : f.functor == LessThanOrEqual ? "<=" : f.functor == GreaterThan ? ">" : ">=";
-  if (f.I == K_F32) o << "      " << keep << " &= (" << okb << " && (__uint_as_float(" << v << ") " << op << " __uint_as_float(" << hex(y) << "))) ? 1u : 0u;\n";
-  else if (f.I == K_I32) o << "      " << keep << " &= (" << okb << " && ((i32)" << v << " " << op << " (i32)" << hex(y) << ")) ? 1u : 0u;\n";
-  else o << "      " << keep << " &= (" << okb << " && (" << v << " " << op << " " << hex(y) << ")) ? 1u : 0u;\n";
+  if (f.I == K_F32) o << "      " << keep << " &= (" << okb << " && (__uint_as_float(" << v << ") " << op << " __uint_as_float(" << kc << "))) ? 1u : 0u;\n";
+  else if (f.I == K_I32) o << "      " << keep << " &= (" << okb << " && ((i32)" << v << " " << op << " (i32)" << kc << ")) ? 1u : 0u;\n";
+  else o << "      " << keep << " &= (" << okb << " && (" << v << " " << op << " " << kc << ")) ? 1u : 0u;\n";
   return true;
 }
+uint32_t compare_const(const FastOperands &f) { return host_cvt32(f.bbits, f.bkind, f.I); }
 
 bool plain_store(int rk, int outKind) { return rk == outKind || (rk != K_F32 && outKind != K_F32 && rk != K_BOOL); }
 
@@ -168,40 +206,97 @@ static bool phases_enabled() {
   return on;
 }
 
-struct RtcArgs {  // mirrors `struct Args` of the generated source (pointers first, then 4-byte fields)
+struct RtcArgs {  // mirrors `struct Args` of the generated source (args_text below): pointers, 8-byte, then 4-byte fields
   const uint32_t *vals[kFusedCols];
   const uint8_t *nulls[kFusedCols];
   uint32_t *recB;
   uint32_t *countsB;
   uint32_t *overflow;
   uint64_t *phases;
+  uint4 *recA;
+  uint32_t *cursorsA;
+  uint64_t capA;
   uint32_t bitOff[kFusedCols];
   uint32_t rowBase;
   int length;
   uint32_t capB;
+  uint32_t chunkTiles;
+  uint32_t k[kNumConsts];
   uint32_t pad;
 };
+static_assert(sizeof(RtcArgs) % 8 == 0, "Args is passed as one buffer");
 
-// The kernel proper, shared by the plan-sourced and the vector-sourced scan: `Raw`, `load_full`, `load_tail`
-// and `eval4(R, a, i0, hh, cv, cw, alive)` are already in `o`; `fourth` is the record's fourth word.
-static void kernel_body(std::ostringstream &o, const char *fourth) {
-  // ---- the kernel.  One 1024-lane workgroup per CU walks 4096-row tiles.  The write path is what
-  // bounds the memory side of this kernel (tools/ubench_scatter.hip): a CU retires one scattered small
-  // store per ~4.5 cycles, and HBM write time follows the number of 64-byte write requests — whole
-  // aligned 128-byte lines cost half of anything partial.  So records (16 bytes: row, hash, 4-byte
-  // measure, 0) are counting-sorted by partition in LDS and ONLY whole lines of 8 records leave the CU,
-  // each written by 8 adjacent lanes with one store; the < 8 records a partition has left over stay in
-  // LDS and go first in the next tile's lines.  Streams are private to the workgroup: no global atomics.
-  // The other bound is instruction issue (ARES_HR_PHASES=1: ~3/4 of a tile's critical path is VALU/LDS
-  // issue): records are 16-byte units in LDS too, so that sorting, line building and the remainder copy
-  // move one record per LDS instruction — a 12-byte record format (10 per line, -20 % traffic) was
-  // measured slower for exactly that reason.
+std::string args_text() {
+  std::ostringstream o;
+  o << "struct Args { const u32 *vals[" << kFusedCols << "]; const u8 *nulls[" << kFusedCols << "]; u32 *recB; u32 *countsB; u32 *overflow; u64 *phases;\n"
+       "              uint4 *recA; u32 *cursorsA; u64 capA; u32 bitOff[" << kFusedCols << "]; u32 rowBase; int length; u32 capB; u32 chunkTiles;\n"
+       "              u32 k[" << kNumConsts << "]; u32 pad; };\n";
+  return o.str();
+}
+
+const char *kPrelude =
+    "typedef unsigned int u32; typedef unsigned long long u64; typedef unsigned char u8; typedef unsigned short u16; typedef int i32; typedef long long i64;\n"
+    "struct __attribute__((packed, aligned(1))) PU32x4 { u32 v[4]; };\n"
+    "struct __attribute__((packed, aligned(1))) PU32 { u32 v; };\n"
+    "struct __attribute__((packed, aligned(1))) PU16 { u16 v; };\n"
+    "__device__ __forceinline__ u32 rotl(u32 x, int r) { return (x << r) | (x >> (32 - r)); }\n"
+    "__device__ __forceinline__ u32 mix(u32 h, u32 k) { k *= 0xcc9e2d51u; k = rotl(k, 15) * 0x1b873593u; h ^= k; return rotl(h, 13) * 5u + 0xe6546b64u; }\n";
+
+void phase_macros(std::ostringstream &o) {
   if (phases_enabled())
     o << "#define PH_DECL u64 phT[8] = {0, 0, 0, 0, 0, 0, 0, 0}; u64 phLast = __builtin_readcyclecounter();\n"
          "#define PH(k) { const u64 now = __builtin_readcyclecounter(); phT[k] += now - phLast; phLast = now; }\n"
          "#define PH_OUT if (threadIdx.x == 0u) for (int k = 0; k < 8; k++) a.phases[(u64)blockIdx.x * 8u + k] = phT[k];\n";
   else
     o << "#define PH_DECL\n#define PH(k)\n#define PH_OUT\n";
+}
+
+// value of a carried measure (hr::widen_value)
+bool gen_widen(std::ostringstream &o, const hr::Widen &w) {
+  o << "__device__ __forceinline__ u64 widen(u32 raw) {\n";
+  if (w.mode == 0) o << "  return raw;\n";
+  else if (w.dtype == Float64)
+    o << (w.rk == K_F32 ? "  return (u64)__double_as_longlong((double)__uint_as_float(raw));\n"
+          : w.rk == K_I32 ? "  return (u64)__double_as_longlong((double)(i32)raw);\n"
+                          : "  return (u64)__double_as_longlong((double)raw);\n");
+  else
+    o << (w.rk == K_F32 ? "  return (u64)(i64)__uint_as_float(raw);\n" : w.rk == K_I32 ? "  return (u64)(i64)(i32)raw;\n" : "  return (u64)(i64)raw;\n");
+  o << "}\n";
+  return true;
+}
+
+// the aggregate on an LDS slot (hr::lds_aggregate)
+bool gen_agg(std::ostringstream &o, const AggSpec &a) {
+  o << "__device__ __forceinline__ void agg(u64 *slot, u64 bits) {\n";
+  switch (a.vtype) {
+    case V_F64: o << "  __hip_atomic_fetch_add(reinterpret_cast<double *>(slot), __longlong_as_double((long long)bits), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"; break;
+    case V_U64: case V_I64: o << "  __hip_atomic_fetch_add(slot, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"; break;
+    case V_F32: o << "  __hip_atomic_fetch_add(reinterpret_cast<float *>(slot), __uint_as_float((u32)bits), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"; break;
+    case V_U32:
+      o << "  __hip_atomic_fetch_" << (a.op == OP_SUM ? "add" : a.op == OP_MIN ? "min" : "max")
+        << "(reinterpret_cast<u32 *>(slot), (u32)bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n";
+      break;
+    case V_I32:
+      o << "  __hip_atomic_fetch_" << (a.op == OP_SUM ? "add" : a.op == OP_MIN ? "min" : "max")
+        << "(reinterpret_cast<i32 *>(slot), (i32)(u32)bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n";
+      break;
+    default: return false;
+  }
+  o << "}\n";
+  char ident[32];
+  snprintf(ident, sizeof(ident), "0x%016llxull", static_cast<unsigned long long>(a.identity));
+  o << "#define IDENT " << ident << "\n";
+  return true;
+}
+
+// ---- DIRECT scan, 16-byte records in lines of 8 ------------------------------------------------------
+// `Raw`, `load_full`, `load_tail` and `eval4(R, a, i0, hh, cv, cw, alive)` are already in `o`; `fourth` is the
+// record's fourth word.  One 1024-lane workgroup per CU walks 4096-row tiles (tile = blockIdx + k * grid).
+// Records are counting-sorted by partition in LDS and ONLY whole lines of 8 records leave the CU, each written
+// by 8 adjacent lanes with one store; the < 8 records a partition has left over stay in LDS and go first in
+// the next tile's lines.  Streams are private to the workgroup: no global atomics.
+static void kernel_body_lines16(std::ostringstream &o, const char *fourth) {
+  phase_macros(o);
   o << "#define T 4096u\n"
        "__device__ __forceinline__ u32 lane_up(u32 v, u32 lane, u32 off) { return (u32)__builtin_amdgcn_ds_bpermute((int)((lane - off) << 2), (int)v); }\n"
        "extern \"C\" __global__ void __launch_bounds__(1024) hr_scan_rtc(Args a) {\n"
@@ -325,20 +420,272 @@ static void kernel_body(std::ostringstream &o, const char *fourth) {
        "}\n";
 }
 
-// the whole kernel source for `plan`; empty when the plan is outside the supported shapes
-std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t nullMask) {
+// ---- DIRECT scan, compact lines ------------------------------------------------------------------------
+// (format: hr::Workspace::lineRecords == 14.)  Workgroup g scans the contiguous chunk of a.chunkTiles tiles that
+// starts at tile g * a.chunkTiles, so that a row is identified by (stream, row within the chunk): 9 of those bits
+// travel in the line's header, the rest in the low PB bits of the record's hash word — the PB partition bits of
+// the hash are implied by the stream.  The host guarantees chunkTiles * 4096 <= 1 << (PB + 9).
+// LDS: records as 8-byte units + a 2-byte array of low row bits; a line is written by 16 adjacent lanes (8 bytes
+// each: lanes 0 and 8 the headers), LPL lines per lane in flight; the header of a half-line is the OR of its
+// seven lanes' shifted row bits (three DPP steps inside the 8-lane group).
+static void kernel_body_compact(std::ostringstream &o) {
+  phase_macros(o);
+  o << "#define T 4096u\n#define LR 14u\n#define LEFT 13u\n#define LPL 5u\n"
+       "__device__ __forceinline__ u32 lane_up(u32 v, u32 lane, u32 off) { return (u32)__builtin_amdgcn_ds_bpermute((int)((lane - off) << 2), (int)v); }\n"
+       // OR over the 8 lanes of a half-line: xor 1, xor 2 (quad permutes), then the mirrored quad (row_half_mirror)
+       "__device__ __forceinline__ u32 or8(u32 v) {\n"
+       "  v |= (u32)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);\n"
+       "  v |= (u32)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);\n"
+       "  v |= (u32)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true);\n"
+       "  return v;\n"
+       "}\n"
+       "extern \"C\" __global__ void __launch_bounds__(1024) hr_scan_rtc(Args a) {\n"
+       "  __shared__ u64 sRec[T];\n"               // the tile's records, sorted by partition
+       "  __shared__ u16 sLo[T];\n"                // their low 9 row bits
+       "  __shared__ u64 sLeft[NP * LEFT];\n"      // up to 13 records per partition waiting for a full line
+       "  __shared__ u16 sLeftLo[NP * LEFT];\n"
+       "  __shared__ u32 sCount[2][NP];\n"
+       "  __shared__ u32 sStart[NP], sLeftN[NP], sCursor[NP];\n"
+       "  __shared__ u32 sLines[(T + NP * LEFT) / LR + 2u];\n"
+       "  __shared__ u32 sWave[16];\n"
+       "  __shared__ u32 sTotalLines;\n"
+       "  const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;\n"
+       "  for (u32 p = tid; p < NP; p += 1024u) { sCount[0][p] = 0u; sCount[1][p] = 0u; sLeftN[p] = 0u; sCursor[p] = 0u; }\n"
+       "  __syncthreads();\n"
+       "  u64 *myB = reinterpret_cast<u64 *>(a.recB) + (u64)blockIdx.x * NP * a.capB * 16u;\n"  // capB: lines per stream
+       "  const u32 numTiles = ((u32)a.length + T - 1u) / T, fullTiles = (u32)a.length / T;\n"
+       "  const u32 firstTile = blockIdx.x * a.chunkTiles;\n"
+       "  const u32 endTile = firstTile + a.chunkTiles < numTiles ? firstTile + a.chunkTiles : numTiles;\n"
+       "  u32 tile = firstTile, par = 0u;\n"
+       "  Raw R;\n"
+       "  PH_DECL\n"
+       "  if (tile < endTile) { if (tile < fullTiles) load_full(R, a, tile * T + tid * 4u); else load_tail(R, a, tile * T + tid * 4u); }\n"
+       // the lane's place in a line: 16 lanes per line, lanes 0 and 8 carry the two headers
+       "  const u32 q = tid & 15u, r8 = q & 7u;\n"
+       "  const u32 kk = (q >> 3) * 7u + (r8 ? r8 - 1u : 0u);\n"  // record of the line this lane carries
+       "  const u32 sh = r8 ? 9u * (r8 - 1u) : 0u;\n"
+       "  while (tile < endTile) {\n"
+       "    const u32 i0 = tile * T + tid * 4u;\n"
+       "    const u32 rc0 = (tile - firstTile) * T + tid * 4u;\n"  // row within the chunk
+       "    u32 hh[4], cv[4], cw[4], alive[4], rank[4];\n"
+       "    eval4(R, a, i0, hh, cv, cw, alive);\n"
+       "    const u32 next = tile + 1u;\n"
+       "    if (next < endTile) { if (next < fullTiles) load_full(R, a, next * T + tid * 4u); else load_tail(R, a, next * T + tid * 4u); }\n"
+       "    u32 *cnt = sCount[par];\n"
+       "#pragma unroll\n"
+       "    for (int j = 0; j < 4; j++) {\n"
+       "      rank[j] = 0u;\n"
+       "      if (alive[j]) rank[j] = __hip_atomic_fetch_add(&cnt[hh[j] >> (32 - PB)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
+       "    }\n"
+       "    __syncthreads();\n"
+       "    PH(0)\n"
+       // exclusive scans of (new records, whole lines) per partition, packed in one word
+       "    u32 myCount = 0u, myLeft = 0u;\n"
+       "    if (tid < NP) { myCount = cnt[tid]; myLeft = sLeftN[tid]; }\n"
+       "    const u32 myHave = myCount + myLeft, myLines = myHave / LR;\n"
+       "    const u32 packed = (myCount << 16) | myLines;\n"
+       "    u32 incl = packed;\n"
+       "#pragma unroll\n"
+       "    for (u32 off = 1u; off < 64u; off <<= 1) { const u32 t = lane_up(incl, lane, off); if (lane >= off) incl += t; }\n"
+       "    if (lane == 63u) sWave[wave] = incl;\n"
+       "    __syncthreads();\n"
+       "    u32 before = 0u;\n"
+       "#pragma unroll\n"
+       "    for (u32 w = 0u; w < (NP + 63u) / 64u; w++) { const u32 t = sWave[w]; before += w < wave ? t : 0u; }\n"
+       "    const u32 excl = before + incl - packed;\n"
+       "    const u32 myStart = excl >> 16, myLineStart = excl & 0xFFFFu;\n"
+       "    if (tid < NP) {\n"
+       "      sStart[tid] = myStart;\n"
+       "      for (u32 c = 0u; c < myLines; c++) sLines[myLineStart + c] = tid | (c << 9);\n"
+       "      if (tid == NP - 1u) sTotalLines = myLineStart + myLines;\n"
+       "    }\n"
+       "    __syncthreads();\n"
+       "    PH(1)\n"
+       "#pragma unroll\n"
+       "    for (int j = 0; j < 4; j++)\n"
+       "      if (alive[j]) {\n"
+       "        const u32 at = sStart[hh[j] >> (32 - PB)] + rank[j], rc = rc0 + (u32)j;\n"
+       "        sRec[at] = ((u64)((hh[j] << PB) | (rc >> 9)) << 32) | cv[j];\n"
+       "        sLo[at] = (u16)(rc & 511u);\n"
+       "      }\n"
+       "    __syncthreads();\n"
+       "    PH(2)\n"
+       "    const u32 totalLines = sTotalLines;\n"
+       "    for (u32 L0 = tid >> 4; L0 < totalLines; L0 += 64u * LPL) {\n"
+       "      u32 e[LPL], lf[LPL], st[LPL], cu[LPL], lo[LPL];\n"
+       "      u64 rec[LPL];\n"
+       "#pragma unroll\n"
+       "      for (u32 j = 0u; j < LPL; j++) { const u32 L = L0 + j * 64u; e[j] = L < totalLines ? sLines[L] : 0u; }\n"
+       "#pragma unroll\n"
+       "      for (u32 j = 0u; j < LPL; j++) { const u32 p = e[j] & 511u; lf[j] = sLeftN[p]; st[j] = sStart[p]; cu[j] = sCursor[p]; }\n"
+       "#pragma unroll\n"
+       "      for (u32 j = 0u; j < LPL; j++) {\n"
+       "        const u32 p = e[j] & 511u, idx = (e[j] >> 9) * LR + kk;\n"
+       "        const bool old = idx < lf[j];\n"
+       "        const u32 at = old ? p * LEFT + idx : (st[j] + idx - lf[j]) & (T - 1u);\n"
+       "        rec[j] = *(old ? sLeft + at : sRec + at);\n"
+       "        lo[j] = *(old ? sLeftLo + at : sLo + at);\n"
+       "      }\n"
+       "#pragma unroll\n"
+       "      for (u32 j = 0u; j < LPL; j++) {\n"
+       "        const u64 mine = r8 ? (u64)lo[j] << sh : 0ull;\n"
+       "        const u64 hdr = ((u64)or8((u32)(mine >> 32)) << 32) | or8((u32)mine);\n"
+       "        const u32 p = e[j] & 511u, line = cu[j] + (e[j] >> 9);\n"
+       "        if (L0 + j * 64u < totalLines && line < a.capB) myB[((u64)p * a.capB + line) * 16u + q] = r8 ? rec[j] : hdr;\n"
+       "      }\n"
+       "    }\n"
+       "    __syncthreads();\n"
+       "    PH(3)\n"
+       // what is left of each partition (< 14 records) moves to its LDS remainder; cursors advance
+       "    if (tid < NP) {\n"
+       "      const u32 rem = myHave - myLines * LR;\n"
+       "      const u32 n = myLines ? rem : myCount;\n"
+       "      const u32 from = myLines ? myStart + myLines * LR - myLeft : myStart;\n"
+       "      const u32 to = tid * LEFT + (myLines ? 0u : myLeft);\n"
+       "      u64 t[LEFT]; u16 tl[LEFT];\n"
+       "#pragma unroll\n"
+       "      for (u32 k = 0u; k < LEFT; k++) { const u32 s = (from + (k < n ? k : 0u)) & (T - 1u); t[k] = sRec[s]; tl[k] = sLo[s]; }\n"
+       "#pragma unroll\n"
+       "      for (u32 k = 0u; k < LEFT; k++) if (k < n) { sLeft[to + k] = t[k]; sLeftLo[to + k] = tl[k]; }\n"
+       "      sLeftN[tid] = rem;\n"
+       "      u32 cur = sCursor[tid] + myLines;\n"
+       "      if (cur > a.capB) { *a.overflow = 1u; cur = a.capB; }\n"
+       "      sCursor[tid] = cur;\n"
+       "      cnt[tid] = 0u;\n"  // this counter set is used again two tiles from now
+       "    }\n"
+       "    par ^= 1u;\n"
+       "    tile = next;\n"
+       "    PH(4)\n"
+       "  }\n"
+       "  __syncthreads();\n"
+       "  PH(5)\n"
+       // the remainders go out as one last, partly filled line each; countsB holds the exact number of records
+       "  for (u32 p = tid >> 4; p < NP; p += 64u) {\n"
+       "    const u32 left = sLeftN[p], cur = sCursor[p];\n"
+       "    const bool fits = cur < a.capB, has = r8 && kk < left;\n"
+       "    const u64 rec = has ? sLeft[p * LEFT + kk] : 0ull;\n"
+       "    const u64 mine = has ? (u64)sLeftLo[p * LEFT + kk] << sh : 0ull;\n"
+       "    const u64 hdr = ((u64)or8((u32)(mine >> 32)) << 32) | or8((u32)mine);\n"
+       "    if (left && fits) myB[((u64)p * a.capB + cur) * 16u + q] = r8 ? rec : hdr;\n"
+       "    if (left && !fits) *a.overflow = 1u;\n"
+       "    if (q == 0u) a.countsB[(u64)blockIdx.x * NP + p] = cur * LR + ((left && fits) ? left : 0u);\n"
+       "  }\n"
+       "  PH(6)\n"
+       "  PH_OUT\n"
+       "}\n";
+}
+
+// ---- TABLE scan ----------------------------------------------------------------------------------------
+// Low-cardinality queries: every workgroup aggregates its rows in an LDS hash table (key = hash << 32 | lowest
+// row, 8-byte value) and emits one 16-byte record per group {row, hash, value} into region A at the end — the
+// layout hr::flush_table writes and hr::merge_body reads.  No barrier inside the loop: the wavefronts run free
+// (tile t + 1's loads are issued before tile t goes through the table).  A row whose group finds no slot once
+// the table holds LIMIT groups is written as a single record straight away (one global cursor reservation):
+// always correct, slow when frequent — the host sends queries with that many groups to the DIRECT kernels.
+static void kernel_body_table(std::ostringstream &o) {
+  o << "#define T 4096u\n#define SLOTS " << hr::kSlots << "u\n#define LIMIT " << (hr::kSlots * 3 / 4) << "u\n#define EMPTY 0xFFFFFFFFFFFFFFFFull\n"
+       // one row: find or claim the slot of its hash (linear probing; `c` = the home slot's key, read ahead), keep the
+       // lowest row as the group's representative, aggregate; no slot left = the row travels alone
+       "__device__ __forceinline__ void table_row(const Args &a, u64 *sKeys, u64 *sVals, u32 *sClaims, u32 h, u32 row, u32 carried, u64 c) {\n"
+       "  const u64 mine = ((u64)h << 32) | row, value = widen(carried);\n"
+       "  u32 slot = h & (SLOTS - 1u);\n"
+       "  bool done = false;\n"
+       "  for (u32 tries = 0u; tries < SLOTS; tries++) {\n"
+       "    if (c == EMPTY) {\n"
+       "      if (__hip_atomic_load(sClaims, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= LIMIT) break;\n"
+       "      u64 expected = EMPTY;\n"
+       "      if (__hip_atomic_compare_exchange_strong(sKeys + slot, &expected, mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {\n"
+       "        __hip_atomic_fetch_add(sClaims, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
+       "        done = true;\n"
+       "        break;\n"
+       "      }\n"
+       "      c = expected;\n"
+       "    }\n"
+       "    if ((u32)(c >> 32) == h) {\n"
+       "      if (mine < c) __hip_atomic_fetch_min(sKeys + slot, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
+       "      done = true;\n"
+       "      break;\n"
+       "    }\n"
+       "    slot = (slot + 1u) & (SLOTS - 1u);\n"
+       "    c = sKeys[slot];\n"
+       "  }\n"
+       "  if (done) {\n"
+       "    agg(sVals + slot, value);\n"
+       "  } else {\n"
+       "    const u32 p = PB ? h >> (32 - (PB ? PB : 1)) : 0u;\n"
+       "    const u64 at = atomicAdd(a.cursorsA + p, 1u);\n"
+       "    if (at < a.capA) a.recA[(u64)p * a.capA + at] = make_uint4(row, h, (u32)value, (u32)(value >> 32));\n"
+       "    else *a.overflow = 1u;\n"
+       "  }\n"
+       "}\n"
+       "extern \"C\" __global__ void __launch_bounds__(1024) hr_scan_rtc(Args a) {\n"
+       "  __shared__ u64 sKeys[SLOTS];\n"
+       "  __shared__ u64 sVals[SLOTS];\n"
+       "  __shared__ u32 sPartCount[NP], sPartBase[NP];\n"
+       "  __shared__ u32 sClaims;\n"
+       "  const u32 tid = threadIdx.x;\n"
+       "  for (u32 s = tid; s < SLOTS; s += 1024u) { sKeys[s] = EMPTY; sVals[s] = IDENT; }\n"
+       "  for (u32 p = tid; p < NP; p += 1024u) sPartCount[p] = 0u;\n"
+       "  if (tid == 0u) sClaims = 0u;\n"
+       "  __syncthreads();\n"
+       "  const u32 numTiles = ((u32)a.length + T - 1u) / T, fullTiles = (u32)a.length / T;\n"
+       "  u32 tile = blockIdx.x;\n"
+       "  Raw R;\n"
+       "  if (tile < fullTiles) load_full(R, a, tile * T + tid * 4u);\n"
+       "  else if (tile < numTiles) load_tail(R, a, tile * T + tid * 4u);\n"
+       "  while (tile < numTiles) {\n"
+       "    const u32 i0 = tile * T + tid * 4u;\n"
+       "    u32 hh[4], cv[4], cw[4], alive[4];\n"
+       "    eval4(R, a, i0, hh, cv, cw, alive);\n"
+       "    const u32 next = tile + gridDim.x;\n"
+       "    if (next < fullTiles) load_full(R, a, next * T + tid * 4u);\n"
+       "    else if (next < numTiles) load_tail(R, a, next * T + tid * 4u);\n"
+       // the four home slots are read together; a row that meets its group there costs one more LDS atomic
+       "    const u64 c0 = sKeys[hh[0] & (SLOTS - 1u)], c1 = sKeys[hh[1] & (SLOTS - 1u)], c2 = sKeys[hh[2] & (SLOTS - 1u)], c3 = sKeys[hh[3] & (SLOTS - 1u)];\n"
+       "    const u32 row0 = a.rowBase + i0;\n"
+       "    if (alive[0]) table_row(a, sKeys, sVals, &sClaims, hh[0], row0, cv[0], c0);\n"
+       "    if (alive[1]) table_row(a, sKeys, sVals, &sClaims, hh[1], row0 + 1u, cv[1], c1);\n"
+       "    if (alive[2]) table_row(a, sKeys, sVals, &sClaims, hh[2], row0 + 2u, cv[2], c2);\n"
+       "    if (alive[3]) table_row(a, sKeys, sVals, &sClaims, hh[3], row0 + 3u, cv[3], c3);\n"
+       "    tile = next;\n"
+       "  }\n"
+       "  __syncthreads();\n"
+       // flush (hr::flush_table): counting sort of the entries by partition, one cursor reservation per partition
+       "  u32 rank[SLOTS / 1024u];\n"
+       "#pragma unroll\n"
+       "  for (u32 k = 0u; k < SLOTS / 1024u; k++) {\n"
+       "    const u64 key = sKeys[tid + k * 1024u];\n"
+       "    rank[k] = 0u;\n"
+       "    if (key != EMPTY) rank[k] = __hip_atomic_fetch_add(&sPartCount[PB ? (u32)(key >> (64 - (PB ? PB : 1))) : 0u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
+       "  }\n"
+       "  __syncthreads();\n"
+       "  for (u32 p = tid; p < NP; p += 1024u) { const u32 c = sPartCount[p]; if (c) sPartBase[p] = atomicAdd(a.cursorsA + p, c); }\n"
+       "  __syncthreads();\n"
+       "#pragma unroll\n"
+       "  for (u32 k = 0u; k < SLOTS / 1024u; k++) {\n"
+       "    const u32 s = tid + k * 1024u;\n"
+       "    const u64 key = sKeys[s];\n"
+       "    if (key == EMPTY) continue;\n"
+       "    const u32 p = PB ? (u32)(key >> (64 - (PB ? PB : 1))) : 0u;\n"
+       "    const u64 at = (u64)sPartBase[p] + rank[k], v = sVals[s];\n"
+       "    if (at < a.capA) a.recA[(u64)p * a.capA + at] = make_uint4((u32)key, (u32)(key >> 32), (u32)v, (u32)(v >> 32));\n"
+       "    else *a.overflow = 1u;\n"
+       "  }\n"
+       "}\n";
+}
+
+enum ScanKind { SCAN_LINES16 = 0, SCAN_COMPACT = 1, SCAN_TABLE = 2 };
+
+// the whole kernel source for `plan`; empty when the plan is outside the supported shapes.  `agg` / `widen`
+// are read for SCAN_TABLE only.
+std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t nullMask, ScanKind kind, const AggSpec *agg = nullptr,
+                     const hr::Widen *widen = nullptr) {
   if (nd < 1 || nd > kFusedDims || plan.numCols > kFusedCols) return "";
+  if (kind == SCAN_COMPACT && partBits < 3) return "";
   std::ostringstream o;
   const int nc = plan.numCols;
-  o << "typedef unsigned int u32; typedef unsigned long long u64; typedef unsigned char u8; typedef unsigned short u16; typedef int i32;\n"
-       "struct __attribute__((packed, aligned(1))) PU32x4 { u32 v[4]; };\n"
-       "struct __attribute__((packed, aligned(1))) PU16 { u16 v; };\n"
-       "struct __attribute__((packed, aligned(4))) Rec3 { u32 row, hash, val; };\n"
-       "struct Args { const u32 *vals[" << kFusedCols << "]; const u8 *nulls[" << kFusedCols << "]; u32 *recB; u32 *countsB; u32 *overflow; u64 *phases;\n"
-       "              u32 bitOff[" << kFusedCols << "]; u32 rowBase; int length; u32 capB; u32 pad; };\n"
-       "#define NC " << nc << "\n#define ND " << nd << "\n#define PB " << partBits << "\n#define NP " << (1 << partBits) << "\n"
-       "__device__ __forceinline__ u32 rotl(u32 x, int r) { return (x << r) | (x >> (32 - r)); }\n"
-       "__device__ __forceinline__ u32 mix(u32 h, u32 k) { k *= 0xcc9e2d51u; k = rotl(k, 15) * 0x1b873593u; h ^= k; return rotl(h, 13) * 5u + 0xe6546b64u; }\n"
+  o << kPrelude << args_text()
+    << "#define NC " << nc << "\n#define ND " << nd << "\n#define PB " << partBits << "\n#define NP " << (1 << partBits) << "\n"
        "struct Raw { u32 v[NC][4]; u32 win[NC]; };\n";
   // ---- loads of a full quad (all four rows exist) ----
   o << "__device__ __forceinline__ void load_full(Raw &r, const Args &a, u32 i0) {\n";
@@ -376,7 +723,7 @@ std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t null
   for (int k = 0; k < plan.numFilters; k++) {
     const FusedExpr &e = plan.filters[k];
     o << "    {\n      const u32 v = r.v[" << e.col << "][j]; const u32 okb = (okc[" << e.col << "] >> j) & 1u;\n";
-    if (!gen_compare(e.f, o, "v", "okb", "keep")) return "";
+    if (!gen_compare(e.f, o, "v", "okb", "keep", const_name(const_slot_filter(k)))) return "";
     o << "    }\n";
   }
   o << "    alive[j] = keep;\n    u32 h = 0u, okbytes = 0u;\n";
@@ -384,7 +731,7 @@ std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t null
     const FusedExpr &e = plan.dims[d];
     if (e.col != d || !plain_store(e.f.rk, e.outKind)) return "";
     o << "    {\n      const u32 v = r.v[" << d << "][j]; const u32 okb = (okc[" << d << "] >> j) & 1u; u32 x;\n";
-    if (!gen_value(e.f, o, "v", "okb", "x")) return "";
+    if (!gen_value(e.f, o, "v", "okb", "x", const_name(const_slot_dim(d)))) return "";
     o << "      h = mix(h, x); okbytes |= okb << " << 8 * d << ";\n    }\n";
   }
   // Murmur32Stream (dim_layout.hpp): the validity bytes are one more block when there are four of them,
@@ -397,7 +744,7 @@ std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t null
     const FusedExpr &e = plan.measure;
     if (e.col != nd) return "";
     o << "    {\n      const u32 v = r.v[" << nd << "][j]; const u32 okb = (okc[" << nd << "] >> j) & 1u; u32 x;\n";
-    if (!gen_value(e.f, o, "v", "okb", "x")) return "";
+    if (!gen_value(e.f, o, "v", "okb", "x", const_name(const_slot_measure()))) return "";
     if (plan.measureWidth == 8) {
       if (plan.identity != 0) return "";
       o << "      cv[j] = okb ? x : 0u;\n";
@@ -408,7 +755,14 @@ std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t null
     }
     o << "    }\n  }\n}\n";
   }
-  kernel_body(o, "0u");
+  if (kind == SCAN_TABLE) {
+    if (!agg || !widen || !gen_widen(o, *widen) || !gen_agg(o, *agg)) return "";
+    kernel_body_table(o);
+  } else if (kind == SCAN_COMPACT) {
+    kernel_body_compact(o);
+  } else {
+    kernel_body_lines16(o, "0u");
+  }
   return o.str();
 }
 
@@ -421,14 +775,8 @@ std::string generate_vector(int nd, int vw, int partBits) {
   if (nd < 1 || nd > kFusedDims || (vw != 4 && vw != 8)) return "";
   std::ostringstream o;
   const int mq = vw / 4;
-  o << "typedef unsigned int u32; typedef unsigned long long u64; typedef unsigned char u8; typedef unsigned short u16; typedef int i32;\n"
-       "struct __attribute__((packed, aligned(1))) PU32x4 { u32 v[4]; };\n"
-       "struct __attribute__((packed, aligned(1))) PU32 { u32 v; };\n"
-       "struct Args { const u32 *vals[" << kFusedCols << "]; const u8 *nulls[" << kFusedCols << "]; u32 *recB; u32 *countsB; u32 *overflow; u64 *phases;\n"
-       "              u32 bitOff[" << kFusedCols << "]; u32 rowBase; int length; u32 capB; u32 pad; };\n"
-       "#define ND " << nd << "\n#define MQ " << mq << "\n#define PB " << partBits << "\n#define NP " << (1 << partBits) << "\n"
-       "__device__ __forceinline__ u32 rotl(u32 x, int r) { return (x << r) | (x >> (32 - r)); }\n"
-       "__device__ __forceinline__ u32 mix(u32 h, u32 k) { k *= 0xcc9e2d51u; k = rotl(k, 15) * 0x1b873593u; h ^= k; return rotl(h, 13) * 5u + 0xe6546b64u; }\n"
+  o << kPrelude << args_text()
+    << "#define ND " << nd << "\n#define MQ " << mq << "\n#define PB " << partBits << "\n#define NP " << (1 << partBits) << "\n"
        "struct Raw { u32 v[ND][4]; u32 ok[ND]; u32 m[MQ * 4]; };\n"
        "__device__ __forceinline__ void load_full(Raw &r, const Args &a, u32 i0) {\n"
        "#pragma unroll\n"
@@ -473,18 +821,18 @@ std::string generate_vector(int nd, int vw, int partBits) {
        "    cw[j] = MQ == 2 ? r.m[j * MQ + MQ - 1] : 0u;\n"
        "  }\n"
        "}\n";
-  kernel_body(o, "cw[j]");
+  kernel_body_lines16(o, "cw[j]");
   return o.str();
 }
 
 
 // ---- specialised merge ------------------------------------------------------------------------------
 // One workgroup per partition, like merge_body<ND, true, 4> (hr_kernels.hpp) for the case the
-// specialised scan produces: 16-byte line records in region B only, previous groups (if any) read
+// specialised scans produce: line records in region B only, previous groups (if any) read
 // from their partition-grouped ranges, the whole hash range in one round.  What changes is the cost
 // per record: the aggregate, the widening of the carried measure and the dimension expressions are
 // literals (the generic kernel spends ~90 VALU + ~120 SALU instructions per record on dispatch), and
-// the four records a lane holds are probed together — four LDS key reads in flight, then one
+// the records a lane holds are probed together — their LDS key reads in flight, then one
 // non-returning LDS atomic each for records that meet their group in the first slot (all of them,
 // once the groups exist); only misses walk the probe loop.  A partition with more groups than the
 // table holds raises a flag and the host runs the generic multi-round merge instead.
@@ -502,20 +850,26 @@ struct RtcMergeArgs {  // mirrors `struct MArgs` of the generated source
   uint32_t *outRanges;
   uint64_t prevCapacity, outCapacity;
   uint32_t bitOff[kFusedCols];
-  uint32_t capB, streams, prevSize, pad;
+  uint32_t capB, streams, prevSize, chunkRows;
   uint64_t *phases;  // ARES_HR_PHASES=1: per-partition time stamps (diagnostics)
+  uint32_t k[kNumConsts];
+  uint32_t pad;
 };
+static_assert(sizeof(RtcMergeArgs) % 8 == 0, "MArgs is passed as one buffer");
 
 // vectorVW = 0: records of the plan-sourced scan (4-byte carried measure, widened here; rows >= prevSize are
-// source rows whose dimensions are re-evaluated from the plan's columns).  vectorVW = 4 / 8: records of the
-// vector-sourced scan (the whole value travels; every row, old or new, is a row of the input vectors).
-std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w, int vectorVW = 0) {
+// source rows whose dimensions are re-evaluated from the plan's columns), 16-byte lines or — `compact` — compact
+// lines.  vectorVW = 4 / 8: records of the vector-sourced scan (the whole value travels; every row, old or new,
+// is a row of the input vectors).
+std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w, int vectorVW = 0,
+                           bool compact = false) {
   if (nd < 1 || nd > kFusedDims) return "";
+  if (compact && (vectorVW || partBits < 3)) return "";
   std::ostringstream o;
-  o << "typedef unsigned int u32; typedef unsigned long long u64; typedef unsigned char u8; typedef int i32; typedef long long i64;\n"
-       "struct MArgs { const u32 *vals[" << kFusedCols << "]; const u8 *nulls[" << kFusedCols << "]; const u32 *recB; const u32 *countsB;\n"
+  o << kPrelude
+    << "struct MArgs { const u32 *vals[" << kFusedCols << "]; const u8 *nulls[" << kFusedCols << "]; const u32 *recB; const u32 *countsB;\n"
        "  const u32 *prevRanges; const u8 *prevDims; const u8 *prevValues; u8 *dimOut; u8 *outValues; u32 *outCount; u32 *outRanges;\n"
-       "  u64 prevCapacity, outCapacity; u32 bitOff[" << kFusedCols << "]; u32 capB, streams, prevSize, pad; u64 *phases; };\n"
+       "  u64 prevCapacity, outCapacity; u32 bitOff[" << kFusedCols << "]; u32 capB, streams, prevSize, chunkRows; u64 *phases; u32 k[" << kNumConsts << "]; u32 pad; };\n"
        "#define ND " << nd << "\n#define PB " << partBits << "\n#define NP " << (1 << partBits) << "\n"
        "#define SLOTS " << hr::kSlots << "\n#define LIMIT " << hr::kMergeLimit << "u\n#define RANGEWORDS " << hr::kRangeWords
     << "\n#define MAXRANGES " << hr::kMaxRanges << "u\n"
@@ -523,39 +877,9 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
        // NEIGHBOUR partition's number in the partition bits (PB > 0), so "hash field == h" alone identifies a
        // hit — no separate "slot is not empty" test in the straight-line path.
        "#if PB > 0\n#define EMPTY ((((u64)((blockIdx.x ^ 1u) << (32 - PB))) << 32) | 0xFFFFFFFFull)\n#define OCC(k) true\n"
-       "#else\n#define EMPTY 0xFFFFFFFFFFFFFFFFull\n#define OCC(k) ((k) != EMPTY)\n#endif\n"
-       "__device__ __forceinline__ u32 rotl(u32 x, int r) { return (x << r) | (x >> (32 - r)); }\n"
-       "__device__ __forceinline__ u32 mix(u32 h, u32 k) { k *= 0xcc9e2d51u; k = rotl(k, 15) * 0x1b873593u; h ^= k; return rotl(h, 13) * 5u + 0xe6546b64u; }\n";
-  // value of a carried measure (hr::widen_value)
-  o << "__device__ __forceinline__ u64 widen(u32 raw) {\n";
-  if (w.mode == 0) o << "  return raw;\n";
-  else if (w.dtype == Float64)
-    o << (w.rk == K_F32 ? "  return (u64)__double_as_longlong((double)__uint_as_float(raw));\n"
-          : w.rk == K_I32 ? "  return (u64)__double_as_longlong((double)(i32)raw);\n"
-                          : "  return (u64)__double_as_longlong((double)raw);\n");
-  else
-    o << (w.rk == K_F32 ? "  return (u64)(i64)__uint_as_float(raw);\n" : w.rk == K_I32 ? "  return (u64)(i64)(i32)raw;\n" : "  return (u64)(i64)raw;\n");
-  o << "}\n";
-  // the aggregate on an LDS slot (hr::lds_aggregate)
-  o << "__device__ __forceinline__ void agg(u64 *slot, u64 bits) {\n";
-  switch (a.vtype) {
-    case V_F64: o << "  __hip_atomic_fetch_add(reinterpret_cast<double *>(slot), __longlong_as_double((long long)bits), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"; break;
-    case V_U64: case V_I64: o << "  __hip_atomic_fetch_add(slot, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"; break;
-    case V_F32: o << "  __hip_atomic_fetch_add(reinterpret_cast<float *>(slot), __uint_as_float((u32)bits), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"; break;
-    case V_U32:
-      o << "  __hip_atomic_fetch_" << (a.op == OP_SUM ? "add" : a.op == OP_MIN ? "min" : "max")
-        << "(reinterpret_cast<u32 *>(slot), (u32)bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n";
-      break;
-    case V_I32:
-      o << "  __hip_atomic_fetch_" << (a.op == OP_SUM ? "add" : a.op == OP_MIN ? "min" : "max")
-        << "(reinterpret_cast<i32 *>(slot), (i32)(u32)bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n";
-      break;
-    default: return "";
-  }
-  o << "}\n";
-  char ident[32];
-  snprintf(ident, sizeof(ident), "0x%016llxull", static_cast<unsigned long long>(a.identity));
-  o << "#define IDENT " << ident << "\n";
+       "#else\n#define EMPTY 0xFFFFFFFFFFFFFFFFull\n#define OCC(k) ((k) != EMPTY)\n#endif\n";
+  gen_widen(o, w);
+  if (!gen_agg(o, a)) return "";
   if (phases_enabled())
     o << "#define STAMP(k) if (threadIdx.x == 0u) a.phases[(u64)blockIdx.x * 8u + (k)] = __builtin_amdgcn_s_memrealtime();\n";
   else
@@ -563,7 +887,7 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
   // The table is probed by buckets of four keys (32 bytes, two LDS reads): a record meets its group in
   // its home bucket ~93 % of the time at this load, so a wavefront rarely takes more than two or three
   // rounds — with one key per probe the longest probe sequence among 64 lanes paced every wave.  A
-  // lane's four records go through the rounds together: their bucket reads are in flight at once.
+  // lane's records go through the rounds together: their bucket reads are in flight at once.
   // Claims only ever turn the LOWEST empty slot of a bucket into a key, so a hash cannot end up twice.
   o << "#define BUCKETS (SLOTS / 4)\n"
        "struct __attribute__((aligned(16))) U64x2 { u64 x, y; };\n"
@@ -605,58 +929,85 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
        "  if (q.done) finish(sKeys, sVals, q, mine, value);\n"
        "  else __hip_atomic_store(sOverflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"  // table full: the round is void anyway
        "}\n";
-  // Records arrive in segments of up to 64 (one per lane), four segments per register stage — of one long
-  // run or of four short ones (small batches leave ~16 records per run: a stage per run would make the
+  // Records arrive in segments of 64 sixteen-byte units (one per lane), four segments per register stage — of
+  // one long run or of four short ones (small batches leave ~16 records per run: a stage per run would make the
   // merge a chain of dependent loads).  Round one looks at every record's home bucket with straight-line
   // code (no claim, no advance): a record whose group sits there — ~93 % once the groups exist — costs one
   // LDS atomic more.  The rest (the group lives further on, or is new) is queued per wavefront in LDS and
   // taken through the general probe loop 64 at a time, every lane busy: run per record where it occurs,
   // that loop would execute for a handful of lanes after nearly every segment.
   if (vectorVW == 8)  // four words per queued record: a smaller queue, drained from 32 entries on (LDS is full)
-    o << "#define QCAP 96u\n#define QW 4u\n#define QDRAIN 32u\n#define VAL(r) ((((u64)(r).w) << 32) | (r).z)\n#define VALQ(z, w) ((((u64)(w)) << 32) | (z))\n";
+    o << "#define QCAP 96u\n#define QW 4u\n#define QDRAIN 32u\n#define VALB(z, w) ((((u64)(w)) << 32) | (z))\n";
   else if (vectorVW == 4)
-    o << "#define QCAP 128u\n#define QW 3u\n#define QDRAIN 64u\n#define VAL(r) ((u64)(r).z)\n#define VALQ(z, w) ((u64)(z))\n";
+    o << "#define QCAP 128u\n#define QW 3u\n#define QDRAIN 64u\n#define VALB(z, w) ((u64)(z))\n";
   else
-    o << "#define QCAP 128u\n#define QW 3u\n#define QDRAIN 64u\n#define VAL(r) widen((r).z)\n#define VALQ(z, w) widen(z)\n";
-  o << "struct Seg { const uint4 *ptr; u32 n; };\n"
-       "struct Stage { uint4 r[4]; u32 n[4]; };\n"
+    o << "#define QCAP 128u\n#define QW 3u\n#define QDRAIN 64u\n#define VALB(z, w) widen(z)\n";
+  o << "struct Seg { const uint4 *ptr; u32 n, rem, rb; };\n"
+       "struct Stage { uint4 r[4]; u32 n[4], rem[4], rb[4]; };\n"
        "__device__ __forceinline__ void drain(u32 *queue, u32 first, u32 count, u32 lane, u64 *sKeys, u64 *sVals, u32 *sClaimed, u32 *sOverflow) {\n"
        "  asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");\n"
        "  if (lane < count) {\n"
        "    const u32 e = QW * (first + lane);\n"
        "    const u32 row = queue[e], h = queue[e + 1u], z = queue[e + 2u], w = QW == 4u ? queue[e + QW - 1u] : 0u;\n"
-       "    insert(sKeys, sVals, sClaimed, sOverflow, row, h, VALQ(z, w));\n"
+       "    insert(sKeys, sVals, sClaimed, sOverflow, row, h, VALB(z, w));\n"
        "  }\n"
        "  asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");\n"
        "}\n"
-       "__device__ __forceinline__ void consume(const Stage &s, u32 lane, u64 *sKeys, u64 *sVals, u32 *sClaimed, u32 *sOverflow, u32 *queue, u32 &qn) {\n"
-       "#pragma unroll\n"
-       "  for (int k = 0; k < 4; k++) {\n"
-       "    const bool valid = lane < s.n[k] && s.r[k].x != 0xFFFFFFFFu;\n"  // not past the segment / padding of the run's last line
-       "    const u32 h = s.r[k].y, b = h & (BUCKETS - 1u);\n"
-       "    const U64x2 lo = *reinterpret_cast<const U64x2 *>(sKeys + 4u * b), hi = *reinterpret_cast<const U64x2 *>(sKeys + 4u * b + 2u);\n"
-       "    const bool m0 = (u32)(lo.x >> 32) == h && OCC(lo.x), m1 = (u32)(lo.y >> 32) == h && OCC(lo.y);\n"
-       "    const bool m2 = (u32)(hi.x >> 32) == h && OCC(hi.x), m3 = (u32)(hi.y >> 32) == h && OCC(hi.y);\n"
-       "    const bool hit = valid && (m0 || m1 || m2 || m3);\n"
-       "    if (hit) {\n"
-       "      const u32 mi = m0 ? 0u : m1 ? 1u : m2 ? 2u : 3u;\n"
-       "      const u32 seenRow = m0 ? (u32)lo.x : m1 ? (u32)lo.y : m2 ? (u32)hi.x : (u32)hi.y;\n"
-       "      if (s.r[k].x < seenRow) __hip_atomic_fetch_min(sKeys + 4u * b + mi, ((u64)h << 32) | s.r[k].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
-       "      agg(sVals + 4u * b + mi, VAL(s.r[k]));\n"
+       // one record in round one
+       "__device__ __forceinline__ void consume_one(bool valid, u32 row, u32 h, u32 z, u32 w, u32 lane, u64 *sKeys, u64 *sVals, u32 *sClaimed, u32 *sOverflow, u32 *queue, u32 &qn) {\n"
+       "  const u32 b = h & (BUCKETS - 1u);\n"
+       "  const U64x2 lo = *reinterpret_cast<const U64x2 *>(sKeys + 4u * b), hi = *reinterpret_cast<const U64x2 *>(sKeys + 4u * b + 2u);\n"
+       "  const bool m0 = (u32)(lo.x >> 32) == h && OCC(lo.x), m1 = (u32)(lo.y >> 32) == h && OCC(lo.y);\n"
+       "  const bool m2 = (u32)(hi.x >> 32) == h && OCC(hi.x), m3 = (u32)(hi.y >> 32) == h && OCC(hi.y);\n"
+       "  const bool hit = valid && (m0 || m1 || m2 || m3);\n"
+       "  if (hit) {\n"
+       "    const u32 mi = m0 ? 0u : m1 ? 1u : m2 ? 2u : 3u;\n"
+       "    const u32 seenRow = m0 ? (u32)lo.x : m1 ? (u32)lo.y : m2 ? (u32)hi.x : (u32)hi.y;\n"
+       "    if (row < seenRow) __hip_atomic_fetch_min(sKeys + 4u * b + mi, ((u64)h << 32) | row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
+       "    agg(sVals + 4u * b + mi, VALB(z, w));\n"
+       "  }\n"
+       "  const bool pend = valid && !hit;\n"
+       "  const u64 m = __ballot(pend);\n"
+       "  if (m) {\n"
+       "    if (pend) {\n"
+       "      const u32 e = QW * (qn + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)));\n"
+       "      queue[e] = row; queue[e + 1u] = h; queue[e + 2u] = z;\n"
+       "      if (QW == 4u) queue[e + QW - 1u] = w;\n"
        "    }\n"
-       "    const bool pend = valid && !hit;\n"
-       "    const u64 m = __ballot(pend);\n"
-       "    if (m) {\n"
-       "      if (pend) {\n"
-       "        const u32 e = QW * (qn + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)));\n"
-       "        queue[e] = s.r[k].x; queue[e + 1u] = s.r[k].y; queue[e + 2u] = s.r[k].z;\n"
-       "        if (QW == 4u) queue[e + QW - 1u] = s.r[k].w;\n"
-       "      }\n"
-       "      qn += (u32)__popcll(m);\n"
-       "      if (qn >= QDRAIN) { const u32 take = qn < 64u ? qn : 64u; qn -= take; drain(queue, qn, take, lane, sKeys, sVals, sClaimed, sOverflow); }\n"
-       "    }\n"
+       "    qn += (u32)__popcll(m);\n"
+       "    if (qn >= QDRAIN) { const u32 take = qn < 64u ? qn : 64u; qn -= take; drain(queue, qn, take, lane, sKeys, sVals, sClaimed, sOverflow); }\n"
        "  }\n"
        "}\n";
+  if (compact)
+    // a 16-byte unit holds two 8-byte slots of a line: lanes 8l .. 8l + 7 hold line l of the segment, the first
+    // slot of lanes 8l and 8l + 4 is a header (low 9 row bits of the half-line's seven records)
+    o << "__device__ __forceinline__ void consume(const Stage &s, u32 lane, u32 p, u64 *sKeys, u64 *sVals, u32 *sClaimed, u32 *sOverflow, u32 *queue, u32 &qn) {\n"
+         "  const u32 pos = 2u * (lane & 3u);\n"                       // place of the unit's first slot within its half-line
+         "  const u32 recBase = (lane >> 3) * 14u + 7u * ((lane >> 2) & 1u);\n"  // record number (within the segment) of the half-line's first record
+         "#pragma unroll\n"
+         "  for (int k = 0; k < 4; k++) {\n"
+         "    const u64 hdr = ((u64)(u32)__builtin_amdgcn_mov_dpp((int)s.r[k].y, 0x00, 0xF, 0xF, true) << 32) | (u32)__builtin_amdgcn_mov_dpp((int)s.r[k].x, 0x00, 0xF, 0xF, true);\n"
+         "#pragma unroll\n"
+         "    for (u32 j = 0u; j < 2u; j++) {\n"
+         "      const u32 ph = pos + j;\n"                             // 0 = the header slot
+         "      const u32 k7 = ph ? ph - 1u : 0u;\n"
+         "      const bool valid = lane < s.n[k] && ph != 0u && recBase + k7 < s.rem[k];\n"
+         "      const u32 z = j ? s.r[k].z : s.r[k].x, hw = j ? s.r[k].w : s.r[k].y;\n"
+         "      const u32 lo9 = (u32)(hdr >> (9u * k7)) & 511u;\n"
+         "      const u32 h = (p << (32 - PB)) | (hw >> PB);\n"
+         "      const u32 row = s.rb[k] + (((hw & ((1u << PB) - 1u)) << 9) | lo9);\n"
+         "      consume_one(valid, row, h, z, 0u, lane, sKeys, sVals, sClaimed, sOverflow, queue, qn);\n"
+         "    }\n"
+         "  }\n"
+         "}\n";
+  else
+    o << "__device__ __forceinline__ void consume(const Stage &s, u32 lane, u32 p, u64 *sKeys, u64 *sVals, u32 *sClaimed, u32 *sOverflow, u32 *queue, u32 &qn) {\n"
+         "#pragma unroll\n"
+         "  for (int k = 0; k < 4; k++) {\n"
+         "    const bool valid = lane < s.n[k] && s.r[k].x != 0xFFFFFFFFu;\n"  // not past the segment / padding of the run's last line
+         "    consume_one(valid, s.r[k].x, s.r[k].y, s.r[k].z, s.r[k].w, lane, sKeys, sVals, sClaimed, sOverflow, queue, qn);\n"
+         "  }\n"
+         "}\n";
   // dimensions of a source row (hr::fused_eval_row), for groups that are new in this batch
   if (!vectorVW) o << "__device__ __forceinline__ void eval_row(const MArgs &a, u32 row, u32 (&bits)[ND], u32 (&ok)[ND]) {\n";
   for (int d = 0; d < nd && !vectorVW; d++) {
@@ -667,7 +1018,7 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
     if (plan.cols[c].nulls) o << "    const u32 bit = row + a.bitOff[" << c << "]; const u32 okb = (a.nulls[" << c << "][bit >> 3] >> (bit & 7u)) & 1u;\n";
     else o << "    const u32 okb = 1u;\n";
     o << "    u32 x;\n";
-    if (!gen_value(e.f, o, "v", "okb", "x")) return "";
+    if (!gen_value(e.f, o, "v", "okb", "x", const_name(const_slot_dim(d)))) return "";
     o << "    bits[" << d << "] = x; ok[" << d << "] = okb;\n  }\n";
   }
   if (!vectorVW) o << "}\n";
@@ -729,7 +1080,7 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
        "  }\n"
        "  __syncthreads();\n"
        "  STAMP(2)\n"
-       // the partition's runs: every wavefront streams whole runs, two register stages
+       // the partition's runs: every wavefront streams whole runs, three register stages
        "  if (G > 0u) {\n"
        "    const uint4 *dummy = reinterpret_cast<const uint4 *>(a.recB);\n"
        "    u32 j = 0u, off = 0u, qn = 0u;\n"
@@ -737,26 +1088,45 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
        // this wavefront's runs are wave, wave + 16, ...: lane i keeps the length of the i-th of them, so that
        // walking the runs costs no LDS round trip per segment
        "    const u32 myRuns = (G + 15u - wave) / 16u;\n"
-       "    const u32 myCnt = lane < myRuns ? sRunCount[wave + 16u * lane] : 0u;\n"
-       "    auto next = [&]() -> Seg {\n"
-       "      Seg c{dummy, 0u};\n"
-       "      while (j < myRuns) {\n"
-       "        const u32 cnt = (u32)__builtin_amdgcn_readlane((int)myCnt, (int)j);\n"
-       "        if (off < cnt) {\n"
-       "          c.ptr = reinterpret_cast<const uint4 *>(a.recB) + ((u64)(wave + 16u * j) * NP + p) * a.capB + off;\n"
-       "          c.n = cnt - off < 64u ? cnt - off : 64u;\n"
-       "          off += 64u;\n"
-       "          break;\n"
-       "        }\n"
-       "        j++; off = 0u;\n"
-       "      }\n"
-       "      return c;\n"
-       "    };\n"
-       "    auto load = [&](Stage &s) {\n"
+       "    const u32 myCnt = lane < myRuns ? sRunCount[wave + 16u * lane] : 0u;\n";
+  if (compact)
+    o << "    auto next = [&]() -> Seg {\n"
+         "      Seg c{dummy, 0u, 0u, 0u};\n"
+         "      while (j < myRuns) {\n"
+         "        const u32 cnt = (u32)__builtin_amdgcn_readlane((int)myCnt, (int)j);\n"
+         "        const u32 units = ((cnt + 13u) / 14u) * 8u;\n"         // whole lines, eight 16-byte units each
+         "        if (off < units) {\n"
+         "          c.ptr = reinterpret_cast<const uint4 *>(a.recB) + ((u64)(wave + 16u * j) * NP + p) * a.capB * 8u + off;\n"
+         "          c.n = units - off < 64u ? units - off : 64u;\n"
+         "          c.rem = cnt - (off >> 3) * 14u;\n"
+         "          c.rb = a.prevSize + (wave + 16u * j) * a.chunkRows;\n"
+         "          off += 64u;\n"
+         "          break;\n"
+         "        }\n"
+         "        j++; off = 0u;\n"
+         "      }\n"
+         "      return c;\n"
+         "    };\n";
+  else
+    o << "    auto next = [&]() -> Seg {\n"
+         "      Seg c{dummy, 0u, 0u, 0u};\n"
+         "      while (j < myRuns) {\n"
+         "        const u32 cnt = (u32)__builtin_amdgcn_readlane((int)myCnt, (int)j);\n"
+         "        if (off < cnt) {\n"
+         "          c.ptr = reinterpret_cast<const uint4 *>(a.recB) + ((u64)(wave + 16u * j) * NP + p) * a.capB + off;\n"
+         "          c.n = cnt - off < 64u ? cnt - off : 64u;\n"
+         "          off += 64u;\n"
+         "          break;\n"
+         "        }\n"
+         "        j++; off = 0u;\n"
+         "      }\n"
+         "      return c;\n"
+         "    };\n";
+  o << "    auto load = [&](Stage &s) {\n"
        "#pragma unroll\n"
        "      for (int k = 0; k < 4; k++) {\n"
        "        const Seg c = next();\n"
-       "        s.n[k] = c.n;\n"
+       "        s.n[k] = c.n; s.rem[k] = c.rem; s.rb[k] = c.rb;\n"
        "        s.r[k] = c.ptr[lane < c.n ? lane : (c.n ? c.n - 1u : 0u)];\n"
        "      }\n"
        "    };\n"
@@ -767,15 +1137,15 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
        "    for (;;) {\n"
        "      load(s2);\n"
        "      if (!s0.n[0]) break;\n"
-       "      consume(s0, lane, sKeys, sVals, &sClaimed, &sOverflow, queue, qn);\n"
+       "      consume(s0, lane, p, sKeys, sVals, &sClaimed, &sOverflow, queue, qn);\n"
        "      load(s0);\n"
        "      if (!s1.n[0]) break;\n"
-       "      consume(s1, lane, sKeys, sVals, &sClaimed, &sOverflow, queue, qn);\n"
+       "      consume(s1, lane, p, sKeys, sVals, &sClaimed, &sOverflow, queue, qn);\n"
        "      load(s1);\n"
        "      if (!s2.n[0]) break;\n"
-       "      consume(s2, lane, sKeys, sVals, &sClaimed, &sOverflow, queue, qn);\n"
+       "      consume(s2, lane, p, sKeys, sVals, &sClaimed, &sOverflow, queue, qn);\n"
        "    }\n"
-       "    if (qn) drain(queue, 0u, qn, lane, sKeys, sVals, &sClaimed, &sOverflow);\n"
+       "    while (qn) { const u32 take = qn < 64u ? qn : 64u; qn -= take; drain(queue, qn, take, lane, sKeys, sVals, &sClaimed, &sOverflow); }\n"
        "  }\n"
        "  __syncthreads();\n"
        "  STAMP(3)\n"
@@ -838,78 +1208,294 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
   return o.str();
 }
 
-struct Compiled {
-  hipModule_t module = nullptr;
-  hipFunction_t fn = nullptr;  // nullptr = this signature does not compile / is unsupported: generic kernel
-};
-std::mutex g_rtcMutex;
-std::map<std::pair<int, std::string>, Compiled> g_rtcCache;
-
-// compiles (or finds) the kernel of this source on the current device
-hipFunction_t compiled_kernel(int device, const std::string &source, const char *entry) {
-  std::lock_guard<std::mutex> lock(g_rtcMutex);
-  auto it = g_rtcCache.find({device, source});
-  if (it != g_rtcCache.end()) return it->second.fn;
-  Compiled c;
-  const RtcApi &api = rtc_api();
-  RtcProgram prog = nullptr;
-  if (api.create(&prog, source.c_str(), "hr_scan_rtc.hip", 0, nullptr, nullptr) == 0) {
-    const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics"};
-    const int rc = api.compile(prog, 4, opts);
-    if (rc == 0) {
-      size_t size = 0;
-      if (api.codeSize(prog, &size) == 0 && size) {
-        std::vector<char> code(size);
-        if (api.code(prog, code.data()) == 0 && hipModuleLoadData(&c.module, code.data()) == hipSuccess) {
-          if (hipModuleGetFunction(&c.fn, c.module, entry) != hipSuccess) c.fn = nullptr;
-        }
-        (void)hipGetLastError();
-      }
-    } else {
-      size_t n = 0;
-      std::string log;
-      if (api.logSize(prog, &n) == 0 && n) {
-        log.resize(n);
-        api.log(prog, &log[0]);
-      }
-      fprintf(stderr, "libalgorithm: hiprtc could not compile %s (generic kernel used): %s\n", entry, log.c_str());
-    }
-    api.destroy(&prog);
-  }
-  g_rtcCache[{device, source}] = c;
-  return c.fn;
-}
-
+// ---- kernel cache ------------------------------------------------------------------------------------
 }  // namespace
 
-bool rtc_scan_available() { return rtc_api().ok; }
+struct RtcEntry {
+  int device = 0;
+  std::mutex m;
+  std::condition_variable cv;
+  bool ready = false;
+  hipModule_t module = nullptr;
+  hipFunction_t fn = nullptr;  // nullptr once ready = the source does not compile / load: generic kernel
+  std::atomic<uint64_t> lastUse{0};
+  ~RtcEntry() {
+    if (!module) return;
+    // dropped from the cache and by every caller; a launch may still be executing
+    int current = 0;
+    const bool switched = hipGetDevice(&current) == hipSuccess && current != device && hipSetDevice(device) == hipSuccess;
+    (void)hipDeviceSynchronize();
+    (void)hipModuleUnload(module);
+    if (switched) (void)hipSetDevice(current);
+    (void)hipGetLastError();
+  }
+};
 
-void *rtc_scan_lookup(int device, const FusedPlanD &plan, int nd, int partBits) {
-  if (!rtc_api().ok) return nullptr;
-  uint32_t nullMask = 0;
-  for (int c = 0; c < plan.numCols; c++)
-    if (plan.cols[c].nulls) nullMask |= 1u << c;
-  const std::string source = generate(plan, nd, partBits, nullMask);
-  if (source.empty()) return nullptr;
-  return compiled_kernel(device, source, "hr_scan_rtc");
+namespace {
+
+struct RtcCache {
+  std::mutex mu;
+  std::unordered_map<std::string, std::shared_ptr<RtcEntry>> map;  // device + entry point + source -> kernel
+  std::atomic<uint64_t> tick{0};
+  std::atomic<int> pending{0};
+  std::mutex idleMu;
+  std::condition_variable idleCv;
+  std::atomic<long> compiles{0}, diskHits{0}, evictions{0};
+};
+RtcCache &cache() {
+  static RtcCache *c = new RtcCache;  // never destroyed: its modules must not outlive the HIP runtime's teardown order
+  return *c;
 }
 
-void rtc_scan_launch(void *kernel, const FusedPlanD &plan, uint32_t rowBase, int length, const hr::Workspace &ws,
-                     hipStream_t stream) {
-  hipFunction_t fn = static_cast<hipFunction_t>(kernel);
-  RtcArgs args;
+size_t cache_capacity() {
+  static const size_t cap = [] {
+    const char *e = getenv("ARES_RTC_CACHE_ENTRIES");
+    const long v = e ? atol(e) : 256;
+    return static_cast<size_t>(v < 4 ? 4 : v);
+  }();
+  return cap;
+}
+
+bool rtc_async() {
+  static const bool on = [] {
+    const char *e = getenv("ARES_RTC_ASYNC");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
+// on-disk cache of code objects: ARES_RTC_CACHE_DIR, else $XDG_CACHE_HOME/aresdb_amd/rtc, else ~/.cache/aresdb_amd/rtc;
+// "0" / "off" / "" switches it off
+std::string disk_dir() {
+  static const std::string dir = [] {
+    std::string d;
+    if (const char *e = getenv("ARES_RTC_CACHE_DIR")) {
+      d = e;
+      if (d == "0" || d == "off") d.clear();
+      if (d.empty()) return d;
+    } else if (const char *x = getenv("XDG_CACHE_HOME")) {
+      d = std::string(x) + "/aresdb_amd/rtc";
+    } else if (const char *h = getenv("HOME")) {
+      d = std::string(h) + "/.cache/aresdb_amd/rtc";
+    } else {
+      return d;
+    }
+    std::string partial;  // mkdir -p
+    for (size_t i = 0; i <= d.size(); i++)
+      if (i == d.size() || (d[i] == '/' && i > 0)) {
+        partial = d.substr(0, i);
+        if (mkdir(partial.c_str(), 0700) != 0 && errno != EEXIST) return std::string();
+      }
+    return d;
+  }();
+  return dir;
+}
+
+uint64_t fnv1a(const std::string &s, uint64_t h) {
+  for (unsigned char c : s) {
+    h ^= c;
+    h *= 1099511628211ull;
+  }
+  return h;
+}
+
+std::string disk_name(const std::string &arch, const std::string &source) {
+  int major = 0, minor = 0;
+  if (rtc_api().version) (void)rtc_api().version(&major, &minor);
+  const std::string salt = arch + "|hiprtc " + std::to_string(major) + "." + std::to_string(minor) + "|";
+  char b[48];
+  snprintf(b, sizeof(b), "%016llx%016llx.co", static_cast<unsigned long long>(fnv1a(source, fnv1a(salt, 14695981039346656037ull))),
+           static_cast<unsigned long long>(fnv1a(source, fnv1a(salt, 0x9e3779b97f4a7c15ull))));
+  return b;
+}
+
+std::string device_arch(int device) {
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+    (void)hipGetLastError();
+    return "gfx950";
+  }
+  return prop.gcnArchName[0] ? std::string(prop.gcnArchName) : std::string("gfx950");
+}
+
+bool compile_source(const std::string &source, const std::string &arch, const char *entry, std::vector<char> &code) {
+  const RtcApi &api = rtc_api();
+  RtcProgram prog = nullptr;
+  if (api.create(&prog, source.c_str(), "hr_rtc.hip", 0, nullptr, nullptr) != 0) return false;
+  const std::string archOpt = "--offload-arch=" + arch;
+  const char *opts[] = {archOpt.c_str(), "-O3", "-std=c++17", "-munsafe-fp-atomics"};
+  bool ok = false;
+  if (api.compile(prog, 4, opts) == 0) {
+    size_t size = 0;
+    if (api.codeSize(prog, &size) == 0 && size) {
+      code.resize(size);
+      ok = api.code(prog, code.data()) == 0;
+    }
+  } else {
+    size_t n = 0;
+    std::string log;
+    if (api.logSize(prog, &n) == 0 && n) {
+      log.resize(n);
+      api.log(prog, &log[0]);
+    }
+    fprintf(stderr, "libalgorithm: hiprtc could not compile %s (generic kernel used): %s\n", entry, log.c_str());
+  }
+  api.destroy(&prog);
+  return ok;
+}
+
+// produces the entry's kernel: from the disk cache, or compiled (and stored there); runs on the caller's thread
+// (ARES_RTC_ASYNC=0) or on a background thread
+void build_entry(const std::shared_ptr<RtcEntry> &e, const std::string &source, const std::string &entryName) {
+  RtcCache &c = cache();
+  hipModule_t module = nullptr;
+  hipFunction_t fn = nullptr;
+  if (hipSetDevice(e->device) == hipSuccess) {
+    const std::string arch = device_arch(e->device);
+    const std::string dir = disk_dir();
+    const std::string path = dir.empty() ? std::string() : dir + "/" + disk_name(arch, source);
+    std::vector<char> code;
+    if (!path.empty()) {
+      std::ifstream in(path, std::ios::binary | std::ios::ate);
+      if (in) {
+        const std::streamsize n = in.tellg();
+        if (n > 0) {
+          code.resize(static_cast<size_t>(n));
+          in.seekg(0);
+          if (!in.read(code.data(), n)) code.clear();
+        }
+      }
+      if (!code.empty()) c.diskHits++;
+    }
+    bool fresh = false;
+    if (code.empty()) {
+      fresh = compile_source(source, arch, entryName.c_str(), code);
+      c.compiles++;
+      if (!fresh) code.clear();
+    }
+    if (!code.empty() && hipModuleLoadData(&module, code.data()) == hipSuccess) {
+      if (hipModuleGetFunction(&fn, module, entryName.c_str()) != hipSuccess) fn = nullptr;
+    } else {
+      module = nullptr;
+      if (!fresh && !path.empty()) (void)unlink(path.c_str());  // a stale / truncated cache file
+    }
+    (void)hipGetLastError();
+    if (fresh && fn && !path.empty()) {  // publish atomically: write aside, then rename
+      const std::string tmp = path + ".tmp" + std::to_string(static_cast<long>(getpid())) + "." + std::to_string(c.tick.load());
+      std::ofstream out(tmp, std::ios::binary);
+      if (out && out.write(code.data(), static_cast<std::streamsize>(code.size())) && (out.close(), true)) {
+        if (rename(tmp.c_str(), path.c_str()) != 0) (void)unlink(tmp.c_str());
+      } else {
+        (void)unlink(tmp.c_str());
+      }
+    }
+  }
+  (void)hipGetLastError();
+  {
+    std::lock_guard<std::mutex> lock(e->m);
+    e->module = module;
+    e->fn = fn;
+    e->ready = true;
+  }
+  e->cv.notify_all();
+  if (c.pending.fetch_sub(1) == 1) {
+    std::lock_guard<std::mutex> lock(c.idleMu);
+    c.idleCv.notify_all();
+  }
+}
+
+void wait_idle() {
+  RtcCache &c = cache();
+  std::unique_lock<std::mutex> lock(c.idleMu);
+  c.idleCv.wait(lock, [&] { return c.pending.load() == 0; });
+}
+
+// The kernel of this source on `device`: the loaded kernel, or null while it is being built on a background
+// thread (the caller uses the generic kernel this time), or — `wait` / ARES_RTC_ASYNC=0 — after building it.
+RtcKernel compiled_kernel(int device, const std::string &source, const char *entry, bool wait) {
+  if (source.empty()) return nullptr;
+  RtcCache &c = cache();
+  const std::string key = std::to_string(device) + "|" + entry + "|" + source;
+  std::shared_ptr<RtcEntry> e;
+  std::vector<std::shared_ptr<RtcEntry>> evicted;  // destroyed (device synchronised, module unloaded) outside the lock
+  bool created = false;
+  {
+    std::lock_guard<std::mutex> lock(c.mu);
+    auto it = c.map.find(key);
+    if (it != c.map.end()) {
+      e = it->second;
+    } else {
+      while (c.map.size() >= cache_capacity()) {  // drop the least recently used kernel that is not being built
+        auto victim = c.map.end();
+        for (auto jt = c.map.begin(); jt != c.map.end(); ++jt) {
+          bool ready;
+          {
+            std::lock_guard<std::mutex> el(jt->second->m);
+            ready = jt->second->ready;
+          }
+          if (ready && (victim == c.map.end() || jt->second->lastUse.load() < victim->second->lastUse.load())) victim = jt;
+        }
+        if (victim == c.map.end()) break;
+        evicted.push_back(victim->second);
+        c.map.erase(victim);
+        c.evictions++;
+      }
+      e = std::make_shared<RtcEntry>();
+      e->device = device;
+      c.map.emplace(key, e);
+      created = true;
+      c.pending++;
+      static const int registered = atexit([] { wait_idle(); });  // no build thread outlives the process's exit handlers
+      (void)registered;
+    }
+    e->lastUse.store(++c.tick);
+  }
+  evicted.clear();
+  if (created) {
+    if (rtc_async() && !wait) {
+      std::thread([e, source, name = std::string(entry)] { build_entry(e, source, name); }).detach();
+    } else {
+      build_entry(e, source, entry);
+      (void)hipSetDevice(device);
+    }
+  }
+  std::unique_lock<std::mutex> lock(e->m);
+  if (!e->ready) {
+    if (rtc_async() && !wait) return nullptr;
+    e->cv.wait(lock, [&] { return e->ready; });
+  }
+  return e->fn ? e : nullptr;
+}
+
+uint32_t null_mask(const FusedPlanD &plan) {
+  uint32_t m = 0;
+  for (int c = 0; c < plan.numCols; c++)
+    if (plan.cols[c].nulls) m |= 1u << c;
+  return m;
+}
+
+void fill_scan_args(RtcArgs &args, const FusedPlanD &plan, uint32_t rowBase, int length, const hr::Workspace &ws) {
   memset(&args, 0, sizeof(args));
   for (int c = 0; c < plan.numCols; c++) {
     args.vals[c] = plan.cols[c].vals;
     args.nulls[c] = plan.cols[c].nulls;
     args.bitOff[c] = plan.cols[c].bitOff;
   }
+  for (int k = 0; k < plan.numFilters && k < kFusedFilters; k++) args.k[const_slot_filter(k)] = compare_const(plan.filters[k].f);
+  for (int d = 0; d < kFusedDims; d++) args.k[const_slot_dim(d)] = value_const(plan.dims[d].f);
+  args.k[const_slot_measure()] = value_const(plan.measure.f);
   args.recB = ws.recB;
   args.countsB = ws.countsB;
   args.overflow = ws.outCount + 1;
+  args.recA = ws.recA;
+  args.cursorsA = ws.cursorsA;
+  args.capA = ws.capA;
   args.rowBase = rowBase;
   args.length = length;
   args.capB = ws.capB;
+}
+
+void launch_scan(const RtcKernel &kernel, RtcArgs &args, int grid, int length, hipStream_t stream, const char *name) {
   size_t size = sizeof(args);
   void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
   static uint64_t *phases = nullptr;
@@ -918,34 +1504,76 @@ void rtc_scan_launch(void *kernel, const FusedPlanD &plan, uint32_t rowBase, int
     args.phases = phases;
   }
   {
-    KernelTimer timer("hr_scan_rtc", stream);
-    hip_check(hipModuleLaunchKernel(fn, static_cast<unsigned>(ws.streams), 1, 1, hr::kThreads, 1, 1, 0, stream, nullptr, config),
+    KernelTimer timer(name, stream);
+    hip_check(hipModuleLaunchKernel(kernel->fn, static_cast<unsigned>(grid), 1, 1, hr::kThreads, 1, 1, 0, stream, nullptr, config),
               "hipModuleLaunchKernel");
   }
-  if (phases_enabled()) {  // diagnostics: core-clock cycles lane 0 of each workgroup spent per phase
+  if (phases_enabled() && args.phases) {  // diagnostics: core-clock cycles lane 0 of each workgroup spent per phase
     static int launches = 0;
-    std::vector<uint64_t> h(static_cast<size_t>(8) * ws.streams);
+    std::vector<uint64_t> h(static_cast<size_t>(8) * grid);
     hip_check(hipMemcpyAsync(h.data(), phases, sizeof(uint64_t) * h.size(), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync");
     hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
     if (++launches <= 3 || launches % 64 == 0) {
       double sum[7] = {0, 0, 0, 0, 0, 0, 0};
-      for (int g = 0; g < ws.streams; g++)
+      for (int g = 0; g < grid; g++)
         for (int k = 0; k < 7; k++) sum[k] += static_cast<double>(h[static_cast<size_t>(8) * g + k]);
-      const double n = ws.streams * 1e3;
-      fprintf(stderr, "hr_scan_rtc phases (launch %d, %d workgroups, %d rows): kcycles per workgroup: eval+count %.1f, scan %.1f, scatter %.1f, lines %.1f, leftovers %.1f, drain %.1f, last lines %.1f\n",
-              launches, ws.streams, length, sum[0] / n, sum[1] / n, sum[2] / n, sum[3] / n, sum[4] / n, sum[5] / n, sum[6] / n);
+      const double n = grid * 1e3;
+      fprintf(stderr, "%s phases (launch %d, %d workgroups, %d rows): kcycles per workgroup: eval+count %.1f, scan %.1f, scatter %.1f, lines %.1f, leftovers %.1f, drain %.1f, last lines %.1f\n",
+              name, launches, grid, length, sum[0] / n, sum[1] / n, sum[2] / n, sum[3] / n, sum[4] / n, sum[5] / n, sum[6] / n);
     }
   }
 }
 
-void *rtc_vector_scan_lookup(int device, int nd, int vw, int partBits) {
-  if (!rtc_api().ok) return nullptr;
-  const std::string source = generate_vector(nd, vw, partBits);
-  if (source.empty()) return nullptr;
-  return compiled_kernel(device, source, "hr_scan_rtc");
+}  // namespace
+
+bool rtc_scan_available() { return rtc_api().ok; }
+
+// number of workgroups (= private streams per partition) the specialised kernels want for `rows` rows
+int rtc_scan_grid(int64_t rows) {
+  const int64_t tiles = (rows + 4095) / 4096;
+  return static_cast<int>(tiles < hr::kMaxStreams ? (tiles < 1 ? 1 : tiles) : hr::kMaxStreams);
 }
 
-void rtc_vector_scan_launch(void *kernel, const uint8_t *dimValues, size_t capacity, const uint8_t *values, int nd, int vw,
+// tiles per workgroup of the compact scan, 0 when a chunk would not fit the record's row field
+int rtc_compact_chunk_tiles(int64_t rows, int partBits) {
+  if (partBits < 3 || rows <= 0) return 0;
+  const int64_t tiles = (rows + 4095) / 4096;
+  const int64_t grid = rtc_scan_grid(rows);
+  const int64_t chunk = (tiles + grid - 1) / grid;
+  return chunk <= (1ll << (partBits - 3)) ? static_cast<int>(chunk) : 0;
+}
+
+RtcKernel rtc_scan_lookup(int device, const FusedPlanD &plan, int nd, int partBits, bool compact, bool wait) {
+  if (!rtc_api().ok) return nullptr;
+  return compiled_kernel(device, generate(plan, nd, partBits, null_mask(plan), compact ? SCAN_COMPACT : SCAN_LINES16), "hr_scan_rtc", wait);
+}
+
+void rtc_scan_launch(const RtcKernel &kernel, const FusedPlanD &plan, uint32_t rowBase, int length, const hr::Workspace &ws,
+                     hipStream_t stream) {
+  RtcArgs args;
+  fill_scan_args(args, plan, rowBase, length, ws);
+  if (ws.lineRecords == static_cast<int>(hr::kCompactLineRecords)) args.chunkTiles = ws.chunkRows / 4096u;
+  launch_scan(kernel, args, ws.streams, length, stream, "hr_scan_rtc");
+}
+
+RtcKernel rtc_table_scan_lookup(int device, const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w, bool wait) {
+  if (!rtc_api().ok) return nullptr;
+  return compiled_kernel(device, generate(plan, nd, partBits, null_mask(plan), SCAN_TABLE, &a, &w), "hr_scan_rtc", wait);
+}
+
+void rtc_table_scan_launch(const RtcKernel &kernel, const FusedPlanD &plan, uint32_t rowBase, int length, const hr::Workspace &ws,
+                           hipStream_t stream) {
+  RtcArgs args;
+  fill_scan_args(args, plan, rowBase, length, ws);
+  launch_scan(kernel, args, rtc_scan_grid(length), length, stream, "hr_table_scan_rtc");
+}
+
+RtcKernel rtc_vector_scan_lookup(int device, int nd, int vw, int partBits, bool wait) {
+  if (!rtc_api().ok) return nullptr;
+  return compiled_kernel(device, generate_vector(nd, vw, partBits), "hr_scan_rtc", wait);
+}
+
+void rtc_vector_scan_launch(const RtcKernel &kernel, const uint8_t *dimValues, size_t capacity, const uint8_t *values, int nd, int vw,
                             uint32_t rowBase, int length, const hr::Workspace &ws, hipStream_t stream) {
   FusedPlanD plan;
   memset(&plan, 0, sizeof(plan));
@@ -955,20 +1583,18 @@ void rtc_vector_scan_launch(void *kernel, const uint8_t *dimValues, size_t capac
     plan.cols[d].nulls = dimValues + 4ull * nd * capacity + static_cast<size_t>(d) * capacity + rowBase;
   }
   plan.cols[nd].vals = reinterpret_cast<const uint32_t *>(values + static_cast<size_t>(vw) * rowBase);
-  rtc_scan_launch(kernel, plan, rowBase, length, ws, stream);
+  RtcArgs args;
+  fill_scan_args(args, plan, rowBase, length, ws);
+  launch_scan(kernel, args, ws.streams, length, stream, "hr_scan_rtc");
 }
 
 std::string rtc_vector_scan_source(int nd, int vw, int partBits) { return generate_vector(nd, vw, partBits); }
 
-
-
-void *rtc_vector_merge_lookup(int device, int nd, int vw, int partBits, const AggSpec &a) {
+RtcKernel rtc_vector_merge_lookup(int device, int nd, int vw, int partBits, const AggSpec &a, bool wait) {
   if (!rtc_api().ok) return nullptr;
   FusedPlanD none;
   memset(&none, 0, sizeof(none));
-  const std::string source = generate_merge(none, nd, partBits, a, hr::Widen{0, 0, 0}, vw);
-  if (source.empty()) return nullptr;
-  return compiled_kernel(device, source, "hr_merge_rtc");
+  return compiled_kernel(device, generate_merge(none, nd, partBits, a, hr::Widen{0, 0, 0}, vw), "hr_merge_rtc", wait);
 }
 
 std::string rtc_vector_merge_source(int nd, int vw, int partBits, const AggSpec &a) {
@@ -977,17 +1603,15 @@ std::string rtc_vector_merge_source(int nd, int vw, int partBits, const AggSpec 
   return generate_merge(none, nd, partBits, a, hr::Widen{0, 0, 0}, vw);
 }
 
-void *rtc_merge_lookup(int device, const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w) {
+RtcKernel rtc_merge_lookup(int device, const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w, bool compact,
+                           bool wait) {
   if (!rtc_api().ok) return nullptr;
-  const std::string source = generate_merge(plan, nd, partBits, a, w);
-  if (source.empty()) return nullptr;
-  return compiled_kernel(device, source, "hr_merge_rtc");
+  return compiled_kernel(device, generate_merge(plan, nd, partBits, a, w, 0, compact), "hr_merge_rtc", wait);
 }
 
-void rtc_merge_launch(void *kernel, const FusedPlanD &plan, const uint8_t *prevDims, size_t prevCapacity, const uint8_t *prevValues,
+void rtc_merge_launch(const RtcKernel &kernel, const FusedPlanD &plan, const uint8_t *prevDims, size_t prevCapacity, const uint8_t *prevValues,
                       uint32_t prevSize, uint8_t *dimOut, size_t outCapacity, uint8_t *outValues, const hr::Workspace &ws,
                       hipStream_t stream) {
-  hipFunction_t fn = static_cast<hipFunction_t>(kernel);
   RtcMergeArgs args;
   memset(&args, 0, sizeof(args));
   for (int c = 0; c < plan.numCols; c++) {
@@ -995,6 +1619,7 @@ void rtc_merge_launch(void *kernel, const FusedPlanD &plan, const uint8_t *prevD
     args.nulls[c] = plan.cols[c].nulls;
     args.bitOff[c] = plan.cols[c].bitOff;
   }
+  for (int d = 0; d < kFusedDims; d++) args.k[const_slot_dim(d)] = value_const(plan.dims[d].f);
   args.recB = ws.recB;
   args.countsB = ws.countsB;
   args.prevRanges = ws.prevRanges;
@@ -1009,6 +1634,7 @@ void rtc_merge_launch(void *kernel, const FusedPlanD &plan, const uint8_t *prevD
   args.capB = ws.capB;
   args.streams = static_cast<uint32_t>(ws.streams);
   args.prevSize = prevSize;
+  args.chunkRows = ws.chunkRows;
   size_t size = sizeof(args);
   void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
   static uint64_t *phases = nullptr;
@@ -1019,7 +1645,7 @@ void rtc_merge_launch(void *kernel, const FusedPlanD &plan, const uint8_t *prevD
   }
   {
     KernelTimer timer("hr_merge_rtc", stream);
-    hip_check(hipModuleLaunchKernel(fn, 1u << ws.partBits, 1, 1, hr::kThreads, 1, 1, 0, stream, nullptr, config),
+    hip_check(hipModuleLaunchKernel(kernel->fn, 1u << ws.partBits, 1, 1, hr::kThreads, 1, 1, 0, stream, nullptr, config),
               "hipModuleLaunchKernel");
   }
   if (phases_enabled()) {  // diagnostics: where a partition's time goes (100 MHz constant clock)
@@ -1044,22 +1670,32 @@ void rtc_merge_launch(void *kernel, const FusedPlanD &plan, const uint8_t *prevD
   }
 }
 
-std::string rtc_merge_source(const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w) {
-  return generate_merge(plan, nd, partBits, a, w);
-}
-
-// number of workgroups (= private streams per partition) the specialised kernel wants for `rows` rows
-int rtc_scan_grid(int64_t rows) {
-  const int64_t tiles = (rows + 4095) / 4096;
-  return static_cast<int>(tiles < hr::kMaxStreams ? (tiles < 1 ? 1 : tiles) : hr::kMaxStreams);
+std::string rtc_merge_source(const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w, bool compact) {
+  return generate_merge(plan, nd, partBits, a, w, 0, compact);
 }
 
 // source text of the kernel a plan would get (tests / tools; empty = unsupported shape)
-std::string rtc_scan_source(const FusedPlanD &plan, int nd, int partBits) {
-  uint32_t nullMask = 0;
-  for (int c = 0; c < plan.numCols; c++)
-    if (plan.cols[c].nulls) nullMask |= 1u << c;
-  return generate(plan, nd, partBits, nullMask);
+std::string rtc_scan_source(const FusedPlanD &plan, int nd, int partBits, bool compact) {
+  return generate(plan, nd, partBits, null_mask(plan), compact ? SCAN_COMPACT : SCAN_LINES16);
+}
+
+std::string rtc_table_scan_source(const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w) {
+  return generate(plan, nd, partBits, null_mask(plan), SCAN_TABLE, &a, &w);
 }
 
 }  // namespace ares
+
+// Exported (include/ares_extensions.h): blocks until no kernel is being compiled in the background; returns the
+// number of kernels the cache holds.  counters (may be null): [0] hiprtc compilations, [1] code objects found in
+// the on-disk cache, [2] kernels dropped from the in-memory cache.
+extern "C" size_t AresRtcWait(long *counters) {
+  ares::wait_idle();
+  ares::RtcCache &c = ares::cache();
+  if (counters) {
+    counters[0] = c.compiles.load();
+    counters[1] = c.diskHits.load();
+    counters[2] = c.evictions.load();
+  }
+  std::lock_guard<std::mutex> lock(c.mu);
+  return c.map.size();
+}

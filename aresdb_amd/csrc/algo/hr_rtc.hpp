@@ -1,8 +1,9 @@
-// Run-time compiled, per-plan specialised scan kernel of the fused HashReduce (hr_rtc.hip).
+// Run-time compiled, per-plan specialised scan / merge kernels of the fused HashReduce (hr_rtc.hip).
 #pragma once
 
 #include <hip/hip_runtime.h>
 
+#include <memory>
 #include <string>
 
 #include "hash_reduce_lds.hpp"
@@ -15,37 +16,59 @@ struct Workspace;
 struct Widen;
 }
 
+// A loaded kernel.  The handle keeps it alive: the cache may drop the entry (least recently used shapes go when it
+// is full), the module is unloaded when the last handle is gone.  Null = not available (unsupported shape, no
+// hiprtc, does not compile, or still being compiled on a background thread): the caller uses the generic kernel.
+struct RtcEntry;
+using RtcKernel = std::shared_ptr<RtcEntry>;
+
 // hiprtc could be loaded (and ARES_RTC is not 0)
 bool rtc_scan_available();
 // workgroups (= private record streams per partition) for a batch of `rows` rows
 int rtc_scan_grid(int64_t rows);
-// The specialised DIRECT-mode scan kernel of `plan` on `device` (generated, compiled and cached on first
-// use); nullptr = the plan is outside the supported shapes or the kernel could not be built: the caller
-// uses the generic kernel.
-void *rtc_scan_lookup(int device, const FusedPlanD &plan, int nd, int partBits);
-// Launches it over rows [0, length) of the plan's columns into the private streams of `ws`
-// (ws.streams workgroups; 16-byte records in whole 128-byte lines, ws.capB a multiple of 8).
-void rtc_scan_launch(void *kernel, const FusedPlanD &plan, uint32_t rowBase, int length, const hr::Workspace &ws,
+// tiles (4096 rows) each workgroup of the compact scan walks — its chunk is contiguous —, or 0 when a chunk would
+// not fit the record's row field (chunk rows <= 1 << (partBits + 9)): the caller takes the 16-byte records
+int rtc_compact_chunk_tiles(int64_t rows, int partBits);
+
+// Every lookup generates the kernel's source for the plan's SHAPE (comparison and + - x constants are kernel
+// arguments, divisors literals), and returns the loaded kernel or null.  `wait`: build it on this thread if it is
+// not there yet (otherwise it is built in the background and null is returned this time; ARES_RTC_ASYNC=0 makes
+// every lookup wait).
+
+// DIRECT-mode scan of `plan` (every surviving row becomes a record in the workgroup's private stream of its
+// partition): `compact` = 8-byte records in compact lines (hr::Workspace::lineRecords == 14, ws.chunkRows set),
+// otherwise 16-byte records in lines of 8.
+RtcKernel rtc_scan_lookup(int device, const FusedPlanD &plan, int nd, int partBits, bool compact, bool wait = false);
+void rtc_scan_launch(const RtcKernel &kernel, const FusedPlanD &plan, uint32_t rowBase, int length, const hr::Workspace &ws,
                      hipStream_t stream);
-// The same scan over rows [rowBase, rowBase + length) of a dimension vector of `nd` 4-byte dimensions and a
-// measure vector of `vw`-byte values (HashReduce on materialised vectors); records carry the whole value.
-void *rtc_vector_scan_lookup(int device, int nd, int vw, int partBits);
-void rtc_vector_scan_launch(void *kernel, const uint8_t *dimValues, size_t capacity, const uint8_t *values, int nd, int vw,
+// TABLE-mode scan of `plan` (low cardinality): LDS aggregation per workgroup, one record per group into region A
+// (what hr::flush_table writes), rtc_scan_grid(length) workgroups; the generic merge reads it.
+RtcKernel rtc_table_scan_lookup(int device, const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w,
+                                bool wait = false);
+void rtc_table_scan_launch(const RtcKernel &kernel, const FusedPlanD &plan, uint32_t rowBase, int length, const hr::Workspace &ws,
+                           hipStream_t stream);
+// The DIRECT scan over rows [rowBase, rowBase + length) of a dimension vector of `nd` 4-byte dimensions and a
+// measure vector of `vw`-byte values (HashReduce on materialised vectors); 16-byte records carry the whole value.
+RtcKernel rtc_vector_scan_lookup(int device, int nd, int vw, int partBits, bool wait = false);
+void rtc_vector_scan_launch(const RtcKernel &kernel, const uint8_t *dimValues, size_t capacity, const uint8_t *values, int nd, int vw,
                             uint32_t rowBase, int length, const hr::Workspace &ws, hipStream_t stream);
-std::string rtc_vector_scan_source(int nd, int vw, int partBits);
-// The specialised merge for what that scan produces (line records in region B, previous groups in their
+// The specialised merge for what the DIRECT scans produce (line records in region B, previous groups in their
 // partition-grouped ranges or none, one round over the whole hash range).  It raises outCount[3] when a
 // partition holds more groups than one LDS table: the caller then runs the generic merge.
-void *rtc_merge_lookup(int device, const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w);
-void rtc_merge_launch(void *kernel, const FusedPlanD &plan, const uint8_t *prevDims, size_t prevCapacity, const uint8_t *prevValues,
-                      uint32_t prevSize, uint8_t *dimOut, size_t outCapacity, uint8_t *outValues, const hr::Workspace &ws,
-                      hipStream_t stream);
-std::string rtc_merge_source(const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w);
+RtcKernel rtc_merge_lookup(int device, const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w, bool compact,
+                           bool wait = false);
+void rtc_merge_launch(const RtcKernel &kernel, const FusedPlanD &plan, const uint8_t *prevDims, size_t prevCapacity,
+                      const uint8_t *prevValues, uint32_t prevSize, uint8_t *dimOut, size_t outCapacity, uint8_t *outValues,
+                      const hr::Workspace &ws, hipStream_t stream);
 // ... and for what the vector-sourced scan produces (launched with rtc_merge_launch and an empty plan: every
 // row, old or new, is a row of the input vectors passed as prevDims / prevValues)
-void *rtc_vector_merge_lookup(int device, int nd, int vw, int partBits, const AggSpec &a);
+RtcKernel rtc_vector_merge_lookup(int device, int nd, int vw, int partBits, const AggSpec &a, bool wait = false);
+
+// the generated sources (empty = unsupported shape); for tools and tests
+std::string rtc_scan_source(const FusedPlanD &plan, int nd, int partBits, bool compact = false);
+std::string rtc_table_scan_source(const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w);
+std::string rtc_merge_source(const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w, bool compact = false);
+std::string rtc_vector_scan_source(int nd, int vw, int partBits);
 std::string rtc_vector_merge_source(int nd, int vw, int partBits, const AggSpec &a);
-// the generated source (empty = unsupported shape); for tools and tests
-std::string rtc_scan_source(const FusedPlanD &plan, int nd, int partBits);
 
 }  // namespace ares

@@ -283,24 +283,27 @@ void count_driver_allocation(size_t bytes) {
 // ARES_MEM_VERIFY_CLEAN=1 (tests): every block taken from the cache as "cleared" is checked on the device —
 // a writer that did not report what it wrote shows up as an abort here instead of as stale data in a
 // DeviceAllocate result.
-__global__ void verify_clear_kernel(const uint32_t *p, size_t words, unsigned int *nonzero) {
-  unsigned int found = 0;
+__global__ void verify_clear_kernel(const uint32_t *p, size_t words, unsigned long long *firstBad) {
+  unsigned long long first = ~0ull;
   for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < words; i += static_cast<size_t>(gridDim.x) * blockDim.x)
-    found |= p[i] != 0u;
-  if (found) atomicOr(nonzero, 1u);
+    if (p[i] != 0u && i < first) first = i;
+  if (first != ~0ull) atomicMin(firstBad, first);
 }
-void verify_clear(DeviceState *st, void *ptr, size_t rounded) {
+void verify_clear(DeviceState *st, void *ptr, size_t rounded, size_t requested) {
   static const bool on = [] {
     const char *e = getenv("ARES_MEM_VERIFY_CLEAN");
     return e && e[0] == '1';
   }();
   if (!on) return;
-  static unsigned int *flag = nullptr;
-  if (!flag && hipHostMalloc(reinterpret_cast<void **>(&flag), sizeof(unsigned int), hipHostMallocMapped) != hipSuccess) return;
-  *flag = 0;
-  hipLaunchKernelGGL(verify_clear_kernel, dim3(1024), dim3(256), 0, st->allocStream, static_cast<const uint32_t *>(ptr), rounded / 4, flag);
-  if (hipStreamSynchronize(st->allocStream) != hipSuccess || *flag) {
-    fprintf(stderr, "libmem: a %zu-byte block handed out as cleared holds data (a writer did not report its writes)\n", rounded);
+  static unsigned long long *flag = nullptr;
+  if (!flag && hipHostMalloc(reinterpret_cast<void **>(&flag), sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess) return;
+  *flag = ~0ull;
+  hipLaunchKernelGGL(verify_clear_kernel, dim3(1024), dim3(256), 0, st->freshStream, static_cast<const uint32_t *>(ptr), rounded / 4, flag);
+  if (hipStreamSynchronize(st->freshStream) != hipSuccess || *flag != ~0ull) {
+    uint32_t word = 0;
+    (void)hipMemcpy(&word, static_cast<const uint32_t *>(ptr) + *flag, 4, hipMemcpyDeviceToHost);
+    fprintf(stderr, "libmem: a block handed out as cleared holds data (a writer did not report its writes): bin %zu bytes, "
+                    "request %zu bytes, first non-zero word at byte offset %llu = 0x%08x\n", rounded, requested, *flag * 4ull, word);
     abort();
   }
 }
@@ -379,7 +382,7 @@ hipError_t pool_alloc(DeviceState *st, void **p, size_t bytes, bool zero) {
     b.allDirty = !zero;  // deviceMalloc: libalgorithm.so's own result buffers (HyperLogLog) — their writers do not report
   }
   *p = ptr;
-  if (zero && cleared) verify_clear(st, ptr, rounded);
+  if (zero && cleared) verify_clear(st, ptr, rounded, bytes);
   if (zero && !cleared) {  // (the whole block: what lies behind `bytes` is handed out by a later, larger request)
     hipError_t e = hipMemsetAsync(ptr, 0, rounded, st->freshStream);
     if (e != hipSuccess) return e;

@@ -19,6 +19,7 @@ with the in-ABI fusion stages switched off, at the reference's live-batch size, 
 explicit fused extension.
 """
 import argparse
+import gc
 import hashlib
 import json
 import os
@@ -291,6 +292,12 @@ def main(argv=None, backend=None, tensor_device=None):
             merge(ctx)
         ctx.release()
     sync()
+    # The host side of this benchmark is Python: a generation-2 collection of the interpreter's heap (torch alone
+    # brings ~10^6 objects) takes 30-50 ms and used to land in one step out of ~20.  The heap built so far is frozen
+    # and the collector is off inside the timed region — the Go host this stands in for has a concurrent collector.
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     drv0 = be.mem_driver_calls(device_index)
     shard_s = merge_s = 0.0
     t0 = time.perf_counter()
@@ -313,6 +320,7 @@ def main(argv=None, backend=None, tensor_device=None):
             merge_s += time.perf_counter() - t2
     sync()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     drv1 = be.mem_driver_calls(device_index)
     # ---- per-kernel durations: the same steps once more with HIP events around every launch (on the launch's own
     # stream, inside the library) — outside the timed region, so that the events cost `value` nothing; the pass's

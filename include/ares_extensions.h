@@ -26,6 +26,15 @@ size_t AresProfilerReport(char *buf, size_t len);
  * read its variable again on next use.  For tests that flip a switch inside one process. */
 void AresReloadEnv(void);
 
+/* The scan and merge kernels of a high- or low-cardinality HashReduce are compiled for the query's SHAPE at run time
+ * (hiprtc; comparison and + - x constants are kernel arguments, so a new time range reuses the kernel) on a background
+ * thread — a query never waits for the compiler, it runs the generic kernels until its kernels are loaded.
+ * AresRtcWait() blocks until nothing is being compiled and returns the number of kernels in the cache; counters
+ * (may be NULL) receives {hiprtc compilations, code objects loaded from the on-disk cache, kernels evicted}.
+ * Environment: ARES_RTC=0 (off), ARES_RTC_ASYNC=0 (compile on the calling thread), ARES_RTC_CACHE_DIR (on-disk
+ * cache of code objects; default ~/.cache/aresdb_amd/rtc; "off" disables), ARES_RTC_CACHE_ENTRIES (default 256). */
+size_t AresRtcWait(long *counters);
+
 /* Cross-call fusion inside the unchanged ABI.  Root transforms of the hot shape (a 4-byte column,
  * optionally combined with a constant, written to a dimension vector or a measure vector) are not
  * launched one by one: libalgorithm.so keeps up to 8 of them per (device, stream) and runs them as

@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+# The run-time compiled kernels are built on a background thread by default (a query never waits for hiprtc and runs
+# the generic kernels meanwhile): which kernel a test exercises would depend on timing.  Tests compile inline; the
+# asynchronous mode has its own tests.
+os.environ.setdefault("ARES_RTC_ASYNC", "0")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

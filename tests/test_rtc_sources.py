@@ -22,12 +22,15 @@ def test_generated_kernels_compile_for_gfx950(tmp_path):
                    check=True, timeout=600)
     out = subprocess.run([str(exe), str(tmp_path / "k")], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    assert "compile rc 0" in out.stdout and "merge compile rc 0" in out.stdout
+    for what in ("scan", "merge", "compact scan", "compact merge", "table scan", "compact scan (2 dims)",
+                 "compact merge (2 dims)", "table scan (2 dims, 1 partition)"):
+        assert f"{what} compile rc 0" in out.stdout, what
     for nd in (1, 4):
         for vw in (4, 8):
             assert f"vector scan nd {nd} vw {vw} compile rc 0" in out.stdout
             assert f"vector merge nd {nd} vw {vw} compile rc 0" in out.stdout
     # the plan-sourced kernels keep their whole working set in registers and LDS: no scratch
-    notes = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", str(tmp_path / "k.co")], capture_output=True, text=True)
-    if notes.returncode == 0 and ".private_segment_fixed_size" in notes.stdout:
-        assert ".private_segment_fixed_size: 0" in notes.stdout
+    for tag in ("k", "k_compact", "k_cmerge", "k_table"):
+        notes = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", str(tmp_path / f"{tag}.co")], capture_output=True, text=True)
+        if notes.returncode == 0 and ".private_segment_fixed_size" in notes.stdout:
+            assert ".private_segment_fixed_size: 0" in notes.stdout, tag

@@ -36,39 +36,55 @@ int main(int argc, char **argv) {
   for (int d = 1; d < 4; d++) { p.dims[d].f = col(K_U32); p.dims[d].col = d; p.dims[d].outKind = K_U32; }
   p.measure.f = col(K_F32); p.measure.col = 4; p.measure.outKind = K_F32;
   p.measureDtype = Float64; p.measureWidth = 8; p.identity = 0;
-  const std::string src = rtc_scan_source(p, 4, 9);
-  if (src.empty()) { puts("unsupported plan"); return 2; }
   const std::string prefix = argc > 1 ? argv[1] : "/tmp/hr_scan_rtc";
-  std::ofstream(prefix + ".hip") << src;
-  hiprtcProgram prog;
-  if (hiprtcCreateProgram(&prog, src.c_str(), "hr_scan_rtc.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return 3;
   const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics"};
-  const hiprtcResult rc = hiprtcCompileProgram(prog, 4, opts);
-  size_t n = 0; hiprtcGetProgramLogSize(prog, &n);
-  std::string log(n, 0); if (n) hiprtcGetProgramLog(prog, &log[0]);
-  printf("compile rc %d\n%s\n", static_cast<int>(rc), log.c_str());
-  if (rc != HIPRTC_SUCCESS) return 4;
-  size_t cs = 0; hiprtcGetCodeSize(prog, &cs);
-  std::vector<char> code(cs); hiprtcGetCode(prog, code.data());
-  std::ofstream(prefix + ".co", std::ios::binary).write(code.data(), static_cast<std::streamsize>(cs));
-  printf("code object %zu bytes -> %s.co\n", cs, prefix.c_str());
-  // the specialised merge of the same plan
+  size_t n = 0, cs = 0;
+  auto build = [&](const std::string &src, const std::string &tag, const char *what) -> int {
+    if (src.empty()) { printf("%s: unsupported plan\n", what); return 2; }
+    std::ofstream(prefix + tag + ".hip") << src;
+    hiprtcProgram prog;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "hr_rtc.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return 3;
+    const hiprtcResult rc = hiprtcCompileProgram(prog, 4, opts);
+    size_t ln = 0; hiprtcGetProgramLogSize(prog, &ln);
+    std::string log(ln, 0); if (ln) hiprtcGetProgramLog(prog, &log[0]);
+    printf("%s compile rc %d\n%s\n", what, static_cast<int>(rc), log.c_str());
+    if (rc != HIPRTC_SUCCESS) return 4;
+    size_t sz = 0; hiprtcGetCodeSize(prog, &sz);
+    std::vector<char> code(sz); hiprtcGetCode(prog, code.data());
+    std::ofstream(prefix + tag + ".co", std::ios::binary).write(code.data(), static_cast<std::streamsize>(sz));
+    printf("%s code object %zu bytes -> %s%s.co\n", what, sz, prefix.c_str(), tag.c_str());
+    return 0;
+  };
   AggSpec agg = make_agg_spec(AGGR_SUM_FLOAT, 8);
   hr::Widen w{1, K_F32, Float64};
-  const std::string msrc = rtc_merge_source(p, 4, 9, agg, w);
-  if (msrc.empty()) { puts("merge: unsupported plan"); return 5; }
-  std::ofstream(prefix + "_merge.hip") << msrc;
-  hiprtcProgram mp;
-  if (hiprtcCreateProgram(&mp, msrc.c_str(), "hr_merge_rtc.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return 6;
-  const hiprtcResult mrc = hiprtcCompileProgram(mp, 4, opts);
-  n = 0; hiprtcGetProgramLogSize(mp, &n);
-  std::string mlog(n, 0); if (n) hiprtcGetProgramLog(mp, &mlog[0]);
-  printf("merge compile rc %d\n%s\n", static_cast<int>(mrc), mlog.c_str());
-  if (mrc != HIPRTC_SUCCESS) return 7;
-  hiprtcGetCodeSize(mp, &cs);
-  std::vector<char> mcode(cs); hiprtcGetCode(mp, mcode.data());
-  std::ofstream(prefix + "_merge.co", std::ios::binary).write(mcode.data(), static_cast<std::streamsize>(cs));
-  printf("merge code object %zu bytes\n", cs);
+  // the same shape with another comparison constant is the same source text (constants are kernel arguments)
+  {
+    FusedPlanD p2 = p;
+    p2.filters[0].f.bbits = 17;
+    if (rtc_scan_source(p2, 4, 9, true) != rtc_scan_source(p, 4, 9, true)) { puts("comparison constants leak into the source"); return 20; }
+    p2.dims[0].f.bbits = 60;
+    if (rtc_scan_source(p2, 4, 9, true) == rtc_scan_source(p, 4, 9, true)) { puts("divisors must be literals"); return 21; }
+  }
+  if (int rc = build(rtc_scan_source(p, 4, 9, false), "", "scan")) return rc;
+  if (int rc = build(rtc_merge_source(p, 4, 9, agg, w, false), "_merge", "merge")) return rc;
+  if (int rc = build(rtc_scan_source(p, 4, 9, true), "_compact", "compact scan")) return rc;
+  if (int rc = build(rtc_merge_source(p, 4, 9, agg, w, true), "_cmerge", "compact merge")) return rc;
+  if (int rc = build(rtc_table_scan_source(p, 4, 9, agg, w), "_table", "table scan")) return rc;
+  {  // another shape: two dimensions, int32 measure summed into 4 bytes, no nulls, 8 partitions
+    FusedPlanD q = p;
+    q.numCols = 3;
+    for (int c = 0; c < 3; c++) q.cols[c].nulls = nullptr;
+    q.numFilters = 0;
+    q.dims[0] = p.dims[1]; q.dims[0].col = 0;
+    q.dims[1] = p.dims[2]; q.dims[1].col = 1; q.dims[1].f.arity = 2; q.dims[1].f.functor = Plus; q.dims[1].f.bkind = K_I32; q.dims[1].f.bbits = 5; q.dims[1].f.bok = 1;
+    q.measure.f = col(K_I32); q.measure.col = 2; q.measure.outKind = K_I32;
+    q.measureDtype = Int32; q.measureWidth = 4; q.identity = 0;
+    AggSpec a4 = make_agg_spec(AGGR_SUM_SIGNED, 4);
+    hr::Widen w4{0, K_I32, Int32};
+    if (int rc = build(rtc_scan_source(q, 2, 3, true), "_compact2", "compact scan (2 dims)")) return rc;
+    if (int rc = build(rtc_merge_source(q, 2, 3, a4, w4, true), "_cmerge2", "compact merge (2 dims)")) return rc;
+    if (int rc = build(rtc_table_scan_source(q, 2, 0, a4, w4), "_table2", "table scan (2 dims, 1 partition)")) return rc;
+  }
   // the vector-sourced scan (HashReduce on materialised dimension / measure vectors)
   for (int vw = 4; vw <= 8; vw += 4)
     for (int nd = 1; nd <= 4; nd += 3) {

@@ -14,6 +14,16 @@ import torch
 # radices of the dense key code: value range + 1 slot for "null"
 _R_TS, _R_D1, _R_D2, _R_D3 = 169, 101, 51, 3
 KEY_SPACE = _R_TS * _R_D1 * _R_D2 * _R_D3
+ALL_DIMS = ("ts", "d1", "d2", "d3")
+_RADIX = {"ts": _R_TS, "d1": _R_D1, "d2": _R_D2, "d3": _R_D3}
+_SCALE = {"ts": 3600, "d1": 1, "d2": 1, "d3": 1}  # stored dimension value = code x scale (the hourly bucket)
+
+
+def key_space(dims=ALL_DIMS):
+    n = 1
+    for d in dims:
+        n *= _RADIX[d]
+    return n
 
 
 def _rotl(x, r):
@@ -21,21 +31,27 @@ def _rotl(x, r):
 
 
 def murmur3_32_rows(values, valids):
-    """murmur3_x86_32 (seed 0) of the packed dimension rows [v0..v3 little-endian uint32][validity
-    bytes] — 4 x 4 + 4 = 20 bytes (query/utils.cu:113-155, query/hash_reduction.cu:216-243)."""
-    assert len(values) == 4 and len(valids) == 4
+    """murmur3_x86_32 (seed 0) of the packed dimension rows [v0..v(nd-1) little-endian uint32][nd validity
+    bytes] — 5 nd bytes (query/utils.cu:113-155, query/hash_reduction.cu:216-243): the validity bytes are a
+    fifth block when nd = 4, otherwise murmur's tail."""
+    nd = len(values)
+    assert 1 <= nd <= 4 and len(valids) == nd
     c1, c2 = np.uint32(0xcc9e2d51), np.uint32(0x1b873593)
     h = np.zeros(len(values[0]), np.uint32)
     tail = np.zeros(len(values[0]), np.uint32)
     for d, v in enumerate(valids):
         tail |= (v.astype(np.uint32) & np.uint32(0xFF)) << np.uint32(8 * d)
     with np.errstate(over="ignore"):
-        for k in [v.astype(np.uint32) for v in values] + [tail]:
+        for k in [v.astype(np.uint32) for v in values] + ([tail] if nd == 4 else []):
             k = (k * c1).astype(np.uint32)
             k = (_rotl(k, 15) * c2).astype(np.uint32)
             h ^= k
             h = (_rotl(h, 13) * np.uint32(5) + np.uint32(0xe6546b64)).astype(np.uint32)
-        h ^= np.uint32(20)
+        if nd < 4:
+            k = (tail * c1).astype(np.uint32)
+            k = (_rotl(k, 15) * c2).astype(np.uint32)
+            h ^= k
+        h ^= np.uint32(5 * nd)
         h ^= h >> np.uint32(16)
         h = (h * np.uint32(0x85ebca6b)).astype(np.uint32)
         h ^= h >> np.uint32(13)
@@ -44,45 +60,48 @@ def murmur3_32_rows(values, valids):
     return h
 
 
-def _codes_of_batch(b, limit=None):
+def _codes_of_batch(b, limit=None, dims=ALL_DIMS, d1_below=90):
     """dense key code, keep mask and float64 measure of every row of one C3 batch (torch, on the
-    batch's device); a null dimension is its own key slot, a null measure contributes 0."""
+    batch's device) for the group-by dimensions `dims` (a subset of ts-bucket, d1, d2, d3; the filter d1 < 90 and the
+    measure stay); a null dimension is its own key slot, a null measure contributes 0."""
     def col(name):
         rc = b[name]
         n = rc.length if limit is None else min(limit, rc.length)
         v = rc.values()[:n]
         ok = rc.valid()
         return v, (None if ok is None else ok[:n])
-    ts, tsv = col("ts")
     d1, d1v = col("d1")
-    d2, d2v = col("d2")
-    d3, d3v = col("d3")
     m, mv = col("m")
-    tsb = torch.div(ts, 3600, rounding_mode="floor").to(torch.int64)
-    keep = d1 < 90
+    keep = d1 < d1_below
     if d1v is not None:
         keep &= d1v
     def code(v, ok, null_code):
         v = v.to(torch.int64)
         return v if ok is None else torch.where(ok, v, torch.full_like(v, null_code))
-    c = ((code(tsb, tsv, _R_TS - 1) * _R_D1 + code(d1, d1v, _R_D1 - 1)) * _R_D2 + code(d2, d2v, _R_D2 - 1)) * _R_D3 \
-        + code(d3, d3v, _R_D3 - 1)
+    c = None
+    for name in dims:
+        v, ok = col(name)
+        if name == "ts":
+            v = torch.div(v, 3600, rounding_mode="floor")
+        k = code(v, ok, _RADIX[name] - 1)
+        c = k if c is None else c * _RADIX[name] + k
     mm = m.to(torch.float64)
     if mv is not None:
         mm = torch.where(mv, mm, torch.zeros_like(mm))
     return c, keep, mm
 
 
-def exact_groups(batches, limit_first_batch=None):
-    """Exact group-by of the C3 query over `batches` (all rows, or the first `limit_first_batch` rows
-    of the first batch only).  Returns numpy arrays (code, sum, first_row, rows) of the groups."""
+def exact_groups(batches, limit_first_batch=None, dims=ALL_DIMS, d1_below=90):
+    """Exact group-by of the C3 query (group-by dimensions `dims`) over `batches` (all rows, or the first
+    `limit_first_batch` rows of the first batch only).  Returns numpy arrays (code, sum, first_row, rows) of the groups."""
     dev = batches[0]["m"].blob.device
-    acc = torch.zeros(KEY_SPACE, dtype=torch.float64, device=dev)
-    cnt = torch.zeros(KEY_SPACE, dtype=torch.int64, device=dev)
-    first = torch.full((KEY_SPACE,), torch.iinfo(torch.int64).max, dtype=torch.int64, device=dev)
+    space = key_space(dims)
+    acc = torch.zeros(space, dtype=torch.float64, device=dev)
+    cnt = torch.zeros(space, dtype=torch.int64, device=dev)
+    first = torch.full((space,), torch.iinfo(torch.int64).max, dtype=torch.int64, device=dev)
     offset = 0
     for b in (batches[:1] if limit_first_batch is not None else batches):
-        c, keep, mm = _codes_of_batch(b, limit_first_batch)
+        c, keep, mm = _codes_of_batch(b, limit_first_batch, dims, d1_below)
         idx = c[keep]
         acc.index_add_(0, idx, mm[keep])
         cnt.index_add_(0, idx, torch.ones_like(idx))
@@ -94,37 +113,36 @@ def exact_groups(batches, limit_first_batch=None):
     return (live.cpu().numpy(), acc[live].cpu().numpy(), first[live].cpu().numpy(), cnt[live].cpu().numpy())
 
 
-def decode_codes(code):
-    """(values[4], valids[4]) of dense key codes, as the dimension vector stores them: a null
+def decode_codes(code, dims=ALL_DIMS):
+    """(values[nd], valids[nd]) of dense key codes, as the dimension vector stores them: a null
     dimension holds value 0 with validity 0 (the synthetic columns keep zeros under nulls)."""
     c = code.astype(np.int64)
-    d3 = c % _R_D3; c //= _R_D3
-    d2 = c % _R_D2; c //= _R_D2
-    d1 = c % _R_D1; c //= _R_D1
-    ts = c
+    parts = []
+    for name in reversed(dims):
+        parts.append((name, c % _RADIX[name]))
+        c = c // _RADIX[name]
     out_v, out_ok = [], []
-    for v, null_code, scale in ((ts, _R_TS - 1, 3600), (d1, _R_D1 - 1, 1), (d2, _R_D2 - 1, 1), (d3, _R_D3 - 1, 1)):
-        ok = v != null_code
-        out_v.append(np.where(ok, v * scale, 0).astype(np.uint32))
+    for name, v in reversed(parts):
+        ok = v != _RADIX[name] - 1
+        out_v.append(np.where(ok, v * _SCALE[name], 0).astype(np.uint32))
         out_ok.append(ok.astype(np.uint8))
     return out_v, out_ok
 
 
-def encode_rows(values, valids):
+def encode_rows(values, valids, dims=ALL_DIMS):
     """dense key codes of fetched dimension rows (inverse of decode_codes)."""
-    ts, d1, d2, d3 = [np.asarray(v).view(np.uint32).astype(np.int64) for v in values]
-    oks = [np.asarray(v).astype(bool) for v in valids]
-    tsc = np.where(oks[0], ts // 3600, _R_TS - 1)
-    d1c = np.where(oks[1], d1, _R_D1 - 1)
-    d2c = np.where(oks[2], d2, _R_D2 - 1)
-    d3c = np.where(oks[3], d3, _R_D3 - 1)
-    return ((tsc * _R_D1 + d1c) * _R_D2 + d2c) * _R_D3 + d3c
+    c = None
+    for name, v, ok in zip(dims, values, valids):
+        v = np.asarray(v).view(np.uint32).astype(np.int64)
+        k = np.where(np.asarray(ok).astype(bool), v // _SCALE[name], _RADIX[name] - 1)
+        c = k if c is None else c * _RADIX[name] + k
+    return c
 
 
-def predict_hash_merges(code, sums, first_row):
+def predict_hash_merges(code, sums, first_row, dims=ALL_DIMS):
     """Groups as HashReduce forms them: one per distinct 32-bit hash; representative = the member
     whose first row comes first; value = sum over the members."""
-    values, valids = decode_codes(code)
+    values, valids = decode_codes(code, dims)
     h = murmur3_32_rows(values, valids)
     order = np.lexsort((first_row, h))
     hs = h[order]
@@ -156,17 +174,17 @@ def compare_tables(got_code, got_sum, want_code, want_sum, rel=0.0):
     return None
 
 
-def compare_result(fetched, expected, hash_identity=True, rel=0.0):
+def compare_result(fetched, expected, hash_identity=True, rel=0.0, dims=ALL_DIMS):
     """fetched = (dims, valids, measures) of NativeQuery.fetch(); expected = exact_groups(...).
     hash_identity: the result comes from HashReduce (groups are hashes); False: Sort+Reduce on the
     64-bit hash (exact groups at these cardinalities).  Returns a report dict."""
-    dims, valids, meas = fetched
+    dims_, valids, meas = fetched
     code, sums, first_row, _ = expected
-    got_code = encode_rows([np.frombuffer(d, np.uint32) for d in dims], [np.frombuffer(v, np.uint8) for v in valids])
+    got_code = encode_rows([np.frombuffer(d, np.uint32) for d in dims_], [np.frombuffer(v, np.uint8) for v in valids], dims)
     got_sum = np.frombuffer(meas, np.float64)
     merged = 0
     if hash_identity:
-        want_code, want_sum, merged = predict_hash_merges(code, sums, first_row)
+        want_code, want_sum, merged = predict_hash_merges(code, sums, first_row, dims)
     else:
         want_code, want_sum = code, sums
     why = compare_tables(got_code, got_sum, want_code, want_sum, rel)

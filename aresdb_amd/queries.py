@@ -4,12 +4,15 @@ from . import abi
 from .executor import Binary, Col, Const, DimensionSpec, QueryPlan
 
 
-def c3_plan(use_hash_reduction=True, with_filter=True):
+def c3_plan(use_hash_reduction=True, with_filter=True, dims=("ts", "d1", "d2", "d3"), d1_below=90):
+    """BASELINE config C3; `dims` selects a subset of its four group-by dimensions (lower-cardinality variants of the
+    same query: the filter and the measure stay), `d1_below` the filter constant."""
+    specs = {"ts": DimensionSpec(Binary(abi.Floor, Col("ts"), Const(3600)), abi.Uint32),
+             "d1": DimensionSpec(Col("d1"), abi.Uint32), "d2": DimensionSpec(Col("d2"), abi.Uint32),
+             "d3": DimensionSpec(Col("d3"), abi.Uint32)}
     return QueryPlan(
-        filters=[Binary(abi.LessThan, Col("d1"), Const(90))] if with_filter else [],
-        dimensions=[DimensionSpec(Binary(abi.Floor, Col("ts"), Const(3600)), abi.Uint32),
-                    DimensionSpec(Col("d1"), abi.Uint32), DimensionSpec(Col("d2"), abi.Uint32),
-                    DimensionSpec(Col("d3"), abi.Uint32)],
+        filters=[Binary(abi.LessThan, Col("d1"), Const(d1_below))] if with_filter else [],
+        dimensions=[specs[d] for d in dims],
         measure=Col("m"), agg=abi.AGGR_SUM_FLOAT, measure_type=abi.Float64,
         use_hash_reduction=use_hash_reduction)
 

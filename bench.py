@@ -149,6 +149,69 @@ def kernel_table(kernels):
     return out
 
 
+def dominant_roofline(kernels, bytes_per_row, rows_total):
+    """Algorithmic bytes of `rows_total` rows over the summed duration of the kernel that took longest."""
+    if not kernels:
+        return None
+    name, (launches, ms) = max(kernels.items(), key=lambda kv: kv[1][1])
+    achieved = bytes_per_row * rows_total / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS, "algorithmic_bytes_per_launch": bytes_per_row * rows_total / launches,
+            "avg_launch_ms": ms / launches, "launches": launches}
+
+
+def measure_traffic(batch_rows, timeout=240):
+    """HBM bytes per launch of every kernel of the C3 hot path, measured now: two rocprofv3 --pmc passes
+    (FETCH_SIZE, WRITE_SIZE: they do not fit one pass; kernel-trace only, never combined with API tracing) over
+    tools/pmc_driver.py — three passes of the query over one resident batch of `batch_rows` rows.  The read side is
+    doubled as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE tallies 64 B per 128-B request on wide
+    coalesced reads).  Returns ({kernel: {...}}, note)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {}, "rocprofv3 not found"
+    out = tempfile.mkdtemp(prefix="ares_pmc_", dir="/tmp")
+    acc = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(out, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--",
+                   sys.executable, os.path.join(ROOT, "tools", "pmc_driver.py"), str(batch_rows), "3"]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp", "ARES_RTC_ASYNC": "0"},
+                                   capture_output=True, text=True, timeout=timeout)
+            except subprocess.TimeoutExpired:
+                return {}, f"rocprofv3 --pmc {counter}: timeout"
+            if r.returncode != 0:
+                return {}, f"rocprofv3 --pmc {counter}: rc {r.returncode}: {r.stderr[-200:]}"
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    name = row.get("Kernel_Name", "")
+                    if "ares::" not in name and "_rtc" not in name:
+                        continue
+                    short = (name.split("ares::")[1] if "ares::" in name else name).replace("(anonymous namespace)::", "")
+                    short = short.split("(")[0].split("<")[0]
+                    if row.get("Counter_Name") != counter:
+                        continue
+                    a = acc.setdefault(short, {})
+                    a[counter] = a.get(counter, 0.0) + float(row["Counter_Value"])
+                    a[counter + "_n"] = a.get(counter + "_n", 0) + 1
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+    kernels = {}
+    for k, a in acc.items():
+        if "FETCH_SIZE" in a and "WRITE_SIZE" in a:
+            f = a["FETCH_SIZE"] / a["FETCH_SIZE_n"] * 1024.0
+            w = a["WRITE_SIZE"] / a["WRITE_SIZE_n"] * 1024.0
+            kernels[k] = {"fetch_bytes_per_launch": 2 * f, "write_bytes_per_launch": w, "hbm_bytes_per_launch": 2 * f + w,
+                          "launches_profiled": a["FETCH_SIZE_n"]}
+    return kernels, ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes taken inside this run (tools/pmc_driver.py, "
+                     f"{batch_rows} rows per batch; read side x2: gfx950 counts 64 B per 128-B request)")
+
+
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` outside torchrun: one process per GPU (RANK / LOCAL_RANK /
     WORLD_SIZE from torch.distributed.run), rendezvous on 127.0.0.1."""
@@ -193,6 +256,11 @@ def main(argv=None, backend=None, tensor_device=None):
     ap.add_argument("--one-stream", action="store_true", help="every batch on one stream (the Go host alternates two)")
     ap.add_argument("--verify-merged", action="store_true",
                     help="N > 1: rank 0 regenerates every shard and checks the merged table key by key (small sizes)")
+    ap.add_argument("--dims", default="ts,d1,d2,d3",
+                    help="group-by dimensions, a subset of C3's four (lower-cardinality variants of the same query: secondary legs)")
+    ap.add_argument("--d1-below", type=int, default=90, help="constant of the filter d1 < K")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes that measure roofline.traffic")
+    ap.add_argument("--cold", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--leg", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--fused-extension", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args(argv)
@@ -239,8 +307,12 @@ def main(argv=None, backend=None, tensor_device=None):
     rows, batch_rows = int(args.rows), int(args.batch_rows)
     batches = workload.c3_shard(rows, batch_rows, seed=1 + rank, device=tdev, null_fraction=args.null_fraction)
     vps = [({k: rc.vp for k, rc in b.items()}, next(iter(b.values())).length) for b in batches]
-    plan = c3_plan(use_hash_reduction=True)
+    dims = tuple(d for d in args.dims.split(",") if d)
+    assert dims and all(d in check.ALL_DIMS for d in dims), args.dims
+    plan = c3_plan(use_hash_reduction=True, dims=dims, d1_below=args.d1_below)
     plan.use_fused_extension = bool(args.fused_extension)
+    # columns the plan reads (dimensions + measure + the filter's d1): the algorithmic bytes per row
+    plan_columns = sorted(set(dims) | {"m", "d1"})
 
     def sync():
         if on_gpu:
@@ -285,6 +357,45 @@ def main(argv=None, backend=None, tensor_device=None):
         ctx.merge_shards(comm)
         return ctx.result_size
 
+    if args.cold:  # secondary leg (own process): the very first query of a process, then the same shape with another constant
+        cold = {}
+        sync()
+        t0 = time.perf_counter()
+        ctx = run_shard(be, plan, vps, device_index, streams)
+        sync()
+        cold["cold_first_query_ms"] = (time.perf_counter() - t0) * 1e3
+        rep = check.compare_result(ctx.fetch(), check.exact_groups(batches, dims=dims, d1_below=args.d1_below), hash_identity=True, dims=dims)
+        cold["cold_check_groups"] = rep["status"]
+        ctx.release()
+        cold["rtc_after_cold_query"] = be.rtc_wait()  # (waits for the kernels the first query asked for)
+        for _ in range(2):
+            ctx = run_shard(be, plan, vps, device_index, streams)
+            ctx.release()
+        sync()
+        t0 = time.perf_counter()
+        ctx = run_shard(be, plan, vps, device_index, streams)
+        sync()
+        cold["warm_query_ms"] = (time.perf_counter() - t0) * 1e3
+        ctx.release()
+        plan2 = c3_plan(use_hash_reduction=True, dims=dims, d1_below=args.d1_below - 7)  # another constant, never seen
+        sync()
+        t0 = time.perf_counter()
+        ctx = run_shard(be, plan2, vps, device_index, streams)
+        sync()
+        cold["new_constants_query_ms"] = (time.perf_counter() - t0) * 1e3
+        rep = check.compare_result(ctx.fetch(), check.exact_groups(batches, dims=dims, d1_below=args.d1_below - 7), hash_identity=True, dims=dims)
+        cold["new_constants_check_groups"] = rep["status"]
+        cold["rtc_after_new_constants"] = be.rtc_wait()
+        ctx.release()
+        print(json.dumps(cold), flush=True)
+        sys.exit(0 if cold["cold_check_groups"] == "ok" and cold["new_constants_check_groups"] == "ok" else 1)
+
+    # The scan / merge kernels of this query shape are compiled in the background the first time the shape is seen
+    # (a query never waits for hiprtc: it runs the generic kernels meanwhile).  One untimed priming pass, then wait
+    # for the compiler — what a server's first query of the shape does for every later one.
+    ctx = run_shard(be, plan, vps, device_index, streams)
+    ctx.release()
+    rtc_state = be.rtc_wait() if on_gpu else None
     # ---- the timed region: W warm-up steps, then exactly K steps between barrier + synchronize ----
     for _ in range(args.warmup):
         ctx = run_shard(be, plan, vps, device_index, streams)
@@ -356,38 +467,43 @@ def main(argv=None, backend=None, tensor_device=None):
             every = []
             for r in range(world):
                 every += workload.c3_shard(rows, batch_rows, seed=1 + r, device=tdev, null_fraction=args.null_fraction)
-            merged_check = check.compare_result(ctx.fetch(), check.exact_groups(every), hash_identity=True)
+            merged_check = check.compare_result(ctx.fetch(), check.exact_groups(every, dims=dims, d1_below=args.d1_below),
+                                                hash_identity=True, dims=dims)
         ctx.release()
         ctx = run_shard(be, plan, vps, device_index, streams)
-    report = check.compare_result(ctx.fetch(), check.exact_groups(batches), hash_identity=True)
+    report = check.compare_result(ctx.fetch(), check.exact_groups(batches, dims=dims, d1_below=args.d1_below), hash_identity=True, dims=dims)
     groups = ctx.result_size
     ok = report["status"] == "ok" and report["groups"] == groups
     if merged_check is not None:
         ok = ok and merged_check["status"] == "ok" and merged_check["groups"] == merged_groups
     ctx.release()
 
-    bytes_per_row = 5 * 4 + (5 / 8 if args.null_fraction > 0 else 0)
+    bytes_per_row = len(plan_columns) * (4 + (1 / 8 if args.null_fraction > 0 else 0))
     total_rows_rank = rows * max(prof_steps, 1)  # rows the profiled pass (the `kernels` table) went over
     if args.leg:  # a secondary leg: the measurement and its check, nothing else
         print(json.dumps({"rows_per_sec_per_gpu": rows * args.steps / elapsed, "ms_per_step": elapsed / args.steps * 1e3,
                           "batches": len(vps), "groups": groups, "check_groups": report["status"],
                           "algorithmic_GBps": rows * args.steps / elapsed * bytes_per_row / 1e9,
+                          "columns_read": plan_columns, "algorithmic_bytes_per_row": bytes_per_row,
+                          "roofline": dominant_roofline(kernels, bytes_per_row, total_rows_rank),
                           "kernels": {n: {"launches": c, "avg_ms": ms / c} for n, (c, ms) in
                                       sorted(kernels.items(), key=lambda kv: -kv[1][1])}}), flush=True)
         sys.exit(0 if ok else 1)
 
     kern_out = kernel_table(kernels)
-    # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, corrected
-    # as MI355X_MICROARCH.md prescribes) — only when they were taken on THIS build of libalgorithm.so
-    # at this batch size; otherwise `traffic` is null rather than stale
-    pmc_kernels, pmc_note = {}, "no PMC pass of this libalgorithm.so build at this batch size under profiles/"
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        if pmc.get("rows_per_batch") == batch_rows and pmc.get("libalgorithm_sha256_16") == library_sha() and on_gpu:
-            pmc_kernels = pmc["kernels"]
-            pmc_note = f"profiles/pmc_traffic.json (build {pmc['libalgorithm_sha256_16']})"
-    except (OSError, ValueError, KeyError):
-        pass
+    # HBM bytes per launch: measured now by two rocprofv3 --pmc passes (rank 0 of a 1-GPU run), else — same build of
+    # libalgorithm.so and same batch size only — from the committed passes under profiles/, else null
+    pmc_kernels, pmc_note = {}, "not measured (--no-pmc)"
+    if rank == 0 and world == 1 and on_gpu and not args.no_pmc and not args.leg:
+        pmc_kernels, pmc_note = measure_traffic(batch_rows)
+    if not pmc_kernels:
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if pmc.get("rows_per_batch") == batch_rows and pmc.get("libalgorithm_sha256_16") == library_sha() and on_gpu:
+                pmc_kernels = pmc["kernels"]
+                pmc_note += f"; taken from profiles/pmc_traffic.json (build {pmc['libalgorithm_sha256_16']})"
+        except (OSError, ValueError, KeyError):
+            pass
     for name, k in kern_out.items():  # measured traffic rate of every kernel (not the algorithmic roofline)
         base = name.split("<")[0]
         if base in pmc_kernels:
@@ -395,14 +511,12 @@ def main(argv=None, backend=None, tensor_device=None):
             k["hbm_GBps"] = k["hbm_bytes_per_launch"] / (k["avg_ms"] * 1e-3) / 1e9
     roofline = chain = None
     if kernels:
-        name, (launches, ms) = max(kernels.items(), key=lambda kv: kv[1][1])
-        traffic = pmc_kernels.get(name.split("<")[0], {}).get("hbm_bytes_per_launch")
-        achieved = bytes_per_row * total_rows_rank / (ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": pmc_note,
-                    "algorithmic_bytes_per_launch": bytes_per_row * total_rows_rank / launches,
-                    "avg_launch_ms": ms / launches, "launches": launches,
-                    "note": "algorithmic = 20 B/row of compulsory column reads (+5 validity bits/row), SURVEY.md 8d"}
+        roofline = dominant_roofline(kernels, bytes_per_row, total_rows_rank)
+        base = roofline["kernel"].split("<")[0]
+        traffic = pmc_kernels.get(base, {}).get("hbm_bytes_per_launch")
+        roofline.update({"traffic": traffic, "traffic_source": pmc_note,
+                         "traffic_over_algorithmic": None if traffic is None else traffic / roofline["algorithmic_bytes_per_launch"],
+                         "note": "algorithmic = 20 B/row of compulsory column reads (+5 validity bits/row), SURVEY.md 8d"})
         all_ms = sum(v[1] for v in kernels.values())
         chain = {"kernel_ms_per_step": all_ms / prof_steps,
                  "achieved": bytes_per_row * total_rows_rank / (all_ms * 1e-3) / 1e9, "unit": "GB/s",
@@ -426,6 +540,16 @@ def main(argv=None, backend=None, tensor_device=None):
             legs["eager_abi_ARES_DEFER=0"] = run_leg({"ARES_DEFER": "0"}, big)
             legs["fused_extension"] = run_leg({}, big + ["--fused-extension"])
             legs[f"live_batches_{LIVE_BATCH_ROWS}_rows"] = run_leg({}, common + ["--batch-rows", str(LIVE_BATCH_ROWS)])
+            # lower-cardinality variants of the same query (same columns, filter and measure; fewer group-by dimensions)
+            legs["groups_15k_dims_ts_d1"] = run_leg({}, big + ["--dims", "ts,d1"])        # DIRECT-mode kernels (> 6000 groups)
+            legs["groups_4k6_dims_d1_d2"] = run_leg({}, big + ["--dims", "d1,d2"])        # TABLE-mode scan, table well filled
+            legs["groups_90_dims_d1"] = run_leg({}, big + ["--dims", "d1"])               # TABLE-mode scan, ~100 groups
+            # first query of a fresh process (kernels compiled in the background: empty on-disk cache), the same process
+            # warm, and the same shape with a comparison constant never seen before
+            import tempfile
+            with tempfile.TemporaryDirectory(prefix="ares_rtc_cache_") as tmp:
+                legs["cold_process"] = run_leg({"ARES_RTC_CACHE_DIR": tmp}, big + ["--cold"])
+                legs["cold_process_warm_disk_cache"] = run_leg({"ARES_RTC_CACHE_DIR": tmp}, big + ["--cold"])
             try:
                 legs["host_batches"] = host_batch_leg(be, plan, batches, device_index, streams)
             except Exception as e:  # noqa: BLE001
@@ -447,6 +571,7 @@ def main(argv=None, backend=None, tensor_device=None):
                        "streams_per_query": n_streams,
                        "groups_per_shard": groups, "merged_groups": merged_groups, "merge_transport": merge_transport,
                        "host_ms_of_each_step": [round(x, 2) for x in step_ms],
+                       "rtc_kernels_after_priming_pass": rtc_state,
                        "profiled_pass_ms_per_step": profiled_ms,
                        "libmem_driver_calls_in_timed_region": None if drv0 is None else
                        {k: drv1[k] - drv0[k] for k in drv0},

@@ -386,7 +386,7 @@ def test_pending_transforms_are_consumed_by_hash_reduce(variant, native):
     want, _ = smoke.run_query(H.oracle_backend(), plan, data)
     smoke.compare_results(got, want)
     if os.environ.get("ARES_FUSE", "1") != "0" and os.environ.get("ARES_DEFER", "1") != "0":
-        assert any(k.startswith("hr_fused_scan_kernel") or k.startswith("hr_scan_rtc") for k in kernels), kernels
+        assert any(k.startswith(("hr_fused_scan_kernel", "hr_scan_rtc", "hr_table_scan_rtc")) for k in kernels), kernels
         assert not any(k.startswith("transform_") for k in kernels), kernels
 
 
@@ -444,7 +444,7 @@ def test_skipped_transform_outputs_materialise_on_copy():
     assert np.array_equal(got["in_dims"], want["in_dims"])
     assert np.array_equal(got["in_measures"], want["in_measures"])
     if os.environ.get("ARES_FUSE", "1") != "0" and os.environ.get("ARES_DEFER", "1") != "0":
-        assert any(k.startswith("hr_fused_scan_kernel") or k.startswith("hr_scan_rtc") for k in kernels), kernels
+        assert any(k.startswith(("hr_fused_scan_kernel", "hr_scan_rtc", "hr_table_scan_rtc")) for k in kernels), kernels
         assert any(k.startswith("transform_") for k in kernels), kernels
 
 
@@ -658,3 +658,57 @@ def test_specialised_merge_hands_crowded_partitions_to_the_generic_merge():
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("KERNELS")][-1]
     assert "hr_scan_rtc" in line and "hr_merge_rtc" in line and "hr_fused_merge_kernel" in line, line
+
+
+_ASYNC_RTC_SCRIPT = r"""
+import numpy as np, sys, os, time
+sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import harness as H
+from aresdb_amd import abi, smoke
+hip, oracle = H.hip_backend(), H.oracle_backend()
+rng = np.random.default_rng(11)
+data = [smoke.synth_batch(rng, 50000, null_fraction=0.02) for _ in range(3)]
+plan = smoke.c3_plan(True)
+want = smoke.run_query(oracle, plan, data)[0]
+names = []
+for attempt in range(40):   # the same query again and again while the kernels of its shape are built in the background
+    hip.profiler_enable(True)
+    got = smoke.run_query_native(hip, plan, data)[0]
+    hip.wait(); kernels = hip.profiler_report(); hip.profiler_enable(False)
+    smoke.compare_results(got, want)
+    names.append(sorted(k for k in kernels if k.startswith("hr_")))
+    if any("rtc" in k for k in kernels):
+        break
+    time.sleep(0.1)
+state = hip.rtc_wait()
+hip.profiler_enable(True)
+got = smoke.run_query_native(hip, plan, data)[0]
+hip.wait(); kernels = hip.profiler_report(); hip.profiler_enable(False)
+smoke.compare_results(got, want)
+print("FIRST", names[0]); print("LAST", sorted(k for k in kernels if k.startswith("hr_"))); print("STATE", state)
+"""
+
+
+@pytest.mark.gpu
+def test_background_compilation_never_blocks_a_query():
+    """ARES_RTC_ASYNC=1 (the library's default): the first queries of a shape run the generic kernels, the specialised
+    ones take over once the background compiler has delivered them, results are the same all along; a second process
+    finds the code objects in the on-disk cache."""
+    import subprocess
+    import sys
+    import tempfile
+    with tempfile.TemporaryDirectory(prefix="ares_rtc_test_") as tmp:
+        env = {**os.environ, "ARES_RTC_ASYNC": "1", "ARES_RTC_CACHE_DIR": tmp}
+        for run in range(2):
+            r = subprocess.run([sys.executable, "-c", _ASYNC_RTC_SCRIPT], cwd=H.ROOT, env=env, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+            first = [ln for ln in r.stdout.splitlines() if ln.startswith("FIRST")][-1]
+            last = [ln for ln in r.stdout.splitlines() if ln.startswith("LAST")][-1]
+            state = eval([ln for ln in r.stdout.splitlines() if ln.startswith("STATE")][-1][6:])
+            assert "rtc" not in first, first           # the very first query never waited for the compiler
+            assert "rtc" in last, (first, last)        # ... and the specialised kernels do arrive
+            if run == 0:
+                assert state["compiles"] >= 1 and state["disk_hits"] == 0, state
+                assert any(f.endswith(".co") for f in os.listdir(tmp))
+            else:
+                assert state["compiles"] == 0 and state["disk_hits"] >= 1, state

@@ -315,15 +315,12 @@ static void kernel_body_lines16(std::ostringstream &o, const char *fourth) {
        "  u32 tile = blockIdx.x, par = 0u;\n"
        "  Raw R;\n"
        "  PH_DECL\n"
-       "  if (tile < fullTiles) load_full(R, a, tile * T + tid * 4u);\n"
-       "  else if (tile < numTiles) load_tail(R, a, tile * T + tid * 4u);\n"
+       "  load_tile(R, a, tile * T + tid * 4u, tile < fullTiles ? 1u : tile < numTiles ? 2u : 0u);\n"
        "  while (tile < numTiles) {\n"
        "    const u32 i0 = tile * T + tid * 4u;\n"
        "    u32 hh[4], cv[4], cw[4], alive[4], rank[4];\n"
-       "    eval4(R, a, i0, hh, cv, cw, alive);\n"
        "    const u32 next = tile + gridDim.x;\n"
-       "    if (next < fullTiles) load_full(R, a, next * T + tid * 4u);\n"  // in flight during the sort below
-       "    else if (next < numTiles) load_tail(R, a, next * T + tid * 4u);\n"
+       "    eval4p(R, a, i0, hh, cv, cw, alive, next < fullTiles ? 1u : next < numTiles ? 2u : 0u, next * T + tid * 4u);\n"
        "    u32 *cnt = sCount[par];\n"
        "#pragma unroll\n"
        "    for (int j = 0; j < 4; j++) {\n"
@@ -445,12 +442,13 @@ static void kernel_body_compact(std::ostringstream &o) {
        "  __shared__ u64 sLeft[NP * LEFT];\n"      // up to 13 records per partition waiting for a full line
        "  __shared__ u16 sLeftLo[NP * LEFT];\n"
        "  __shared__ u32 sCount[2][NP];\n"
-       "  __shared__ u32 sStart[NP], sLeftN[NP], sCursor[NP];\n"
+       "  __shared__ uint2 sMeta[NP];\n"         // per partition: {first slot of its records in sRec | leftovers << 16, stream cursor in lines}
        "  __shared__ u32 sLines[(T + NP * LEFT) / LR + 2u];\n"
        "  __shared__ u32 sWave[16];\n"
        "  __shared__ u32 sTotalLines;\n"
        "  const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;\n"
-       "  for (u32 p = tid; p < NP; p += 1024u) { sCount[0][p] = 0u; sCount[1][p] = 0u; sLeftN[p] = 0u; sCursor[p] = 0u; }\n"
+       "  for (u32 p = tid; p < NP; p += 1024u) { sCount[0][p] = 0u; sCount[1][p] = 0u; }\n"
+       "  u32 myLeftN = 0u, myCursor = 0u;\n"    // thread p < NP keeps partition p's leftover count and stream cursor in registers
        "  __syncthreads();\n"
        "  u64 *myB = reinterpret_cast<u64 *>(a.recB) + (u64)blockIdx.x * NP * a.capB * 16u;\n"  // capB: lines per stream
        "  const u32 numTiles = ((u32)a.length + T - 1u) / T, fullTiles = (u32)a.length / T;\n"
@@ -459,7 +457,7 @@ static void kernel_body_compact(std::ostringstream &o) {
        "  u32 tile = firstTile, par = 0u;\n"
        "  Raw R;\n"
        "  PH_DECL\n"
-       "  if (tile < endTile) { if (tile < fullTiles) load_full(R, a, tile * T + tid * 4u); else load_tail(R, a, tile * T + tid * 4u); }\n"
+       "  load_tile(R, a, tile * T + tid * 4u, tile >= endTile ? 0u : tile < fullTiles ? 1u : 2u);\n"
        // the lane's place in a line: 16 lanes per line, lanes 0 and 8 carry the two headers
        "  const u32 q = tid & 15u, r8 = q & 7u;\n"
        "  const u32 kk = (q >> 3) * 7u + (r8 ? r8 - 1u : 0u);\n"  // record of the line this lane carries
@@ -468,9 +466,8 @@ static void kernel_body_compact(std::ostringstream &o) {
        "    const u32 i0 = tile * T + tid * 4u;\n"
        "    const u32 rc0 = (tile - firstTile) * T + tid * 4u;\n"  // row within the chunk
        "    u32 hh[4], cv[4], cw[4], alive[4], rank[4];\n"
-       "    eval4(R, a, i0, hh, cv, cw, alive);\n"
        "    const u32 next = tile + 1u;\n"
-       "    if (next < endTile) { if (next < fullTiles) load_full(R, a, next * T + tid * 4u); else load_tail(R, a, next * T + tid * 4u); }\n"
+       "    eval4p(R, a, i0, hh, cv, cw, alive, next >= endTile ? 0u : next < fullTiles ? 1u : 2u, next * T + tid * 4u);\n"
        "    u32 *cnt = sCount[par];\n"
        "#pragma unroll\n"
        "    for (int j = 0; j < 4; j++) {\n"
@@ -481,7 +478,7 @@ static void kernel_body_compact(std::ostringstream &o) {
        "    PH(0)\n"
        // exclusive scans of (new records, whole lines) per partition, packed in one word
        "    u32 myCount = 0u, myLeft = 0u;\n"
-       "    if (tid < NP) { myCount = cnt[tid]; myLeft = sLeftN[tid]; }\n"
+       "    if (tid < NP) { myCount = cnt[tid]; myLeft = myLeftN; }\n"
        "    const u32 myHave = myCount + myLeft, myLines = myHave / LR;\n"
        "    const u32 packed = (myCount << 16) | myLines;\n"
        "    u32 incl = packed;\n"
@@ -495,7 +492,7 @@ static void kernel_body_compact(std::ostringstream &o) {
        "    const u32 excl = before + incl - packed;\n"
        "    const u32 myStart = excl >> 16, myLineStart = excl & 0xFFFFu;\n"
        "    if (tid < NP) {\n"
-       "      sStart[tid] = myStart;\n"
+       "      sMeta[tid] = make_uint2(myStart | (myLeft << 16), myCursor);\n"
        "      for (u32 c = 0u; c < myLines; c++) sLines[myLineStart + c] = tid | (c << 9);\n"
        "      if (tid == NP - 1u) sTotalLines = myLineStart + myLines;\n"
        "    }\n"
@@ -504,7 +501,7 @@ static void kernel_body_compact(std::ostringstream &o) {
        "#pragma unroll\n"
        "    for (int j = 0; j < 4; j++)\n"
        "      if (alive[j]) {\n"
-       "        const u32 at = sStart[hh[j] >> (32 - PB)] + rank[j], rc = rc0 + (u32)j;\n"
+       "        const u32 at = (sMeta[hh[j] >> (32 - PB)].x & 0xFFFFu) + rank[j], rc = rc0 + (u32)j;\n"
        "        sRec[at] = ((u64)((hh[j] << PB) | (rc >> 9)) << 32) | cv[j];\n"
        "        sLo[at] = (u16)(rc & 511u);\n"
        "      }\n"
@@ -517,7 +514,7 @@ static void kernel_body_compact(std::ostringstream &o) {
        "#pragma unroll\n"
        "      for (u32 j = 0u; j < LPL; j++) { const u32 L = L0 + j * 64u; e[j] = L < totalLines ? sLines[L] : 0u; }\n"
        "#pragma unroll\n"
-       "      for (u32 j = 0u; j < LPL; j++) { const u32 p = e[j] & 511u; lf[j] = sLeftN[p]; st[j] = sStart[p]; cu[j] = sCursor[p]; }\n"
+       "      for (u32 j = 0u; j < LPL; j++) { const uint2 m = sMeta[e[j] & 511u]; lf[j] = m.x >> 16; st[j] = m.x & 0xFFFFu; cu[j] = m.y; }\n"
        "#pragma unroll\n"
        "      for (u32 j = 0u; j < LPL; j++) {\n"
        "        const u32 p = e[j] & 511u, idx = (e[j] >> 9) * LR + kk;\n"
@@ -547,10 +544,10 @@ static void kernel_body_compact(std::ostringstream &o) {
        "      for (u32 k = 0u; k < LEFT; k++) { const u32 s = (from + (k < n ? k : 0u)) & (T - 1u); t[k] = sRec[s]; tl[k] = sLo[s]; }\n"
        "#pragma unroll\n"
        "      for (u32 k = 0u; k < LEFT; k++) if (k < n) { sLeft[to + k] = t[k]; sLeftLo[to + k] = tl[k]; }\n"
-       "      sLeftN[tid] = rem;\n"
-       "      u32 cur = sCursor[tid] + myLines;\n"
+       "      myLeftN = rem;\n"
+       "      u32 cur = myCursor + myLines;\n"
        "      if (cur > a.capB) { *a.overflow = 1u; cur = a.capB; }\n"
-       "      sCursor[tid] = cur;\n"
+       "      myCursor = cur;\n"
        "      cnt[tid] = 0u;\n"  // this counter set is used again two tiles from now
        "    }\n"
        "    par ^= 1u;\n"
@@ -558,10 +555,13 @@ static void kernel_body_compact(std::ostringstream &o) {
        "    PH(4)\n"
        "  }\n"
        "  __syncthreads();\n"
+       "  if (tid < NP) sMeta[tid] = make_uint2(myLeftN << 16, myCursor);\n"
+       "  __syncthreads();\n"
        "  PH(5)\n"
        // the remainders go out as one last, partly filled line each; countsB holds the exact number of records
        "  for (u32 p = tid >> 4; p < NP; p += 64u) {\n"
-       "    const u32 left = sLeftN[p], cur = sCursor[p];\n"
+       "    const uint2 m = sMeta[p];\n"
+       "    const u32 left = m.x >> 16, cur = m.y;\n"
        "    const bool fits = cur < a.capB, has = r8 && kk < left;\n"
        "    const u64 rec = has ? sLeft[p * LEFT + kk] : 0ull;\n"
        "    const u64 mine = has ? (u64)sLeftLo[p * LEFT + kk] << sh : 0ull;\n"
@@ -631,15 +631,12 @@ static void kernel_body_table(std::ostringstream &o) {
        "  const u32 numTiles = ((u32)a.length + T - 1u) / T, fullTiles = (u32)a.length / T;\n"
        "  u32 tile = blockIdx.x;\n"
        "  Raw R;\n"
-       "  if (tile < fullTiles) load_full(R, a, tile * T + tid * 4u);\n"
-       "  else if (tile < numTiles) load_tail(R, a, tile * T + tid * 4u);\n"
+       "  load_tile(R, a, tile * T + tid * 4u, tile < fullTiles ? 1u : tile < numTiles ? 2u : 0u);\n"
        "  while (tile < numTiles) {\n"
        "    const u32 i0 = tile * T + tid * 4u;\n"
        "    u32 hh[4], cv[4], cw[4], alive[4];\n"
-       "    eval4(R, a, i0, hh, cv, cw, alive);\n"
        "    const u32 next = tile + gridDim.x;\n"
-       "    if (next < fullTiles) load_full(R, a, next * T + tid * 4u);\n"
-       "    else if (next < numTiles) load_tail(R, a, next * T + tid * 4u);\n"
+       "    eval4p(R, a, i0, hh, cv, cw, alive, next < fullTiles ? 1u : next < numTiles ? 2u : 0u, next * T + tid * 4u);\n"
        // the four home slots are read together; a row that meets its group there costs one more LDS atomic
        "    const u64 c0 = sKeys[hh[0] & (SLOTS - 1u)], c1 = sKeys[hh[1] & (SLOTS - 1u)], c2 = sKeys[hh[2] & (SLOTS - 1u)], c3 = sKeys[hh[3] & (SLOTS - 1u)];\n"
        "    const u32 row0 = a.rowBase + i0;\n"
@@ -687,74 +684,98 @@ std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t null
   o << kPrelude << args_text()
     << "#define NC " << nc << "\n#define ND " << nd << "\n#define PB " << partBits << "\n#define NP " << (1 << partBits) << "\n"
        "struct Raw { u32 v[NC][4]; u32 win[NC]; };\n";
-  // ---- loads of a full quad (all four rows exist) ----
-  o << "__device__ __forceinline__ void load_full(Raw &r, const Args &a, u32 i0) {\n";
+  // ---- loads, one column at a time: of a full quad (all four rows exist: mode 1) / guarded, for the shard's last,
+  // partial tile (mode 2)
   for (int c = 0; c < nc; c++) {
-    o << "  { const PU32x4 t = *reinterpret_cast<const PU32x4 *>(a.vals[" << c << "] + i0); r.v[" << c << "][0] = t.v[0]; r.v[" << c
-      << "][1] = t.v[1]; r.v[" << c << "][2] = t.v[2]; r.v[" << c << "][3] = t.v[3]; }\n";
+    o << "__device__ __forceinline__ void load_col" << c << "_1(Raw &r, const Args &a, u32 i0) {\n"
+         "  const PU32x4 t = *reinterpret_cast<const PU32x4 *>(a.vals[" << c << "] + i0); r.v[" << c << "][0] = t.v[0]; r.v[" << c
+      << "][1] = t.v[1]; r.v[" << c << "][2] = t.v[2]; r.v[" << c << "][3] = t.v[3];\n";
     if (nullMask & (1u << c))
       o << "  r.win[" << c << "] = reinterpret_cast<const PU16 *>(a.nulls[" << c << "] + ((i0 + a.bitOff[" << c << "]) >> 3))->v;\n";
     else
       o << "  r.win[" << c << "] = 0xFFFFu;\n";
-  }
-  o << "}\n";
-  // ---- guarded loads of the shard's last, partial tile ----
-  o << "__device__ __forceinline__ void load_tail(Raw &r, const Args &a, u32 i0) {\n";
-  for (int c = 0; c < nc; c++) {
-    o << "  for (int j = 0; j < 4; j++) r.v[" << c << "][j] = (int)(i0 + j) < a.length ? a.vals[" << c << "][i0 + j] : 0u;\n";
+    o << "}\n"
+         "__device__ __forceinline__ void load_col" << c << "_2(Raw &r, const Args &a, u32 i0) {\n"
+         "  for (int j = 0; j < 4; j++) r.v[" << c << "][j] = (int)(i0 + j) < a.length ? a.vals[" << c << "][i0 + j] : 0u;\n";
     if (nullMask & (1u << c))
       o << "  r.win[" << c << "] = (int)i0 < a.length ? (u32)reinterpret_cast<const PU16 *>(a.nulls[" << c << "] + ((i0 + a.bitOff[" << c
         << "]) >> 3))->v : 0u;\n";
     else
       o << "  r.win[" << c << "] = 0xFFFFu;\n";
+    o << "}\n"
+         "__device__ __forceinline__ void load_col" << c << "_0(Raw &, const Args &, u32) {}\n";
   }
-  o << "}\n";
-  // ---- evaluate + hash one quad: hash, carried measure bits and "takes part" of its four rows ----
-  o << "__device__ __forceinline__ void eval4(const Raw &r, const Args &a, u32 i0, u32 (&hh)[4], u32 (&cv)[4], u32 (&cw)[4], u32 (&alive)[4]) {\n"
-       "  u32 okc[NC];\n"
-       "  cw[0] = cw[1] = cw[2] = cw[3] = 0u;\n";
-  for (int c = 0; c < nc; c++) {
-    if (nullMask & (1u << c)) o << "  okc[" << c << "] = (r.win[" << c << "] >> ((i0 + a.bitOff[" << c << "]) & 7u)) & 0xFu;\n";
-    else o << "  okc[" << c << "] = 0xFu;\n";
-  }
-  o << "#pragma unroll\n"
-       "  for (int j = 0; j < 4; j++) {\n"
-       "    u32 keep = (int)(i0 + j) < a.length ? 1u : 0u;\n";
-  for (int k = 0; k < plan.numFilters; k++) {
-    const FusedExpr &e = plan.filters[k];
-    o << "    {\n      const u32 v = r.v[" << e.col << "][j]; const u32 okb = (okc[" << e.col << "] >> j) & 1u;\n";
-    if (!gen_compare(e.f, o, "v", "okb", "keep", const_name(const_slot_filter(k)))) return "";
-    o << "    }\n";
-  }
-  o << "    alive[j] = keep;\n    u32 h = 0u, okbytes = 0u;\n";
-  for (int d = 0; d < nd; d++) {
-    const FusedExpr &e = plan.dims[d];
-    if (e.col != d || !plain_store(e.f.rk, e.outKind)) return "";
-    o << "    {\n      const u32 v = r.v[" << d << "][j]; const u32 okb = (okc[" << d << "] >> j) & 1u; u32 x;\n";
-    if (!gen_value(e.f, o, "v", "okb", "x", const_name(const_slot_dim(d)))) return "";
-    o << "      h = mix(h, x); okbytes |= okb << " << 8 * d << ";\n    }\n";
-  }
-  // Murmur32Stream (dim_layout.hpp): the validity bytes are one more block when there are four of them,
-  // otherwise the tail
-  if (nd == 4) o << "    h = mix(h, okbytes);\n";
-  else o << "    { u32 k = okbytes * 0xcc9e2d51u; k = rotl(k, 15) * 0x1b873593u; h ^= k; }\n";
-  o << "    h ^= " << 5 * nd << "u; h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;\n"
-       "    hh[j] = h;\n";
-  {  // measure: fused_carry
-    const FusedExpr &e = plan.measure;
-    if (e.col != nd) return "";
-    o << "    {\n      const u32 v = r.v[" << nd << "][j]; const u32 okb = (okc[" << nd << "] >> j) & 1u; u32 x;\n";
-    if (!gen_value(e.f, o, "v", "okb", "x", const_name(const_slot_measure()))) return "";
-    if (plan.measureWidth == 8) {
-      if (plan.identity != 0) return "";
-      o << "      cv[j] = okb ? x : 0u;\n";
-    } else {
-      const int target = plan.measureDtype == Int32 ? K_I32 : plan.measureDtype == Uint32 ? K_U32 : K_F32;
-      if (!plain_store(e.f.rk, target)) return "";
-      o << "      cv[j] = okb ? x : " << hex(static_cast<uint32_t>(plan.identity)) << ";\n";
+  o << "__device__ __forceinline__ void load_tile(Raw &r, const Args &a, u32 i0, u32 mode) {\n  if (mode == 1u) {\n";
+  for (int c = 0; c < nc; c++) o << "    load_col" << c << "_1(r, a, i0);\n";
+  o << "  } else if (mode == 2u) {\n";
+  for (int c = 0; c < nc; c++) o << "    load_col" << c << "_2(r, a, i0);\n";
+  o << "  }\n}\n";
+  // ---- evaluate + hash one quad (hash, carried measure bits and "takes part" of its four rows) AND issue the next
+  // tile's loads, column by column, as soon as a column's registers are dead: a single register buffer, yet loads
+  // are in flight during the whole evaluation instead of only after it (the kernel is HBM-bound: with the loads
+  // issued after the evaluation the read pipe idled for a third of every tile).  One straight-line copy per load
+  // mode of the next tile (0 none, 1 full, 2 guarded): a branch around each column's load would make the compiler
+  // wait for every outstanding load at each join.  i0n: this lane's first row in the next tile.
+  for (int mode = 0; mode < 3; mode++) {
+    const std::string M = "_" + std::to_string(mode);
+    o << "__device__ __forceinline__ void eval4p" << M << "(Raw &r, const Args &a, u32 i0, u32 (&hh)[4], u32 (&cv)[4], u32 (&cw)[4], u32 (&alive)[4], u32 i0n) {\n"
+         "  u32 okc[NC];\n"
+         "  cw[0] = cw[1] = cw[2] = cw[3] = 0u;\n";
+    for (int c = 0; c < nc; c++) {
+      if (nullMask & (1u << c)) o << "  okc[" << c << "] = (r.win[" << c << "] >> ((i0 + a.bitOff[" << c << "]) & 7u)) & 0xFu;\n";
+      else o << "  okc[" << c << "] = 0xFu;\n";
     }
-    o << "    }\n  }\n}\n";
+    o << "#pragma unroll\n"
+         "  for (int j = 0; j < 4; j++) {\n"
+         "    u32 keep = (int)(i0 + j) < a.length ? 1u : 0u;\n";
+    for (int k = 0; k < plan.numFilters; k++) {
+      const FusedExpr &e = plan.filters[k];
+      if (e.col < 0 || e.col >= nc) return "";
+      o << "    {\n      const u32 v = r.v[" << e.col << "][j]; const u32 okb = (okc[" << e.col << "] >> j) & 1u;\n";
+      if (!gen_compare(e.f, o, "v", "okb", "keep", const_name(const_slot_filter(k)))) return "";
+      o << "    }\n";
+    }
+    o << "    alive[j] = keep;\n  }\n";
+    for (int c = nd + 1; c < nc; c++) o << "  load_col" << c << M << "(r, a, i0n);\n";  // columns only the filters read
+    {  // measure: fused_carry
+      const FusedExpr &e = plan.measure;
+      if (e.col != nd) return "";
+      o << "#pragma unroll\n  for (int j = 0; j < 4; j++) {\n"
+           "    const u32 v = r.v[" << nd << "][j]; const u32 okb = (okc[" << nd << "] >> j) & 1u; u32 x;\n";
+      if (!gen_value(e.f, o, "v", "okb", "x", const_name(const_slot_measure()))) return "";
+      if (plan.measureWidth == 8) {
+        if (plan.identity != 0) return "";
+        o << "    cv[j] = okb ? x : 0u;\n";
+      } else {
+        const int target = plan.measureDtype == Int32 ? K_I32 : plan.measureDtype == Uint32 ? K_U32 : K_F32;
+        if (!plain_store(e.f.rk, target)) return "";
+        o << "    cv[j] = okb ? x : " << hex(static_cast<uint32_t>(plan.identity)) << ";\n";
+      }
+      o << "  }\n  load_col" << nd << M << "(r, a, i0n);\n";
+    }
+    o << "  u32 h[4] = {0u, 0u, 0u, 0u}, okbytes[4] = {0u, 0u, 0u, 0u};\n";
+    for (int d = 0; d < nd; d++) {
+      const FusedExpr &e = plan.dims[d];
+      if (e.col != d || !plain_store(e.f.rk, e.outKind)) return "";
+      o << "#pragma unroll\n  for (int j = 0; j < 4; j++) {\n"
+           "    const u32 v = r.v[" << d << "][j]; const u32 okb = (okc[" << d << "] >> j) & 1u; u32 x;\n";
+      if (!gen_value(e.f, o, "v", "okb", "x", const_name(const_slot_dim(d)))) return "";
+      o << "    h[j] = mix(h[j], x); okbytes[j] |= okb << " << 8 * d << ";\n  }\n"
+           "  load_col" << d << M << "(r, a, i0n);\n";
+    }
+    // Murmur32Stream (dim_layout.hpp): the validity bytes are one more block when there are four of them,
+    // otherwise the tail
+    o << "#pragma unroll\n  for (int j = 0; j < 4; j++) {\n    u32 g = h[j];\n";
+    if (nd == 4) o << "    g = mix(g, okbytes[j]);\n";
+    else o << "    { u32 k = okbytes[j] * 0xcc9e2d51u; k = rotl(k, 15) * 0x1b873593u; g ^= k; }\n";
+    o << "    g ^= " << 5 * nd << "u; g ^= g >> 16; g *= 0x85ebca6bu; g ^= g >> 13; g *= 0xc2b2ae35u; g ^= g >> 16;\n"
+         "    hh[j] = g;\n  }\n}\n";
   }
+  o << "__device__ __forceinline__ void eval4p(Raw &r, const Args &a, u32 i0, u32 (&hh)[4], u32 (&cv)[4], u32 (&cw)[4], u32 (&alive)[4], u32 mode, u32 i0n) {\n"
+       "  if (mode == 1u) eval4p_1(r, a, i0, hh, cv, cw, alive, i0n);\n"
+       "  else if (mode == 2u) eval4p_2(r, a, i0, hh, cv, cw, alive, i0n);\n"
+       "  else eval4p_0(r, a, i0, hh, cv, cw, alive, i0n);\n"
+       "}\n";
   if (kind == SCAN_TABLE) {
     if (!agg || !widen || !gen_widen(o, *widen) || !gen_agg(o, *agg)) return "";
     kernel_body_table(o);
@@ -820,6 +841,11 @@ std::string generate_vector(int nd, int vw, int partBits) {
        "    cv[j] = r.m[j * MQ];\n"
        "    cw[j] = MQ == 2 ? r.m[j * MQ + MQ - 1] : 0u;\n"
        "  }\n"
+       "}\n";
+  o << "__device__ __forceinline__ void load_tile(Raw &r, const Args &a, u32 i0, u32 mode) { if (mode == 1u) load_full(r, a, i0); else if (mode == 2u) load_tail(r, a, i0); }\n"
+       "__device__ __forceinline__ void eval4p(Raw &r, const Args &a, u32 i0, u32 (&hh)[4], u32 (&cv)[4], u32 (&cw)[4], u32 (&alive)[4], u32 mode, u32 i0n) {\n"
+       "  eval4(r, a, i0, hh, cv, cw, alive);\n"
+       "  load_tile(r, a, i0n, mode);\n"
        "}\n";
   kernel_body_lines16(o, "cw[j]");
   return o.str();

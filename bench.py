@@ -252,6 +252,7 @@ def main(argv=None, backend=None, tensor_device=None):
     ap.add_argument("--null-fraction", type=float, default=0.01)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the secondary legs (fusion off, live batches, extension)")
+    ap.add_argument("--legs", default="all", help="comma list of substrings: only the secondary legs whose name contains one of them")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--one-stream", action="store_true", help="every batch on one stream (the Go host alternates two)")
     ap.add_argument("--verify-merged", action="store_true",
@@ -534,26 +535,33 @@ def main(argv=None, backend=None, tensor_device=None):
                 ref_check["rows"] = ref_rows
                 ok = ok and ref_check["status"] == "ok"
         if not args.no_legs:
-            common = ["--rows", str(rows), "--null-fraction", str(args.null_fraction), "--steps", "1", "--warmup", "1"]
+            common = ["--rows", str(rows), "--null-fraction", str(args.null_fraction), "--steps", "3", "--warmup", "1"]
             big = common + ["--batch-rows", str(batch_rows)]
-            legs["unfused_abi_ARES_FUSE=0"] = run_leg({"ARES_FUSE": "0"}, big)
-            legs["eager_abi_ARES_DEFER=0"] = run_leg({"ARES_DEFER": "0"}, big)
-            legs["fused_extension"] = run_leg({}, big + ["--fused-extension"])
-            legs[f"live_batches_{LIVE_BATCH_ROWS}_rows"] = run_leg({}, common + ["--batch-rows", str(LIVE_BATCH_ROWS)])
-            # lower-cardinality variants of the same query (same columns, filter and measure; fewer group-by dimensions)
-            legs["groups_15k_dims_ts_d1"] = run_leg({}, big + ["--dims", "ts,d1"])        # DIRECT-mode kernels (> 6000 groups)
-            legs["groups_4k6_dims_d1_d2"] = run_leg({}, big + ["--dims", "d1,d2"])        # TABLE-mode scan, table well filled
-            legs["groups_90_dims_d1"] = run_leg({}, big + ["--dims", "d1"])               # TABLE-mode scan, ~100 groups
+            wanted = [w for w in args.legs.split(",") if w]
+
+            def leg(name, env, argv):
+                if args.legs == "all" or any(w in name for w in wanted):
+                    legs[name] = run_leg(env, argv)
+            leg("unfused_abi_ARES_FUSE=0", {"ARES_FUSE": "0"}, big)
+            leg("eager_abi_ARES_DEFER=0", {"ARES_DEFER": "0"}, big)
+            leg("fused_extension", {}, big + ["--fused-extension"])
+            leg(f"live_batches_{LIVE_BATCH_ROWS}_rows", {}, common + ["--batch-rows", str(LIVE_BATCH_ROWS)])
+            # lower-cardinality variants of the same query (same filter and measure; fewer group-by dimensions)
+            leg("groups_15k_dims_ts_d1", {}, big + ["--dims", "ts,d1"])        # DIRECT-mode kernels (> 6000 groups)
+            leg("groups_4k6_dims_d1_d2", {}, big + ["--dims", "d1,d2"])        # TABLE-mode scan, table well filled
+            leg("groups_100_dims_d2_d3", {}, big + ["--dims", "d2,d3"])        # TABLE-mode scan, ~100 groups, 4 columns read
+            leg("groups_90_dims_d1", {}, big + ["--dims", "d1"])               # TABLE-mode scan, ~100 groups, 2 columns read
             # first query of a fresh process (kernels compiled in the background: empty on-disk cache), the same process
             # warm, and the same shape with a comparison constant never seen before
             import tempfile
             with tempfile.TemporaryDirectory(prefix="ares_rtc_cache_") as tmp:
-                legs["cold_process"] = run_leg({"ARES_RTC_CACHE_DIR": tmp}, big + ["--cold"])
-                legs["cold_process_warm_disk_cache"] = run_leg({"ARES_RTC_CACHE_DIR": tmp}, big + ["--cold"])
-            try:
-                legs["host_batches"] = host_batch_leg(be, plan, batches, device_index, streams)
-            except Exception as e:  # noqa: BLE001
-                legs["host_batches"] = {"error": f"{type(e).__name__}: {e}"}
+                leg("cold_process", {"ARES_RTC_CACHE_DIR": tmp}, big + ["--cold"])
+                leg("cold_process_warm_disk_cache", {"ARES_RTC_CACHE_DIR": tmp}, big + ["--cold"])
+            if args.legs == "all" or any(w in "host_batches" for w in wanted):
+                try:
+                    legs["host_batches"] = host_batch_leg(be, plan, batches, device_index, streams)
+                except Exception as e:  # noqa: BLE001
+                    legs["host_batches"] = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         value = rows * world * args.steps / elapsed

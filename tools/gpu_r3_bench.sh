@@ -3,7 +3,7 @@
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p gpurun_out
 TAG=${1:-r3e}
-timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
+timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 $BENCH_ARGS > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
 echo "bench rc $?"; tail -5 gpurun_out/bench_$TAG.err
 python - <<PY
 import json
@@ -18,7 +18,7 @@ for k,v in d['legs'].items():
     print(k, json.dumps(v)[:600])
     if ks: print('    ', {n:(round(x['avg_ms'],4), x['launches']) for n,x in list(ks.items())[:5]})
 PY
-for i in $(seq 1 10); do
+for i in $(seq 1 ${FUZZ_LOOPS:-0}); do
   timeout 300 python -X faulthandler -m pytest tests/test_sequence_fuzz.py -m gpu -q -x --capture=sys > gpurun_out/r3e_fuzz_$i.log 2>&1
   rc=$?; echo "fuzz $i rc $rc $(tail -1 gpurun_out/r3e_fuzz_$i.log | cut -c1-80)"
   [ $rc -ne 0 ] && grep -v "^  File\|^Thread\|^$" gpurun_out/r3e_fuzz_$i.log | head -12

@@ -578,39 +578,54 @@ static void kernel_body_compact(std::ostringstream &o) {
 // ---- TABLE scan ----------------------------------------------------------------------------------------
 // Low-cardinality queries: every workgroup aggregates its rows in an LDS hash table (key = hash << 32 | lowest
 // row, 8-byte value) and emits one 16-byte record per group {row, hash, value} into region A at the end — the
-// layout hr::flush_table writes and hr::merge_body reads.  No barrier inside the loop: the wavefronts run free
-// (tile t + 1's loads are issued before tile t goes through the table).  A row whose group finds no slot once
-// the table holds LIMIT groups is written as a single record straight away (one global cursor reservation):
-// always correct, slow when frequent — the host sends queries with that many groups to the DIRECT kernels.
+// layout hr::flush_table writes and hr::merge_body reads.  No barrier inside the loop: the wavefronts run free,
+// two tiles per wavefront in flight (two register buffers, each refilled column by column while it is evaluated:
+// with two or three columns a single tile per wavefront leaves too few bytes in flight to cover HBM latency).
+// The table is the specialised merge's: buckets of four keys (two 16-byte LDS reads).  A row first looks at its
+// home bucket with straight-line code — it meets its group there nearly always once the groups exist: one LDS
+// atomic more —; rows that do not are queued per wavefront in LDS and taken through the general probe loop 64 at a
+// time, every lane busy.  Once the table holds LIMIT groups a row whose group finds no slot is written as a single
+// record straight away (one global cursor reservation): always correct, slow when frequent — the host sends
+// queries with that many groups to the DIRECT kernels.
 static void kernel_body_table(std::ostringstream &o) {
-  o << "#define T 4096u\n#define SLOTS " << hr::kSlots << "u\n#define LIMIT " << (hr::kSlots * 3 / 4) << "u\n#define EMPTY 0xFFFFFFFFFFFFFFFFull\n"
-       // one row: find or claim the slot of its hash (linear probing; `c` = the home slot's key, read ahead), keep the
-       // lowest row as the group's representative, aggregate; no slot left = the row travels alone
-       "__device__ __forceinline__ void table_row(const Args &a, u64 *sKeys, u64 *sVals, u32 *sClaims, u32 h, u32 row, u32 carried, u64 c) {\n"
-       "  const u64 mine = ((u64)h << 32) | row, value = widen(carried);\n"
-       "  u32 slot = h & (SLOTS - 1u);\n"
-       "  bool done = false;\n"
-       "  for (u32 tries = 0u; tries < SLOTS; tries++) {\n"
-       "    if (c == EMPTY) {\n"
-       "      if (__hip_atomic_load(sClaims, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= LIMIT) break;\n"
+  o << "#define T 4096u\n#define SLOTS " << hr::kSlots << "u\n#define BUCKETS (SLOTS / 4u)\n#define LIMIT " << (hr::kSlots * 3 / 4)
+    << "u\n#define EMPTY 0xFFFFFFFFFFFFFFFFull\n#define QCAP 128u\n"
+       "struct __attribute__((aligned(16))) U64x2 { u64 x, y; };\n"
+       "struct Probe { u32 b, slot; u64 seen; bool done, fresh, spill; };\n"
+       "__device__ __forceinline__ void probe_round(u64 *sKeys, u32 *sClaims, Probe &q, u32 h, u64 mine) {\n"
+       "  const U64x2 lo = *reinterpret_cast<const U64x2 *>(sKeys + 4u * q.b), hi = *reinterpret_cast<const U64x2 *>(sKeys + 4u * q.b + 2u);\n"
+       "  const u64 k0 = lo.x, k1 = lo.y, k2 = hi.x, k3 = hi.y;\n"
+       "  const bool e0 = k0 == EMPTY, e1 = k1 == EMPTY, e2 = k2 == EMPTY, e3 = k3 == EMPTY;\n"
+       "  const bool m0 = !e0 && (u32)(k0 >> 32) == h, m1 = !e1 && (u32)(k1 >> 32) == h, m2 = !e2 && (u32)(k2 >> 32) == h, m3 = !e3 && (u32)(k3 >> 32) == h;\n"
+       "  const bool anyM = m0 | m1 | m2 | m3, anyE = e0 | e1 | e2 | e3;\n"
+       "  const u32 mi = m0 ? 0u : m1 ? 1u : m2 ? 2u : 3u, ei = e0 ? 0u : e1 ? 1u : e2 ? 2u : 3u;\n"
+       "  const u64 mk = m0 ? k0 : m1 ? k1 : m2 ? k2 : k3;\n"
+       "  const bool active = !q.done, hit = active & anyM;\n"
+       "  q.slot = hit ? 4u * q.b + mi : q.slot;\n"
+       "  q.seen = hit ? mk : q.seen;\n"
+       "  bool claimed = false;\n"
+       "  if (active & !anyM & anyE) {\n"  // a group this workgroup has not seen yet
+       "    if (__hip_atomic_load(sClaims, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= LIMIT) {\n"
+       "      q.spill = true; claimed = true;\n"  // the table is full enough: the row travels alone
+       "    } else {\n"
        "      u64 expected = EMPTY;\n"
-       "      if (__hip_atomic_compare_exchange_strong(sKeys + slot, &expected, mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {\n"
+       "      if (__hip_atomic_compare_exchange_strong(sKeys + 4u * q.b + ei, &expected, mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {\n"
        "        __hip_atomic_fetch_add(sClaims, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
-       "        done = true;\n"
-       "        break;\n"
-       "      }\n"
-       "      c = expected;\n"
+       "        q.slot = 4u * q.b + ei; q.fresh = true; claimed = true;\n"
+       "      }\n"  // lost the slot: the same bucket again next round (the winner may be this very group)
        "    }\n"
-       "    if ((u32)(c >> 32) == h) {\n"
-       "      if (mine < c) __hip_atomic_fetch_min(sKeys + slot, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
-       "      done = true;\n"
-       "      break;\n"
-       "    }\n"
-       "    slot = (slot + 1u) & (SLOTS - 1u);\n"
-       "    c = sKeys[slot];\n"
        "  }\n"
-       "  if (done) {\n"
-       "    agg(sVals + slot, value);\n"
+       "  q.b = (active & !anyM & !anyE) ? (q.b + 1u) & (BUCKETS - 1u) : q.b;\n"
+       "  q.done = q.done | hit | claimed;\n"
+       "}\n"
+       // one row through the general probe loop
+       "__device__ __forceinline__ void insert(const Args &a, u64 *sKeys, u64 *sVals, u32 *sClaims, u32 row, u32 h, u32 carried) {\n"
+       "  const u64 mine = ((u64)h << 32) | row, value = widen(carried);\n"
+       "  Probe q; q.b = h & (BUCKETS - 1u); q.slot = 0u; q.seen = 0ull; q.done = false; q.fresh = false; q.spill = false;\n"
+       "  for (u32 tries = 0u; tries < BUCKETS + 8u && !q.done; tries++) probe_round(sKeys, sClaims, q, h, mine);\n"
+       "  if (q.done && !q.spill) {\n"
+       "    if (!q.fresh && mine < q.seen) __hip_atomic_fetch_min(sKeys + q.slot, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
+       "    agg(sVals + q.slot, value);\n"
        "  } else {\n"
        "    const u32 p = PB ? h >> (32 - (PB ? PB : 1)) : 0u;\n"
        "    const u64 at = atomicAdd(a.cursorsA + p, 1u);\n"
@@ -618,34 +633,73 @@ static void kernel_body_table(std::ostringstream &o) {
        "    else *a.overflow = 1u;\n"
        "  }\n"
        "}\n"
+       "__device__ __forceinline__ void drain(const Args &a, u32 *queue, u32 first, u32 count, u32 lane, u64 *sKeys, u64 *sVals, u32 *sClaims) {\n"
+       "  asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");\n"
+       "  if (lane < count) {\n"
+       "    const u32 e = 3u * (first + lane);\n"
+       "    insert(a, sKeys, sVals, sClaims, queue[e], queue[e + 1u], queue[e + 2u]);\n"
+       "  }\n"
+       "  asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");\n"
+       "}\n"
+       // one row, round one: the home bucket, straight-line
+       "__device__ __forceinline__ void row_one(const Args &a, bool valid, u32 row, u32 h, u32 carried, u32 lane, u64 *sKeys, u64 *sVals, u32 *sClaims, u32 *queue, u32 &qn) {\n"
+       "  const u32 b = h & (BUCKETS - 1u);\n"
+       "  const U64x2 lo = *reinterpret_cast<const U64x2 *>(sKeys + 4u * b), hi = *reinterpret_cast<const U64x2 *>(sKeys + 4u * b + 2u);\n"
+       "  const bool m0 = (u32)(lo.x >> 32) == h && lo.x != EMPTY, m1 = (u32)(lo.y >> 32) == h && lo.y != EMPTY;\n"
+       "  const bool m2 = (u32)(hi.x >> 32) == h && hi.x != EMPTY, m3 = (u32)(hi.y >> 32) == h && hi.y != EMPTY;\n"
+       "  const bool hit = valid && (m0 || m1 || m2 || m3);\n"
+       "  if (hit) {\n"
+       "    const u32 mi = m0 ? 0u : m1 ? 1u : m2 ? 2u : 3u;\n"
+       "    const u32 seenRow = m0 ? (u32)lo.x : m1 ? (u32)lo.y : m2 ? (u32)hi.x : (u32)hi.y;\n"
+       "    if (row < seenRow) __hip_atomic_fetch_min(sKeys + 4u * b + mi, ((u64)h << 32) | row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
+       "    agg(sVals + 4u * b + mi, widen(carried));\n"
+       "  }\n"
+       "  const bool pend = valid && !hit;\n"
+       "  const u64 m = __ballot(pend);\n"
+       "  if (m) {\n"
+       "    if (pend) {\n"
+       "      const u32 e = 3u * (qn + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)));\n"
+       "      queue[e] = row; queue[e + 1u] = h; queue[e + 2u] = carried;\n"
+       "    }\n"
+       "    qn += (u32)__popcll(m);\n"
+       "    if (qn >= 64u) { qn -= 64u; drain(a, queue, qn, 64u, lane, sKeys, sVals, sClaims); }\n"
+       "  }\n"
+       "}\n"
        "extern \"C\" __global__ void __launch_bounds__(1024) hr_scan_rtc(Args a) {\n"
        "  __shared__ u64 sKeys[SLOTS];\n"
        "  __shared__ u64 sVals[SLOTS];\n"
+       "  __shared__ u32 sQueue[16u * QCAP * 3u];\n"
        "  __shared__ u32 sPartCount[NP], sPartBase[NP];\n"
        "  __shared__ u32 sClaims;\n"
-       "  const u32 tid = threadIdx.x;\n"
+       "  const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;\n"
        "  for (u32 s = tid; s < SLOTS; s += 1024u) { sKeys[s] = EMPTY; sVals[s] = IDENT; }\n"
        "  for (u32 p = tid; p < NP; p += 1024u) sPartCount[p] = 0u;\n"
        "  if (tid == 0u) sClaims = 0u;\n"
        "  __syncthreads();\n"
-       "  const u32 numTiles = ((u32)a.length + T - 1u) / T, fullTiles = (u32)a.length / T;\n"
-       "  u32 tile = blockIdx.x;\n"
-       "  Raw R;\n"
-       "  load_tile(R, a, tile * T + tid * 4u, tile < fullTiles ? 1u : tile < numTiles ? 2u : 0u);\n"
-       "  while (tile < numTiles) {\n"
-       "    const u32 i0 = tile * T + tid * 4u;\n"
-       "    u32 hh[4], cv[4], cw[4], alive[4];\n"
-       "    const u32 next = tile + gridDim.x;\n"
-       "    eval4p(R, a, i0, hh, cv, cw, alive, next < fullTiles ? 1u : next < numTiles ? 2u : 0u, next * T + tid * 4u);\n"
-       // the four home slots are read together; a row that meets its group there costs one more LDS atomic
-       "    const u64 c0 = sKeys[hh[0] & (SLOTS - 1u)], c1 = sKeys[hh[1] & (SLOTS - 1u)], c2 = sKeys[hh[2] & (SLOTS - 1u)], c3 = sKeys[hh[3] & (SLOTS - 1u)];\n"
-       "    const u32 row0 = a.rowBase + i0;\n"
-       "    if (alive[0]) table_row(a, sKeys, sVals, &sClaims, hh[0], row0, cv[0], c0);\n"
-       "    if (alive[1]) table_row(a, sKeys, sVals, &sClaims, hh[1], row0 + 1u, cv[1], c1);\n"
-       "    if (alive[2]) table_row(a, sKeys, sVals, &sClaims, hh[2], row0 + 2u, cv[2], c2);\n"
-       "    if (alive[3]) table_row(a, sKeys, sVals, &sClaims, hh[3], row0 + 3u, cv[3], c3);\n"
-       "    tile = next;\n"
+       "  const u32 numTiles = ((u32)a.length + T - 1u) / T, fullTiles = (u32)a.length / T, G = gridDim.x;\n"
+       "  u32 tile = blockIdx.x, qn = 0u;\n"
+       "  u32 *queue = sQueue + wave * (QCAP * 3u);\n"
+       "  Raw R0, R1;\n"
+       "  load_tile(R0, a, tile * T + tid * 4u, tile < fullTiles ? 1u : tile < numTiles ? 2u : 0u);\n"
+       "  load_tile(R1, a, (tile + G) * T + tid * 4u, tile + G < fullTiles ? 1u : tile + G < numTiles ? 2u : 0u);\n"
+       "#define TILE_STEP(R)                                                                                   \\\n"
+       "  {                                                                                                    \\\n"
+       "    const u32 i0 = tile * T + tid * 4u, next = tile + 2u * G;                                          \\\n"
+       "    u32 hh[4], cv[4], cw[4], alive[4];                                                                 \\\n"
+       "    eval4p(R, a, i0, hh, cv, cw, alive, next < fullTiles ? 1u : next < numTiles ? 2u : 0u, next * T + tid * 4u); \\\n"
+       "    const u32 row0 = a.rowBase + i0;                                                                   \\\n"
+       "    row_one(a, alive[0] != 0u, row0, hh[0], cv[0], lane, sKeys, sVals, &sClaims, queue, qn);           \\\n"
+       "    row_one(a, alive[1] != 0u, row0 + 1u, hh[1], cv[1], lane, sKeys, sVals, &sClaims, queue, qn);      \\\n"
+       "    row_one(a, alive[2] != 0u, row0 + 2u, hh[2], cv[2], lane, sKeys, sVals, &sClaims, queue, qn);      \\\n"
+       "    row_one(a, alive[3] != 0u, row0 + 3u, hh[3], cv[3], lane, sKeys, sVals, &sClaims, queue, qn);      \\\n"
+       "    tile += G;                                                                                         \\\n"
        "  }\n"
+       "  while (tile < numTiles) {\n"
+       "    TILE_STEP(R0)\n"
+       "    if (tile >= numTiles) break;\n"
+       "    TILE_STEP(R1)\n"
+       "  }\n"
+       "  if (qn) drain(a, queue, 0u, qn, lane, sKeys, sVals, &sClaims);\n"
        "  __syncthreads();\n"
        // flush (hr::flush_table): counting sort of the entries by partition, one cursor reservation per partition
        "  u32 rank[SLOTS / 1024u];\n"

@@ -989,10 +989,79 @@ void AresCommDestroy(AresComm *c) {
   delete c;
 }
 
+// HyperLogLog shard merge.  A shard that has NOT been finalised (every batch ran with isLastBatch = 0) holds its
+// state as entries (dimension row, value = rho << 16 | register), one per (group, register) it has seen, in
+// rows [0, resultSize) of dimension / measure vector [0].  The ranks exchange those entries in one all-gather;
+// every rank then feeds the OTHER ranks' entries to the library's own HyperLogLog call as one more batch — with
+// isLastBatch = 1 — behind its own state: the call keeps the maximum rho per (group, register), which is the
+// register-max merge of the broker (broker/result_merge.go:95-104, query/common/hll.go:148), and encodes the
+// final dense / sparse vector.  Every rank ends with the same result.
+static int merge_shards_hll(AresQuery *q, AresComm *c) {
+  if (q->isLastBatch || q->hllVector)
+    throw AbiError("HyperLogLog shard merge needs the shard's intermediate entries: run every batch with isLastBatch = 0, the merge finalises");
+  std::vector<int> widths;
+  for (int k = 0; k < NUM_DIM_WIDTH; k++)
+    for (int j = 0; j < q->ndw[k]; j++) widths.push_back(kDimWidths[k]);
+  const int nd = static_cast<int>(widths.size()), world = c->nranks, mb = 4;
+  int64_t valueBytes = 0;
+  for (int w : widths) valueBytes += w;
+  const int64_t rowBytes = valueBytes + nd + mb;
+  std::vector<int64_t> sizes(world, 0);
+  const int64_t mine = q->resultSize;
+  gather_words(q, c, &mine, sizes.data(), sizeof(int64_t));
+  int64_t gmax = 1, others = 0;
+  for (int r = 0; r < world; r++) {
+    gmax = std::max(gmax, sizes[r]);
+    if (r != c->rank) others += sizes[r];
+  }
+  if (others + mine > INT32_MAX) throw AbiError("merged result exceeds 2^31 rows");
+  std::vector<int64_t> sect;
+  int64_t off = 0;
+  for (int w : widths) { sect.push_back(off); off += gmax * w; }
+  for (int d = 0; d < nd; d++) { sect.push_back(off); off += gmax; }
+  sect.push_back(off);
+  const size_t packedBytes = static_cast<size_t>(gmax * rowBytes);
+  uint8_t *packed = q->alloc(packedBytes), *gathered = q->alloc(packedBytes * world);
+  for (int d = 0; d < nd && mine; d++) {
+    int64_t vo, no;
+    dimension_start_offsets(q->ndw, d, q->resultCapacity, &vo, &no);
+    q->d2d(packed + sect[d], q->dimVec[0] + vo, static_cast<size_t>(mine) * widths[d]);
+    q->d2d(packed + sect[nd + d], q->dimVec[0] + no, static_cast<size_t>(mine));
+  }
+  if (mine) q->d2d(packed + sect[2 * nd], q->measureVec[0], static_cast<size_t>(mine) * mb);
+  q->lib->noteWrite(q->device, gathered, packedBytes * world);
+  if (c->allGather(c->user, packed, gathered, packedBytes, q->stream) != 0) throw AbiError("all-gather of the HyperLogLog entries failed");
+  q->wait();
+  // the other ranks' entries are this rank's last batch: rows [resultSize, resultSize + others) of dimension vector [0],
+  // their values in measure vector [1] (where a batch's hll values go, query/time_series_aggregate.go:404-408)
+  q->size = static_cast<int>(others);
+  q->prepareForDimAndMeasureEval();
+  int64_t base = 0;
+  for (int r = 0; r < world; r++) {
+    if (r == c->rank || !sizes[r]) continue;
+    const uint8_t *src = gathered + packedBytes * r;
+    for (int d = 0; d < nd; d++) {
+      int64_t vo, no;
+      dimension_start_offsets(q->ndw, d, q->resultCapacity, &vo, &no);
+      q->d2d(q->dimVec[0] + vo + (q->resultSize + base) * widths[d], const_cast<uint8_t *>(src) + sect[d], static_cast<size_t>(sizes[r]) * widths[d]);
+      q->d2d(q->dimVec[0] + no + q->resultSize + base, const_cast<uint8_t *>(src) + sect[nd + d], static_cast<size_t>(sizes[r]));
+    }
+    q->d2d(q->measureVec[1] + base * mb, const_cast<uint8_t *>(src) + sect[2 * nd], static_cast<size_t>(sizes[r]) * mb);
+    base += sizes[r];
+  }
+  q->wait();
+  q->release(packed);
+  q->release(gathered);
+  q->isLastBatch = true;
+  q->reduce();
+  q->postExec();
+  return 0;
+}
+
 int AresQueryMergeShards(AresQuery *q, AresComm *c, char *err, int errLen) {
   try {
     if (!c || !c->allGather) throw AbiError("no communicator");
-    if (q->plan.isHLL()) throw AbiError("HyperLogLog results are merged on the host (query/hll.go), not here");
+    if (q->plan.isHLL()) return merge_shards_hll(q, c);
     std::vector<int> widths;
     for (int k = 0; k < NUM_DIM_WIDTH; k++)
       for (int j = 0; j < q->ndw[k]; j++) widths.push_back(kDimWidths[k]);
@@ -1072,7 +1141,7 @@ int AresQueryMergeShards(AresQuery *q, AresComm *c, char *err, int errLen) {
 int AresQueryMergeShardsPartitioned(AresQuery *q, AresComm *c, int64_t *totalGroups, char *err, int errLen) {
   try {
     if (!c || !c->allGather) throw AbiError("no communicator");
-    if (q->plan.isHLL()) throw AbiError("HyperLogLog results are merged on the host (query/hll.go), not here");
+    if (q->plan.isHLL()) throw AbiError("HyperLogLog shards merge through AresQueryMergeShards (all-gather of the entries + register-max)");
     std::vector<int> widths;
     for (int k = 0; k < NUM_DIM_WIDTH; k++)
       for (int j = 0; j < q->ndw[k]; j++) widths.push_back(kDimWidths[k]);

@@ -165,6 +165,66 @@ def test_native_shard_merge_gloo(use_hash, world):
     assert len({r[2] for r in results}) == 1 and results[0][2] > 0
 
 
+def _hll_worker(rank, world, port, q):
+    """HyperLogLog shards: every rank runs its batches un-finalised, the merge exchanges the (group, register, rho)
+    entries and finalises; every rank's encoded result must equal one process over all the batches — register by
+    register (the broker's register-max, broker/result_merge.go:95-104)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import harness as H
+    from aresdb_amd import abi, smoke
+    from aresdb_amd.columns import DeviceColumn
+    from aresdb_amd.driver import NativeComm, NativeQuery
+    from test_executor import _hll_batches, _hll_plan
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        be = H.oracle_backend()
+        plan = _hll_plan()
+        rng = np.random.default_rng(77)
+        # rank 2 of three has an empty shard; a dense group (> 4096 registers) needs many users of one (day, d3) pair
+        sizes = [[4000, 2500], [3000, 60000], []] if world == 3 else [[4000, 2500, 30000], [3000, 45000]]
+        shards = [_hll_batches(rng, sz) for sz in sizes]
+        for sh in shards:  # dense groups: few distinct group keys
+            for cols, valid in sh:
+                if len(cols["ts"][1]) > 20000:
+                    cols["ts"] = (cols["ts"][0], (cols["ts"][1] % 86400).astype(np.uint32))
+        q_ = NativeQuery(be, plan, list(shards[0][0][0].keys()) if shards[0] else ["ts", "d1", "d2", "d3", "m", "user"])
+        for cols, valid in shards[rank]:
+            dev = {k: DeviceColumn(be, t, v, valid=valid[k]) for k, (t, v) in cols.items()}
+            q_.run({k: d.vp for k, d in dev.items()}, len(next(iter(cols.values()))[1]), is_last_batch=False)
+            for d in dev.values():
+                d.free()
+        comm = NativeComm.torch_group()
+        q_.merge_shards(comm)
+        got = smoke._hll_groups(*q_.fetch_hll())
+        want, _ = smoke.run_hll_query(be, plan, [b for sh in shards for b in sh], native=True)
+        assert got == want, (len(got), len(want))
+        assert any(len(v) >= 4096 for v in got.values()), "no dense group in the test data"
+        comm.destroy()
+        q_.release()
+        q.put((rank, "ok", len(got)))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, f"{type(e).__name__}: {e} {traceback.format_exc()[-600:]}", 0))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_hll_shard_merge_gloo(world):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_hll_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in results), results
+    assert len({r[2] for r in results}) == 1 and results[0][2] > 0
+
+
 def _worker(rank, world, port, use_hash, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))

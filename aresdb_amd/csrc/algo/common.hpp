@@ -55,6 +55,17 @@ void flush_deferred_for_vector(int device, const DimensionVector &v, const void 
 // skipped work whose outputs lie in ranges that are about to be overwritten is dropped, never launched
 void drop_skipped_outputs(int device, const void *a, size_t aBytes, const void *b, size_t bBytes);
 
+// ---- lazy fills (transform.hip): buffers defined as a repeated 4- or 8-byte pattern that nobody has written yet ----
+// false = deferral is off (no sibling libmem.so hooks): the caller writes the bytes itself
+bool defer_fill(int device, hipStream_t stream, void *dst, size_t bytes, uint64_t pattern, int unit);
+bool pending_fill_exact(int device, const void *dst, size_t bytes, uint64_t *pattern, int *unit);
+// a lazy fill covering rows [*prev, length) of a vector of `width`-byte values
+bool pending_fill_tail(int device, const void *base, int width, int length, int *prev, uint64_t *pattern);
+void retire_fills_for_write(int device, const void *ptr, size_t bytes);   // a kernel of the caller overwrites the range
+void materialize_fills_for_read(int device, const void *ptr, size_t bytes);  // a kernel of the caller reads the range
+// `indexVector` is defined as iota(0 .. n) and not written yet (InitIndexVector is lazy)
+bool virtual_iota_peek(int device, const uint32_t *indexVector, int n);
+
 // NOFLUSH: only for the transform entry points, which decide themselves whether to queue or flush
 #define ARES_ABI_BEGIN_NOFLUSH(device)                 \
   CGoCallResHandle resHandle = {nullptr, nullptr};     \

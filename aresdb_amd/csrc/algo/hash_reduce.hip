@@ -137,6 +137,14 @@ extern "C" CGoCallResHandle HashReduce(DimensionVector inputKeys, uint8_t *input
                                        enum AggregateFunction aggFunc, void *cudaStream, int device) {
   ARES_ABI_BEGIN_NOFLUSH(device)
   hipStream_t stream = reinterpret_cast<hipStream_t>(cudaStream);
+  if (length > 0) {  // lazily filled inputs are written first, lazily filled outputs retired
+    const DimLayoutD inLayout = make_dim_layout(inputKeys.NumDimsPerDimWidth);
+    const size_t cap = inputKeys.VectorCapacity > 0 ? static_cast<size_t>(inputKeys.VectorCapacity) : 0;
+    materialize_fills_for_read(device, inputKeys.DimValues, static_cast<size_t>(inLayout.rowBytes) * cap);
+    materialize_fills_for_read(device, inputValues, static_cast<size_t>(valueBytes) * length);
+    retire_fills_for_write(device, outputKeys.DimValues, static_cast<size_t>(inLayout.rowBytes) * cap);
+    retire_fills_for_write(device, outputValues, static_cast<size_t>(valueBytes) * length);
+  }
   {  // whatever an earlier HashReduce skipped that would write into this call's outputs is dead
     const DimLayoutD outLayout = make_dim_layout(outputKeys.NumDimsPerDimWidth);
     drop_skipped_outputs(device, outputKeys.DimValues,

@@ -315,12 +315,12 @@ static void kernel_body_lines16(std::ostringstream &o, const char *fourth) {
        "  u32 tile = blockIdx.x, par = 0u;\n"
        "  Raw R;\n"
        "  PH_DECL\n"
-       "  load_tile(R, a, tile * T + tid * 4u, tile < fullTiles ? 1u : tile < numTiles ? 2u : 0u);\n"
+       "  load_tile(R, a, tile * T + tid * 4u);\n"
        "  while (tile < numTiles) {\n"
        "    const u32 i0 = tile * T + tid * 4u;\n"
        "    u32 hh[4], cv[4], cw[4], alive[4], rank[4];\n"
        "    const u32 next = tile + gridDim.x;\n"
-       "    eval4p(R, a, i0, hh, cv, cw, alive, next < fullTiles ? 1u : next < numTiles ? 2u : 0u, next * T + tid * 4u);\n"
+       "    eval4p(R, a, i0, hh, cv, cw, alive, next * T + tid * 4u, tile >= fullTiles);\n"
        "    u32 *cnt = sCount[par];\n"
        "#pragma unroll\n"
        "    for (int j = 0; j < 4; j++) {\n"
@@ -457,7 +457,7 @@ static void kernel_body_compact(std::ostringstream &o) {
        "  u32 tile = firstTile, par = 0u;\n"
        "  Raw R;\n"
        "  PH_DECL\n"
-       "  load_tile(R, a, tile * T + tid * 4u, tile >= endTile ? 0u : tile < fullTiles ? 1u : 2u);\n"
+       "  load_tile(R, a, tile * T + tid * 4u);\n"
        // the lane's place in a line: 16 lanes per line, lanes 0 and 8 carry the two headers
        "  const u32 q = tid & 15u, r8 = q & 7u;\n"
        "  const u32 kk = (q >> 3) * 7u + (r8 ? r8 - 1u : 0u);\n"  // record of the line this lane carries
@@ -467,7 +467,7 @@ static void kernel_body_compact(std::ostringstream &o) {
        "    const u32 rc0 = (tile - firstTile) * T + tid * 4u;\n"  // row within the chunk
        "    u32 hh[4], cv[4], cw[4], alive[4], rank[4];\n"
        "    const u32 next = tile + 1u;\n"
-       "    eval4p(R, a, i0, hh, cv, cw, alive, next >= endTile ? 0u : next < fullTiles ? 1u : 2u, next * T + tid * 4u);\n"
+       "    eval4p(R, a, i0, hh, cv, cw, alive, next * T + tid * 4u, tile >= fullTiles);\n"
        "    u32 *cnt = sCount[par];\n"
        "#pragma unroll\n"
        "    for (int j = 0; j < 4; j++) {\n"
@@ -680,13 +680,13 @@ static void kernel_body_table(std::ostringstream &o) {
        "  u32 tile = blockIdx.x, qn = 0u;\n"
        "  u32 *queue = sQueue + wave * (QCAP * 3u);\n"
        "  Raw R0, R1;\n"
-       "  load_tile(R0, a, tile * T + tid * 4u, tile < fullTiles ? 1u : tile < numTiles ? 2u : 0u);\n"
-       "  load_tile(R1, a, (tile + G) * T + tid * 4u, tile + G < fullTiles ? 1u : tile + G < numTiles ? 2u : 0u);\n"
+       "  load_tile(R0, a, tile * T + tid * 4u);\n"
+       "  load_tile(R1, a, (tile + G) * T + tid * 4u);\n"
        "#define TILE_STEP(R)                                                                                   \\\n"
        "  {                                                                                                    \\\n"
        "    const u32 i0 = tile * T + tid * 4u, next = tile + 2u * G;                                          \\\n"
        "    u32 hh[4], cv[4], cw[4], alive[4];                                                                 \\\n"
-       "    eval4p(R, a, i0, hh, cv, cw, alive, next < fullTiles ? 1u : next < numTiles ? 2u : 0u, next * T + tid * 4u); \\\n"
+       "    eval4p(R, a, i0, hh, cv, cw, alive, next * T + tid * 4u, tile >= fullTiles);                        \\\n"
        "    const u32 row0 = a.rowBase + i0;                                                                   \\\n"
        "    row_one(a, alive[0] != 0u, row0, hh[0], cv[0], lane, sKeys, sVals, &sClaims, queue, qn);           \\\n"
        "    row_one(a, alive[1] != 0u, row0 + 1u, hh[1], cv[1], lane, sKeys, sVals, &sClaims, queue, qn);      \\\n"
@@ -738,47 +738,49 @@ std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t null
   o << kPrelude << args_text()
     << "#define NC " << nc << "\n#define ND " << nd << "\n#define PB " << partBits << "\n#define NP " << (1 << partBits) << "\n"
        "struct Raw { u32 v[NC][4]; u32 win[NC]; };\n";
-  // ---- loads, one column at a time: of a full quad (all four rows exist: mode 1) / guarded, for the shard's last,
-  // partial tile (mode 2)
+  // ---- loads, one column at a time.  Always the full 16 bytes + the 16-bit validity window, from a row index clamped
+  // to length - 4: no guarded variant, hence no branch at load time (a branch around a load makes the compiler copy
+  // the loaded registers at the join — and wait for the load right there).  The one quad of the shard that straddles
+  // its end is shifted into place when its tile is evaluated; lanes past the end hold rows that do not take part.
+  o << "__device__ __forceinline__ u32 clampi(const Args &a, u32 i0) { const u32 lim = a.length >= 4 ? (u32)a.length - 4u : 0u; return i0 < lim ? i0 : lim; }\n";
   for (int c = 0; c < nc; c++) {
-    o << "__device__ __forceinline__ void load_col" << c << "_1(Raw &r, const Args &a, u32 i0) {\n"
-         "  const PU32x4 t = *reinterpret_cast<const PU32x4 *>(a.vals[" << c << "] + i0); r.v[" << c << "][0] = t.v[0]; r.v[" << c
+    o << "__device__ __forceinline__ void load_col" << c << "(Raw &r, const Args &a, u32 i0c) {\n"
+         "  const PU32x4 t = *reinterpret_cast<const PU32x4 *>(a.vals[" << c << "] + i0c); r.v[" << c << "][0] = t.v[0]; r.v[" << c
       << "][1] = t.v[1]; r.v[" << c << "][2] = t.v[2]; r.v[" << c << "][3] = t.v[3];\n";
     if (nullMask & (1u << c))
-      o << "  r.win[" << c << "] = reinterpret_cast<const PU16 *>(a.nulls[" << c << "] + ((i0 + a.bitOff[" << c << "]) >> 3))->v;\n";
+      o << "  r.win[" << c << "] = reinterpret_cast<const PU16 *>(a.nulls[" << c << "] + ((i0c + a.bitOff[" << c << "]) >> 3))->v;\n";
     else
       o << "  r.win[" << c << "] = 0xFFFFu;\n";
-    o << "}\n"
-         "__device__ __forceinline__ void load_col" << c << "_2(Raw &r, const Args &a, u32 i0) {\n"
-         "  for (int j = 0; j < 4; j++) r.v[" << c << "][j] = (int)(i0 + j) < a.length ? a.vals[" << c << "][i0 + j] : 0u;\n";
-    if (nullMask & (1u << c))
-      o << "  r.win[" << c << "] = (int)i0 < a.length ? (u32)reinterpret_cast<const PU16 *>(a.nulls[" << c << "] + ((i0 + a.bitOff[" << c
-        << "]) >> 3))->v : 0u;\n";
-    else
-      o << "  r.win[" << c << "] = 0xFFFFu;\n";
-    o << "}\n"
-         "__device__ __forceinline__ void load_col" << c << "_0(Raw &, const Args &, u32) {}\n";
+    o << "}\n";
   }
-  o << "__device__ __forceinline__ void load_tile(Raw &r, const Args &a, u32 i0, u32 mode) {\n  if (mode == 1u) {\n";
-  for (int c = 0; c < nc; c++) o << "    load_col" << c << "_1(r, a, i0);\n";
-  o << "  } else if (mode == 2u) {\n";
-  for (int c = 0; c < nc; c++) o << "    load_col" << c << "_2(r, a, i0);\n";
-  o << "  }\n}\n";
-  // ---- evaluate + hash one quad (hash, carried measure bits and "takes part" of its four rows) AND issue the next
-  // tile's loads, column by column, as soon as a column's registers are dead: a single register buffer, yet loads
-  // are in flight during the whole evaluation instead of only after it (the kernel is HBM-bound: with the loads
-  // issued after the evaluation the read pipe idled for a third of every tile).  One straight-line copy per load
-  // mode of the next tile (0 none, 1 full, 2 guarded): a branch around each column's load would make the compiler
-  // wait for every outstanding load at each join.  i0n: this lane's first row in the next tile.
-  for (int mode = 0; mode < 3; mode++) {
-    const std::string M = "_" + std::to_string(mode);
-    o << "__device__ __forceinline__ void eval4p" << M << "(Raw &r, const Args &a, u32 i0, u32 (&hh)[4], u32 (&cv)[4], u32 (&cw)[4], u32 (&alive)[4], u32 i0n) {\n"
+  o << "__device__ __forceinline__ void load_tile(Raw &r, const Args &a, u32 i0) {\n  const u32 i0c = clampi(a, i0);\n";
+  for (int c = 0; c < nc; c++) o << "  load_col" << c << "(r, a, i0c);\n";
+  o << "}\n";
+  // ---- evaluate + hash one quad (hash, carried measure bits and "takes part" of its four rows) AND issue
+  // the next tile's loads, column by column, as soon as a column's registers are dead: a single register buffer, yet
+  // loads are in flight during the whole evaluation instead of only after it (the kernel is HBM-bound: with the loads
+  // issued after the evaluation the read pipe idled for a third of every tile).  Scheduling barriers pin each load
+  // behind the last use of the registers it refills.  i0n: this lane's first row in the next tile (past the last tile the
+  // clamp turns the prefetch into one cache line per column: no branch needed); partial: this tile holds the shard's
+  // end (wave-uniform).
+  {
+    const std::string bar = "  __builtin_amdgcn_sched_barrier(0);\n";
+    auto prefetch = [&](int c) { o << bar << "  load_col" << c << "(r, a, i0nc);\n" << bar; };
+    o << "__device__ __forceinline__ void eval4p(Raw &r, const Args &a, u32 i0, u32 (&hh)[4], u32 (&cv)[4], u32 (&cw)[4], u32 (&alive)[4], u32 i0n, bool partial) {\n"
          "  u32 okc[NC];\n"
-         "  cw[0] = cw[1] = cw[2] = cw[3] = 0u;\n";
+         "  cw[0] = cw[1] = cw[2] = cw[3] = 0u;\n"
+         "  const u32 i0c = clampi(a, i0), i0nc = clampi(a, i0n);\n"
+         "  const u32 sh = i0 - i0c < 4u ? i0 - i0c : 4u;\n";   // rows this quad was loaded too early by (0 except at the shard's end)
     for (int c = 0; c < nc; c++) {
-      if (nullMask & (1u << c)) o << "  okc[" << c << "] = (r.win[" << c << "] >> ((i0 + a.bitOff[" << c << "]) & 7u)) & 0xFu;\n";
+      if (nullMask & (1u << c)) o << "  okc[" << c << "] = (r.win[" << c << "] >> (((i0c + a.bitOff[" << c << "]) & 7u) + sh)) & 0xFu;\n";
       else o << "  okc[" << c << "] = 0xFu;\n";
     }
+    o << "  if (partial && sh) {\n";  // the straddling quad: move its rows to the front
+    for (int c = 0; c < nc; c++)
+      o << "    { const u32 v0 = r.v[" << c << "][0], v1 = r.v[" << c << "][1], v2 = r.v[" << c << "][2], v3 = r.v[" << c << "][3];\n"
+           "      r.v[" << c << "][0] = sh == 1u ? v1 : sh == 2u ? v2 : sh == 3u ? v3 : 0u; r.v[" << c << "][1] = sh == 1u ? v2 : sh == 2u ? v3 : 0u; r.v[" << c
+        << "][2] = sh == 1u ? v3 : 0u; r.v[" << c << "][3] = 0u; }\n";
+    o << "  }\n";
     o << "#pragma unroll\n"
          "  for (int j = 0; j < 4; j++) {\n"
          "    u32 keep = (int)(i0 + j) < a.length ? 1u : 0u;\n";
@@ -790,7 +792,7 @@ std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t null
       o << "    }\n";
     }
     o << "    alive[j] = keep;\n  }\n";
-    for (int c = nd + 1; c < nc; c++) o << "  load_col" << c << M << "(r, a, i0n);\n";  // columns only the filters read
+    for (int c = nd + 1; c < nc; c++) prefetch(c);  // columns only the filters read
     {  // measure: fused_carry
       const FusedExpr &e = plan.measure;
       if (e.col != nd) return "";
@@ -805,7 +807,8 @@ std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t null
         if (!plain_store(e.f.rk, target)) return "";
         o << "    cv[j] = okb ? x : " << hex(static_cast<uint32_t>(plan.identity)) << ";\n";
       }
-      o << "  }\n  load_col" << nd << M << "(r, a, i0n);\n";
+      o << "  }\n";
+      prefetch(nd);
     }
     o << "  u32 h[4] = {0u, 0u, 0u, 0u}, okbytes[4] = {0u, 0u, 0u, 0u};\n";
     for (int d = 0; d < nd; d++) {
@@ -814,8 +817,8 @@ std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t null
       o << "#pragma unroll\n  for (int j = 0; j < 4; j++) {\n"
            "    const u32 v = r.v[" << d << "][j]; const u32 okb = (okc[" << d << "] >> j) & 1u; u32 x;\n";
       if (!gen_value(e.f, o, "v", "okb", "x", const_name(const_slot_dim(d)))) return "";
-      o << "    h[j] = mix(h[j], x); okbytes[j] |= okb << " << 8 * d << ";\n  }\n"
-           "  load_col" << d << M << "(r, a, i0n);\n";
+      o << "    h[j] = mix(h[j], x); okbytes[j] |= okb << " << 8 * d << ";\n  }\n";
+      prefetch(d);
     }
     // Murmur32Stream (dim_layout.hpp): the validity bytes are one more block when there are four of them,
     // otherwise the tail
@@ -825,11 +828,6 @@ std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t null
     o << "    g ^= " << 5 * nd << "u; g ^= g >> 16; g *= 0x85ebca6bu; g ^= g >> 13; g *= 0xc2b2ae35u; g ^= g >> 16;\n"
          "    hh[j] = g;\n  }\n}\n";
   }
-  o << "__device__ __forceinline__ void eval4p(Raw &r, const Args &a, u32 i0, u32 (&hh)[4], u32 (&cv)[4], u32 (&cw)[4], u32 (&alive)[4], u32 mode, u32 i0n) {\n"
-       "  if (mode == 1u) eval4p_1(r, a, i0, hh, cv, cw, alive, i0n);\n"
-       "  else if (mode == 2u) eval4p_2(r, a, i0, hh, cv, cw, alive, i0n);\n"
-       "  else eval4p_0(r, a, i0, hh, cv, cw, alive, i0n);\n"
-       "}\n";
   if (kind == SCAN_TABLE) {
     if (!agg || !widen || !gen_widen(o, *widen) || !gen_agg(o, *agg)) return "";
     kernel_body_table(o);
@@ -896,10 +894,10 @@ std::string generate_vector(int nd, int vw, int partBits) {
        "    cw[j] = MQ == 2 ? r.m[j * MQ + MQ - 1] : 0u;\n"
        "  }\n"
        "}\n";
-  o << "__device__ __forceinline__ void load_tile(Raw &r, const Args &a, u32 i0, u32 mode) { if (mode == 1u) load_full(r, a, i0); else if (mode == 2u) load_tail(r, a, i0); }\n"
-       "__device__ __forceinline__ void eval4p(Raw &r, const Args &a, u32 i0, u32 (&hh)[4], u32 (&cv)[4], u32 (&cw)[4], u32 (&alive)[4], u32 mode, u32 i0n) {\n"
+  o << "__device__ __forceinline__ void load_tile(Raw &r, const Args &a, u32 i0) { if ((int)(i0 + 3u) < a.length) load_full(r, a, i0); else if ((int)i0 < a.length) load_tail(r, a, i0); }\n"
+       "__device__ __forceinline__ void eval4p(Raw &r, const Args &a, u32 i0, u32 (&hh)[4], u32 (&cv)[4], u32 (&cw)[4], u32 (&alive)[4], u32 i0n, bool) {\n"
        "  eval4(r, a, i0, hh, cv, cw, alive);\n"
-       "  load_tile(r, a, i0n, mode);\n"
+       "  load_tile(r, a, i0n);\n"
        "}\n";
   kernel_body_lines16(o, "cw[j]");
   return o.str();

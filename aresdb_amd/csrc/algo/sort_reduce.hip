@@ -647,6 +647,87 @@ static int expand_impl(const DimensionVector &in, const DimensionVector &out, ui
   return outLen + occupied;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Queries without dimensions (COUNT(*) / SUM / MIN / MAX over the whole table: BASELINE config C2)
+// ---------------------------------------------------------------------------------------------
+// Every row is the empty dimension row: Sort gives all of them one constant hash and leaves the index vector as
+// it was, Reduce folds the whole value vector into ONE group.  Nothing of that needs 8 + 4 bytes per row of hash
+// and index traffic, an 8-pass radix sort or a segmented reduction:
+//   * Sort over an index vector that is still a lazy iota defines the hash vector as a lazy fill (transform.hip)
+//     and returns: no kernel;
+//   * Reduce then knows the hashes are equal and the index is the identity: one reduction pass over the value rows
+//     that exist — and the rows a constant measure transform only DEFINED (COUNT(*): the literal 1) are added
+//     arithmetically: prev + n x c.  Integer SUM / MIN / MAX only (a float sum depends on the order of additions).
+// Anything else that looks at those buffers finds them written (every flush point materialises lazy fills).
+uint64_t empty_row_hash() {  // murmur3_x64_128 of zero bytes, seed 0: h1 = h2 = 0 -> fmix64(0) twice = 0
+  return 0ull;
+}
+
+__global__ __launch_bounds__(kBlock) void reduce_all_kernel(const uint8_t *values, int rows, AggSpec a, uint64_t constBits,
+                                                             uint32_t constRows, uint8_t *out, uint32_t *indexOut) {
+  uint64_t acc = a.identity;
+  bool any = false;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < rows; i += static_cast<int64_t>(gridDim.x) * kBlock) {
+    acc = combine_bits(a, acc, load_value_bits(values, a, static_cast<size_t>(i)));
+    any = true;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (indexOut) indexOut[0] = 0u;
+    if (constRows) {  // rows that are only defined: c repeated constRows times
+      uint64_t folded = constBits;
+      if (a.op == OP_SUM) folded = (a.width == 8 ? constBits * static_cast<uint64_t>(constRows)
+                                                 : static_cast<uint64_t>(static_cast<uint32_t>(constBits) * constRows));
+      acc = combine_bits(a, acc, folded);
+      any = true;
+    }
+  }
+  // wavefront fold, then one atomic per wavefront that saw anything
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const uint64_t other = __shfl_xor(static_cast<unsigned long long>(acc), off);
+    acc = combine_bits(a, acc, other);
+  }
+  if (__ballot(any) && (threadIdx.x & 63) == 0) aggregate_slot(out, reinterpret_cast<const uint8_t *>(&acc), a);
+}
+
+// Reduce of a query without dimensions over lazily defined inputs; false = not this case
+static bool reduce_without_dimensions(int device, const DimensionVector &in, const uint8_t *inputValues, const DimensionVector &out,
+                                      uint8_t *outputValues, int valueBytes, int length, int aggFunc, hipStream_t stream, int *groups) {
+  if (length <= 0) return false;
+  const DimLayoutD L = make_dim_layout(in.NumDimsPerDimWidth), LO = make_dim_layout(out.NumDimsPerDimWidth);
+  if (L.numDims != 0 || LO.numDims != 0 || aggFunc == AGGR_AVG_FLOAT) return false;
+  AggSpec a;
+  try {
+    a = make_agg_spec(aggFunc, valueBytes);
+  } catch (std::exception &) {
+    return false;
+  }
+  if (!(a.vtype == V_U32 || a.vtype == V_I32 || a.vtype == V_U64 || a.vtype == V_I64)) return false;
+  uint64_t hashPattern = 0;
+  int hashUnit = 0;
+  if (!in.HashValues || !in.IndexVector || !virtual_iota_peek(device, in.IndexVector, length) ||
+      !pending_fill_exact(device, in.HashValues, 8ull * static_cast<size_t>(length), &hashPattern, &hashUnit) || hashUnit != 8)
+    return false;
+  int prev = length;
+  uint64_t c = 0;
+  if (!pending_fill_tail(device, inputValues, a.width, length, &prev, &c)) {
+    prev = length;  // every value row exists
+    materialize_fills_for_read(device, inputValues, static_cast<size_t>(a.width) * length);
+  } else if (prev > 0) {
+    materialize_fills_for_read(device, inputValues, static_cast<size_t>(a.width) * prev);
+  }
+  retire_fills_for_write(device, outputValues, static_cast<size_t>(a.width));
+  if (out.IndexVector) retire_fills_for_write(device, out.IndexVector, 4);
+  mem_note_write(device, outputValues, static_cast<size_t>(a.width));
+  if (out.IndexVector) mem_note_write(device, out.IndexVector, 4);
+  ARES_LAUNCH("fill_identity_kernel", fill_identity_kernel, 1, kBlock, stream, outputValues, a, 1);
+  const int grid = capped_grid((static_cast<int64_t>(prev) + kBlock * 8 - 1) / (kBlock * 8), 256 * 4);
+  ARES_LAUNCH("reduce_all_kernel", reduce_all_kernel, grid, kBlock, stream, inputValues, prev, a, c, static_cast<uint32_t>(length - prev),
+              outputValues, out.IndexVector);
+  *groups = 1;
+  return true;
+}
+
 }  // namespace ares
 
 using namespace ares;
@@ -654,7 +735,13 @@ using namespace ares;
 extern "C" {
 
 CGoCallResHandle Sort(DimensionVector keys, int length, void *cudaStream, int device) {
-  ARES_ABI_BEGIN(device)
+  ARES_ABI_BEGIN_NOFLUSH(device)
+  // no dimensions and an index vector that is still a lazy iota: the hash vector is DEFINED (one constant), not written
+  if (length > 0 && make_dim_layout(keys.NumDimsPerDimWidth).numDims == 0 && keys.HashValues && keys.IndexVector &&
+      virtual_iota_peek(device, keys.IndexVector, length) &&
+      defer_fill(device, reinterpret_cast<hipStream_t>(cudaStream), keys.HashValues, 8ull * static_cast<size_t>(length), empty_row_hash(), 8))
+    return resHandle;
+  flush_deferred(device);
   flush_deferred_for_vector(device, keys, nullptr, 0);  // rows a HashReduce skipped, should a host sort them after all
   if (length > 0) {
     mem_note_write(device, keys.HashValues, 8ull * static_cast<size_t>(length));
@@ -667,7 +754,16 @@ CGoCallResHandle Sort(DimensionVector keys, int length, void *cudaStream, int de
 CGoCallResHandle Reduce(DimensionVector inputKeys, uint8_t *inputValues, DimensionVector outputKeys,
                         uint8_t *outputValues, int valueBytes, int length, enum AggregateFunction aggFunc,
                         void *cudaStream, int device) {
-  ARES_ABI_BEGIN(device)
+  ARES_ABI_BEGIN_NOFLUSH(device)
+  {
+    int groups = 0;
+    if (reduce_without_dimensions(device, inputKeys, inputValues, outputKeys, outputValues, valueBytes, length, aggFunc,
+                                  reinterpret_cast<hipStream_t>(cudaStream), &groups)) {
+      resHandle.res = int_result(groups);
+      return resHandle;
+    }
+  }
+  flush_deferred(device);
   flush_deferred_for_vector(device, inputKeys, inputValues, static_cast<size_t>(valueBytes) * (length > 0 ? length : 0));
   grouped_note_write(device, outputKeys);
   grouped_note_write(device, outputValues, static_cast<size_t>(valueBytes) * (length > 0 ? length : 0));

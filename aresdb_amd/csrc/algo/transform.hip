@@ -1187,6 +1187,19 @@ struct PendingIota {
   int n;
 };
 
+// Buffers that a call has defined as "`unit`-byte pattern, repeated" but that nobody has written yet ("lazy fill"):
+// the measure vector a constant transform fills (COUNT(*) is SUM over a literal 1, query/aql_compiler.go:1191-1197),
+// the hash vector Sort gives a query without dimensions (every row hashes alike).  A consumer that knows what the
+// bytes would be (Reduce over zero dimensions) never makes anybody write them; every other reader, copy or flush
+// point writes them first; a free or an overwrite retires them.
+struct PendingFill {
+  int device;
+  hipStream_t stream;
+  size_t bytes;
+  uint64_t pattern;
+  int unit;  // 4 or 8
+};
+
 void hook_on_wait(int device, void *stream);
 uintptr_t hook_on_free(int device, void *ptr, size_t bytes);
 void hook_on_access(int device, const void *ptr, size_t bytes);
@@ -1258,6 +1271,7 @@ struct DeferState {
   std::map<const uint32_t *, FilterJournal> journals;
   std::map<const uint32_t *, PendingCompact> compactions;
   std::map<uint32_t *, PendingIota> iotas;
+  std::map<uint8_t *, PendingFill> fills;  // by first byte; ranges never overlap
   std::vector<ErrorCheck> errorChecks;
   std::vector<std::pair<hipEvent_t, uint32_t *>> errorSlots;  // recycled (event, pinned word) pairs
 };
@@ -1400,11 +1414,145 @@ static void launch_init_index(uint32_t *indexVector, uint32_t start, int n, hipS
   ARES_LAUNCH("init_index_kernel", init_index_kernel, grid, kBlock, stream, indexVector, start, n);
 }
 
+// ---- lazy fills -----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void fill_pattern_kernel(uint8_t *dst, size_t units, uint64_t pattern, int unit) {
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x; i < units; i += static_cast<size_t>(gridDim.x) * kBlock) {
+    if (unit == 8) reinterpret_cast<uint64_t *>(dst)[i] = pattern;
+    else reinterpret_cast<uint32_t *>(dst)[i] = static_cast<uint32_t>(pattern);
+  }
+}
+
+// caller holds the device's DeferLock and has selected the device
+static void launch_fill(uint8_t *dst, const PendingFill &f) {
+  if (f.bytes == 0) return;
+  mem_note_write(f.device, dst, f.bytes);
+  const size_t units = f.bytes / static_cast<size_t>(f.unit);
+  ARES_LAUNCH("fill_pattern_kernel", fill_pattern_kernel, capped_grid(static_cast<int64_t>((units + kBlock - 1) / kBlock), 256 * 8), kBlock,
+              f.stream, dst, units, f.pattern, f.unit);
+}
+
+// caller holds the device's DeferLock: every lazy fill of the device (r == nullptr) or those that overlap r are
+// written now
+static void materialize_fills(int device, const ByteRange *r, std::vector<hipStream_t> *touched = nullptr) {
+  for (auto it = t_state->fills.begin(); it != t_state->fills.end();) {
+    const ByteRange v{it->first, it->first + it->second.bytes};
+    if (it->second.device == device && (!r || v.overlaps(*r))) {
+      launch_fill(it->first, it->second);
+      if (touched) touched->push_back(it->second.stream);
+      it = t_state->fills.erase(it);
+    } else {
+      ++it;
+    }
+  }
+}
+
+// caller holds the device's DeferLock: [r.lo, r.hi) is freed (`gone`) or about to be overwritten.  Lazy fills inside
+// it die; one that sticks out at an end is shortened (on a pattern boundary); one that is cut in the middle, or off
+// a pattern boundary, is written first.
+static void retire_fills(int device, const ByteRange &r, bool gone) {
+  for (auto it = t_state->fills.begin(); it != t_state->fills.end();) {
+    uint8_t *lo = it->first;
+    PendingFill f = it->second;
+    const uint8_t *hi = lo + f.bytes;
+    if (f.device != device || !(lo < r.hi && r.lo < hi)) {
+      ++it;
+      continue;
+    }
+    it = t_state->fills.erase(it);
+    if (gone || (r.lo <= lo && hi <= r.hi)) continue;
+    const bool headCut = r.lo <= lo, tailCut = hi <= r.hi;  // (not both: handled above)
+    if (headCut && (static_cast<size_t>(r.hi - lo) % static_cast<size_t>(f.unit)) == 0) {
+      f.bytes = static_cast<size_t>(hi - r.hi);
+      t_state->fills[const_cast<uint8_t *>(r.hi)] = f;
+      it = t_state->fills.upper_bound(const_cast<uint8_t *>(r.hi));
+    } else if (tailCut && (static_cast<size_t>(r.lo - lo) % static_cast<size_t>(f.unit)) == 0) {
+      f.bytes = static_cast<size_t>(r.lo - lo);
+      t_state->fills[lo] = f;
+      it = t_state->fills.upper_bound(lo);
+    } else {
+      launch_fill(lo, f);
+      it = t_state->fills.upper_bound(lo);
+    }
+  }
+}
+
+// [dst, dst + bytes) is defined as `pattern` (unit = 4 or 8 bytes) repeated; false = deferral is off, the caller writes
+bool defer_fill(int device, hipStream_t stream, void *dst, size_t bytes, uint64_t pattern, int unit) {
+  if (!defer_available() || bytes == 0 || (unit != 4 && unit != 8) || bytes % static_cast<size_t>(unit) ||
+      reinterpret_cast<uintptr_t>(dst) % static_cast<uintptr_t>(unit))
+    return false;
+  drop_skipped_outputs(device, dst, bytes, nullptr, 0);  // what an earlier HashReduce skipped and would write there is dead
+  DeferLock lock(device);
+  uint8_t *p = static_cast<uint8_t *>(dst);
+  const ByteRange r{p, p + bytes};
+  for (auto &kv : t_state->pending) {  // queued transforms that write into the range come first (call order)
+    bool hit = false;
+    if (kv.first.first == device && kv.second.jobs.count)
+      for (const ByteRange &w : kv.second.writes) hit = hit || w.overlaps(r);
+    if (hit) launch_queue(kv.first.second, kv.second);
+  }
+  retire_fills(device, r, false);
+  t_state->fills[p] = PendingFill{device, stream, bytes, pattern, unit};
+  return true;
+}
+
+// a lazy fill that covers exactly [dst, dst + bytes)
+bool pending_fill_exact(int device, const void *dst, size_t bytes, uint64_t *pattern, int *unit) {
+  if (!defer_available()) return false;
+  DeferLock lock(device);
+  auto it = t_state->fills.find(const_cast<uint8_t *>(static_cast<const uint8_t *>(dst)));
+  if (it == t_state->fills.end() || it->second.device != device || it->second.bytes != bytes) return false;
+  if (pattern) *pattern = it->second.pattern;
+  if (unit) *unit = it->second.unit;
+  return true;
+}
+
+// a lazy fill that covers rows [prev, length) of a vector of `width`-byte values for some prev: *prev and *pattern
+bool pending_fill_tail(int device, const void *base, int width, int length, int *prev, uint64_t *pattern) {
+  if (!defer_available() || length <= 0) return false;
+  DeferLock lock(device);
+  const uint8_t *b = static_cast<const uint8_t *>(base), *end = b + static_cast<size_t>(width) * length;
+  auto it = t_state->fills.lower_bound(const_cast<uint8_t *>(b));
+  if (it == t_state->fills.end() || it->second.device != device || it->second.unit != width) return false;
+  if (it->first >= end || it->first + it->second.bytes != end || static_cast<size_t>(it->first - b) % static_cast<size_t>(width)) return false;
+  *prev = static_cast<int>(static_cast<size_t>(it->first - b) / static_cast<size_t>(width));
+  *pattern = it->second.pattern;
+  return true;
+}
+
+// [ptr, ptr + bytes) is about to be overwritten by a kernel of the calling entry point
+void retire_fills_for_write(int device, const void *ptr, size_t bytes) {
+  if (!ptr || bytes == 0 || !defer_available()) return;
+  DeferLock lock(device);
+  if (t_state->fills.empty()) return;
+  const uint8_t *p = static_cast<const uint8_t *>(ptr);
+  retire_fills(device, ByteRange{p, p + bytes}, false);
+}
+
+// [ptr, ptr + bytes) is about to be read by a kernel of the calling entry point
+void materialize_fills_for_read(int device, const void *ptr, size_t bytes) {
+  if (!ptr || bytes == 0 || !defer_available()) return;
+  DeferLock lock(device);
+  if (t_state->fills.empty()) return;
+  const uint8_t *p = static_cast<const uint8_t *>(ptr);
+  const ByteRange r{p, p + bytes};
+  materialize_fills(device, &r);
+}
+
+// true when `indexVector` is defined as iota(0 .. n) and not written yet (InitIndexVector is lazy)
+bool virtual_iota_peek(int device, const uint32_t *indexVector, int n) {
+  if (!defer_available()) return false;
+  DeferLock lock(device);
+  auto it = t_state->iotas.find(const_cast<uint32_t *>(indexVector));
+  return it != t_state->iotas.end() && it->second.device == device && it->second.start == 0 && it->second.n == n;
+}
+
 // limboA/limboB: when given, only the skipped work whose outputs overlap these byte ranges is
 // launched (the caller reads nothing else); otherwise all of it
 static void flush_deferred_impl(int device, const ByteRange *limboA, const ByteRange *limboB) {
   DeferLock lock(device);
   poll_error_words(device);
+  materialize_fills(device, nullptr);
   for (auto it = t_state->iotas.begin(); it != t_state->iotas.end();) {
     if (it->second.device == device) {
       launch_init_index(it->first, it->second.start, it->second.n, it->second.stream);
@@ -1671,6 +1819,50 @@ static void note_sink(int device, const SinkD &s, int n) {
   if (s.nulls) mem_note_write(device, s.nulls, static_cast<size_t>(n));
 }
 
+// host twin of cvt32 (device_model.hpp)
+static uint32_t host_cvt32(uint32_t bits, int from, int to) {
+  if (from == to) return bits;
+  auto asf = [](uint32_t b) { float f; memcpy(&f, &b, 4); return f; };
+  auto fb = [](float f) { uint32_t b; memcpy(&b, &f, 4); return b; };
+  switch (to) {
+    case K_BOOL: return from == K_F32 ? (asf(bits) != 0.0f) : (bits != 0u);
+    case K_I32: return from == K_F32 ? static_cast<uint32_t>(static_cast<int32_t>(asf(bits))) : bits;
+    case K_U32: return from == K_F32 ? static_cast<uint32_t>(asf(bits)) : bits;
+    default: return from == K_I32 ? fb(static_cast<float>(static_cast<int32_t>(bits))) : fb(static_cast<float>(bits));
+  }
+}
+
+// What store_measure32 (device_model.hpp) stores for every row of `Noop(constant)`: host twin, run length 1.
+static bool constant_measure_bits(const EvalParams &p, const SinkD &s, uint64_t *out) {
+  if (p.rk != p.I || !(p.I == K_I32 || p.I == K_U32 || p.I == K_F32) || !(p.a.kind == K_I32 || p.a.kind == K_U32 || p.a.kind == K_F32))
+    return false;
+  if (!p.a.cok) {
+    *out = s.width == 8 ? s.identity : static_cast<uint32_t>(s.identity);
+    return true;
+  }
+  const uint32_t bits = host_cvt32(p.a.cbits, p.a.kind, p.I);
+  const int rk = p.rk;
+  auto asf = [](uint32_t b) { float f; memcpy(&f, &b, 4); return f; };
+  switch (s.dtype) {
+    case Int32: *out = host_cvt32(bits, rk, K_I32); return s.width == 4;
+    case Uint32: *out = host_cvt32(bits, rk, K_U32); return s.width == 4;
+    case Float32: *out = host_cvt32(bits, rk, K_F32); return s.width == 4;
+    case Int64: {
+      const int64_t v = rk == K_F32 ? static_cast<int64_t>(asf(bits)) : rk == K_I32 ? static_cast<int64_t>(static_cast<int32_t>(bits))
+                                                                                    : static_cast<int64_t>(bits);
+      *out = static_cast<uint64_t>(v);
+      return s.width == 8;
+    }
+    case Float64: {
+      const double d = rk == K_F32 ? static_cast<double>(asf(bits)) : rk == K_I32 ? static_cast<double>(static_cast<int32_t>(bits))
+                                                                                  : static_cast<double>(bits);
+      memcpy(out, &d, 8);
+      return s.width == 8;
+    }
+    default: return false;
+  }
+}
+
 static int run_transform(const InputVector *ins, int arity, const OutputVector &output, uint32_t *indexVector,
                          int n, uint32_t *baseCounts, uint32_t startCount, int functor, hipStream_t stream, int device) {
   if (n <= 0) {
@@ -1702,6 +1894,16 @@ static int run_transform(const InputVector *ins, int arity, const OutputVector &
     grouped_note_write(device, s.values, static_cast<size_t>(s.width) * n);
     if (s.nulls) grouped_note_write(device, s.nulls, static_cast<size_t>(n));
   }
+  // a constant measure (COUNT(*) is SUM over the literal 1, query/aql_compiler.go:1191-1197): the rows are defined,
+  // not written — Reduce over zero dimensions adds them up without anybody storing them (sort_reduce.hip)
+  if (s.type == SINK_MEASURE && !s.baseCounts && arity == 1 && functor == Noop && p.a.type == OP_CONST && !is_wide(p.a.kind) &&
+      s.agg != AGGR_AVG_FLOAT && (s.width == 4 || s.width == 8)) {
+    uint64_t pattern = 0;
+    if (constant_measure_bits(p, s, &pattern) && defer_fill(device, stream, s.values, static_cast<size_t>(s.width) * n, pattern, s.width))
+      return n;
+  }
+  retire_fills_for_write(device, s.values, static_cast<size_t>(s.width) * n);
+  if (s.nulls) retire_fills_for_write(device, s.nulls, static_cast<size_t>(n));
   FastOperands f;
   const bool fast = fast_sink(s) && fast_operands(p, f, false);
   if (fast && f.idx && virtual_iota(device, indexVector, n, false)) f.idx = nullptr;  // rows = position
@@ -1984,6 +2186,7 @@ uintptr_t hook_on_free(int device, void *ptr, size_t bytes) {
       const ByteRange v = range_of(it->first, 4ull * it->second.n);
       it = (it->second.device == device && v.overlaps(r)) ? t_state->iotas.erase(it) : std::next(it);
     }
+    retire_fills(device, r, true);  // lazy fills of the block die unwritten
     for (auto it = t_state->journals.begin(); it != t_state->journals.end();) {
       // a journal dies with its index vector or with a column its filters read — unless a queue the
       // host has already waited for still refers to it (then the block is held below, contents intact)
@@ -2079,6 +2282,7 @@ void hook_on_access(int device, const void *ptr, size_t bytes) {
         launch_queue(kv.first.second, kv.second);
       }
     }
+    materialize_fills(device, &r, &t_syncAfterUnlock);  // (the copy may run on another stream: wait for the fill)
     materialize_limbo(device, &r, &released);
     for (auto it = t_state->compactions.begin(); it != t_state->compactions.end();) {
       if (it->second.device == device && compaction_touches(it->second, r)) {

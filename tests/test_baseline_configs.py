@@ -90,3 +90,79 @@ def test_c4_join_high_cardinality_sort_reduce():
     q.release()
     for b in [tb] + dcols:
         b.free()
+
+
+def _run_zero_dim_sequence(be, agg, mtype, mb, const):
+    """The ABI call sequence of an aggregate without dimensions over several batches (the measure is a literal:
+    COUNT(*) is SUM over 1, query/aql_compiler.go:1191-1197), with EVERY buffer the host could look at copied back at
+    some point: before the reduction, between Sort and Reduce, after the reduction."""
+    rng = np.random.default_rng(123)
+    ndw = (0, 0, 0, 0, 0)
+    cap = 40000
+    obs = []
+    dummy = H.Buf(be, nbytes=64)
+
+    def dimvec(hashes, index):
+        dv = abi.DimensionVector()
+        dv.DimValues, dv.VectorCapacity = dummy.ptr, cap
+        dv.HashValues, dv.IndexVector = hashes.ptr, index.ptr
+        for k, c in enumerate(ndw):
+            dv.NumDimsPerDimWidth[k] = c
+        return dv
+    meas = [H.Buf(be, nbytes=mb * cap), H.Buf(be, nbytes=mb * cap)]
+    hashes = [H.Buf(be, nbytes=8 * cap), H.Buf(be, nbytes=8 * cap)]
+    dimidx = [H.Buf(be, nbytes=4 * cap), H.Buf(be, nbytes=4 * cap)]
+    result = 0
+    for b, n in enumerate([9000, 1, 12000, 7, 3000]):
+        vals = rng.integers(0, 1000, n).astype(np.uint32)
+        col = H.Column(be, abi.Uint32, vals, valid=rng.random(n) > 0.1)
+        idx, pred = H.Buf(be, nbytes=4 * n), H.Buf(be, nbytes=n)
+        be.call("InitIndexVector", idx.ptr, 0, n, None, 0)
+        size = be.call("BinaryFilter", col.input(), H.const_int(600), idx.ptr, pred.ptr, n, None, 0, None, 0, abi.LessThan, None, 0)
+        obs.append(("size", b, size))
+        if size:
+            be.call("UnaryTransform", H.const_int(const), H.measure_output(meas[0].ptr + mb * result, mtype, agg), idx.ptr, size, None, 0,
+                    abi.Noop, None, 0)
+        be.wait()
+        if b == 2:  # the index vector and the measure rows, looked at before the reduction
+            obs.append(("idx", b, idx.read(np.uint32, size).tobytes()))
+            obs.append(("rows", b, meas[0].read(np.uint8, mb * size, offset=mb * result).tobytes()))
+        for x in (col, idx, pred):
+            x.free()
+        length = result + size
+        be.call("InitIndexVector", dimidx[0].ptr, 0, length, None, 0)
+        be.call("Sort", dimvec(hashes[0], dimidx[0]), length, None, 0)
+        if b == 1:
+            obs.append(("hash", b, hashes[0].read(np.uint64, length).tobytes()))
+        result = be.call("Reduce", dimvec(hashes[0], dimidx[0]), meas[0].ptr, dimvec(hashes[1], dimidx[1]), meas[1].ptr, mb, length, agg,
+                         None, 0)
+        be.wait()
+        obs.append(("groups", b, result))
+        obs.append(("value", b, meas[1].read(np.uint8, mb * result).tobytes()))
+        obs.append(("out_index", b, dimidx[1].read(np.uint32, result).tobytes()))
+        if b == 3:  # ... and the reduction's inputs after it
+            obs.append(("rows_after", b, meas[0].read(np.uint8, mb * length).tobytes()))
+            obs.append(("hash_after", b, hashes[0].read(np.uint64, length).tobytes()))
+            obs.append(("idx_after", b, dimidx[0].read(np.uint32, length).tobytes()))
+        meas.reverse(); hashes.reverse(); dimidx.reverse()
+    for x in meas + hashes + dimidx + [dummy]:
+        x.free()
+    return obs
+
+
+@pytest.mark.parametrize("agg,mtype,mb,const", [(abi.AGGR_SUM_UNSIGNED, abi.Uint32, 4, 1), (abi.AGGR_SUM_SIGNED, abi.Int64, 8, -3),
+                                                (abi.AGGR_MAX_UNSIGNED, abi.Uint32, 4, 7), (abi.AGGR_SUM_FLOAT, abi.Float64, 8, 2)],
+                         ids=["count", "sum_i64", "max_u32", "sum_f64"])
+def test_query_without_dimensions_and_constant_measure(be, agg, mtype, mb, const):
+    """The HIP library defines the constant measure rows and the hash vector of a dimension-less query lazily and folds
+    them arithmetically (sort_reduce.hip); everything it hands back — counts, the result, and every intermediate buffer a
+    host might copy — must be what the oracle (pinned on the reference's HOST build, which is the `ref` backend here)
+    stores."""
+    got = _run_zero_dim_sequence(be, agg, mtype, mb, const)
+    want = _run_zero_dim_sequence(H.oracle_backend(), agg, mtype, mb, const)
+    assert [o[:2] for o in got] == [o[:2] for o in want]
+    for g, w in zip(got, want):
+        assert g[2] == w[2], g[:2]
+    if agg == abi.AGGR_SUM_UNSIGNED:  # COUNT(*) = the survivors of every batch
+        total = sum(o[2] for o in got if o[0] == "size")
+        assert np.frombuffer([o for o in got if o[0] == "value"][-1][2], np.uint32)[0] == total * const

@@ -116,9 +116,13 @@ void (*g_memTrimCache)(int) = nullptr;  // AresMemTrimCache of the sibling libme
 // the Go host creates and destroys two streams per query, blocks cached under dead handles would only pile up,
 // and giving them back to the driver costs a device-synchronising hipFree each plus a hipMalloc in the next query.
 void stream_cache_purge(int device, hipStream_t stream) {
-  static const bool keep = [] {  // ARES_TEMP_ORPHANS=0: give the blocks back to the driver instead (hipFree synchronises the device)
+  // ARES_TEMP_ORPHANS=1 keeps the blocks for the device's other streams; the default gives them back to the driver
+  // (hipFree, which synchronises the device) as in round 2: with the blocks kept, the GPU suite showed a rare
+  // (one run in two of the whole suite, never in isolation) off-by-one filter count in the sequence fuzzer whose
+  // cause is not found yet — the device-wide synchronisation at every stream destruction hides it.
+  static const bool keep = [] {
     const char *e = getenv("ARES_TEMP_ORPHANS");
-    return !(e && e[0] == '0');
+    return e && e[0] == '1';
   }();
   if (!keep) {
     std::vector<void *> blocks;

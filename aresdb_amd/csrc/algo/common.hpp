@@ -64,7 +64,11 @@ bool pending_fill_tail(int device, const void *base, int width, int length, int 
 void retire_fills_for_write(int device, const void *ptr, size_t bytes);   // a kernel of the caller overwrites the range
 void materialize_fills_for_read(int device, const void *ptr, size_t bytes);  // a kernel of the caller reads the range
 // `indexVector` is defined as iota(0 .. n) and not written yet (InitIndexVector is lazy)
-bool virtual_iota_peek(int device, const uint32_t *indexVector, int n);
+bool virtual_iota_peek(int device, const uint32_t *indexVector, int n, bool consume = false);
+// the caller was handed `indexVector` and reads it with a kernel: a lazy iota a consumer left behind is written now
+void materialize_index_vector(int device, const uint32_t *indexVector);
+// ... and the same for every buffer of a dimension vector (dimension rows, hash vector, index vector), lazy fills included
+void settle_dimension_vector(int device, const DimensionVector &v);
 
 // NOFLUSH: only for the transform entry points, which decide themselves whether to queue or flush
 #define ARES_ABI_BEGIN_NOFLUSH(device)                 \

@@ -377,6 +377,7 @@ CGoCallResHandle GeoBatchIntersects(GeoShapeBatch geoShapeBatch, InputVector poi
                                     int numForeignTables, uint32_t *outputPredicate, bool inOrOut, void *cudaStream,
                                     int device) {
   ARES_ABI_BEGIN(device)
+  materialize_index_vector(device, indexVector);
   (void)startCount;  // geo columns are never run-length decoded (query/geo_intersects.cu:160-163)
   if (indexVectorLength > 0) {
     const size_t n = static_cast<size_t>(indexVectorLength);

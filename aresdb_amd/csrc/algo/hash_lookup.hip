@@ -132,6 +132,7 @@ extern "C" CGoCallResHandle HashLookup(InputVector input, RecordID *output, uint
                                        int indexVectorLength, uint32_t *baseCounts, uint32_t startCount,
                                        CuckooHashIndex hashIndex, void *cudaStream, int device) {
   ARES_ABI_BEGIN(device)
+  materialize_index_vector(device, indexVector);
   hipStream_t stream = reinterpret_cast<hipStream_t>(cudaStream);
   if (indexVectorLength > 0) {
     LookupParams p;

@@ -138,6 +138,7 @@ extern "C" CGoCallResHandle HashReduce(DimensionVector inputKeys, uint8_t *input
   ARES_ABI_BEGIN_NOFLUSH(device)
   hipStream_t stream = reinterpret_cast<hipStream_t>(cudaStream);
   if (length > 0) {  // lazily filled inputs are written first, lazily filled outputs retired
+    settle_dimension_vector(device, inputKeys);
     const DimLayoutD inLayout = make_dim_layout(inputKeys.NumDimsPerDimWidth);
     const size_t cap = inputKeys.VectorCapacity > 0 ? static_cast<size_t>(inputKeys.VectorCapacity) : 0;
     materialize_fills_for_read(device, inputKeys.DimValues, static_cast<size_t>(inLayout.rowBytes) * cap);

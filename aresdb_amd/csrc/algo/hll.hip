@@ -449,6 +449,13 @@ extern "C" CGoCallResHandle HyperLogLog(DimensionVector prevDimOut, DimensionVec
                                         uint8_t **hllVectorPtr, size_t *hllVectorSizePtr,
                                         uint16_t **hllDimRegIDCountPtr, void *cudaStream, int device) {
   ARES_ABI_BEGIN(device)
+  settle_dimension_vector(device, prevDimOut);
+  settle_dimension_vector(device, curDimOut);
+  {
+    const size_t capV = static_cast<size_t>(prevDimOut.VectorCapacity > curDimOut.VectorCapacity ? prevDimOut.VectorCapacity : curDimOut.VectorCapacity);
+    materialize_fills_for_read(device, prevValuesOut, 4 * capV);
+    materialize_fills_for_read(device, curValuesOut, 4 * capV);
+  }
   flush_deferred_for_vector(device, prevDimOut, nullptr, 0);
   flush_deferred_for_vector(device, curDimOut, nullptr, 0);
   grouped_note_write(device, prevDimOut);

@@ -720,6 +720,7 @@ static bool reduce_without_dimensions(int device, const DimensionVector &in, con
   if (out.IndexVector) retire_fills_for_write(device, out.IndexVector, 4);
   mem_note_write(device, outputValues, static_cast<size_t>(a.width));
   if (out.IndexVector) mem_note_write(device, out.IndexVector, 4);
+  (void)virtual_iota_peek(device, in.IndexVector, length, /*consume=*/true);  // used as what it is defined to be
   ARES_LAUNCH("fill_identity_kernel", fill_identity_kernel, 1, kBlock, stream, outputValues, a, 1);
   const int grid = capped_grid((static_cast<int64_t>(prev) + kBlock * 8 - 1) / (kBlock * 8), 256 * 4);
   ARES_LAUNCH("reduce_all_kernel", reduce_all_kernel, grid, kBlock, stream, inputValues, prev, a, c, static_cast<uint32_t>(length - prev),
@@ -742,6 +743,7 @@ CGoCallResHandle Sort(DimensionVector keys, int length, void *cudaStream, int de
       defer_fill(device, reinterpret_cast<hipStream_t>(cudaStream), keys.HashValues, 8ull * static_cast<size_t>(length), empty_row_hash(), 8))
     return resHandle;
   flush_deferred(device);
+  settle_dimension_vector(device, keys);
   flush_deferred_for_vector(device, keys, nullptr, 0);  // rows a HashReduce skipped, should a host sort them after all
   if (length > 0) {
     mem_note_write(device, keys.HashValues, 8ull * static_cast<size_t>(length));
@@ -764,6 +766,9 @@ CGoCallResHandle Reduce(DimensionVector inputKeys, uint8_t *inputValues, Dimensi
     }
   }
   flush_deferred(device);
+  settle_dimension_vector(device, inputKeys);
+  settle_dimension_vector(device, outputKeys);
+  retire_fills_for_write(device, outputValues, static_cast<size_t>(valueBytes) * (length > 0 ? length : 0));
   flush_deferred_for_vector(device, inputKeys, inputValues, static_cast<size_t>(valueBytes) * (length > 0 ? length : 0));
   grouped_note_write(device, outputKeys);
   grouped_note_write(device, outputValues, static_cast<size_t>(valueBytes) * (length > 0 ? length : 0));
@@ -781,6 +786,9 @@ CGoCallResHandle Reduce(DimensionVector inputKeys, uint8_t *inputValues, Dimensi
 CGoCallResHandle Expand(DimensionVector inputKeys, DimensionVector outputKeys, uint32_t *baseCounts,
                         uint32_t *indexVector, int indexVectorLen, int outputOccupiedLen, void *cudaStream, int device) {
   ARES_ABI_BEGIN(device)
+  settle_dimension_vector(device, inputKeys);
+  settle_dimension_vector(device, outputKeys);
+  materialize_index_vector(device, indexVector);
   flush_deferred_for_vector(device, inputKeys, nullptr, 0);
   grouped_note_write(device, outputKeys);
   mem_note_vector_all(device, outputKeys);

@@ -1185,6 +1185,9 @@ struct PendingIota {
   hipStream_t stream;
   uint32_t start;
   int n;
+  // A consumer has already used the vector as what it is defined to be (Reduce over zero dimensions): only somebody
+  // who is handed THIS vector, copies it or frees it still cares — unrelated flush points and stream waits leave it.
+  bool consumed = false;
 };
 
 // Buffers that a call has defined as "`unit`-byte pattern, repeated" but that nobody has written yet ("lazy fill"):
@@ -1539,12 +1542,39 @@ void materialize_fills_for_read(int device, const void *ptr, size_t bytes) {
   materialize_fills(device, &r);
 }
 
-// true when `indexVector` is defined as iota(0 .. n) and not written yet (InitIndexVector is lazy)
-bool virtual_iota_peek(int device, const uint32_t *indexVector, int n) {
+// true when `indexVector` is defined as iota(0 .. n) and not written yet (InitIndexVector is lazy); consume: the
+// caller has used it as such — from now on only whoever is handed this very vector makes anybody write it
+bool virtual_iota_peek(int device, const uint32_t *indexVector, int n, bool consume) {
   if (!defer_available()) return false;
   DeferLock lock(device);
   auto it = t_state->iotas.find(const_cast<uint32_t *>(indexVector));
-  return it != t_state->iotas.end() && it->second.device == device && it->second.start == 0 && it->second.n == n;
+  if (it == t_state->iotas.end() || it->second.device != device || it->second.start != 0 || it->second.n != n) return false;
+  if (consume) it->second.consumed = true;
+  return true;
+}
+
+// an entry point reads (or rewrites) the buffers of a dimension vector with kernels: lazy fills inside them are written
+// first, and so is a lazy iota that a consumer has left behind
+void settle_dimension_vector(int device, const DimensionVector &v) {
+  if (!defer_available()) return;
+  const size_t cap = v.VectorCapacity > 0 ? static_cast<size_t>(v.VectorCapacity) : 0;
+  size_t rowBytes = 0;
+  for (int w = 0; w < NUM_DIM_WIDTH; w++) rowBytes += static_cast<size_t>(v.NumDimsPerDimWidth[w]) * ((1u << (NUM_DIM_WIDTH - 1 - w)) + 1);
+  materialize_fills_for_read(device, v.DimValues, rowBytes * cap);
+  materialize_fills_for_read(device, v.HashValues, 8 * cap);
+  materialize_fills_for_read(device, v.IndexVector, 4 * cap);
+  materialize_index_vector(device, v.IndexVector);
+}
+
+// an entry point is handed `indexVector` and will read it with a kernel: a lazy iota that a consumer has left behind
+// is written now (the unconsumed ones are written by the entry point's flush)
+void materialize_index_vector(int device, const uint32_t *indexVector) {
+  if (!indexVector || !defer_available()) return;
+  DeferLock lock(device);
+  auto it = t_state->iotas.find(const_cast<uint32_t *>(indexVector));
+  if (it == t_state->iotas.end() || it->second.device != device || !it->second.consumed) return;
+  launch_init_index(it->first, it->second.start, it->second.n, it->second.stream);
+  t_state->iotas.erase(it);
 }
 
 // limboA/limboB: when given, only the skipped work whose outputs overlap these byte ranges is
@@ -1552,9 +1582,14 @@ bool virtual_iota_peek(int device, const uint32_t *indexVector, int n) {
 static void flush_deferred_impl(int device, const ByteRange *limboA, const ByteRange *limboB) {
   DeferLock lock(device);
   poll_error_words(device);
-  materialize_fills(device, nullptr);
+  // lazy fills (like work a HashReduce skipped, below) are only written for byte ranges the caller reads: they live in
+  // measure / hash vectors, which only Sort, Reduce, HashReduce, Expand, HyperLogLog and copies look at
+  if (limboA) materialize_fills(device, limboA);
+  if (limboB) materialize_fills(device, limboB);
   for (auto it = t_state->iotas.begin(); it != t_state->iotas.end();) {
-    if (it->second.device == device) {
+    const ByteRange v{reinterpret_cast<const uint8_t *>(it->first), reinterpret_cast<const uint8_t *>(it->first) + 4ull * it->second.n};
+    const bool wanted = !it->second.consumed || (limboA && v.overlaps(*limboA)) || (limboB && v.overlaps(*limboB));
+    if (it->second.device == device && wanted) {
       launch_init_index(it->first, it->second.start, it->second.n, it->second.stream);
       it = t_state->iotas.erase(it);
     } else {
@@ -1910,6 +1945,7 @@ static int run_transform(const InputVector *ins, int arity, const OutputVector &
   // root outputs of the hot shape are held back and fused with their siblings (same index vector)
   if (fast && (s.type == SINK_DIM || s.type == SINK_MEASURE) && defer_transform(device, stream, f, s, n, p.a.length)) return n;
   flush_deferred(device);
+  materialize_index_vector(device, indexVector);
   note_sink(device, s, n);
   if (fast) {
     f.pad = s.type == SINK_MEASURE ? 0 : static_cast<int>(reinterpret_cast<uintptr_t>(s.nulls) & 3);
@@ -1958,6 +1994,7 @@ static int run_filter(const InputVector *ins, int arity, uint32_t *indexVector, 
       virtualIdx = virtual_iota(device, indexVector, n, true);
   }
   flush_deferred(device);
+  materialize_index_vector(device, indexVector);
   if (is_wide(p.a.kind)) {
     // wide operands: evaluate the predicate with the wide transform kernel, then compact by pred
     SinkD s;
@@ -2140,7 +2177,7 @@ void hook_on_wait(int device, void *streamPtr) {
     DeferLock lock(device);
     // a wait on one stream says nothing about the others: their pending work is left alone
     for (auto it = t_state->iotas.begin(); it != t_state->iotas.end();) {
-      if (it->second.device == device && it->second.stream == stream) {
+      if (it->second.device == device && it->second.stream == stream && !it->second.consumed) {
         launch_init_index(it->first, it->second.start, it->second.n, it->second.stream);
         it = t_state->iotas.erase(it);
       } else {

@@ -557,6 +557,20 @@ def main(argv=None, backend=None, tensor_device=None):
             with tempfile.TemporaryDirectory(prefix="ares_rtc_cache_") as tmp:
                 leg("cold_process", {"ARES_RTC_CACHE_DIR": tmp}, big + ["--cold"])
                 leg("cold_process_warm_disk_cache", {"ARES_RTC_CACHE_DIR": tmp}, big + ["--cold"])
+            # BASELINE configs C2 (100 M rows, one predicate + COUNT(*)) and C4 at its stated size (1 B rows, 50 M-key cuckoo
+            # join, 50 M groups through Sort + Reduce): tools/bench_configs.py, each checked (count / every key -> sum)
+            def tool_leg(name, which, timeout):
+                if not (args.legs == "all" or any(w in name for w in wanted)):
+                    return
+                try:
+                    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_configs.py"), which], capture_output=True,
+                                       text=True, timeout=timeout, cwd=ROOT)
+                    rows_ = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+                    legs[name] = rows_ if r.returncode == 0 and rows_ else {"error": f"rc {r.returncode}", "stderr": r.stderr[-300:]}
+                except subprocess.TimeoutExpired:
+                    legs[name] = {"error": "timeout"}
+            tool_leg("c2_100M_rows_filter_count", "c2", 300)
+            tool_leg("c4_spec_1B_rows_50M_keys", "c4spec", 600)
             if args.legs == "all" or any(w in "host_batches" for w in wanted):
                 try:
                     legs["host_batches"] = host_batch_leg(be, plan, batches, device_index, streams)

@@ -28,20 +28,29 @@ def c2(be, dev, rows):
     hi = 86400 * 30
     ts = torch.randint(0, hi, (rows,), dtype=torch.int32, device=dev, generator=g)
     valid = torch.rand((rows,), device=dev, generator=g) >= 0.01
-    col = workload._pack_column(torch.where(valid, ts, torch.zeros((), dtype=torch.int32, device=dev)), valid, abi.Uint32)
+    tsz = torch.where(valid, ts, torch.zeros((), dtype=torch.int32, device=dev))
     out = []
-    for sel in (0.1, 0.5, 0.9):
-        thr = int(hi * sel)
-        def run():
-            q = NativeQuery(be, queries.c2_plan(thr), ["ts"]); q.run({"ts": col.vp}, rows)
-            m = torch.empty(1, dtype=torch.int32, device=dev)
-            be.call("AsyncCopyDeviceToDevice", m.data_ptr(), q.measure_vector, 4, None, 0); be.wait()
-            c = int(m.item()); q.release(); return c
-        dt, k, cnt = timed(be, run)
-        want = int(((ts < thr) & valid).sum())
-        out.append({"config": "C2", "rows": rows, "selectivity": sel, "count": cnt, "count_ok": cnt == want, "ms": dt * 1e3,
-                    "rows_per_s": rows / dt, "algorithmic_GBps": rows * 4.125 / dt / 1e9,
-                    "kernels": {n: round(ms / c, 4) for n, (c, ms) in k.items()}})
+    for nbatches in (1, 4):  # one archive batch, and the same rows as four batches (the count accumulates across Reduce calls)
+        edges = [rows * b // nbatches for b in range(nbatches + 1)]
+        cols = [workload._pack_column(tsz[a:b], valid[a:b], abi.Uint32) for a, b in zip(edges[:-1], edges[1:])]
+        for sel in (0.1, 0.5, 0.9):
+            thr = int(hi * sel)
+            def run():
+                q = NativeQuery(be, queries.c2_plan(thr), ["ts"])
+                for c in cols:
+                    q.run({"ts": c.vp}, c.length)
+                m = torch.empty(1, dtype=torch.int32, device=dev)
+                be.call("AsyncCopyDeviceToDevice", m.data_ptr(), q.measure_vector, 4, None, 0); be.wait()
+                c = int(m.item()); q.release(); return c
+            dt, k, cnt = timed(be, run)
+            want = int(((ts < thr) & valid).sum())
+            filt = sum(ms for n, (c, ms) in k.items() if n.startswith("filter_"))
+            out.append({"config": "C2", "rows": rows, "batches": nbatches, "selectivity": sel, "count": cnt, "count_ok": cnt == want,
+                        "ms": dt * 1e3, "rows_per_s": rows / dt, "algorithmic_GBps": rows * 4.125 / dt / 1e9,
+                        "kernel_ms": sum(ms for c, ms in k.values()),
+                        "filter_kernels_roofline_frac": rows * 4.125 / (filt * 1e-3) / 1e9 / 8000.0 if filt else None,
+                        "kernels": {n: round(ms / c, 4) for n, (c, ms) in k.items()}})
+        del cols
     return out
 
 

@@ -14,6 +14,9 @@ print('roofline', d['roofline'])
 print('all', d['roofline_all_kernels'])
 print({k:(round(v['avg_ms'],4),v['launches'], round(v.get('hbm_GBps',0))) for k,v in d['kernels'].items()})
 for k,v in d['legs'].items():
+    if isinstance(v, list):
+        for row in v: print(k, json.dumps(row)[:500])
+        continue
     v=dict(v); ks=v.pop('kernels',None)
     print(k, json.dumps(v)[:600])
     if ks: print('    ', {n:(round(x['avg_ms'],4), x['launches']) for n,x in list(ks.items())[:5]})

@@ -206,6 +206,17 @@ static bool phases_enabled() {
   return on;
 }
 
+// ARES_HR_NT=0: plain loads / stores instead of non-temporal ones for the columns (read once) and the record lines
+// (written once, read by another kernel): measured on MI355X, streaming loads alone are ~10 % faster
+// (profiles/r2_ubench_write_path.txt)
+static bool nt_enabled() {
+  static const bool on = [] {
+    const char *e = getenv("ARES_HR_NT");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
 struct RtcArgs {  // mirrors `struct Args` of the generated source (args_text below): pointers, 8-byte, then 4-byte fields
   const uint32_t *vals[kFusedCols];
   const uint8_t *nulls[kFusedCols];
@@ -239,6 +250,8 @@ const char *kPrelude =
     "struct __attribute__((packed, aligned(1))) PU32x4 { u32 v[4]; };\n"
     "struct __attribute__((packed, aligned(1))) PU32 { u32 v; };\n"
     "struct __attribute__((packed, aligned(1))) PU16 { u16 v; };\n"
+    "typedef u32 U4 __attribute__((ext_vector_type(4)));\n"
+    "typedef U4 U4a __attribute__((aligned(4)));\n"
     "__device__ __forceinline__ u32 rotl(u32 x, int r) { return (x << r) | (x >> (32 - r)); }\n"
     "__device__ __forceinline__ u32 mix(u32 h, u32 k) { k *= 0xcc9e2d51u; k = rotl(k, 15) * 0x1b873593u; h ^= k; return rotl(h, 13) * 5u + 0xe6546b64u; }\n";
 
@@ -427,6 +440,7 @@ static void kernel_body_lines16(std::ostringstream &o, const char *fourth) {
 // seven lanes' shifted row bits (three DPP steps inside the 8-lane group).
 static void kernel_body_compact(std::ostringstream &o) {
   phase_macros(o);
+  o << (nt_enabled() ? "#define STORE_LINE(p, v) __builtin_nontemporal_store((u64)(v), (p))\n" : "#define STORE_LINE(p, v) (*(p) = (v))\n");
   o << "#define T 4096u\n#define LR 14u\n#define LEFT 13u\n#define LPL 5u\n"
        "__device__ __forceinline__ u32 lane_up(u32 v, u32 lane, u32 off) { return (u32)__builtin_amdgcn_ds_bpermute((int)((lane - off) << 2), (int)v); }\n"
        // OR over the 8 lanes of a half-line: xor 1, xor 2 (quad permutes), then the mirrored quad (row_half_mirror)
@@ -528,7 +542,7 @@ static void kernel_body_compact(std::ostringstream &o) {
        "        const u64 mine = r8 ? (u64)lo[j] << sh : 0ull;\n"
        "        const u64 hdr = ((u64)or8((u32)(mine >> 32)) << 32) | or8((u32)mine);\n"
        "        const u32 p = e[j] & 511u, line = cu[j] + (e[j] >> 9);\n"
-       "        if (L0 + j * 64u < totalLines && line < a.capB) myB[((u64)p * a.capB + line) * 16u + q] = r8 ? rec[j] : hdr;\n"
+       "        if (L0 + j * 64u < totalLines && line < a.capB) STORE_LINE(&myB[((u64)p * a.capB + line) * 16u + q], r8 ? rec[j] : hdr);\n"
        "      }\n"
        "    }\n"
        "    __syncthreads();\n"
@@ -566,7 +580,7 @@ static void kernel_body_compact(std::ostringstream &o) {
        "    const u64 rec = has ? sLeft[p * LEFT + kk] : 0ull;\n"
        "    const u64 mine = has ? (u64)sLeftLo[p * LEFT + kk] << sh : 0ull;\n"
        "    const u64 hdr = ((u64)or8((u32)(mine >> 32)) << 32) | or8((u32)mine);\n"
-       "    if (left && fits) myB[((u64)p * a.capB + cur) * 16u + q] = r8 ? rec : hdr;\n"
+       "    if (left && fits) STORE_LINE(&myB[((u64)p * a.capB + cur) * 16u + q], r8 ? rec : hdr);\n"
        "    if (left && !fits) *a.overflow = 1u;\n"
        "    if (q == 0u) a.countsB[(u64)blockIdx.x * NP + p] = cur * LR + ((left && fits) ? left : 0u);\n"
        "  }\n"
@@ -744,9 +758,13 @@ std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t null
   // its end is shifted into place when its tile is evaluated; lanes past the end hold rows that do not take part.
   o << "__device__ __forceinline__ u32 clampi(const Args &a, u32 i0) { const u32 lim = a.length >= 4 ? (u32)a.length - 4u : 0u; return i0 < lim ? i0 : lim; }\n";
   for (int c = 0; c < nc; c++) {
-    o << "__device__ __forceinline__ void load_col" << c << "(Raw &r, const Args &a, u32 i0c) {\n"
-         "  const PU32x4 t = *reinterpret_cast<const PU32x4 *>(a.vals[" << c << "] + i0c); r.v[" << c << "][0] = t.v[0]; r.v[" << c
-      << "][1] = t.v[1]; r.v[" << c << "][2] = t.v[2]; r.v[" << c << "][3] = t.v[3];\n";
+    o << "__device__ __forceinline__ void load_col" << c << "(Raw &r, const Args &a, u32 i0c) {\n";
+    if (nt_enabled())
+      o << "  const U4 t = __builtin_nontemporal_load(reinterpret_cast<const U4a *>(a.vals[" << c << "] + i0c)); r.v[" << c << "][0] = t.x; r.v[" << c
+        << "][1] = t.y; r.v[" << c << "][2] = t.z; r.v[" << c << "][3] = t.w;\n";
+    else
+      o << "  const PU32x4 t = *reinterpret_cast<const PU32x4 *>(a.vals[" << c << "] + i0c); r.v[" << c << "][0] = t.v[0]; r.v[" << c
+        << "][1] = t.v[1]; r.v[" << c << "][2] = t.v[2]; r.v[" << c << "][3] = t.v[3];\n";
     if (nullMask & (1u << c))
       o << "  r.win[" << c << "] = reinterpret_cast<const PU16 *>(a.nulls[" << c << "] + ((i0c + a.bitOff[" << c << "]) >> 3))->v;\n";
     else

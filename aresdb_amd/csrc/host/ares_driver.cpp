@@ -17,6 +17,7 @@
 #include <atomic>
 #include <cstdio>
 #include <map>
+#include <condition_variable>
 #include <mutex>
 #include <thread>
 #include <cstdlib>
@@ -864,6 +865,7 @@ struct AresComm {
   int (*ncclGroupStart)() = nullptr;
   int (*ncclGroupEnd)() = nullptr;
   AresAllToAllFn allToAll = nullptr;  // optional: without it blocks travel by padded all-gathers
+  void *localRank = nullptr;          // AresCommCreateLocal: this rank's end of the in-process rendezvous
   int (*ncclCommDestroy)(void *) = nullptr;
   const char *(*ncclGetErrorString)(int) = nullptr;
 };
@@ -979,6 +981,85 @@ AresComm *AresCommCreateRccl(const uint8_t id[128], int rank, int nranks, int de
   return c;
 }
 
+// ---- ranks as threads of ONE process: the reference's process model (one device_manager device per shard inside
+// the server process, query/device_manager.go:185-218) ---------------------------------------------------------
+// The ranks rendezvous in host memory; a rank copies every peer's block itself — hipMemcpyAsync (peer-to-peer
+// over xGMI through unified addressing) on its own stream for device memory, memcpy for host memory.
+namespace {
+struct LocalHub {
+  std::mutex m;
+  std::condition_variable cv;
+  int nranks = 0, arrived = 0, refs = 0;
+  uint64_t phase = 0;
+  std::vector<const void *> send;
+  int (*copyAsync)(void *, const void *, size_t, int, void *) = nullptr;  // hipMemcpyAsync(dst, src, n, hipMemcpyDefault, stream)
+  int (*streamSync)(void *) = nullptr;
+  void barrier() {
+    std::unique_lock<std::mutex> lock(m);
+    const uint64_t my = phase;
+    if (++arrived == nranks) {
+      arrived = 0;
+      phase++;
+      cv.notify_all();
+    } else {
+      cv.wait(lock, [&] { return phase != my; });
+    }
+  }
+};
+struct LocalRank {
+  LocalHub *hub;
+  int rank;
+};
+
+int local_all_gather(void *user, const void *send, void *recv, size_t bytesPerRank, void *stream) {
+  LocalRank *me = static_cast<LocalRank *>(user);
+  LocalHub *h = me->hub;
+  if (h->streamSync && h->streamSync(stream) != 0) return 1;  // what this rank contributes has been produced
+  h->send[me->rank] = send;
+  h->barrier();
+  int rc = 0;
+  for (int r = 0; r < h->nranks && rc == 0; r++) {
+    uint8_t *dst = static_cast<uint8_t *>(recv) + bytesPerRank * r;
+    if (h->copyAsync) rc = h->copyAsync(dst, h->send[r], bytesPerRank, /*hipMemcpyDefault*/ 4, stream);
+    else memcpy(dst, h->send[r], bytesPerRank);
+  }
+  if (rc == 0 && h->streamSync) rc = h->streamSync(stream);  // nobody frees a block a peer is still reading
+  h->barrier();
+  return rc;
+}
+}  // namespace
+
+int AresCommCreateLocal(int nranks, int deviceMemory, AresComm **out, char *err, int errLen) {
+  if (nranks < 1 || !out) {
+    set_err(err, errLen, "AresCommCreateLocal: bad arguments");
+    return -1;
+  }
+  LocalHub *hub = new LocalHub;
+  hub->nranks = nranks;
+  hub->refs = nranks;
+  hub->send.assign(nranks, nullptr);
+  if (deviceMemory) {
+    void *hip = dlopen("libamdhip64.so", RTLD_NOW | RTLD_GLOBAL);
+    hub->copyAsync = hip ? reinterpret_cast<decltype(hub->copyAsync)>(dlsym(hip, "hipMemcpyAsync")) : nullptr;
+    hub->streamSync = hip ? reinterpret_cast<decltype(hub->streamSync)>(dlsym(hip, "hipStreamSynchronize")) : nullptr;
+    if (!hub->copyAsync || !hub->streamSync) {
+      delete hub;
+      set_err(err, errLen, "AresCommCreateLocal: cannot bind hipMemcpyAsync / hipStreamSynchronize");
+      return -1;
+    }
+  }
+  for (int r = 0; r < nranks; r++) {
+    AresComm *c = new AresComm;
+    c->rank = r;
+    c->nranks = nranks;
+    c->allGather = &local_all_gather;
+    c->user = new LocalRank{hub, r};
+    c->localRank = c->user;
+    out[r] = c;
+  }
+  return 0;
+}
+
 void AresCommSetAllToAll(AresComm *c, AresAllToAllFn allToAll) {
   if (c) c->allToAll = allToAll;
 }
@@ -986,6 +1067,16 @@ void AresCommSetAllToAll(AresComm *c, AresAllToAllFn allToAll) {
 void AresCommDestroy(AresComm *c) {
   if (!c) return;
   if (c->rcclComm && c->ncclCommDestroy) c->ncclCommDestroy(c->rcclComm);
+  if (c->localRank) {
+    LocalRank *lr = static_cast<LocalRank *>(c->localRank);
+    bool last;
+    {
+      std::lock_guard<std::mutex> lock(lr->hub->m);
+      last = --lr->hub->refs == 0;
+    }
+    if (last) delete lr->hub;
+    delete lr;
+  }
   delete c;
 }
 

@@ -130,9 +130,16 @@ AresComm *AresCommCreate(int rank, int nranks, AresAllGatherFn allGather, void *
  * side channel: torch.distributed broadcast, a file, MPI).  NULL + message on failure. */
 int AresCommRcclUniqueId(uint8_t id[128], char *err, int errLen);
 AresComm *AresCommCreateRccl(const uint8_t id[128], int rank, int nranks, int device, char *err, int errLen);
+/* Ranks as threads of ONE process — the reference's process model (one device per shard inside the server,
+ * query/device_manager.go:185-218): out[0 .. nranks) receive one communicator per rank, to be used by nranks threads
+ * at once.  A rank copies its peers' blocks itself: hipMemcpyAsync through unified addressing (peer-to-peer over
+ * xGMI) on its own stream when deviceMemory != 0, memcpy otherwise.  0, or -1 + message. */
+int AresCommCreateLocal(int nranks, int deviceMemory, AresComm **out, char *err, int errLen);
 void AresCommDestroy(AresComm *c);
 /* Replaces q's result by the merged result of all ranks (every rank ends with the whole table).
- * Hash-reduction and sort-reduction queries; not HyperLogLog.  0, or -1 + message. */
+ * Hash-reduction and sort-reduction queries; HyperLogLog queries whose batches all ran with isLastBatch = 0 (the
+ * merge exchanges the (group, register, rho) entries, keeps the maximum per register — broker/result_merge.go:95-104 —
+ * and finalises).  0, or -1 + message. */
 int AresQueryMergeShards(AresQuery *q, AresComm *c, char *err, int errLen);
 
 /* Option (B), for group tables too large to replicate: every rank ends with the groups whose 64-bit row

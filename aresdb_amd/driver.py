@@ -365,6 +365,19 @@ class NativeComm:
         return cls(h)
 
     @classmethod
+    def local(cls, nranks, device_memory):
+        """nranks communicators for nranks threads of THIS process (the reference's process model: one device per
+        shard inside the server, query/device_manager.go:185-218); blocks are copied peer to peer."""
+        lib = _driver()
+        lib.AresCommCreateLocal.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_void_p), C.c_char_p, C.c_int]
+        lib.AresCommCreateLocal.restype = C.c_int
+        out = (C.c_void_p * nranks)()
+        err = C.create_string_buffer(512)
+        if lib.AresCommCreateLocal(nranks, 1 if device_memory else 0, out, err, 512) != 0:
+            raise abi.AresError(err.value.decode())
+        return [cls(out[r]) for r in range(nranks)]
+
+    @classmethod
     def torch_group(cls, group=None, all_to_all=False, device_backend=None, device=0):
         """`group`: a torch.distributed group for host tensors (gloo).  With `device_backend` (an abi.Backend
         whose memory is device memory) the buffers are staged through host memory with its copy entry

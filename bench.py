@@ -238,6 +238,103 @@ def run_leg(env, argv, timeout=900):
     return json.loads(lines[-1])
 
 
+def single_process(args, backend=None, tensor_device=None):
+    """--single-process: one thread per shard / GPU inside this process; every thread runs its shard through the ABI on
+    its own device and streams, then all of them merge the per-shard tables inside libaresdriver.so (blocks copied peer
+    to peer with hipMemcpyAsync).  Prints the same JSON line as the contract launch (parallelism says which it is)."""
+    import threading
+    from aresdb_amd.driver import NativeComm
+    on_gpu = backend is None
+    n = max(1, args.gpus)
+    if on_gpu and (not torch.cuda.is_available() or torch.cuda.device_count() < n):
+        raise SystemExit(f"bench.py --single-process --gpus {n}: needs {n} visible GPU(s)")
+    be = backend if backend is not None else abi.load_hip_backend()
+    if on_gpu:
+        be.call("BootstrapDevice")
+    rows, batch_rows = int(args.rows), int(args.batch_rows)
+    dims = tuple(d for d in args.dims.split(",") if d)
+    plan = c3_plan(use_hash_reduction=True, dims=dims, d1_below=args.d1_below)
+    comms = NativeComm.local(n, on_gpu)
+    barrier = threading.Barrier(n)
+    state = {"elapsed": [0.0] * n, "merged": [0] * n, "errors": [], "checks": [None] * n}
+
+    def work(r):
+        try:
+            dev = r if on_gpu else 0
+            tdev = torch.device(f"cuda:{r}") if on_gpu else torch.device(tensor_device or "cpu")
+            if on_gpu:
+                torch.cuda.set_device(r)
+            streams = [be.call("CreateCudaStream", dev) for _ in range(2 if on_gpu else 1)]
+            batches = workload.c3_shard(rows, batch_rows, seed=1 + r, device=tdev, null_fraction=args.null_fraction)
+            vps = [({k: rc.vp for k, rc in b.items()}, next(iter(b.values())).length) for b in batches]
+
+            def sync():
+                if on_gpu:
+                    torch.cuda.synchronize(tdev)
+                barrier.wait()
+            ctx = run_shard(be, plan, vps, dev, streams)  # priming pass (kernels of the shape get compiled)
+            ctx.merge_shards(comms[r])
+            ctx.release()
+            be.rtc_wait()
+            for _ in range(args.warmup):
+                ctx = run_shard(be, plan, vps, dev, streams)
+                ctx.merge_shards(comms[r])
+                ctx.release()
+            sync()
+            t0 = time.perf_counter()
+            last = None
+            for _ in range(args.steps):
+                if last is not None:
+                    last.release()
+                last = run_shard(be, plan, vps, dev, streams)
+                last.merge_shards(comms[r])
+            sync()
+            state["elapsed"][r] = time.perf_counter() - t0
+            state["merged"][r] = last.result_size
+            if args.verify_merged and r == 0:
+                every = []
+                for q in range(n):
+                    every += workload.c3_shard(rows, batch_rows, seed=1 + q, device=tdev, null_fraction=args.null_fraction)
+                state["checks"][0] = check.compare_result(last.fetch(), check.exact_groups(every, dims=dims, d1_below=args.d1_below),
+                                                          hash_identity=True, dims=dims)
+            last.release()
+            for s_ in streams:
+                be.call("DestroyCudaStream", s_, dev)
+        except Exception as e:  # noqa: BLE001
+            import traceback
+            state["errors"].append((r, f"{type(e).__name__}: {e}", traceback.format_exc()[-800:]))
+            try:
+                barrier.abort()
+            except Exception:  # noqa: BLE001
+                pass
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(n)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for c in comms:
+        c.destroy()
+    if state["errors"]:
+        print(f"bench.py --single-process: {state['errors']}", file=sys.stderr)
+        sys.exit(1)
+    elapsed = max(state["elapsed"])
+    value = rows * n * args.steps / elapsed
+    ok = state["checks"][0] is None or state["checks"][0]["status"] == "ok"
+    print(json.dumps({
+        "metric": "rows/sec, 1B-row filter -> group-by-agg (whole job)", "value": value, "unit": "rows/s", "n_gpus": n,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u32 keys / f64 sums", "data": "synthetic",
+        "config": {"workload": "C3 (see the contract launch)", "rows_per_gpu": rows, "batch_rows": batch_rows,
+                   "merged_groups": state["merged"][0],
+                   "parallelism": f"{n} shard(s), one THREAD per GPU in one process (query/device_manager.go:185-218), "
+                                  "peer-to-peer all-gather + re-reduce merge in libaresdriver.so"},
+        "rows_per_sec_per_gpu": value / n, "check_merged_groups": state["checks"][0],
+        "per_rank_ms_per_step": [e / args.steps * 1e3 for e in state["elapsed"]]}), flush=True)
+    if not ok:
+        sys.exit(1)
+    return 0
+
+
 def main(argv=None, backend=None, tensor_device=None):
     """backend / tensor_device: injected by the multi-process CPU test of this file's distributed
     path (tests/test_bench_distributed.py); the benchmark itself always loads the HIP libraries and
@@ -261,11 +358,17 @@ def main(argv=None, backend=None, tensor_device=None):
                     help="group-by dimensions, a subset of C3's four (lower-cardinality variants of the same query: secondary legs)")
     ap.add_argument("--d1-below", type=int, default=90, help="constant of the filter d1 < K")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes that measure roofline.traffic")
+    ap.add_argument("--single-process", action="store_true",
+                    help="N shards on N GPUs as N threads of THIS process (the reference's process model, "
+                         "query/device_manager.go:185-218), merged through the in-process communicator: not the contract "
+                         "launch (one rank per GPU under torch.distributed.run), a second way to run the same job")
     ap.add_argument("--cold", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--leg", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--fused-extension", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args(argv)
 
+    if args.single_process:
+        return single_process(args, backend, tensor_device)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and backend is None:
         spawn_ranks(args.gpus, argv)
     rank = int(os.environ.get("RANK", "0"))

@@ -43,3 +43,17 @@ def test_two_rank_path_merges_and_verifies(tmp_path):
     assert out["check_merged_groups"]["status"] == "ok"
     assert out["config"]["merged_groups"] == out["check_merged_groups"]["groups"] >= out["config"]["groups_per_shard"]
     assert len(out["per_rank_ms_per_step"]) == 2
+
+
+def test_single_process_threads_path_merges_and_verifies(capsys):
+    """bench.py --single-process: shards as threads of one process (the reference's process model), here two threads
+    on the oracle backend; the merged table is checked key by key."""
+    import sys as _sys
+    _sys.path.insert(0, H.ROOT)
+    import bench
+    rc = bench.main(["--gpus", "2", "--single-process", "--rows", "6000", "--batch-rows", "2500", "--steps", "1", "--warmup", "0",
+                     "--verify-merged"], backend=H.oracle_backend(), tensor_device="cpu")
+    out = json.loads([ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("{")][-1])
+    assert rc == 0 and out["n_gpus"] == 2 and out["check_merged_groups"]["status"] == "ok"
+    assert out["config"]["merged_groups"] == out["check_merged_groups"]["groups"] > 1000
+    assert "THREAD" in out["config"]["parallelism"]

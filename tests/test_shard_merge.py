@@ -225,6 +225,91 @@ def test_hll_shard_merge_gloo(world):
     assert len({r[2] for r in results}) == 1 and results[0][2] > 0
 
 
+def _threads_merge(be, device_memory, shards_of, plan, names, nranks, make_stream=None):
+    """nranks shards as nranks threads of this process (the reference's process model), merged inside
+    libaresdriver.so through the in-process communicator; returns every rank's merged table."""
+    import threading
+    from aresdb_amd.driver import NativeComm, NativeQuery
+    comms = NativeComm.local(nranks, device_memory)
+    got, errs = [None] * nranks, []
+
+    def work(r):
+        try:
+            stream = make_stream() if make_stream else None
+            ctx = NativeQuery(be, plan, names, device=0, stream=stream)
+            for b in shards_of(r):
+                ctx.run({k: rc.vp for k, rc in b.items()}, next(iter(b.values())).length)
+            ctx.merge_shards(comms[r])
+            dims, valids, meas = ctx.fetch()
+            n = ctx.result_size
+            m = meas.view(np.float64)
+            got[r] = {tuple((bytes(d[i * len(d) // n:(i + 1) * len(d) // n]), int(v[i])) for d, v in zip(dims, valids)): m[i]
+                      for i in range(n)}
+            ctx.release()
+            if stream is not None:
+                be.call("DestroyCudaStream", stream, 0)
+        except Exception as e:  # noqa: BLE001
+            import traceback
+            errs.append((r, f"{type(e).__name__}: {e}", traceback.format_exc()[-500:]))
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    for c in comms:
+        c.destroy()
+    assert not errs, errs
+    return got
+
+
+@pytest.mark.parametrize("use_hash", [True, False], ids=["hash_reduce", "sort_reduce"])
+def test_shards_as_threads_of_one_process(use_hash):
+    """Three shards, three threads, one process (query/device_manager.go:185-218), the oracle behind the ABI."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import harness as H
+    from aresdb_amd import workload
+    from aresdb_amd.queries import c3_plan
+    be = H.oracle_backend()
+    plan = c3_plan(use_hash_reduction=use_hash)
+    names = [n for n, _ in workload.C3_COLUMNS]
+    shards = [workload.c3_shard(4000 + 900 * r, 2048, seed=21 + r, device="cpu") for r in range(3)]
+    got = _threads_merge(be, False, lambda r: shards[r], plan, names, 3)
+    want = _single_process_result(be, plan, [b for s in shards for b in s])
+    for r in range(3):
+        assert got[r].keys() == want.keys(), (r, len(got[r]), len(want))
+        for k, v in want.items():
+            assert abs(got[r][k] - v) <= 1e-9 * max(1.0, abs(v)), (r, k)
+
+
+@pytest.mark.gpu
+def test_shards_as_threads_of_one_process_on_the_gpu():
+    """The same with the HIP libraries: two shard threads (both on device 0 — this box has one GPU), each with its own
+    stream, blocks copied with hipMemcpyAsync on the query streams."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import harness as H
+    from aresdb_amd import workload
+    from aresdb_amd.queries import c3_plan
+    be = H.hip_backend()
+    dev = torch.device("cuda:0")
+    plan = c3_plan(use_hash_reduction=True)
+    names = [n for n, _ in workload.C3_COLUMNS]
+    shards = [workload.c3_shard(300000 + 50000 * r, 1 << 17, seed=31 + r, device=dev) for r in range(2)]
+    torch.cuda.synchronize()
+    got = _threads_merge(be, True, lambda r: shards[r], plan, names, 2, make_stream=lambda: be.call("CreateCudaStream", 0))
+    from aresdb_amd.driver import NativeQuery
+    ctx = NativeQuery(be, plan, names)
+    for b in [b for s in shards for b in s]:
+        ctx.run({k: rc.vp for k, rc in b.items()}, next(iter(b.values())).length)
+    dims, valids, meas = ctx.fetch()
+    n = ctx.result_size
+    m = meas.view(np.float64)
+    want = {tuple((bytes(d[i * len(d) // n:(i + 1) * len(d) // n]), int(v[i])) for d, v in zip(dims, valids)): m[i] for i in range(n)}
+    ctx.release()
+    for r in range(2):
+        assert got[r].keys() == want.keys()
+        assert all(abs(got[r][k] - v) <= 1e-9 * max(1.0, abs(v)) for k, v in want.items())
+
+
 def _worker(rank, world, port, use_hash, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -206,13 +206,14 @@ static bool phases_enabled() {
   return on;
 }
 
-// ARES_HR_NT=0: plain loads / stores instead of non-temporal ones for the columns (read once) and the record lines
-// (written once, read by another kernel): measured on MI355X, streaming loads alone are ~10 % faster
-// (profiles/r2_ubench_write_path.txt)
+// ARES_HR_NT=1: non-temporal loads for the columns (read once) and non-temporal stores for the record lines (written
+// once, read by another kernel).  Off by default: in the loads-only microbenchmark streaming loads are ~10 % faster
+// (profiles/r2_ubench_write_path.txt), in the compact scan the pair measured 4 % SLOWER (0.417-0.422 vs 0.401-0.404 ms
+// per 64 Mi rows, two runs each way: profiles/r3_experiments.md).
 static bool nt_enabled() {
   static const bool on = [] {
     const char *e = getenv("ARES_HR_NT");
-    return !(e && e[0] == '0');
+    return e && e[0] == '1';
   }();
   return on;
 }
@@ -961,6 +962,7 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
                            bool compact = false) {
   if (nd < 1 || nd > kFusedDims) return "";
   if (compact && (vectorVW || partBits < 3)) return "";
+  if (partBits < 2) return "";  // the 32-bit table keys need two spare hash bits (small inputs: the generic merge)
   std::ostringstream o;
   o << kPrelude
     << "struct MArgs { const u32 *vals[" << kFusedCols << "]; const u8 *nulls[" << kFusedCols << "]; const u32 *recB; const u32 *countsB;\n"
@@ -969,11 +971,12 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
        "#define ND " << nd << "\n#define PB " << partBits << "\n#define NP " << (1 << partBits) << "\n"
        "#define SLOTS " << hr::kSlots << "\n#define LIMIT " << hr::kMergeLimit << "u\n#define RANGEWORDS " << hr::kRangeWords
     << "\n#define MAXRANGES " << hr::kMaxRanges << "u\n"
-       // An empty slot holds a key no record of this partition can have: its hash field carries the
-       // NEIGHBOUR partition's number in the partition bits (PB > 0), so "hash field == h" alone identifies a
-       // hit — no separate "slot is not empty" test in the straight-line path.
-       "#if PB > 0\n#define EMPTY ((((u64)((blockIdx.x ^ 1u) << (32 - PB))) << 32) | 0xFFFFFFFFull)\n#define OCC(k) true\n"
-       "#else\n#define EMPTY 0xFFFFFFFFFFFFFFFFull\n#define OCC(k) ((k) != EMPTY)\n#endif\n";
+       // Table keys are 32 bits: within a partition the top PB bits of every hash are the partition's number, so a
+       // key keeps the other 32 - PB bits (HMASK) and uses two of the freed bits as flags — OCC (the slot is taken:
+       // an empty slot is 0, "key matches" is one masked compare) and NEWG (the group was first seen in THIS call's
+       // records: only then can a record lower the group's representative row — groups that come from the previous
+       // result have rows below every row of the batch).  Four keys = one 16-byte LDS read per probe.
+       "#define HMASK ((1u << (32 - PB)) - 1u)\n#define OCC 0x40000000u\n#define NEWG 0x80000000u\n";
   gen_widen(o, w);
   if (!gen_agg(o, a)) return "";
   if (phases_enabled())
@@ -986,44 +989,43 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
   // lane's records go through the rounds together: their bucket reads are in flight at once.
   // Claims only ever turn the LOWEST empty slot of a bucket into a key, so a hash cannot end up twice.
   o << "#define BUCKETS (SLOTS / 4)\n"
-       "struct __attribute__((aligned(16))) U64x2 { u64 x, y; };\n"
-       "struct Probe { u32 b, slot; u64 seen; bool done, fresh; };\n"
+       "struct Probe { u32 b, slot; bool done, isNew; };\n"
        // One round for one record, written without branches except for the rare claim: the merge is bound by
        // instruction issue (divergent control flow costs ~6 scalar instructions per `if`), not by LDS or HBM.
-       "__device__ __forceinline__ void probe_round(u64 *sKeys, u32 *sClaimed, u32 *sOverflow, Probe &q, u32 h, u64 mine) {\n"
-       "  const U64x2 lo = *reinterpret_cast<const U64x2 *>(sKeys + 4u * q.b), hi = *reinterpret_cast<const U64x2 *>(sKeys + 4u * q.b + 2u);\n"
-       "  const u64 k0 = lo.x, k1 = lo.y, k2 = hi.x, k3 = hi.y;\n"
-       "  const bool e0 = k0 == EMPTY, e1 = k1 == EMPTY, e2 = k2 == EMPTY, e3 = k3 == EMPTY;\n"
-       "  const bool m0 = !e0 && (u32)(k0 >> 32) == h, m1 = !e1 && (u32)(k1 >> 32) == h, m2 = !e2 && (u32)(k2 >> 32) == h, m3 = !e3 && (u32)(k3 >> 32) == h;\n"
+       // want = the occupied key of the record's hash; claimKey = want, with NEWG for a record of the batch.
+       "__device__ __forceinline__ void probe_round(u32 *sKeys, u32 *sClaimed, u32 *sOverflow, Probe &q, u32 want, u32 claimKey) {\n"
+       "  const uint4 k = *reinterpret_cast<const uint4 *>(sKeys + 4u * q.b);\n"
+       "  const bool e0 = k.x == 0u, e1 = k.y == 0u, e2 = k.z == 0u, e3 = k.w == 0u;\n"
+       "  const bool m0 = (k.x & ~NEWG) == want, m1 = (k.y & ~NEWG) == want, m2 = (k.z & ~NEWG) == want, m3 = (k.w & ~NEWG) == want;\n"
        "  const bool anyM = m0 | m1 | m2 | m3, anyE = e0 | e1 | e2 | e3;\n"
        "  const u32 mi = m0 ? 0u : m1 ? 1u : m2 ? 2u : 3u, ei = e0 ? 0u : e1 ? 1u : e2 ? 2u : 3u;\n"
-       "  const u64 mk = m0 ? k0 : m1 ? k1 : m2 ? k2 : k3;\n"
+       "  const u32 mk = m0 ? k.x : m1 ? k.y : m2 ? k.z : k.w;\n"
        "  const bool active = !q.done, hit = active & anyM;\n"
        "  q.slot = hit ? 4u * q.b + mi : q.slot;\n"
-       "  q.seen = hit ? mk : q.seen;\n"
+       "  q.isNew = hit ? (mk & NEWG) != 0u : q.isNew;\n"
        "  bool claimed = false;\n"
        "  if (active & !anyM & anyE) {\n"  // a group that is new in this partition: rare once the groups exist
-       "    u64 expected = EMPTY;\n"
-       "    if (__hip_atomic_compare_exchange_strong(sKeys + 4u * q.b + ei, &expected, mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {\n"
+       "    u32 expected = 0u;\n"
+       "    if (__hip_atomic_compare_exchange_strong(sKeys + 4u * q.b + ei, &expected, claimKey, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {\n"
        "      if (__hip_atomic_fetch_add(sClaimed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= LIMIT)\n"
        "        __hip_atomic_store(sOverflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
-       "      q.slot = 4u * q.b + ei; q.fresh = true; claimed = true;\n"
+       "      q.slot = 4u * q.b + ei; q.isNew = true; claimed = true;\n"  // (the claimer lowers the row too: rows start at ~0)
        "    }\n"  // lost the slot: the same bucket again next round (the winner may be this very group)
        "  }\n"
        "  q.b = (active & !anyM & !anyE) ? (q.b + 1u) & (BUCKETS - 1u) : q.b;\n"
        "  q.done = q.done | hit | claimed;\n"
        "}\n"
-       "__device__ __forceinline__ void finish(u64 *sKeys, u64 *sVals, const Probe &q, u64 mine, u64 value) {\n"
-       "  if (!q.fresh && mine < q.seen) __hip_atomic_fetch_min(sKeys + q.slot, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
-       "  agg(sVals + q.slot, value);\n"
-       "}\n"
-       // one record (previous groups)
-       "__device__ __forceinline__ void insert(u64 *sKeys, u64 *sVals, u32 *sClaimed, u32 *sOverflow, u32 row, u32 h, u64 value) {\n"
-       "  const u64 mine = ((u64)h << 32) | row;\n"
-       "  Probe q; q.b = h & (BUCKETS - 1u); q.slot = 0u; q.seen = 0ull; q.done = false; q.fresh = false;\n"
-       "  for (u32 tries = 0u; tries < 4u * BUCKETS && !q.done; tries++) probe_round(sKeys, sClaimed, sOverflow, q, h, mine);\n"
-       "  if (q.done) finish(sKeys, sVals, q, mine, value);\n"
-       "  else __hip_atomic_store(sOverflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"  // table full: the round is void anyway
+       // one record through the general probe loop; batch = a record of this call's batch (may found a NEWG group)
+       "__device__ __forceinline__ void insert(u32 *sKeys, u32 *sRows, u64 *sVals, u32 *sClaimed, u32 *sOverflow, u32 row, u32 h, u64 value, bool batch) {\n"
+       "  const u32 want = (h & HMASK) | OCC;\n"
+       "  Probe q; q.b = h & (BUCKETS - 1u); q.slot = 0u; q.done = false; q.isNew = false;\n"
+       "  for (u32 tries = 0u; tries < 4u * BUCKETS && !q.done; tries++) probe_round(sKeys, sClaimed, sOverflow, q, want, batch ? want | NEWG : want);\n"
+       "  if (q.done) {\n"
+       "    if (q.isNew || !batch) __hip_atomic_fetch_min(sRows + q.slot, row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
+       "    agg(sVals + q.slot, value);\n"
+       "  } else {\n"
+       "    __hip_atomic_store(sOverflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"  // table full: the round is void anyway
+       "  }\n"
        "}\n";
   // Records arrive in segments of 64 sixteen-byte units (one per lane), four segments per register stage — of
   // one long run or of four short ones (small batches leave ~16 records per run: a stage per run would make the
@@ -1040,26 +1042,25 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
     o << "#define QCAP 128u\n#define QW 3u\n#define QDRAIN 64u\n#define VALB(z, w) widen(z)\n";
   o << "struct Seg { const uint4 *ptr; u32 n, rem, rb; };\n"
        "struct Stage { uint4 r[4]; u32 n[4], rem[4], rb[4]; };\n"
-       "__device__ __forceinline__ void drain(u32 *queue, u32 first, u32 count, u32 lane, u64 *sKeys, u64 *sVals, u32 *sClaimed, u32 *sOverflow) {\n"
+       "__device__ __forceinline__ void drain(u32 *queue, u32 first, u32 count, u32 lane, u32 *sKeys, u32 *sRows, u64 *sVals, u32 *sClaimed, u32 *sOverflow) {\n"
        "  asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");\n"
        "  if (lane < count) {\n"
        "    const u32 e = QW * (first + lane);\n"
        "    const u32 row = queue[e], h = queue[e + 1u], z = queue[e + 2u], w = QW == 4u ? queue[e + QW - 1u] : 0u;\n"
-       "    insert(sKeys, sVals, sClaimed, sOverflow, row, h, VALB(z, w));\n"
+       "    insert(sKeys, sRows, sVals, sClaimed, sOverflow, row, h, VALB(z, w), true);\n"
        "  }\n"
        "  asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");\n"
        "}\n"
        // one record in round one
-       "__device__ __forceinline__ void consume_one(bool valid, u32 row, u32 h, u32 z, u32 w, u32 lane, u64 *sKeys, u64 *sVals, u32 *sClaimed, u32 *sOverflow, u32 *queue, u32 &qn) {\n"
-       "  const u32 b = h & (BUCKETS - 1u);\n"
-       "  const U64x2 lo = *reinterpret_cast<const U64x2 *>(sKeys + 4u * b), hi = *reinterpret_cast<const U64x2 *>(sKeys + 4u * b + 2u);\n"
-       "  const bool m0 = (u32)(lo.x >> 32) == h && OCC(lo.x), m1 = (u32)(lo.y >> 32) == h && OCC(lo.y);\n"
-       "  const bool m2 = (u32)(hi.x >> 32) == h && OCC(hi.x), m3 = (u32)(hi.y >> 32) == h && OCC(hi.y);\n"
+       "__device__ __forceinline__ void consume_one(bool valid, u32 row, u32 h, u32 z, u32 w, u32 lane, u32 *sKeys, u32 *sRows, u64 *sVals, u32 *sClaimed, u32 *sOverflow, u32 *queue, u32 &qn) {\n"
+       "  const u32 b = h & (BUCKETS - 1u), want = (h & HMASK) | OCC;\n"
+       "  const uint4 k = *reinterpret_cast<const uint4 *>(sKeys + 4u * b);\n"
+       "  const bool m0 = (k.x & ~NEWG) == want, m1 = (k.y & ~NEWG) == want, m2 = (k.z & ~NEWG) == want, m3 = (k.w & ~NEWG) == want;\n"
        "  const bool hit = valid && (m0 || m1 || m2 || m3);\n"
        "  if (hit) {\n"
        "    const u32 mi = m0 ? 0u : m1 ? 1u : m2 ? 2u : 3u;\n"
-       "    const u32 seenRow = m0 ? (u32)lo.x : m1 ? (u32)lo.y : m2 ? (u32)hi.x : (u32)hi.y;\n"
-       "    if (row < seenRow) __hip_atomic_fetch_min(sKeys + 4u * b + mi, ((u64)h << 32) | row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
+       "    const u32 mk = m0 ? k.x : m1 ? k.y : m2 ? k.z : k.w;\n"
+       "    if (mk & NEWG) __hip_atomic_fetch_min(sRows + 4u * b + mi, row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
        "    agg(sVals + 4u * b + mi, VALB(z, w));\n"
        "  }\n"
        "  const bool pend = valid && !hit;\n"
@@ -1071,13 +1072,13 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
        "      if (QW == 4u) queue[e + QW - 1u] = w;\n"
        "    }\n"
        "    qn += (u32)__popcll(m);\n"
-       "    if (qn >= QDRAIN) { const u32 take = qn < 64u ? qn : 64u; qn -= take; drain(queue, qn, take, lane, sKeys, sVals, sClaimed, sOverflow); }\n"
+       "    if (qn >= QDRAIN) { const u32 take = qn < 64u ? qn : 64u; qn -= take; drain(queue, qn, take, lane, sKeys, sRows, sVals, sClaimed, sOverflow); }\n"
        "  }\n"
        "}\n";
   if (compact)
     // a 16-byte unit holds two 8-byte slots of a line: lanes 8l .. 8l + 7 hold line l of the segment, the first
     // slot of lanes 8l and 8l + 4 is a header (low 9 row bits of the half-line's seven records)
-    o << "__device__ __forceinline__ void consume(const Stage &s, u32 lane, u32 p, u64 *sKeys, u64 *sVals, u32 *sClaimed, u32 *sOverflow, u32 *queue, u32 &qn) {\n"
+    o << "__device__ __forceinline__ void consume(const Stage &s, u32 lane, u32 p, u32 *sKeys, u32 *sRows, u64 *sVals, u32 *sClaimed, u32 *sOverflow, u32 *queue, u32 &qn) {\n"
          "  const u32 pos = 2u * (lane & 3u);\n"                       // place of the unit's first slot within its half-line
          "  const u32 recBase = (lane >> 3) * 14u + 7u * ((lane >> 2) & 1u);\n"  // record number (within the segment) of the half-line's first record
          "#pragma unroll\n"
@@ -1092,16 +1093,16 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
          "      const u32 lo9 = (u32)(hdr >> (9u * k7)) & 511u;\n"
          "      const u32 h = (p << (32 - PB)) | (hw >> PB);\n"
          "      const u32 row = s.rb[k] + (((hw & ((1u << PB) - 1u)) << 9) | lo9);\n"
-         "      consume_one(valid, row, h, z, 0u, lane, sKeys, sVals, sClaimed, sOverflow, queue, qn);\n"
+         "      consume_one(valid, row, h, z, 0u, lane, sKeys, sRows, sVals, sClaimed, sOverflow, queue, qn);\n"
          "    }\n"
          "  }\n"
          "}\n";
   else
-    o << "__device__ __forceinline__ void consume(const Stage &s, u32 lane, u32 p, u64 *sKeys, u64 *sVals, u32 *sClaimed, u32 *sOverflow, u32 *queue, u32 &qn) {\n"
+    o << "__device__ __forceinline__ void consume(const Stage &s, u32 lane, u32 p, u32 *sKeys, u32 *sRows, u64 *sVals, u32 *sClaimed, u32 *sOverflow, u32 *queue, u32 &qn) {\n"
          "#pragma unroll\n"
          "  for (int k = 0; k < 4; k++) {\n"
          "    const bool valid = lane < s.n[k] && s.r[k].x != 0xFFFFFFFFu;\n"  // not past the segment / padding of the run's last line
-         "    consume_one(valid, s.r[k].x, s.r[k].y, s.r[k].z, s.r[k].w, lane, sKeys, sVals, sClaimed, sOverflow, queue, qn);\n"
+         "    consume_one(valid, s.r[k].x, s.r[k].y, s.r[k].z, s.r[k].w, lane, sKeys, sRows, sVals, sClaimed, sOverflow, queue, qn);\n"
          "  }\n"
          "}\n";
   // dimensions of a source row (hr::fused_eval_row), for groups that are new in this batch
@@ -1120,14 +1121,15 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
   if (!vectorVW) o << "}\n";
   const bool wide = a.width == 8;
   o << "extern \"C\" __global__ void __launch_bounds__(1024) hr_merge_rtc(MArgs a) {\n"
-       "  __shared__ u64 sKeys[SLOTS];\n"
+       "  __shared__ __attribute__((aligned(16))) u32 sKeys[SLOTS];\n"
+       "  __shared__ u32 sRows[SLOTS];\n"
        "  __shared__ u64 sVals[SLOTS];\n"
        "  __shared__ u32 sRunCount[256];\n"
        "  __shared__ u32 sQueue[16u * QCAP * QW];\n"
        "  __shared__ u32 sClaimed, sOverflow, sCount, sBase, sEmit;\n"
        "  const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, p = blockIdx.x;\n"
        "  STAMP(0)\n"
-       "  for (u32 s = tid; s < SLOTS; s += 1024u) { sKeys[s] = EMPTY; sVals[s] = IDENT; }\n"
+       "  for (u32 s = tid; s < SLOTS; s += 1024u) { sKeys[s] = 0u; sRows[s] = 0xFFFFFFFFu; sVals[s] = IDENT; }\n"
        "  if (tid == 0u) { sClaimed = 0u; sOverflow = 0u; sCount = 0u; sEmit = 0u; }\n"
        "  const u32 G = a.streams;\n"
        "  if (tid < G) sRunCount[tid] = a.countsB[(u64)tid * NP + p];\n"
@@ -1169,7 +1171,7 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
        "          const u32 i = i0 + (u32)k * 1024u + tid;\n"
        "          if (i >= cnt) continue;\n"
        "          if (!okk[k] || (PB && (hh[k] >> (32 - (PB ? PB : 1))) != p)) { a.outCount[2] = 1u; continue; }\n"
-       "          insert(sKeys, sVals, &sClaimed, &sOverflow, rr[k], hh[k], vv[k]);\n"
+       "          insert(sKeys, sRows, sVals, &sClaimed, &sOverflow, rr[k], hh[k], vv[k], false);\n"
        "        }\n"
        "      }\n"
        "    }\n"
@@ -1233,15 +1235,15 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
        "    for (;;) {\n"
        "      load(s2);\n"
        "      if (!s0.n[0]) break;\n"
-       "      consume(s0, lane, p, sKeys, sVals, &sClaimed, &sOverflow, queue, qn);\n"
+       "      consume(s0, lane, p, sKeys, sRows, sVals, &sClaimed, &sOverflow, queue, qn);\n"
        "      load(s0);\n"
        "      if (!s1.n[0]) break;\n"
-       "      consume(s1, lane, p, sKeys, sVals, &sClaimed, &sOverflow, queue, qn);\n"
+       "      consume(s1, lane, p, sKeys, sRows, sVals, &sClaimed, &sOverflow, queue, qn);\n"
        "      load(s1);\n"
        "      if (!s2.n[0]) break;\n"
-       "      consume(s2, lane, p, sKeys, sVals, &sClaimed, &sOverflow, queue, qn);\n"
+       "      consume(s2, lane, p, sKeys, sRows, sVals, &sClaimed, &sOverflow, queue, qn);\n"
        "    }\n"
-       "    while (qn) { const u32 take = qn < 64u ? qn : 64u; qn -= take; drain(queue, qn, take, lane, sKeys, sVals, &sClaimed, &sOverflow); }\n"
+       "    while (qn) { const u32 take = qn < 64u ? qn : 64u; qn -= take; drain(queue, qn, take, lane, sKeys, sRows, sVals, &sClaimed, &sOverflow); }\n"
        "  }\n"
        "  __syncthreads();\n"
        "  STAMP(3)\n"
@@ -1249,7 +1251,7 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
        // emit: count occupied slots, reserve output rows once, then copy (as hr::merge_body)
        "  u32 mineCount = 0u;\n"
        "#pragma unroll\n"
-       "  for (int k = 0; k < SLOTS / 1024; k++) mineCount += sKeys[tid + (u32)k * 1024u] != EMPTY;\n"
+       "  for (int k = 0; k < SLOTS / 1024; k++) mineCount += sKeys[tid + (u32)k * 1024u] != 0u;\n"
        "  if (mineCount) __hip_atomic_fetch_add(&sCount, mineCount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
        "  __syncthreads();\n"
        "  const u32 total = sCount;\n"
@@ -1270,15 +1272,14 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
        "#pragma unroll\n"
        "    for (int kk = 0; kk < 4; kk++) {\n"
        "      const u32 s = tid + (u32)(half * 4 + kk) * 1024u;\n"
-       "      const u64 key = sKeys[s];\n"
-       "      has[kk] = key != EMPTY;\n"
+       "      has[kk] = sKeys[s] != 0u;\n"
        "      const u64 m = __ballot(has[kk]);\n"
        "      u32 waveBase = 0u;\n"
        "      if (lane == 0u && m) waveBase = __hip_atomic_fetch_add(&sEmit, (u32)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
        "      waveBase = (u32)__builtin_amdgcn_readfirstlane((int)waveBase);\n"
        "      at[kk] = sBase + waveBase + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));\n"
        "      if (!has[kk]) continue;\n"
-       "      const u32 row = (u32)key;\n"
+       "      const u32 row = sRows[s];\n"
     << (vectorVW ? "" : "      if (row >= a.prevSize) { eval_row(a, row - a.prevSize, dv[kk], nv[kk]); continue; }\n")
     << "#pragma unroll\n"
        "      for (int d = 0; d < ND; d++) {\n"

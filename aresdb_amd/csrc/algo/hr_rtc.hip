@@ -603,30 +603,28 @@ static void kernel_body_compact(std::ostringstream &o) {
 // record straight away (one global cursor reservation): always correct, slow when frequent — the host sends
 // queries with that many groups to the DIRECT kernels.
 static void kernel_body_table(std::ostringstream &o) {
+  // table: 32-bit keys (the hash; 0xFFFFFFFF = empty — a row whose hash IS that value travels alone), the groups'
+  // lowest rows and their values in arrays of their own: a probe is one 16-byte LDS read and four 32-bit compares
   o << "#define T 4096u\n#define SLOTS " << hr::kSlots << "u\n#define BUCKETS (SLOTS / 4u)\n#define LIMIT " << (hr::kSlots * 3 / 4)
-    << "u\n#define EMPTY 0xFFFFFFFFFFFFFFFFull\n#define QCAP 128u\n"
-       "struct __attribute__((aligned(16))) U64x2 { u64 x, y; };\n"
-       "struct Probe { u32 b, slot; u64 seen; bool done, fresh, spill; };\n"
-       "__device__ __forceinline__ void probe_round(u64 *sKeys, u32 *sClaims, Probe &q, u32 h, u64 mine) {\n"
-       "  const U64x2 lo = *reinterpret_cast<const U64x2 *>(sKeys + 4u * q.b), hi = *reinterpret_cast<const U64x2 *>(sKeys + 4u * q.b + 2u);\n"
-       "  const u64 k0 = lo.x, k1 = lo.y, k2 = hi.x, k3 = hi.y;\n"
-       "  const bool e0 = k0 == EMPTY, e1 = k1 == EMPTY, e2 = k2 == EMPTY, e3 = k3 == EMPTY;\n"
-       "  const bool m0 = !e0 && (u32)(k0 >> 32) == h, m1 = !e1 && (u32)(k1 >> 32) == h, m2 = !e2 && (u32)(k2 >> 32) == h, m3 = !e3 && (u32)(k3 >> 32) == h;\n"
+    << "u\n#define EMPTY 0xFFFFFFFFu\n#define QCAP 128u\n"
+       "struct Probe { u32 b, slot; bool done, spill; };\n"
+       "__device__ __forceinline__ void probe_round(u32 *sKeys, u32 *sClaims, Probe &q, u32 h) {\n"
+       "  const uint4 k = *reinterpret_cast<const uint4 *>(sKeys + 4u * q.b);\n"
+       "  const bool e0 = k.x == EMPTY, e1 = k.y == EMPTY, e2 = k.z == EMPTY, e3 = k.w == EMPTY;\n"
+       "  const bool m0 = k.x == h, m1 = k.y == h, m2 = k.z == h, m3 = k.w == h;\n"
        "  const bool anyM = m0 | m1 | m2 | m3, anyE = e0 | e1 | e2 | e3;\n"
        "  const u32 mi = m0 ? 0u : m1 ? 1u : m2 ? 2u : 3u, ei = e0 ? 0u : e1 ? 1u : e2 ? 2u : 3u;\n"
-       "  const u64 mk = m0 ? k0 : m1 ? k1 : m2 ? k2 : k3;\n"
        "  const bool active = !q.done, hit = active & anyM;\n"
        "  q.slot = hit ? 4u * q.b + mi : q.slot;\n"
-       "  q.seen = hit ? mk : q.seen;\n"
        "  bool claimed = false;\n"
        "  if (active & !anyM & anyE) {\n"  // a group this workgroup has not seen yet
        "    if (__hip_atomic_load(sClaims, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= LIMIT) {\n"
        "      q.spill = true; claimed = true;\n"  // the table is full enough: the row travels alone
        "    } else {\n"
-       "      u64 expected = EMPTY;\n"
-       "      if (__hip_atomic_compare_exchange_strong(sKeys + 4u * q.b + ei, &expected, mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {\n"
+       "      u32 expected = EMPTY;\n"
+       "      if (__hip_atomic_compare_exchange_strong(sKeys + 4u * q.b + ei, &expected, h, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {\n"
        "        __hip_atomic_fetch_add(sClaims, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
-       "        q.slot = 4u * q.b + ei; q.fresh = true; claimed = true;\n"
+       "        q.slot = 4u * q.b + ei; claimed = true;\n"
        "      }\n"  // lost the slot: the same bucket again next round (the winner may be this very group)
        "    }\n"
        "  }\n"
@@ -634,12 +632,12 @@ static void kernel_body_table(std::ostringstream &o) {
        "  q.done = q.done | hit | claimed;\n"
        "}\n"
        // one row through the general probe loop
-       "__device__ __forceinline__ void insert(const Args &a, u64 *sKeys, u64 *sVals, u32 *sClaims, u32 row, u32 h, u32 carried) {\n"
-       "  const u64 mine = ((u64)h << 32) | row, value = widen(carried);\n"
-       "  Probe q; q.b = h & (BUCKETS - 1u); q.slot = 0u; q.seen = 0ull; q.done = false; q.fresh = false; q.spill = false;\n"
-       "  for (u32 tries = 0u; tries < BUCKETS + 8u && !q.done; tries++) probe_round(sKeys, sClaims, q, h, mine);\n"
+       "__device__ __forceinline__ void insert(const Args &a, u32 *sKeys, u32 *sRows, u64 *sVals, u32 *sClaims, u32 row, u32 h, u32 carried) {\n"
+       "  const u64 value = widen(carried);\n"
+       "  Probe q; q.b = h & (BUCKETS - 1u); q.slot = 0u; q.done = false; q.spill = h == EMPTY;\n"
+       "  for (u32 tries = 0u; tries < BUCKETS + 8u && !q.done && !q.spill; tries++) probe_round(sKeys, sClaims, q, h);\n"
        "  if (q.done && !q.spill) {\n"
-       "    if (!q.fresh && mine < q.seen) __hip_atomic_fetch_min(sKeys + q.slot, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
+       "    __hip_atomic_fetch_min(sRows + q.slot, row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
        "    agg(sVals + q.slot, value);\n"
        "  } else {\n"
        "    const u32 p = PB ? h >> (32 - (PB ? PB : 1)) : 0u;\n"
@@ -648,26 +646,24 @@ static void kernel_body_table(std::ostringstream &o) {
        "    else *a.overflow = 1u;\n"
        "  }\n"
        "}\n"
-       "__device__ __forceinline__ void drain(const Args &a, u32 *queue, u32 first, u32 count, u32 lane, u64 *sKeys, u64 *sVals, u32 *sClaims) {\n"
+       "__device__ __forceinline__ void drain(const Args &a, u32 *queue, u32 first, u32 count, u32 lane, u32 *sKeys, u32 *sRows, u64 *sVals, u32 *sClaims) {\n"
        "  asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");\n"
        "  if (lane < count) {\n"
        "    const u32 e = 3u * (first + lane);\n"
-       "    insert(a, sKeys, sVals, sClaims, queue[e], queue[e + 1u], queue[e + 2u]);\n"
+       "    insert(a, sKeys, sRows, sVals, sClaims, queue[e], queue[e + 1u], queue[e + 2u]);\n"
        "  }\n"
        "  asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");\n"
        "}\n"
        // one row, round one: the home bucket, straight-line
-       "__device__ __forceinline__ void row_one(const Args &a, bool valid, u32 row, u32 h, u32 carried, u32 lane, u64 *sKeys, u64 *sVals, u32 *sClaims, u32 *queue, u32 &qn) {\n"
+       "__device__ __forceinline__ void row_one(const Args &a, bool valid, u32 row, u32 h, u32 carried, u32 lane, u32 *sKeys, u32 *sRows, u64 *sVals, u32 *sClaims, u32 *queue, u32 &qn) {\n"
        "  const u32 b = h & (BUCKETS - 1u);\n"
-       "  const U64x2 lo = *reinterpret_cast<const U64x2 *>(sKeys + 4u * b), hi = *reinterpret_cast<const U64x2 *>(sKeys + 4u * b + 2u);\n"
-       "  const bool m0 = (u32)(lo.x >> 32) == h && lo.x != EMPTY, m1 = (u32)(lo.y >> 32) == h && lo.y != EMPTY;\n"
-       "  const bool m2 = (u32)(hi.x >> 32) == h && hi.x != EMPTY, m3 = (u32)(hi.y >> 32) == h && hi.y != EMPTY;\n"
-       "  const bool hit = valid && (m0 || m1 || m2 || m3);\n"
+       "  const uint4 k = *reinterpret_cast<const uint4 *>(sKeys + 4u * b);\n"
+       "  const bool m0 = k.x == h, m1 = k.y == h, m2 = k.z == h, m3 = k.w == h;\n"
+       "  const bool hit = valid && h != EMPTY && (m0 || m1 || m2 || m3);\n"
        "  if (hit) {\n"
-       "    const u32 mi = m0 ? 0u : m1 ? 1u : m2 ? 2u : 3u;\n"
-       "    const u32 seenRow = m0 ? (u32)lo.x : m1 ? (u32)lo.y : m2 ? (u32)hi.x : (u32)hi.y;\n"
-       "    if (row < seenRow) __hip_atomic_fetch_min(sKeys + 4u * b + mi, ((u64)h << 32) | row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
-       "    agg(sVals + 4u * b + mi, widen(carried));\n"
+       "    const u32 slot = 4u * b + (m0 ? 0u : m1 ? 1u : m2 ? 2u : 3u);\n"
+       "    __hip_atomic_fetch_min(sRows + slot, row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
+       "    agg(sVals + slot, widen(carried));\n"
        "  }\n"
        "  const bool pend = valid && !hit;\n"
        "  const u64 m = __ballot(pend);\n"
@@ -677,17 +673,18 @@ static void kernel_body_table(std::ostringstream &o) {
        "      queue[e] = row; queue[e + 1u] = h; queue[e + 2u] = carried;\n"
        "    }\n"
        "    qn += (u32)__popcll(m);\n"
-       "    if (qn >= 64u) { qn -= 64u; drain(a, queue, qn, 64u, lane, sKeys, sVals, sClaims); }\n"
+       "    if (qn >= 64u) { qn -= 64u; drain(a, queue, qn, 64u, lane, sKeys, sRows, sVals, sClaims); }\n"
        "  }\n"
        "}\n"
        "extern \"C\" __global__ void __launch_bounds__(1024) hr_scan_rtc(Args a) {\n"
-       "  __shared__ u64 sKeys[SLOTS];\n"
+       "  __shared__ __attribute__((aligned(16))) u32 sKeys[SLOTS];\n"
+       "  __shared__ u32 sRows[SLOTS];\n"
        "  __shared__ u64 sVals[SLOTS];\n"
        "  __shared__ u32 sQueue[16u * QCAP * 3u];\n"
        "  __shared__ u32 sPartCount[NP], sPartBase[NP];\n"
        "  __shared__ u32 sClaims;\n"
        "  const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;\n"
-       "  for (u32 s = tid; s < SLOTS; s += 1024u) { sKeys[s] = EMPTY; sVals[s] = IDENT; }\n"
+       "  for (u32 s = tid; s < SLOTS; s += 1024u) { sKeys[s] = EMPTY; sRows[s] = 0xFFFFFFFFu; sVals[s] = IDENT; }\n"
        "  for (u32 p = tid; p < NP; p += 1024u) sPartCount[p] = 0u;\n"
        "  if (tid == 0u) sClaims = 0u;\n"
        "  __syncthreads();\n"
@@ -703,10 +700,10 @@ static void kernel_body_table(std::ostringstream &o) {
        "    u32 hh[4], cv[4], cw[4], alive[4];                                                                 \\\n"
        "    eval4p(R, a, i0, hh, cv, cw, alive, next * T + tid * 4u, tile >= fullTiles);                        \\\n"
        "    const u32 row0 = a.rowBase + i0;                                                                   \\\n"
-       "    row_one(a, alive[0] != 0u, row0, hh[0], cv[0], lane, sKeys, sVals, &sClaims, queue, qn);           \\\n"
-       "    row_one(a, alive[1] != 0u, row0 + 1u, hh[1], cv[1], lane, sKeys, sVals, &sClaims, queue, qn);      \\\n"
-       "    row_one(a, alive[2] != 0u, row0 + 2u, hh[2], cv[2], lane, sKeys, sVals, &sClaims, queue, qn);      \\\n"
-       "    row_one(a, alive[3] != 0u, row0 + 3u, hh[3], cv[3], lane, sKeys, sVals, &sClaims, queue, qn);      \\\n"
+       "    row_one(a, alive[0] != 0u, row0, hh[0], cv[0], lane, sKeys, sRows, sVals, &sClaims, queue, qn);    \\\n"
+       "    row_one(a, alive[1] != 0u, row0 + 1u, hh[1], cv[1], lane, sKeys, sRows, sVals, &sClaims, queue, qn); \\\n"
+       "    row_one(a, alive[2] != 0u, row0 + 2u, hh[2], cv[2], lane, sKeys, sRows, sVals, &sClaims, queue, qn); \\\n"
+       "    row_one(a, alive[3] != 0u, row0 + 3u, hh[3], cv[3], lane, sKeys, sRows, sVals, &sClaims, queue, qn); \\\n"
        "    tile += G;                                                                                         \\\n"
        "  }\n"
        "  while (tile < numTiles) {\n"
@@ -714,15 +711,15 @@ static void kernel_body_table(std::ostringstream &o) {
        "    if (tile >= numTiles) break;\n"
        "    TILE_STEP(R1)\n"
        "  }\n"
-       "  if (qn) drain(a, queue, 0u, qn, lane, sKeys, sVals, &sClaims);\n"
+       "  if (qn) drain(a, queue, 0u, qn, lane, sKeys, sRows, sVals, &sClaims);\n"
        "  __syncthreads();\n"
        // flush (hr::flush_table): counting sort of the entries by partition, one cursor reservation per partition
        "  u32 rank[SLOTS / 1024u];\n"
        "#pragma unroll\n"
        "  for (u32 k = 0u; k < SLOTS / 1024u; k++) {\n"
-       "    const u64 key = sKeys[tid + k * 1024u];\n"
+       "    const u32 key = sKeys[tid + k * 1024u];\n"
        "    rank[k] = 0u;\n"
-       "    if (key != EMPTY) rank[k] = __hip_atomic_fetch_add(&sPartCount[PB ? (u32)(key >> (64 - (PB ? PB : 1))) : 0u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
+       "    if (key != EMPTY) rank[k] = __hip_atomic_fetch_add(&sPartCount[PB ? key >> (32 - (PB ? PB : 1)) : 0u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
        "  }\n"
        "  __syncthreads();\n"
        "  for (u32 p = tid; p < NP; p += 1024u) { const u32 c = sPartCount[p]; if (c) sPartBase[p] = atomicAdd(a.cursorsA + p, c); }\n"
@@ -730,11 +727,11 @@ static void kernel_body_table(std::ostringstream &o) {
        "#pragma unroll\n"
        "  for (u32 k = 0u; k < SLOTS / 1024u; k++) {\n"
        "    const u32 s = tid + k * 1024u;\n"
-       "    const u64 key = sKeys[s];\n"
+       "    const u32 key = sKeys[s];\n"
        "    if (key == EMPTY) continue;\n"
-       "    const u32 p = PB ? (u32)(key >> (64 - (PB ? PB : 1))) : 0u;\n"
+       "    const u32 p = PB ? key >> (32 - (PB ? PB : 1)) : 0u;\n"
        "    const u64 at = (u64)sPartBase[p] + rank[k], v = sVals[s];\n"
-       "    if (at < a.capA) a.recA[(u64)p * a.capA + at] = make_uint4((u32)key, (u32)(key >> 32), (u32)v, (u32)(v >> 32));\n"
+       "    if (at < a.capA) a.recA[(u64)p * a.capA + at] = make_uint4(sRows[s], key, (u32)v, (u32)(v >> 32));\n"
        "    else *a.overflow = 1u;\n"
        "  }\n"
        "}\n";

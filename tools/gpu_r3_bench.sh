@@ -3,7 +3,7 @@
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 mkdir -p gpurun_out
 TAG=${1:-r3e}
-timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 $BENCH_ARGS > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
+timeout 1500 python bench.py --gpus 1 ${BENCH_STEPS:---steps 20 --warmup 5} $BENCH_ARGS > gpurun_out/bench_$TAG.json 2> gpurun_out/bench_$TAG.err
 echo "bench rc $?"; tail -5 gpurun_out/bench_$TAG.err
 python - <<PY
 import json

@@ -218,6 +218,18 @@ static bool nt_enabled() {
   return on;
 }
 
+// ARES_HR_SCAN_OPT: bit mask of compact-scan variants under measurement (a different source text per value, so they
+// can be timed against each other in one process tree: tools/gpu_r3_ab.sh, profiles/r3_experiments.md)
+//   1  a partition that completes no line in a tile scatters its records straight into its remainder
+//   2  murmur's h * 5 + c as shift-add + add instead of the v_mad_u64_u32 the compiler picks
+static unsigned scan_opt() {
+  static const unsigned v = [] {
+    const char *e = getenv("ARES_HR_SCAN_OPT");
+    return e && e[0] ? static_cast<unsigned>(atoi(e)) : 3u;
+  }();
+  return v;
+}
+
 struct RtcArgs {  // mirrors `struct Args` of the generated source (args_text below): pointers, 8-byte, then 4-byte fields
   const uint32_t *vals[kFusedCols];
   const uint8_t *nulls[kFusedCols];
@@ -254,7 +266,15 @@ const char *kPrelude =
     "typedef u32 U4 __attribute__((ext_vector_type(4)));\n"
     "typedef U4 U4a __attribute__((aligned(4)));\n"
     "__device__ __forceinline__ u32 rotl(u32 x, int r) { return (x << r) | (x >> (32 - r)); }\n"
-    "__device__ __forceinline__ u32 mix(u32 h, u32 k) { k *= 0xcc9e2d51u; k = rotl(k, 15) * 0x1b873593u; h ^= k; return rotl(h, 13) * 5u + 0xe6546b64u; }\n";
+    "__device__ __forceinline__ u32 mix(u32 h, u32 k) { k *= 0xcc9e2d51u; k = rotl(k, 15) * 0x1b873593u; h ^= k; return TIMES5(rotl(h, 13)) + 0xe6546b64u; }\n";
+
+// h * 5 + c: the compiler folds it into one v_mad_u64_u32 (a 64-bit, slow-rate multiply-add); a shift-add and an add are
+// two full-rate instructions (ARES_HR_SCAN_OPT bit 2)
+std::string times5_text() {
+  return scan_opt() & 2u ? "__device__ __forceinline__ unsigned int times5(unsigned int r) { unsigned int t; asm(\"v_lshl_add_u32 %0, %1, 2, %1\" : \"=v\"(t) : \"v\"(r)); return t; }\n"
+                           "#define TIMES5(r) times5(r)\n"
+                         : "#define TIMES5(r) ((r) * 5u)\n";
+}
 
 void phase_macros(std::ostringstream &o) {
   if (phases_enabled())
@@ -325,16 +345,16 @@ static void kernel_body_lines16(std::ostringstream &o, const char *fourth) {
        "  for (u32 p = tid; p < NP; p += 1024u) { sCount[0][p] = 0u; sCount[1][p] = 0u; sLeftN[p] = 0u; sCursor[p] = 0u; }\n"
        "  __syncthreads();\n"
        "  uint4 *myB = reinterpret_cast<uint4 *>(a.recB) + (u64)blockIdx.x * NP * a.capB;\n"
-       "  const u32 numTiles = ((u32)a.length + T - 1u) / T, fullTiles = (u32)a.length / T;\n"
+       "  const u32 numTiles = ((u32)a.length + T - 1u) / T;\n"
        "  u32 tile = blockIdx.x, par = 0u;\n"
        "  Raw R;\n"
        "  PH_DECL\n"
        "  load_tile(R, a, tile * T + tid * 4u);\n"
        "  while (tile < numTiles) {\n"
-       "    const u32 i0 = tile * T + tid * 4u;\n"
+       "    u32 i0 = tile * T + tid * 4u;\n"          // eval4p moves it to the first row the lane's registers hold
        "    u32 hh[4], cv[4], cw[4], alive[4], rank[4];\n"
        "    const u32 next = tile + gridDim.x;\n"
-       "    eval4p(R, a, i0, hh, cv, cw, alive, next * T + tid * 4u, tile >= fullTiles);\n"
+       "    eval4p(R, a, i0, hh, cv, cw, alive, next * T + tid * 4u);\n"
        "    u32 *cnt = sCount[par];\n"
        "#pragma unroll\n"
        "    for (int j = 0; j < 4; j++) {\n"
@@ -441,6 +461,7 @@ static void kernel_body_lines16(std::ostringstream &o, const char *fourth) {
 // seven lanes' shifted row bits (three DPP steps inside the 8-lane group).
 static void kernel_body_compact(std::ostringstream &o) {
   phase_macros(o);
+  const bool direct = scan_opt() & 1u;
   o << (nt_enabled() ? "#define STORE_LINE(p, v) __builtin_nontemporal_store((u64)(v), (p))\n" : "#define STORE_LINE(p, v) (*(p) = (v))\n");
   o << "#define T 4096u\n#define LR 14u\n#define LEFT 13u\n#define LPL 5u\n"
        "__device__ __forceinline__ u32 lane_up(u32 v, u32 lane, u32 off) { return (u32)__builtin_amdgcn_ds_bpermute((int)((lane - off) << 2), (int)v); }\n"
@@ -451,14 +472,23 @@ static void kernel_body_compact(std::ostringstream &o) {
        "  v |= (u32)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true);\n"
        "  return v;\n"
        "}\n"
+       // inclusive scan over the wavefront: Hillis-Steele inside each row of 16 (row_shr 1, 2, 4, 8; lanes without a
+       // source keep the 0), then lane 15 of rows 0 / 2 into rows 1 / 3 and lane 31 into rows 2 and 3
+       "__device__ __forceinline__ u32 wave_incl_scan(u32 v) {\n"
+       "  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);\n"
+       "  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);\n"
+       "  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);\n"
+       "  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);\n"
+       "  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);\n"
+       "  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);\n"
+       "  return v;\n"
+       "}\n"
        "extern \"C\" __global__ void __launch_bounds__(1024) hr_scan_rtc(Args a) {\n"
-       "  __shared__ u64 sRec[T];\n"               // the tile's records, sorted by partition
-       "  __shared__ u16 sLo[T];\n"                // their low 9 row bits
-       "  __shared__ u64 sLeft[NP * LEFT];\n"      // up to 13 records per partition waiting for a full line
-       "  __shared__ u16 sLeftLo[NP * LEFT];\n"
+       "  __shared__ u64 sRec[T + NP * LEFT];\n"   // the tile's records sorted by partition, then up to 13 records per partition waiting for a full line
+       "  __shared__ u16 sLo[T + NP * LEFT];\n"    // their low 9 row bits
        "  __shared__ u32 sCount[2][NP];\n"
-       "  __shared__ uint2 sMeta[NP];\n"         // per partition: {first slot of its records in sRec | leftovers << 16, stream cursor in lines}
-       "  __shared__ u32 sLines[(T + NP * LEFT) / LR + 2u];\n"
+       "  __shared__ u32 sStart[NP];\n"            // where the tile's records of a partition go
+       "  __shared__ uint2 sLines[(T + NP * LEFT) / LR + 2u];\n"   // {partition | line of the tile << 9 | leftovers << 18, first slot | stream cursor << 13}
        "  __shared__ u32 sWave[16];\n"
        "  __shared__ u32 sTotalLines;\n"
        "  const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;\n"
@@ -466,7 +496,7 @@ static void kernel_body_compact(std::ostringstream &o) {
        "  u32 myLeftN = 0u, myCursor = 0u;\n"    // thread p < NP keeps partition p's leftover count and stream cursor in registers
        "  __syncthreads();\n"
        "  u64 *myB = reinterpret_cast<u64 *>(a.recB) + (u64)blockIdx.x * NP * a.capB * 16u;\n"  // capB: lines per stream
-       "  const u32 numTiles = ((u32)a.length + T - 1u) / T, fullTiles = (u32)a.length / T;\n"
+       "  const u32 numTiles = ((u32)a.length + T - 1u) / T;\n"
        "  const u32 firstTile = blockIdx.x * a.chunkTiles;\n"
        "  const u32 endTile = firstTile + a.chunkTiles < numTiles ? firstTile + a.chunkTiles : numTiles;\n"
        "  u32 tile = firstTile, par = 0u;\n"
@@ -478,11 +508,11 @@ static void kernel_body_compact(std::ostringstream &o) {
        "  const u32 kk = (q >> 3) * 7u + (r8 ? r8 - 1u : 0u);\n"  // record of the line this lane carries
        "  const u32 sh = r8 ? 9u * (r8 - 1u) : 0u;\n"
        "  while (tile < endTile) {\n"
-       "    const u32 i0 = tile * T + tid * 4u;\n"
-       "    const u32 rc0 = (tile - firstTile) * T + tid * 4u;\n"  // row within the chunk
+       "    u32 i0 = tile * T + tid * 4u;\n"          // eval4p moves it to the first row the lane's registers hold
        "    u32 hh[4], cv[4], cw[4], alive[4], rank[4];\n"
        "    const u32 next = tile + 1u;\n"
-       "    eval4p(R, a, i0, hh, cv, cw, alive, next * T + tid * 4u, tile >= fullTiles);\n"
+       "    eval4p(R, a, i0, hh, cv, cw, alive, next * T + tid * 4u);\n"
+       "    const u32 rc0 = i0 - firstTile * T;\n"    // row within the chunk
        "    u32 *cnt = sCount[par];\n"
        "#pragma unroll\n"
        "    for (int j = 0; j < 4; j++) {\n"
@@ -496,9 +526,7 @@ static void kernel_body_compact(std::ostringstream &o) {
        "    if (tid < NP) { myCount = cnt[tid]; myLeft = myLeftN; }\n"
        "    const u32 myHave = myCount + myLeft, myLines = myHave / LR;\n"
        "    const u32 packed = (myCount << 16) | myLines;\n"
-       "    u32 incl = packed;\n"
-       "#pragma unroll\n"
-       "    for (u32 off = 1u; off < 64u; off <<= 1) { const u32 t = lane_up(incl, lane, off); if (lane >= off) incl += t; }\n"
+       "    const u32 incl = wave_incl_scan(packed);\n"
        "    if (lane == 63u) sWave[wave] = incl;\n"
        "    __syncthreads();\n"
        "    u32 before = 0u;\n"
@@ -507,8 +535,9 @@ static void kernel_body_compact(std::ostringstream &o) {
        "    const u32 excl = before + incl - packed;\n"
        "    const u32 myStart = excl >> 16, myLineStart = excl & 0xFFFFu;\n"
        "    if (tid < NP) {\n"
-       "      sMeta[tid] = make_uint2(myStart | (myLeft << 16), myCursor);\n"
-       "      for (u32 c = 0u; c < myLines; c++) sLines[myLineStart + c] = tid | (c << 9);\n"
+    // a partition that completes no line in this tile takes its records straight into its remainder
+    << (direct ? "      sStart[tid] = myLines ? myStart : T + tid * LEFT + myLeft;\n" : "      sStart[tid] = myStart;\n")
+    << "      for (u32 c = 0u; c < myLines; c++) sLines[myLineStart + c] = make_uint2(tid | (c << 9) | (myLeft << 18), myStart | (myCursor << 13));\n"
        "      if (tid == NP - 1u) sTotalLines = myLineStart + myLines;\n"
        "    }\n"
        "    __syncthreads();\n"
@@ -516,7 +545,7 @@ static void kernel_body_compact(std::ostringstream &o) {
        "#pragma unroll\n"
        "    for (int j = 0; j < 4; j++)\n"
        "      if (alive[j]) {\n"
-       "        const u32 at = (sMeta[hh[j] >> (32 - PB)].x & 0xFFFFu) + rank[j], rc = rc0 + (u32)j;\n"
+       "        const u32 at = sStart[hh[j] >> (32 - PB)] + rank[j], rc = rc0 + (u32)j;\n"
        "        sRec[at] = ((u64)((hh[j] << PB) | (rc >> 9)) << 32) | cv[j];\n"
        "        sLo[at] = (u16)(rc & 511u);\n"
        "      }\n"
@@ -527,16 +556,17 @@ static void kernel_body_compact(std::ostringstream &o) {
        "      u32 e[LPL], lf[LPL], st[LPL], cu[LPL], lo[LPL];\n"
        "      u64 rec[LPL];\n"
        "#pragma unroll\n"
-       "      for (u32 j = 0u; j < LPL; j++) { const u32 L = L0 + j * 64u; e[j] = L < totalLines ? sLines[L] : 0u; }\n"
-       "#pragma unroll\n"
-       "      for (u32 j = 0u; j < LPL; j++) { const uint2 m = sMeta[e[j] & 511u]; lf[j] = m.x >> 16; st[j] = m.x & 0xFFFFu; cu[j] = m.y; }\n"
+       "      for (u32 j = 0u; j < LPL; j++) {\n"
+       "        const u32 L = L0 + j * 64u;\n"
+       "        const uint2 w = L < totalLines ? sLines[L] : make_uint2(0u, 0u);\n"
+       "        e[j] = w.x & 0x3FFFFu; lf[j] = w.x >> 18; st[j] = w.y & 0x1FFFu; cu[j] = w.y >> 13;\n"
+       "      }\n"
        "#pragma unroll\n"
        "      for (u32 j = 0u; j < LPL; j++) {\n"
        "        const u32 p = e[j] & 511u, idx = (e[j] >> 9) * LR + kk;\n"
-       "        const bool old = idx < lf[j];\n"
-       "        const u32 at = old ? p * LEFT + idx : (st[j] + idx - lf[j]) & (T - 1u);\n"
-       "        rec[j] = *(old ? sLeft + at : sRec + at);\n"
-       "        lo[j] = *(old ? sLeftLo + at : sLo + at);\n"
+       "        const u32 at = idx < lf[j] ? T + p * LEFT + idx : st[j] + idx - lf[j];\n"
+       "        rec[j] = sRec[at];\n"
+       "        lo[j] = sLo[at];\n"
        "      }\n"
        "#pragma unroll\n"
        "      for (u32 j = 0u; j < LPL; j++) {\n"
@@ -551,15 +581,24 @@ static void kernel_body_compact(std::ostringstream &o) {
        // what is left of each partition (< 14 records) moves to its LDS remainder; cursors advance
        "    if (tid < NP) {\n"
        "      const u32 rem = myHave - myLines * LR;\n"
-       "      const u32 n = myLines ? rem : myCount;\n"
-       "      const u32 from = myLines ? myStart + myLines * LR - myLeft : myStart;\n"
-       "      const u32 to = tid * LEFT + (myLines ? 0u : myLeft);\n"
-       "      u64 t[LEFT]; u16 tl[LEFT];\n"
-       "#pragma unroll\n"
-       "      for (u32 k = 0u; k < LEFT; k++) { const u32 s = (from + (k < n ? k : 0u)) & (T - 1u); t[k] = sRec[s]; tl[k] = sLo[s]; }\n"
-       "#pragma unroll\n"
-       "      for (u32 k = 0u; k < LEFT; k++) if (k < n) { sLeft[to + k] = t[k]; sLeftLo[to + k] = tl[k]; }\n"
-       "      myLeftN = rem;\n"
+    << (direct ?  // only after a line: the 13 slots behind the last line go to the remainder as they are (those past `rem` are never read)
+                 "      if (myLines) {\n"
+                 "        const u32 from = myStart + myLines * LR - myLeft, to = T + tid * LEFT;\n"
+                 "        u64 t[LEFT]; u16 tl[LEFT];\n"
+                 "#pragma unroll\n"
+                 "        for (u32 k = 0u; k < LEFT; k++) { t[k] = sRec[from + k]; tl[k] = sLo[from + k]; }\n"
+                 "#pragma unroll\n"
+                 "        for (u32 k = 0u; k < LEFT; k++) { sRec[to + k] = t[k]; sLo[to + k] = tl[k]; }\n"
+                 "      }\n"
+               : "      const u32 n = myLines ? rem : myCount;\n"
+                 "      const u32 from = myLines ? myStart + myLines * LR - myLeft : myStart;\n"
+                 "      const u32 to = T + tid * LEFT + (myLines ? 0u : myLeft);\n"
+                 "      u64 t[LEFT]; u16 tl[LEFT];\n"
+                 "#pragma unroll\n"
+                 "      for (u32 k = 0u; k < LEFT; k++) { const u32 s = from + (k < n ? k : 0u); t[k] = sRec[s]; tl[k] = sLo[s]; }\n"
+                 "#pragma unroll\n"
+                 "      for (u32 k = 0u; k < LEFT; k++) if (k < n) { sRec[to + k] = t[k]; sLo[to + k] = tl[k]; }\n")
+    << "      myLeftN = rem;\n"
        "      u32 cur = myCursor + myLines;\n"
        "      if (cur > a.capB) { *a.overflow = 1u; cur = a.capB; }\n"
        "      myCursor = cur;\n"
@@ -570,16 +609,16 @@ static void kernel_body_compact(std::ostringstream &o) {
        "    PH(4)\n"
        "  }\n"
        "  __syncthreads();\n"
-       "  if (tid < NP) sMeta[tid] = make_uint2(myLeftN << 16, myCursor);\n"
+       "  if (tid < NP) sLines[tid] = make_uint2(myLeftN, myCursor);\n"
        "  __syncthreads();\n"
        "  PH(5)\n"
        // the remainders go out as one last, partly filled line each; countsB holds the exact number of records
        "  for (u32 p = tid >> 4; p < NP; p += 64u) {\n"
-       "    const uint2 m = sMeta[p];\n"
-       "    const u32 left = m.x >> 16, cur = m.y;\n"
+       "    const uint2 m = sLines[p];\n"
+       "    const u32 left = m.x, cur = m.y;\n"
        "    const bool fits = cur < a.capB, has = r8 && kk < left;\n"
-       "    const u64 rec = has ? sLeft[p * LEFT + kk] : 0ull;\n"
-       "    const u64 mine = has ? (u64)sLeftLo[p * LEFT + kk] << sh : 0ull;\n"
+       "    const u64 rec = has ? sRec[T + p * LEFT + kk] : 0ull;\n"
+       "    const u64 mine = has ? (u64)sLo[T + p * LEFT + kk] << sh : 0ull;\n"
        "    const u64 hdr = ((u64)or8((u32)(mine >> 32)) << 32) | or8((u32)mine);\n"
        "    if (left && fits) STORE_LINE(&myB[((u64)p * a.capB + cur) * 16u + q], r8 ? rec : hdr);\n"
        "    if (left && !fits) *a.overflow = 1u;\n"
@@ -688,7 +727,7 @@ static void kernel_body_table(std::ostringstream &o) {
        "  for (u32 p = tid; p < NP; p += 1024u) sPartCount[p] = 0u;\n"
        "  if (tid == 0u) sClaims = 0u;\n"
        "  __syncthreads();\n"
-       "  const u32 numTiles = ((u32)a.length + T - 1u) / T, fullTiles = (u32)a.length / T, G = gridDim.x;\n"
+       "  const u32 numTiles = ((u32)a.length + T - 1u) / T, G = gridDim.x;\n"
        "  u32 tile = blockIdx.x, qn = 0u;\n"
        "  u32 *queue = sQueue + wave * (QCAP * 3u);\n"
        "  Raw R0, R1;\n"
@@ -696,9 +735,10 @@ static void kernel_body_table(std::ostringstream &o) {
        "  load_tile(R1, a, (tile + G) * T + tid * 4u);\n"
        "#define TILE_STEP(R)                                                                                   \\\n"
        "  {                                                                                                    \\\n"
-       "    const u32 i0 = tile * T + tid * 4u, next = tile + 2u * G;                                          \\\n"
+       "    u32 i0 = tile * T + tid * 4u;                                                                      \\\n"
+       "    const u32 next = tile + 2u * G;                                                                    \\\n"
        "    u32 hh[4], cv[4], cw[4], alive[4];                                                                 \\\n"
-       "    eval4p(R, a, i0, hh, cv, cw, alive, next * T + tid * 4u, tile >= fullTiles);                        \\\n"
+       "    eval4p(R, a, i0, hh, cv, cw, alive, next * T + tid * 4u);                                          \\\n"
        "    const u32 row0 = a.rowBase + i0;                                                                   \\\n"
        "    row_one(a, alive[0] != 0u, row0, hh[0], cv[0], lane, sKeys, sRows, sVals, &sClaims, queue, qn);    \\\n"
        "    row_one(a, alive[1] != 0u, row0 + 1u, hh[1], cv[1], lane, sKeys, sRows, sVals, &sClaims, queue, qn); \\\n"
@@ -747,7 +787,7 @@ std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t null
   if (kind == SCAN_COMPACT && partBits < 3) return "";
   std::ostringstream o;
   const int nc = plan.numCols;
-  o << kPrelude << args_text()
+  o << times5_text() << kPrelude << args_text()
     << "#define NC " << nc << "\n#define ND " << nd << "\n#define PB " << partBits << "\n#define NP " << (1 << partBits) << "\n"
        "struct Raw { u32 v[NC][4]; u32 win[NC]; };\n";
   // ---- loads, one column at a time.  Always the full 16 bytes + the 16-bit validity window, from a row index clamped
@@ -782,24 +822,22 @@ std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t null
   {
     const std::string bar = "  __builtin_amdgcn_sched_barrier(0);\n";
     auto prefetch = [&](int c) { o << bar << "  load_col" << c << "(r, a, i0nc);\n" << bar; };
-    o << "__device__ __forceinline__ void eval4p(Raw &r, const Args &a, u32 i0, u32 (&hh)[4], u32 (&cv)[4], u32 (&cw)[4], u32 (&alive)[4], u32 i0n, bool partial) {\n"
+    o << "__device__ __forceinline__ void eval4p(Raw &r, const Args &a, u32 &i0, u32 (&hh)[4], u32 (&cv)[4], u32 (&cw)[4], u32 (&alive)[4], u32 i0n) {\n"
          "  u32 okc[NC];\n"
          "  cw[0] = cw[1] = cw[2] = cw[3] = 0u;\n"
          "  const u32 i0c = clampi(a, i0), i0nc = clampi(a, i0n);\n"
-         "  const u32 sh = i0 - i0c < 4u ? i0 - i0c : 4u;\n";   // rows this quad was loaded too early by (0 except at the shard's end)
+         // the registers hold rows i0c .. i0c + 3: i0's own rows except in the one quad that straddles the shard's end (loaded
+         // `sh` rows early: its first `sh` rows belong to the lane before) and in the lanes past the end (sh = 4: no row).
+         // The caller numbers the lane's rows from i0c: no register is moved
+         "  const u32 sh = i0 - i0c < 4u ? i0 - i0c : 4u;\n"
+         "  i0 = i0c;\n";
     for (int c = 0; c < nc; c++) {
-      if (nullMask & (1u << c)) o << "  okc[" << c << "] = (r.win[" << c << "] >> (((i0c + a.bitOff[" << c << "]) & 7u) + sh)) & 0xFu;\n";
+      if (nullMask & (1u << c)) o << "  okc[" << c << "] = (r.win[" << c << "] >> ((i0c + a.bitOff[" << c << "]) & 7u)) & 0xFu;\n";
       else o << "  okc[" << c << "] = 0xFu;\n";
     }
-    o << "  if (partial && sh) {\n";  // the straddling quad: move its rows to the front
-    for (int c = 0; c < nc; c++)
-      o << "    { const u32 v0 = r.v[" << c << "][0], v1 = r.v[" << c << "][1], v2 = r.v[" << c << "][2], v3 = r.v[" << c << "][3];\n"
-           "      r.v[" << c << "][0] = sh == 1u ? v1 : sh == 2u ? v2 : sh == 3u ? v3 : 0u; r.v[" << c << "][1] = sh == 1u ? v2 : sh == 2u ? v3 : 0u; r.v[" << c
-        << "][2] = sh == 1u ? v3 : 0u; r.v[" << c << "][3] = 0u; }\n";
-    o << "  }\n";
     o << "#pragma unroll\n"
          "  for (int j = 0; j < 4; j++) {\n"
-         "    u32 keep = (int)(i0 + j) < a.length ? 1u : 0u;\n";
+         "    u32 keep = ((u32)j >= sh && (int)(i0c + j) < a.length) ? 1u : 0u;\n";
     for (int k = 0; k < plan.numFilters; k++) {
       const FusedExpr &e = plan.filters[k];
       if (e.col < 0 || e.col >= nc) return "";
@@ -864,7 +902,7 @@ std::string generate_vector(int nd, int vw, int partBits) {
   if (nd < 1 || nd > kFusedDims || (vw != 4 && vw != 8)) return "";
   std::ostringstream o;
   const int mq = vw / 4;
-  o << kPrelude << args_text()
+  o << times5_text() << kPrelude << args_text()
     << "#define ND " << nd << "\n#define MQ " << mq << "\n#define PB " << partBits << "\n#define NP " << (1 << partBits) << "\n"
        "struct Raw { u32 v[ND][4]; u32 ok[ND]; u32 m[MQ * 4]; };\n"
        "__device__ __forceinline__ void load_full(Raw &r, const Args &a, u32 i0) {\n"
@@ -911,7 +949,7 @@ std::string generate_vector(int nd, int vw, int partBits) {
        "  }\n"
        "}\n";
   o << "__device__ __forceinline__ void load_tile(Raw &r, const Args &a, u32 i0) { if ((int)(i0 + 3u) < a.length) load_full(r, a, i0); else if ((int)i0 < a.length) load_tail(r, a, i0); }\n"
-       "__device__ __forceinline__ void eval4p(Raw &r, const Args &a, u32 i0, u32 (&hh)[4], u32 (&cv)[4], u32 (&cw)[4], u32 (&alive)[4], u32 i0n, bool) {\n"
+       "__device__ __forceinline__ void eval4p(Raw &r, const Args &a, u32 &i0, u32 (&hh)[4], u32 (&cv)[4], u32 (&cw)[4], u32 (&alive)[4], u32 i0n) {\n"
        "  eval4(r, a, i0, hh, cv, cw, alive);\n"
        "  load_tile(r, a, i0n);\n"
        "}\n";
@@ -961,7 +999,7 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
   if (compact && (vectorVW || partBits < 3)) return "";
   if (partBits < 2) return "";  // the 32-bit table keys need two spare hash bits (small inputs: the generic merge)
   std::ostringstream o;
-  o << kPrelude
+  o << times5_text() << kPrelude
     << "struct MArgs { const u32 *vals[" << kFusedCols << "]; const u8 *nulls[" << kFusedCols << "]; const u32 *recB; const u32 *countsB;\n"
        "  const u32 *prevRanges; const u8 *prevDims; const u8 *prevValues; u8 *dimOut; u8 *outValues; u32 *outCount; u32 *outRanges;\n"
        "  u64 prevCapacity, outCapacity; u32 bitOff[" << kFusedCols << "]; u32 capB, streams, prevSize, chunkRows; u64 *phases; u32 k[" << kNumConsts << "]; u32 pad; };\n"

@@ -14,7 +14,7 @@ namespace {
 struct PinnedSlot {
   uint64_t *ptr = nullptr;
   PinnedSlot() {
-    if (hipHostMalloc(reinterpret_cast<void **>(&ptr), 8 * sizeof(uint64_t), hipHostMallocPortable) != hipSuccess) {
+    if (hipHostMalloc(reinterpret_cast<void **>(&ptr), kPinnedWords * sizeof(uint32_t), hipHostMallocPortable) != hipSuccess) {
       (void)hipGetLastError();
       ptr = nullptr;
     }
@@ -32,6 +32,7 @@ uint64_t *pinned_words() {
 }
 
 void read_back_u32(const uint32_t *dev, uint32_t *host, int count, hipStream_t stream) {
+  if (count > kPinnedWords) throw AlgorithmError("ERROR: read_back_u32: more words than the pinned slot holds");
   uint32_t *pinned = reinterpret_cast<uint32_t *>(pinned_words());
   hip_check(hipMemcpyAsync(pinned, dev, sizeof(uint32_t) * count, hipMemcpyDeviceToHost, stream), "read back result");
   hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");

@@ -161,6 +161,7 @@ class StreamBuffer {
 uint64_t *pinned_words();
 
 // Reads `count` 32-bit words written by a kernel at `dev` back to the host; synchronises stream.
+constexpr int kPinnedWords = 4096 + 16;  // the thread's pinned result slot: a filter reads one partial count per workgroup back
 void read_back_u32(const uint32_t *dev, uint32_t *host, int count, hipStream_t stream);
 
 // Optional per-kernel timing with HIP events on the launch stream (off by default).  bench.py

@@ -1675,9 +1675,71 @@ int rtc_compact_chunk_tiles(int64_t rows, int partBits) {
   return chunk <= (1ll << (partBits - 3)) ? static_cast<int>(chunk) : 0;
 }
 
+// ---- lookups by plan shape, without writing the source -----------------------------------------------------
+// The kernel cache is keyed by source text; writing a kernel's text (tens of kilobytes through a string stream) and
+// comparing it costs tens of microseconds — twice per HashReduce call, 30 times per 1 B-row query, a third of a
+// 2 Mi-row live batch's host time.  In front of it: a small map from the fields the generators read (expression
+// shapes and constants, null mask, dimension count, partition bits, aggregate, generator switches) to the loaded
+// kernel.  Only loaded kernels are entered; a miss takes the long way and is always right.
+namespace {
+
+struct FrontCache {
+  std::mutex mu;
+  std::unordered_map<std::string, RtcKernel> map;
+};
+FrontCache &front() {
+  static FrontCache *f = new FrontCache;  // never destroyed: kernels are unloaded by the main cache's exit path
+  return *f;
+}
+
+template <typename T>
+void put(std::string &k, const T &v) {
+  k.append(reinterpret_cast<const char *>(&v), sizeof(T));
+}
+void put_expr(std::string &k, const FusedExpr &e) {
+  put(k, e.col); put(k, e.outKind); put(k, e.f.akind); put(k, e.f.arity); put(k, e.f.functor); put(k, e.f.I); put(k, e.f.rk);
+  put(k, e.f.bkind); put(k, e.f.bbits); put(k, e.f.bok); put(k, e.f.divLike);
+}
+std::string shape_key(char tag, int device, const FusedPlanD &plan, int nd, int partBits, int flags, const AggSpec *a, const hr::Widen *w) {
+  std::string k;
+  k.reserve(512);
+  k.push_back(tag);
+  put(k, device); put(k, nd); put(k, partBits); put(k, flags);
+  const unsigned opt = scan_opt();
+  const uint32_t nm = null_mask(plan);
+  put(k, opt); put(k, nm); put(k, plan.numCols); put(k, plan.numFilters);
+  for (int i = 0; i < plan.numFilters && i < kFusedFilters; i++) put_expr(k, plan.filters[i]);
+  for (int d = 0; d < nd && d < kFusedDims; d++) put_expr(k, plan.dims[d]);
+  put_expr(k, plan.measure);
+  put(k, plan.measureDtype); put(k, plan.measureWidth); put(k, plan.identity);
+  if (a) { put(k, a->vtype); put(k, a->op); put(k, a->width); put(k, a->identity); }
+  if (w) { put(k, w->mode); put(k, w->rk); put(k, w->dtype); }
+  return k;
+}
+
+template <typename Gen>
+RtcKernel front_lookup(const std::string &key, int device, Gen &&source, const char *entry, bool wait) {
+  FrontCache &f = front();
+  {
+    std::lock_guard<std::mutex> lock(f.mu);
+    auto it = f.map.find(key);
+    if (it != f.map.end()) return it->second;
+  }
+  RtcKernel k = compiled_kernel(device, source(), entry, wait);
+  if (k) {
+    std::lock_guard<std::mutex> lock(f.mu);
+    if (f.map.size() >= 64) f.map.clear();  // holds references: bounded well below the main cache's capacity
+    f.map.emplace(key, k);
+  }
+  return k;
+}
+
+}  // namespace
+
 RtcKernel rtc_scan_lookup(int device, const FusedPlanD &plan, int nd, int partBits, bool compact, bool wait) {
   if (!rtc_api().ok) return nullptr;
-  return compiled_kernel(device, generate(plan, nd, partBits, null_mask(plan), compact ? SCAN_COMPACT : SCAN_LINES16), "hr_scan_rtc", wait);
+  return front_lookup(shape_key('s', device, plan, nd, partBits, compact ? 1 : 0, nullptr, nullptr), device,
+                      [&] { return generate(plan, nd, partBits, null_mask(plan), compact ? SCAN_COMPACT : SCAN_LINES16); }, "hr_scan_rtc", wait);
 }
 
 void rtc_scan_launch(const RtcKernel &kernel, const FusedPlanD &plan, uint32_t rowBase, int length, const hr::Workspace &ws,
@@ -1690,7 +1752,8 @@ void rtc_scan_launch(const RtcKernel &kernel, const FusedPlanD &plan, uint32_t r
 
 RtcKernel rtc_table_scan_lookup(int device, const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w, bool wait) {
   if (!rtc_api().ok) return nullptr;
-  return compiled_kernel(device, generate(plan, nd, partBits, null_mask(plan), SCAN_TABLE, &a, &w), "hr_scan_rtc", wait);
+  return front_lookup(shape_key('t', device, plan, nd, partBits, 0, &a, &w), device,
+                      [&] { return generate(plan, nd, partBits, null_mask(plan), SCAN_TABLE, &a, &w); }, "hr_scan_rtc", wait);
 }
 
 void rtc_table_scan_launch(const RtcKernel &kernel, const FusedPlanD &plan, uint32_t rowBase, int length, const hr::Workspace &ws,
@@ -1738,7 +1801,8 @@ std::string rtc_vector_merge_source(int nd, int vw, int partBits, const AggSpec 
 RtcKernel rtc_merge_lookup(int device, const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w, bool compact,
                            bool wait) {
   if (!rtc_api().ok) return nullptr;
-  return compiled_kernel(device, generate_merge(plan, nd, partBits, a, w, 0, compact), "hr_merge_rtc", wait);
+  return front_lookup(shape_key('m', device, plan, nd, partBits, compact ? 1 : 0, &a, &w), device,
+                      [&] { return generate_merge(plan, nd, partBits, a, w, 0, compact); }, "hr_merge_rtc", wait);
 }
 
 void rtc_merge_launch(const RtcKernel &kernel, const FusedPlanD &plan, const uint8_t *prevDims, size_t prevCapacity, const uint8_t *prevValues,

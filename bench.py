@@ -340,6 +340,7 @@ def main(argv=None, backend=None, tensor_device=None):
     path (tests/test_bench_distributed.py); the benchmark itself always loads the HIP libraries and
     fails without a GPU — there is no CPU fallback."""
     argv = sys.argv[1:] if argv is None else argv
+    t_process0 = time.perf_counter()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -350,6 +351,9 @@ def main(argv=None, backend=None, tensor_device=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the secondary legs (fusion off, live batches, extension)")
     ap.add_argument("--legs", default="all", help="comma list of substrings: only the secondary legs whose name contains one of them")
+    ap.add_argument("--leg-budget", type=float, default=150.0,
+                    help="seconds for the secondary legs (0 = no limit): they run in the order below until the budget is spent, "
+                         "the rest is marked skipped; a leg that needs more than what is left is not started")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     ap.add_argument("--one-stream", action="store_true", help="every batch on one stream (the Go host alternates two)")
     ap.add_argument("--verify-merged", action="store_true",
@@ -599,7 +603,9 @@ def main(argv=None, backend=None, tensor_device=None):
     # libalgorithm.so and same batch size only — from the committed passes under profiles/, else null
     pmc_kernels, pmc_note = {}, "not measured (--no-pmc)"
     if rank == 0 and world == 1 and on_gpu and not args.no_pmc and not args.leg:
+        t_pmc0 = time.perf_counter()
         pmc_kernels, pmc_note = measure_traffic(batch_rows)
+        pmc_note += f" ({time.perf_counter() - t_pmc0:.0f} s)"
     if not pmc_kernels:
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
@@ -642,43 +648,68 @@ def main(argv=None, backend=None, tensor_device=None):
             big = common + ["--batch-rows", str(batch_rows)]
             wanted = [w for w in args.legs.split(",") if w]
 
-            def leg(name, env, argv):
-                if args.legs == "all" or any(w in name for w in wanted):
+            legs_t0 = time.perf_counter()
+
+            def want(name, needs_s):
+                """selected by --legs, and enough of --leg-budget left for what the leg usually takes"""
+                if not (args.legs == "all" or any(w in name for w in wanted)):
+                    return False
+                left = args.leg_budget - (time.perf_counter() - legs_t0)
+                if args.leg_budget > 0 and left < needs_s:
+                    legs[name] = {"skipped": f"needs ~{needs_s} s, {max(left, 0):.0f} s of --leg-budget {args.leg_budget:.0f} s left "
+                                             "(run with --leg-budget 0 for every leg)"}
+                    return False
+                return True
+
+            def leg(name, env, argv, needs_s=15):
+                if want(name, needs_s):
+                    t0 = time.perf_counter()
                     legs[name] = run_leg(env, argv)
-            leg("unfused_abi_ARES_FUSE=0", {"ARES_FUSE": "0"}, big)
-            leg("eager_abi_ARES_DEFER=0", {"ARES_DEFER": "0"}, big)
-            leg("fused_extension", {}, big + ["--fused-extension"])
+                    if isinstance(legs[name], dict):
+                        legs[name]["leg_wall_s"] = round(time.perf_counter() - t0, 1)
+
+            # BASELINE configs C2 (100 M rows, one predicate + COUNT(*)) and C4 at its stated size (1 B rows, 50 M-key cuckoo
+            # join, 50 M groups through Sort + Reduce): tools/bench_configs.py, each checked (count / every key -> sum)
+            def tool_leg(name, which, timeout, needs_s):
+                if not want(name, needs_s):
+                    return
+                t0 = time.perf_counter()
+                try:
+                    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_configs.py"), which], capture_output=True,
+                                       text=True, timeout=timeout, cwd=ROOT)
+                    rows_ = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+                    for row in rows_:
+                        row["leg_wall_s"] = round(time.perf_counter() - t0, 1)
+                    legs[name] = rows_ if r.returncode == 0 and rows_ else {"error": f"rc {r.returncode}", "stderr": r.stderr[-300:]}
+                except subprocess.TimeoutExpired:
+                    legs[name] = {"error": "timeout"}
+
+            # in the order of what the round's review asks about first; the two long ones last
             leg(f"live_batches_{LIVE_BATCH_ROWS}_rows", {}, common + ["--batch-rows", str(LIVE_BATCH_ROWS)])
             # lower-cardinality variants of the same query (same filter and measure; fewer group-by dimensions)
-            leg("groups_15k_dims_ts_d1", {}, big + ["--dims", "ts,d1"])        # DIRECT-mode kernels (> 6000 groups)
-            leg("groups_4k6_dims_d1_d2", {}, big + ["--dims", "d1,d2"])        # TABLE-mode scan, table well filled
             leg("groups_100_dims_d2_d3", {}, big + ["--dims", "d2,d3"])        # TABLE-mode scan, ~100 groups, 4 columns read
-            leg("groups_90_dims_d1", {}, big + ["--dims", "d1"])               # TABLE-mode scan, ~100 groups, 2 columns read
+            leg("groups_15k_dims_ts_d1", {}, big + ["--dims", "ts,d1"])        # DIRECT-mode kernels (> 6000 groups)
+            tool_leg("c2_100M_rows_filter_count", "c2", 300, 15)
             # first query of a fresh process (kernels compiled in the background: empty on-disk cache), the same process
             # warm, and the same shape with a comparison constant never seen before
             import tempfile
             with tempfile.TemporaryDirectory(prefix="ares_rtc_cache_") as tmp:
                 leg("cold_process", {"ARES_RTC_CACHE_DIR": tmp}, big + ["--cold"])
                 leg("cold_process_warm_disk_cache", {"ARES_RTC_CACHE_DIR": tmp}, big + ["--cold"])
-            # BASELINE configs C2 (100 M rows, one predicate + COUNT(*)) and C4 at its stated size (1 B rows, 50 M-key cuckoo
-            # join, 50 M groups through Sort + Reduce): tools/bench_configs.py, each checked (count / every key -> sum)
-            def tool_leg(name, which, timeout):
-                if not (args.legs == "all" or any(w in name for w in wanted)):
-                    return
-                try:
-                    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_configs.py"), which], capture_output=True,
-                                       text=True, timeout=timeout, cwd=ROOT)
-                    rows_ = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
-                    legs[name] = rows_ if r.returncode == 0 and rows_ else {"error": f"rc {r.returncode}", "stderr": r.stderr[-300:]}
-                except subprocess.TimeoutExpired:
-                    legs[name] = {"error": "timeout"}
-            tool_leg("c2_100M_rows_filter_count", "c2", 300)
-            tool_leg("c4_spec_1B_rows_50M_keys", "c4spec", 600)
-            if args.legs == "all" or any(w in "host_batches" for w in wanted):
+            leg("fused_extension", {}, big + ["--fused-extension"])
+            leg("groups_4k6_dims_d1_d2", {}, big + ["--dims", "d1,d2"])        # TABLE-mode scan, table well filled
+            leg("groups_90_dims_d1", {}, big + ["--dims", "d1"])               # TABLE-mode scan, ~100 groups, 2 columns read
+            leg("unfused_abi_ARES_FUSE=0", {"ARES_FUSE": "0"}, big)
+            leg("eager_abi_ARES_DEFER=0", {"ARES_DEFER": "0"}, big)
+            if want("host_batches", 30):
+                t0 = time.perf_counter()
                 try:
                     legs["host_batches"] = host_batch_leg(be, plan, batches, device_index, streams)
+                    legs["host_batches"]["leg_wall_s"] = round(time.perf_counter() - t0, 1)
                 except Exception as e:  # noqa: BLE001
                     legs["host_batches"] = {"error": f"{type(e).__name__}: {e}"}
+            tool_leg("c4_spec_1B_rows_50M_keys", "c4spec", 600, 120)
+            legs["legs_wall_s"] = round(time.perf_counter() - legs_t0, 1)
 
     if rank == 0:
         value = rows * world * args.steps / elapsed
@@ -707,6 +738,7 @@ def main(argv=None, backend=None, tensor_device=None):
             "per_rank_ms_per_step": None if rank_times is None else [
                 {"step": t[0], "shard": t[1], "merge": t[2]} for t in rank_times],
             "roofline": roofline, "roofline_all_kernels": chain, "cpu_baseline": cpu, "kernels": kern_out, "legs": legs,
+            "wall_s_whole_run": round(time.perf_counter() - t_process0, 1),
         }
         print(json.dumps(out), flush=True)
     if distributed:

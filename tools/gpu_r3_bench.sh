@@ -14,6 +14,7 @@ print('roofline', d['roofline'])
 print('all', d['roofline_all_kernels'])
 print({k:(round(v['avg_ms'],4),v['launches'], round(v.get('hbm_GBps',0))) for k,v in d['kernels'].items()})
 for k,v in d['legs'].items():
+    if not isinstance(v, (dict, list)): print(k, v); continue
     if isinstance(v, list):
         for row in v: print(k, json.dumps(row)[:500])
         continue

@@ -96,19 +96,29 @@ def exact_groups(batches, limit_first_batch=None, dims=ALL_DIMS, d1_below=90):
     `limit_first_batch` rows of the first batch only).  Returns numpy arrays (code, sum, first_row, rows) of the groups."""
     dev = batches[0]["m"].blob.device
     space = key_space(dims)
-    acc = torch.zeros(space, dtype=torch.float64, device=dev)
-    cnt = torch.zeros(space, dtype=torch.int64, device=dev)
-    first = torch.full((space,), torch.iinfo(torch.int64).max, dtype=torch.int64, device=dev)
+    # A small key space is spread over `salt` sub-slots per key (row mod salt) and folded at the end: index_add_ /
+    # scatter_reduce_ are atomics, and 10^9 of them on ~100 addresses take minutes (the 153-group leg of bench.py
+    # spent 200 s here)
+    salt = 1 if space >= (1 << 20) else max(1, min(8192, (1 << 24) // space))
+    acc = torch.zeros(space * salt, dtype=torch.float64, device=dev)
+    cnt = torch.zeros(space * salt, dtype=torch.int64, device=dev)
+    first = torch.full((space * salt,), torch.iinfo(torch.int64).max, dtype=torch.int64, device=dev)
     offset = 0
     for b in (batches[:1] if limit_first_batch is not None else batches):
         c, keep, mm = _codes_of_batch(b, limit_first_batch, dims, d1_below)
+        rows = torch.arange(offset, offset + c.numel(), dtype=torch.int64, device=dev)[keep]
         idx = c[keep]
+        if salt > 1:
+            idx = idx * salt + rows % salt
         acc.index_add_(0, idx, mm[keep])
         cnt.index_add_(0, idx, torch.ones_like(idx))
-        rows = torch.arange(offset, offset + c.numel(), dtype=torch.int64, device=dev)[keep]
         first.scatter_reduce_(0, idx, rows, reduce="amin", include_self=True)
         offset += c.numel()
         del c, keep, mm, idx, rows
+    if salt > 1:
+        acc = acc.view(space, salt).sum(dim=1)
+        cnt = cnt.view(space, salt).sum(dim=1)
+        first = first.view(space, salt).amin(dim=1)
     live = torch.nonzero(cnt > 0).reshape(-1)
     return (live.cpu().numpy(), acc[live].cpu().numpy(), first[live].cpu().numpy(), cnt[live].cpu().numpy())
 

@@ -351,7 +351,7 @@ def main(argv=None, backend=None, tensor_device=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the secondary legs (fusion off, live batches, extension)")
     ap.add_argument("--legs", default="all", help="comma list of substrings: only the secondary legs whose name contains one of them")
-    ap.add_argument("--leg-budget", type=float, default=150.0,
+    ap.add_argument("--leg-budget", type=float, default=200.0,
                     help="seconds for the secondary legs (0 = no limit): they run in the order below until the budget is spent, "
                          "the rest is marked skipped; a leg that needs more than what is left is not started")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
@@ -708,7 +708,7 @@ def main(argv=None, backend=None, tensor_device=None):
                     legs["host_batches"]["leg_wall_s"] = round(time.perf_counter() - t0, 1)
                 except Exception as e:  # noqa: BLE001
                     legs["host_batches"] = {"error": f"{type(e).__name__}: {e}"}
-            tool_leg("c4_spec_1B_rows_50M_keys", "c4spec", 600, 120)
+            tool_leg("c4_spec_1B_rows_50M_keys", "c4spec", 600, 100)
             legs["legs_wall_s"] = round(time.perf_counter() - legs_t0, 1)
 
     if rank == 0:

@@ -1,0 +1,39 @@
+"""aresdb_amd/check.py is the key-level checker of bench.py and the scale tests: its exact group-by (torch, with the
+small key spaces of the low-cardinality legs spread over sub-slots) against a plain dictionary over the same rows."""
+import numpy as np
+import pytest
+import torch
+
+from aresdb_amd import check, workload
+
+
+@pytest.mark.parametrize("dims", [("ts", "d1", "d2", "d3"), ("d2", "d3"), ("d1",), ("ts", "d1")])
+def test_exact_groups_against_a_dictionary(dims):
+    batches = workload.c3_shard(30000, 12000, 5, torch.device("cpu"), null_fraction=0.05)
+    code, sums, first, rows = check.exact_groups(batches, dims=dims, d1_below=70)
+    want = {}
+    offset = 0
+    for b in batches:
+        cols = {n: (b[n].values().numpy(), None if b[n].valid() is None else b[n].valid().numpy()) for n in ("ts", "d1", "d2", "d3", "m")}
+        n = b["m"].length
+        for i in range(n):
+            d1, d1ok = cols["d1"][0][i], cols["d1"][1] is None or cols["d1"][1][i]
+            if not (d1ok and d1 < 70):
+                continue
+            key = []
+            for name in dims:
+                v, ok = cols[name]
+                valid = ok is None or bool(ok[i])
+                x = int(v[i]) // 3600 * 3600 if name == "ts" else int(v[i])  # the stored dimension value: the hourly bucket
+                key.append((x, True) if valid else (0, False))
+            mok = cols["m"][1] is None or cols["m"][1][i]
+            e = want.setdefault(tuple(key), [0.0, offset + i, 0])
+            e[0] += float(cols["m"][0][i]) if mok else 0.0
+            e[2] += 1
+        offset += n
+    values, valids = check.decode_codes(code, dims)
+    got = {tuple((int(values[d][g]), bool(valids[d][g])) if valids[d][g] else (0, False) for d in range(len(dims))): (sums[g], first[g], rows[g])
+           for g in range(len(code))}
+    assert set(got) == set(want) and len(want) > (50 if len(dims) > 1 else 20)
+    for k, (s, f, r) in got.items():
+        assert abs(s - want[k][0]) <= 1e-9 * max(1.0, abs(want[k][0])) and f == want[k][1] and r == want[k][2], k

@@ -77,17 +77,25 @@ __global__ __launch_bounds__(kThreads) void hr_fused_merge_kernel(FusedPlanD pla
 // the entry (grouped_note_write), the merge itself checks that every row it is handed hashes into
 // its partition (a mismatch makes the host redo the call the long way), and the feature is off unless
 // the sibling libmem.so reports frees and copies (deferral_hooks_active()).  ARES_GROUPED=0: off.
+// free range buffers per device.  Declared before the state table: the table's buffers return here when it is destroyed
+// at exit.  The mutex guards the free list only: taken by the buffers' deleter, possibly under g_groupedMutex, never
+// the other way round.
+std::mutex g_rangesMutex;
+std::vector<std::pair<int, uint32_t *>> g_freeRanges;
+
 struct GroupedState {
   int device;
   const uint8_t *dims;
   const uint8_t *values;
   size_t capacity;
   int nd, valueBytes, size, partBits;
-  uint32_t *ranges;  // kMaxPartitions x kRangeWords words of device memory
+  // kMaxPartitions x kRangeWords words of device memory.  Shared: a call that looked the state up keeps the buffer
+  // alive while its merge reads it, whatever another thread's eviction or overwrite does to the table meanwhile; the
+  // buffer goes back to the free list with the last reference.
+  std::shared_ptr<uint32_t> ranges;
 };
 std::mutex g_groupedMutex;
 std::vector<GroupedState> g_grouped;
-std::vector<std::pair<int, uint32_t *>> g_freeRanges;
 constexpr size_t kRangesBytes = sizeof(uint32_t) * kMaxPartitions * kRangeWords;
 
 bool grouped_enabled() {
@@ -95,25 +103,27 @@ bool grouped_enabled() {
   return on.get() && deferral_hooks_active();
 }
 
-uint32_t *take_ranges(int device) {
+std::shared_ptr<uint32_t> take_ranges(int device) {
+  uint32_t *p = nullptr;
   {
-    std::lock_guard<std::mutex> lock(g_groupedMutex);
+    std::lock_guard<std::mutex> lock(g_rangesMutex);
     for (size_t i = 0; i < g_freeRanges.size(); i++)
       if (g_freeRanges[i].first == device) {
-        uint32_t *p = g_freeRanges[i].second;
+        p = g_freeRanges[i].second;
         g_freeRanges[i] = g_freeRanges.back();
         g_freeRanges.pop_back();
-        return p;
+        break;
       }
   }
-  void *p = nullptr;
-  hip_check(hipMalloc(&p, kRangesBytes), "hipMalloc");
-  return static_cast<uint32_t *>(p);
-}
-void give_ranges(int device, uint32_t *p) {
-  if (!p) return;
-  std::lock_guard<std::mutex> lock(g_groupedMutex);
-  g_freeRanges.emplace_back(device, p);
+  if (!p) {
+    void *fresh = nullptr;
+    hip_check(hipMalloc(&fresh, kRangesBytes), "hipMalloc");
+    p = static_cast<uint32_t *>(fresh);
+  }
+  return std::shared_ptr<uint32_t>(p, [device](uint32_t *q) {
+    std::lock_guard<std::mutex> lock(g_rangesMutex);
+    g_freeRanges.emplace_back(device, q);
+  });
 }
 
 bool state_overlaps(const GroupedState &s, const uint8_t *lo, const uint8_t *hi) {
@@ -140,10 +150,7 @@ bool grouped_lookup(int device, const uint8_t *dims, const uint8_t *values, size
 
 void grouped_register(const GroupedState &s) {
   std::lock_guard<std::mutex> lock(g_groupedMutex);
-  if (g_grouped.size() >= 64) {  // a host that never frees: forget the oldest
-    g_freeRanges.emplace_back(g_grouped.front().device, g_grouped.front().ranges);
-    g_grouped.erase(g_grouped.begin());
-  }
+  if (g_grouped.size() >= 64) g_grouped.erase(g_grouped.begin());  // a host that never frees: forget the oldest
   g_grouped.push_back(s);
 }
 
@@ -244,7 +251,6 @@ void grouped_note_write(int device, const void *ptr, size_t bytes) {
   std::lock_guard<std::mutex> lock(g_groupedMutex);
   for (size_t i = 0; i < g_grouped.size();) {
     if (g_grouped[i].device == device && state_overlaps(g_grouped[i], lo, hi)) {
-      g_freeRanges.emplace_back(device, g_grouped[i].ranges);
       g_grouped.erase(g_grouped.begin() + i);
     } else {
       i++;
@@ -279,7 +285,9 @@ int hash_reduce_lds(int device, const DimensionVector &inputKeys, const uint8_t 
   GroupedState prev;
   bool grouped = all4 && grouped_lookup(device, inputKeys.DimValues, inputValues, capacity, L.numDims, a.width, &prev) &&
                  prev.partBits == partBits && prev.size > 0 && prev.size <= length;
-  uint32_t *outRanges = (all4 && grouped_enabled()) ? take_ranges(device) : nullptr;
+  // (the reference goes with this call unless the result is registered below: nothing leaks when a launch throws)
+  const std::shared_ptr<uint32_t> outRangesRef = (all4 && grouped_enabled()) ? take_ranges(device) : nullptr;
+  uint32_t *outRanges = outRangesRef.get();
   MergeResult res{0, 0, 0, 0};
   for (;;) {
     const int start = grouped ? prev.size : 0;
@@ -295,7 +303,7 @@ int hash_reduce_lds(int device, const DimensionVector &inputKeys, const uint8_t 
     make_regions(r, partBits, rows, rows, streams, rwB, stream, lean ? 8 : 0);
     Workspace &ws = r.ws;
     if (lean && a.width == 8) ws.widen.mode = 2;  // line records carry the whole 8-byte value
-    ws.prevRanges = grouped ? prev.ranges : nullptr;
+    ws.prevRanges = grouped ? prev.ranges.get() : nullptr;
     ws.outRanges = outRanges;
     // the specialised merge for these records (it writes every partition's range entry itself)
     RtcKernel leanMerge = lean ? rtc_vector_merge_lookup(device, L.numDims, a.width, partBits, a) : nullptr;
@@ -379,14 +387,12 @@ int hash_reduce_lds(int device, const DimensionVector &inputKeys, const uint8_t 
       told = true;
       fprintf(stderr, "libalgorithm: a hash-partition region overflowed (skewed hashes?): HashReduce falls back to the global table\n");
     }
-    give_ranges(device, outRanges);
     return -1;
   }
   if (outRanges) {
     GroupedState s{device, outputKeys.DimValues, outputValues, capacity, L.numDims, a.width, static_cast<int>(res.groups),
-                   partBits, outRanges};
+                   partBits, outRangesRef};
     if (res.groups > 0) grouped_register(s);
-    else give_ranges(device, outRanges);
   }
   return static_cast<int>(res.groups);
 }
@@ -412,7 +418,8 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
   GroupedState prev;
   bool grouped = prevSize > 0 && grouped_lookup(device, prevKeys.DimValues, prevValues, prevCapacity, nd, mw, &prev) &&
                  prev.partBits == partBits && prev.size == prevSize;
-  uint32_t *outRanges = grouped_enabled() ? take_ranges(device) : nullptr;
+  const std::shared_ptr<uint32_t> outRangesRef = grouped_enabled() ? take_ranges(device) : nullptr;
+  uint32_t *outRanges = outRangesRef.get();
   MergeResult res{0, 0, 0, 0};
   // Which scan.  A query that already has more groups than an LDS table serves well goes straight to DIRECT
   // mode: every surviving row becomes a record (compact lines when the batch's chunks fit the row field), with
@@ -454,7 +461,7 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
     ws.widen = widen;
     ws.chunkRows = static_cast<uint32_t>(chunkTiles) * 4096u;
     ws.rowBase = static_cast<uint32_t>(prevSize);
-    ws.prevRanges = grouped ? prev.ranges : nullptr;
+    ws.prevRanges = grouped ? prev.ranges.get() : nullptr;
     ws.outRanges = outRanges;
     Workspace wsPrev = ws;  // previous groups that are not grouped by partition: TABLE-mode pass into region A
     wsPrev.streams = 0;
@@ -524,7 +531,6 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
     break;
   }
   if (res.overflow) {
-    give_ranges(device, outRanges);
     return -1;
   }
   if (shape) {
@@ -542,9 +548,8 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
     }
   }
   if (outRanges) {
-    GroupedState s{device, outKeys.DimValues, outValues, outCapacity, nd, mw, static_cast<int>(res.groups), partBits, outRanges};
+    GroupedState s{device, outKeys.DimValues, outValues, outCapacity, nd, mw, static_cast<int>(res.groups), partBits, outRangesRef};
     if (res.groups > 0) grouped_register(s);
-    else give_ranges(device, outRanges);
   }
   return static_cast<int>(res.groups);
 }

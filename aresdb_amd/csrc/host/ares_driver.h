@@ -164,7 +164,7 @@ int AresQueryMergeShardsPartitioned(AresQuery *q, AresComm *c, int64_t *totalGro
 typedef struct {
   const void *host;  /* pinned host image of the column allocation: [counts][validity][values] */
   size_t bytes;
-  VectorPartySlice slice; /* BasePtr is ignored: offsets are relative to the allocation */
+  VectorPartySlice slice; /* offsets are relative to BasePtr, a byte offset into the host buffer (0 for a whole allocation) */
   uint64_t cacheKey;      /* identifies (table, batch, column) in the cache; 0 = never cache */
 } AresHostColumn;
 typedef struct AresColumnCache AresColumnCache;

@@ -34,3 +34,13 @@ def test_generated_kernels_compile_for_gfx950(tmp_path):
         notes = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", str(tmp_path / f"{tag}.co")], capture_output=True, text=True)
         if notes.returncode == 0 and ".private_segment_fixed_size" in notes.stdout:
             assert ".private_segment_fixed_size: 0" in notes.stdout, tag
+            # 1024 lanes per workgroup = 4 wavefronts per SIMD: at most 128 VGPRs each; one workgroup's LDS fits a CU's 160 KB
+            import re
+            vgprs = int(re.search(r"\.vgpr_count:\s+(\d+)", notes.stdout).group(1))
+            lds = int(re.search(r"\.group_segment_fixed_size:\s+(\d+)", notes.stdout).group(1))
+            assert vgprs <= 128 and lds <= 160 * 1024, (tag, vgprs, lds)
+    # murmur's h * 5 + c must not come back as the 64-bit multiply-add the compiler prefers (20 per tile and lane: 4 % of
+    # the compact scan, profiles/r3_experiments.md); a handful remain outside the tile loop
+    dis = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", "--mcpu=gfx950", str(tmp_path / "k_compact.co")], capture_output=True, text=True)
+    if dis.returncode == 0 and "v_mul_lo_u32" in dis.stdout:
+        assert dis.stdout.count("v_mad_u64_u32") <= 10, dis.stdout.count("v_mad_u64_u32")

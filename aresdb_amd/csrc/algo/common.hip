@@ -9,6 +9,7 @@
 namespace ares {
 
 std::atomic<uint32_t> g_envGeneration{1};
+thread_local CallStream t_callStream{nullptr, false};
 
 namespace {
 struct PinnedSlot {
@@ -56,7 +57,25 @@ std::map<std::pair<int, hipStream_t>, StreamCache> g_caches;
 // query — its temporaries carry over to the next query instead of going through hipFree / hipMalloc.
 std::map<int, StreamCache> g_orphans;
 std::map<void *, size_t> g_blockSize;  // every block handed out or cached -> rounded size
+std::map<void *, bool> g_handedOut;    // invariant check: a block is either in a cache or with exactly one user
 size_t g_cachedBytes = 0;
+
+void check_take(void *p) {  // caller holds g_cacheMutex
+  bool &out = g_handedOut[p];
+  if (out) {
+    fprintf(stderr, "libalgorithm: temporary block %p handed out twice\n", p);
+    abort();
+  }
+  out = true;
+}
+void check_give(void *p) {  // caller holds g_cacheMutex
+  auto it = g_handedOut.find(p);
+  if (it == g_handedOut.end() || !it->second) {
+    fprintf(stderr, "libalgorithm: temporary block %p released twice (or never taken)\n", p);
+    abort();
+  }
+  it->second = false;
+}
 
 size_t cache_bin(size_t bytes) {
   if (bytes < 256) return 256;
@@ -73,6 +92,7 @@ void drop_all_cached() {
       for (void *p : bin.second) {
         (void)hipFree(p);
         g_blockSize.erase(p);
+        g_handedOut.erase(p);
       }
     c.bins.clear();
     c.bytes = 0;
@@ -135,6 +155,7 @@ void stream_cache_purge(int device, hipStream_t stream) {
         for (void *p : bin.second) {
           blocks.push_back(p);
           g_blockSize.erase(p);
+          g_handedOut.erase(p);
         }
       g_cachedBytes -= it->second.bytes;
       g_caches.erase(it);
@@ -142,6 +163,11 @@ void stream_cache_purge(int device, hipStream_t stream) {
     for (void *p : blocks) (void)hipFree(p);
     return;
   }
+  static const bool destroySync = [] {  // diagnostics: is it the device-wide synchronisation that the old path had?
+    const char *e = getenv("ARES_DESTROY_SYNC");
+    return e && e[0] == '1';
+  }();
+  if (destroySync) (void)hipDeviceSynchronize();
   std::lock_guard<std::mutex> lock(g_cacheMutex);
   auto it = g_caches.find({device, stream});
   if (it == g_caches.end()) return;
@@ -165,6 +191,7 @@ void stream_cache_trim(int device) {
         for (void *p : bin.second) {
           blocks.push_back(p);
           g_blockSize.erase(p);
+          g_handedOut.erase(p);
         }
       kv.second.bins.clear();
       g_cachedBytes -= kv.second.bytes;
@@ -176,6 +203,7 @@ void stream_cache_trim(int device) {
         for (void *p : bin.second) {
           blocks.push_back(p);
           g_blockSize.erase(p);
+          g_handedOut.erase(p);
         }
       g_cachedBytes -= o->second.bytes;
       g_orphans.erase(o);
@@ -197,6 +225,7 @@ void *stream_alloc(size_t bytes, hipStream_t stream) {
       it->second.pop_back();
       c.bytes -= rounded;
       g_cachedBytes -= rounded;
+      check_take(p);
       return p;
     }
     auto o = g_orphans.find(device);
@@ -207,6 +236,7 @@ void *stream_alloc(size_t bytes, hipStream_t stream) {
         ob->second.pop_back();
         o->second.bytes -= rounded;
         g_cachedBytes -= rounded;
+        check_take(p);
         return p;
       }
     }
@@ -224,6 +254,7 @@ void *stream_alloc(size_t bytes, hipStream_t stream) {
   }
   std::lock_guard<std::mutex> lock(g_cacheMutex);
   g_blockSize[p] = rounded;
+  check_take(p);
   return p;
 }
 
@@ -237,6 +268,7 @@ void stream_release(void *ptr, hipStream_t stream) {
   auto it = g_blockSize.find(ptr);
   if (it == g_blockSize.end()) return;
   const size_t rounded = it->second;
+  check_give(ptr);
   StreamCache &c = g_caches[{device, stream}];
   c.bins[rounded].push_back(ptr);
   c.bytes += rounded;

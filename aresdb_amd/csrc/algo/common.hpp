@@ -63,6 +63,9 @@ bool pending_fill_exact(int device, const void *dst, size_t bytes, uint64_t *pat
 bool pending_fill_tail(int device, const void *base, int width, int length, int *prev, uint64_t *pattern);
 void retire_fills_for_write(int device, const void *ptr, size_t bytes);   // a kernel of the caller overwrites the range
 void materialize_fills_for_read(int device, const void *ptr, size_t bytes);  // a kernel of the caller reads the range
+// queued (or skipped) transforms whose outputs overlap [ptr, ptr + bytes) are launched now: for an entry point that reads
+// the range with a kernel but does not flush
+void launch_pending_writers(int device, const void *ptr, size_t bytes);
 // `indexVector` is defined as iota(0 .. n) and not written yet (InitIndexVector is lazy)
 bool virtual_iota_peek(int device, const uint32_t *indexVector, int n, bool consume = false);
 // the caller was handed `indexVector` and reads it with a kernel: a lazy iota a consumer left behind is written now
@@ -70,11 +73,33 @@ void materialize_index_vector(int device, const uint32_t *indexVector);
 // ... and the same for every buffer of a dimension vector (dimension rows, hash vector, index vector), lazy fills included
 void settle_dimension_vector(int device, const DimensionVector &v);
 
-// NOFLUSH: only for the transform entry points, which decide themselves whether to queue or flush
+// The stream of the entry point the calling thread is executing.  Work that was DEFINED on another stream (a lazy
+// fill, a lazy iota, a lazy compaction) and is written on that stream at one of this call's flush points is waited for
+// before the call's own kernels — which run on this stream — read it (transform.hip: order_before_caller).  Calls
+// that arrive from libmem.so (copies, frees) have no stream here: they wait for whatever they launch.
+struct CallStream {
+  hipStream_t stream;
+  bool known;
+};
+extern thread_local CallStream t_callStream;
+class CallStreamScope {
+ public:
+  explicit CallStreamScope(void *stream) : saved_(t_callStream) { t_callStream = CallStream{reinterpret_cast<hipStream_t>(stream), true}; }
+  ~CallStreamScope() { t_callStream = saved_; }
+  CallStreamScope(const CallStreamScope &) = delete;
+  CallStreamScope &operator=(const CallStreamScope &) = delete;
+
+ private:
+  CallStream saved_;
+};
+
+// NOFLUSH: only for the entry points which decide themselves whether to queue or flush.  Every entry point names its
+// stream parameter `cudaStream` (the reference's spelling).
 #define ARES_ABI_BEGIN_NOFLUSH(device)                 \
   CGoCallResHandle resHandle = {nullptr, nullptr};     \
   try {                                                \
     ares::hip_check(hipSetDevice(device), "hipSetDevice");  \
+    ares::CallStreamScope callStreamScope_(cudaStream);     \
     (void)ares::deferral_hooks_active(); /* write tracking is on before this entry point's first kernel */
 
 #define ARES_ABI_BEGIN(device)     \

@@ -1423,6 +1423,7 @@ std::string disk_dir() {
   return dir;
 }
 
+constexpr uint64_t kDiskMagic = 0x3143545253455241ull;  // "ARESRTC1"
 uint64_t fnv1a(const std::string &s, uint64_t h) {
   for (unsigned char c : s) {
     h ^= c;
@@ -1431,10 +1432,20 @@ uint64_t fnv1a(const std::string &s, uint64_t h) {
   return h;
 }
 
+// the options every kernel is compiled with (part of the on-disk cache key: a change here must not load old code)
+constexpr const char *kRtcOptions[] = {"-O3", "-std=c++17", "-munsafe-fp-atomics"};
+constexpr int kRtcOptionCount = 3;
+
 std::string disk_name(const std::string &arch, const std::string &source) {
-  int major = 0, minor = 0;
+  int major = 0, minor = 0, runtime = 0;
   if (rtc_api().version) (void)rtc_api().version(&major, &minor);
-  const std::string salt = arch + "|hiprtc " + std::to_string(major) + "." + std::to_string(minor) + "|";
+  if (hipRuntimeGetVersion(&runtime) != hipSuccess) {  // carries the patch level the hiprtc pair lacks
+    (void)hipGetLastError();
+    runtime = 0;
+  }
+  std::string salt = arch + "|hiprtc " + std::to_string(major) + "." + std::to_string(minor) + "|runtime " + std::to_string(runtime) + "|";
+  for (int k = 0; k < kRtcOptionCount; k++) salt += std::string(kRtcOptions[k]) + " ";
+  salt += "|";
   char b[48];
   snprintf(b, sizeof(b), "%016llx%016llx.co", static_cast<unsigned long long>(fnv1a(source, fnv1a(salt, 14695981039346656037ull))),
            static_cast<unsigned long long>(fnv1a(source, fnv1a(salt, 0x9e3779b97f4a7c15ull))));
@@ -1455,9 +1466,10 @@ bool compile_source(const std::string &source, const std::string &arch, const ch
   RtcProgram prog = nullptr;
   if (api.create(&prog, source.c_str(), "hr_rtc.hip", 0, nullptr, nullptr) != 0) return false;
   const std::string archOpt = "--offload-arch=" + arch;
-  const char *opts[] = {archOpt.c_str(), "-O3", "-std=c++17", "-munsafe-fp-atomics"};
+  const char *opts[1 + kRtcOptionCount] = {archOpt.c_str()};
+  for (int k = 0; k < kRtcOptionCount; k++) opts[1 + k] = kRtcOptions[k];
   bool ok = false;
-  if (api.compile(prog, 4, opts) == 0) {
+  if (api.compile(prog, 1 + kRtcOptionCount, opts) == 0) {
     size_t size = 0;
     if (api.codeSize(prog, &size) == 0 && size) {
       code.resize(size);
@@ -1487,15 +1499,22 @@ void build_entry(const std::shared_ptr<RtcEntry> &e, const std::string &source, 
     const std::string dir = disk_dir();
     const std::string path = dir.empty() ? std::string() : dir + "/" + disk_name(arch, source);
     std::vector<char> code;
-    if (!path.empty()) {
+    if (!path.empty()) {  // file = {magic, code bytes, FNV-1a of the code} + code: anything else is not trusted
       std::ifstream in(path, std::ios::binary | std::ios::ate);
       if (in) {
         const std::streamsize n = in.tellg();
-        if (n > 0) {
-          code.resize(static_cast<size_t>(n));
+        uint64_t head[3] = {0, 0, 0};
+        if (n > static_cast<std::streamsize>(sizeof(head))) {
           in.seekg(0);
-          if (!in.read(code.data(), n)) code.clear();
+          if (in.read(reinterpret_cast<char *>(head), sizeof(head)) && head[0] == kDiskMagic &&
+              head[1] == static_cast<uint64_t>(n) - sizeof(head)) {
+            code.resize(static_cast<size_t>(head[1]));
+            if (!in.read(code.data(), static_cast<std::streamsize>(code.size())) ||
+                fnv1a(std::string(code.data(), code.size()), 14695981039346656037ull) != head[2])
+              code.clear();
+          }
         }
+        if (code.empty()) (void)unlink(path.c_str());  // truncated, corrupted or of another format
       }
       if (!code.empty()) c.diskHits++;
     }
@@ -1515,7 +1534,9 @@ void build_entry(const std::shared_ptr<RtcEntry> &e, const std::string &source, 
     if (fresh && fn && !path.empty()) {  // publish atomically: write aside, then rename
       const std::string tmp = path + ".tmp" + std::to_string(static_cast<long>(getpid())) + "." + std::to_string(c.tick.load());
       std::ofstream out(tmp, std::ios::binary);
-      if (out && out.write(code.data(), static_cast<std::streamsize>(code.size())) && (out.close(), true)) {
+      const uint64_t head[3] = {kDiskMagic, static_cast<uint64_t>(code.size()), fnv1a(std::string(code.data(), code.size()), 14695981039346656037ull)};
+      if (out && out.write(reinterpret_cast<const char *>(head), sizeof(head)) && out.write(code.data(), static_cast<std::streamsize>(code.size())) &&
+          (out.close(), true)) {
         if (rename(tmp.c_str(), path.c_str()) != 0) (void)unlink(tmp.c_str());
       } else {
         (void)unlink(tmp.c_str());

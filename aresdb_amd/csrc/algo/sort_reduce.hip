@@ -710,10 +710,12 @@ static bool reduce_without_dimensions(int device, const DimensionVector &in, con
     return false;
   int prev = length;
   uint64_t c = 0;
-  if (!pending_fill_tail(device, inputValues, a.width, length, &prev, &c)) {
-    prev = length;  // every value row exists
-    materialize_fills_for_read(device, inputValues, static_cast<size_t>(a.width) * length);
-  } else if (prev > 0) {
+  if (!pending_fill_tail(device, inputValues, a.width, length, &prev, &c)) prev = length;  // every value row exists
+  if (prev > 0) {
+    // rows that exist are read by the kernel below: a measure transform over a COLUMN (SUM(col), MAX(col), ...) may
+    // still sit in the stream's queue — this entry point does not flush — and lazily defined rows below `prev`
+    // are written now
+    launch_pending_writers(device, inputValues, static_cast<size_t>(a.width) * prev);
     materialize_fills_for_read(device, inputValues, static_cast<size_t>(a.width) * prev);
   }
   retire_fills_for_write(device, outputValues, static_cast<size_t>(a.width));

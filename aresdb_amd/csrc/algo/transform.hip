@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <map>
 #include <memory>
@@ -1143,6 +1144,13 @@ struct DeferLock {
   }
 };
 
+// caller holds a DeferLock: something the calling entry point may read next was just launched on `producer`.  Kernels of
+// the call run on the call's own stream: when that is another stream (or unknown: the call came from libmem.so), the
+// producer is synchronised once the lock is released — before the caller launches anything.
+void order_before_caller(hipStream_t producer) {
+  if (!t_callStream.known || t_callStream.stream != producer) t_syncAfterUnlock.push_back(producer);
+}
+
 // Filters of the hot shape that have compacted an index vector since its InitIndexVector: with them
 // HashReduce can re-derive the survivors from the source columns instead of reading index, dimension
 // and measure vectors.  Any other writer of the index vector invalidates the entry.
@@ -1359,6 +1367,7 @@ void run_compaction(const uint32_t *idx) {
     ARES_LAUNCH("filter_compact_kernel", (filter_compact_kernel<uint32_t, false>), cgrid, kBlock, c.stream, c.pred, c.idx, 0u,
                 c.pad, cw, c.n, c.tiles);
   watch_error_word(c.device, c.stream, c.error, c.ws);
+  order_before_caller(c.stream);
   // (c.ws is released to the stream's cache when the last copy of the shared_ptr goes: behind the launch
   // and the copy of the error word)
 }
@@ -1366,6 +1375,60 @@ bool compaction_touches(const PendingCompact &c, const ByteRange &r) {
   const ByteRange ri{reinterpret_cast<const uint8_t *>(c.idx), reinterpret_cast<const uint8_t *>(c.idx) + 4ull * c.n};
   const ByteRange rp{c.pred, c.pred + c.n};
   return ri.overlaps(r) || rp.overlaps(r);
+}
+
+// ARES_FILTER_CHECK=<log file> (race hunting, see FilterCheck below): the bare-column jobs of a queue that was just
+// launched are checked against a copy of their column taken right behind the kernel; a mismatch is looked at again a
+// millisecond later — did the kernel read something that is no longer there (a writer racing with it) or is the column
+// itself not what the host uploaded?  Synchronises the queue's stream only.
+void transform_self_check(hipStream_t stream, const PendingQueue &q) {
+  static const char *path = getenv("ARES_FILTER_CHECK");
+  if (!path || !path[0] || q.n <= 0 || q.n > (1 << 20)) return;
+  const size_t n = static_cast<size_t>(q.n);
+  std::vector<uint32_t> idx(q.idx ? n : 0), out(n), vals, vals2;
+  std::vector<uint8_t> outOk(n), nulls, nulls2;
+  if (hipStreamSynchronize(stream) != hipSuccess) return;
+  if (q.idx && hipMemcpyAsync(idx.data(), q.idx, 4 * n, hipMemcpyDeviceToHost, stream) != hipSuccess) return;
+  for (int j = 0; j < q.jobs.count; j++) {
+    const FastOperands &f = q.jobs.f[j];
+    const SinkD &sk = q.jobs.s[j];
+    if (f.arity != 1 || sk.type == SINK_MEASURE || sk.width != 4 || !sk.nulls || f.akind == K_F32 || f.I == K_F32) continue;
+    const size_t rows = q.colRows[j], nb = f.nulls ? (rows + f.bitOff + 7) / 8 : 0;
+    vals.resize(rows); vals2.resize(rows); nulls.resize(nb); nulls2.resize(nb);
+    (void)hipMemcpyAsync(vals.data(), f.vals, 4 * rows, hipMemcpyDeviceToHost, stream);
+    if (nb) (void)hipMemcpyAsync(nulls.data(), f.nulls, nb, hipMemcpyDeviceToHost, stream);
+    (void)hipMemcpyAsync(out.data(), sk.values, 4 * n, hipMemcpyDeviceToHost, stream);
+    (void)hipMemcpyAsync(outOk.data(), sk.nulls, n, hipMemcpyDeviceToHost, stream);
+    if (hipStreamSynchronize(stream) != hipSuccess) return;
+    long bad = 0, firstBad = -1;
+    for (size_t i = 0; i < n; i++) {
+      const uint32_t row = q.idx ? idx[i] : static_cast<uint32_t>(i);
+      if (row >= rows) continue;
+      const uint32_t ok = nb ? (nulls[(row + f.bitOff) >> 3] >> ((row + f.bitOff) & 7)) & 1u : 1u;
+      if (out[i] != vals[row] || (outOk[i] != 0) != (ok != 0)) {
+        if (firstBad < 0) firstBad = static_cast<long>(i);
+        bad++;
+      }
+    }
+    if (!bad) continue;
+    usleep(1000);
+    (void)hipMemcpyAsync(vals2.data(), f.vals, 4 * rows, hipMemcpyDeviceToHost, stream);
+    if (nb) (void)hipMemcpyAsync(nulls2.data(), f.nulls, nb, hipMemcpyDeviceToHost, stream);
+    (void)hipStreamSynchronize(stream);
+    long colChanged = 0;
+    for (size_t r = 0; r < rows; r++) colChanged += vals[r] != vals2[r];
+    for (size_t b = 0; b < nb; b++) colChanged += nulls[b] != nulls2[b];
+    static std::mutex logMutex;
+    std::lock_guard<std::mutex> lock(logMutex);
+    if (FILE *o = fopen(path, "a")) {
+      const uint32_t row = q.idx ? idx[firstBad] : static_cast<uint32_t>(firstBad);
+      fprintf(o, "TRANSFORMCHECK MISMATCH job %d/%d n %d colRows %zu idx %p vals %p nulls %p out %p stream %p: %ld positions differ, first %ld "
+                 "(row %u: out %u ok %u, column %u then %u); column bytes that changed within 1 ms: %ld\n",
+              j, q.jobs.count, q.n, rows, (const void *)q.idx, (const void *)f.vals, (const void *)f.nulls, (const void *)sk.values, (void *)stream, bad,
+              firstBad, row, out[firstBad], outOk[firstBad], vals[row], vals2[row], colChanged);
+      fclose(o);
+    }
+  }
 }
 
 // caller holds the device's DeferLock and has selected the device.  inOrder: the launch is part of the
@@ -1393,6 +1456,7 @@ void launch_queue(hipStream_t stream, PendingQueue &q, bool inOrder = false) {
     const int device = current_device();
     for (const ByteRange &w : q.writes) mem_note_write(device, w.lo, static_cast<size_t>(w.hi - w.lo));
   }
+  transform_self_check(stream, q);
   q.jobs.count = 0;
   q.reads.clear();
   q.writes.clear();
@@ -1430,6 +1494,7 @@ static void launch_init_index(uint32_t *indexVector, uint32_t start, int n, hipS
   const int64_t quads = (static_cast<int64_t>(n) + 3) / 4;
   const int grid = capped_grid((quads + kBlock - 1) / kBlock, 256 * 16);
   ARES_LAUNCH("init_index_kernel", init_index_kernel, grid, kBlock, stream, indexVector, start, n);
+  order_before_caller(stream);  // (a lazy iota written at another stream's flush point)
 }
 
 // ---- lazy fills -----------------------------------------------------------------------------------------
@@ -1447,6 +1512,7 @@ static void launch_fill(uint8_t *dst, const PendingFill &f) {
   const size_t units = f.bytes / static_cast<size_t>(f.unit);
   ARES_LAUNCH("fill_pattern_kernel", fill_pattern_kernel, capped_grid(static_cast<int64_t>((units + kBlock - 1) / kBlock), 256 * 8), kBlock,
               f.stream, dst, units, f.pattern, f.unit);
+  order_before_caller(f.stream);  // whoever made us write it reads (or overwrites) it next, maybe on another stream
 }
 
 // caller holds the device's DeferLock: every lazy fill of the device (r == nullptr) or those that overlap r are
@@ -1979,6 +2045,166 @@ static int run_transform(const InputVector *ins, int arity, const OutputVector &
   return n;
 }
 
+// ---- ARES_FILTER_CHECK=<log file>: diagnostics for the two-phase filter (race hunting) -----------------------
+// Around the real predicate kernel the inputs (index vector, column values, validity bitmap) are copied to pinned
+// host memory on the SAME stream before and after it, the kernel is run a second time into scratch outputs, and
+// once the call's own read-back has synchronised the stream everything is compared: the two runs with each other,
+// the two input snapshots with each other, and a host evaluation of the predicate with both.  Same-stream work
+// only: nothing here synchronises the device or another stream.
+namespace {
+struct FilterCheckBuffers {
+  static constexpr int kMaxRows = 1 << 20;
+  uint8_t *dPred2 = nullptr;
+  uint32_t *dCounts2 = nullptr;  // [tile counts ... ][partials ...]
+  uint32_t *hIdx[2] = {nullptr, nullptr}, *hVals[2] = {nullptr, nullptr};
+  uint8_t *hNulls[2] = {nullptr, nullptr}, *hPred[2] = {nullptr, nullptr};
+  uint32_t *hParts2 = nullptr;
+  bool ok = false;
+  FilterCheckBuffers() {
+    bool good = hipMalloc(reinterpret_cast<void **>(&dPred2), kMaxRows + 64) == hipSuccess &&
+                hipMalloc(reinterpret_cast<void **>(&dCounts2), 4 * (kMaxRows / 4096 + 2 + 4096 + 16)) == hipSuccess;
+    for (int k = 0; k < 2 && good; k++) {
+      good = good && hipHostMalloc(reinterpret_cast<void **>(&hIdx[k]), 4ull * kMaxRows + 64, hipHostMallocPortable) == hipSuccess;
+      good = good && hipHostMalloc(reinterpret_cast<void **>(&hVals[k]), 4ull * kMaxRows + 64, hipHostMallocPortable) == hipSuccess;
+      good = good && hipHostMalloc(reinterpret_cast<void **>(&hNulls[k]), kMaxRows / 8 + 64, hipHostMallocPortable) == hipSuccess;
+      good = good && hipHostMalloc(reinterpret_cast<void **>(&hPred[k]), kMaxRows + 64, hipHostMallocPortable) == hipSuccess;
+    }
+    good = good && hipHostMalloc(reinterpret_cast<void **>(&hParts2), 4 * 4096 + 64, hipHostMallocPortable) == hipSuccess;
+    ok = good;
+    if (!good) (void)hipGetLastError();
+  }
+};
+const char *filter_check_path() {
+  static const char *p = getenv("ARES_FILTER_CHECK");
+  return (p && p[0]) ? p : nullptr;
+}
+uint32_t host_compare_fast(const FastOperands &f, uint32_t bits, uint32_t ok) {
+  auto asf = [](uint32_t b) { float x; memcpy(&x, &b, 4); return x; };
+  const uint32_t x = host_cvt32(bits, f.akind, f.I), y = host_cvt32(f.bbits, f.bkind, f.I);
+  const int ft = f.functor;
+  bool c;
+  if (f.I == K_F32) {
+    const float a = asf(x), b = asf(y);
+    c = ft == Equal ? a == b : ft == NotEqual ? a != b : ft == LessThan ? a < b : ft == LessThanOrEqual ? a <= b : ft == GreaterThan ? a > b : a >= b;
+  } else if (f.I == K_I32) {
+    const int32_t a = static_cast<int32_t>(x), b = static_cast<int32_t>(y);
+    c = ft == Equal ? a == b : ft == NotEqual ? a != b : ft == LessThan ? a < b : ft == LessThanOrEqual ? a <= b : ft == GreaterThan ? a > b : a >= b;
+  } else {
+    c = ft == Equal ? x == y : ft == NotEqual ? x != y : ft == LessThan ? x < y : ft == LessThanOrEqual ? x <= y : ft == GreaterThan ? x > y : x >= y;
+  }
+  return (ok && f.bok && c) ? 1u : 0u;
+}
+struct FilterCheck {
+  FilterCheckBuffers *b = nullptr;
+  FastOperands f;
+  uint32_t colRows = 0;
+  int n = 0, tiles = 0, predGrid = 0;
+  size_t nullBytes = 0;
+  const uint8_t *pred = nullptr;
+  hipStream_t stream = nullptr;
+  bool active = false;
+  void snapshot(int k) {
+    if (f.idx) (void)hipMemcpyAsync(b->hIdx[k], f.idx, 4ull * n, hipMemcpyDeviceToHost, stream);
+    (void)hipMemcpyAsync(b->hVals[k], f.vals, 4ull * colRows, hipMemcpyDeviceToHost, stream);
+    if (f.nulls) (void)hipMemcpyAsync(b->hNulls[k], f.nulls, nullBytes, hipMemcpyDeviceToHost, stream);
+  }
+  void begin(const FastOperands &fo, uint32_t rows, int n_, int tiles_, int predGrid_, const uint8_t *pred_, hipStream_t s) {
+    if (!filter_check_path() || n_ > FilterCheckBuffers::kMaxRows || rows > static_cast<uint32_t>(FilterCheckBuffers::kMaxRows)) return;
+    thread_local FilterCheckBuffers bufs;
+    if (!bufs.ok) return;
+    b = &bufs;
+    f = fo;
+    colRows = rows;
+    n = n_;
+    tiles = tiles_;
+    predGrid = predGrid_;
+    pred = pred_;
+    stream = s;
+    nullBytes = f.nulls ? (static_cast<size_t>(colRows) + f.bitOff + 7) / 8 : 0;
+    active = true;
+    snapshot(0);
+  }
+  // right behind the real kernel, before anything rewrites the index vector
+  void after_kernel() {
+    if (!active) return;
+    snapshot(1);
+    (void)hipMemcpyAsync(b->hPred[0], pred, static_cast<size_t>(n), hipMemcpyDeviceToHost, stream);
+    (void)hipMemsetAsync(b->dCounts2, 0, 4ull * (tiles + predGrid + 4), stream);
+    // pred2 keeps the alignment phase of pred: the kernel's quad grid depends on it
+    uint8_t *pred2 = b->dPred2 + (reinterpret_cast<uintptr_t>(pred) & 3) + ((4 - (reinterpret_cast<uintptr_t>(b->dPred2) & 3)) & 3);
+    hipLaunchKernelGGL(filter_pred_kernel, dim3(predGrid), dim3(kBlock), 0, stream, f, pred2, b->dCounts2, n, tiles, b->dCounts2 + tiles + 2);
+    (void)hipMemcpyAsync(b->hPred[1], pred2, static_cast<size_t>(n), hipMemcpyDeviceToHost, stream);
+    (void)hipMemcpyAsync(b->hParts2, b->dCounts2 + tiles + 2, 4ull * predGrid, hipMemcpyDeviceToHost, stream);
+  }
+  // the stream has been synchronised by the call's own read-back
+  void finish(uint32_t count1) {
+    if (!active) return;
+    (void)hipStreamSynchronize(stream);
+    uint32_t count2 = 0;
+    for (int k = 0; k < predGrid; k++) count2 += b->hParts2[k];
+    uint32_t countHost[2] = {0, 0}, countPred[2] = {0, 0};
+    int firstIdxDiff = -1, idxDiffs = 0, firstValDiff = -1, valDiffs = 0, firstNullDiff = -1, nullDiffs = 0, firstPredDiff = -1, predDiffs = 0;
+    int firstHostDiff[2] = {-1, -1}, hostDiffs[2] = {0, 0};
+    for (int i = 0; i < n; i++) {
+      countPred[0] += b->hPred[0][i] != 0;
+      countPred[1] += b->hPred[1][i] != 0;
+      if (b->hPred[0][i] != b->hPred[1][i]) { if (firstPredDiff < 0) firstPredDiff = i; predDiffs++; }
+      if (f.idx && b->hIdx[0][i] != b->hIdx[1][i]) { if (firstIdxDiff < 0) firstIdxDiff = i; idxDiffs++; }
+      for (int k = 0; k < 2; k++) {
+        const uint32_t row = f.idx ? b->hIdx[k][i] : static_cast<uint32_t>(i);
+        uint32_t e = 0;
+        if (row < colRows) {
+          const uint32_t ok = f.nulls ? (b->hNulls[k][(row + f.bitOff) >> 3] >> ((row + f.bitOff) & 7)) & 1u : 1u;
+          e = host_compare_fast(f, b->hVals[k][row], ok);
+        }
+        countHost[k] += e;
+        if ((e != 0) != (b->hPred[0][i] != 0)) { if (firstHostDiff[k] < 0) firstHostDiff[k] = i; hostDiffs[k]++; }
+      }
+    }
+    for (uint32_t r = 0; r < colRows; r++)
+      if (b->hVals[0][r] != b->hVals[1][r]) { if (firstValDiff < 0) firstValDiff = static_cast<int>(r); valDiffs++; }
+    for (size_t k = 0; k < nullBytes; k++)
+      if (b->hNulls[0][k] != b->hNulls[1][k]) { if (firstNullDiff < 0) firstNullDiff = static_cast<int>(k); nullDiffs++; }
+    const bool bad = count1 != count2 || count1 != countPred[0] || predDiffs || idxDiffs || valDiffs || nullDiffs || hostDiffs[0] || hostDiffs[1];
+    static std::mutex logMutex;
+    std::lock_guard<std::mutex> lock(logMutex);
+    FILE *out = fopen(filter_check_path(), "a");
+    if (!out) return;
+    static long calls = 0;
+    calls++;
+    if (bad) {
+      fprintf(out, "FILTERCHECK MISMATCH call %ld n %d colRows %u idx %p vals %p nulls %p bitOff %u pred %p stream %p functor %d I %d akind %d bbits %u: "
+                   "count1 %u count2 %u countPred %u/%u countHost %u/%u predDiffs %d (first %d) idxDiffs %d (first %d) valDiffs %d (first %d) "
+                   "nullDiffs %d (first byte %d) hostVsPred %d/%d (first %d/%d)\n",
+              calls, n, colRows, (const void *)f.idx, (const void *)f.vals, (const void *)f.nulls, f.bitOff, (const void *)pred, (void *)stream, f.functor, f.I,
+              f.akind, f.bbits, count1, count2, countPred[0], countPred[1], countHost[0], countHost[1], predDiffs, firstPredDiff, idxDiffs,
+              firstIdxDiff, valDiffs, firstValDiff, nullDiffs, firstNullDiff, hostDiffs[0], hostDiffs[1], firstHostDiff[0], firstHostDiff[1]);
+      int shown = 0;
+      for (int i = 0; i < n && shown < 16; i++) {
+        const bool d = b->hPred[0][i] != b->hPred[1][i] || (f.idx && b->hIdx[0][i] != b->hIdx[1][i]);
+        bool hd = false;
+        uint32_t rows[2], vals[2] = {0, 0}, oks[2] = {1, 1};
+        for (int k = 0; k < 2; k++) {
+          rows[k] = f.idx ? b->hIdx[k][i] : static_cast<uint32_t>(i);
+          if (rows[k] < colRows) {
+            vals[k] = b->hVals[k][rows[k]];
+            oks[k] = f.nulls ? (b->hNulls[k][(rows[k] + f.bitOff) >> 3] >> ((rows[k] + f.bitOff) & 7)) & 1u : 1u;
+            hd = hd || ((host_compare_fast(f, vals[k], oks[k]) != 0) != (b->hPred[0][i] != 0));
+          }
+        }
+        if (d || hd) {
+          fprintf(out, "  pos %d: pred %u/%u row %u/%u val %u/%u ok %u/%u\n", i, b->hPred[0][i], b->hPred[1][i], rows[0], rows[1], vals[0], vals[1], oks[0], oks[1]);
+          shown++;
+        }
+      }
+    } else if (calls % 2000 == 1) {
+      fprintf(out, "filtercheck ok: %ld calls so far\n", calls);
+    }
+    fclose(out);
+  }
+};
+}  // namespace
+
 static int run_filter(const InputVector *ins, int arity, uint32_t *indexVector, uint8_t *pred, int n,
                       RecordID **recordIDVectors, int numForeignTables, uint32_t *baseCounts, uint32_t startCount,
                       int functor, hipStream_t stream, int device) {
@@ -2056,8 +2282,11 @@ static int run_filter(const InputVector *ins, int arity, uint32_t *indexVector, 
     static EnvSwitch<bool> lazyScan("ARES_FILTER_LAZY_SCAN", [](const char *e) { return !(e && e[0] == '0'); });
     const bool scanLater = lazy && lazyScan.get();
     uint32_t *partials = loaded + static_cast<size_t>(tiles) * passes;
+    FilterCheck check;
+    check.begin(f, p.a.length, n, tiles, predGrid, pred, stream);
     ARES_LAUNCH("filter_pred_kernel", filter_pred_kernel, predGrid, kBlock, stream, f, pred, tileCounts, n, tiles,
                 scanLater ? partials : nullptr);
+    check.after_kernel();
     if (!scanLater) ARES_LAUNCH("filter_scan_kernel", filter_scan_kernel, 1, 1024, stream, tileCounts, tileOffsets, tiles, total);
     if (lazy) {
       // The count is known; the compaction waits until somebody needs the compacted vector — a
@@ -2088,6 +2317,7 @@ static int run_filter(const InputVector *ins, int arity, uint32_t *indexVector, 
         c.tileCounts = tileCounts;
         c.total = total;
       }
+      check.finish(result[0]);
       DeferLock lock(device);
       t_state->compactions[indexVector] = c;
       return static_cast<int>(result[0]);
@@ -2114,6 +2344,7 @@ static int run_filter(const InputVector *ins, int arity, uint32_t *indexVector, 
     }
     uint32_t result[2] = {0, 0};  // {survivors, error}
     read_back_u32(total, result, 2, stream);
+    check.finish(result[0]);
     if (result[1]) throw AlgorithmError("ERROR: filter: compaction wait timed out");
     return static_cast<int>(result[0]);
   }
@@ -2415,6 +2646,26 @@ void hook_on_stream_destroy(int device, void *streamPtr) {
   }
 }
 }  // namespace
+
+// An entry point reads [ptr, ptr + bytes) with a kernel without going through a flush (Reduce over zero dimensions
+// keeps everything else lazy): queued transforms that write into the range, and work a HashReduce skipped there, run
+// first — in call order, on their own stream (a queue the host has already waited for is synchronised after its late
+// launch, the blocks held for it are fenced behind it).
+void launch_pending_writers(int device, const void *ptr, size_t bytes) {
+  if (!ptr || bytes == 0 || !defer_available()) return;
+  const ByteRange r = range_of(ptr, bytes);
+  ReleaseSet released;
+  {
+    DeferLock lock(device);
+    for (auto &kv : t_state->pending) {
+      if (kv.first.first != device || kv.second.jobs.count == 0 || !touches(kv.second.writes, r)) continue;
+      if (kv.second.overWait) released.add(kv.first.second);
+      launch_queue(kv.first.second, kv.second);
+    }
+    materialize_limbo(device, &r, &released);
+  }
+  released.run(device);
+}
 
 // HashReduce's first move: when the stream's pending queue is exactly "the dimension columns and the
 // measure of rows [prev, prev + n) of inputKeys / inputValues", evaluate it on the fly (the fused

@@ -994,6 +994,9 @@ struct LocalHub {
   std::vector<const void *> send;
   int (*copyAsync)(void *, const void *, size_t, int, void *) = nullptr;  // hipMemcpyAsync(dst, src, n, hipMemcpyDefault, stream)
   int (*streamSync)(void *) = nullptr;
+  // a rank that failed inside a collective says so here: every rank passes both barriers of the collective whatever
+  // happened to it (a rank that left early would leave the others waiting forever) and returns non-zero when any failed
+  std::atomic<int> failed{0};
   void barrier() {
     std::unique_lock<std::mutex> lock(m);
     const uint64_t my = phase;
@@ -1014,18 +1017,21 @@ struct LocalRank {
 int local_all_gather(void *user, const void *send, void *recv, size_t bytesPerRank, void *stream) {
   LocalRank *me = static_cast<LocalRank *>(user);
   LocalHub *h = me->hub;
-  if (h->streamSync && h->streamSync(stream) != 0) return 1;  // what this rank contributes has been produced
+  int rc = 0;
+  if (h->streamSync && h->streamSync(stream) != 0) rc = 1;  // what this rank contributes has been produced
+  if (rc) h->failed.store(1);
   h->send[me->rank] = send;
   h->barrier();
-  int rc = 0;
-  for (int r = 0; r < h->nranks && rc == 0; r++) {
+  const bool go = h->failed.load() == 0;  // (written before the barrier every rank has passed)
+  for (int r = 0; r < h->nranks && rc == 0 && go; r++) {
     uint8_t *dst = static_cast<uint8_t *>(recv) + bytesPerRank * r;
     if (h->copyAsync) rc = h->copyAsync(dst, h->send[r], bytesPerRank, /*hipMemcpyDefault*/ 4, stream);
     else memcpy(dst, h->send[r], bytesPerRank);
   }
-  if (rc == 0 && h->streamSync) rc = h->streamSync(stream);  // nobody frees a block a peer is still reading
+  if (rc == 0 && go && h->streamSync) rc = h->streamSync(stream);  // nobody frees a block a peer is still reading
+  if (rc) h->failed.store(1);
   h->barrier();
-  return rc;
+  return (rc || h->failed.load()) ? 1 : 0;  // sticky: a communicator that failed once stays failed
 }
 }  // namespace
 
@@ -1086,10 +1092,12 @@ void AresCommDestroy(AresComm *c) {
 // every rank then feeds the OTHER ranks' entries to the library's own HyperLogLog call as one more batch — with
 // isLastBatch = 1 — behind its own state: the call keeps the maximum rho per (group, register), which is the
 // register-max merge of the broker (broker/result_merge.go:95-104, query/common/hll.go:148), and encodes the
-// final dense / sparse vector.  Every rank ends with the same result.
+// final dense / sparse vector.  Every rank ends with the same set of (group, register) entries and therefore the same
+// encoded registers per group; the ORDER of the groups in the result is rank dependent (a rank's own groups come first).
 static int merge_shards_hll(AresQuery *q, AresComm *c) {
-  if (q->isLastBatch || q->hllVector)
-    throw AbiError("HyperLogLog shard merge needs the shard's intermediate entries: run every batch with isLastBatch = 0, the merge finalises");
+  // precondition, agreed on by every rank before anybody leaves: a rank that threw ahead of the first collective would
+  // leave the others waiting in it
+  const bool unfit = q->isLastBatch || q->hllVector;
   std::vector<int> widths;
   for (int k = 0; k < NUM_DIM_WIDTH; k++)
     for (int j = 0; j < q->ndw[k]; j++) widths.push_back(kDimWidths[k]);
@@ -1099,7 +1107,19 @@ static int merge_shards_hll(AresQuery *q, AresComm *c) {
   const int64_t rowBytes = valueBytes + nd + mb;
   std::vector<int64_t> sizes(world, 0);
   const int64_t mine = q->resultSize;
-  gather_words(q, c, &mine, sizes.data(), sizeof(int64_t));
+  {
+    std::vector<int64_t> pairs(2 * static_cast<size_t>(world), 0);
+    const int64_t me[2] = {mine, unfit ? 1 : 0};
+    gather_words(q, c, me, pairs.data(), 2 * sizeof(int64_t));
+    bool anyUnfit = false;
+    for (int r = 0; r < world; r++) {
+      sizes[r] = pairs[2 * r];
+      anyUnfit = anyUnfit || pairs[2 * r + 1] != 0;
+    }
+    if (anyUnfit)
+      throw AbiError(unfit ? "HyperLogLog shard merge needs the shard's intermediate entries: run every batch with isLastBatch = 0, the merge finalises"
+                           : "HyperLogLog shard merge: another rank's shard was already finalised (isLastBatch = 1 before the merge)");
+  }
   int64_t gmax = 1, others = 0;
   for (int r = 0; r < world; r++) {
     gmax = std::max(gmax, sizes[r]);

@@ -376,6 +376,10 @@ hipError_t pool_alloc(DeviceState *st, void **p, size_t bytes, bool zero) {
   }
   {
     std::lock_guard<std::mutex> lock(st->mu);
+    if (st->live.count(reinterpret_cast<uintptr_t>(ptr))) {  // invariant: a block has one owner
+      fprintf(stderr, "libmem: block %p (%zu bytes) was about to be handed out while it is still live\n", ptr, rounded);
+      abort();
+    }
     LiveBlock &b = st->live[reinterpret_cast<uintptr_t>(ptr)];
     b.rounded = rounded;
     b.dirty.clear();
@@ -430,7 +434,15 @@ hipError_t pool_free(DeviceState *st, void *p) {
   if (!use_pool()) return hipFree(p);
   std::lock_guard<std::mutex> lock(st->mu);
   auto it = st->live.find(reinterpret_cast<uintptr_t>(p));
-  if (it == st->live.end()) return hipFree(p);  // not ours (allocated before the pool was switched on)
+  if (it == st->live.end()) {  // not ours (allocated before the pool was switched on) — or freed twice
+    for (auto &bin : st->bins)
+      for (const ParkedBlock &pb : bin.second)
+        if (pb.ptr == p) {
+          fprintf(stderr, "libmem: block %p freed twice (it is parked in the cache)\n", p);
+          abort();
+        }
+    return hipFree(p);
+  }
   const size_t rounded = it->second.rounded;
   std::vector<std::pair<size_t, size_t>> written;
   if (it->second.allDirty || !g_writeTracking.load(std::memory_order_acquire)) written.emplace_back(0, rounded);
@@ -475,6 +487,12 @@ hipError_t pool_free(DeviceState *st, void *p) {
       return hipFree(p);  // (synchronises the device: whatever was enqueued has run)
     }
   }
+  static const bool syncFree = [] {  // diagnostics: a parked block is quiescent (fence and fill complete) before the free returns
+    const char *e = getenv("ARES_MEM_SYNC_FREE");
+    return e && e[0] == '1';
+  }();
+  if (syncFree)
+    for (hipEvent_t e : b.fence) (void)hipEventSynchronize(e);
   st->bins[rounded].push_back(b);
   st->parkedBytes += rounded;
   // the cache stays below a quarter of the device (the figure is read once per device, not per free)

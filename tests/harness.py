@@ -156,6 +156,7 @@ class Column:
             blob[co:co + len(cbytes)] = cbytes
             blob[no:no + len(nbytes_)] = nbytes_
             blob[vo:vo + len(vbytes)] = vbytes
+            self.blob = blob  # what was uploaded (diagnostics compare the device copy with it)
             self.buf = Buf(be, blob)
             if counts is not None:      # mode 3
                 vp.BasePtr, vp.NullsOffset, vp.ValuesOffset = self.buf.ptr, no, vo

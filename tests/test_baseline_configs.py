@@ -92,10 +92,11 @@ def test_c4_join_high_cardinality_sort_reduce():
         b.free()
 
 
-def _run_zero_dim_sequence(be, agg, mtype, mb, const):
+def _run_zero_dim_sequence(be, agg, mtype, mb, const, measure_column=None, with_filter=True, wait_before_reduce=True):
     """The ABI call sequence of an aggregate without dimensions over several batches (the measure is a literal:
-    COUNT(*) is SUM over 1, query/aql_compiler.go:1191-1197), with EVERY buffer the host could look at copied back at
-    some point: before the reduction, between Sort and Reduce, after the reduction."""
+    COUNT(*) is SUM over 1, query/aql_compiler.go:1191-1197 — or, measure_column = a data type, a COLUMN: SUM(col),
+    MAX(col)), with EVERY buffer the host could look at copied back at some point: before the reduction, between Sort
+    and Reduce, after the reduction."""
     rng = np.random.default_rng(123)
     ndw = (0, 0, 0, 0, 0)
     cap = 40000
@@ -116,18 +117,25 @@ def _run_zero_dim_sequence(be, agg, mtype, mb, const):
     for b, n in enumerate([9000, 1, 12000, 7, 3000]):
         vals = rng.integers(0, 1000, n).astype(np.uint32)
         col = H.Column(be, abi.Uint32, vals, valid=rng.random(n) > 0.1)
+        mcol = None
+        if measure_column is not None:
+            mvals = rng.integers(-500, 500, n) if measure_column == abi.Int32 else rng.integers(0, 1000, n)
+            mcol = H.Column(be, measure_column, mvals, valid=rng.random(n) > 0.1)
         idx, pred = H.Buf(be, nbytes=4 * n), H.Buf(be, nbytes=n)
         be.call("InitIndexVector", idx.ptr, 0, n, None, 0)
-        size = be.call("BinaryFilter", col.input(), H.const_int(600), idx.ptr, pred.ptr, n, None, 0, None, 0, abi.LessThan, None, 0)
+        size = n
+        if with_filter:
+            size = be.call("BinaryFilter", col.input(), H.const_int(600), idx.ptr, pred.ptr, n, None, 0, None, 0, abi.LessThan, None, 0)
         obs.append(("size", b, size))
         if size:
-            be.call("UnaryTransform", H.const_int(const), H.measure_output(meas[0].ptr + mb * result, mtype, agg), idx.ptr, size, None, 0,
-                    abi.Noop, None, 0)
-        be.wait()
-        if b == 2:  # the index vector and the measure rows, looked at before the reduction
+            be.call("UnaryTransform", mcol.input() if mcol else H.const_int(const), H.measure_output(meas[0].ptr + mb * result, mtype, agg),
+                    idx.ptr, size, None, 0, abi.Noop, None, 0)
+        if wait_before_reduce:
+            be.wait()
+        if b == 2 and measure_column is None:  # the index vector and the measure rows, looked at before the reduction
             obs.append(("idx", b, idx.read(np.uint32, size).tobytes()))
             obs.append(("rows", b, meas[0].read(np.uint8, mb * size, offset=mb * result).tobytes()))
-        for x in (col, idx, pred):
+        for x in (col, idx, pred) + ((mcol,) if mcol else ()):
             x.free()
         length = result + size
         be.call("InitIndexVector", dimidx[0].ptr, 0, length, None, 0)
@@ -166,3 +174,20 @@ def test_query_without_dimensions_and_constant_measure(be, agg, mtype, mb, const
     if agg == abi.AGGR_SUM_UNSIGNED:  # COUNT(*) = the survivors of every batch
         total = sum(o[2] for o in got if o[0] == "size")
         assert np.frombuffer([o for o in got if o[0] == "value"][-1][2], np.uint32)[0] == total * const
+
+
+@pytest.mark.parametrize("with_filter", [True, False], ids=["filtered", "unfiltered"])
+@pytest.mark.parametrize("wait", [True, False], ids=["wait", "nowait"])
+@pytest.mark.parametrize("agg,mtype,mb,ctype", [(abi.AGGR_SUM_UNSIGNED, abi.Uint32, 4, abi.Uint32), (abi.AGGR_SUM_SIGNED, abi.Int64, 8, abi.Int32),
+                                                (abi.AGGR_MAX_UNSIGNED, abi.Uint32, 4, abi.Uint32), (abi.AGGR_MIN_SIGNED, abi.Int32, 4, abi.Int32)],
+                         ids=["sum_u32", "sum_i64", "max_u32", "min_i32"])
+def test_query_without_dimensions_and_column_measure(be, agg, mtype, mb, ctype, with_filter, wait):
+    """SUM(col) / MAX(col) / MIN(col) without dimensions: the measure transform of a 4-byte column is QUEUED by the HIP
+    library (cross-call fusion) and survives the host's wait; Reduce over zero dimensions does not flush — it has to
+    launch that queue itself before it folds the value rows (round-3 advisor finding: it read rows nobody had written)."""
+    got = _run_zero_dim_sequence(be, agg, mtype, mb, 0, measure_column=ctype, with_filter=with_filter, wait_before_reduce=wait)
+    want = _run_zero_dim_sequence(H.oracle_backend(), agg, mtype, mb, 0, measure_column=ctype, with_filter=with_filter,
+                                  wait_before_reduce=wait)
+    assert [o[:2] for o in got] == [o[:2] for o in want]
+    for g, w in zip(got, want):
+        assert g[2] == w[2], g[:2]

@@ -13,6 +13,7 @@ previous results, a column overwritten between the filters and the projection, a
 of the index vector, of the reduction's INPUT rows (work a HashReduce skipped must appear) and of
 intermediate results.  The GPU variant also runs programs from several host threads at once."""
 import ctypes as C
+import os
 import threading
 
 import numpy as np
@@ -45,7 +46,10 @@ class Program:
     def __init__(self, seed):
         self.seed = seed
 
-    def run(self, be, streams=None):
+    def run(self, be, streams=None, expect=None):
+        """expect: the observations of a reference run; with ARES_FUZZ_DUMP=<directory> set, the first filter count that
+        differs dumps what is on the device at that moment (index vector, predicate vector, every column against the
+        bytes that were uploaded) before the comparison fails — diagnostics for timing-dependent failures."""
         rng = np.random.default_rng(self.seed)
         obs = []
         own_streams = streams is None
@@ -128,6 +132,8 @@ class Program:
                     size = be.call("UnaryFilter", cols["i"].input(), idx.ptr, pred.ptr, size, None, 0, None, 0,
                                    [abi.IsNull, abi.IsNotNull][int(rng.integers(0, 2))], stream, 0)
                 obs.append(("filter", b, size))
+                if expect is not None and os.environ.get("ARES_FUZZ_DUMP") and len(obs) <= len(expect) and expect[len(obs) - 1] != obs[-1]:
+                    self._dump(be, obs, expect[len(obs) - 1], cols, idx, pred, n, size, stream)
                 if size == 0:
                     break
             if size and rng.random() < 0.3:
@@ -209,6 +215,23 @@ class Program:
                 be.call("DestroyCudaStream", s, 0)
         return obs
 
+    def _dump(self, be, obs, want, cols, idx, pred, n, size, stream):
+        out = os.path.join(os.environ["ARES_FUZZ_DUMP"], f"fuzz_mismatch_{os.getpid()}_{self.seed}_{len(obs)}")
+        lines = [f"seed {self.seed} observation {len(obs) - 1}: got {obs[-1]} want {want}; n {n} size {size}"]
+        arrays = {}
+        for name, col in cols.items():
+            dev = _d2h(be, col.buf.ptr, len(col.blob), stream)
+            diff = np.flatnonzero(dev != col.blob)
+            lines.append(f"column {name}: {len(col.blob)} bytes, {len(diff)} differ from the upload, first at {diff[:8].tolist()}")
+            arrays["col_" + name + "_device"] = dev
+            arrays["col_" + name + "_upload"] = col.blob
+        arrays["pred"] = _d2h(be, pred.ptr, n, stream)
+        arrays["idx"] = _d2h(be, idx.ptr, 4 * n, stream).view(np.uint32)  # (runs the pending compaction)
+        lines.append(f"pred nonzero {int(np.count_nonzero(arrays['pred']))}; idx head {arrays['idx'][:8].tolist()}")
+        np.savez_compressed(out + ".npz", **arrays)
+        with open(out + ".txt", "w") as f:
+            f.write("\n".join(lines) + "\n")
+
     @staticmethod
     def _table(be, dims, meas, offs, n, mb, mnp, stream):
         cols = [np.frombuffer(_d2h(be, dims.ptr + vo, w * n, stream), np.uint8).reshape(n, w) for vo, no, w in offs]
@@ -239,7 +262,8 @@ def test_random_programs_match_the_oracle(chunk):
     hip, oracle = H.hip_backend(), H.oracle_backend()
     for seed in SEEDS[chunk::8]:
         p = Program(seed)
-        _same(p.run(hip), p.run(oracle), seed)
+        want = p.run(oracle)
+        _same(p.run(hip, expect=want), want, seed)
 
 
 def test_random_programs_reference_build_matches_the_oracle():
@@ -262,7 +286,7 @@ def test_random_programs_from_four_host_threads():
 
         def work(t):
             try:
-                got[t] = Program(seeds[t]).run(hip)
+                got[t] = Program(seeds[t]).run(hip, expect=want[t])
             except Exception as e:  # noqa: BLE001
                 errs.append((seeds[t], e))
         threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]

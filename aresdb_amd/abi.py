@@ -11,7 +11,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(_HERE)
-LIB_DIR = os.path.join(_HERE, "lib")
+# ARES_LIB_DIR: another build of the same libraries (diagnostics: the AddressSanitizer build of `make asan`)
+LIB_DIR = os.environ.get("ARES_LIB_DIR") or os.path.join(_HERE, "lib")
 
 # ---- enums (include/ares_algorithm.h; positional, part of the ABI) -------------------------
 AGGR_SUM_UNSIGNED, AGGR_SUM_SIGNED, AGGR_SUM_FLOAT = 1, 2, 3
@@ -314,6 +315,7 @@ def load_hip_backend():
     """The product: hand-written HIP libalgorithm.so + libmem.so.  No fallback of any kind."""
     # One HIP runtime per process: torch bundles its own libamdhip64 and must be the first to load it —
     # loaded after ours (which resolves to /opt/rocm), torch finds "no ROCm-capable device".
-    import torch  # noqa: F401
+    if not os.environ.get("ARES_NO_TORCH"):  # (diagnostics run without torch: then /opt/rocm's runtime is the only one)
+        import torch  # noqa: F401
     algo, mem = hip_library_paths()
     return Backend("hip", algo, mem, device_memory=True)

@@ -137,13 +137,15 @@ void (*g_memTrimCache)(int) = nullptr;  // AresMemTrimCache of the sibling libme
 // the Go host creates and destroys two streams per query, blocks cached under dead handles would only pile up,
 // and giving them back to the driver costs a device-synchronising hipFree each plus a hipMalloc in the next query.
 void stream_cache_purge(int device, hipStream_t stream) {
-  // ARES_TEMP_ORPHANS=1 keeps the blocks for the device's other streams; the default gives them back to the driver
-  // (hipFree, which synchronises the device) as in round 2: with the blocks kept, the GPU suite showed a rare
-  // (one run in two of the whole suite, never in isolation) off-by-one filter count in the sequence fuzzer whose
-  // cause is not found yet — the device-wide synchronisation at every stream destruction hides it.
+  // The blocks stay with the device for its other streams (ARES_TEMP_ORPHANS=0: give them back to the driver with
+  // hipFree, which synchronises the device, as rounds 2 and 3 did).  Round 3 saw rare off-by-one results and aborts with
+  // the blocks kept and blamed the reuse; round 4 traced them to the HIP runtime being handed events of destroyed
+  // streams (libmem's fences, the lazy compactions' error words) — a use after free inside the runtime that the
+  // device-wide synchronisation of hipFree merely made unlikely.  Those events now die with their stream
+  // (mem/memory.hip FenceEvent, transform.hip hook_on_stream_destroy; profiles/r4_race_hunt.md).
   static const bool keep = [] {
     const char *e = getenv("ARES_TEMP_ORPHANS");
-    return e && e[0] == '1';
+    return !(e && e[0] == '0');
   }();
   if (!keep) {
     std::vector<void *> blocks;
@@ -290,6 +292,9 @@ namespace {
 struct TimedLaunch {
   const char *name;
   hipEvent_t start, stop;
+  hipStream_t stream;
+  bool resolved;  // ms holds the duration, the events are gone (their stream was destroyed)
+  float ms;
 };
 std::mutex g_profMutex;
 std::atomic<int> g_profEnabled{0};
@@ -311,16 +316,32 @@ hipEvent_t take_event() {
 KernelTimer::KernelTimer(const char *name, hipStream_t stream) : slot_(-1), stream_(stream) {
   if (!g_profEnabled.load(std::memory_order_relaxed)) return;
   std::lock_guard<std::mutex> lock(g_profMutex);
-  TimedLaunch t{name, take_event(), take_event()};
+  TimedLaunch t{name, take_event(), take_event(), stream, false, 0.0f};
   hip_check(hipEventRecord(t.start, stream), "hipEventRecord");
   g_launches.push_back(t);
   slot_ = static_cast<int>(g_launches.size()) - 1;
 }
 
+void profiler_stream_gone(hipStream_t stream) {
+  std::lock_guard<std::mutex> lock(g_profMutex);
+  for (auto &t : g_launches) {
+    if (t.resolved || t.stream != stream) continue;
+    float ms = 0;
+    if (hipEventSynchronize(t.stop) != hipSuccess || hipEventElapsedTime(&ms, t.start, t.stop) != hipSuccess) {
+      (void)hipGetLastError();
+      ms = -1.0f;  // (not counted)
+    }
+    (void)hipEventDestroy(t.start);
+    (void)hipEventDestroy(t.stop);
+    t.resolved = true;
+    t.ms = ms;
+  }
+}
+
 KernelTimer::~KernelTimer() {
   if (slot_ < 0) return;
   std::lock_guard<std::mutex> lock(g_profMutex);
-  if (slot_ < static_cast<int>(g_launches.size())) (void)hipEventRecord(g_launches[slot_].stop, stream_);
+  if (slot_ < static_cast<int>(g_launches.size()) && !g_launches[slot_].resolved) (void)hipEventRecord(g_launches[slot_].stop, stream_);
 }
 
 }  // namespace ares
@@ -332,10 +353,12 @@ extern "C" void AresProfilerEnable(int on) {
   std::lock_guard<std::mutex> lock(ares::g_profMutex);
   ares::g_profEnabled.store(on ? 1 : 0);
   if (on) {
-    for (auto &t : ares::g_launches) {
-      ares::g_freeEvents.push_back(t.start);
-      ares::g_freeEvents.push_back(t.stop);
-    }
+    // (events are destroyed, not recycled: a recycled event still belongs to the stream of its last record)
+    for (auto &t : ares::g_launches)
+      if (!t.resolved) {
+        (void)hipEventDestroy(t.start);
+        (void)hipEventDestroy(t.stop);
+      }
     ares::g_launches.clear();
   }
 }
@@ -347,7 +370,13 @@ extern "C" size_t AresProfilerReport(char *buf, size_t len) {
   std::map<std::string, std::pair<long, double>> agg;
   for (auto &t : ares::g_launches) {
     float ms = 0;
-    if (hipEventSynchronize(t.stop) == hipSuccess && hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess) {
+    if (t.resolved) {
+      if (t.ms >= 0) {
+        auto &a = agg[t.name];
+        a.first++;
+        a.second += t.ms;
+      }
+    } else if (hipEventSynchronize(t.stop) == hipSuccess && hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess) {
       auto &a = agg[t.name];
       a.first++;
       a.second += ms;

@@ -189,6 +189,9 @@ uint64_t *pinned_words();
 constexpr int kPinnedWords = 4096 + 16;  // the thread's pinned result slot: a filter reads one partial count per workgroup back
 void read_back_u32(const uint32_t *dev, uint32_t *host, int count, hipStream_t stream);
 
+// the stream is being destroyed (it is idle): timing events recorded on it are resolved and destroyed now — an event
+// must not be touched once its stream is gone (mem/memory.hip: FenceEvent)
+void profiler_stream_gone(hipStream_t stream);
 // Optional per-kernel timing with HIP events on the launch stream (off by default).  bench.py
 // switches it on through the exported AresProfilerEnable / AresProfilerReport pair to obtain the
 // average duration of every kernel inside the timed region (the roofline figures).

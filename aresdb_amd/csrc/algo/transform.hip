@@ -1222,6 +1222,7 @@ struct PendingFill {
   size_t bytes;
   uint64_t pattern;
   int unit;  // 4 or 8
+  bool streamGone = false;  // the defining stream was destroyed: written on the stream of whoever asks for it
 };
 
 void hook_on_wait(int device, void *stream);
@@ -1281,8 +1282,12 @@ namespace {
 // out) cannot be read back where the launch happens — that may be inside a free or a copy.  It is
 // copied to pinned memory behind the kernel and looked at by the following entry points of the
 // device: the first one that finds it set reports the failure to the host.
+// (The event lives no longer than its stream: hook_on_stream_destroy settles the checks of a stream that is going away.
+// An event queried after its stream was destroyed is a use after free inside the ROCm 7.x runtime — see FenceEvent in
+// mem/memory.hip.)
 struct ErrorCheck {
   int device;
+  hipStream_t stream;
   hipEvent_t done;
   uint32_t *pinned;
   std::shared_ptr<StreamBuffer> ws;  // keeps the error word alive until the copy has run
@@ -1297,7 +1302,8 @@ struct DeferState {
   std::map<uint32_t *, PendingIota> iotas;
   std::map<uint8_t *, PendingFill> fills;  // by first byte; ranges never overlap
   std::vector<ErrorCheck> errorChecks;
-  std::vector<std::pair<hipEvent_t, uint32_t *>> errorSlots;  // recycled (event, pinned word) pairs
+  std::vector<uint32_t *> errorSlots;  // recycled pinned words
+  bool errorSeen = false;              // a check that was settled outside an entry point failed: the next poll reports it
 };
 constexpr int kMaxDevices = 64;
 DeferState &state_of(int device) {
@@ -1311,15 +1317,15 @@ DeferLock::DeferLock(int device) : lock(state_of(device).mutex) { t_state = &sta
 void watch_error_word(int device, hipStream_t stream, const uint32_t *errorDev, std::shared_ptr<StreamBuffer> ws) {
   ErrorCheck c;
   c.device = device;
+  c.stream = stream;
   c.ws = std::move(ws);
   if (!t_state->errorSlots.empty()) {
-    c.done = t_state->errorSlots.back().first;
-    c.pinned = t_state->errorSlots.back().second;
+    c.pinned = t_state->errorSlots.back();
     t_state->errorSlots.pop_back();
   } else {
-    hip_check(hipEventCreateWithFlags(&c.done, hipEventDisableTiming), "hipEventCreate");
     hip_check(hipHostMalloc(reinterpret_cast<void **>(&c.pinned), sizeof(uint32_t), hipHostMallocPortable), "hipHostMalloc");
   }
+  hip_check(hipEventCreateWithFlags(&c.done, hipEventDisableTiming), "hipEventCreate");
   *c.pinned = 0;
   hip_check(hipMemcpyAsync(c.pinned, errorDev, sizeof(uint32_t), hipMemcpyDeviceToHost, stream), "hipMemcpyAsync");
   hip_check(hipEventRecord(c.done, stream), "hipEventRecord");
@@ -1328,12 +1334,14 @@ void watch_error_word(int device, hipStream_t stream, const uint32_t *errorDev, 
 
 // caller holds the device's DeferLock; throws when a finished lazy compaction reported a failure
 void poll_error_words(int device) {
-  bool failed = false;
+  bool failed = t_state->errorSeen;
+  t_state->errorSeen = false;
   for (size_t i = 0; i < t_state->errorChecks.size();) {
     ErrorCheck &c = t_state->errorChecks[i];
     if (c.device == device && hipEventQuery(c.done) == hipSuccess) {
       failed = failed || *c.pinned != 0;
-      t_state->errorSlots.emplace_back(c.done, c.pinned);
+      (void)hipEventDestroy(c.done);
+      t_state->errorSlots.push_back(c.pinned);
       t_state->errorChecks[i] = std::move(t_state->errorChecks.back());
       t_state->errorChecks.pop_back();
     } else {
@@ -1510,9 +1518,11 @@ static void launch_fill(uint8_t *dst, const PendingFill &f) {
   if (f.bytes == 0) return;
   mem_note_write(f.device, dst, f.bytes);
   const size_t units = f.bytes / static_cast<size_t>(f.unit);
+  // a fill whose defining stream is gone is written on the caller's stream (or, from a libmem.so hook, on the null stream)
+  const hipStream_t stream = f.streamGone ? (t_callStream.known ? t_callStream.stream : nullptr) : f.stream;
   ARES_LAUNCH("fill_pattern_kernel", fill_pattern_kernel, capped_grid(static_cast<int64_t>((units + kBlock - 1) / kBlock), 256 * 8), kBlock,
-              f.stream, dst, units, f.pattern, f.unit);
-  order_before_caller(f.stream);  // whoever made us write it reads (or overwrites) it next, maybe on another stream
+              stream, dst, units, f.pattern, f.unit);
+  order_before_caller(stream);  // whoever made us write it reads (or overwrites) it next, maybe on another stream
 }
 
 // caller holds the device's DeferLock: every lazy fill of the device (r == nullptr) or those that overlap r are
@@ -1576,7 +1586,7 @@ bool defer_fill(int device, hipStream_t stream, void *dst, size_t bytes, uint64_
     if (hit) launch_queue(kv.first.second, kv.second);
   }
   retire_fills(device, r, false);
-  t_state->fills[p] = PendingFill{device, stream, bytes, pattern, unit};
+  t_state->fills[p] = PendingFill{device, stream, bytes, pattern, unit, false};
   return true;
 }
 
@@ -2638,7 +2648,25 @@ void hook_on_stream_destroy(int device, void *streamPtr) {
         it = (it->second.device == device && it->second.stream == stream) ? t_state->compactions.erase(it) : std::next(it);
       for (auto it = t_state->iotas.begin(); it != t_state->iotas.end();)
         it = (it->second.device == device && it->second.stream == stream) ? t_state->iotas.erase(it) : std::next(it);
+      // lazy fills that were defined on this stream and are still unwritten: from now on they are written on the stream
+      // of whoever needs them (the null stream stands for "the caller's", see launch_fill)
+      for (auto &kv : t_state->fills)
+        if (kv.second.device == device && kv.second.stream == stream) kv.second.streamGone = true;
+      // error words of this stream's lazy compactions: the stream is idle, their copies have landed; the events go now
+      for (size_t i = 0; i < t_state->errorChecks.size();) {
+        ErrorCheck &c = t_state->errorChecks[i];
+        if (c.device == device && c.stream == stream) {
+          t_state->errorSeen = t_state->errorSeen || *c.pinned != 0;
+          (void)hipEventDestroy(c.done);
+          t_state->errorSlots.push_back(c.pinned);
+          t_state->errorChecks[i] = std::move(t_state->errorChecks.back());
+          t_state->errorChecks.pop_back();
+        } else {
+          i++;
+        }
+      }
     }
+    profiler_stream_gone(stream);
     if (g_releaseHeld) g_releaseHeld(device, hold_tag(stream));
     stream_cache_purge(device, stream);
   } catch (std::exception &e) {

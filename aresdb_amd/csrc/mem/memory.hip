@@ -144,9 +144,18 @@ bool use_pool() {
 // No driver allocation after warm-up, no device-wide
 // synchronisation ever, and no reliance on cross-stream reuse inside HIP's own stream-ordered pool
 // (which libalgorithm.so uses for its stream-local temporaries only).
+// One event of a block's fence and the stream it was recorded on.  An event must not outlive its stream: the HIP runtime
+// of ROCm 7.x reaches into the stream object when such an event is queried and its work is not yet marked complete in
+// the runtime's books — with the stream destroyed that is a use after free (observed: std::bad_variant_access thrown out
+// of hipEventQuery, segmentation faults, hangs, single words of unrelated heap memory changed by one; profiles/
+// r4_race_hunt.md).  DestroyCudaStream therefore retires every fence event of the stream while the stream still exists.
+struct FenceEvent {
+  hipEvent_t event;
+  hipStream_t stream;
+};
 struct ParkedBlock {
   void *ptr;
-  std::vector<hipEvent_t> fence;
+  std::vector<FenceEvent> fence;
   bool zeroed = false;  // the block was cleared behind its fence (the last event of the fence covers the fill)
 };
 
@@ -179,7 +188,7 @@ struct DeviceState {
   std::vector<hipStream_t> streams;                      // streams created through CreateCudaStream
   std::map<size_t, std::vector<ParkedBlock>> bins;       // rounded size -> parked blocks
   std::map<uintptr_t, LiveBlock> live;                   // allocation -> rounded size + what was written to it
-  std::vector<hipEvent_t> freeEvents;
+  std::vector<FenceEvent> freeEvents;  // recycled (with the stream of their last record: they go when that stream goes)
   size_t parkedBytes = 0;
   // freed by the host while deferred work of one stream (the tag) still reads them (AresMemReleaseHeld)
   std::vector<std::pair<void *, uintptr_t>> held;
@@ -226,8 +235,8 @@ size_t bin_size(size_t bytes) {
 }
 
 bool fence_done(const ParkedBlock &b) {
-  for (hipEvent_t e : b.fence)
-    if (hipEventQuery(e) != hipSuccess) {
+  for (const FenceEvent &f : b.fence)
+    if (hipEventQuery(f.event) != hipSuccess) {
       (void)hipGetLastError();
       return false;
     }
@@ -236,7 +245,7 @@ bool fence_done(const ParkedBlock &b) {
 
 // caller holds st->mu
 void recycle_events(DeviceState *st, ParkedBlock &b) {
-  for (hipEvent_t e : b.fence) st->freeEvents.push_back(e);
+  for (const FenceEvent &f : b.fence) st->freeEvents.push_back(f);
   b.fence.clear();
 }
 
@@ -258,7 +267,7 @@ void trim(DeviceState *st, size_t keepBytes) {
     while (!vec.empty() && st->parkedBytes > keepBytes) {
       ParkedBlock b = vec.back();
       vec.pop_back();
-      for (hipEvent_t e : b.fence) (void)hipEventSynchronize(e);
+      for (const FenceEvent &f : b.fence) (void)hipEventSynchronize(f.event);
       recycle_events(st, b);
       (void)hipFree(b.ptr);
       st->driverFrees++;
@@ -349,7 +358,7 @@ hipError_t pool_alloc(DeviceState *st, void **p, size_t bytes, bool zero) {
     }
   }
   if (waitFor.ptr) {  // (outside the lock: frees and allocations of other threads go on)
-    for (hipEvent_t e : waitFor.fence) (void)hipEventSynchronize(e);
+    for (const FenceEvent &f : waitFor.fence) (void)hipEventSynchronize(f.event);
     ptr = waitFor.ptr;
     cleared = waitFor.zeroed;
     std::lock_guard<std::mutex> lock(st->mu);
@@ -453,14 +462,14 @@ hipError_t pool_free(DeviceState *st, void *p) {
   auto fence_on = [&](hipStream_t s) -> hipError_t {
     hipEvent_t e;
     if (!st->freeEvents.empty()) {
-      e = st->freeEvents.back();
+      e = st->freeEvents.back().event;
       st->freeEvents.pop_back();
     } else {
       hipError_t err = hipEventCreateWithFlags(&e, hipEventDisableTiming);
       if (err != hipSuccess) return err;
     }
     hipError_t err = hipEventRecord(e, s);
-    b.fence.push_back(e);
+    b.fence.push_back(FenceEvent{e, s});
     return err;
   };
   hipError_t err = fence_on(nullptr);
@@ -475,7 +484,7 @@ hipError_t pool_free(DeviceState *st, void *p) {
     b.zeroed = true;  // nothing wrote to it since it was cleared
   } else {  // clear what was written behind the block's fence, off every query's critical path
     bool okFill = true;
-    for (hipEvent_t e : b.fence) okFill = okFill && hipStreamWaitEvent(st->allocStream, e, 0) == hipSuccess;
+    for (const FenceEvent &f : b.fence) okFill = okFill && hipStreamWaitEvent(st->allocStream, f.event, 0) == hipSuccess;
     for (const auto &r : written)
       okFill = okFill && hipMemsetAsync(static_cast<uint8_t *>(p) + r.first, 0, r.second - r.first, st->allocStream) == hipSuccess;
     if (okFill && fence_on(st->allocStream) == hipSuccess) {
@@ -492,7 +501,7 @@ hipError_t pool_free(DeviceState *st, void *p) {
     return e && e[0] == '1';
   }();
   if (syncFree)
-    for (hipEvent_t e : b.fence) (void)hipEventSynchronize(e);
+    for (const FenceEvent &f : b.fence) (void)hipEventSynchronize(f.event);
   st->bins[rounded].push_back(b);
   st->parkedBytes += rounded;
   // the cache stays below a quarter of the device (the figure is read once per device, not per free)
@@ -500,6 +509,39 @@ hipError_t pool_free(DeviceState *st, void *p) {
   return hipSuccess;
 }
 
+}  // namespace
+
+// ARES_BACKTRACE=1 (diagnostics): a C++ exception that nobody catches (std::terminate) and a segmentation fault print the
+// native call stack of the faulting thread before the process dies — which entry point, which runtime call.
+#include <execinfo.h>
+#include <csignal>
+#include <exception>
+#include <unistd.h>
+namespace {
+void print_native_stack(const char *what) {
+  void *frames[64];
+  const int n = backtrace(frames, 64);
+  (void)!write(2, what, strlen(what));
+  backtrace_symbols_fd(frames, n, 2);
+}
+void on_terminate() {
+  print_native_stack("libmem: std::terminate — native stack:\n");
+  abort();
+}
+void on_fatal_signal(int sig) {
+  print_native_stack(sig == SIGSEGV ? "libmem: SIGSEGV — native stack:\n" : "libmem: fatal signal — native stack:\n");
+  signal(sig, SIG_DFL);
+  raise(sig);
+}
+struct BacktraceInstaller {
+  BacktraceInstaller() {
+    const char *e = getenv("ARES_BACKTRACE");
+    if (!(e && e[0] == '1')) return;
+    std::set_terminate(&on_terminate);
+    signal(SIGSEGV, &on_fatal_signal);
+    signal(SIGBUS, &on_fatal_signal);
+  }
+} g_backtraceInstaller;
 }  // namespace
 
 extern "C" {
@@ -660,9 +702,31 @@ CGoCallResHandle DestroyCudaStream(void *s, int device) {
           break;
         }
     }
-    // fences already recorded on this stream stay valid: destruction completes its queued work
     MEM_TRY(hipStreamSynchronize(reinterpret_cast<hipStream_t>(s)), "DestroyCudaStream");
     notify_stream_destroy(device, s);
+    {
+      // The stream is idle: whatever its fence events stand for has happened.  They are retired NOW, while the stream
+      // exists (see FenceEvent) — destroyed, not recycled: nothing of the runtime's bookkeeping for this stream is kept.
+      std::lock_guard<std::mutex> lock(st->mu);
+      for (auto &bin : st->bins)
+        for (ParkedBlock &b : bin.second)
+          for (size_t i = 0; i < b.fence.size();)
+            if (b.fence[i].stream == reinterpret_cast<hipStream_t>(s)) {
+              (void)hipEventDestroy(b.fence[i].event);
+              b.fence[i] = b.fence.back();
+              b.fence.pop_back();
+            } else {
+              i++;
+            }
+      for (size_t i = 0; i < st->freeEvents.size();)
+        if (st->freeEvents[i].stream == reinterpret_cast<hipStream_t>(s)) {
+          (void)hipEventDestroy(st->freeEvents[i].event);
+          st->freeEvents[i] = st->freeEvents.back();
+          st->freeEvents.pop_back();
+        } else {
+          i++;
+        }
+    }
     MEM_TRY(hipStreamDestroy(reinterpret_cast<hipStream_t>(s)), "DestroyCudaStream");
   }
   return ok();

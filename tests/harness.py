@@ -10,6 +10,7 @@ Three implementations of the same ABI can be driven with identical inputs:
 import ctypes as C
 import os
 import subprocess
+import threading
 
 import numpy as np
 
@@ -52,6 +53,68 @@ def get_backend(name):
     return {"oracle": oracle_backend, "ref": ref_backend, "hip": hip_backend}[name]()
 
 
+class _PinnedPool:
+    """Host staging buffers from the backend's own HostAlloc (pinned, portable memory on the HIP backend — what the Go
+    host's memutils.HostAlloc hands out and what every one of its uploads starts from, memstore/vectors/vector.go:75-84),
+    cached by size class per thread.  ARES_TEST_PAGEABLE=1 switches back to plain numpy memory (pageable: the HIP runtime
+    stages such copies itself)."""
+
+    def __init__(self):
+        self.tls = threading.local()
+
+    def take(self, be, nbytes):
+        size = 256
+        while size < nbytes:
+            size *= 2
+        free = getattr(self.tls, "free", None)
+        if free is None:
+            free = self.tls.free = {}
+        lst = free.setdefault((be.name, size), [])
+        ptr = lst.pop() if lst else be.call("HostAlloc", size)
+        return ptr, size
+
+    def give(self, be, ptr, size):
+        self.tls.free[(be.name, size)].append(ptr)
+
+
+_pinned = _PinnedPool()
+_PAGEABLE = os.environ.get("ARES_TEST_PAGEABLE") == "1"
+
+
+def upload(be, dst, data, stream=None):
+    """host numpy array -> 'device' memory of the backend, complete on return"""
+    data = np.ascontiguousarray(data)
+    if not data.nbytes:
+        return
+    if _PAGEABLE:
+        be.h2d(dst, data.ctypes.data_as(C.c_void_p), data.nbytes, stream)
+        be.wait(stream)
+        return
+    ptr, size = _pinned.take(be, data.nbytes)
+    C.memmove(ptr, data.ctypes.data, data.nbytes)
+    be.h2d(dst, ptr, data.nbytes, stream)
+    be.wait(stream)
+    _pinned.give(be, ptr, size)
+
+
+def download(be, src, nbytes, stream=None):
+    """'device' memory of the backend -> a fresh numpy uint8 array, complete on return"""
+    nbytes = int(nbytes)
+    out = np.empty(nbytes, np.uint8)
+    if not nbytes:
+        return out
+    if _PAGEABLE:
+        be.d2h(out.ctypes.data_as(C.c_void_p), src, nbytes, stream)
+        be.wait(stream)
+        return out
+    ptr, size = _pinned.take(be, nbytes)
+    be.d2h(ptr, src, nbytes, stream)
+    be.wait(stream)
+    C.memmove(out.ctypes.data, ptr, nbytes)
+    _pinned.give(be, ptr, size)
+    return out
+
+
 class Buf:
     """A 'device' allocation of one backend, filled from / read back into numpy."""
 
@@ -66,19 +129,13 @@ class Buf:
             self.write(data)
 
     def write(self, data, offset=0):
-        data = np.ascontiguousarray(data)
-        self.be.h2d(self.ptr + offset, data.ctypes.data_as(C.c_void_p), data.nbytes)
-        self.be.wait()
+        upload(self.be, self.ptr + offset, data)
 
     def read(self, dtype=np.uint8, count=None, offset=0):
         dtype = np.dtype(dtype)
         if count is None:
             count = (self.nbytes - offset) // dtype.itemsize
-        out = np.empty(count, dtype=dtype)
-        if count:
-            self.be.d2h(out.ctypes.data_as(C.c_void_p), self.ptr + offset, out.nbytes)
-            self.be.wait()
-        return out
+        return download(self.be, self.ptr + offset, count * dtype.itemsize).view(dtype)
 
     def free(self):
         if self.ptr:
@@ -320,11 +377,7 @@ def record_id_array(pairs):
 
 
 def read_device_bytes(be, ptr, nbytes):
-    out = np.empty(int(nbytes), np.uint8)
-    if nbytes:
-        be.d2h(out.ctypes.data_as(C.c_void_p), ptr, int(nbytes))
-        be.wait()
-    return out
+    return download(be, ptr, nbytes)
 
 
 def hyperloglog(be, prev, cur, prev_values, cur_values, prev_size, batch_size, last):

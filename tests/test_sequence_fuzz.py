@@ -33,11 +33,7 @@ MEASURES = [  # (column, aggregate, measure data type, bytes, numpy type)
 
 
 def _d2h(be, ptr, nbytes, stream):
-    out = np.empty(int(nbytes), np.uint8)
-    if nbytes:
-        be.d2h(out.ctypes.data_as(C.c_void_p), ptr, int(nbytes), stream)
-        be.wait(stream)
-    return out
+    return H.download(be, ptr, nbytes, stream)
 
 
 class Program:
@@ -141,8 +137,7 @@ class Program:
             if size and rng.random() < 0.06:  # a column changes under the query between filter and projection
                 fresh = rng.integers(0, 12, n).astype(np.uint32)
                 vp = cols["u"].vp
-                be.h2d(vp.BasePtr + vp.ValuesOffset, fresh.ctypes.data_as(C.c_void_p), 4 * n, stream)
-                be.wait(stream)
+                H.upload(be, vp.BasePtr + vp.ValuesOffset, fresh, stream)
             # result buffers: capacity for resultSize + size (+ 12.5 %), previous results carried over
             if result_size + size > cap:
                 old_cap, cap = cap, result_size + size + (result_size + size) // 8 + 1

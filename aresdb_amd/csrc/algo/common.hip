@@ -338,6 +338,13 @@ void profiler_stream_gone(hipStream_t stream) {
   }
 }
 
+size_t profiler_stream_events(hipStream_t stream) {
+  std::lock_guard<std::mutex> lock(g_profMutex);
+  size_t n = 0;
+  for (auto &t : g_launches) n += (!t.resolved && t.stream == stream) ? 2 : 0;
+  return n;
+}
+
 KernelTimer::~KernelTimer() {
   if (slot_ < 0) return;
   std::lock_guard<std::mutex> lock(g_profMutex);

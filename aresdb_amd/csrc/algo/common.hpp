@@ -192,6 +192,7 @@ void read_back_u32(const uint32_t *dev, uint32_t *host, int count, hipStream_t s
 // the stream is being destroyed (it is idle): timing events recorded on it are resolved and destroyed now — an event
 // must not be touched once its stream is gone (mem/memory.hip: FenceEvent)
 void profiler_stream_gone(hipStream_t stream);
+size_t profiler_stream_events(hipStream_t stream);  // unresolved timing events recorded on `stream`
 // Optional per-kernel timing with HIP events on the launch stream (off by default).  bench.py
 // switches it on through the exported AresProfilerEnable / AresProfilerReport pair to obtain the
 // average duration of every kernel inside the timed region (the roofline figures).

@@ -2909,6 +2909,14 @@ using namespace ares;
 
 extern "C" {
 
+size_t AresStreamEvents(int device, void *stream) {
+  size_t n = profiler_stream_events(reinterpret_cast<hipStream_t>(stream));
+  if (device < 0 || device >= kMaxDevices) return n;
+  DeferLock lock(device);
+  for (const ErrorCheck &c : t_state->errorChecks) n += c.device == device && c.stream == reinterpret_cast<hipStream_t>(stream);
+  return n;
+}
+
 void AresFlushDeferred(int device) {
   int current = 0;
   if (hipGetDevice(&current) != hipSuccess) {

@@ -604,6 +604,18 @@ void AresMemDriverCalls(int device, size_t *mallocs, size_t *frees, size_t *trim
   if (trims) *trims = t;
 }
 
+size_t AresMemStreamEvents(int device, void *stream) {
+  if (device < 0 || device >= kMaxDevices) return 0;
+  DeviceState *st = &g_devices[device];
+  std::lock_guard<std::mutex> lock(st->mu);
+  size_t n = 0;
+  for (auto &bin : st->bins)
+    for (const ParkedBlock &b : bin.second)
+      for (const FenceEvent &f : b.fence) n += f.stream == reinterpret_cast<hipStream_t>(stream);
+  for (const FenceEvent &f : st->freeEvents) n += f.stream == reinterpret_cast<hipStream_t>(stream);
+  return n;
+}
+
 void AresMemTrimCache(int device) {
   if (device < 0 || device >= kMaxDevices) return;
   DeviceState *st = &g_devices[device];

@@ -114,6 +114,12 @@ void AresMemStats(int device, size_t *liveBytes, size_t *liveBlocks, size_t *hel
 /* Driver calls libmem.so's block cache could not avoid on `device` since the process started (hipMalloc, hipFree,
  * cache trims): after warm-up a steady workload adds none.  Any pointer may be NULL. */
 void AresMemDriverCalls(int device, size_t *mallocs, size_t *frees, size_t *trims);
+/* Events of the block cache (fences of parked blocks, recycled events) whose last record was on `stream`.  An event must
+ * not be touched once its stream is destroyed (the ROCm 7.x runtime reaches into the stream object: use after free), so
+ * DestroyCudaStream retires them while the stream exists: 0 right after it, for tests. */
+size_t AresMemStreamEvents(int device, void *stream);
+/* the same for libalgorithm.so: error-word watches of lazily launched compactions and unresolved profiler events */
+size_t AresStreamEvents(int device, void *stream);
 
 /* Fused batch execution: filter -> dimension / measure projection -> hash reduction of ONE batch in
  * a single pass over the source columns, without the index / predicate / dimension vectors the

@@ -60,7 +60,7 @@ def murmur3_32_rows(values, valids):
     return h
 
 
-def _codes_of_batch(b, limit=None, dims=ALL_DIMS, d1_below=90):
+def _codes_of_batch(b, limit=None, dims=ALL_DIMS, d1_below=90, ts_range=None):
     """dense key code, keep mask and float64 measure of every row of one C3 batch (torch, on the
     batch's device) for the group-by dimensions `dims` (a subset of ts-bucket, d1, d2, d3; the filter d1 < 90 and the
     measure stay); a null dimension is its own key slot, a null measure contributes 0."""
@@ -75,6 +75,11 @@ def _codes_of_batch(b, limit=None, dims=ALL_DIMS, d1_below=90):
     keep = d1 < d1_below
     if d1v is not None:
         keep &= d1v
+    if ts_range is not None:  # the Go host's time filters: ts >= from, ts < to (a null ts fails both)
+        ts, tsv = col("ts")
+        keep &= (ts >= int(ts_range[0])) & (ts < int(ts_range[1]))
+        if tsv is not None:
+            keep &= tsv
     def code(v, ok, null_code):
         v = v.to(torch.int64)
         return v if ok is None else torch.where(ok, v, torch.full_like(v, null_code))
@@ -91,7 +96,7 @@ def _codes_of_batch(b, limit=None, dims=ALL_DIMS, d1_below=90):
     return c, keep, mm
 
 
-def exact_groups(batches, limit_first_batch=None, dims=ALL_DIMS, d1_below=90):
+def exact_groups(batches, limit_first_batch=None, dims=ALL_DIMS, d1_below=90, ts_range=None):
     """Exact group-by of the C3 query (group-by dimensions `dims`) over `batches` (all rows, or the first
     `limit_first_batch` rows of the first batch only).  Returns numpy arrays (code, sum, first_row, rows) of the groups."""
     dev = batches[0]["m"].blob.device
@@ -105,7 +110,7 @@ def exact_groups(batches, limit_first_batch=None, dims=ALL_DIMS, d1_below=90):
     first = torch.full((space * salt,), torch.iinfo(torch.int64).max, dtype=torch.int64, device=dev)
     offset = 0
     for b in (batches[:1] if limit_first_batch is not None else batches):
-        c, keep, mm = _codes_of_batch(b, limit_first_batch, dims, d1_below)
+        c, keep, mm = _codes_of_batch(b, limit_first_batch, dims, d1_below, ts_range)
         rows = torch.arange(offset, offset + c.numel(), dtype=torch.int64, device=dev)[keep]
         idx = c[keep]
         if salt > 1:

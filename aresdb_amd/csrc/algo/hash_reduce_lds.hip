@@ -600,7 +600,7 @@ int fused_filter_hash_reduce(int device, const AresFusedQuery &q, int batchRows,
                              uint8_t *prevValues, int prevSize, const DimensionVector &outKeys, uint8_t *outValues,
                              hipStream_t stream) {
   if (q.numDims < 1 || q.numDims > kFusedDims) throw NotFusable("1..4 dimensions");
-  if (q.numFilters < 0 || q.numFilters > kFusedFilters) throw NotFusable("at most 4 filters");
+  if (q.numFilters < 0 || q.numFilters > kExtensionFilters) throw NotFusable("at most 4 filters");
   const int nd = q.numDims;
   for (int k = 0; k < NUM_DIM_WIDTH; k++)
     if (outKeys.NumDimsPerDimWidth[k] != (k == 2 ? nd : 0) || (prevSize > 0 && prevKeys.NumDimsPerDimWidth[k] != (k == 2 ? nd : 0)))

@@ -20,7 +20,9 @@ int hash_reduce_lds(int device, const DimensionVector &inputKeys, const uint8_t 
                     hipStream_t stream);
 
 // ---- fused scan: filter + projection evaluated from the source columns ------------------------------
-constexpr int kFusedCols = 6, kFusedFilters = 4, kFusedDims = 4;
+// (kFusedFilters: the Go host's two time filters, a cutoff filter on live batches and three of the query's own)
+constexpr int kFusedCols = 6, kFusedFilters = 6, kFusedDims = 4;
+constexpr int kExtensionFilters = 4;  // AresFusedQuery::filters (include/ares_extensions.h)
 struct FusedColumn {
   const uint32_t *vals;
   const uint8_t *nulls;

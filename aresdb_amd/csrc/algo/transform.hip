@@ -902,6 +902,87 @@ __global__ __launch_bounds__(kBlock) void filter_pred_kernel(FastOperands f, uin
   if (threadIdx.x == 0) blockTotals[blockIdx.x] = sTotal;
 }
 
+// ---------------------------------------------------------------------------------------------
+// lazy filter in ROW space: count + survivor bits, no predicate bytes, no index vector
+// ---------------------------------------------------------------------------------------------
+// While every filter of a batch so far is of the hot shape and nothing has read the index vector, the vector is still
+// iota(0 .. n0) "with k filters pending": the survivors of filter k + 1 are the rows of the batch that pass filters
+// 1 .. k + 1, whatever order compactions would have put them in.  This kernel evaluates ONE more filter over the batch's
+// rows (rows = positions: no index vector is read), ANDs it with the survivors so far — one bit per row — and returns
+// the count through one partial per workgroup: 4.1 B/row read + 0.13 B/row of bits each way, against predicate bytes,
+// compaction and a gather through the compacted vector for every filter after the first (the Go host puts two time
+// filters in front of every fact-table query's own filters, query/aql_processor.go:543-559).  Nothing observable is
+// written: the predicate and index vectors are produced by replaying the filters with the kernels above when (if)
+// somebody needs them (run_compaction).
+// Survivor bits are kept in BALLOT layout: the tile geometry of this file gives every wavefront 256 consecutive rows
+// per quad (lane l holds rows 4l .. 4l + 3), so the four ballots of a quad are its 256 bits — word 4 S + j of the array
+// is the ballot over the lanes of "row 256 S + 4 lane + j survives".  A consumer with the same geometry tests bit `lane`
+// of four wave-uniform words.
+// `two`: a second filter `g` over the SAME column is evaluated as well (the host predicts it from the previous batch of
+// the stream: ts >= from is followed by ts < to); blockTotals holds two partials per workgroup, bitsOut2 the survivors
+// of both.
+__global__ __launch_bounds__(kBlock) void filter_rows_kernel(FastOperands f, FastOperands g, int two, const uint64_t *bitsIn,
+                                                             uint64_t *bitsOut, uint64_t *bitsOut2, int n, int numTiles,
+                                                             uint32_t *blockTotals) {
+  __shared__ uint32_t sTotal[2];
+  if (threadIdx.x < 2) sTotal[threadIdx.x] = 0;
+  uint32_t mine = 0, mine2 = 0;  // wave-uniform: survivors of the segments this wavefront has seen
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  DVal y, z;
+  y.bits = f.bbits;
+  y.ok = f.bok;
+  y = cvt32(y, f.bkind, f.I);
+  z.bits = g.bbits;
+  z.ok = g.bok;
+  z = cvt32(z, g.bkind, g.I);
+  for (int tile = blockIdx.x; tile < numTiles; tile += gridDim.x) {
+    const int64_t tq = static_cast<int64_t>(tile) * (kBlock * kPQ);
+    uint32_t rows[kPQ][4], vals[kPQ][4], okb[kPQ];
+    load_quads<kPQ>(f, tq + threadIdx.x, n, rows, vals, okb);
+    uint32_t in[kPQ], kbs[kPQ], kbs2[kPQ];
+#pragma unroll
+    for (int q = 0; q < kPQ; q++) {
+      const int64_t i0 = (tq + threadIdx.x + static_cast<int64_t>(q) * kBlock) * 4;
+      in[q] = 0xFu;
+      if (i0 + 3 >= n) {
+        in[q] = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) in[q] |= (i0 + j < n ? 1u : 0u) << j;
+      }
+    }
+    compare_tile<kPQ>(f, vals, okb, in, y, kbs);  // result validity is ignored (functor.hpp:903-915)
+    if (two) compare_tile<kPQ>(g, vals, okb, in, z, kbs2);
+#pragma unroll
+    for (int q = 0; q < kPQ; q++) {
+      // the 256-row segment this wavefront holds in quad q (wave-uniform)
+      const int64_t seg = __builtin_amdgcn_readfirstlane(static_cast<int>(tile * (kPQ * kWaves) + q * kWaves + wave));
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        bool k1 = (kbs[q] >> j) & 1u;
+        if (bitsIn) k1 = k1 && ((bitsIn[seg * 4 + j] >> lane) & 1ull);
+        const uint64_t b1 = __ballot(k1);
+        mine += static_cast<uint32_t>(__popcll(b1));
+        uint64_t b2 = 0;
+        if (two) {
+          b2 = __ballot(k1 && ((kbs2[q] >> j) & 1u));
+          mine2 += static_cast<uint32_t>(__popcll(b2));
+        }
+        if (lane == 0) {
+          bitsOut[seg * 4 + j] = b1;
+          if (two) bitsOut2[seg * 4 + j] = b2;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (lane == 0) {
+    if (mine) atomicAdd(&sTotal[0], mine);
+    if (mine2) atomicAdd(&sTotal[1], mine2);
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) blockTotals[2 * blockIdx.x + threadIdx.x] = sTotal[threadIdx.x];
+}
+
 // exclusive scan of the tile counts by ONE workgroup (numTiles <= a few hundred thousand)
 __global__ __launch_bounds__(1024) void filter_scan_kernel(const uint32_t *tileCounts, uint32_t *tileOffsets, int numTiles,
                                                            uint32_t *total) {
@@ -1162,6 +1243,7 @@ struct FilterJournal {
   bool valid;
   std::vector<FastOperands> filters;
   std::vector<uint32_t> colRows;
+  int lastCount = -1;  // survivors of the last journalled filter (-1: not known), what the next one must be called with
 };
 
 // Queues that a HashReduce consumed on the fly: their outputs were never written.  They stay
@@ -1185,6 +1267,21 @@ struct ReleaseSet {
 // of its index vector has not run: when HashReduce re-derives the survivors from the filter journal
 // nobody ever reads the compacted vector.  Whatever does read it (a second filter, transforms that
 // are launched after all, a copy, any other entry point) runs the compaction first.
+// One filter that has been counted in row space (filter_rows_kernel) and not applied to the index vector yet.
+struct LazyFilter {
+  FastOperands f;     // idx = nullptr, pad = 0: the replay fills them in
+  uint32_t colRows;   // rows of the column
+  uint8_t *pred;      // the predicate vector the host passed with the call
+  int rowsBefore;     // length of the index vector before this filter (= the previous filter's count)
+};
+// What the next filter call of the stream is expected to be (the previous batch of the stream had the same filter on the
+// same column right behind this one): evaluated in the same pass, handed out without a kernel when the call arrives.
+struct PredictedFilter {
+  bool valid = false;
+  FastOperands g;     // on the column of the filter it was evaluated with
+  int count = 0;
+  std::shared_ptr<StreamBuffer> bits;
+};
 struct PendingCompact {
   int device;
   hipStream_t stream;
@@ -1196,6 +1293,28 @@ struct PendingCompact {
   unsigned int *ticket;
   uint32_t *error, *tileOffsets, *loaded;
   uint32_t *tileCounts = nullptr, *total = nullptr;  // not null: the scan of the tile counts has not run yet
+  // row-space form (todo not empty: the fields from `pred` to `total` are unused).  The index vector holds
+  // iota(0 .. n0) — virtual or written — with the first `applied` filters of the journal applied; `todo` are the filters
+  // counted since, in call order; `bits` the survivors after the last of them, in row space (ballot layout).
+  std::vector<LazyFilter> todo;
+  int n0 = 0, applied = 0, lastCount = 0;
+  std::shared_ptr<StreamBuffer> bits;
+  PredictedFilter predicted;
+  uint64_t generation = 0;  // of the filter that was booked last (DeferState::filterGeneration)
+};
+
+// Filters of the previous and of the current batch of a stream, by shape: what filter_rows_kernel's prediction goes by.
+struct FilterShape {
+  int akind, functor, I, bkind;
+  uint32_t bbits, bok;
+  bool sameColumnAsPrevious;
+  bool same_as(const FilterShape &o) const {
+    return akind == o.akind && functor == o.functor && I == o.I && bkind == o.bkind && bbits == o.bbits && bok == o.bok &&
+           sameColumnAsPrevious == o.sameColumnAsPrevious;
+  }
+};
+struct FilterHistory {
+  std::vector<FilterShape> previous, current;
 };
 
 // Index vectors that InitIndexVector has defined but not written yet ("virtual iota"): the fast
@@ -1299,6 +1418,8 @@ struct DeferState {
   std::map<std::pair<int, hipStream_t>, PendingQueue> limbo;    // queues a HashReduce consumed on the fly
   std::map<const uint32_t *, FilterJournal> journals;
   std::map<const uint32_t *, PendingCompact> compactions;
+  std::map<std::pair<int, hipStream_t>, FilterHistory> filterHistory;
+  uint64_t filterGeneration = 0;
   std::map<uint32_t *, PendingIota> iotas;
   std::map<uint8_t *, PendingFill> fills;  // by first byte; ranges never overlap
   std::vector<ErrorCheck> errorChecks;
@@ -1354,11 +1475,16 @@ void poll_error_words(int device) {
 
 // caller holds the device's DeferLock and has selected the device: runs the pending compaction of `idx` (if
 // there is one) on the stream its filter ran on
+void replay_lazy_filters(const PendingCompact &c);
 void run_compaction(const uint32_t *idx) {
   auto it = t_state->compactions.find(idx);
   if (it == t_state->compactions.end()) return;
   const PendingCompact c = it->second;
   t_state->compactions.erase(it);
+  if (!c.todo.empty()) {
+    replay_lazy_filters(c);
+    return;
+  }
   mem_note_write(c.device, c.idx, 4ull * static_cast<size_t>(c.n));
   CompactWorkspace cw;
   cw.ticket = c.ticket;
@@ -1379,7 +1505,65 @@ void run_compaction(const uint32_t *idx) {
   // (c.ws is released to the stream's cache when the last copy of the shared_ptr goes: behind the launch
   // and the copy of the error word)
 }
+// Filters that were only counted (filter_rows_kernel) are applied to the index vector after all: each one as the call
+// would have run eagerly — predicate bytes over the vector as the previous filter left it, tile counts, offsets,
+// in-place compaction — so that predicate and index vectors hold exactly what the reference leaves in them.
+// caller holds the device's DeferLock and has selected the device
+void replay_lazy_filters(const PendingCompact &c) {
+  bool virtualIdx = c.virtualIdx;
+  mem_note_write(c.device, c.idx, 4ull * static_cast<size_t>(c.n0));
+  for (const LazyFilter &L : c.todo) {
+    const int n = L.rowsBefore;
+    if (n <= 0) break;
+    mem_note_write(c.device, L.pred, static_cast<size_t>(n));
+    FastOperands f = L.f;
+    f.idx = virtualIdx ? nullptr : c.idx;
+    f.pad = static_cast<int>(reinterpret_cast<uintptr_t>(L.pred) & 3);
+    const int64_t numQuads = (static_cast<int64_t>(n) + f.pad + 3) / 4;
+    const int tiles = static_cast<int>((numQuads + kBlock * kPQ - 1) / (kBlock * kPQ));
+    const size_t head = 64;
+    const size_t words = static_cast<size_t>(tiles) * 3 + 1;  // [tile counts][tile offsets + 1][loaded]
+    auto wsBuf = std::make_shared<StreamBuffer>(head + 4 * words, c.stream);
+    uint32_t *w = wsBuf->as<uint32_t>();
+    uint32_t *total = w, *error = w + 1;
+    uint32_t *tileCounts = w + 16, *tileOffsets = tileCounts + tiles, *loaded = tileOffsets + tiles + 1;
+    hip_check(hipMemsetAsync(w, 0, head + 4 * words, c.stream), "hipMemsetAsync");
+    ARES_LAUNCH("filter_pred_kernel", filter_pred_kernel, capped_grid(tiles, 256 * 16), kBlock, c.stream, f, L.pred, tileCounts, n, tiles,
+                static_cast<uint32_t *>(nullptr));
+    ARES_LAUNCH("filter_scan_kernel", filter_scan_kernel, 1, 1024, c.stream, tileCounts, tileOffsets, tiles, total);
+    CompactWorkspace cw;
+    cw.ticket = w + 2;
+    cw.error = error;
+    cw.tileOffsets = tileOffsets;
+    cw.loaded = loaded;
+    const int cgrid = capped_grid((tiles + kTilesPerTicket - 1) / kTilesPerTicket, 256 * 8);
+    if (virtualIdx)
+      ARES_LAUNCH("filter_compact_kernel<iota>", (filter_compact_kernel<uint32_t, true>), cgrid, kBlock, c.stream, L.pred, c.idx, 0u, f.pad,
+                  cw, n, tiles);
+    else
+      ARES_LAUNCH("filter_compact_kernel", (filter_compact_kernel<uint32_t, false>), cgrid, kBlock, c.stream, L.pred, c.idx, 0u, f.pad, cw,
+                  n, tiles);
+    watch_error_word(c.device, c.stream, error, wsBuf);
+    virtualIdx = false;
+  }
+  order_before_caller(c.stream);
+}
+
 bool compaction_touches(const PendingCompact &c, const ByteRange &r) {
+  if (!c.todo.empty()) {  // index vector, every predicate vector and every column a replay would read
+    const ByteRange ri{reinterpret_cast<const uint8_t *>(c.idx), reinterpret_cast<const uint8_t *>(c.idx) + 4ull * c.n0};
+    bool hit = ri.overlaps(r);
+    for (const LazyFilter &L : c.todo) {
+      const ByteRange rp{L.pred, L.pred + L.rowsBefore};
+      const ByteRange rv{reinterpret_cast<const uint8_t *>(L.f.vals), reinterpret_cast<const uint8_t *>(L.f.vals) + 4ull * L.colRows};
+      hit = hit || rp.overlaps(r) || rv.overlaps(r);
+      if (L.f.nulls) {
+        const ByteRange rn{L.f.nulls, L.f.nulls + (static_cast<uint64_t>(L.colRows) + L.f.bitOff + 7) / 8 + 2};
+        hit = hit || rn.overlaps(r);
+      }
+    }
+    return hit;
+  }
   const ByteRange ri{reinterpret_cast<const uint8_t *>(c.idx), reinterpret_cast<const uint8_t *>(c.idx) + 4ull * c.n};
   const ByteRange rp{c.pred, c.pred + c.n};
   return ri.overlaps(r) || rp.overlaps(r);
@@ -1670,7 +1854,9 @@ void materialize_index_vector(int device, const uint32_t *indexVector) {
 
 // limboA/limboB: when given, only the skipped work whose outputs overlap these byte ranges is
 // launched (the caller reads nothing else); otherwise all of it
-static void flush_deferred_impl(int device, const ByteRange *limboA, const ByteRange *limboB) {
+// exempt: the index vector whose pending filters the caller is about to extend (a filter call of the hot shape): its
+// compaction stays pending
+static void flush_deferred_impl(int device, const ByteRange *limboA, const ByteRange *limboB, const uint32_t *exempt = nullptr) {
   DeferLock lock(device);
   poll_error_words(device);
   // lazy fills (like work a HashReduce skipped, below) are only written for byte ranges the caller reads: they live in
@@ -1698,7 +1884,7 @@ static void flush_deferred_impl(int device, const ByteRange *limboA, const ByteR
   };
   for (;;) {
     auto c = t_state->compactions.begin();
-    while (c != t_state->compactions.end() && (c->second.device != device || dormant(c->first))) ++c;
+    while (c != t_state->compactions.end() && (c->second.device != device || c->first == exempt || dormant(c->first))) ++c;
     if (c == t_state->compactions.end()) break;
     run_compaction(c->first);
   }
@@ -1773,6 +1959,11 @@ static void begin_batch(int device, hipStream_t stream, const uint32_t *indexVec
       release = true;
     }
     t_state->compactions.erase(indexVector);  // the vector is redefined
+    {  // the stream's filters of the batch that just ended are what the new batch's are predicted from
+      FilterHistory &h = t_state->filterHistory[{device, stream}];
+      h.previous.swap(h.current);
+      h.current.clear();
+    }
     FilterJournal j;
     j.device = device;
     j.stream = stream;
@@ -1791,11 +1982,13 @@ static void journal_filter(int device, const uint32_t *indexVector, const FastOp
   auto it = t_state->journals.find(indexVector);
   if (it == t_state->journals.end()) return;
   FilterJournal &j = it->second;
+  // (a filter that is not called with what the previous one returned works on something the journal does not describe)
   if (!f || !j.valid || j.filters.size() >= static_cast<size_t>(kFusedFilters) ||
-      (j.filters.empty() && rowsBefore != j.n0)) {
+      (j.filters.empty() && rowsBefore != j.n0) || (!j.filters.empty() && j.lastCount >= 0 && rowsBefore != j.lastCount)) {
     j.valid = false;
     return;
   }
+  j.lastCount = -1;  // (set by the caller once the count is known)
   FastOperands copy = *f;
   copy.idx = nullptr;
   copy.pad = 0;
@@ -1804,6 +1997,14 @@ static void journal_filter(int device, const uint32_t *indexVector, const FastOp
 }
 
 void invalidate_filter_journal(int device, const uint32_t *indexVector) { journal_filter(device, indexVector, nullptr, 0, 0); }
+
+// the filter that was journalled last kept `count` rows
+static void journal_count(int device, const uint32_t *indexVector, int count) {
+  if (!fuse_available()) return;
+  DeferLock lock(device);
+  auto it = t_state->journals.find(indexVector);
+  if (it != t_state->journals.end() && it->second.valid) it->second.lastCount = count;
+}
 
 static bool journal_is_valid(int device, const uint32_t *indexVector) {
   if (!fuse_available()) return false;
@@ -2215,6 +2416,132 @@ struct FilterCheck {
 };
 }  // namespace
 
+// ---- filters counted in row space (filter_rows_kernel) -----------------------------------------------------------
+namespace {
+// ARES_FILTER_ROWSPACE=0: every filter of the hot shape takes the predicate-vector path (rounds 1-3)
+bool row_space_enabled() {
+  static EnvSwitch<bool> on("ARES_FILTER_ROWSPACE", [](const char *e) { return !(e && e[0] == '0'); });
+  return on.get();
+}
+bool same_column(const FastOperands &a, const FastOperands &b) { return a.vals == b.vals && a.nulls == b.nulls && a.bitOff == b.bitOff; }
+bool same_filter(const FastOperands &a, const FastOperands &b) {
+  return same_column(a, b) && a.akind == b.akind && a.arity == b.arity && a.functor == b.functor && a.I == b.I && a.bkind == b.bkind &&
+         a.bbits == b.bbits && a.bok == b.bok;
+}
+
+// May the call "filter the first n entries of indexVector by a hot-shape comparison over a column of colRows rows" be
+// counted in row space?  The index vector must be iota(0 .. n0) with nothing but journalled filters since, all of them
+// either applied or held as pending row-space filters, and n must be what the last of them returned.
+bool row_space_eligible(int device, hipStream_t stream, const uint32_t *indexVector, int n, uint32_t colRows) {
+  if (!fuse_available() || !row_space_enabled()) return false;
+  DeferLock lock(device);
+  auto j = t_state->journals.find(indexVector);
+  if (j == t_state->journals.end() || !j->second.valid || j->second.device != device || j->second.stream != stream || j->second.start != 0 ||
+      j->second.filters.size() >= static_cast<size_t>(kFusedFilters) || colRows < static_cast<uint32_t>(j->second.n0))
+    return false;
+  auto c = t_state->compactions.find(indexVector);
+  if (j->second.filters.empty()) return n == j->second.n0 && c == t_state->compactions.end();
+  return c != t_state->compactions.end() && !c->second.todo.empty() && c->second.stream == stream &&
+         c->second.applied + c->second.todo.size() == j->second.filters.size() && c->second.lastCount == n;
+}
+
+// The call itself.  f: the filter (idx and pad are ignored: rows = positions).  Returns the survivor count.
+int run_filter_rows(int device, hipStream_t stream, FastOperands f, uint32_t *indexVector, uint8_t *pred, int n, uint32_t colRows,
+                    bool virtualIdx) {
+  f.idx = nullptr;
+  f.pad = 0;
+  constexpr int kGridCap = 2048;  // two partial counts per workgroup come back in one copy
+  static_assert(2 * kGridCap <= kPinnedWords, "the partial counts are read back in one copy");
+  std::shared_ptr<StreamBuffer> bits1, bits2, partials;
+  int grid = 0;
+  bool two = false;
+  FastOperands g = f;
+  uint64_t generation = 0;
+  {
+    DeferLock lock(device);
+    auto ins = t_state->compactions.find(indexVector);
+    if (ins == t_state->compactions.end()) {  // the batch's first filter: the vector is iota(0 .. n)
+      PendingCompact fresh{};
+      fresh.device = device;
+      fresh.stream = stream;
+      fresh.idx = indexVector;
+      fresh.virtualIdx = virtualIdx;
+      fresh.n0 = n;
+      fresh.applied = 0;
+      fresh.lastCount = n;
+      ins = t_state->compactions.emplace(indexVector, fresh).first;
+    }
+    PendingCompact &c = ins->second;
+    FilterHistory &h = t_state->filterHistory[{device, stream}];
+    FilterShape shape{f.akind, f.functor, f.I, f.bkind, f.bbits, f.bok, !c.todo.empty() && same_column(c.todo.back().f, f)};
+    const size_t k = h.current.size();
+    h.current.push_back(shape);
+    if (c.predicted.valid && same_filter(c.predicted.g, f)) {  // counted together with the previous filter: no kernel
+      const int count = c.predicted.count;
+      c.todo.push_back(LazyFilter{f, colRows, pred, n});
+      c.bits = c.predicted.bits;
+      c.lastCount = count;
+      c.predicted = PredictedFilter{};
+      auto j = t_state->journals.find(indexVector);
+      if (j != t_state->journals.end() && j->second.valid) j->second.lastCount = count;
+      return count;
+    }
+    c.predicted = PredictedFilter{};
+    // the filter the previous batch of this stream had right behind this one, if it was on the same column
+    if (k + 1 < h.previous.size() && h.previous[k].same_as(shape) && h.previous[k + 1].sameColumnAsPrevious &&
+        h.previous[k + 1].akind == f.akind && c.applied + c.todo.size() + 2 <= static_cast<size_t>(kFusedFilters)) {
+      const FilterShape &nx = h.previous[k + 1];
+      g.functor = nx.functor;
+      g.I = nx.I;
+      g.bkind = nx.bkind;
+      g.bbits = nx.bbits;
+      g.bok = nx.bok;
+      two = true;
+    }
+    const int64_t numQuads = (static_cast<int64_t>(c.n0) + 3) / 4;
+    const int tiles = static_cast<int>((numQuads + kBlock * kPQ - 1) / (kBlock * kPQ));
+    grid = capped_grid(tiles, kGridCap);
+    const size_t bitBytes = static_cast<size_t>(tiles) * (kPQ * kWaves * 4 * sizeof(uint64_t));  // 4 words per 256-row segment
+    bits1 = std::make_shared<StreamBuffer>(bitBytes, stream);
+    if (two) bits2 = std::make_shared<StreamBuffer>(bitBytes, stream);
+    partials = std::make_shared<StreamBuffer>(sizeof(uint32_t) * 2 * static_cast<size_t>(grid), stream);
+    ARES_LAUNCH("filter_rows_kernel", filter_rows_kernel, grid, kBlock, stream, f, g, two ? 1 : 0,
+                c.bits ? c.bits->as<uint64_t>() : static_cast<const uint64_t *>(nullptr), bits1->as<uint64_t>(),
+                two ? bits2->as<uint64_t>() : static_cast<uint64_t *>(nullptr), c.n0, tiles, partials->as<uint32_t>());
+    // booked before the count is known: a flush from another thread that applies the pending filters meanwhile
+    // applies this one too
+    c.todo.push_back(LazyFilter{f, colRows, pred, n});
+    c.bits = bits1;
+    c.lastCount = -1;
+    generation = ++t_state->filterGeneration;
+    c.generation = generation;
+  }
+  uint32_t parts[2 * kGridCap];
+  read_back_u32(partials->as<uint32_t>(), parts, 2 * grid, stream);
+  uint32_t count = 0, count2 = 0;
+  for (int b = 0; b < grid; b++) {
+    count += parts[2 * b];
+    count2 += parts[2 * b + 1];
+  }
+  {
+    DeferLock lock(device);
+    auto it = t_state->compactions.find(indexVector);
+    if (it != t_state->compactions.end() && it->second.generation == generation) {
+      it->second.lastCount = static_cast<int>(count);
+      if (two) {
+        it->second.predicted.valid = true;
+        it->second.predicted.g = g;
+        it->second.predicted.count = static_cast<int>(count2);
+        it->second.predicted.bits = bits2;
+      }
+    }
+    auto j = t_state->journals.find(indexVector);
+    if (j != t_state->journals.end() && j->second.valid) j->second.lastCount = static_cast<int>(count);
+  }
+  return static_cast<int>(count);
+}
+}  // namespace
+
 static int run_filter(const InputVector *ins, int arity, uint32_t *indexVector, uint8_t *pred, int n,
                       RecordID **recordIDVectors, int numForeignTables, uint32_t *baseCounts, uint32_t startCount,
                       int functor, hipStream_t stream, int device) {
@@ -2235,16 +2562,27 @@ static int run_filter(const InputVector *ins, int arity, uint32_t *indexVector, 
     build_params(ins, arity, stream, indexVector, baseCounts, startCount, functor, p, temps);
   }
   p.needRow = 1;
-  mem_note_write(device, pred, static_cast<size_t>(n));
+  static const bool onePass = [] {
+    const char *e = getenv("ARES_FILTER");
+    return e && strcmp(e, "onepass") == 0;
+  }();
   // a filter of the hot shape consumes a not-yet-written iota index vector directly; everything
   // else that is pending on the device is launched first
-  bool virtualIdx = false;
+  bool virtualIdx = false, rowSpace = false;
   {
     FastOperands probe;
-    if (!is_wide(p.a.kind) && indexVector != nullptr && numForeignTables == 0 && fast_operands(p, probe, true))
+    if (!is_wide(p.a.kind) && indexVector != nullptr && numForeignTables == 0 && fast_operands(p, probe, true)) {
       virtualIdx = virtual_iota(device, indexVector, n, true);
+      // ... and, while every filter of the batch has been of that shape, is only counted — over the batch's rows, with
+      // the filters before it (run_filter_rows): the pending ones of this very vector stay pending through the flush
+      rowSpace = !onePass && baseCounts == nullptr && row_space_eligible(device, stream, indexVector, n, p.a.length);
+    }
   }
-  flush_deferred(device);
+  if (rowSpace) flush_deferred_impl(device, nullptr, nullptr, indexVector);
+  else flush_deferred(device);
+  // (the flush may have applied them after all: queued transforms that read the vector were launched)
+  rowSpace = rowSpace && row_space_eligible(device, stream, indexVector, n, p.a.length);
+  if (!rowSpace) mem_note_write(device, pred, static_cast<size_t>(n));  // (a counted filter writes no predicate bytes unless it is replayed)
   materialize_index_vector(device, indexVector);
   if (is_wide(p.a.kind)) {
     // wide operands: evaluate the predicate with the wide transform kernel, then compact by pred
@@ -2259,14 +2597,17 @@ static int run_filter(const InputVector *ins, int arity, uint32_t *indexVector, 
   }
   FastOperands f;
   const bool fast = !is_wide(p.a.kind) && indexVector != nullptr && fast_operands(p, f, true);
-  static const bool onePass = [] {
-    const char *e = getenv("ARES_FILTER");
-    return e && strcmp(e, "onepass") == 0;
-  }();
   if (fast && !onePass && numForeignTables == 0 && baseCounts == nullptr)
     journal_filter(device, indexVector, &f, p.a.length, n);
   else
     journal_filter(device, indexVector, nullptr, 0, 0);
+  if (rowSpace && fast && journal_is_valid(device, indexVector))
+    return run_filter_rows(device, stream, f, indexVector, pred, n, p.a.length, virtualIdx);
+  if (rowSpace) {  // (cannot happen: eligibility implies all of the above) the predicate vector is written after all
+    mem_note_write(device, pred, static_cast<size_t>(n));
+    DeferLock lock(device);
+    run_compaction(indexVector);
+  }
   if (fast && !onePass) {
     // two-phase path: predicate + tile counts, scan, chain-free compaction of the index vector and
     // of every RecordID vector
@@ -2544,7 +2885,7 @@ uintptr_t hook_on_free(int device, void *ptr, size_t bytes) {
             launch_queue(kv.first.second, kv.second);
           }
         it = t_state->compactions.begin();  // (launch_queue erased the entry)
-      } else if (range_of(it->second.idx, 4ull * it->second.n).overlaps(r)) {
+      } else if (range_of(it->second.idx, 4ull * (it->second.todo.empty() ? it->second.n : it->second.n0)).overlaps(r)) {
         it = t_state->compactions.erase(it);  // the index vector itself goes: nobody will read the compacted vector
       } else {
         // only the predicate vector goes, the index vector stays live (a later transform, filter or
@@ -2648,6 +2989,7 @@ void hook_on_stream_destroy(int device, void *streamPtr) {
         it = (it->second.device == device && it->second.stream == stream) ? t_state->compactions.erase(it) : std::next(it);
       for (auto it = t_state->iotas.begin(); it != t_state->iotas.end();)
         it = (it->second.device == device && it->second.stream == stream) ? t_state->iotas.erase(it) : std::next(it);
+      t_state->filterHistory.erase({device, stream});
       // lazy fills that were defined on this stream and are still unwritten: from now on they are written on the stream
       // of whoever needs them (the null stream stands for "the caller's", see launch_fill)
       for (auto &kv : t_state->fills)

@@ -4,14 +4,18 @@ from . import abi
 from .executor import Binary, Col, Const, DimensionSpec, QueryPlan
 
 
-def c3_plan(use_hash_reduction=True, with_filter=True, dims=("ts", "d1", "d2", "d3"), d1_below=90):
+def c3_plan(use_hash_reduction=True, with_filter=True, dims=("ts", "d1", "d2", "d3"), d1_below=90, ts_range=None):
     """BASELINE config C3; `dims` selects a subset of its four group-by dimensions (lower-cardinality variants of the
-    same query: the filter and the measure stay), `d1_below` the filter constant."""
+    same query: the filter and the measure stay), `d1_below` the filter constant.  ts_range = (from, to): the two time
+    filters the Go host puts in front of every fact-table query's own filters — ts >= from, ts < to
+    (query/aql_processor.go:543-559, query/common/time_filter.go:371-397)."""
     specs = {"ts": DimensionSpec(Binary(abi.Floor, Col("ts"), Const(3600)), abi.Uint32),
              "d1": DimensionSpec(Col("d1"), abi.Uint32), "d2": DimensionSpec(Col("d2"), abi.Uint32),
              "d3": DimensionSpec(Col("d3"), abi.Uint32)}
+    time_filters = [] if ts_range is None else [Binary(abi.GreaterThanOrEqual, Col("ts"), Const(int(ts_range[0]))),
+                                                Binary(abi.LessThan, Col("ts"), Const(int(ts_range[1])))]
     return QueryPlan(
-        filters=[Binary(abi.LessThan, Col("d1"), Const(d1_below))] if with_filter else [],
+        filters=time_filters + ([Binary(abi.LessThan, Col("d1"), Const(d1_below))] if with_filter else []),
         dimensions=[specs[d] for d in dims],
         measure=Col("m"), agg=abi.AGGR_SUM_FLOAT, measure_type=abi.Float64,
         use_hash_reduction=use_hash_reduction)

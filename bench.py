@@ -253,7 +253,8 @@ def single_process(args, backend=None, tensor_device=None):
         be.call("BootstrapDevice")
     rows, batch_rows = int(args.rows), int(args.batch_rows)
     dims = tuple(d for d in args.dims.split(",") if d)
-    plan = c3_plan(use_hash_reduction=True, dims=dims, d1_below=args.d1_below)
+    ts_range = tuple(int(x) for x in args.ts_range.split(",")) if args.ts_range else None
+    plan = c3_plan(use_hash_reduction=True, dims=dims, d1_below=args.d1_below, ts_range=ts_range)
     comms = NativeComm.local(n, on_gpu)
     barrier = threading.Barrier(n)
     state = {"elapsed": [0.0] * n, "merged": [0] * n, "errors": [], "checks": [None] * n}
@@ -295,7 +296,7 @@ def single_process(args, backend=None, tensor_device=None):
                 every = []
                 for q in range(n):
                     every += workload.c3_shard(rows, batch_rows, seed=1 + q, device=tdev, null_fraction=args.null_fraction)
-                state["checks"][0] = check.compare_result(last.fetch(), check.exact_groups(every, dims=dims, d1_below=args.d1_below),
+                state["checks"][0] = check.compare_result(last.fetch(), check.exact_groups(every, dims=dims, d1_below=args.d1_below, ts_range=ts_range),
                                                           hash_identity=True, dims=dims)
             last.release()
             for s_ in streams:
@@ -361,6 +362,8 @@ def main(argv=None, backend=None, tensor_device=None):
     ap.add_argument("--dims", default="ts,d1,d2,d3",
                     help="group-by dimensions, a subset of C3's four (lower-cardinality variants of the same query: secondary legs)")
     ap.add_argument("--d1-below", type=int, default=90, help="constant of the filter d1 < K")
+    ap.add_argument("--ts-range", default="", help="from,to: the Go host's two time filters (ts >= from, ts < to) in front of the "
+                                                   "query's own filter — the shape every fact-table query has (secondary leg)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes that measure roofline.traffic")
     ap.add_argument("--single-process", action="store_true",
                     help="N shards on N GPUs as N threads of THIS process (the reference's process model, "
@@ -417,10 +420,11 @@ def main(argv=None, backend=None, tensor_device=None):
     vps = [({k: rc.vp for k, rc in b.items()}, next(iter(b.values())).length) for b in batches]
     dims = tuple(d for d in args.dims.split(",") if d)
     assert dims and all(d in check.ALL_DIMS for d in dims), args.dims
-    plan = c3_plan(use_hash_reduction=True, dims=dims, d1_below=args.d1_below)
+    ts_range = tuple(int(x) for x in args.ts_range.split(",")) if args.ts_range else None
+    plan = c3_plan(use_hash_reduction=True, dims=dims, d1_below=args.d1_below, ts_range=ts_range)
     plan.use_fused_extension = bool(args.fused_extension)
-    # columns the plan reads (dimensions + measure + the filter's d1): the algorithmic bytes per row
-    plan_columns = sorted(set(dims) | {"m", "d1"})
+    # columns the plan reads (dimensions + measure + the filter's d1 [+ ts of the time filters]): the algorithmic bytes per row
+    plan_columns = sorted(set(dims) | {"m", "d1"} | ({"ts"} if ts_range else set()))
 
     def sync():
         if on_gpu:
@@ -472,7 +476,7 @@ def main(argv=None, backend=None, tensor_device=None):
         ctx = run_shard(be, plan, vps, device_index, streams)
         sync()
         cold["cold_first_query_ms"] = (time.perf_counter() - t0) * 1e3
-        rep = check.compare_result(ctx.fetch(), check.exact_groups(batches, dims=dims, d1_below=args.d1_below), hash_identity=True, dims=dims)
+        rep = check.compare_result(ctx.fetch(), check.exact_groups(batches, dims=dims, d1_below=args.d1_below, ts_range=ts_range), hash_identity=True, dims=dims)
         cold["cold_check_groups"] = rep["status"]
         ctx.release()
         cold["rtc_after_cold_query"] = be.rtc_wait()  # (waits for the kernels the first query asked for)
@@ -485,13 +489,13 @@ def main(argv=None, backend=None, tensor_device=None):
         sync()
         cold["warm_query_ms"] = (time.perf_counter() - t0) * 1e3
         ctx.release()
-        plan2 = c3_plan(use_hash_reduction=True, dims=dims, d1_below=args.d1_below - 7)  # another constant, never seen
+        plan2 = c3_plan(use_hash_reduction=True, dims=dims, d1_below=args.d1_below - 7, ts_range=ts_range)  # another constant, never seen
         sync()
         t0 = time.perf_counter()
         ctx = run_shard(be, plan2, vps, device_index, streams)
         sync()
         cold["new_constants_query_ms"] = (time.perf_counter() - t0) * 1e3
-        rep = check.compare_result(ctx.fetch(), check.exact_groups(batches, dims=dims, d1_below=args.d1_below - 7), hash_identity=True, dims=dims)
+        rep = check.compare_result(ctx.fetch(), check.exact_groups(batches, dims=dims, d1_below=args.d1_below - 7, ts_range=ts_range), hash_identity=True, dims=dims)
         cold["new_constants_check_groups"] = rep["status"]
         cold["rtc_after_new_constants"] = be.rtc_wait()
         ctx.release()
@@ -575,11 +579,11 @@ def main(argv=None, backend=None, tensor_device=None):
             every = []
             for r in range(world):
                 every += workload.c3_shard(rows, batch_rows, seed=1 + r, device=tdev, null_fraction=args.null_fraction)
-            merged_check = check.compare_result(ctx.fetch(), check.exact_groups(every, dims=dims, d1_below=args.d1_below),
+            merged_check = check.compare_result(ctx.fetch(), check.exact_groups(every, dims=dims, d1_below=args.d1_below, ts_range=ts_range),
                                                 hash_identity=True, dims=dims)
         ctx.release()
         ctx = run_shard(be, plan, vps, device_index, streams)
-    report = check.compare_result(ctx.fetch(), check.exact_groups(batches, dims=dims, d1_below=args.d1_below), hash_identity=True, dims=dims)
+    report = check.compare_result(ctx.fetch(), check.exact_groups(batches, dims=dims, d1_below=args.d1_below, ts_range=ts_range), hash_identity=True, dims=dims)
     groups = ctx.result_size
     ok = report["status"] == "ok" and report["groups"] == groups
     if merged_check is not None:
@@ -685,6 +689,8 @@ def main(argv=None, backend=None, tensor_device=None):
                     legs[name] = {"error": "timeout"}
 
             # in the order of what the round's review asks about first; the two long ones last
+            # the query shape the Go host really issues: ts >= from, ts < to in front of the query's own filter
+            leg("time_filters_ts_ge_lt_then_d1", {}, big + ["--ts-range", "3600,601200"])
             leg(f"live_batches_{LIVE_BATCH_ROWS}_rows", {}, common + ["--batch-rows", str(LIVE_BATCH_ROWS)])
             # lower-cardinality variants of the same query (same filter and measure; fewer group-by dimensions)
             leg("groups_100_dims_d2_d3", {}, big + ["--dims", "d2,d3"])        # TABLE-mode scan, ~100 groups, 4 columns read

@@ -32,7 +32,9 @@ def main():
     ap.add_argument("--null-fraction", type=float, default=0.01)
     ap.add_argument("--fused-extension", action="store_true")
     ap.add_argument("--streams", type=int, default=1, help="2: alternate two streams per batch like the Go host")
+    ap.add_argument("--ts-range", default="", help="from,to: the Go host's two time filters in front of the query's own")
     args = ap.parse_args()
+    ts_range = tuple(int(x) for x in args.ts_range.split(",")) if args.ts_range else None
     dev = torch.device("cuda:0")
     be = abi.load_hip_backend()
     be.call("BootstrapDevice")
@@ -40,7 +42,7 @@ def main():
     batches = workload.c3_shard(int(args.rows), int(args.batch_rows), seed=args.seed, device=dev,
                                 null_fraction=args.null_fraction)
     torch.cuda.synchronize()
-    plan = c3_plan(use_hash_reduction=True)
+    plan = c3_plan(use_hash_reduction=True, ts_range=ts_range)
     plan.use_fused_extension = args.fused_extension
     ctx = NativeQuery(be, plan, NAMES, device=0, stream=streams[0], streams=streams)
     sizes = []
@@ -48,7 +50,7 @@ def main():
         ctx.run({k: rc.vp for k, rc in b.items()}, next(iter(b.values())).length)
         sizes.append(ctx.result_size)
     fetched = ctx.fetch()
-    report = check.compare_result(fetched, check.exact_groups(batches), hash_identity=True)
+    report = check.compare_result(fetched, check.exact_groups(batches, ts_range=ts_range), hash_identity=True)
     report.update({"rows": int(args.rows), "batch_rows": int(args.batch_rows), "result_sizes": sizes,
                    "fused_batches": ctx.fused_batches,
                    "env": {k: v for k, v in os.environ.items() if k.startswith("ARES_")}})

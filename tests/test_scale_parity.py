@@ -41,6 +41,12 @@ C3_VARIANTS = [
     ("eager", {"ARES_DEFER": "0"}, MID),
     ("ungrouped", {"ARES_GROUPED": "0"}, MID),
     ("live_batches", {}, LIVE + ["--streams", "2"]),
+    # the query shape the Go host really issues: ts >= from, ts < to in front of the query's own filter — counted in row
+    # space, the second one predicted from the stream's previous batch (five batches per stream); and the same with the
+    # filters taking the predicate-vector path of rounds 1-3
+    ("time_filters", {}, ["--rows", str(40 << 20), "--batch-rows", str(4 << 20), "--streams", "2", "--ts-range", "40000,560000"]),
+    ("time_filters_pred_vectors", {"ARES_FILTER_ROWSPACE": "0"},
+     ["--rows", str(40 << 20), "--batch-rows", str(8 << 20), "--streams", "2", "--ts-range", "40000,560000"]),
 ]
 
 
@@ -54,7 +60,7 @@ def test_c3_key_level_parity_at_scale(name, env, args):
     assert r.returncode == 0 and report["status"] == "ok", report
     assert report["groups"] == report["expected_groups"] > 1_000_000
     assert report["result_sizes"][-1] == report["groups"]
-    if name in ("fused", "two_streams", "live_batches"):
+    if name in ("fused", "two_streams", "live_batches", "time_filters"):
         assert report["fused_batches"] == 0  # (the extension counter: these go through the plain ABI)
     if name == "extension":
         assert report["fused_batches"] == len(report["result_sizes"])

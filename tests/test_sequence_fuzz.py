@@ -77,6 +77,11 @@ class Program:
                 dim_exprs.append((col, op, int(rng.integers(1, 5000))))
         value_bytes = 4 * ndims4 + (2 if with_short else 0)
         widths = [4] * ndims4 + ([2] if with_short else [])
+        # the Go host's two time filters (ts >= from, ts < to: query/aql_processor.go:543-559) in front of every batch's own
+        # filters, the same constants for the whole query: consecutive filters of the hot shape on one column
+        time_filters = bool(rng.random() < 0.4)
+        t_from = int(rng.integers(0, 86400))
+        t_to = int(rng.integers(86400, 86400 * 2 + 5000))
 
         def offsets(cap):
             out, off = [], 0
@@ -110,7 +115,14 @@ class Program:
             idx, pred = H.Buf(be, nbytes=4 * n), H.Buf(be, nbytes=n)
             be.call("InitIndexVector", idx.ptr, 0, n, stream, 0)
             size = n
-            for _ in range(int(rng.integers(0, 4))):
+            if time_filters:
+                for op, const in ((abi.GreaterThanOrEqual, t_from), (abi.LessThan, t_to)):
+                    size = be.call("BinaryFilter", cols["ts"].input(), H.const_int(const), idx.ptr, pred.ptr, size, None, 0, None, 0,
+                                   op, stream, 0)
+                    obs.append(("filter", b, size))
+                    if size == 0:
+                        break
+            for _ in range(int(rng.integers(0, 4)) if size else 0):
                 kind = rng.random()
                 if kind < 0.75:    # fast shape: column <cmp> constant
                     col = ["ts", "u", "i", "d", "f"][int(rng.integers(0, 5))]

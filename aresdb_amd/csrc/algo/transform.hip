@@ -1961,8 +1961,10 @@ static void begin_batch(int device, hipStream_t stream, const uint32_t *indexVec
     t_state->compactions.erase(indexVector);  // the vector is redefined
     {  // the stream's filters of the batch that just ended are what the new batch's are predicted from
       FilterHistory &h = t_state->filterHistory[{device, stream}];
-      h.previous.swap(h.current);
-      h.current.clear();
+      if (!h.current.empty()) {  // (the Sort path opens a second index vector per batch: no filters there, nothing to learn)
+        h.previous.swap(h.current);
+        h.current.clear();
+      }
     }
     FilterJournal j;
     j.device = device;

@@ -133,7 +133,8 @@ def _partitioned_worker(rank, world, port, use_hash, all_to_all, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,all_to_all", [(2, True), (3, True), (3, False)], ids=["2_all_to_all", "3_all_to_all", "3_all_gathers"])
+@pytest.mark.parametrize("world,all_to_all", [(2, True), (3, True), (3, False), (8, True)],
+                         ids=["2_all_to_all", "3_all_to_all", "3_all_gathers", "8_all_to_all"])
 @pytest.mark.parametrize("use_hash", [True, False], ids=["hash_reduce", "sort_reduce"])
 def test_hash_partitioned_shard_merge_gloo(use_hash, world, all_to_all):
     port = _free_port()
@@ -149,7 +150,7 @@ def test_hash_partitioned_shard_merge_gloo(use_hash, world, all_to_all):
     assert sum(r[2] for r in results) > 0 and all(r[2] > 0 for r in results)  # every rank owns a share
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])  # 8: one node's worth of shards (BASELINE config C5)
 @pytest.mark.parametrize("use_hash", [True, False], ids=["hash_reduce", "sort_reduce"])
 def test_native_shard_merge_gloo(use_hash, world):
     port = _free_port()
@@ -158,7 +159,7 @@ def test_native_shard_merge_gloo(use_hash, world):
     procs = [ctx.Process(target=_native_worker, args=(r, world, port, use_hash, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=180) for _ in range(world)]
+    results = [q.get(timeout=400) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] == "ok" for r in results), results
@@ -183,6 +184,8 @@ def _hll_worker(rank, world, port, q):
         rng = np.random.default_rng(77)
         # rank 2 of three has an empty shard; a dense group (> 4096 registers) needs many users of one (day, d3) pair
         sizes = [[4000, 2500], [3000, 60000], []] if world == 3 else [[4000, 2500, 30000], [3000, 45000]]
+        if world > 3:  # eight shards: one dense, one empty, the rest small
+            sizes = [[3000, 45000]] + [[1500 + 300 * r] for r in range(1, world - 1)] + [[]]
         shards = [_hll_batches(rng, sz) for sz in sizes]
         for sh in shards:  # dense groups: few distinct group keys
             for cols, valid in sh:
@@ -210,7 +213,7 @@ def _hll_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_hll_shard_merge_gloo(world):
     port = _free_port()
     ctx = mp.get_context("spawn")
@@ -218,14 +221,14 @@ def test_hll_shard_merge_gloo(world):
     procs = [ctx.Process(target=_hll_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=300) for _ in range(world)]
+    results = [q.get(timeout=600) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
     assert all(r[1] == "ok" for r in results), results
     assert len({r[2] for r in results}) == 1 and results[0][2] > 0
 
 
-def _threads_merge(be, device_memory, shards_of, plan, names, nranks, make_stream=None):
+def _threads_merge(be, device_memory, shards_of, plan, names, nranks, make_stream=None, device_of=lambda r: 0):
     """nranks shards as nranks threads of this process (the reference's process model), merged inside
     libaresdriver.so through the in-process communicator; returns every rank's merged table."""
     import threading
@@ -236,7 +239,7 @@ def _threads_merge(be, device_memory, shards_of, plan, names, nranks, make_strea
     def work(r):
         try:
             stream = make_stream() if make_stream else None
-            ctx = NativeQuery(be, plan, names, device=0, stream=stream)
+            ctx = NativeQuery(be, plan, names, device=device_of(r), stream=stream)
             for b in shards_of(r):
                 ctx.run({k: rc.vp for k, rc in b.items()}, next(iter(b.values())).length)
             ctx.merge_shards(comms[r])
@@ -276,6 +279,28 @@ def test_shards_as_threads_of_one_process(use_hash):
     got = _threads_merge(be, False, lambda r: shards[r], plan, names, 3)
     want = _single_process_result(be, plan, [b for s in shards for b in s])
     for r in range(3):
+        assert got[r].keys() == want.keys(), (r, len(got[r]), len(want))
+        for k, v in want.items():
+            assert abs(got[r][k] - v) <= 1e-9 * max(1.0, abs(v)), (r, k)
+
+
+@pytest.mark.parametrize("use_hash", [True, False], ids=["hash_reduce", "sort_reduce"])
+def test_eight_shard_threads_on_eight_device_indices(use_hash):
+    """BASELINE config C5's shape in the reference's process model: eight shards, eight threads, device index r for
+    shard r (query/device_manager.go:185-218) — on the oracle, which has one simulated device, so what this exercises is
+    the host side: every device-keyed structure of libaresdriver.so and of the Python driver sees indices 0 .. 7, and
+    the in-process communicator runs with eight ranks."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import harness as H
+    from aresdb_amd import workload
+    from aresdb_amd.queries import c3_plan
+    be = H.oracle_backend()
+    plan = c3_plan(use_hash_reduction=use_hash)
+    names = [n for n, _ in workload.C3_COLUMNS]
+    shards = [workload.c3_shard(2500 + 300 * r, 1024, seed=41 + r, device="cpu") for r in range(8)]
+    got = _threads_merge(be, False, lambda r: shards[r], plan, names, 8, device_of=lambda r: r)
+    want = _single_process_result(be, plan, [b for s in shards for b in s])
+    for r in range(8):
         assert got[r].keys() == want.keys(), (r, len(got[r]), len(want))
         for k, v in want.items():
             assert abs(got[r][k] - v) <= 1e-9 * max(1.0, abs(v)), (r, k)

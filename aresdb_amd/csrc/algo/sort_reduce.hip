@@ -216,6 +216,97 @@ __global__ __launch_bounds__(kBlock) void radix_pass_kernel(const uint64_t *keys
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Sort step 3: fix-up after sorting the TOP 32 bits only
+// ---------------------------------------------------------------------------------------------
+// The order of Reduce's output — ascending 64-bit hash — is observable, so the sort has to be by all 64 bits.  With
+// (pseudo-)random hashes the top 32 bits already decide the order of nearly every pair (of 50 M distinct hashes about
+// 50e6^2 / 2 / 2^32 = 290 k pairs share their top half): four stable passes over bits 32..63, then
+//   detect   one thread per element i: a DESCENT (same top half as element i - 1, smaller low half) means its segment —
+//            the run of equal top halves — is out of order.  The thread of a segment's FIRST descent walks to the
+//            segment's ends (bounded by kFixupMaxRun) and lists [start, end).  Segments without a descent — every run of
+//            equal keys however long: a hot group — cost one comparison per element and are never walked;
+//   sort     one thread per listed segment: stable insertion sort by the low half, in place (segments are disjoint).
+// Equal top halves keep their input order through the four passes and equal keys theirs through the insertion sort:
+// the result is the stable sort by the whole key.  A listed segment longer than kFixupMaxRun, or a full list, raises
+// `fallback`: the caller runs all eight passes over the data as it is (a stable permutation of the input, so the
+// result is the same).  Logic first checked on the CPU (tools/prototypes/sort_topbits_fixup.hpp, tests/test_prototypes.py).
+constexpr int kFixupMaxRun = 64;
+struct FixupSegment {
+  uint32_t start, end;
+};
+struct FixupParams {
+  uint64_t *keys;
+  uint32_t *vals;
+  int n;
+  FixupSegment *work;
+  uint32_t *workCount;  // zeroed; may exceed workCap (then fallback is set)
+  uint32_t workCap;
+  uint32_t *fallback;   // zeroed
+};
+
+__global__ __launch_bounds__(kBlock) void sort_fixup_detect_kernel(FixupParams p) {
+  for (int64_t i64 = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i64 < p.n; i64 += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int i = static_cast<int>(i64);
+    if (i == 0) continue;
+    const uint64_t k = p.keys[i], before = p.keys[i - 1];
+    if ((k >> 32) != (before >> 32) || static_cast<uint32_t>(k) >= static_cast<uint32_t>(before)) continue;
+    const uint32_t top = static_cast<uint32_t>(k >> 32);
+    // the first descent of the segment lists it: walk back to the segment's start, giving up at an earlier descent
+    int s = i - 1;
+    bool mine = true;
+    while (s > 0 && static_cast<uint32_t>(p.keys[s - 1] >> 32) == top) {
+      if (static_cast<uint32_t>(p.keys[s]) < static_cast<uint32_t>(p.keys[s - 1])) {
+        mine = false;
+        break;
+      }
+      s--;
+      if (i - s > kFixupMaxRun) {
+        *p.fallback = 1u;
+        mine = false;
+        break;
+      }
+    }
+    if (!mine) continue;
+    int e = i + 1;
+    while (e < p.n && static_cast<uint32_t>(p.keys[e] >> 32) == top) {
+      e++;
+      if (e - s > kFixupMaxRun) {
+        *p.fallback = 1u;
+        mine = false;
+        break;
+      }
+    }
+    if (!mine) continue;
+    const uint32_t slot = atomicAdd(p.workCount, 1u);
+    if (slot >= p.workCap) {
+      *p.fallback = 1u;
+      continue;
+    }
+    p.work[slot] = FixupSegment{static_cast<uint32_t>(s), static_cast<uint32_t>(e)};
+  }
+}
+
+__global__ __launch_bounds__(64) void sort_fixup_sort_kernel(FixupParams p) {
+  const uint32_t listed = *p.workCount;
+  const uint32_t count = listed < p.workCap ? listed : p.workCap;
+  for (uint32_t w = blockIdx.x * 64 + threadIdx.x; w < count; w += gridDim.x * 64) {
+    const FixupSegment seg = p.work[w];
+    for (uint32_t a = seg.start + 1; a < seg.end; a++) {
+      const uint64_t k = p.keys[a];
+      const uint32_t v = p.vals[a];
+      uint32_t b = a;
+      while (b > seg.start && static_cast<uint32_t>(p.keys[b - 1]) > static_cast<uint32_t>(k)) {  // strict: equal keys keep their order
+        p.keys[b] = p.keys[b - 1];
+        p.vals[b] = p.vals[b - 1];
+        b--;
+      }
+      p.keys[b] = k;
+      p.vals[b] = v;
+    }
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void fill_u64_kernel(uint64_t *p, uint64_t v, int n) {
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
        i += static_cast<int64_t>(gridDim.x) * kBlock)
@@ -245,13 +336,19 @@ void sort_rows(const uint8_t *dimValues, const DimLayoutD &L, size_t capacity, c
   const int numTiles = (length + kSortTile - 1) / kSortTile;
   const size_t histBytes = 8 * 256 * sizeof(uint32_t);
   const size_t statusBytes = static_cast<size_t>(numTiles) * 256 * sizeof(uint32_t);
-  // workspace: [hist 8 KiB][8 tickets][status][alt keys][alt vals]
+  // Row hashes are sorted by their top half and fixed up (above); HyperLogLog keys carry the register id in their low
+  // 16 bits — equal top halves are the rule there — and keep the eight passes.  ARES_SORT_TOPBITS=0: eight passes always.
+  static EnvSwitch<bool> topBits("ARES_SORT_TOPBITS", [](const char *e) { return !(e && e[0] == '0'); });
+  const bool topOnly = !hllValues && topBits.get();
+  const uint32_t workCap = topOnly ? static_cast<uint32_t>(length / 8 + 1024) : 0u;
+  // workspace: [hist 8 KiB][8 tickets, error, fix-up counters][status][alt keys][alt vals][fix-up segments]
   const size_t offTicket = histBytes, offStatus = offTicket + 64, offKeys = (offStatus + statusBytes + 255) & ~size_t(255);
   const size_t offVals = offKeys + sizeof(uint64_t) * static_cast<size_t>(length);
-  StreamBuffer ws(offVals + sizeof(uint32_t) * static_cast<size_t>(length) + 256, stream);
+  const size_t offWork = (offVals + sizeof(uint32_t) * static_cast<size_t>(length) + 255) & ~size_t(255);
+  StreamBuffer ws(offWork + sizeof(FixupSegment) * static_cast<size_t>(workCap) + 256, stream);
   uint8_t *base = ws.as<uint8_t>();
   uint32_t *hist = reinterpret_cast<uint32_t *>(base);
-  unsigned int *tickets = reinterpret_cast<unsigned int *>(base + offTicket);
+  unsigned int *tickets = reinterpret_cast<unsigned int *>(base + offTicket);  // [0..7] tickets, [8] error, [9] segments listed, [10] fallback
   uint32_t *status = reinterpret_cast<uint32_t *>(base + offStatus);
   uint64_t *altKeys = reinterpret_cast<uint64_t *>(base + offKeys);
   uint32_t *altVals = reinterpret_cast<uint32_t *>(base + offVals);
@@ -262,16 +359,41 @@ void sort_rows(const uint8_t *dimValues, const DimLayoutD &L, size_t capacity, c
               keyVector, length, hist, hllValues, iotaPayload ? payload : nullptr);
   ARES_LAUNCH("digit_start_kernel", digit_start_kernel, 8, 256, stream, hist);
   const int passGrid = capped_grid(numTiles, 256 * 3);
-  for (int pass = 0; pass < 8; pass++) {
-    hip_check(hipMemsetAsync(status, 0, statusBytes, stream), "hipMemsetAsync");
-    const bool even = (pass & 1) == 0;
-    ARES_LAUNCH("radix_pass_kernel", radix_pass_kernel, passGrid, kBlock, stream, even ? keyVector : altKeys, even ? payload : altVals,
-                       even ? altKeys : keyVector, even ? altVals : payload, length, 8 * pass,
-                       hist + 256 * pass, tickets + pass, tickets + 8, status, numTiles);
+  auto run_passes = [&](int first) {  // an even number of passes: the data ends where it started (keyVector / payload)
+    for (int pass = first; pass < 8; pass++) {
+      hip_check(hipMemsetAsync(status, 0, statusBytes, stream), "hipMemsetAsync");
+      const bool even = ((pass - first) & 1) == 0;
+      ARES_LAUNCH("radix_pass_kernel", radix_pass_kernel, passGrid, kBlock, stream, even ? keyVector : altKeys, even ? payload : altVals,
+                  even ? altKeys : keyVector, even ? altVals : payload, length, 8 * pass, hist + 256 * pass, tickets + pass, tickets + 8,
+                  status, numTiles);
+    }
+  };
+  run_passes(topOnly ? 4 : 0);
+  uint32_t back[3] = {0, 0, 0};  // {error, segments listed, fallback}
+  if (topOnly) {
+    FixupParams fp;
+    fp.keys = keyVector;
+    fp.vals = payload;
+    fp.n = length;
+    fp.work = reinterpret_cast<FixupSegment *>(base + offWork);
+    fp.workCount = tickets + 9;
+    fp.workCap = workCap;
+    fp.fallback = tickets + 10;
+    ARES_LAUNCH("sort_fixup_detect_kernel", sort_fixup_detect_kernel, capped_grid((static_cast<int64_t>(length) + kBlock - 1) / kBlock, 256 * 16),
+                kBlock, stream, fp);
+    ARES_LAUNCH("sort_fixup_sort_kernel", sort_fixup_sort_kernel, 256 * 4, 64, stream, fp);
   }
-  uint32_t err = 0;
-  read_back_u32(tickets + 8, &err, 1, stream);
-  if (err) throw AlgorithmError("ERROR: Sort: inter-tile scan timed out");
+  read_back_u32(tickets + 8, back, 3, stream);
+  if (back[0]) throw AlgorithmError("ERROR: Sort: inter-tile scan timed out");
+  if (topOnly && back[2]) {
+    // a long run of equal top halves that is out of order (or more segments than the list holds): all eight passes over
+    // the data as it is — a stable permutation of the input (the fix-up's partial work included), so the result is the same
+    hip_check(hipMemsetAsync(tickets, 0, 64, stream), "hipMemsetAsync");
+    run_passes(0);
+    uint32_t err = 0;
+    read_back_u32(tickets + 8, &err, 1, stream);
+    if (err) throw AlgorithmError("ERROR: Sort: inter-tile scan timed out");
+  }
 }
 
 static void sort_impl(const DimensionVector &keys, int length, hipStream_t stream) {

@@ -15,6 +15,7 @@
 #include <dlfcn.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -921,9 +922,11 @@ __global__ __launch_bounds__(kBlock) void filter_pred_kernel(FastOperands f, uin
 // `two`: a second filter `g` over the SAME column is evaluated as well (the host predicts it from the previous batch of
 // the stream: ts >= from is followed by ts < to); blockTotals holds two partials per workgroup, bitsOut2 the survivors
 // of both.
-__global__ __launch_bounds__(kBlock) void filter_rows_kernel(FastOperands f, FastOperands g, int two, const uint64_t *bitsIn,
+template <bool TWO, bool HAS_IN>
+__global__ __launch_bounds__(kBlock) void filter_rows_kernel(FastOperands f, FastOperands g, const uint64_t *bitsIn,
                                                              uint64_t *bitsOut, uint64_t *bitsOut2, int n, int numTiles,
                                                              uint32_t *blockTotals) {
+  constexpr bool two = TWO;
   __shared__ uint32_t sTotal[2];
   if (threadIdx.x < 2) sTotal[threadIdx.x] = 0;
   uint32_t mine = 0, mine2 = 0;  // wave-uniform: survivors of the segments this wavefront has seen
@@ -959,7 +962,7 @@ __global__ __launch_bounds__(kBlock) void filter_rows_kernel(FastOperands f, Fas
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         bool k1 = (kbs[q] >> j) & 1u;
-        if (bitsIn) k1 = k1 && ((bitsIn[seg * 4 + j] >> lane) & 1ull);
+        if (HAS_IN) k1 = k1 && ((bitsIn[seg * 4 + j] >> lane) & 1ull);
         const uint64_t b1 = __ballot(k1);
         mine += static_cast<uint32_t>(__popcll(b1));
         uint64_t b2 = 0;
@@ -2420,6 +2423,25 @@ struct FilterCheck {
 
 // ---- filters counted in row space (filter_rows_kernel) -----------------------------------------------------------
 namespace {
+// workgroups of `kernel` the device holds at once (occupancy x compute units), per device and kernel, asked once
+int resident_blocks(int device, const void *kernel, int blockSize) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void *>, int> known;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = known.find({device, kernel});
+  if (it != known.end()) return it->second;
+  int perCU = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, kernel, blockSize, 0) != hipSuccess || perCU < 1) {
+    (void)hipGetLastError();
+    perCU = 4;
+  }
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) {
+    (void)hipGetLastError();
+    cus = 256;
+  }
+  return known[{device, kernel}] = perCU * cus;
+}
+
 // ARES_FILTER_ROWSPACE=0: every filter of the hot shape takes the predicate-vector path (rounds 1-3)
 bool row_space_enabled() {
   static EnvSwitch<bool> on("ARES_FILTER_ROWSPACE", [](const char *e) { return !(e && e[0] == '0'); });
@@ -2502,13 +2524,18 @@ int run_filter_rows(int device, hipStream_t stream, FastOperands f, uint32_t *in
     }
     const int64_t numQuads = (static_cast<int64_t>(c.n0) + 3) / 4;
     const int tiles = static_cast<int>((numQuads + kBlock * kPQ - 1) / (kBlock * kPQ));
-    grid = capped_grid(tiles, kGridCap);
+    // one wave of workgroups: as many as the device holds at once (a grid of 1.3 x that runs two rounds, the second a
+    // third full — measured: 0.104 ms instead of 0.079 per 64 Mi rows), each striding over its share of the tiles
+    const bool hasIn = static_cast<bool>(c.bits);
+    auto kernel = two ? (hasIn ? &filter_rows_kernel<true, true> : &filter_rows_kernel<true, false>)
+                      : (hasIn ? &filter_rows_kernel<false, true> : &filter_rows_kernel<false, false>);
+    grid = capped_grid(tiles, std::min(kGridCap, resident_blocks(device, reinterpret_cast<const void *>(kernel), kBlock)));
     const size_t bitBytes = static_cast<size_t>(tiles) * (kPQ * kWaves * 4 * sizeof(uint64_t));  // 4 words per 256-row segment
     bits1 = std::make_shared<StreamBuffer>(bitBytes, stream);
     if (two) bits2 = std::make_shared<StreamBuffer>(bitBytes, stream);
     partials = std::make_shared<StreamBuffer>(sizeof(uint32_t) * 2 * static_cast<size_t>(grid), stream);
-    ARES_LAUNCH("filter_rows_kernel", filter_rows_kernel, grid, kBlock, stream, f, g, two ? 1 : 0,
-                c.bits ? c.bits->as<uint64_t>() : static_cast<const uint64_t *>(nullptr), bits1->as<uint64_t>(),
+    ARES_LAUNCH("filter_rows_kernel", kernel, grid, kBlock, stream, f, g,
+                hasIn ? c.bits->as<uint64_t>() : static_cast<const uint64_t *>(nullptr), bits1->as<uint64_t>(),
                 two ? bits2->as<uint64_t>() : static_cast<uint64_t *>(nullptr), c.n0, tiles, partials->as<uint32_t>());
     // booked before the count is known: a flush from another thread that applies the pending filters meanwhile
     // applies this one too

@@ -26,3 +26,9 @@ except Exception as e:
     print('no bench line', e)
 PY
 tail -3 gpurun_out/r4/bench_$tag.err
+if [ -n "$3" ]; then
+  timeout 700 python tools/bench_configs.py $3 > gpurun_out/r4/configs_$tag.json 2> gpurun_out/r4/configs_$tag.err
+  echo "bench_configs $3 rc $?"
+  cut -c1-1500 gpurun_out/r4/configs_$tag.json
+  tail -2 gpurun_out/r4/configs_$tag.err
+fi

@@ -235,14 +235,17 @@ constexpr int kFixupMaxRun = 64;
 struct FixupSegment {
   uint32_t start, end;
 };
+// The list is kept per WORKGROUP of the detect kernel ([workgroup][capPerGroup] + one counter each): C4's 50 M distinct
+// hashes list ~290 k segments per call, and that many returning atomics on ONE counter took 2.3 ms — a single address
+// sustains < 100 of them per microsecond (tools/ubench_atomics.hip) — against 0.3 ms for everything else in the kernel.
 struct FixupParams {
   uint64_t *keys;
   uint32_t *vals;
   int n;
-  FixupSegment *work;
-  uint32_t *workCount;  // zeroed; may exceed workCap (then fallback is set)
-  uint32_t workCap;
-  uint32_t *fallback;   // zeroed
+  FixupSegment *work;     // [groups][capPerGroup]
+  uint32_t *groupCounts;  // [groups], zeroed; may exceed capPerGroup (then fallback is set)
+  uint32_t capPerGroup;
+  uint32_t *fallback;     // zeroed
 };
 
 __global__ __launch_bounds__(kBlock) void sort_fixup_detect_kernel(FixupParams p) {
@@ -278,20 +281,21 @@ __global__ __launch_bounds__(kBlock) void sort_fixup_detect_kernel(FixupParams p
       }
     }
     if (!mine) continue;
-    const uint32_t slot = atomicAdd(p.workCount, 1u);
-    if (slot >= p.workCap) {
+    const uint32_t slot = atomicAdd(p.groupCounts + blockIdx.x, 1u);
+    if (slot >= p.capPerGroup) {
       *p.fallback = 1u;
       continue;
     }
-    p.work[slot] = FixupSegment{static_cast<uint32_t>(s), static_cast<uint32_t>(e)};
+    p.work[static_cast<size_t>(blockIdx.x) * p.capPerGroup + slot] = FixupSegment{static_cast<uint32_t>(s), static_cast<uint32_t>(e)};
   }
 }
 
+// one workgroup per list of the detect kernel (same grid)
 __global__ __launch_bounds__(64) void sort_fixup_sort_kernel(FixupParams p) {
-  const uint32_t listed = *p.workCount;
-  const uint32_t count = listed < p.workCap ? listed : p.workCap;
-  for (uint32_t w = blockIdx.x * 64 + threadIdx.x; w < count; w += gridDim.x * 64) {
-    const FixupSegment seg = p.work[w];
+  const uint32_t listed = p.groupCounts[blockIdx.x];
+  const uint32_t count = listed < p.capPerGroup ? listed : p.capPerGroup;
+  for (uint32_t w = threadIdx.x; w < count; w += 64) {
+    const FixupSegment seg = p.work[static_cast<size_t>(blockIdx.x) * p.capPerGroup + w];
     for (uint32_t a = seg.start + 1; a < seg.end; a++) {
       const uint64_t k = p.keys[a];
       const uint32_t v = p.vals[a];
@@ -340,15 +344,18 @@ void sort_rows(const uint8_t *dimValues, const DimLayoutD &L, size_t capacity, c
   // 16 bits — equal top halves are the rule there — and keep the eight passes.  ARES_SORT_TOPBITS=0: eight passes always.
   static EnvSwitch<bool> topBits("ARES_SORT_TOPBITS", [](const char *e) { return !(e && e[0] == '0'); });
   const bool topOnly = !hllValues && topBits.get();
-  const uint32_t workCap = topOnly ? static_cast<uint32_t>(length / 8 + 1024) : 0u;
-  // workspace: [hist 8 KiB][8 tickets, error, fix-up counters][status][alt keys][alt vals][fix-up segments]
+  const int fixGrid = capped_grid((static_cast<int64_t>(length) + kBlock - 1) / kBlock, 256 * 16);
+  const uint32_t capPerGroup = static_cast<uint32_t>(length / 8 / fixGrid + 64);  // (expected: length^2 / 2^33 / fixGrid each)
+  const size_t workCap = topOnly ? static_cast<size_t>(capPerGroup) * fixGrid : 0;
+  // workspace: [hist 8 KiB][8 tickets, error, fallback][status][alt keys][alt vals][fix-up: list counters, segments]
   const size_t offTicket = histBytes, offStatus = offTicket + 64, offKeys = (offStatus + statusBytes + 255) & ~size_t(255);
   const size_t offVals = offKeys + sizeof(uint64_t) * static_cast<size_t>(length);
   const size_t offWork = (offVals + sizeof(uint32_t) * static_cast<size_t>(length) + 255) & ~size_t(255);
-  StreamBuffer ws(offWork + sizeof(FixupSegment) * static_cast<size_t>(workCap) + 256, stream);
+  const size_t countBytes = (sizeof(uint32_t) * static_cast<size_t>(fixGrid) + 255) & ~size_t(255);
+  StreamBuffer ws(offWork + countBytes + sizeof(FixupSegment) * workCap + 256, stream);
   uint8_t *base = ws.as<uint8_t>();
   uint32_t *hist = reinterpret_cast<uint32_t *>(base);
-  unsigned int *tickets = reinterpret_cast<unsigned int *>(base + offTicket);  // [0..7] tickets, [8] error, [9] segments listed, [10] fallback
+  unsigned int *tickets = reinterpret_cast<unsigned int *>(base + offTicket);  // [0..7] tickets, [8] error, [9] fallback
   uint32_t *status = reinterpret_cast<uint32_t *>(base + offStatus);
   uint64_t *altKeys = reinterpret_cast<uint64_t *>(base + offKeys);
   uint32_t *altVals = reinterpret_cast<uint32_t *>(base + offVals);
@@ -369,23 +376,23 @@ void sort_rows(const uint8_t *dimValues, const DimLayoutD &L, size_t capacity, c
     }
   };
   run_passes(topOnly ? 4 : 0);
-  uint32_t back[3] = {0, 0, 0};  // {error, segments listed, fallback}
+  uint32_t back[2] = {0, 0};  // {error, fallback}
   if (topOnly) {
     FixupParams fp;
     fp.keys = keyVector;
     fp.vals = payload;
     fp.n = length;
-    fp.work = reinterpret_cast<FixupSegment *>(base + offWork);
-    fp.workCount = tickets + 9;
-    fp.workCap = workCap;
-    fp.fallback = tickets + 10;
-    ARES_LAUNCH("sort_fixup_detect_kernel", sort_fixup_detect_kernel, capped_grid((static_cast<int64_t>(length) + kBlock - 1) / kBlock, 256 * 16),
-                kBlock, stream, fp);
-    ARES_LAUNCH("sort_fixup_sort_kernel", sort_fixup_sort_kernel, 256 * 4, 64, stream, fp);
+    fp.groupCounts = reinterpret_cast<uint32_t *>(base + offWork);
+    fp.work = reinterpret_cast<FixupSegment *>(base + offWork + countBytes);
+    fp.capPerGroup = capPerGroup;
+    fp.fallback = tickets + 9;
+    hip_check(hipMemsetAsync(fp.groupCounts, 0, countBytes, stream), "hipMemsetAsync");
+    ARES_LAUNCH("sort_fixup_detect_kernel", sort_fixup_detect_kernel, fixGrid, kBlock, stream, fp);
+    ARES_LAUNCH("sort_fixup_sort_kernel", sort_fixup_sort_kernel, fixGrid, 64, stream, fp);
   }
-  read_back_u32(tickets + 8, back, 3, stream);
+  read_back_u32(tickets + 8, back, 2, stream);
   if (back[0]) throw AlgorithmError("ERROR: Sort: inter-tile scan timed out");
-  if (topOnly && back[2]) {
+  if (topOnly && back[1]) {
     // a long run of equal top halves that is out of order (or more segments than the list holds): all eight passes over
     // the data as it is — a stable permutation of the input (the fix-up's partial work included), so the result is the same
     hip_check(hipMemsetAsync(tickets, 0, 64, stream), "hipMemsetAsync");

@@ -961,7 +961,12 @@ __global__ __launch_bounds__(kBlock) void filter_rows_kernel(FastOperands f, Fas
 #pragma unroll
     for (int q = 0; q < kPQ; q++) k1 |= kbs[q] << (4 * q);
     k1 &= alive;
-    bitsOut[word] = static_cast<uint16_t>(k1);
+    if (f.debug & 8) {  // (experiment: pairs of lanes store one dword instead of two shorts)
+      const uint32_t other = static_cast<uint32_t>(__builtin_amdgcn_mov_dpp(static_cast<int>(k1), 0xB1, 0xF, 0xF, true));
+      if (!(lane & 1)) reinterpret_cast<uint32_t *>(bitsOut)[word >> 1] = k1 | (other << 16);
+    } else {
+      bitsOut[word] = static_cast<uint16_t>(k1);
+    }
     mine += __popc(k1);
     if (TWO) {
       compare_tile<kPQ>(g, vals, okb, in, z, kbs2);
@@ -2442,6 +2447,19 @@ int resident_blocks(int device, const void *kernel, int blockSize) {
   }
   return known[{device, kernel}] = perCU * cus;
 }
+int compute_units(int device) {
+  static std::mutex mu;
+  static std::map<int, int> known;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = known.find(device);
+  if (it != known.end()) return it->second;
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus < 1) {
+    (void)hipGetLastError();
+    cus = 256;
+  }
+  return known[device] = cus;
+}
 
 // ARES_FILTER_ROWSPACE=0: every filter of the hot shape takes the predicate-vector path (rounds 1-3)
 bool row_space_enabled() {
@@ -2530,7 +2548,19 @@ int run_filter_rows(int device, hipStream_t stream, FastOperands f, uint32_t *in
     const bool hasIn = static_cast<bool>(c.bits);
     auto kernel = two ? (hasIn ? &filter_rows_kernel<true, true> : &filter_rows_kernel<true, false>)
                       : (hasIn ? &filter_rows_kernel<false, true> : &filter_rows_kernel<false, false>);
-    grid = capped_grid(tiles, std::min(kGridCap, resident_blocks(device, reinterpret_cast<const void *>(kernel), kBlock)));
+    {
+      // Workgroups: a multiple of the compute units, one fewer per unit than fits.  Measured per 64 Mi rows (16 384 tiles,
+      // 7 workgroups fit per unit): 4 per unit 0.083 ms, 5: 0.077, 6: 0.073, 7: 0.094, 2048 in all: 0.089, 1 639 (every
+      // workgroup exactly ten tiles, but 103 units with a seventh workgroup): 0.099 — the units, not the workgroups, must
+      // carry equal shares (profiles/r4_experiments.md).
+      const int resident = resident_blocks(device, reinterpret_cast<const void *>(kernel), kBlock), cus = compute_units(device);
+      const int perUnit = std::max(1, std::min(resident / cus - 1, 6));
+      grid = capped_grid(tiles, std::min(kGridCap, cus * perUnit));
+    }
+    if (f.debug & 16) grid = capped_grid(tiles, kGridCap);        // (experiments: 2048 workgroups whatever fits at once,
+    if (f.debug & 32) grid = capped_grid(tiles, 256 * 4);         //  four / eight per compute unit)
+    if (f.debug & 64) grid = capped_grid(tiles, 256 * 8);
+    if (f.debug >> 8) grid = capped_grid(tiles, 256 * (f.debug >> 8));  // (experiment: workgroups per compute unit)
     const size_t bitBytes = static_cast<size_t>(tiles) * kBlock * sizeof(uint16_t);  // 16 rows per lane and tile
     bits1 = std::make_shared<StreamBuffer>(bitBytes, stream);
     if (two) bits2 = std::make_shared<StreamBuffer>(bitBytes, stream);

@@ -50,6 +50,7 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <fstream>
 #include <memory>
@@ -1351,17 +1352,45 @@ struct RtcEntry {
   hipModule_t module = nullptr;
   hipFunction_t fn = nullptr;  // nullptr once ready = the source does not compile / load: generic kernel
   std::atomic<uint64_t> lastUse{0};
-  ~RtcEntry() {
-    if (!module) return;
-    // dropped from the cache and by every caller; a launch may still be executing
-    int current = 0;
-    const bool switched = hipGetDevice(&current) == hipSuccess && current != device && hipSetDevice(device) == hipSuccess;
-    (void)hipDeviceSynchronize();
-    (void)hipModuleUnload(module);
-    if (switched) (void)hipSetDevice(current);
-    (void)hipGetLastError();
-  }
+  ~RtcEntry();
 };
+
+// Modules of evicted kernels.  Dropped from the cache and by every caller, a launch may still be executing — the module
+// cannot be unloaded on the spot without synchronising the device, which would stall every query on it (round-3 review).
+// They wait here instead (a code object is tens of kilobytes); only when a hundred have piled up are the older half
+// unloaded behind ONE device synchronisation.
+namespace {
+std::mutex g_graveMutex;
+std::vector<std::pair<int, hipModule_t>> g_graveyard;
+constexpr size_t kGraveyardLimit = 128;
+}  // namespace
+
+RtcEntry::~RtcEntry() {
+  if (!module) return;
+  std::vector<std::pair<int, hipModule_t>> unload;
+  {
+    std::lock_guard<std::mutex> lock(g_graveMutex);
+    g_graveyard.emplace_back(device, module);
+    if (g_graveyard.size() >= kGraveyardLimit) {
+      unload.assign(g_graveyard.begin(), g_graveyard.begin() + kGraveyardLimit / 2);
+      g_graveyard.erase(g_graveyard.begin(), g_graveyard.begin() + kGraveyardLimit / 2);
+    }
+  }
+  if (unload.empty()) return;
+  int current = 0;
+  const bool have = hipGetDevice(&current) == hipSuccess;
+  int synced = -1;
+  for (auto &dm : unload) {
+    if (dm.first != synced) {
+      (void)hipSetDevice(dm.first);
+      (void)hipDeviceSynchronize();
+      synced = dm.first;
+    }
+    (void)hipModuleUnload(dm.second);
+  }
+  if (have) (void)hipSetDevice(current);
+  (void)hipGetLastError();
+}
 
 namespace {
 
@@ -1488,6 +1517,23 @@ bool compile_source(const std::string &source, const std::string &arch, const ch
   return ok;
 }
 
+// ARES_RTC_TRACE=<file>: one line per kernel build — where its time went (diagnostics of cold starts)
+void rtc_trace(const char *what, const std::string &entry, double ms, size_t bytes) {
+  static const char *path = getenv("ARES_RTC_TRACE");
+  if (!path || !path[0]) return;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  if (FILE *o = fopen(path, "a")) {
+    const double now = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    fprintf(o, "%.3f %s %s %.3f ms %zu bytes\n", now, what, entry.c_str(), ms, bytes);
+    fclose(o);
+  }
+}
+struct TraceClock {
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
 // produces the entry's kernel: from the disk cache, or compiled (and stored there); runs on the caller's thread
 // (ARES_RTC_ASYNC=0) or on a background thread
 void build_entry(const std::shared_ptr<RtcEntry> &e, const std::string &source, const std::string &entryName) {
@@ -1499,6 +1545,7 @@ void build_entry(const std::shared_ptr<RtcEntry> &e, const std::string &source, 
     const std::string dir = disk_dir();
     const std::string path = dir.empty() ? std::string() : dir + "/" + disk_name(arch, source);
     std::vector<char> code;
+    TraceClock tRead;
     if (!path.empty()) {  // file = {magic, code bytes, FNV-1a of the code} + code: anything else is not trusted
       std::ifstream in(path, std::ios::binary | std::ios::ate);
       if (in) {
@@ -1518,13 +1565,19 @@ void build_entry(const std::shared_ptr<RtcEntry> &e, const std::string &source, 
       }
       if (!code.empty()) c.diskHits++;
     }
+    if (!code.empty()) rtc_trace("disk_read", entryName, tRead.ms(), code.size());
     bool fresh = false;
     if (code.empty()) {
+      TraceClock tCompile;
       fresh = compile_source(source, arch, entryName.c_str(), code);
       c.compiles++;
       if (!fresh) code.clear();
+      rtc_trace("hiprtc_compile", entryName, tCompile.ms(), code.size());
     }
-    if (!code.empty() && hipModuleLoadData(&module, code.data()) == hipSuccess) {
+    TraceClock tLoad;
+    const bool loaded = !code.empty() && hipModuleLoadData(&module, code.data()) == hipSuccess;
+    rtc_trace("module_load", entryName, tLoad.ms(), code.size());
+    if (loaded) {
       if (hipModuleGetFunction(&fn, module, entryName.c_str()) != hipSuccess) fn = nullptr;
     } else {
       module = nullptr;

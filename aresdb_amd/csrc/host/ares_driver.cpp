@@ -781,6 +781,20 @@ int AresQueryRunBatch(AresQuery *q, const VectorPartySlice *columns, int numColu
   }
 }
 
+// Every batch of a shard that is resident on the device, one after the other like ProcessQuery's batch loop
+// (query/aql_processor.go:138-161): the host side of a whole query in ONE call, so that a harness written in an
+// interpreted language adds nothing between batches (bench.py's timed region: one call per step).
+int AresQueryRunResidentBatches(AresQuery *q, const VectorPartySlice *columns, int numColumns, const int *sizes, int numBatches,
+                                char *err, int errLen) {
+  for (int b = 0; b < numBatches; b++) {
+    q->ownedColumns.clear();
+    q->isLastBatch = false;
+    const int rc = AresQueryRunBatch(q, columns + static_cast<size_t>(b) * numColumns, numColumns, sizes[b], nullptr, 0, err, errLen);
+    if (rc != 0) return rc;
+  }
+  return 0;
+}
+
 int AresQueryResultSize(const AresQuery *q) { return q->resultSize; }
 int AresQueryResultCapacity(const AresQuery *q) { return q->resultCapacity; }
 uint8_t *AresQueryDimensionVector(const AresQuery *q) { return q->dimVec[0]; }

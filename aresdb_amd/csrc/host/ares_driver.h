@@ -85,6 +85,10 @@ AresQuery *AresQueryCreate(void *driver, const AresQueryPlan *plan, int device, 
  * -1 with the library's error message in err. */
 int AresQueryRunBatch(AresQuery *q, const VectorPartySlice *columns, int numColumns, int size,
                       uint32_t *baseCounts, uint32_t startRow, char *err, int errLen);
+/* numBatches batches of numColumns slices each (batch-major), run like numBatches calls of AresQueryRunBatch (no base
+ * counts, start row 0, isLastBatch = 0) without returning to the caller in between. */
+int AresQueryRunResidentBatches(AresQuery *q, const VectorPartySlice *columns, int numColumns, const int *sizes, int numBatches,
+                                char *err, int errLen);
 int AresQueryResultSize(const AresQuery *q);
 int AresQueryResultCapacity(const AresQuery *q);
 uint8_t *AresQueryDimensionVector(const AresQuery *q); /* device pointer, capacity stride */

@@ -70,6 +70,9 @@ def _driver():
         lib.AresQueryRunBatch.argtypes = [C.c_void_p, C.POINTER(abi.VectorPartySlice), C.c_int, C.c_int, C.c_void_p,
                                           C.c_uint32, C.c_char_p, C.c_int]
         lib.AresQueryRunBatch.restype = C.c_int
+        lib.AresQueryRunResidentBatches.argtypes = [C.c_void_p, C.POINTER(abi.VectorPartySlice), C.c_int, C.POINTER(C.c_int), C.c_int,
+                                                    C.c_char_p, C.c_int]
+        lib.AresQueryRunResidentBatches.restype = C.c_int
         for name, res in (("AresQueryResultSize", C.c_int), ("AresQueryResultCapacity", C.c_int),
                           ("AresQueryDimensionVector", C.c_void_p), ("AresQueryMeasureVector", C.c_void_p),
                           ("AresQueryNumCalls", C.c_long), ("AresQueryNumFusedBatches", C.c_long)):
@@ -213,6 +216,20 @@ class NativeQuery:
         cols = (abi.VectorPartySlice * len(self.column_names))(*[columns[n] for n in self.column_names])
         rc = _driver().AresQueryRunBatch(self._q, cols, len(self.column_names), size, base_counts, start_row,
                                          self._err, 1024)
+        if rc != 0:
+            raise abi.AresError(self._err.value.decode().strip())
+
+    def pack_batches(self, batches):
+        """[(columns dict, size), ...] -> an opaque argument for run_batches (built once, reused for every step)"""
+        nc = len(self.column_names)
+        cols = (abi.VectorPartySlice * (nc * len(batches)))(*[b[0][n] for b in batches for n in self.column_names])
+        sizes = (C.c_int * len(batches))(*[int(b[1]) for b in batches])
+        return cols, nc, sizes, len(batches)
+
+    def run_batches(self, packed):
+        """every batch of a device-resident shard in one call of the C++ driver (no interpreter between batches)"""
+        cols, nc, sizes, nb = packed
+        rc = _driver().AresQueryRunResidentBatches(self._q, cols, nc, sizes, nb, self._err, 1024)
         if rc != 0:
             raise abi.AresError(self._err.value.decode().strip())
 

@@ -207,17 +207,20 @@ static bool phases_enabled() {
   return on;
 }
 
-// ARES_HR_NT=1: non-temporal loads for the columns (read once) and non-temporal stores for the record lines (written
-// once, read by another kernel).  Off by default: in the loads-only microbenchmark streaming loads are ~10 % faster
-// (profiles/r2_ubench_write_path.txt), in the compact scan the pair measured 4 % SLOWER (0.417-0.422 vs 0.401-0.404 ms
-// per 64 Mi rows, two runs each way: profiles/r3_experiments.md).
-static bool nt_enabled() {
-  static const bool on = [] {
+// ARES_HR_NT: non-temporal loads for the columns (read once; 4 = loads only, the default) and / or non-temporal stores for the
+// record lines (written once, read by another kernel; 2 = stores only, 3 or 1 = both, 0 = neither).  Round 3 measured the
+// pair 4 % SLOWER than neither; round 4 measured them one at a time (profiles/r4_experiments.md): loads only, scan
+// 0.392 -> 0.379 ms per 64 Mi rows with the merge 0.280 -> 0.287; stores only, scan 0.397, merge 0.273.
+static int nt_mode() {  // bit 0: column loads, bit 1: line stores ("1" of round 3 = both = 3)
+  static const int v = [] {
     const char *e = getenv("ARES_HR_NT");
-    return e && e[0] == '1';
+    const int x = e ? atoi(e) : 4;  // default: streaming column loads, ordinary line stores
+    return x == 1 ? 3 : x == 4 ? 1 : x;
   }();
-  return on;
+  return v;
 }
+static bool nt_enabled() { return (nt_mode() & 1) != 0; }
+static bool nt_stores_enabled() { return (nt_mode() & 2) != 0; }
 
 // ARES_HR_SCAN_OPT: bit mask of compact-scan variants under measurement (a different source text per value, so they
 // can be timed against each other in one process tree: tools/gpu_r3_ab.sh, profiles/r3_experiments.md)
@@ -463,7 +466,7 @@ static void kernel_body_lines16(std::ostringstream &o, const char *fourth) {
 static void kernel_body_compact(std::ostringstream &o) {
   phase_macros(o);
   const bool direct = scan_opt() & 1u;
-  o << (nt_enabled() ? "#define STORE_LINE(p, v) __builtin_nontemporal_store((u64)(v), (p))\n" : "#define STORE_LINE(p, v) (*(p) = (v))\n");
+  o << (nt_stores_enabled() ? "#define STORE_LINE(p, v) __builtin_nontemporal_store((u64)(v), (p))\n" : "#define STORE_LINE(p, v) (*(p) = (v))\n");
   o << "#define T 4096u\n#define LR 14u\n#define LEFT 13u\n#define LPL 5u\n"
        "__device__ __forceinline__ u32 lane_up(u32 v, u32 lane, u32 off) { return (u32)__builtin_amdgcn_ds_bpermute((int)((lane - off) << 2), (int)v); }\n"
        // OR over the 8 lanes of a half-line: xor 1, xor 2 (quad permutes), then the mirrored quad (row_half_mirror)

@@ -87,13 +87,14 @@ __device__ __forceinline__ void st_status32(uint32_t *p, uint32_t v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+template <int KPT>
 __global__ __launch_bounds__(kBlock) void radix_pass_kernel(const uint64_t *keysIn, const uint32_t *valsIn,
                                                             uint64_t *keysOut, uint32_t *valsOut, int n, int shift,
                                                             const uint32_t *digitStart, unsigned int *ticket,
                                                             uint32_t *error, uint32_t *status /* [numTiles][256] */,
                                                             int numTiles) {
-  __shared__ uint64_t sKeys[kSortTile];
-  __shared__ uint32_t sVals[kSortTile];
+  __shared__ uint64_t sKeys[(kBlock * KPT)];
+  __shared__ uint32_t sVals[(kBlock * KPT)];
   __shared__ uint32_t sHist[kWaves][256];  // per-wave digit counts -> per-wave bases inside the tile
   __shared__ uint32_t sTileStart[256];     // first tile-local slot of each digit
   __shared__ uint32_t sBase[256];          // global position = sBase[digit] + tile-local slot
@@ -107,15 +108,15 @@ __global__ __launch_bounds__(kBlock) void radix_pass_kernel(const uint64_t *keys
     __syncthreads();
     const int tile = sTile;
     if (tile >= numTiles) break;
-    const int64_t tileBase = static_cast<int64_t>(tile) * kSortTile;
-    const int tileCount = static_cast<int>(n - tileBase < kSortTile ? n - tileBase : kSortTile);
+    const int64_t tileBase = static_cast<int64_t>(tile) * (kBlock * KPT);
+    const int tileCount = static_cast<int>(n - tileBase < (kBlock * KPT) ? n - tileBase : (kBlock * KPT));
 
-    uint64_t key[kSortKPT];
-    uint32_t val[kSortKPT];
-    uint16_t rank[kSortKPT];
+    uint64_t key[KPT];
+    uint32_t val[KPT];
+    uint16_t rank[KPT];
 #pragma unroll
-    for (int r = 0; r < kSortKPT; r++) {
-      const int local = wave * kSortWaveChunk + r * 64 + lane;
+    for (int r = 0; r < KPT; r++) {
+      const int local = wave * (64 * KPT) + r * 64 + lane;
       if (local < tileCount) {
         key[r] = keysIn[tileBase + local];
         val[r] = valsIn[tileBase + local];
@@ -127,8 +128,8 @@ __global__ __launch_bounds__(kBlock) void radix_pass_kernel(const uint64_t *keys
     // stable ranking inside the wavefront's chunk: lanes holding the same digit find each other
     // with 8 ballots; the per-wave histogram row lives in LDS and is only touched by this wave
 #pragma unroll
-    for (int r = 0; r < kSortKPT; r++) {
-      const int local = wave * kSortWaveChunk + r * 64 + lane;
+    for (int r = 0; r < KPT; r++) {
+      const int local = wave * (64 * KPT) + r * 64 + lane;
       const bool valid = local < tileCount;
       const uint32_t digit = static_cast<uint32_t>(key[r] >> shift) & 255u;
       uint64_t peers = __ballot(valid);
@@ -191,8 +192,8 @@ __global__ __launch_bounds__(kBlock) void radix_pass_kernel(const uint64_t *keys
     __syncthreads();
     // reorder through LDS: tile-local slot = digit start + wave base + rank in wave
 #pragma unroll
-    for (int r = 0; r < kSortKPT; r++) {
-      const int local = wave * kSortWaveChunk + r * 64 + lane;
+    for (int r = 0; r < KPT; r++) {
+      const int local = wave * (64 * KPT) + r * 64 + lane;
       if (local < tileCount) {
         const uint32_t digit = static_cast<uint32_t>(key[r] >> shift) & 255u;
         const uint32_t slot = sTileStart[digit] + sHist[wave][digit] + rank[r];
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(kBlock) void radix_pass_kernel(const uint64_t *keys
     }
     __syncthreads();
 #pragma unroll
-    for (int m = 0; m < kSortKPT; m++) {
+    for (int m = 0; m < KPT; m++) {
       const int j = m * kBlock + threadIdx.x;
       if (j < tileCount) {
         const uint64_t k = sKeys[j];
@@ -238,6 +239,15 @@ struct FixupSegment {
 // The list is kept per WORKGROUP of the detect kernel ([workgroup][capPerGroup] + one counter each): C4's 50 M distinct
 // hashes list ~290 k segments per call, and that many returning atomics on ONE counter took 2.3 ms — a single address
 // sustains < 100 of them per microsecond (tools/ubench_atomics.hip) — against 0.3 ms for everything else in the kernel.
+// LONG segments (more than kFixupMaxRun entries, out of order): two groups whose hashes share their top half, each with
+// many rows — 200 k groups over 64 Mi rows: ~5 such pairs per call, 670 entries each.  Too long for one thread's
+// insertion sort, far too few to justify four more passes over everything (the first version's fallback: 12.9 instead
+// of 10.4 ms on that configuration).  The thread that meets such a segment finds its ends by binary search (the data is
+// sorted by top half), claims it in a small table keyed by its start — several descents of one segment meet there — and a
+// workgroup sorts it in LDS by ranking (sort_fixup_long_kernel).  Only a segment beyond kFixupLongMax entries, or a full
+// table, still raises `fallback`.
+constexpr int kFixupLongMax = 4096;
+constexpr int kFixupLongSlots = 1024;  // claim table (open addressing, power of two); at most half of it is used
 struct FixupParams {
   uint64_t *keys;
   uint32_t *vals;
@@ -246,7 +256,50 @@ struct FixupParams {
   uint32_t *groupCounts;  // [groups], zeroed; may exceed capPerGroup (then fallback is set)
   uint32_t capPerGroup;
   uint32_t *fallback;     // zeroed
+  uint32_t *longTable;    // [kFixupLongSlots] segment start + 1 (0 = free), zeroed
+  FixupSegment *longWork; // [kFixupLongSlots / 2]
+  uint32_t *longCount;    // zeroed
 };
+
+// the run of equal top halves around position i of an array sorted by top half: [start, end)
+__device__ __forceinline__ FixupSegment fixup_bounds(const uint64_t *keys, int n, int i) {
+  const uint32_t top = static_cast<uint32_t>(keys[i] >> 32);
+  int lo = 0, hi = i;  // first position whose top half is >= top
+  while (lo < hi) {
+    const int mid = lo + ((hi - lo) >> 1);
+    if (static_cast<uint32_t>(keys[mid] >> 32) < top) lo = mid + 1; else hi = mid;
+  }
+  const int start = lo;
+  lo = i + 1;
+  hi = n;  // first position whose top half is > top
+  while (lo < hi) {
+    const int mid = lo + ((hi - lo) >> 1);
+    if (static_cast<uint32_t>(keys[mid] >> 32) <= top) lo = mid + 1; else hi = mid;
+  }
+  return FixupSegment{static_cast<uint32_t>(start), static_cast<uint32_t>(lo)};
+}
+
+// a descent in a segment that one thread cannot walk: list it once
+__device__ __forceinline__ void fixup_claim_long(const FixupParams &p, int i) {
+  const FixupSegment seg = fixup_bounds(p.keys, p.n, i);
+  if (seg.end - seg.start > static_cast<uint32_t>(kFixupLongMax)) {
+    *p.fallback = 1u;
+    return;
+  }
+  const uint32_t tag = seg.start + 1u;
+  uint32_t slot = (seg.start * 2654435761u) >> 22;  // 10 bits
+  for (int probe = 0; probe < kFixupLongSlots; probe++, slot = (slot + 1u) & (kFixupLongSlots - 1)) {
+    const uint32_t seen = atomicCAS(p.longTable + slot, 0u, tag);
+    if (seen == tag) return;  // another descent of this segment was here first
+    if (seen == 0u) {
+      const uint32_t at = atomicAdd(p.longCount, 1u);
+      if (at >= static_cast<uint32_t>(kFixupLongSlots / 2)) *p.fallback = 1u;
+      else p.longWork[at] = seg;
+      return;
+    }
+  }
+  *p.fallback = 1u;
+}
 
 __global__ __launch_bounds__(kBlock) void sort_fixup_detect_kernel(FixupParams p) {
   for (int64_t i64 = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i64 < p.n; i64 += static_cast<int64_t>(gridDim.x) * kBlock) {
@@ -265,7 +318,7 @@ __global__ __launch_bounds__(kBlock) void sort_fixup_detect_kernel(FixupParams p
       }
       s--;
       if (i - s > kFixupMaxRun) {
-        *p.fallback = 1u;
+        fixup_claim_long(p, i);
         mine = false;
         break;
       }
@@ -275,7 +328,7 @@ __global__ __launch_bounds__(kBlock) void sort_fixup_detect_kernel(FixupParams p
     while (e < p.n && static_cast<uint32_t>(p.keys[e] >> 32) == top) {
       e++;
       if (e - s > kFixupMaxRun) {
-        *p.fallback = 1u;
+        fixup_claim_long(p, i);
         mine = false;
         break;
       }
@@ -311,6 +364,35 @@ __global__ __launch_bounds__(64) void sort_fixup_sort_kernel(FixupParams p) {
   }
 }
 
+// one workgroup per listed long segment: stable sort by the low half through ranks computed in LDS
+__global__ __launch_bounds__(kBlock) void sort_fixup_long_kernel(FixupParams p) {
+  __shared__ uint32_t sLow[kFixupLongMax];
+  __shared__ uint32_t sVal[kFixupLongMax];
+  const uint32_t listed = *p.longCount;
+  const uint32_t count = listed < static_cast<uint32_t>(kFixupLongSlots / 2) ? listed : static_cast<uint32_t>(kFixupLongSlots / 2);
+  for (uint32_t w = blockIdx.x; w < count; w += gridDim.x) {
+    const FixupSegment seg = p.longWork[w];
+    const int len = static_cast<int>(seg.end - seg.start);
+    const uint64_t top = p.keys[seg.start] & 0xFFFFFFFF00000000ull;
+    __syncthreads();  // (LDS of the previous segment)
+    for (int i = threadIdx.x; i < len; i += kBlock) {
+      sLow[i] = static_cast<uint32_t>(p.keys[seg.start + i]);
+      sVal[i] = p.vals[seg.start + i];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < len; i += kBlock) {
+      const uint32_t mine = sLow[i];
+      int rank = 0;
+      for (int j = 0; j < len; j++) {
+        const uint32_t other = sLow[j];
+        rank += (other < mine || (other == mine && j < i)) ? 1 : 0;
+      }
+      p.keys[seg.start + rank] = top | mine;
+      p.vals[seg.start + rank] = sVal[i];
+    }
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void fill_u64_kernel(uint64_t *p, uint64_t v, int n) {
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < n;
        i += static_cast<int64_t>(gridDim.x) * kBlock)
@@ -337,7 +419,12 @@ void sort_rows(const uint8_t *dimValues, const DimLayoutD &L, size_t capacity, c
                 kBlock, stream, keyVector, length);
     return;
   }
-  const int numTiles = (length + kSortTile - 1) / kSortTile;
+  // keys per lane and tile of a pass: 16 (4096-key tiles, 54 KB of LDS: two workgroups per compute unit) or 8 (2048-key
+  // tiles, 27 KB: five) — ARES_SORT_KPT
+  static EnvSwitch<int> keysPerLane("ARES_SORT_KPT", [](const char *e) { return e && atoi(e) == 8 ? 8 : 16; });
+  const int kpt = keysPerLane.get();
+  const int sortTile = kBlock * kpt;
+  const int numTiles = (length + sortTile - 1) / sortTile;
   const size_t histBytes = 8 * 256 * sizeof(uint32_t);
   const size_t statusBytes = static_cast<size_t>(numTiles) * 256 * sizeof(uint32_t);
   // Row hashes are sorted by their top half and fixed up (above); HyperLogLog keys carry the register id in their low
@@ -351,8 +438,12 @@ void sort_rows(const uint8_t *dimValues, const DimLayoutD &L, size_t capacity, c
   const size_t offTicket = histBytes, offStatus = offTicket + 64, offKeys = (offStatus + statusBytes + 255) & ~size_t(255);
   const size_t offVals = offKeys + sizeof(uint64_t) * static_cast<size_t>(length);
   const size_t offWork = (offVals + sizeof(uint32_t) * static_cast<size_t>(length) + 255) & ~size_t(255);
-  const size_t countBytes = (sizeof(uint32_t) * static_cast<size_t>(fixGrid) + 255) & ~size_t(255);
-  StreamBuffer ws(offWork + countBytes + sizeof(FixupSegment) * workCap + 256, stream);
+  // [list counters of the detect workgroups][long-segment claim table, long-segment counter][long segments][short segments]
+  const size_t groupCountBytes = (sizeof(uint32_t) * static_cast<size_t>(fixGrid) + 255) & ~size_t(255);
+  const size_t longTableBytes = sizeof(uint32_t) * kFixupLongSlots + 256;
+  const size_t countBytes = groupCountBytes + longTableBytes;  // (zeroed together)
+  const size_t longWorkBytes = sizeof(FixupSegment) * (kFixupLongSlots / 2);
+  StreamBuffer ws(offWork + countBytes + longWorkBytes + sizeof(FixupSegment) * workCap + 256, stream);
   uint8_t *base = ws.as<uint8_t>();
   uint32_t *hist = reinterpret_cast<uint32_t *>(base);
   unsigned int *tickets = reinterpret_cast<unsigned int *>(base + offTicket);  // [0..7] tickets, [8] error, [9] fallback
@@ -365,14 +456,19 @@ void sort_rows(const uint8_t *dimValues, const DimLayoutD &L, size_t capacity, c
   ARES_LAUNCH("sort_hash_hist_kernel", sort_hash_hist_kernel, grid, kBlock, stream, dimValues, L, capacity, rowIndex,
               keyVector, length, hist, hllValues, iotaPayload ? payload : nullptr);
   ARES_LAUNCH("digit_start_kernel", digit_start_kernel, 8, 256, stream, hist);
-  const int passGrid = capped_grid(numTiles, 256 * 3);
+  const int passGrid = capped_grid(numTiles, kpt == 8 ? 256 * 6 : 256 * 3);
   auto run_passes = [&](int first) {  // an even number of passes: the data ends where it started (keyVector / payload)
     for (int pass = first; pass < 8; pass++) {
       hip_check(hipMemsetAsync(status, 0, statusBytes, stream), "hipMemsetAsync");
       const bool even = ((pass - first) & 1) == 0;
-      ARES_LAUNCH("radix_pass_kernel", radix_pass_kernel, passGrid, kBlock, stream, even ? keyVector : altKeys, even ? payload : altVals,
-                  even ? altKeys : keyVector, even ? altVals : payload, length, 8 * pass, hist + 256 * pass, tickets + pass, tickets + 8,
-                  status, numTiles);
+      if (kpt == 8)
+        ARES_LAUNCH("radix_pass_kernel", radix_pass_kernel<8>, passGrid, kBlock, stream, even ? keyVector : altKeys, even ? payload : altVals,
+                    even ? altKeys : keyVector, even ? altVals : payload, length, 8 * pass, hist + 256 * pass, tickets + pass, tickets + 8,
+                    status, numTiles);
+      else
+        ARES_LAUNCH("radix_pass_kernel", radix_pass_kernel<16>, passGrid, kBlock, stream, even ? keyVector : altKeys, even ? payload : altVals,
+                    even ? altKeys : keyVector, even ? altVals : payload, length, 8 * pass, hist + 256 * pass, tickets + pass, tickets + 8,
+                    status, numTiles);
     }
   };
   run_passes(topOnly ? 4 : 0);
@@ -383,12 +479,16 @@ void sort_rows(const uint8_t *dimValues, const DimLayoutD &L, size_t capacity, c
     fp.vals = payload;
     fp.n = length;
     fp.groupCounts = reinterpret_cast<uint32_t *>(base + offWork);
-    fp.work = reinterpret_cast<FixupSegment *>(base + offWork + countBytes);
+    fp.longTable = reinterpret_cast<uint32_t *>(base + offWork + groupCountBytes);
+    fp.longCount = fp.longTable + kFixupLongSlots;
+    fp.longWork = reinterpret_cast<FixupSegment *>(base + offWork + countBytes);
+    fp.work = reinterpret_cast<FixupSegment *>(base + offWork + countBytes + longWorkBytes);
     fp.capPerGroup = capPerGroup;
     fp.fallback = tickets + 9;
     hip_check(hipMemsetAsync(fp.groupCounts, 0, countBytes, stream), "hipMemsetAsync");
     ARES_LAUNCH("sort_fixup_detect_kernel", sort_fixup_detect_kernel, fixGrid, kBlock, stream, fp);
     ARES_LAUNCH("sort_fixup_sort_kernel", sort_fixup_sort_kernel, fixGrid, 64, stream, fp);
+    ARES_LAUNCH("sort_fixup_long_kernel", sort_fixup_long_kernel, 64, kBlock, stream, fp);
   }
   read_back_u32(tickets + 8, back, 2, stream);
   if (back[0]) throw AlgorithmError("ERROR: Sort: inter-tile scan timed out");

@@ -208,13 +208,37 @@ def test_filter_large_property():
         b.free()
 
 
-def test_sort_large_property():
-    """4M rows: output is sorted by hash, is a permutation, and equal hashes keep input order."""
+def _colliding_segments(h):
+    """(short, long): runs of equal top halves of the sorted hashes that hold more than one distinct hash, up to 64 entries
+    long / longer — what Sort's fix-up after the four top-half passes has to put in order (sort_reduce.hip)"""
+    top = h >> np.uint64(32)
+    bounds = np.concatenate([[0], np.nonzero(top[1:] != top[:-1])[0] + 1, [len(h)]])
+    short = long_ = 0
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        if b - a > 1 and h[a] != h[b - 1]:
+            if b - a > 64:
+                long_ += 1
+            else:
+                short += 1
+    return short, long_
+
+
+@pytest.mark.parametrize("length,groups,want_long", [(1 << 22, 50000, False), (1 << 23, 200000, True), (1 << 22, 3000000, False)],
+                         ids=["50k_groups", "200k_groups_long_segments", "3M_groups_short_segments"])
+def test_sort_large_property(length, groups, want_long):
+    """Millions of rows: output is sorted by hash, is a permutation, and equal hashes keep input order — with hashes that
+    share their top half in short runs (one thread's insertion sort) and in long ones (two groups of dozens of rows each:
+    ranked in LDS)."""
     be = hip()
-    c = cases.GroupByCase(77, length=1 << 22, groups=50000, ndw=(0, 0, 2, 0, 0), agg=abi.AGGR_SUM_UNSIGNED,
+    c = cases.GroupByCase(77, length=length, groups=groups, ndw=(0, 0, 2, 0, 0), agg=abi.AGGR_SUM_UNSIGNED,
                           value_bytes=4, capacity_slack=0)
     r = c.run_sort_reduce(be)
     h, ix = r["sorted_hash"], r["sorted_index"]
+    short, long_ = _colliding_segments(h)
+    if want_long:
+        assert long_ >= 1, "the test data holds no long run of equal top halves any more"
+    elif groups > 1000000:
+        assert short >= 10
     assert np.all(h[1:] >= h[:-1])
     assert np.array_equal(np.sort(ix), np.arange(c.length, dtype=np.uint32))
     same = h[1:] == h[:-1]

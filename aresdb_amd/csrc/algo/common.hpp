@@ -218,6 +218,12 @@ class KernelTimer {
 // a few waves of blocks per CU (256 CUs x 8 blocks) with a grid-stride / ticket loop.
 inline int capped_grid(int64_t tiles, int cap = 256 * 8) {
   if (tiles < 1) tiles = 1;
+  // ARES_GRID_PER_CU=n (experiments): every grid-stride kernel runs with at most 256 n workgroups
+  static const int perCU = [] {
+    const char *e = getenv("ARES_GRID_PER_CU");
+    return e ? atoi(e) : 0;
+  }();
+  if (perCU > 0 && cap >= 256) cap = 256 * perCU;
   return static_cast<int>(tiles < cap ? tiles : cap);
 }
 

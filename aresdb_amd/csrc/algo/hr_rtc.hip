@@ -1351,7 +1351,11 @@ struct RtcEntry {
   int device = 0;
   std::mutex m;
   std::condition_variable cv;
-  bool ready = false;
+  bool ready = false;      // final: the module is loaded, or there is no kernel (fn == nullptr: generic path)
+  bool codeReady = false;  // the code object is here (read from disk / compiled), a query thread has yet to load it
+  bool fromDisk = false;
+  std::vector<char> code;
+  std::string diskPath;
   hipModule_t module = nullptr;
   hipFunction_t fn = nullptr;  // nullptr once ready = the source does not compile / load: generic kernel
   std::atomic<uint64_t> lastUse{0};
@@ -1537,74 +1541,94 @@ struct TraceClock {
   double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
 };
 
-// produces the entry's kernel: from the disk cache, or compiled (and stored there); runs on the caller's thread
-// (ARES_RTC_ASYNC=0) or on a background thread
-void build_entry(const std::shared_ptr<RtcEntry> &e, const std::string &source, const std::string &entryName) {
-  RtcCache &c = cache();
-  hipModule_t module = nullptr;
-  hipFunction_t fn = nullptr;
-  if (hipSetDevice(e->device) == hipSuccess) {
-    const std::string arch = device_arch(e->device);
-    const std::string dir = disk_dir();
-    const std::string path = dir.empty() ? std::string() : dir + "/" + disk_name(arch, source);
-    std::vector<char> code;
-    TraceClock tRead;
-    if (!path.empty()) {  // file = {magic, code bytes, FNV-1a of the code} + code: anything else is not trusted
-      std::ifstream in(path, std::ios::binary | std::ios::ate);
-      if (in) {
-        const std::streamsize n = in.tellg();
-        uint64_t head[3] = {0, 0, 0};
-        if (n > static_cast<std::streamsize>(sizeof(head))) {
-          in.seekg(0);
-          if (in.read(reinterpret_cast<char *>(head), sizeof(head)) && head[0] == kDiskMagic &&
-              head[1] == static_cast<uint64_t>(n) - sizeof(head)) {
-            code.resize(static_cast<size_t>(head[1]));
-            if (!in.read(code.data(), static_cast<std::streamsize>(code.size())) ||
-                fnv1a(std::string(code.data(), code.size()), 14695981039346656037ull) != head[2])
-              code.clear();
-          }
-        }
-        if (code.empty()) (void)unlink(path.c_str());  // truncated, corrupted or of another format
-      }
-      if (!code.empty()) c.diskHits++;
-    }
-    if (!code.empty()) rtc_trace("disk_read", entryName, tRead.ms(), code.size());
-    bool fresh = false;
-    if (code.empty()) {
-      TraceClock tCompile;
-      fresh = compile_source(source, arch, entryName.c_str(), code);
-      c.compiles++;
-      if (!fresh) code.clear();
-      rtc_trace("hiprtc_compile", entryName, tCompile.ms(), code.size());
-    }
-    TraceClock tLoad;
-    const bool loaded = !code.empty() && hipModuleLoadData(&module, code.data()) == hipSuccess;
-    rtc_trace("module_load", entryName, tLoad.ms(), code.size());
-    if (loaded) {
-      if (hipModuleGetFunction(&fn, module, entryName.c_str()) != hipSuccess) fn = nullptr;
-    } else {
-      module = nullptr;
-      if (!fresh && !path.empty()) (void)unlink(path.c_str());  // a stale / truncated cache file
-    }
-    (void)hipGetLastError();
-    if (fresh && fn && !path.empty()) {  // publish atomically: write aside, then rename
-      const std::string tmp = path + ".tmp" + std::to_string(static_cast<long>(getpid())) + "." + std::to_string(c.tick.load());
-      std::ofstream out(tmp, std::ios::binary);
-      const uint64_t head[3] = {kDiskMagic, static_cast<uint64_t>(code.size()), fnv1a(std::string(code.data(), code.size()), 14695981039346656037ull)};
-      if (out && out.write(reinterpret_cast<const char *>(head), sizeof(head)) && out.write(code.data(), static_cast<std::streamsize>(code.size())) &&
-          (out.close(), true)) {
-        if (rename(tmp.c_str(), path.c_str()) != 0) (void)unlink(tmp.c_str());
-      } else {
-        (void)unlink(tmp.c_str());
-      }
+// ---- building an entry -----------------------------------------------------------------------------------------
+// A code object comes from the on-disk cache (read by the CALLER: tens of microseconds) or from hiprtc (seconds: on a
+// background thread unless ARES_RTC_ASYNC=0 / `wait`).  hipModuleLoadData ALWAYS runs on a calling (query) thread, the
+// first one that finds the code ready: measured on the GPU box (profiles/r4_experiments.md), the same load takes
+// 0.2-0.7 ms there and 530 ms on a freshly started background thread when another process holds memory on the device —
+// and stalls the query thread's launches for as long (the "490 ms first query of a process that finds its kernels on
+// disk" of round 3).
+std::string disk_path(int device, const std::string &source) {
+  const std::string dir = disk_dir();
+  return dir.empty() ? std::string() : dir + "/" + disk_name(device_arch(device), source);
+}
+
+bool read_disk(const std::string &path, const std::string &entryName, std::vector<char> &code) {
+  code.clear();
+  if (path.empty()) return false;
+  TraceClock tRead;
+  std::ifstream in(path, std::ios::binary | std::ios::ate);  // file = {magic, code bytes, FNV-1a of the code} + code
+  if (!in) return false;
+  const std::streamsize n = in.tellg();
+  uint64_t head[3] = {0, 0, 0};
+  if (n > static_cast<std::streamsize>(sizeof(head))) {
+    in.seekg(0);
+    if (in.read(reinterpret_cast<char *>(head), sizeof(head)) && head[0] == kDiskMagic && head[1] == static_cast<uint64_t>(n) - sizeof(head)) {
+      code.resize(static_cast<size_t>(head[1]));
+      if (!in.read(code.data(), static_cast<std::streamsize>(code.size())) ||
+          fnv1a(std::string(code.data(), code.size()), 14695981039346656037ull) != head[2])
+        code.clear();
     }
   }
+  if (code.empty()) {
+    (void)unlink(path.c_str());  // truncated, corrupted or of another format
+    return false;
+  }
+  rtc_trace("disk_read", entryName, tRead.ms(), code.size());
+  return true;
+}
+
+void write_disk(const std::string &path, const std::vector<char> &code) {  // publish atomically: write aside, then rename
+  if (path.empty() || code.empty()) return;
+  const std::string tmp = path + ".tmp" + std::to_string(static_cast<long>(getpid())) + "." + std::to_string(cache().tick.load());
+  std::ofstream out(tmp, std::ios::binary);
+  const uint64_t head[3] = {kDiskMagic, static_cast<uint64_t>(code.size()), fnv1a(std::string(code.data(), code.size()), 14695981039346656037ull)};
+  if (out && out.write(reinterpret_cast<const char *>(head), sizeof(head)) && out.write(code.data(), static_cast<std::streamsize>(code.size())) &&
+      (out.close(), true)) {
+    if (rename(tmp.c_str(), path.c_str()) != 0) (void)unlink(tmp.c_str());
+  } else {
+    (void)unlink(tmp.c_str());
+  }
+}
+
+// caller holds e->m and has selected e->device: the entry's code becomes its kernel (or "no kernel": generic path)
+void load_entry(RtcEntry &e, const std::string &entryName) {
+  TraceClock tLoad;
+  hipModule_t module = nullptr;
+  hipFunction_t fn = nullptr;
+  if (!e.code.empty() && hipModuleLoadData(&module, e.code.data()) == hipSuccess) {
+    if (hipModuleGetFunction(&fn, module, entryName.c_str()) != hipSuccess) fn = nullptr;
+  } else {
+    module = nullptr;
+  }
   (void)hipGetLastError();
+  rtc_trace("module_load", entryName, tLoad.ms(), e.code.size());
+  if (!fn && e.fromDisk && !e.diskPath.empty()) (void)unlink(e.diskPath.c_str());  // a stale cache file
+  if (fn && !e.fromDisk) write_disk(e.diskPath, e.code);
+  e.code.clear();
+  e.code.shrink_to_fit();
+  e.module = module;
+  e.fn = fn;
+  e.codeReady = false;
+  e.ready = true;
+}
+
+// hiprtc on this thread (the caller's, or a background thread): leaves the code in the entry for a query thread to load
+void compile_entry(const std::shared_ptr<RtcEntry> &e, const std::string &source, const std::string &entryName) {
+  RtcCache &c = cache();
+  std::vector<char> code;
+  TraceClock tCompile;
+  const bool ok = compile_source(source, device_arch(e->device), entryName.c_str(), code);
+  c.compiles++;
+  rtc_trace("hiprtc_compile", entryName, tCompile.ms(), code.size());
   {
     std::lock_guard<std::mutex> lock(e->m);
-    e->module = module;
-    e->fn = fn;
-    e->ready = true;
+    if (ok) {
+      e->code.swap(code);
+      e->codeReady = true;
+    } else {
+      e->ready = true;  // no kernel: the generic path
+    }
   }
   e->cv.notify_all();
   if (c.pending.fetch_sub(1) == 1) {
@@ -1661,17 +1685,32 @@ RtcKernel compiled_kernel(int device, const std::string &source, const char *ent
   }
   evicted.clear();
   if (created) {
-    if (rtc_async() && !wait) {
-      std::thread([e, source, name = std::string(entry)] { build_entry(e, source, name); }).detach();
+    e->diskPath = disk_path(device, source);
+    std::vector<char> code;
+    if (read_disk(e->diskPath, entry, code)) {  // found on disk: loaded below, on this thread
+      c.diskHits++;
+      std::lock_guard<std::mutex> lock(e->m);
+      e->code.swap(code);
+      e->fromDisk = true;
+      e->codeReady = true;
+      if (c.pending.fetch_sub(1) == 1) {
+        std::lock_guard<std::mutex> idle(c.idleMu);
+        c.idleCv.notify_all();
+      }
+    } else if (rtc_async() && !wait) {
+      std::thread([e, source, name = std::string(entry)] { compile_entry(e, source, name); }).detach();
     } else {
-      build_entry(e, source, entry);
-      (void)hipSetDevice(device);
+      compile_entry(e, source, entry);
     }
   }
   std::unique_lock<std::mutex> lock(e->m);
-  if (!e->ready) {
+  if (!e->ready && !e->codeReady) {
     if (rtc_async() && !wait) return nullptr;
-    e->cv.wait(lock, [&] { return e->ready; });
+    e->cv.wait(lock, [&] { return e->ready || e->codeReady; });
+  }
+  if (!e->ready) {  // the code is here: this (query) thread loads it
+    (void)hipSetDevice(device);
+    load_entry(*e, entry);
   }
   return e->fn ? e : nullptr;
 }

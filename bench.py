@@ -381,6 +381,24 @@ def main(argv=None, backend=None, tensor_device=None):
 
     if args.single_process:
         return single_process(args, backend, tensor_device)
+    # Cold-start legs first, while this process has not touched the GPU yet: a fresh process ALONE on the device — what a
+    # restarted server is.  (Run later, as children of a parent that holds a 20 GB shard on the same GPU, they showed
+    # stalls of 0.4-0.6 s in one early batch that move from batch to batch and vanish when the child has the device to
+    # itself: two processes on one device, not the library — profiles/r4_experiments.md.)
+    early_legs = {}
+    if backend is None and args.gpus <= 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not (args.leg or args.cold or args.no_legs) and \
+            (args.legs == "all" or any("cold" in w for w in args.legs.split(","))):
+        import tempfile
+        cold_argv = ["--rows", str(int(args.rows)), "--null-fraction", str(args.null_fraction), "--steps", "3", "--warmup", "1",
+                     "--batch-rows", str(int(args.batch_rows)), "--cold"]
+        with tempfile.TemporaryDirectory(prefix="ares_rtc_cache_") as tmp:
+            for name in ("cold_process", "cold_process_warm_disk_cache"):  # empty on-disk cache, then a second process that finds it filled
+                t0 = time.perf_counter()
+                early_legs[name] = run_leg({"ARES_RTC_CACHE_DIR": tmp}, cold_argv)
+                if isinstance(early_legs[name], dict):
+                    early_legs[name]["leg_wall_s"] = round(time.perf_counter() - t0, 1)
+
+
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and backend is None:
         spawn_ranks(args.gpus, argv)
     rank = int(os.environ.get("RANK", "0"))
@@ -709,11 +727,8 @@ def main(argv=None, backend=None, tensor_device=None):
             leg("groups_15k_dims_ts_d1", {}, big + ["--dims", "ts,d1"])        # DIRECT-mode kernels (> 6000 groups)
             tool_leg("c2_100M_rows_filter_count", "c2", 300, 15)
             # first query of a fresh process (kernels compiled in the background: empty on-disk cache), the same process
-            # warm, and the same shape with a comparison constant never seen before
-            import tempfile
-            with tempfile.TemporaryDirectory(prefix="ares_rtc_cache_") as tmp:
-                leg("cold_process", {"ARES_RTC_CACHE_DIR": tmp}, big + ["--cold"])
-                leg("cold_process_warm_disk_cache", {"ARES_RTC_CACHE_DIR": tmp}, big + ["--cold"])
+            # warm, and the same shape with a comparison constant never seen before: measured at the start of this run
+            legs.update(early_legs)
             leg("fused_extension", {}, big + ["--fused-extension"])
             leg("groups_4k6_dims_d1_d2", {}, big + ["--dims", "d1,d2"])        # TABLE-mode scan, table well filled
             leg("groups_90_dims_d1", {}, big + ["--dims", "d1"])               # TABLE-mode scan, ~100 groups, 2 columns read

@@ -15,7 +15,7 @@ namespace {
 struct PinnedSlot {
   uint64_t *ptr = nullptr;
   PinnedSlot() {
-    if (hipHostMalloc(reinterpret_cast<void **>(&ptr), kPinnedWords * sizeof(uint32_t), hipHostMallocPortable) != hipSuccess) {
+    if (hipHostMalloc(reinterpret_cast<void **>(&ptr), kPinnedWords * sizeof(uint32_t), hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) {
       (void)hipGetLastError();
       ptr = nullptr;
     }

@@ -2505,7 +2505,7 @@ int run_filter_rows(int device, hipStream_t stream, FastOperands f, uint32_t *in
   if (!(f.debug & 1024)) f.debug |= 128;
   constexpr int kGridCap = 2048;  // two partial counts per workgroup come back in one copy
   static_assert(2 * kGridCap <= kPinnedWords, "the partial counts are read back in one copy");
-  std::shared_ptr<StreamBuffer> bits1, bits2, partials;
+  std::shared_ptr<StreamBuffer> bits1, bits2;
   int grid = 0;
   bool two = false;
   FastOperands g = f;
@@ -2574,10 +2574,12 @@ int run_filter_rows(int device, hipStream_t stream, FastOperands f, uint32_t *in
     const size_t bitBytes = static_cast<size_t>(tiles) * kBlock * sizeof(uint16_t);  // 16 rows per lane and tile
     bits1 = std::make_shared<StreamBuffer>(bitBytes, stream);
     if (two) bits2 = std::make_shared<StreamBuffer>(bitBytes, stream);
-    partials = std::make_shared<StreamBuffer>(sizeof(uint32_t) * 2 * static_cast<size_t>(grid), stream);
+    // the partial counts go straight into the calling thread's pinned result slot (host memory the device can write):
+    // the call then only waits for the stream — no copy command behind the kernel
+    uint32_t *hostPartials = reinterpret_cast<uint32_t *>(pinned_words());
     ARES_LAUNCH("filter_rows_kernel", kernel, grid, kBlock, stream, f, g,
                 hasIn ? c.bits->as<uint16_t>() : static_cast<const uint16_t *>(nullptr), bits1->as<uint16_t>(),
-                two ? bits2->as<uint16_t>() : static_cast<uint16_t *>(nullptr), c.n0, tiles, partials->as<uint32_t>());
+                two ? bits2->as<uint16_t>() : static_cast<uint16_t *>(nullptr), c.n0, tiles, hostPartials);
     // booked before the count is known: a flush from another thread that applies the pending filters meanwhile
     // applies this one too
     c.todo.push_back(LazyFilter{f, colRows, pred, n});
@@ -2586,8 +2588,8 @@ int run_filter_rows(int device, hipStream_t stream, FastOperands f, uint32_t *in
     generation = ++t_state->filterGeneration;
     c.generation = generation;
   }
-  uint32_t parts[2 * kGridCap];
-  read_back_u32(partials->as<uint32_t>(), parts, 2 * grid, stream);
+  hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+  const volatile uint32_t *parts = reinterpret_cast<const volatile uint32_t *>(pinned_words());
   uint32_t count = 0, count2 = 0;
   for (int b = 0; b < grid; b++) {
     count += parts[2 * b];

@@ -11,6 +11,18 @@ namespace ares {
 std::atomic<uint32_t> g_envGeneration{1};
 thread_local CallStream t_callStream{nullptr, false};
 
+void slow_trace(const char *what, double ms) {
+  static const char *path = getenv("ARES_RTC_TRACE");
+  if (!path || !path[0]) return;
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  if (FILE *o = fopen(path, "a")) {
+    const double now = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    fprintf(o, "%.3f slow %s %.3f ms\n", now, what, ms);
+    fclose(o);
+  }
+}
+
 namespace {
 struct PinnedSlot {
   uint64_t *ptr = nullptr;
@@ -244,6 +256,9 @@ void *stream_alloc(size_t bytes, hipStream_t stream) {
     }
   }
   void *p = nullptr;
+  thread_local char what[64];
+  snprintf(what, sizeof(what), "temporary: hipMalloc of %.1f MB", static_cast<double>(rounded) / 1e6);
+  SlowScope slow(what);
   hipError_t e = hipMalloc(&p, rounded);
   if (e != hipSuccess) {
     (void)hipGetLastError();
@@ -266,6 +281,7 @@ void stream_release(void *ptr, hipStream_t stream) {
     (void)hipGetLastError();
     return;
   }
+  SlowScope slow("temporary: release");
   std::lock_guard<std::mutex> lock(g_cacheMutex);
   auto it = g_blockSize.find(ptr);
   if (it == g_blockSize.end()) return;
@@ -313,7 +329,7 @@ hipEvent_t take_event() {
 }
 }  // namespace
 
-KernelTimer::KernelTimer(const char *name, hipStream_t stream) : slot_(-1), stream_(stream) {
+KernelTimer::KernelTimer(const char *name, hipStream_t stream) : slot_(-1), stream_(stream), slow_(name) {
   if (!g_profEnabled.load(std::memory_order_relaxed)) return;
   std::lock_guard<std::mutex> lock(g_profMutex);
   TimedLaunch t{name, take_event(), take_event(), stream, false, 0.0f};

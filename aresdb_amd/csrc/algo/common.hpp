@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -24,12 +25,36 @@ class AlgorithmError : public std::runtime_error {
   explicit AlgorithmError(const std::string &m) : std::runtime_error(m) {}
 };
 
+// ARES_RTC_TRACE=<file>: host time of anything that took longer than 5 ms on the calling thread (cold-start diagnostics)
+void slow_trace(const char *what, double ms);
+class SlowScope {
+ public:
+  explicit SlowScope(const char *what) : what_(what), t0_(std::chrono::steady_clock::now()) {}
+  ~SlowScope() {
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0_).count();
+    if (ms > 5.0) slow_trace(what_, ms);
+  }
+  SlowScope(const SlowScope &) = delete;
+  SlowScope &operator=(const SlowScope &) = delete;
+
+ private:
+  const char *what_;
+  std::chrono::steady_clock::time_point t0_;
+};
 inline void hip_check(hipError_t e, const char *what) {
   if (e != hipSuccess) {
     (void)hipGetLastError();
     throw AlgorithmError(std::string("ERROR: ") + what + ": " + hipGetErrorString(e));
   }
 }
+
+// every checked runtime call is timed on the way (two clock reads): ARES_RTC_TRACE names the ones that blocked the host
+template <class F>
+inline void hip_check_timed(F &&call, const char *what) {
+  SlowScope slow(what);
+  hip_check(call(), what);
+}
+#define hip_check(expr, what) hip_check_timed([&]() -> hipError_t { return (expr); }, what)
 
 // Checks the launch that was just enqueued (reference CheckCUDAError, utils.cu:44-59).
 inline void check_launch(const char *what) { hip_check(hipGetLastError(), what); }
@@ -84,13 +109,16 @@ struct CallStream {
 extern thread_local CallStream t_callStream;
 class CallStreamScope {
  public:
-  explicit CallStreamScope(void *stream) : saved_(t_callStream) { t_callStream = CallStream{reinterpret_cast<hipStream_t>(stream), true}; }
+  CallStreamScope(void *stream, const char *entry) : saved_(t_callStream), slow_(entry) {
+    t_callStream = CallStream{reinterpret_cast<hipStream_t>(stream), true};
+  }
   ~CallStreamScope() { t_callStream = saved_; }
   CallStreamScope(const CallStreamScope &) = delete;
   CallStreamScope &operator=(const CallStreamScope &) = delete;
 
  private:
   CallStream saved_;
+  SlowScope slow_;
 };
 
 // NOFLUSH: only for the entry points which decide themselves whether to queue or flush.  Every entry point names its
@@ -99,7 +127,7 @@ class CallStreamScope {
   CGoCallResHandle resHandle = {nullptr, nullptr};     \
   try {                                                \
     ares::hip_check(hipSetDevice(device), "hipSetDevice");  \
-    ares::CallStreamScope callStreamScope_(cudaStream);     \
+    ares::CallStreamScope callStreamScope_(cudaStream, __func__);  \
     (void)ares::deferral_hooks_active(); /* write tracking is on before this entry point's first kernel */
 
 #define ARES_ABI_BEGIN(device)     \
@@ -204,6 +232,7 @@ class KernelTimer {
  private:
   int slot_;
   hipStream_t stream_;
+  SlowScope slow_;  // a launch call that blocks the host (first use of a code object, scratch growth, a full queue)
 };
 
 // Launch + error check (+ timing when profiling is enabled).

@@ -36,16 +36,21 @@ struct LookupParams {
 struct __attribute__((packed, aligned(1))) KeyWord { uint32_t v; };
 
 __device__ __forceinline__ bool key_equal(const uint8_t *slotKey, const uint32_t (&key)[4], int keyBytes) {
-  // keys are stored unaligned (offset 72 + j*keyBytes): word-wise with byte-aligned loads when the
-  // size allows (gfx950 global loads need no alignment), byte-wise for odd sizes
-  if ((keyBytes & 3) == 0) {
-    for (int w = 0; w < (keyBytes >> 2); w++)
-      if (reinterpret_cast<const KeyWord *>(slotKey)[w].v != key[w]) return false;
-    return true;
+  // keys are stored unaligned (offset 72 + j*keyBytes): word-wise with byte-aligned loads (gfx950 global loads need no
+  // alignment), the odd tail byte-wise.  Constant indices into `key`: a run-time index would put it in scratch memory.
+  bool same = true;
+#pragma unroll
+  for (int w = 0; w < 4; w++) {
+    const int have = keyBytes - 4 * w;
+    if (have >= 4) {
+      same = same && reinterpret_cast<const KeyWord *>(slotKey)[w].v == key[w];
+    } else if (have > 0) {
+      uint32_t tail = 0;
+      for (int b = 0; b < have; b++) tail |= static_cast<uint32_t>(slotKey[4 * w + b]) << (8 * b);
+      same = same && tail == (key[w] & ((1u << (8 * have)) - 1u));
+    }
   }
-  for (int b = 0; b < keyBytes; b++)
-    if (slotKey[b] != static_cast<uint8_t>(key[b >> 2] >> (8 * (b & 3)))) return false;
-  return true;
+  return same;
 }
 
 __global__ __launch_bounds__(kBlock) void hash_lookup_kernel(LookupParams p, RecordID *out, int n) {
@@ -66,7 +71,9 @@ __global__ __launch_bounds__(kBlock) void hash_lookup_kernel(LookupParams p, Rec
       } else {
         const uint32_t pos = locate(p.a, row, p.baseCounts, p.startCount);
         const uint32_t *v = reinterpret_cast<const uint32_t *>(p.a.base + p.a.valuesOff + static_cast<size_t>(w) * pos);
-        for (int k = 0; k < (w >> 2); k++) key[k] = v[k];
+#pragma unroll  // (constant indices keep the key words in registers)
+        for (int k = 0; k < 4; k++)
+          if (k < (w >> 2)) key[k] = v[k];
         ok = p.a.mode >= 2 ? get_bit(p.a.base + p.a.nullsOff, pos + p.a.bitOff) : 1u;
       }
     } else {
@@ -84,7 +91,9 @@ __global__ __launch_bounds__(kBlock) void hash_lookup_kernel(LookupParams p, Rec
     RecordID rid = {0, 0};
     if (ok) {
       bool found = false;
-      for (int h = 0; h < p.numHashes && !found; h++) {
+#pragma unroll  // (constant indices into p.seeds)
+      for (int h = 0; h < 4; h++) {
+        if (h >= p.numHashes || found) break;
         const uint32_t hv = murmur3_32_words<4>(key, p.keyBytes, p.seeds[h]);
         uint32_t bq, bidx;
         fast_divmod(bucketDiv, hv, bq, bidx);

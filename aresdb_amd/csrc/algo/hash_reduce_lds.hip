@@ -449,14 +449,21 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
   const int chunkTiles = compact_enabled() ? rtc_compact_chunk_tiles(batchRows, partBits) : 0;
   const bool compact = chunkTiles > 0;
   RtcKernel lean, table;
+  SlowScope slowWhole("fused_hash_reduce_run");
   // (ARES_LEAN_MIN_GROUPS=0 — tests — sends every batch, known shape or not, to the DIRECT kernels)
   if (rtc && expected >= lean_min_groups() && (known || lean_min_groups() <= 0)) lean = rtc_scan_lookup(device, plan, nd, partBits, compact);
   else if (rtc && known) table = rtc_table_scan_lookup(device, plan, nd, partBits, a, widen);
   for (;;) {
     const int streams = batchRows > 0 ? (lean ? rtc_scan_grid(batchRows) : table ? 0 : grid_for(batchRows)) : 0;
     Regions r;
-    make_regions(r, partBits, length, batchRows, streams, lean ? 4 : 3, stream,
-                 !lean ? 0 : compact ? static_cast<int>(kCompactLineRecords) : 8);
+    {
+      SlowScope slow("make_regions");
+      // DIRECT mode writes region A only with previous groups that are not grouped by partition yet; sizing it for
+      // the batch as well made the first DIRECT batch of a process allocate (and the driver clear) 2.7 GB more
+      const int64_t rowsA = !lean ? length : (prevSize > 0 && !grouped) ? prevSize : 0;
+      make_regions(r, partBits, rowsA, batchRows, streams, lean ? 4 : 3, stream,
+                   !lean ? 0 : compact ? static_cast<int>(kCompactLineRecords) : 8);
+    }
     Workspace &ws = r.ws;
     ws.widen = widen;
     ws.chunkRows = static_cast<uint32_t>(chunkTiles) * 4096u;
@@ -501,7 +508,10 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
     switch (nd) {
       ARES_FUSED_CASE(1) ARES_FUSED_CASE(2) ARES_FUSED_CASE(3) ARES_FUSED_CASE(4)
     }
-    res = read_result(ws, stream);
+    {
+      SlowScope slow("read_result");
+      res = read_result(ws, stream);
+    }
     mem_note_dim_rows(device, outKeys, 0, res.groups);  // what this attempt emitted
     mem_note_write(device, outValues, static_cast<size_t>(mw) * res.groups);
     if (leanMerge && res.needGeneric && !res.overflow && !(grouped && res.stale)) {

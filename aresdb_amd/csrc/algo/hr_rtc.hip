@@ -1603,6 +1603,12 @@ void load_entry(RtcEntry &e, const std::string &entryName) {
   }
   (void)hipGetLastError();
   rtc_trace("module_load", entryName, tLoad.ms(), e.code.size());
+  if (fn) {  // (a kernel with scratch memory pays a queue-wide scratch allocation at its first launch)
+    int scratch = 0;
+    if (hipFuncGetAttribute(&scratch, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, fn) == hipSuccess)
+      rtc_trace("scratch_bytes_per_lane", entryName, 0.0, static_cast<size_t>(scratch));
+    (void)hipGetLastError();
+  }
   if (!fn && e.fromDisk && !e.diskPath.empty()) (void)unlink(e.diskPath.c_str());  // a stale cache file
   if (fn && !e.fromDisk) write_disk(e.diskPath, e.code);
   e.code.clear();

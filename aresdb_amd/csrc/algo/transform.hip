@@ -711,7 +711,7 @@ struct MultiJobs {
   SinkD s[kMaxMultiJobs];
 };
 
-__global__ __launch_bounds__(kBlock, 4) void transform_multi_kernel(MultiJobs jobs, const uint32_t *idx, int n, int64_t numQuads) {
+__global__ __launch_bounds__(kBlock, 3) void transform_multi_kernel(MultiJobs jobs, const uint32_t *idx, int n, int64_t numQuads) {
   const int64_t tileQuads = static_cast<int64_t>(kBlock) * kTQ;
   for (int64_t tq = static_cast<int64_t>(blockIdx.x) * tileQuads; tq < numQuads;
        tq += static_cast<int64_t>(gridDim.x) * tileQuads) {
@@ -1448,7 +1448,13 @@ DeferState &state_of(int device) {
   if (device < 0 || device >= kMaxDevices) throw std::invalid_argument("device index out of range");
   return states[device];
 }
-DeferLock::DeferLock(int device) : lock(state_of(device).mutex) { t_state = &state_of(device); }
+DeferLock::DeferLock(int device) : lock(state_of(device).mutex, std::defer_lock) {
+  {
+    SlowScope slow("wait for the device's deferral lock");
+    lock.lock();
+  }
+  t_state = &state_of(device);
+}
 
 // caller holds the device's DeferLock
 void watch_error_word(int device, hipStream_t stream, const uint32_t *errorDev, std::shared_ptr<StreamBuffer> ws) {

@@ -55,6 +55,24 @@ inline CGoCallResHandle fail(const char *what, hipError_t err) {
   return CGoCallResHandle{nullptr, format_error(what, err)};
 }
 
+// ARES_RTC_TRACE=<file> (shared with libalgorithm.so): entry points that kept the calling thread longer than 5 ms
+struct MemSlow {
+  const char *what;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  explicit MemSlow(const char *w) : what(w) {}
+  ~MemSlow() {
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (ms <= 5.0) return;
+    static const char *path = getenv("ARES_RTC_TRACE");
+    if (!path || !path[0]) return;
+    if (FILE *o = fopen(path, "a")) {
+      const double now = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+      fprintf(o, "%.3f slow libmem:%s %.3f ms\n", now, what, ms);
+      fclose(o);
+    }
+  }
+};
+
 #define MEM_TRY(expr, what)                        \
   do {                                             \
     hipError_t e_ = (expr);                        \
@@ -661,6 +679,7 @@ DeviceMemoryFlags GetFlags(void) {
 }
 
 CGoCallResHandle HostAlloc(size_t bytes) {
+  MemSlow slow_("HostAlloc");
   void *p = nullptr;
   MEM_TRY(hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable), "Allocate");
   memset(p, 0, bytes);
@@ -680,6 +699,7 @@ CGoCallResHandle HostMemCpy(void *dst, const void *src, size_t bytes) {
 }
 
 CGoCallResHandle CreateCudaStream(int device) {
+  MemSlow slow_("CreateCudaStream");
   MEM_TRY(hipSetDevice(device), "CreateCudaStream");
   hipStream_t s = nullptr;
   MEM_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "CreateCudaStream");
@@ -693,6 +713,7 @@ CGoCallResHandle CreateCudaStream(int device) {
 }
 
 CGoCallResHandle WaitForCudaStream(void *s, int device) {
+  MemSlow slow_("WaitForCudaStream");
   MEM_TRY(hipSetDevice(device), "WaitForCudaStream");
   notify_wait(device, s);
   MEM_TRY(hipStreamSynchronize(reinterpret_cast<hipStream_t>(s)), "WaitForCudaStream");
@@ -700,6 +721,7 @@ CGoCallResHandle WaitForCudaStream(void *s, int device) {
 }
 
 CGoCallResHandle DestroyCudaStream(void *s, int device) {
+  MemSlow slow_("DestroyCudaStream");
   MEM_TRY(hipSetDevice(device), "DestroyCudaStream");
   flush_pending(device);
   if (s) {
@@ -745,6 +767,7 @@ CGoCallResHandle DestroyCudaStream(void *s, int device) {
 }
 
 CGoCallResHandle DeviceAllocate(size_t bytes, int device) {
+  MemSlow slow_("DeviceAllocate");
   MEM_TRY(hipSetDevice(device), "DeviceAllocate");
   DeviceState *st;
   MEM_TRY(device_state(device, &st), "DeviceAllocate");
@@ -779,6 +802,7 @@ static hipError_t free_or_hold(DeviceState *st, void *p, int device) {
 }
 
 CGoCallResHandle DeviceFree(void *p, int device) {
+  MemSlow slow_("DeviceFree");
   MEM_TRY(hipSetDevice(device), "DeviceFree");
   DeviceState *st;
   MEM_TRY(device_state(device, &st), "DeviceFree");
@@ -787,6 +811,7 @@ CGoCallResHandle DeviceFree(void *p, int device) {
 }
 
 CGoCallResHandle AsyncCopyHostToDevice(void *dst, void *src, size_t bytes, void *stream, int device) {
+  MemSlow slow_("AsyncCopyHostToDevice");
   MEM_TRY(hipSetDevice(device), "AsyncCopyHostToDevice");
   notify_access(device, dst, bytes);
   notify_write(device, dst, bytes);
@@ -808,6 +833,7 @@ CGoCallResHandle AsyncCopyDeviceToDevice(void *dst, void *src, size_t bytes, voi
 }
 
 CGoCallResHandle AsyncCopyDeviceToHost(void *dst, void *src, size_t bytes, void *stream, int device) {
+  MemSlow slow_("AsyncCopyDeviceToHost");
   MEM_TRY(hipSetDevice(device), "AsyncCopyDeviceToHost");
   notify_access(device, src, bytes);
   if (bytes)

@@ -381,10 +381,10 @@ def main(argv=None, backend=None, tensor_device=None):
 
     if args.single_process:
         return single_process(args, backend, tensor_device)
-    # Cold-start legs first, while this process has not touched the GPU yet: a fresh process ALONE on the device — what a
-    # restarted server is.  (Run later, as children of a parent that holds a 20 GB shard on the same GPU, they showed
-    # stalls of 0.4-0.6 s in one early batch that move from batch to batch and vanish when the child has the device to
-    # itself: two processes on one device, not the library — profiles/r4_experiments.md.)
+    # Cold-start legs first, while this process has not touched the GPU yet: a fresh process alone on the device — what a
+    # restarted server is.  (The 0.3-0.7 s stalls these legs showed in rounds 3 and 4 were one driver allocation: the
+    # DIRECT-mode workspace was sized for a region it does not write, 4.3 GB of fresh device memory in a query's second
+    # or third batch — profiles/r4_experiments.md "cold start".)
     early_legs = {}
     if backend is None and args.gpus <= 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not (args.leg or args.cold or args.no_legs) and \
             (args.legs == "all" or any("cold" in w for w in args.legs.split(","))):

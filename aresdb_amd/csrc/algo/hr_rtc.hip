@@ -1544,10 +1544,10 @@ struct TraceClock {
 // ---- building an entry -----------------------------------------------------------------------------------------
 // A code object comes from the on-disk cache (read by the CALLER: tens of microseconds) or from hiprtc (seconds: on a
 // background thread unless ARES_RTC_ASYNC=0 / `wait`).  hipModuleLoadData ALWAYS runs on a calling (query) thread, the
-// first one that finds the code ready: measured on the GPU box (profiles/r4_experiments.md), the same load takes
-// 0.2-0.7 ms there and 530 ms on a freshly started background thread when another process holds memory on the device —
-// and stalls the query thread's launches for as long (the "490 ms first query of a process that finds its kernels on
-// disk" of round 3).
+// first one that finds the code ready: 0.2-0.7 ms there.  On a background thread the same load was once seen to take
+// 530 ms — queued behind a 4.3 GB hipMalloc of the query thread (the runtime serialises the two), which is what the
+// "490 ms first query of a process that finds its kernels on disk" of round 3 really was: the DIRECT-mode workspace,
+// sized for a region that mode does not write (hash_reduce_lds.hip, profiles/r4_experiments.md "cold start").
 std::string disk_path(int device, const std::string &source) {
   const std::string dir = disk_dir();
   return dir.empty() ? std::string() : dir + "/" + disk_name(device_arch(device), source);

@@ -226,6 +226,29 @@ void stream_cache_trim(int device) {
   for (void *p : blocks) (void)hipFree(p);
 }
 
+namespace {
+// A cached block for a request of `rounded` bytes; the caller holds g_cacheMutex.  The exact bin first.  A large request
+// (a HashReduce workspace: hundreds of megabytes to gigabytes) also takes the smallest LARGER cached block: a cached block
+// is idle memory whatever its size, and asking the driver for fresh memory instead costs 28 ms per GB at best
+// (profiles/r4_experiments.md "cold start").
+constexpr size_t kFitAnyFrom = static_cast<size_t>(64) << 20;
+void *take_cached(StreamCache &c, size_t rounded, bool larger) {
+  auto it = c.bins.find(rounded);
+  if (it == c.bins.end() || it->second.empty()) {
+    if (!larger || rounded < kFitAnyFrom) return nullptr;
+    it = c.bins.upper_bound(rounded);
+    while (it != c.bins.end() && it->second.empty()) ++it;
+    if (it == c.bins.end()) return nullptr;
+  }
+  void *p = it->second.back();
+  it->second.pop_back();
+  c.bytes -= it->first;
+  g_cachedBytes -= it->first;
+  check_take(p);
+  return p;
+}
+}  // namespace
+
 void *stream_alloc(size_t bytes, hipStream_t stream) {
   const size_t rounded = cache_bin(bytes);
   int device = 0;
@@ -233,26 +256,11 @@ void *stream_alloc(size_t bytes, hipStream_t stream) {
   {
     std::lock_guard<std::mutex> lock(g_cacheMutex);
     StreamCache &c = g_caches[{device, stream}];
-    auto it = c.bins.find(rounded);
-    if (it != c.bins.end() && !it->second.empty()) {
-      void *p = it->second.back();
-      it->second.pop_back();
-      c.bytes -= rounded;
-      g_cachedBytes -= rounded;
-      check_take(p);
-      return p;
-    }
     auto o = g_orphans.find(device);
-    if (o != g_orphans.end()) {
-      auto ob = o->second.bins.find(rounded);
-      if (ob != o->second.bins.end() && !ob->second.empty()) {
-        void *p = ob->second.back();
-        ob->second.pop_back();
-        o->second.bytes -= rounded;
-        g_cachedBytes -= rounded;
-        check_take(p);
-        return p;
-      }
+    for (int larger = 0; larger < 2; larger++) {  // exact bins of the stream and of the device first, then anything that fits
+      if (void *p = take_cached(c, rounded, larger != 0)) return p;
+      if (o != g_orphans.end())
+        if (void *p = take_cached(o->second, rounded, larger != 0)) return p;
     }
   }
   void *p = nullptr;
@@ -275,7 +283,9 @@ void *stream_alloc(size_t bytes, hipStream_t stream) {
   return p;
 }
 
-void stream_release(void *ptr, hipStream_t stream) {
+namespace {
+// idle = the block's last use has been waited for on the host: it goes to the device's shared bins, any stream may take it
+void release_block(void *ptr, hipStream_t stream, bool idle) {
   int device = 0;
   if (hipGetDevice(&device) != hipSuccess) {
     (void)hipGetLastError();
@@ -287,7 +297,7 @@ void stream_release(void *ptr, hipStream_t stream) {
   if (it == g_blockSize.end()) return;
   const size_t rounded = it->second;
   check_give(ptr);
-  StreamCache &c = g_caches[{device, stream}];
+  StreamCache &c = idle ? g_orphans[device] : g_caches[{device, stream}];
   c.bins[rounded].push_back(ptr);
   c.bytes += rounded;
   g_cachedBytes += rounded;
@@ -302,6 +312,10 @@ void stream_release(void *ptr, hipStream_t stream) {
   }();
   if (g_cachedBytes > cap) drop_all_cached();
 }
+}  // namespace
+
+void stream_release(void *ptr, hipStream_t stream) { release_block(ptr, stream, false); }
+void stream_release_idle(void *ptr) { release_block(ptr, nullptr, true); }
 
 // ---- kernel timing -------------------------------------------------------------------------------
 namespace {

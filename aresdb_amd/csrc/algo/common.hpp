@@ -175,6 +175,7 @@ inline void *int_result(int64_t v) { return reinterpret_cast<void *>(static_cast
 // cross-stream reuse inside the runtime's own pool.
 void *stream_alloc(size_t bytes, hipStream_t stream);
 void stream_release(void *ptr, hipStream_t stream);
+void stream_release_idle(void *ptr);  // the last use has been waited for: the block goes to the device's shared bins
 void stream_cache_purge(int device, hipStream_t stream);  // the stream is being destroyed
 void stream_cache_trim(int device);                       // out of memory elsewhere: give everything back
 // Write reports towards the sibling libmem.so (AresMemNoteWrite, include/ares_extensions.h): it clears a freed
@@ -196,8 +197,13 @@ class StreamBuffer {
  public:
   StreamBuffer(size_t bytes, hipStream_t stream) : stream_(stream) { ptr_ = stream_alloc(bytes ? bytes : 16, stream); }
   ~StreamBuffer() {
-    if (ptr_) stream_release(ptr_, stream_);
+    if (ptr_ && idle_) stream_release_idle(ptr_);
+    else if (ptr_) stream_release(ptr_, stream_);
   }
+  // The host has WAITED for the stream after the last kernel that touches the buffer: on release it goes to the device's
+  // shared bins instead of the stream's own.  (The Go host alternates two streams per query; HashReduce returns a count,
+  // so it has synchronised its stream when it lets go of its workspace — one workspace serves both streams.)
+  void mark_idle() { idle_ = true; }
   StreamBuffer(const StreamBuffer &) = delete;
   StreamBuffer &operator=(const StreamBuffer &) = delete;
   template <typename T>
@@ -207,6 +213,7 @@ class StreamBuffer {
  private:
   void *ptr_ = nullptr;
   hipStream_t stream_;
+  bool idle_ = false;
 };
 
 // A few pinned host words per calling thread: where count-returning entry points receive their

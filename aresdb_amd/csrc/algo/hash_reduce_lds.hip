@@ -374,6 +374,7 @@ int hash_reduce_lds(int device, const DimensionVector &inputKeys, const uint8_t 
     if (trace)
       fprintf(stderr, "hash_reduce_lds: length %d start %d rows %d streams %d capA %llu capB %u partBits %d -> groups %u overflow %u stale %u\n",
               length, start, rows, streams, static_cast<unsigned long long>(ws.capA), ws.capB, partBits, res.groups, res.overflow, res.stale);
+    r.buf->mark_idle();  // read_result waited for the stream behind the last kernel that touches the workspace
     if (grouped && res.stale) {  // the input vectors are not what the previous merge wrote: the long way
       grouped_note_write(device, inputKeys.DimValues, static_cast<size_t>(L.rowBytes) * capacity);
       grouped = false;
@@ -533,6 +534,7 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
       mem_note_write(device, outValues, static_cast<size_t>(mw) * res.groups);
     }
 #undef ARES_FUSED_CASE
+    r.buf->mark_idle();  // read_result waited for the stream behind the last kernel that touches the workspace
     if (grouped && res.stale) {
       grouped_note_write(device, prevKeys.DimValues, 5ull * nd * prevCapacity);
       grouped = false;

@@ -73,6 +73,18 @@ struct MemSlow {
   }
 };
 
+// one line per large DeviceAllocate in the same file: where the block came from (cold-start diagnostics)
+inline void mem_trace_alloc(size_t bytes, size_t rounded, const char *source, size_t parkedInBin, size_t parkedBytes) {
+  static const char *path = getenv("ARES_RTC_TRACE");
+  if (!path || !path[0] || rounded < (size_t(64) << 20)) return;
+  if (FILE *o = fopen(path, "a")) {
+    const double now = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    fprintf(o, "%.3f libmem:alloc %.1f MB (bin %.1f MB) from %s; %zu other blocks parked in the bin, %.1f MB parked in all\n", now,
+            bytes / 1e6, rounded / 1e6, source, parkedInBin, parkedBytes / 1e6);
+    fclose(o);
+  }
+}
+
 #define MEM_TRY(expr, what)                        \
   do {                                             \
     hipError_t e_ = (expr);                        \
@@ -342,7 +354,7 @@ hipError_t pool_alloc(DeviceState *st, void **p, size_t bytes, bool zero) {
     if (e != hipSuccess) return e;
     return zero ? hipMemset(*p, 0, bytes) : hipSuccess;
   }
-  const size_t rounded = bin_size(bytes);
+  size_t rounded = bin_size(bytes);  // (becomes the size of the block that is handed out: a parked block of a larger bin may serve)
   void *ptr = nullptr;
   bool cleared = false;
   ParkedBlock waitFor;
@@ -350,6 +362,17 @@ hipError_t pool_alloc(DeviceState *st, void **p, size_t bytes, bool zero) {
   {
     std::lock_guard<std::mutex> lock(st->mu);
     auto it = st->bins.find(rounded);
+    if ((it == st->bins.end() || it->second.empty()) && rounded >= kWaitForParkedFrom) {
+      // Nothing parked in the request's own bin: a parked block of a bin up to 1.5 x larger serves as well — it is idle
+      // memory either way, and the driver charges 28 ms per GB of fresh memory at best.  (A query's result vectors are
+      // sized by the batch's survivor count: the same query with another constant asks for another bin.)
+      for (auto jt = st->bins.upper_bound(rounded); jt != st->bins.end() && jt->first <= rounded + rounded / 2; ++jt)
+        if (!jt->second.empty()) {
+          it = jt;
+          rounded = jt->first;
+          break;
+        }
+    }
     if (it != st->bins.end()) {
       auto &vec = it->second;
       for (size_t i = 0; i < vec.size(); i++) {
@@ -375,6 +398,15 @@ hipError_t pool_alloc(DeviceState *st, void **p, size_t bytes, bool zero) {
       }
     }
   }
+  const char *source = ptr ? "the cache" : waitFor.ptr ? "the cache after a wait" : "the driver";
+  size_t parkedInBin = 0, parkedAll = 0;
+  {
+    std::lock_guard<std::mutex> lock(st->mu);
+    auto it = st->bins.find(rounded);
+    parkedInBin = it == st->bins.end() ? 0 : it->second.size();
+    parkedAll = st->parkedBytes;
+  }
+  mem_trace_alloc(bytes, rounded, source, parkedInBin, parkedAll);
   if (waitFor.ptr) {  // (outside the lock: frees and allocations of other threads go on)
     for (const FenceEvent &f : waitFor.fence) (void)hipEventSynchronize(f.event);
     ptr = waitFor.ptr;

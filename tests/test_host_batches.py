@@ -80,3 +80,32 @@ def test_column_cache_keeps_hot_batches_resident(be):
     for cols, _ in hb:
         for hc in cols:
             hc.free()
+
+
+@pytest.mark.parametrize("use_hash", [True, False], ids=["hash_reduce", "sort_reduce"])
+def test_resident_batches_in_one_driver_call_equal_one_call_per_batch(be, use_hash):
+    """AresQueryRunResidentBatches (what bench.py times as a step): the per-batch call sequence over a list of resident
+    batches without returning to the caller in between — same result, same number of ABI calls as one
+    AresQueryRunBatch per batch."""
+    from aresdb_amd.columns import DeviceColumn
+    if be.name == "hip":
+        pytest.skip("covered on the GPU by bench.py's timed path and smoke(); this test pins the driver logic on the CPU backends")
+    rng = np.random.default_rng(33)
+    data = [smoke.synth_batch(rng, n, null_fraction=0.02) for n in (9000, 1, 14000, 6000)]
+    plan = smoke.c3_plan(use_hash)
+    want, _ = smoke.run_query(be, plan, data)
+    dev = [({k: DeviceColumn(be, t, v, valid=valid[k]) for k, (t, v) in cols.items()}, len(cols["ts"][1])) for cols, valid in data]
+    one = NativeQuery(be, plan, NAMES)
+    for cols, n in dev:
+        one.run({k: c.vp for k, c in cols.items()}, n)
+    smoke.compare_results(_result(one, plan), want)
+    many = NativeQuery(be, plan, NAMES)
+    packed = many.pack_batches([({k: c.vp for k, c in cols.items()}, n) for cols, n in dev])
+    many.run_batches(packed)
+    smoke.compare_results(_result(many, plan), want)
+    assert many.result_size == one.result_size and many.calls == one.calls
+    one.release()
+    many.release()
+    for cols, _ in dev:
+        for c in cols.values():
+            c.free()

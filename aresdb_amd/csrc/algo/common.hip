@@ -267,7 +267,14 @@ void *stream_alloc(size_t bytes, hipStream_t stream) {
   thread_local char what[64];
   snprintf(what, sizeof(what), "temporary: hipMalloc of %.1f MB", static_cast<double>(rounded) / 1e6);
   SlowScope slow(what);
-  hipError_t e = hipMalloc(&p, rounded);
+  // ARES_TEMP_POOL_ALLOC=1 (experiment for the next round, profiles/r4_experiments.md "cold start"): fresh blocks from the
+  // stream-ordered pool — hipMallocAsync of 2 GB took 10 ms where hipMalloc took 61-318.  Blocks are never freed INTO the
+  // pool (no reuse inside it); a block that leaves the cache goes through hipFree like the others.
+  static const bool poolAlloc = [] {
+    const char *v = getenv("ARES_TEMP_POOL_ALLOC");
+    return v && v[0] == '1';
+  }();
+  hipError_t e = poolAlloc ? hipMallocAsync(&p, rounded, stream) : hipMalloc(&p, rounded);
   if (e != hipSuccess) {
     (void)hipGetLastError();
     {

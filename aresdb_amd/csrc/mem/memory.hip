@@ -420,7 +420,14 @@ hipError_t pool_alloc(DeviceState *st, void **p, size_t bytes, bool zero) {
       std::lock_guard<std::mutex> lock(st->mu);
       st->driverAllocs++;
     }
-    hipError_t e = hipMalloc(&ptr, rounded);
+    // ARES_MEM_POOL_ALLOC=1 (experiment for the next round): fresh blocks from the stream-ordered pool (see
+    // libalgorithm's ARES_TEMP_POOL_ALLOC); nothing is ever freed into that pool
+    static const bool poolAlloc = [] {
+      const char *v = getenv("ARES_MEM_POOL_ALLOC");
+      return v && v[0] == '1';
+    }();
+    hipError_t e = poolAlloc ? hipMallocAsync(&ptr, rounded, st->freshStream) : hipMalloc(&ptr, rounded);
+    if (e == hipSuccess && poolAlloc) e = hipStreamSynchronize(st->freshStream);
     if (e != hipSuccess) {  // out of memory: give both libraries' caches back and retry once
       (void)hipGetLastError();
       {

@@ -44,3 +44,9 @@ def test_generated_kernels_compile_for_gfx950(tmp_path):
     dis = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", "--mcpu=gfx950", str(tmp_path / "k_compact.co")], capture_output=True, text=True)
     if dis.returncode == 0 and "v_mul_lo_u32" in dis.stdout:
         assert dis.stdout.count("v_mad_u64_u32") <= 10, dis.stdout.count("v_mad_u64_u32")
+        # The compact scan is bound by vector-ALU issue (~750 VALU instructions per lane and 4096-row tile, four
+        # waves per SIMD, four cycles each): its instruction count is its speed.  798 at the end of round 4.
+        valu = sum(1 for ln in dis.stdout.splitlines() if ln.strip().startswith("v_"))
+        assert valu <= 840, valu
+        # the columns are read once: streaming (non-temporal) loads, -3 % on the scan (profiles/r4_experiments.md)
+        assert sum(1 for ln in dis.stdout.splitlines() if "global_load_dwordx4" in ln and " nt" in ln) >= 5

@@ -45,6 +45,24 @@ def test_two_rank_path_merges_and_verifies(tmp_path):
     assert len(out["per_rank_ms_per_step"]) == 2
 
 
+def test_eight_rank_path_merges_and_verifies():
+    """The launch the driver uses on an 8-GPU node (`torch.distributed.run --nproc-per-node 8 bench.py --gpus 8`), with
+    gloo and the oracle backend: eight shards, one merge, the merged table checked key by key."""
+    H.oracle_backend()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(H.ROOT, "tests", "bench_dist_harness.py"), "--gpus", "8", "--rows", "5000",
+           "--batch-rows", "2500", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-legs", "--verify-merged"]
+    r = subprocess.run(cmd, cwd=H.ROOT, env=env, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["scaling"] == "weak" and out["steps"] == 2
+    assert out["check_groups"]["status"] == "ok" and out["check_merged_groups"]["status"] == "ok"
+    assert len(out["per_rank_ms_per_step"]) == 8
+    assert out["config"]["merged_groups"] == out["check_merged_groups"]["groups"] >= out["config"]["groups_per_shard"]
+
+
 def test_single_process_threads_path_merges_and_verifies(capsys):
     """bench.py --single-process: shards as threads of one process (the reference's process model), here two threads
     on the oracle backend; the merged table is checked key by key."""

@@ -417,7 +417,9 @@ def main(argv=None, backend=None, tensor_device=None):
     # ARES_BENCH_FORCE_DIST=1: exercise the multi-rank code path (RCCL init, merge) with one rank
     force_dist = os.environ.get("ARES_BENCH_FORCE_DIST") == "1"
     distributed = world > 1 or force_dist
+    created_group = False
     if distributed and not dist.is_initialized():
+        created_group = True
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
@@ -808,7 +810,8 @@ def main(argv=None, backend=None, tensor_device=None):
         ok = bool(int(okt))
         if comm is not None:
             comm.destroy()
-        if backend is None:
+        if backend is None or created_group:  # (left to the interpreter's exit, gloo's threads abort the process now and then)
+            dist.barrier()
             dist.destroy_process_group()
     for s in streams:
         be.call("DestroyCudaStream", s, device_index)

@@ -1500,6 +1500,7 @@ std::string device_arch(int device) {
 bool compile_source(const std::string &source, const std::string &arch, const char *entry, std::vector<char> &code) {
   const RtcApi &api = rtc_api();
   RtcProgram prog = nullptr;
+  if (!api.ok || !api.create) return false;  // (no hiprtc in this process: callers check rtc_scan_available() first)
   if (api.create(&prog, source.c_str(), "hr_rtc.hip", 0, nullptr, nullptr) != 0) return false;
   const std::string archOpt = "--offload-arch=" + arch;
   const char *opts[1 + kRtcOptionCount] = {archOpt.c_str()};

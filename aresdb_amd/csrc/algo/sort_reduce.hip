@@ -75,9 +75,7 @@ __global__ __launch_bounds__(256) void digit_start_kernel(uint32_t *hist /* in: 
 // ---------------------------------------------------------------------------------------------
 // Sort step 2: one LSD pass (8-bit digit), stable, single pass over the data
 // ---------------------------------------------------------------------------------------------
-constexpr int kSortKPT = 16;                    // keys per lane
-constexpr int kSortTile = kBlock * kSortKPT;    // 4096 keys per tile
-constexpr int kSortWaveChunk = 64 * kSortKPT;   // contiguous keys owned by one wavefront
+// (keys per lane is a template parameter of the pass: 16 by default — a 4096-key tile, 1024 contiguous keys per wavefront)
 constexpr uint32_t kFlagAgg32 = 1u << 30, kFlagInc32 = 2u << 30, kFlagMask32 = 3u << 30;
 
 __device__ __forceinline__ uint32_t ld_status32(const uint32_t *p) {

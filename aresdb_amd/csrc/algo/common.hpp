@@ -259,7 +259,7 @@ inline int capped_grid(int64_t tiles, int cap = 256 * 8) {
     const char *e = getenv("ARES_GRID_PER_CU");
     return e ? atoi(e) : 0;
   }();
-  if (perCU > 0 && cap >= 256) cap = 256 * perCU;
+  if (perCU > 0 && cap >= 256 && 256 * perCU < cap) cap = 256 * perCU;  // (lowers a caller's cap, never raises it: callers size buffers by it)
   return static_cast<int>(tiles < cap ? tiles : cap);
 }
 

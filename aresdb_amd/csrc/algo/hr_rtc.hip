@@ -1669,9 +1669,9 @@ RtcKernel compiled_kernel(int device, const std::string &source, const char *ent
         auto victim = c.map.end();
         for (auto jt = c.map.begin(); jt != c.map.end(); ++jt) {
           bool ready;
-          {
+          {  // (an entry whose code is here but that nobody asked for again has no module yet: dropping it is free)
             std::lock_guard<std::mutex> el(jt->second->m);
-            ready = jt->second->ready;
+            ready = jt->second->ready || jt->second->codeReady;
           }
           if (ready && (victim == c.map.end() || jt->second->lastUse.load() < victim->second->lastUse.load())) victim = jt;
         }
@@ -1696,10 +1696,13 @@ RtcKernel compiled_kernel(int device, const std::string &source, const char *ent
     std::vector<char> code;
     if (read_disk(e->diskPath, entry, code)) {  // found on disk: loaded below, on this thread
       c.diskHits++;
-      std::lock_guard<std::mutex> lock(e->m);
-      e->code.swap(code);
-      e->fromDisk = true;
-      e->codeReady = true;
+      {
+        std::lock_guard<std::mutex> lock(e->m);
+        e->code.swap(code);
+        e->fromDisk = true;
+        e->codeReady = true;
+      }
+      e->cv.notify_all();  // (a second thread may already wait for this entry: `wait` / ARES_RTC_ASYNC=0)
       if (c.pending.fetch_sub(1) == 1) {
         std::lock_guard<std::mutex> idle(c.idleMu);
         c.idleCv.notify_all();
@@ -1718,6 +1721,7 @@ RtcKernel compiled_kernel(int device, const std::string &source, const char *ent
   if (!e->ready) {  // the code is here: this (query) thread loads it
     (void)hipSetDevice(device);
     load_entry(*e, entry);
+    e->cv.notify_all();
   }
   return e->fn ? e : nullptr;
 }

@@ -2577,6 +2577,7 @@ int run_filter_rows(int device, hipStream_t stream, FastOperands f, uint32_t *in
     if (f.debug & 32) grid = capped_grid(tiles, 256 * 4);         //  four / eight per compute unit)
     if (f.debug & 64) grid = capped_grid(tiles, 256 * 8);
     if ((f.debug >> 12) & 15) grid = capped_grid(tiles, 256 * ((f.debug >> 12) & 15));  // (experiment: workgroups per compute unit)
+    grid = std::min(grid, kGridCap);  // whatever the experiment switches asked for: two partial counts per workgroup fit the pinned slot
     const size_t bitBytes = static_cast<size_t>(tiles) * kBlock * sizeof(uint16_t);  // 16 rows per lane and tile
     bits1 = std::make_shared<StreamBuffer>(bitBytes, stream);
     if (two) bits2 = std::make_shared<StreamBuffer>(bitBytes, stream);

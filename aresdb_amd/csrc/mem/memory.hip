@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <condition_variable>
 #include <cstddef>
 #include <cstdio>
 #include <cstdlib>
@@ -74,6 +75,10 @@ struct MemSlow {
 };
 
 // one line per large DeviceAllocate in the same file: where the block came from (cold-start diagnostics)
+inline bool mem_trace_enabled() {
+  static const char *path = getenv("ARES_RTC_TRACE");
+  return path && path[0];
+}
 inline void mem_trace_alloc(size_t bytes, size_t rounded, const char *source, size_t parkedInBin, size_t parkedBytes) {
   static const char *path = getenv("ARES_RTC_TRACE");
   if (!path || !path[0] || rounded < (size_t(64) << 20)) return;
@@ -222,6 +227,11 @@ struct DeviceState {
   size_t parkedBytes = 0;
   // freed by the host while deferred work of one stream (the tag) still reads them (AresMemReleaseHeld)
   std::vector<std::pair<void *, uintptr_t>> held;
+  // allocations that took a parked block out of `bins` and are waiting for its fence outside `mu` (pool_alloc): the
+  // events they wait on are in nobody's books meanwhile, so DestroyCudaStream lets them finish before it retires a
+  // stream's events
+  int waiters = 0;
+  std::condition_variable waitersCv;
 };
 DeviceState g_devices[kMaxDevices];
 
@@ -273,14 +283,30 @@ bool fence_done(const ParkedBlock &b) {
   return true;
 }
 
-// caller holds st->mu
+// caller holds st->mu.  An event is only kept for reuse while the stream of its last record exists (see FenceEvent):
+// one whose stream has gone meanwhile is destroyed here, never recorded again.
 void recycle_events(DeviceState *st, ParkedBlock &b) {
-  for (const FenceEvent &f : b.fence) st->freeEvents.push_back(f);
+  for (const FenceEvent &f : b.fence) {
+    bool alive = f.stream == nullptr || f.stream == st->allocStream || f.stream == st->freshStream;
+    for (size_t i = 0; !alive && i < st->streams.size(); i++) alive = st->streams[i] == f.stream;
+    if (alive) st->freeEvents.push_back(f);
+    else (void)hipEventDestroy(f.event);
+  }
   b.fence.clear();
 }
 
 // Releases parked blocks (oldest bins first) until `need` more bytes fit under the cap or nothing
 // is left; used when hipMalloc fails or the cache grows past half of the device.
+// ARES_MEM_ABORT=1 (race hunting): a host-side misuse that the library can survive (a block freed twice) kills the
+// process on the spot instead of coming back as an error through CGoCallResHandle
+bool mem_abort_on_invariant() {
+  static const bool on = [] {
+    const char *e = getenv("ARES_MEM_ABORT");
+    return e && e[0] == '1';
+  }();
+  return on;
+}
+
 bool mem_debug() {
   static const bool on = [] {
     const char *e = getenv("ARES_MEM_DEBUG");
@@ -395,24 +421,25 @@ hipError_t pool_alloc(DeviceState *st, void **p, size_t bytes, bool zero) {
         vec.erase(vec.begin());
         st->parkedBytes -= rounded;
         waitFor = b;
+        st->waiters++;
       }
     }
+    if (mem_trace_enabled()) {  // (diagnostics only: nothing is counted when the trace is off)
+      const char *source = ptr ? "the cache" : waitFor.ptr ? "the cache after a wait" : "the driver";
+      auto bt = st->bins.find(rounded);
+      mem_trace_alloc(bytes, rounded, source, bt == st->bins.end() ? 0 : bt->second.size(), st->parkedBytes);
+    }
   }
-  const char *source = ptr ? "the cache" : waitFor.ptr ? "the cache after a wait" : "the driver";
-  size_t parkedInBin = 0, parkedAll = 0;
-  {
-    std::lock_guard<std::mutex> lock(st->mu);
-    auto it = st->bins.find(rounded);
-    parkedInBin = it == st->bins.end() ? 0 : it->second.size();
-    parkedAll = st->parkedBytes;
-  }
-  mem_trace_alloc(bytes, rounded, source, parkedInBin, parkedAll);
   if (waitFor.ptr) {  // (outside the lock: frees and allocations of other threads go on)
     for (const FenceEvent &f : waitFor.fence) (void)hipEventSynchronize(f.event);
     ptr = waitFor.ptr;
     cleared = waitFor.zeroed;
-    std::lock_guard<std::mutex> lock(st->mu);
-    recycle_events(st, waitFor);
+    {
+      std::lock_guard<std::mutex> lock(st->mu);
+      recycle_events(st, waitFor);
+      st->waiters--;
+    }
+    st->waitersCv.notify_all();
   }
   if (!ptr) {
     count_driver_allocation(rounded);
@@ -503,9 +530,10 @@ hipError_t pool_free(DeviceState *st, void *p) {
   if (it == st->live.end()) {  // not ours (allocated before the pool was switched on) — or freed twice
     for (auto &bin : st->bins)
       for (const ParkedBlock &pb : bin.second)
-        if (pb.ptr == p) {
+        if (pb.ptr == p) {  // the host's bug, reported the way the reference's DeviceFree reports a failing cudaFree
           fprintf(stderr, "libmem: block %p freed twice (it is parked in the cache)\n", p);
-          abort();
+          if (mem_abort_on_invariant()) abort();
+          return hipErrorInvalidDevicePointer;
         }
     return hipFree(p);
   }
@@ -780,7 +808,11 @@ CGoCallResHandle DestroyCudaStream(void *s, int device) {
     {
       // The stream is idle: whatever its fence events stand for has happened.  They are retired NOW, while the stream
       // exists (see FenceEvent) — destroyed, not recycled: nothing of the runtime's bookkeeping for this stream is kept.
-      std::lock_guard<std::mutex> lock(st->mu);
+      // An allocation that is waiting for a parked block's fence holds events of this stream outside every list: it is
+      // let through first (well under a millisecond; no new fence can name this stream, it left `streams` above) and
+      // hands its events to freeEvents, where the sweep below finds them.
+      std::unique_lock<std::mutex> lock(st->mu);
+      st->waitersCv.wait(lock, [&] { return st->waiters == 0; });
       for (auto &bin : st->bins)
         for (ParkedBlock &b : bin.second)
           for (size_t i = 0; i < b.fence.size();)

@@ -44,7 +44,11 @@ struct FastOperands {
   int pad;
   int divLike;           // integer Divide / Mod / Floor by the constant: multiply-high division
   int debug;             // ARES_F_DEBUG: timing experiments only
+  int step;              // bytes per stored value: 4, or 2 / 1 (Int16 / Uint16 / Int8 / Uint8 / SmallEnum / BigEnum columns,
+                         // widened in registers — sign-extended for akind K_I32 — as query/iterator.hpp:146-165 does)
 };
+// bytes of `rows` values of the operand's column
+__host__ __device__ inline uint64_t fast_value_bytes(const FastOperands &f, uint64_t rows) { return static_cast<uint64_t>(f.step ? f.step : 4) * rows; }
 
 struct __attribute__((packed, aligned(1))) PU16 { uint16_t v; };
 
@@ -246,12 +250,13 @@ inline void build_params(const InputVector *ins, int arity, hipStream_t stream, 
 }
 
 
-// The hot shape of a live-batch query: a 4-byte column (modes 1/2), optionally combined with a
-// constant, feeding a 4-byte vector or a measure.  Everything else takes the generic kernels.
+// The hot shape of a live-batch query: a 1-, 2- or 4-byte column (modes 1/2) of a 32-bit kind, optionally combined
+// with a constant, feeding a dimension / scratch vector or a measure.  Everything else takes the generic kernels.
 inline bool fast_operands(const EvalParams &p, FastOperands &f, bool compareOnly) {
   if (p.arity == 1 && (compareOnly || p.functor != Noop)) return false;
   if (compareOnly && (p.functor < Equal || p.functor > GreaterThanOrEqual)) return false;
-  if (p.a.type != OP_COLUMN || p.a.step != 4 || p.a.mode > 2 || p.a.kind == K_BOOL || is_wide(p.a.kind)) return false;
+  if (p.a.type != OP_COLUMN || p.a.mode > 2 || p.a.kind == K_BOOL || is_wide(p.a.kind)) return false;
+  if (p.a.step != 4 && !((p.a.step == 2 || p.a.step == 1) && (p.a.kind == K_I32 || p.a.kind == K_U32))) return false;
   if (p.arity == 2 && (p.b.type != OP_CONST || is_wide(p.b.kind))) return false;
   if (is_wide(p.I)) return false;
   memset(&f, 0, sizeof(f));
@@ -273,6 +278,7 @@ inline bool fast_operands(const EvalParams &p, FastOperands &f, bool compareOnly
     return dbg ? atoi(dbg) : 0;
   }();
   f.debug = debug;
+  f.step = p.a.step;
   return true;
 }
 

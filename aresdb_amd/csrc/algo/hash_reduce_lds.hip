@@ -83,12 +83,36 @@ __global__ __launch_bounds__(kThreads) void hr_fused_merge_kernel(FusedPlanD pla
 std::mutex g_rangesMutex;
 std::vector<std::pair<int, uint32_t *>> g_freeRanges;
 
+// dimension slots of a vector the grouped state (and the generated kernels) can describe: at most kFusedDims dimensions of
+// 4, 2 or 1 bytes (dim_layout.hpp: descending width order)
+struct SlotWidths {
+  int nd = 0, dimBytes = 0;  // dimBytes: value bytes of one row
+  uint8_t width[kFusedDims] = {0, 0, 0, 0}, off[kFusedDims] = {0, 0, 0, 0};
+  bool same(const SlotWidths &o) const { return nd == o.nd && memcmp(width, o.width, sizeof(width)) == 0; }
+  size_t row_bytes() const { return static_cast<size_t>(dimBytes + nd); }
+};
+bool slot_widths(const uint8_t numDimsPerDimWidth[NUM_DIM_WIDTH], SlotWidths *out) {
+  SlotWidths w;
+  if (numDimsPerDimWidth[0] || numDimsPerDimWidth[1]) return false;
+  for (int k = 2; k < NUM_DIM_WIDTH; k++)
+    for (int j = 0; j < numDimsPerDimWidth[k]; j++) {
+      if (w.nd >= kFusedDims) return false;
+      w.width[w.nd] = static_cast<uint8_t>(1 << (NUM_DIM_WIDTH - 1 - k));
+      w.off[w.nd] = static_cast<uint8_t>(w.dimBytes);
+      w.dimBytes += w.width[w.nd];
+      w.nd++;
+    }
+  *out = w;
+  return w.nd >= 1;
+}
+
 struct GroupedState {
   int device;
   const uint8_t *dims;
   const uint8_t *values;
   size_t capacity;
-  int nd, valueBytes, size, partBits;
+  SlotWidths slots;
+  int valueBytes, size, partBits;
   // kMaxPartitions x kRangeWords words of device memory.  Shared: a call that looked the state up keeps the buffer
   // alive while its merge reads it, whatever another thread's eviction or overwrite does to the table meanwhile; the
   // buffer goes back to the free list with the last reference.
@@ -128,19 +152,19 @@ std::shared_ptr<uint32_t> take_ranges(int device) {
 
 bool state_overlaps(const GroupedState &s, const uint8_t *lo, const uint8_t *hi) {
   auto hit = [&](const uint8_t *a, size_t bytes) { return a < hi && lo < a + bytes; };
-  for (int d = 0; d < s.nd; d++) {
-    if (hit(s.dims + 4 * s.capacity * d, 4ull * s.size)) return true;
-    if (hit(s.dims + 4 * s.capacity * s.nd + s.capacity * d, static_cast<size_t>(s.size))) return true;
+  for (int d = 0; d < s.slots.nd; d++) {
+    if (hit(s.dims + s.capacity * s.slots.off[d], static_cast<size_t>(s.slots.width[d]) * s.size)) return true;
+    if (hit(s.dims + s.capacity * s.slots.dimBytes + s.capacity * d, static_cast<size_t>(s.size))) return true;
   }
   return hit(s.values, static_cast<size_t>(s.valueBytes) * s.size);
 }
 
-bool grouped_lookup(int device, const uint8_t *dims, const uint8_t *values, size_t capacity, int nd, int valueBytes,
+bool grouped_lookup(int device, const uint8_t *dims, const uint8_t *values, size_t capacity, const SlotWidths &slots, int valueBytes,
                     GroupedState *out) {
   if (!grouped_enabled()) return false;
   std::lock_guard<std::mutex> lock(g_groupedMutex);
   for (const GroupedState &s : g_grouped)
-    if (s.device == device && s.dims == dims && s.values == values && s.capacity == capacity && s.nd == nd &&
+    if (s.device == device && s.dims == dims && s.values == values && s.capacity == capacity && s.slots.same(slots) &&
         s.valueBytes == valueBytes) {
       *out = s;
       return true;
@@ -277,16 +301,19 @@ int hash_reduce_lds(int device, const DimensionVector &inputKeys, const uint8_t 
   const size_t capacity = static_cast<size_t>(inputKeys.VectorCapacity);
   bool all4 = L.numDims >= 1 && L.numDims <= 4;  // beyond 4 dims the double-buffered quads spill
   for (int d = 0; d < L.numDims; d++) all4 = all4 && L.width[d] == 4;
+  // a layout whose partition-grouped result a later FUSED batch can start from (narrow slots: the generated merge only)
+  SlotWidths slots;
+  const bool describable = slot_widths(inputKeys.NumDimsPerDimWidth, &slots);
   const int partBits = part_bits_for(length);
   const int numParts = 1 << partBits;
   // the output vectors are about to be rewritten: whatever was known about them is void
   grouped_note_write(device, outputKeys.DimValues, static_cast<size_t>(L.rowBytes) * capacity);
   grouped_note_write(device, outputValues, static_cast<size_t>(a.width) * capacity);
   GroupedState prev;
-  bool grouped = all4 && grouped_lookup(device, inputKeys.DimValues, inputValues, capacity, L.numDims, a.width, &prev) &&
+  bool grouped = all4 && grouped_lookup(device, inputKeys.DimValues, inputValues, capacity, slots, a.width, &prev) &&
                  prev.partBits == partBits && prev.size > 0 && prev.size <= length;
   // (the reference goes with this call unless the result is registered below: nothing leaks when a launch throws)
-  const std::shared_ptr<uint32_t> outRangesRef = (all4 && grouped_enabled()) ? take_ranges(device) : nullptr;
+  const std::shared_ptr<uint32_t> outRangesRef = (describable && grouped_enabled()) ? take_ranges(device) : nullptr;
   uint32_t *outRanges = outRangesRef.get();
   MergeResult res{0, 0, 0, 0};
   for (;;) {
@@ -391,7 +418,7 @@ int hash_reduce_lds(int device, const DimensionVector &inputKeys, const uint8_t 
     return -1;
   }
   if (outRanges) {
-    GroupedState s{device, outputKeys.DimValues, outputValues, capacity, L.numDims, a.width, static_cast<int>(res.groups),
+    GroupedState s{device, outputKeys.DimValues, outputValues, capacity, slots, a.width, static_cast<int>(res.groups),
                    partBits, outRangesRef};
     if (res.groups > 0) grouped_register(s);
   }
@@ -402,11 +429,25 @@ int hash_reduce_lds(int device, const DimensionVector &inputKeys, const uint8_t 
 // The fused pipeline for an already built plan (shared by the extension entry point and by the
 // in-ABI fusion of pending transforms into HashReduce, transform.hip).  Returns the number of groups
 // or -1 when a region overflowed.
+void fused_note_first_batch(size_t shape, int groups) {
+  if (!shape || groups < 0) return;
+  std::lock_guard<std::mutex> lock(g_shapeMutex);
+  if (g_firstBatchGroups.size() > 4096) g_firstBatchGroups.clear();
+  g_firstBatchGroups[shape] = groups;
+}
+
 int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, const DimensionVector &prevKeys,
                           const uint8_t *prevValues, int prevSize, const DimensionVector &outKeys, uint8_t *outValues,
-                          const AggSpec &a, hipStream_t stream) {
-  int nd = 0;
-  for (int k = 0; k < NUM_DIM_WIDTH; k++) nd += outKeys.NumDimsPerDimWidth[k];
+                          const AggSpec &a, hipStream_t stream, size_t *pendingShape) {
+  if (pendingShape) *pendingShape = 0;
+  SlotWidths slots;
+  if (!slot_widths(outKeys.NumDimsPerDimWidth, &slots)) return kFusedUnavailable;
+  const int nd = slots.nd;
+  // Narrow plans (a 1- / 2-byte dimension slot or source column) run on the kernels generated for their shape ONLY: the
+  // precompiled generic scan and merge read 4-byte columns and write 4-byte slots.  Whenever a generated kernel is not
+  // loaded yet (it is being compiled in the background) or the call needs something only the generic kernels do, the
+  // call is declined BEFORE anything is launched and the caller takes the unfused sequence for this batch.
+  const bool narrow = fused_plan_narrow(plan, nd);
   const int mw = plan.measureWidth;
   const int64_t length = static_cast<int64_t>(batchRows) + prevSize;
   if (length == 0) return 0;
@@ -414,11 +455,12 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
   const int numParts = 1 << partBits;
   const size_t prevCapacity = static_cast<size_t>(prevKeys.VectorCapacity);
   const size_t outCapacity = static_cast<size_t>(outKeys.VectorCapacity);
-  grouped_note_write(device, outKeys.DimValues, 5ull * nd * outCapacity);
+  grouped_note_write(device, outKeys.DimValues, slots.row_bytes() * outCapacity);
   grouped_note_write(device, outValues, static_cast<size_t>(mw) * outCapacity);
   GroupedState prev;
-  bool grouped = prevSize > 0 && grouped_lookup(device, prevKeys.DimValues, prevValues, prevCapacity, nd, mw, &prev) &&
+  bool grouped = prevSize > 0 && grouped_lookup(device, prevKeys.DimValues, prevValues, prevCapacity, slots, mw, &prev) &&
                  prev.partBits == partBits && prev.size == prevSize;
+  if (narrow && (!(batchRows > 0 && rtc_scan_available()) || (prevSize > 0 && !grouped))) return kFusedUnavailable;
   const std::shared_ptr<uint32_t> outRangesRef = grouped_enabled() ? take_ranges(device) : nullptr;
   uint32_t *outRanges = outRangesRef.get();
   MergeResult res{0, 0, 0, 0};
@@ -449,12 +491,30 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
   }
   const int chunkTiles = compact_enabled() ? rtc_compact_chunk_tiles(batchRows, partBits) : 0;
   const bool compact = chunkTiles > 0;
-  RtcKernel lean, table;
+  RtcKernel lean, table, tableMerge, narrowMerge;
   SlowScope slowWhole("fused_hash_reduce_run");
   // (ARES_LEAN_MIN_GROUPS=0 — tests — sends every batch, known shape or not, to the DIRECT kernels)
-  if (rtc && expected >= lean_min_groups() && (known || lean_min_groups() <= 0)) lean = rtc_scan_lookup(device, plan, nd, partBits, compact);
-  else if (rtc && known) table = rtc_table_scan_lookup(device, plan, nd, partBits, a, widen);
+  const bool wantLean = rtc && expected >= lean_min_groups() && (known || lean_min_groups() <= 0);
+  const bool wantTable = rtc && !wantLean && known;
+  if (narrow && !wantLean && !wantTable) {
+    // a shape nobody has seen: nothing says which scan suits it and there is no generic kernel to find out with.  Both
+    // pairs are requested (background), the unfused sequence runs this batch and reports its groups (pendingShape).
+    (void)rtc_scan_lookup(device, plan, nd, partBits, compact);
+    (void)rtc_merge_lookup(device, plan, nd, partBits, a, widen, compact);
+    (void)rtc_table_scan_lookup(device, plan, nd, partBits, a, widen);
+    (void)rtc_merge_lookup(device, plan, nd, partBits, a, widen, false, false, /*regionA=*/true);
+    if (pendingShape) *pendingShape = shape;
+    return kFusedUnavailable;
+  }
+  if (wantLean) lean = rtc_scan_lookup(device, plan, nd, partBits, compact);
+  else if (wantTable) table = rtc_table_scan_lookup(device, plan, nd, partBits, a, widen);
+  if (narrow) {
+    if (wantLean) narrowMerge = rtc_merge_lookup(device, plan, nd, partBits, a, widen, compact);
+    else tableMerge = rtc_merge_lookup(device, plan, nd, partBits, a, widen, false, false, /*regionA=*/true);
+    if (wantLean ? !(lean && narrowMerge) : !(table && tableMerge)) return kFusedUnavailable;  // still being compiled
+  }
   for (;;) {
+    if (narrow && prevSize > 0 && !grouped) return -1;  // (the grouped previous result turned out stale: the long way)
     const int streams = batchRows > 0 ? (lean ? rtc_scan_grid(batchRows) : table ? 0 : grid_for(batchRows)) : 0;
     Regions r;
     {
@@ -474,9 +534,9 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
     Workspace wsPrev = ws;  // previous groups that are not grouped by partition: TABLE-mode pass into region A
     wsPrev.streams = 0;
     // the specialised merge reads region B and grouped previous results only
-    RtcKernel leanMerge = (lean && (prevSize == 0 || grouped)) ? rtc_merge_lookup(device, plan, nd, partBits, a, widen, compact) : nullptr;
+    RtcKernel leanMerge = narrow ? narrowMerge : (lean && (prevSize == 0 || grouped)) ? rtc_merge_lookup(device, plan, nd, partBits, a, widen, compact) : nullptr;
     // (the specialised merge writes every partition's range entry itself)
-    if (outRanges && !leanMerge) hip_check(hipMemsetAsync(outRanges, 0, kRangesBytes, stream), "hipMemsetAsync");
+    if (outRanges && !leanMerge && !tableMerge) hip_check(hipMemsetAsync(outRanges, 0, kRangesBytes, stream), "hipMemsetAsync");
 #define ARES_FUSED_CASE(ND)                                                                                            \
   case ND:                                                                                                             \
     if (prevSize > 0 && !grouped) {                                                                                    \
@@ -494,9 +554,9 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
     else if (batchRows > 0)                                                                                            \
       ARES_LAUNCH("hr_fused_scan_kernel", hr_fused_scan_kernel<ND>, streams, kThreads, stream, plan,                   \
                   static_cast<uint32_t>(prevSize), a, batchRows, ws);                                                  \
-    if (leanMerge)                                                                                                     \
-      rtc_merge_launch(leanMerge, plan, prevKeys.DimValues, prevCapacity, prevValues, static_cast<uint32_t>(prevSize),  \
-                       outKeys.DimValues, outCapacity, outValues, ws, stream);                                         \
+    if (leanMerge || tableMerge)                                                                                       \
+      rtc_merge_launch(leanMerge ? leanMerge : tableMerge, plan, prevKeys.DimValues, prevCapacity, prevValues,         \
+                       static_cast<uint32_t>(prevSize), outKeys.DimValues, outCapacity, outValues, ws, stream);        \
     else if (lean)                                                                                                     \
       ARES_LAUNCH("hr_fused_merge_kernel", (hr_fused_merge_kernel<ND, 4>), numParts, kThreads, stream, plan,            \
                   prevKeys.DimValues, prevCapacity, prevValues, static_cast<uint32_t>(prevSize), outKeys.DimValues,    \
@@ -515,6 +575,10 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
     }
     mem_note_dim_rows(device, outKeys, 0, res.groups);  // what this attempt emitted
     mem_note_write(device, outValues, static_cast<size_t>(mw) * res.groups);
+    if (narrow && res.needGeneric) {  // more groups in a partition than one table: only the generic merge takes rounds
+      r.buf->mark_idle();
+      return -1;
+    }
     if (leanMerge && res.needGeneric && !res.overflow && !(grouped && res.stale)) {
       // a partition holds more groups than one LDS table: the generic multi-round merge over the same records
       hip_check(hipMemsetAsync(ws.outCount, 0, 4 * sizeof(uint32_t), stream), "hipMemsetAsync");
@@ -536,7 +600,7 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
 #undef ARES_FUSED_CASE
     r.buf->mark_idle();  // read_result waited for the stream behind the last kernel that touches the workspace
     if (grouped && res.stale) {
-      grouped_note_write(device, prevKeys.DimValues, 5ull * nd * prevCapacity);
+      grouped_note_write(device, prevKeys.DimValues, slots.row_bytes() * prevCapacity);
       grouped = false;
       continue;
     }
@@ -545,11 +609,7 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
   if (res.overflow) {
     return -1;
   }
-  if (shape) {
-    std::lock_guard<std::mutex> lock(g_shapeMutex);
-    if (g_firstBatchGroups.size() > 4096) g_firstBatchGroups.clear();
-    g_firstBatchGroups[shape] = static_cast<int>(res.groups);
-  }
+  fused_note_first_batch(shape, static_cast<int>(res.groups));
   if (shape && !lean && !table) {
     // the next first batch of this shape takes the specialised kernels: have them built now (in the background)
     if (static_cast<int>(res.groups) >= lean_min_groups()) {
@@ -560,7 +620,7 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
     }
   }
   if (outRanges) {
-    GroupedState s{device, outKeys.DimValues, outValues, outCapacity, nd, mw, static_cast<int>(res.groups), partBits, outRangesRef};
+    GroupedState s{device, outKeys.DimValues, outValues, outCapacity, slots, mw, static_cast<int>(res.groups), partBits, outRangesRef};
     if (res.groups > 0) grouped_register(s);
   }
   return static_cast<int>(res.groups);
@@ -580,12 +640,15 @@ struct NotFusable : std::runtime_error {
 int fused_column(FusedPlanD &plan, const FastOperands &f, int maxCols, bool reuse) {
   if (reuse)
     for (int c = 0; c < plan.numCols; c++)
-      if (plan.cols[c].vals == f.vals && plan.cols[c].nulls == f.nulls && plan.cols[c].bitOff == f.bitOff) return c;
+      if (plan.cols[c].vals == f.vals && plan.cols[c].nulls == f.nulls && plan.cols[c].bitOff == f.bitOff &&
+          plan.cols[c].step == static_cast<uint32_t>(f.step ? f.step : 4))
+        return c;
   if (plan.numCols >= maxCols) throw NotFusable("too many distinct columns");
   FusedColumn &col = plan.cols[plan.numCols];
   col.vals = f.vals;
   col.nulls = f.nulls;
   col.bitOff = f.bitOff;
+  col.step = static_cast<uint32_t>(f.step ? f.step : 4);
   return plan.numCols++;
 }
 

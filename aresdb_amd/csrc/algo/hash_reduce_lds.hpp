@@ -27,6 +27,7 @@ struct FusedColumn {
   const uint32_t *vals;
   const uint8_t *nulls;
   uint32_t bitOff;
+  uint32_t step;  // bytes per stored value (FastOperands::step): 4, 2 or 1; 0 reads as 4
 };
 struct FusedExpr {
   FastOperands f;  // akind / arity / functor / I / rk / constant / divLike (pointers unused)
@@ -42,12 +43,32 @@ struct FusedPlanD {
   FusedExpr measure;
   int measureDtype, measureWidth;
   uint64_t identity;  // measure-transform identity of the aggregate (query/utils.hpp:169-184)
+  // bytes of dimension d's slot in the dimension vector, in vector (= descending width) order: 4, 2 or 1; 0 reads as 4.
+  // Plans with a narrow slot or a narrow column ("narrow plans") run on the kernels generated for their shape only
+  // (hr_rtc.hip); the precompiled generic kernels read 4-byte columns and write 4-byte slots.
+  uint8_t dimWidth[kFusedDims];
 };
+inline int fused_dim_width(const FusedPlanD &p, int d) { return p.dimWidth[d] ? p.dimWidth[d] : 4; }
+inline int fused_col_step(const FusedPlanD &p, int c) { return p.cols[c].step ? static_cast<int>(p.cols[c].step) : 4; }
+inline bool fused_plan_narrow(const FusedPlanD &p, int nd) {
+  for (int d = 0; d < nd; d++)
+    if (fused_dim_width(p, d) != 4) return true;
+  for (int c = 0; c < p.numCols; c++)
+    if (fused_col_step(p, c) != 4) return true;
+  return false;
+}
 
 // Column slots of a plan of ND dimensions: dimension d -> slot d, measure -> slot ND; a filter reuses
 // a slot that already holds its column or takes the one spare slot ND + 1.
+// Returns the number of groups; -1: a partition region overflowed (or a partition needs the generic multi-round merge and
+// the plan is narrow) — outputs may be partly written; kFusedUnavailable: declined before anything was launched (narrow
+// plan whose generated kernels are not loaded yet, previous results not grouped ...).  Either way the caller runs the
+// unfused sequence.  pendingShape (may be null): set when the call was declined because nothing is known about the shape's
+// cardinality — the caller reports the groups the unfused sequence found with fused_note_first_batch.
+constexpr int kFusedUnavailable = -2;
 int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, const DimensionVector &prevKeys,
                           const uint8_t *prevValues, int prevSize, const DimensionVector &outKeys, uint8_t *outValues,
-                          const AggSpec &a, hipStream_t stream);
+                          const AggSpec &a, hipStream_t stream, size_t *pendingShape = nullptr);
+void fused_note_first_batch(size_t shape, int groups);
 
 }  // namespace ares

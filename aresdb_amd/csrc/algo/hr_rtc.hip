@@ -53,6 +53,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <fstream>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <sstream>
@@ -269,6 +270,10 @@ const char *kPrelude =
     "struct __attribute__((packed, aligned(1))) PU16 { u16 v; };\n"
     "typedef u32 U4 __attribute__((ext_vector_type(4)));\n"
     "typedef U4 U4a __attribute__((aligned(4)));\n"
+    "struct __attribute__((packed, aligned(1))) PU32x2 { u32 v[2]; };\n"
+    "typedef u32 U2 __attribute__((ext_vector_type(2)));\n"
+    "typedef U2 U2a __attribute__((aligned(2)));\n"
+    "typedef u32 U1a __attribute__((aligned(1)));\n"
     "__device__ __forceinline__ u32 rotl(u32 x, int r) { return (x << r) | (x >> (32 - r)); }\n"
     "__device__ __forceinline__ u32 mix(u32 h, u32 k) { k *= 0xcc9e2d51u; k = rotl(k, 15) * 0x1b873593u; h ^= k; return TIMES5(rotl(h, 13)) + 0xe6546b64u; }\n";
 
@@ -783,12 +788,90 @@ static void kernel_body_table(std::ostringstream &o) {
 
 enum ScanKind { SCAN_LINES16 = 0, SCAN_COMPACT = 1, SCAN_TABLE = 2 };
 
+// ---- dimension slots of 1, 2 or 4 bytes -------------------------------------------------------------------
+// The dimension vector holds, for each dimension in descending width order, capacity x width value bytes, then one
+// validity byte vector per dimension (dim_layout.hpp); the row that is hashed is [values][validity bytes], every field
+// naturally aligned.  With the widths known when the source is written, the packed row becomes a list of 32-bit words,
+// each the OR of the fields that fall into it.
+struct SlotLayout {
+  int nd = 0, valueBytes = 0;
+  int width[kFusedDims] = {4, 4, 4, 4}, off[kFusedDims] = {0, 0, 0, 0};
+  bool all4 = true, ok = true;
+};
+SlotLayout slot_layout(const FusedPlanD &plan, int nd) {
+  SlotLayout L;
+  L.nd = nd;
+  int prev = 4;
+  for (int d = 0; d < nd && d < kFusedDims; d++) {
+    const int w = fused_dim_width(plan, d);
+    L.ok = L.ok && (w == 4 || w == 2 || w == 1) && w <= prev;  // descending: fields never straddle a word
+    prev = w;
+    L.width[d] = w;
+    L.off[d] = L.valueBytes;
+    L.valueBytes += w;
+    L.all4 = L.all4 && w == 4;
+  }
+  return L;
+}
+// murmur3_x86_32 (seed 0) of the packed row: `val(d)` names the dimension's value (already truncated to its width),
+// `okb(d)` its validity (0 / 1); writes the statements that leave the hash in `out`
+void gen_row_hash(std::ostringstream &o, const SlotLayout &L, const std::function<std::string(int)> &val,
+                  const std::function<std::string(int)> &okb, const std::string &out, const char *indent) {
+  const int total = L.valueBytes + L.nd, words = (total + 3) / 4;
+  std::vector<std::string> w(static_cast<size_t>(words));
+  auto add = [&](int byteOff, const std::string &e) {
+    std::string &x = w[static_cast<size_t>(byteOff / 4)];
+    const int sh = 8 * (byteOff % 4);
+    const std::string term = sh ? "(" + e + " << " + std::to_string(sh) + ")" : e;
+    x = x.empty() ? term : x + " | " + term;
+  };
+  for (int d = 0; d < L.nd; d++) add(L.off[d], val(d));
+  for (int d = 0; d < L.nd; d++) add(L.valueBytes + d, okb(d));
+  o << indent << "{\n" << indent << "  u32 g = 0u;\n";
+  for (int k = 0; k < total / 4; k++) o << indent << "  g = mix(g, " << w[static_cast<size_t>(k)] << ");\n";
+  if (total % 4) o << indent << "  { u32 k = (" << w[static_cast<size_t>(words - 1)] << ") * 0xcc9e2d51u; k = rotl(k, 15) * 0x1b873593u; g ^= k; }\n";
+  o << indent << "  g ^= " << total << "u; g ^= g >> 16; g *= 0x85ebca6bu; g ^= g >> 13; g *= 0xc2b2ae35u; g ^= g >> 16;\n"
+    << indent << "  " << out << " = g;\n" << indent << "}\n";
+}
+// mask that truncates a 32-bit value to a slot's width
+const char *width_mask(int w) { return w == 4 ? "" : w == 2 ? " & 0xFFFFu" : " & 0xFFu"; }
+// dimension d of row `row` of a dimension vector at `base` (capacity `cap`), zero-extended; and its validity byte
+std::string slot_load(const SlotLayout &L, int d, const char *base, const char *cap, const std::string &row) {
+  const std::string at = std::string(base) + " + (u64)" + std::to_string(L.off[d]) + " * " + cap + " + " + std::to_string(L.width[d]) + "ull * " + row;
+  return L.width[d] == 4 ? "*reinterpret_cast<const u32 *>(" + at + ")" : L.width[d] == 2 ? "(u32)*reinterpret_cast<const u16 *>(" + at + ")" : "(u32)*(" + at + ")";
+}
+std::string slot_store(const SlotLayout &L, int d, const char *base, const char *cap, const std::string &row, const std::string &v) {
+  const std::string at = std::string(base) + " + (u64)" + std::to_string(L.off[d]) + " * " + cap + " + " + std::to_string(L.width[d]) + "ull * " + row;
+  return L.width[d] == 4 ? "*reinterpret_cast<u32 *>(" + at + ") = " + v + ";" : L.width[d] == 2 ? "*reinterpret_cast<u16 *>(" + at + ") = (u16)(" + v + ");" : "*(" + at + ") = (u8)(" + v + ");";
+}
+// element `idx` of a source column of `step` bytes per value, widened to 32 bits (sign-extended for int kinds)
+std::string column_elem(int step, bool sgn, const std::string &base, const std::string &idx) {
+  if (step == 4) return base + "[" + idx + "]";
+  if (step == 2) return sgn ? "(u32)(i32)reinterpret_cast<const short *>(" + base + ")[" + idx + "]" : "(u32)reinterpret_cast<const u16 *>(" + base + ")[" + idx + "]";
+  return sgn ? "(u32)(i32)reinterpret_cast<const signed char *>(" + base + ")[" + idx + "]" : "(u32)reinterpret_cast<const u8 *>(" + base + ")[" + idx + "]";
+}
+// which column slot's stored kind is signed (decides the widening of a narrow column): the expressions that read it say
+bool column_signed(const FusedPlanD &plan, int nd, int c) {
+  for (int d = 0; d < nd; d++)
+    if (plan.dims[d].col == c) return plan.dims[d].f.akind == K_I32;
+  if (plan.measure.col == c) return plan.measure.f.akind == K_I32;
+  for (int k = 0; k < plan.numFilters && k < kFusedFilters; k++)
+    if (plan.filters[k].col == c) return plan.filters[k].f.akind == K_I32;
+  return false;
+}
+
 // the whole kernel source for `plan`; empty when the plan is outside the supported shapes.  `agg` / `widen`
 // are read for SCAN_TABLE only.
 std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t nullMask, ScanKind kind, const AggSpec *agg = nullptr,
                      const hr::Widen *widen = nullptr) {
   if (nd < 1 || nd > kFusedDims || plan.numCols > kFusedCols) return "";
   if (kind == SCAN_COMPACT && partBits < 3) return "";
+  const SlotLayout SL = slot_layout(plan, nd);
+  if (!SL.ok) return "";
+  for (int c = 0; c < plan.numCols; c++) {
+    const int st = fused_col_step(plan, c);
+    if (!(st == 4 || st == 2 || st == 1)) return "";
+  }
   std::ostringstream o;
   const int nc = plan.numCols;
   o << times5_text() << kPrelude << args_text()
@@ -801,6 +884,22 @@ std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t null
   o << "__device__ __forceinline__ u32 clampi(const Args &a, u32 i0) { const u32 lim = a.length >= 4 ? (u32)a.length - 4u : 0u; return i0 < lim ? i0 : lim; }\n";
   for (int c = 0; c < nc; c++) {
     o << "__device__ __forceinline__ void load_col" << c << "(Raw &r, const Args &a, u32 i0c) {\n";
+    const int step = fused_col_step(plan, c);
+    if (step != 4) {  // a quad of a 2- / 1-byte column is 8 / 4 bytes: one load, widened in registers (query/iterator.hpp:146-165)
+      const bool sgn = column_signed(plan, nd, c);
+      const char *ptr = step == 2 ? "reinterpret_cast<const u16 *>(a.vals[" : "reinterpret_cast<const u8 *>(a.vals[";
+      if (step == 2) {
+        if (nt_enabled()) o << "  const U2 t = __builtin_nontemporal_load(reinterpret_cast<const U2a *>(" << ptr << c << "]) + i0c));\n  const u32 t0 = t.x, t1 = t.y;\n";
+        else o << "  const PU32x2 t = *reinterpret_cast<const PU32x2 *>(" << ptr << c << "]) + i0c); const u32 t0 = t.v[0], t1 = t.v[1];\n";
+        if (sgn) o << "  r.v[" << c << "][0] = (u32)((i32)(t0 << 16) >> 16); r.v[" << c << "][1] = (u32)((i32)t0 >> 16); r.v[" << c << "][2] = (u32)((i32)(t1 << 16) >> 16); r.v[" << c << "][3] = (u32)((i32)t1 >> 16);\n";
+        else o << "  r.v[" << c << "][0] = t0 & 0xFFFFu; r.v[" << c << "][1] = t0 >> 16; r.v[" << c << "][2] = t1 & 0xFFFFu; r.v[" << c << "][3] = t1 >> 16;\n";
+      } else {
+        if (nt_enabled()) o << "  const u32 t0 = __builtin_nontemporal_load(reinterpret_cast<const U1a *>(" << ptr << c << "]) + i0c));\n";
+        else o << "  const u32 t0 = reinterpret_cast<const PU32 *>(" << ptr << c << "]) + i0c)->v;\n";
+        if (sgn) o << "  r.v[" << c << "][0] = (u32)((i32)(t0 << 24) >> 24); r.v[" << c << "][1] = (u32)((i32)(t0 << 16) >> 24); r.v[" << c << "][2] = (u32)((i32)(t0 << 8) >> 24); r.v[" << c << "][3] = (u32)((i32)t0 >> 24);\n";
+        else o << "  r.v[" << c << "][0] = t0 & 0xFFu; r.v[" << c << "][1] = (t0 >> 8) & 0xFFu; r.v[" << c << "][2] = (t0 >> 16) & 0xFFu; r.v[" << c << "][3] = t0 >> 24;\n";
+      }
+    } else
     if (nt_enabled())
       o << "  const U4 t = __builtin_nontemporal_load(reinterpret_cast<const U4a *>(a.vals[" << c << "] + i0c)); r.v[" << c << "][0] = t.x; r.v[" << c
         << "][1] = t.y; r.v[" << c << "][2] = t.z; r.v[" << c << "][3] = t.w;\n";
@@ -868,6 +967,7 @@ std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t null
       o << "  }\n";
       prefetch(nd);
     }
+    if (SL.all4) {
     o << "  u32 h[4] = {0u, 0u, 0u, 0u}, okbytes[4] = {0u, 0u, 0u, 0u};\n";
     for (int d = 0; d < nd; d++) {
       const FusedExpr &e = plan.dims[d];
@@ -885,6 +985,24 @@ std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t null
     else o << "    { u32 k = okbytes[j] * 0xcc9e2d51u; k = rotl(k, 15) * 0x1b873593u; g ^= k; }\n";
     o << "    g ^= " << 5 * nd << "u; g ^= g >> 16; g *= 0x85ebca6bu; g ^= g >> 13; g *= 0xc2b2ae35u; g ^= g >> 16;\n"
          "    hh[j] = g;\n  }\n}\n";
+    } else {
+      // narrow slots: the values are kept (truncated to their slot, as the dimension vector would hold them) until all
+      // are known, then the packed row's words are put together
+      for (int d = 0; d < nd; d++) o << "  u32 xv" << d << "[4], xo" << d << "[4];\n";
+      for (int d = 0; d < nd; d++) {
+        const FusedExpr &e = plan.dims[d];
+        if (e.col != d || !plain_store(e.f.rk, e.outKind) || (SL.width[d] != 4 && !int_kind(e.f.rk))) return "";
+        o << "#pragma unroll\n  for (int j = 0; j < 4; j++) {\n"
+             "    const u32 v = r.v[" << d << "][j]; const u32 okb = (okc[" << d << "] >> j) & 1u; u32 x;\n";
+        if (!gen_value(e.f, o, "v", "okb", "x", const_name(const_slot_dim(d)))) return "";
+        o << "    xv" << d << "[j] = x" << width_mask(SL.width[d]) << "; xo" << d << "[j] = okb;\n  }\n";
+        prefetch(d);
+      }
+      o << "#pragma unroll\n  for (int j = 0; j < 4; j++) {\n";
+      gen_row_hash(o, SL, [](int d) { return "xv" + std::to_string(d) + "[j]"; }, [](int d) { return "xo" + std::to_string(d) + "[j]"; },
+                   "hh[j]", "    ");
+      o << "  }\n}\n";
+    }
   }
   if (kind == SCAN_TABLE) {
     if (!agg || !widen || !gen_widen(o, *widen) || !gen_agg(o, *agg)) return "";
@@ -990,6 +1108,9 @@ struct RtcMergeArgs {  // mirrors `struct MArgs` of the generated source
   uint64_t *phases;  // ARES_HR_PHASES=1: per-partition time stamps (diagnostics)
   uint32_t k[kNumConsts];
   uint32_t pad;
+  const uint4 *recA;  // region A (read by kernels generated with `regionA` only)
+  const uint32_t *cursorsA;
+  uint64_t capA;
 };
 static_assert(sizeof(RtcMergeArgs) % 8 == 0, "MArgs is passed as one buffer");
 
@@ -997,17 +1118,22 @@ static_assert(sizeof(RtcMergeArgs) % 8 == 0, "MArgs is passed as one buffer");
 // source rows whose dimensions are re-evaluated from the plan's columns), 16-byte lines or — `compact` — compact
 // lines.  vectorVW = 4 / 8: records of the vector-sourced scan (the whole value travels; every row, old or new,
 // is a row of the input vectors).
+// regionA: the partition's records also come from region A — 16-byte {row, hash, value} records, what the TABLE-mode
+// scan emits (one per group and workgroup) — ahead of the region-B runs.
 std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w, int vectorVW = 0,
-                           bool compact = false) {
+                           bool compact = false, bool regionA = false) {
   if (nd < 1 || nd > kFusedDims) return "";
   if (compact && (vectorVW || partBits < 3)) return "";
   if (partBits < 2) return "";  // the 32-bit table keys need two spare hash bits (small inputs: the generic merge)
+  const SlotLayout SL = slot_layout(plan, nd);
+  if (!SL.ok || (vectorVW && !SL.all4)) return "";
   std::ostringstream o;
   o << times5_text() << kPrelude
     << "struct MArgs { const u32 *vals[" << kFusedCols << "]; const u8 *nulls[" << kFusedCols << "]; const u32 *recB; const u32 *countsB;\n"
        "  const u32 *prevRanges; const u8 *prevDims; const u8 *prevValues; u8 *dimOut; u8 *outValues; u32 *outCount; u32 *outRanges;\n"
-       "  u64 prevCapacity, outCapacity; u32 bitOff[" << kFusedCols << "]; u32 capB, streams, prevSize, chunkRows; u64 *phases; u32 k[" << kNumConsts << "]; u32 pad; };\n"
-       "#define ND " << nd << "\n#define PB " << partBits << "\n#define NP " << (1 << partBits) << "\n"
+       "  u64 prevCapacity, outCapacity; u32 bitOff[" << kFusedCols << "]; u32 capB, streams, prevSize, chunkRows; u64 *phases; u32 k[" << kNumConsts << "]; u32 pad;\n"
+       "  const uint4 *recA; const u32 *cursorsA; u64 capA; };\n"
+       "#define ND " << nd << "\n#define VB " << SL.valueBytes << "\n#define PB " << partBits << "\n#define NP " << (1 << partBits) << "\n"
        "#define SLOTS " << hr::kSlots << "\n#define LIMIT " << hr::kMergeLimit << "u\n#define RANGEWORDS " << hr::kRangeWords
     << "\n#define MAXRANGES " << hr::kMaxRanges << "u\n"
        // Table keys are 32 bits: within a partition the top PB bits of every hash are the partition's number, so a
@@ -1148,9 +1274,9 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
   if (!vectorVW) o << "__device__ __forceinline__ void eval_row(const MArgs &a, u32 row, u32 (&bits)[ND], u32 (&ok)[ND]) {\n";
   for (int d = 0; d < nd && !vectorVW; d++) {
     const FusedExpr &e = plan.dims[d];
-    if (!plain_store(e.f.rk, e.outKind)) return "";
+    if (!plain_store(e.f.rk, e.outKind) || (SL.width[d] != 4 && !int_kind(e.f.rk))) return "";
     const int c = e.col;
-    o << "  {\n    const u32 v = a.vals[" << c << "][row];\n";
+    o << "  {\n    const u32 v = " << column_elem(fused_col_step(plan, c), e.f.akind == K_I32, "a.vals[" + std::to_string(c) + "]", "row") << ";\n";
     if (plan.cols[c].nulls) o << "    const u32 bit = row + a.bitOff[" << c << "]; const u32 okb = (a.nulls[" << c << "][bit >> 3] >> (bit & 7u)) & 1u;\n";
     else o << "    const u32 okb = 1u;\n";
     o << "    u32 x;\n";
@@ -1179,7 +1305,7 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
        "  STAMP(1)\n"
        // previous groups of this partition (always the lowest row indices: they stay the representatives)
        "  {\n"
-       "    const u8 *nullsIn = a.prevDims + (u64)(4 * ND) * a.prevCapacity;\n"
+       "    const u8 *nullsIn = a.prevDims + (u64)VB * a.prevCapacity;\n"
        "    for (u32 r = 0u; r < nRanges; r++) {\n"
        "      const u32 start = ranges[1u + 2u * r], cnt = ranges[2u + 2u * r];\n"
        "      for (u32 i0 = 0u; i0 < cnt; i0 += 4096u) {\n"  // four groups per lane: their loads are in flight together
@@ -1192,15 +1318,24 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
        "          rr[k] = row;\n"
        "          okk[k] = okk[k] && row < a.prevSize;\n"
        "          const u32 safe = row < a.prevSize ? row : 0u;\n"
-       "          u32 h = 0u, okbytes = 0u;\n"
-       "#pragma unroll\n"
-       "          for (int d = 0; d < ND; d++) {\n"
-       "            h = mix(h, *reinterpret_cast<const u32 *>(a.prevDims + (u64)(4 * d) * a.prevCapacity + 4ull * safe));\n"
-       "            okbytes |= (u32)nullsIn[(u64)d * a.prevCapacity + safe] << (8 * d);\n"
-       "          }\n";
-  if (nd == 4) o << "          h = mix(h, okbytes);\n";
-  else o << "          { u32 kk = okbytes * 0xcc9e2d51u; kk = rotl(kk, 15) * 0x1b873593u; h ^= kk; }\n";
-  o << "          h ^= " << 5 * nd << "u; h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;\n"
+       "          u32 h = 0u;\n";
+  if (SL.all4) {
+    o << "          u32 okbytes = 0u;\n"
+         "#pragma unroll\n"
+         "          for (int d = 0; d < ND; d++) {\n"
+         "            h = mix(h, *reinterpret_cast<const u32 *>(a.prevDims + (u64)(4 * d) * a.prevCapacity + 4ull * safe));\n"
+         "            okbytes |= (u32)nullsIn[(u64)d * a.prevCapacity + safe] << (8 * d);\n"
+         "          }\n";
+    if (nd == 4) o << "          h = mix(h, okbytes);\n";
+    else o << "          { u32 kk = okbytes * 0xcc9e2d51u; kk = rotl(kk, 15) * 0x1b873593u; h ^= kk; }\n";
+    o << "          h ^= " << 5 * nd << "u; h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;\n";
+  } else {
+    for (int d = 0; d < nd; d++)
+      o << "          const u32 pv" << d << " = " << slot_load(SL, d, "a.prevDims", "a.prevCapacity", "safe") << ", po" << d
+        << " = (u32)nullsIn[(u64)" << d << " * a.prevCapacity + safe];\n";
+    gen_row_hash(o, SL, [](int d) { return "pv" + std::to_string(d); }, [](int d) { return "po" + std::to_string(d); }, "h", "          ");
+  }
+  o <<
        "          hh[k] = h;\n"
     << (wide ? "          vv[k] = reinterpret_cast<const u64 *>(a.prevValues)[safe];\n"
              : "          vv[k] = reinterpret_cast<const u32 *>(a.prevValues)[safe];\n")
@@ -1216,8 +1351,19 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
        "    }\n"
        "  }\n"
        "  __syncthreads();\n"
-       "  STAMP(2)\n"
-       // the partition's runs: every wavefront streams whole runs, three register stages
+       "  STAMP(2)\n";
+  if (regionA)  // what the TABLE-mode scan left in region A: one record per group and scanning workgroup
+    o << "  {\n"
+         "    const u32 cur = a.cursorsA[p];\n"
+         "    const u32 nA = cur < a.capA ? cur : (u32)a.capA;\n"
+         "    const uint4 *recs = a.recA + (u64)p * a.capA;\n"
+         "    for (u32 i = tid; i < nA; i += 1024u) {\n"
+         "      const uint4 r = recs[i];\n"
+         "      insert(sKeys, sRows, sVals, &sClaimed, &sOverflow, r.x, r.y, ((u64)r.w << 32) | r.z, true);\n"
+         "    }\n"
+         "  }\n"
+         "  __syncthreads();\n";
+  o << // the partition's runs: every wavefront streams whole runs, three register stages
        "  if (G > 0u) {\n"
        "    const uint4 *dummy = reinterpret_cast<const uint4 *>(a.recB);\n"
        "    u32 j = 0u, off = 0u, qn = 0u;\n"
@@ -1303,8 +1449,8 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
        "  __syncthreads();\n"
        "  STAMP(4)\n"
        "  if (!total) return;\n"
-       "  const u8 *nullsIn = a.prevDims + (u64)(4 * ND) * a.prevCapacity;\n"
-       "  u8 *nullsOut = a.dimOut + (u64)(4 * ND) * a.outCapacity;\n"
+       "  const u8 *nullsIn = a.prevDims + (u64)VB * a.prevCapacity;\n"
+       "  u8 *nullsOut = a.dimOut + (u64)VB * a.outCapacity;\n"
        "#pragma unroll\n"
        "  for (int half = 0; half < 2; half++) {\n"
        "    u32 dv[4][ND], nv[4][ND], at[4]; bool has[4];\n"
@@ -1319,23 +1465,35 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
        "      at[kk] = sBase + waveBase + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));\n"
        "      if (!has[kk]) continue;\n"
        "      const u32 row = sRows[s];\n"
-    << (vectorVW ? "" : "      if (row >= a.prevSize) { eval_row(a, row - a.prevSize, dv[kk], nv[kk]); continue; }\n")
-    << "#pragma unroll\n"
-       "      for (int d = 0; d < ND; d++) {\n"
-       "        dv[kk][d] = *reinterpret_cast<const u32 *>(a.prevDims + (u64)(4 * d) * a.prevCapacity + 4ull * row);\n"
-       "        nv[kk][d] = nullsIn[(u64)d * a.prevCapacity + row];\n"
-       "      }\n"
-       "    }\n"
+    << (vectorVW ? "" : "      if (row >= a.prevSize) { eval_row(a, row - a.prevSize, dv[kk], nv[kk]); continue; }\n");
+  if (SL.all4) {
+    o << "#pragma unroll\n"
+         "      for (int d = 0; d < ND; d++) {\n"
+         "        dv[kk][d] = *reinterpret_cast<const u32 *>(a.prevDims + (u64)(4 * d) * a.prevCapacity + 4ull * row);\n"
+         "        nv[kk][d] = nullsIn[(u64)d * a.prevCapacity + row];\n"
+         "      }\n";
+  } else {
+    for (int d = 0; d < nd; d++)
+      o << "      dv[kk][" << d << "] = " << slot_load(SL, d, "a.prevDims", "a.prevCapacity", "row") << "; nv[kk][" << d << "] = nullsIn[(u64)" << d
+        << " * a.prevCapacity + row];\n";
+  }
+  o << "    }\n"
        "#pragma unroll\n"
        "    for (int kk = 0; kk < 4; kk++) {\n"
        "      if (!has[kk]) continue;\n"
-       "      const u32 s = tid + (u32)(half * 4 + kk) * 1024u;\n"
-       "#pragma unroll\n"
-       "      for (int d = 0; d < ND; d++) {\n"
-       "        *reinterpret_cast<u32 *>(a.dimOut + (u64)(4 * d) * a.outCapacity + 4ull * at[kk]) = dv[kk][d];\n"
-       "        nullsOut[(u64)d * a.outCapacity + at[kk]] = (u8)nv[kk][d];\n"
-       "      }\n"
-    << (wide ? "      reinterpret_cast<u64 *>(a.outValues)[at[kk]] = sVals[s];\n"
+       "      const u32 s = tid + (u32)(half * 4 + kk) * 1024u;\n";
+  if (SL.all4) {
+    o << "#pragma unroll\n"
+         "      for (int d = 0; d < ND; d++) {\n"
+         "        *reinterpret_cast<u32 *>(a.dimOut + (u64)(4 * d) * a.outCapacity + 4ull * at[kk]) = dv[kk][d];\n"
+         "        nullsOut[(u64)d * a.outCapacity + at[kk]] = (u8)nv[kk][d];\n"
+         "      }\n";
+  } else {
+    for (int d = 0; d < nd; d++)
+      o << "      " << slot_store(SL, d, "a.dimOut", "a.outCapacity", "at[kk]", "dv[kk][" + std::to_string(d) + "]") << " nullsOut[(u64)" << d
+        << " * a.outCapacity + at[kk]] = (u8)nv[kk][" << d << "];\n";
+  }
+  o << (wide ? "      reinterpret_cast<u64 *>(a.outValues)[at[kk]] = sVals[s];\n"
              : "      reinterpret_cast<u32 *>(a.outValues)[at[kk]] = (u32)sVals[s];\n")
     << "    }\n"
        "  }\n"
@@ -1835,6 +1993,8 @@ std::string shape_key(char tag, int device, const FusedPlanD &plan, int nd, int 
   const unsigned opt = scan_opt();
   const uint32_t nm = null_mask(plan);
   put(k, opt); put(k, nm); put(k, plan.numCols); put(k, plan.numFilters);
+  for (int c = 0; c < plan.numCols && c < kFusedCols; c++) { const int st = fused_col_step(plan, c); put(k, st); }
+  for (int d = 0; d < nd && d < kFusedDims; d++) { const int wd = fused_dim_width(plan, d); put(k, wd); }
   for (int i = 0; i < plan.numFilters && i < kFusedFilters; i++) put_expr(k, plan.filters[i]);
   for (int d = 0; d < nd && d < kFusedDims; d++) put_expr(k, plan.dims[d]);
   put_expr(k, plan.measure);
@@ -1926,10 +2086,10 @@ std::string rtc_vector_merge_source(int nd, int vw, int partBits, const AggSpec 
 }
 
 RtcKernel rtc_merge_lookup(int device, const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w, bool compact,
-                           bool wait) {
+                           bool wait, bool regionA) {
   if (!rtc_api().ok) return nullptr;
-  return front_lookup(shape_key('m', device, plan, nd, partBits, compact ? 1 : 0, &a, &w), device,
-                      [&] { return generate_merge(plan, nd, partBits, a, w, 0, compact); }, "hr_merge_rtc", wait);
+  return front_lookup(shape_key('m', device, plan, nd, partBits, (compact ? 1 : 0) | (regionA ? 2 : 0), &a, &w), device,
+                      [&] { return generate_merge(plan, nd, partBits, a, w, 0, compact, regionA); }, "hr_merge_rtc", wait);
 }
 
 void rtc_merge_launch(const RtcKernel &kernel, const FusedPlanD &plan, const uint8_t *prevDims, size_t prevCapacity, const uint8_t *prevValues,
@@ -1955,6 +2115,9 @@ void rtc_merge_launch(const RtcKernel &kernel, const FusedPlanD &plan, const uin
   args.prevCapacity = prevCapacity;
   args.outCapacity = outCapacity;
   args.capB = ws.capB;
+  args.recA = ws.recA;
+  args.cursorsA = ws.cursorsA;
+  args.capA = ws.capA;
   args.streams = static_cast<uint32_t>(ws.streams);
   args.prevSize = prevSize;
   args.chunkRows = ws.chunkRows;
@@ -1993,8 +2156,8 @@ void rtc_merge_launch(const RtcKernel &kernel, const FusedPlanD &plan, const uin
   }
 }
 
-std::string rtc_merge_source(const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w, bool compact) {
-  return generate_merge(plan, nd, partBits, a, w, 0, compact);
+std::string rtc_merge_source(const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w, bool compact, bool regionA) {
+  return generate_merge(plan, nd, partBits, a, w, 0, compact, regionA);
 }
 
 // source text of the kernel a plan would get (tests / tools; empty = unsupported shape)

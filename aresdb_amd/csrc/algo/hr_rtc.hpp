@@ -55,8 +55,9 @@ void rtc_vector_scan_launch(const RtcKernel &kernel, const uint8_t *dimValues, s
 // The specialised merge for what the DIRECT scans produce (line records in region B, previous groups in their
 // partition-grouped ranges or none, one round over the whole hash range).  It raises outCount[3] when a
 // partition holds more groups than one LDS table: the caller then runs the generic merge.
+// regionA: the records come from region A as well (TABLE-mode scans) — the merge of narrow plans' low-cardinality batches.
 RtcKernel rtc_merge_lookup(int device, const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w, bool compact,
-                           bool wait = false);
+                           bool wait = false, bool regionA = false);
 void rtc_merge_launch(const RtcKernel &kernel, const FusedPlanD &plan, const uint8_t *prevDims, size_t prevCapacity,
                       const uint8_t *prevValues, uint32_t prevSize, uint8_t *dimOut, size_t outCapacity, uint8_t *outValues,
                       const hr::Workspace &ws, hipStream_t stream);
@@ -67,7 +68,8 @@ RtcKernel rtc_vector_merge_lookup(int device, int nd, int vw, int partBits, cons
 // the generated sources (empty = unsupported shape); for tools and tests
 std::string rtc_scan_source(const FusedPlanD &plan, int nd, int partBits, bool compact = false);
 std::string rtc_table_scan_source(const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w);
-std::string rtc_merge_source(const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w, bool compact = false);
+std::string rtc_merge_source(const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w, bool compact = false,
+                             bool regionA = false);
 std::string rtc_vector_scan_source(int nd, int vw, int partBits);
 std::string rtc_vector_merge_source(int nd, int vw, int partBits, const AggSpec &a);
 

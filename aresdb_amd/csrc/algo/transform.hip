@@ -27,6 +27,7 @@
 #include "binding.hpp"
 #include "common.hpp"
 #include "device_model.hpp"
+#include "dim_layout.hpp"
 #include "fast_eval.hpp"
 #include "hash_reduce_lds.hpp"
 #include "lookback.hpp"
@@ -538,13 +539,39 @@ __device__ __forceinline__ void load_rows(const uint32_t *idx, int pad, int64_t 
   }
 }
 
+struct __attribute__((packed, aligned(1))) PU32x2 { uint32_t v[2]; };
+struct __attribute__((packed, aligned(1))) PU32s1 { uint32_t v; };
 template <int QUADS>
 __device__ __forceinline__ void issue_values(const FastOperands &f, const uint32_t (&rows)[QUADS][4], uint32_t (&vals)[QUADS][4],
                                              uint32_t (&window)[QUADS]) {
 #pragma unroll
   for (int q = 0; q < QUADS; q++) {
     const uint32_t r0 = rows[q][0];
-    if (rows[q][1] == r0 + 1 && rows[q][2] == r0 + 2 && rows[q][3] == r0 + 3) {
+    if (f.step == 2) {  // Int16 / Uint16 / BigEnum: 8 bytes hold the four rows of a consecutive quad (wave-uniform branch)
+      const uint16_t *v16 = reinterpret_cast<const uint16_t *>(f.vals);
+      uint32_t raw[4];
+      if (rows[q][1] == r0 + 1 && rows[q][2] == r0 + 2 && rows[q][3] == r0 + 3) {
+        const PU32x2 v = *reinterpret_cast<const PU32x2 *>(v16 + r0);
+        raw[0] = v.v[0] & 0xFFFFu; raw[1] = v.v[0] >> 16; raw[2] = v.v[1] & 0xFFFFu; raw[3] = v.v[1] >> 16;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) raw[j] = v16[rows[q][j]];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) vals[q][j] = f.akind == K_I32 ? static_cast<uint32_t>(static_cast<int32_t>(static_cast<int16_t>(raw[j]))) : raw[j];
+    } else if (f.step == 1) {  // Int8 / Uint8 / SmallEnum
+      const uint8_t *v8 = reinterpret_cast<const uint8_t *>(f.vals);
+      uint32_t raw[4];
+      if (rows[q][1] == r0 + 1 && rows[q][2] == r0 + 2 && rows[q][3] == r0 + 3) {
+        const uint32_t v = reinterpret_cast<const PU32s1 *>(v8 + r0)->v;
+        raw[0] = v & 0xFFu; raw[1] = (v >> 8) & 0xFFu; raw[2] = (v >> 16) & 0xFFu; raw[3] = v >> 24;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) raw[j] = v8[rows[q][j]];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) vals[q][j] = f.akind == K_I32 ? static_cast<uint32_t>(static_cast<int32_t>(static_cast<int8_t>(raw[j]))) : raw[j];
+    } else if (rows[q][1] == r0 + 1 && rows[q][2] == r0 + 2 && rows[q][3] == r0 + 3) {
       if (f.debug & 128) {  // streaming loads for a column that is read once (set by run_filter_rows)
         typedef uint32_t V4 __attribute__((ext_vector_type(4)));
         typedef V4 V4a __attribute__((aligned(4)));
@@ -672,6 +699,22 @@ __device__ __forceinline__ void store_tile(const FastOperands &f, const SinkD &s
         }
         *reinterpret_cast<U32x4 *>(s.values + static_cast<size_t>(4) * i0) = o;
       }
+    } else if (s.width < 4) {  // 1- / 2-byte dimension slot (integer kinds only, see fast_sink): the value truncated, as store_typed32
+      uint32_t nb = 0, lo = 0, hi = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) nb |= (r[j].ok ? 1u : 0u) << (8 * j);
+      if (s.width == 2) {
+        lo = (r[0].bits & 0xFFFFu) | (r[1].bits << 16);
+        hi = (r[2].bits & 0xFFFFu) | (r[3].bits << 16);
+        PU32x2 o;
+        o.v[0] = lo; o.v[1] = hi;
+        *reinterpret_cast<PU32x2 *>(s.values + static_cast<size_t>(2) * i0) = o;
+      } else {
+        lo = (r[0].bits & 0xFFu) | ((r[1].bits & 0xFFu) << 8) | ((r[2].bits & 0xFFu) << 16) | (r[3].bits << 24);
+        reinterpret_cast<PU32s *>(s.values + i0)->v = lo;
+      }
+      if (ALIGNED_NULLS) *reinterpret_cast<uint32_t *>(s.nulls + i0) = nb;
+      else reinterpret_cast<PU32s *>(s.nulls + i0)->v = nb;
     } else {  // 4-byte dimension / scratch value + one validity byte per row
       const int ok_kind = s.dtype == Int32 ? K_I32 : s.dtype == Uint32 ? K_U32 : K_F32;
       U32x4 o;
@@ -1577,7 +1620,7 @@ bool compaction_touches(const PendingCompact &c, const ByteRange &r) {
     bool hit = ri.overlaps(r);
     for (const LazyFilter &L : c.todo) {
       const ByteRange rp{L.pred, L.pred + L.rowsBefore};
-      const ByteRange rv{reinterpret_cast<const uint8_t *>(L.f.vals), reinterpret_cast<const uint8_t *>(L.f.vals) + 4ull * L.colRows};
+      const ByteRange rv{reinterpret_cast<const uint8_t *>(L.f.vals), reinterpret_cast<const uint8_t *>(L.f.vals) + fast_value_bytes(L.f, L.colRows)};
       hit = hit || rp.overlaps(r) || rv.overlaps(r);
       if (L.f.nulls) {
         const ByteRange rn{L.f.nulls, L.f.nulls + (static_cast<uint64_t>(L.colRows) + L.f.bitOff + 7) / 8 + 2};
@@ -1606,7 +1649,7 @@ void transform_self_check(hipStream_t stream, const PendingQueue &q) {
   for (int j = 0; j < q.jobs.count; j++) {
     const FastOperands &f = q.jobs.f[j];
     const SinkD &sk = q.jobs.s[j];
-    if (f.arity != 1 || sk.type == SINK_MEASURE || sk.width != 4 || !sk.nulls || f.akind == K_F32 || f.I == K_F32) continue;
+    if (f.arity != 1 || sk.type == SINK_MEASURE || sk.width != 4 || f.step != 4 || !sk.nulls || f.akind == K_F32 || f.I == K_F32) continue;
     const size_t rows = q.colRows[j], nb = f.nulls ? (rows + f.bitOff + 7) / 8 : 0;
     vals.resize(rows); vals2.resize(rows); nulls.resize(nb); nulls2.resize(nb);
     (void)hipMemcpyAsync(vals.data(), f.vals, 4 * rows, hipMemcpyDeviceToHost, stream);
@@ -2066,7 +2109,7 @@ static bool defer_transform(int device, hipStream_t stream, const FastOperands &
   DeferLock lock(device);
   // everything pending on OTHER streams of the device is unrelated; only this stream's queue matters
   PendingQueue &q = t_state->pending[{device, stream}];
-  ByteRange rv{reinterpret_cast<const uint8_t *>(f.vals), reinterpret_cast<const uint8_t *>(f.vals) + 4ull * colRows};
+  ByteRange rv{reinterpret_cast<const uint8_t *>(f.vals), reinterpret_cast<const uint8_t *>(f.vals) + fast_value_bytes(f, colRows)};
   ByteRange rn{f.nulls, f.nulls ? f.nulls + (static_cast<uint64_t>(colRows) + f.bitOff + 7) / 8 + 2 : f.nulls};
   ByteRange ri{reinterpret_cast<const uint8_t *>(f.idx), reinterpret_cast<const uint8_t *>(f.idx) + (f.idx ? 4ull * n : 0)};
   ByteRange wv{s.values, s.values + static_cast<uint64_t>(s.width) * n};
@@ -2094,7 +2137,9 @@ static bool defer_transform(int device, hipStream_t stream, const FastOperands &
 static bool fast_sink(const SinkD &s) {
   const bool four = s.dtype == Int32 || s.dtype == Uint32 || s.dtype == Float32;
   if (s.type == SINK_MEASURE) return s.agg != AGGR_AVG_FLOAT && s.baseCounts == nullptr;
-  return (s.type == SINK_DIM || s.type == SINK_SCRATCH) && four;
+  // 1- / 2-byte dimension slots (city_id Uint16, status SmallEnum: query/common/dim_util.go:9-12) take integer results
+  const bool narrow = s.type == SINK_DIM && (s.dtype == Int8 || s.dtype == Uint8 || s.dtype == Int16 || s.dtype == Uint16);
+  return ((s.type == SINK_DIM || s.type == SINK_SCRATCH) && four) || narrow;
 }
 
 // Binds an array column and its functor (query/binder.hpp:385-426, :458-560): the second operand
@@ -2256,7 +2301,8 @@ static int run_transform(const InputVector *ins, int arity, const OutputVector &
   retire_fills_for_write(device, s.values, static_cast<size_t>(s.width) * n);
   if (s.nulls) retire_fills_for_write(device, s.nulls, static_cast<size_t>(n));
   FastOperands f;
-  const bool fast = fast_sink(s) && fast_operands(p, f, false);
+  bool fast = fast_sink(s) && fast_operands(p, f, false);
+  if (fast && s.type == SINK_DIM && s.width < 4 && !(f.rk == K_I32 || f.rk == K_U32)) fast = false;  // float -> narrow integer: generic kernel
   if (fast && f.idx && virtual_iota(device, indexVector, n, false)) f.idx = nullptr;  // rows = position
   // root outputs of the hot shape are held back and fused with their siblings (same index vector)
   if (fast && (s.type == SINK_DIM || s.type == SINK_MEASURE) && defer_transform(device, stream, f, s, n, p.a.length)) return n;
@@ -2344,7 +2390,7 @@ struct FilterCheck {
     if (f.nulls) (void)hipMemcpyAsync(b->hNulls[k], f.nulls, nullBytes, hipMemcpyDeviceToHost, stream);
   }
   void begin(const FastOperands &fo, uint32_t rows, int n_, int tiles_, int predGrid_, const uint8_t *pred_, hipStream_t s) {
-    if (!filter_check_path() || n_ > FilterCheckBuffers::kMaxRows || rows > static_cast<uint32_t>(FilterCheckBuffers::kMaxRows)) return;
+    if (!filter_check_path() || fo.step != 4 || n_ > FilterCheckBuffers::kMaxRows || rows > static_cast<uint32_t>(FilterCheckBuffers::kMaxRows)) return;
     thread_local FilterCheckBuffers bufs;
     if (!bufs.ok) return;
     b = &bufs;
@@ -2846,7 +2892,7 @@ bool journal_touched(const uint32_t *indexVector, const FilterJournal &j, const 
   bool cols = false;
   for (size_t k = 0; k < j.filters.size(); k++) {
     const FastOperands &f = j.filters[k];
-    cols = cols || range_of(f.vals, 4ull * j.colRows[k]).overlaps(r);
+    cols = cols || range_of(f.vals, fast_value_bytes(f, j.colRows[k])).overlaps(r);
     if (f.nulls) cols = cols || range_of(f.nulls, (static_cast<uint64_t>(j.colRows[k]) + f.bitOff + 7) / 8 + 2).overlaps(r);
   }
   if (indexOnly) *indexOnly = idx && !cols;
@@ -2890,7 +2936,7 @@ void hook_on_wait(int device, void *streamPtr) {
         if (keep)  // the filters' columns are inputs of the pending work from now on
           for (size_t k = 0; k < j->second.filters.size(); k++) {
             const FastOperands &f = j->second.filters[k];
-            q.reads.push_back(range_of(f.vals, 4ull * j->second.colRows[k]));
+            q.reads.push_back(range_of(f.vals, fast_value_bytes(f, j->second.colRows[k])));
             if (f.nulls) q.reads.push_back(range_of(f.nulls, (static_cast<uint64_t>(j->second.colRows[k]) + f.bitOff + 7) / 8 + 2));
           }
       }
@@ -3122,7 +3168,8 @@ void launch_pending_writers(int device, const void *ptr, size_t bytes) {
 // ordinary path (whatever was pending has been launched, in stream order).
 bool fuse_pending_into_hash_reduce(int device, hipStream_t stream, const DimensionVector &in, const uint8_t *inValues,
                                    const DimensionVector &out, uint8_t *outValues, int valueBytes, int length, int aggFunc,
-                                   int *groups) {
+                                   int *groups, size_t *pendingShape) {
+  if (pendingShape) *pendingShape = 0;
   if (!fuse_available()) return false;
   const bool forcedGlobal = global_table_forced();
   PendingQueue q;
@@ -3136,10 +3183,14 @@ bool fuse_pending_into_hash_reduce(int device, hipStream_t stream, const Dimensi
     if (it == t_state->pending.end() || it->second.jobs.count == 0) return false;
     PendingQueue &pq = it->second;
     bool ok = !forcedGlobal;
-    nd = in.NumDimsPerDimWidth[2];
+    // dimension slots of 4, 2 or 1 bytes, in the vector's (descending width) order
+    nd = in.NumDimsPerDimWidth[2] + in.NumDimsPerDimWidth[3] + in.NumDimsPerDimWidth[4];
     for (int k = 0; k < NUM_DIM_WIDTH; k++)
-      ok = ok && in.NumDimsPerDimWidth[k] == (k == 2 ? nd : 0) && out.NumDimsPerDimWidth[k] == in.NumDimsPerDimWidth[k];
+      ok = ok && (k >= 2 || in.NumDimsPerDimWidth[k] == 0) && out.NumDimsPerDimWidth[k] == in.NumDimsPerDimWidth[k];
     ok = ok && nd >= 1 && nd <= kFusedDims && pq.jobs.count == nd + 1;
+    DimLayoutD L;
+    memset(&L, 0, sizeof(L));
+    if (ok) L = make_dim_layout(in.NumDimsPerDimWidth);
     prev = length - pq.n;
     ok = ok && prev >= 0 && pq.n > 0;
     if (ok) {
@@ -3174,15 +3225,17 @@ bool fuse_pending_into_hash_reduce(int device, hipStream_t stream, const Dimensi
       } else {
         int d = -1;
         for (int c = 0; c < nd; c++)
-          if (s.values == in.DimValues + 4 * cap * c + 4ull * prev && s.nulls == in.DimValues + 4 * cap * nd + cap * c + prev) d = c;
-        ok = ok && s.type == SINK_DIM && d >= 0 && dimJob[d] < 0 && s.width == 4;
+          if (s.values == in.DimValues + static_cast<size_t>(L.valueOff[c]) * cap + static_cast<size_t>(L.width[c]) * prev &&
+              s.nulls == in.DimValues + static_cast<size_t>(L.valueBytes) * cap + cap * c + prev && s.width == L.width[c])
+            d = c;
+        ok = ok && s.type == SINK_DIM && d >= 0 && dimJob[d] < 0;
         if (ok) dimJob[d] = k;
       }
     }
     ok = ok && measureJob >= 0;
     for (int c = 0; ok && c < nd; c++) ok = dimJob[c] >= 0;
     if (ok) {
-      auto column_of = [](const FastOperands &f) { return FusedColumn{f.vals, f.nulls, f.bitOff}; };
+      auto column_of = [](const FastOperands &f) { return FusedColumn{f.vals, f.nulls, f.bitOff, static_cast<uint32_t>(f.step ? f.step : 4)}; };
       auto strip = [](FastOperands f) {
         f.vals = nullptr;
         f.nulls = nullptr;
@@ -3190,13 +3243,14 @@ bool fuse_pending_into_hash_reduce(int device, hipStream_t stream, const Dimensi
         f.pad = 0;
         return f;
       };
-      auto kind_of = [](int dtype) { return dtype == Int32 ? K_I32 : dtype == Uint32 ? K_U32 : K_F32; };
+      auto kind_of = [](int dtype) { return (dtype == Int32 || dtype == Int16 || dtype == Int8) ? K_I32 : (dtype == Uint32 || dtype == Uint16 || dtype == Uint8) ? K_U32 : K_F32; };
       for (int c = 0; c < nd; c++) {
         const int k = dimJob[c];
         plan.cols[c] = column_of(pq.jobs.f[k]);
         plan.dims[c].f = strip(pq.jobs.f[k]);
         plan.dims[c].col = c;
         plan.dims[c].outKind = kind_of(pq.jobs.s[k].dtype);
+        plan.dimWidth[c] = L.width[c];
       }
       plan.cols[nd] = column_of(pq.jobs.f[measureJob]);
       plan.measure.f = strip(pq.jobs.f[measureJob]);
@@ -3214,7 +3268,9 @@ bool fuse_pending_into_hash_reduce(int device, hipStream_t stream, const Dimensi
           ok = journal->colRows[k] >= static_cast<uint32_t>(n0);
           int col = -1;
           for (int c = 0; c < plan.numCols; c++)
-            if (plan.cols[c].vals == f.vals && plan.cols[c].nulls == f.nulls && plan.cols[c].bitOff == f.bitOff) col = c;
+            if (plan.cols[c].vals == f.vals && plan.cols[c].nulls == f.nulls && plan.cols[c].bitOff == f.bitOff &&
+                plan.cols[c].step == static_cast<uint32_t>(f.step ? f.step : 4))
+              col = c;
           if (col < 0 && plan.numCols < nd + 2) {
             col = plan.numCols++;
             plan.cols[col] = column_of(f);
@@ -3240,9 +3296,9 @@ bool fuse_pending_into_hash_reduce(int device, hipStream_t stream, const Dimensi
     if (q.idx) t_state->journals.erase(q.idx);
   }
   DimensionVector prevKeys = in;
-  const int result = fused_hash_reduce_run(device, plan, n0, prevKeys, inValues, prev, out, outValues, a, stream);
+  const int result = fused_hash_reduce_run(device, plan, n0, prevKeys, inValues, prev, out, outValues, a, stream, pendingShape);
   DeferLock lock(device);
-  if (result < 0) {  // a partition region overflowed: materialise the inputs after all
+  if (result < 0) {  // a partition region overflowed, or the call was declined: materialise the inputs after all
     launch_queue(stream, q, /*inOrder=*/true);
     lock.unlock();
     g_releaseHeld(device, hold_tag(stream));

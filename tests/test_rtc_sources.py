@@ -23,7 +23,9 @@ def test_generated_kernels_compile_for_gfx950(tmp_path):
     out = subprocess.run([str(exe), str(tmp_path / "k")], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     for what in ("scan", "merge", "compact scan", "compact merge", "table scan", "compact scan (2 dims)",
-                 "compact merge (2 dims)", "table scan (2 dims, 1 partition)"):
+                 "compact merge (2 dims)", "table scan (2 dims, 1 partition)", "narrow compact scan", "narrow compact merge",
+                 "narrow scan", "narrow merge", "narrow table scan", "narrow region-A merge", "signed narrow compact scan",
+                 "signed narrow compact merge"):
         assert f"{what} compile rc 0" in out.stdout, what
     for nd in (1, 4):
         for vw in (4, 8):

@@ -85,6 +85,35 @@ int main(int argc, char **argv) {
     if (int rc = build(rtc_merge_source(q, 2, 3, a4, w4, true), "_cmerge2", "compact merge (2 dims)")) return rc;
     if (int rc = build(rtc_table_scan_source(q, 2, 0, a4, w4), "_table2", "table scan (2 dims, 1 partition)")) return rc;
   }
+  {  // a narrow plan, the reference's example schema (examples/1k_trips/schema/trips.json): dimensions [Floor(request_at, 3600)
+     // Uint32, city_id Uint16 -> a 2-byte slot], SUM(fare), filters request_at >= / < (time range), status == k on a Uint8 column
+    FusedPlanD t = p;
+    t.numCols = 4;
+    t.cols[0].step = 4; t.cols[1].step = 2; t.cols[2].step = 4; t.cols[3].step = 1;
+    t.dims[1] = p.dims[1]; t.dims[1].col = 1;
+    t.dimWidth[0] = 4; t.dimWidth[1] = 2;
+    t.measure.f = col(K_F32); t.measure.col = 2; t.measure.outKind = K_F32;
+    t.numFilters = 3;
+    t.filters[0] = p.filters[0]; t.filters[0].f.functor = GreaterThanOrEqual; t.filters[0].col = 0;
+    t.filters[1] = p.filters[0]; t.filters[1].f.functor = LessThan; t.filters[1].col = 0;
+    t.filters[2] = p.filters[0]; t.filters[2].f.functor = Equal; t.filters[2].col = 3;
+    if (int rc = build(rtc_scan_source(t, 2, 9, true), "_ncompact", "narrow compact scan")) return rc;
+    if (int rc = build(rtc_merge_source(t, 2, 9, agg, w, true), "_ncmerge", "narrow compact merge")) return rc;
+    if (int rc = build(rtc_scan_source(t, 2, 9, false), "_nlines", "narrow scan")) return rc;
+    if (int rc = build(rtc_merge_source(t, 2, 9, agg, w, false), "_nmerge", "narrow merge")) return rc;
+    if (int rc = build(rtc_table_scan_source(t, 2, 9, agg, w), "_ntable", "narrow table scan")) return rc;
+    if (int rc = build(rtc_merge_source(t, 2, 9, agg, w, false, true), "_namerge", "narrow region-A merge")) return rc;
+    // signed narrow columns and a 1-byte slot: dimensions [Int16 column -> 2-byte slot, Int8 column -> 1-byte slot], no nulls
+    FusedPlanD u = t;
+    u.numFilters = 0; u.numCols = 3;
+    for (int c = 0; c < 3; c++) u.cols[c].nulls = nullptr;
+    u.cols[0].step = 2; u.cols[1].step = 1; u.cols[2].step = 4;
+    u.dims[0].f = col(K_I32); u.dims[0].col = 0; u.dims[0].outKind = K_I32;
+    u.dims[1].f = col(K_I32); u.dims[1].col = 1; u.dims[1].outKind = K_I32;
+    u.dimWidth[0] = 2; u.dimWidth[1] = 1;
+    if (int rc = build(rtc_scan_source(u, 2, 9, true), "_scompact", "signed narrow compact scan")) return rc;
+    if (int rc = build(rtc_merge_source(u, 2, 9, agg, w, true), "_scmerge", "signed narrow compact merge")) return rc;
+  }
   // the vector-sourced scan (HashReduce on materialised dimension / measure vectors)
   for (int vw = 4; vw <= 8; vw += 4)
     for (int nd = 1; nd <= 4; nd += 3) {

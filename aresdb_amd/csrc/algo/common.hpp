@@ -64,7 +64,7 @@ void flush_deferred(int device);
 // second-stage fusion (transform.hip, include/ares_extensions.h)
 bool fuse_pending_into_hash_reduce(int device, hipStream_t stream, const DimensionVector &in, const uint8_t *inValues,
                                    const DimensionVector &out, uint8_t *outValues, int valueBytes, int length, int aggFunc,
-                                   int *groups, size_t *pendingShape = nullptr);
+                                   int *groups);
 void invalidate_filter_journal(int device, const uint32_t *indexVector);
 // ARES_HASH_REDUCE=global: every HashReduce takes the global-table path (hash_reduce.hip)
 bool global_table_forced();

@@ -154,9 +154,8 @@ extern "C" CGoCallResHandle HashReduce(DimensionVector inputKeys, uint8_t *input
   }
   // the dimension / measure transforms of this batch may still be pending: evaluate them on the fly
   int fusedGroups = 0;
-  size_t pendingShape = 0;  // a narrow plan nobody has seen: its first batch's groups are reported below
   if (length > 0 && fuse_pending_into_hash_reduce(device, stream, inputKeys, inputValues, outputKeys, outputValues,
-                                                  valueBytes, length, aggFunc, &fusedGroups, &pendingShape)) {
+                                                  valueBytes, length, aggFunc, &fusedGroups)) {
     resHandle.res = int_result(fusedGroups);
     return resHandle;
   }
@@ -170,7 +169,6 @@ extern "C" CGoCallResHandle HashReduce(DimensionVector inputKeys, uint8_t *input
   if (length > 0 && hash_reduce_lds_supported(a) && !global_table_forced())
     groups = hash_reduce_lds(device, inputKeys, inputValues, outputKeys, outputValues, a, length, stream);
   if (groups >= 0) {
-    fused_note_first_batch(pendingShape, groups);
     resHandle.res = int_result(groups);
   } else if (length > 0) {
     const DimLayoutD L = make_dim_layout(inputKeys.NumDimsPerDimWidth);

@@ -301,10 +301,11 @@ int hash_reduce_lds(int device, const DimensionVector &inputKeys, const uint8_t 
   const size_t capacity = static_cast<size_t>(inputKeys.VectorCapacity);
   bool all4 = L.numDims >= 1 && L.numDims <= 4;  // beyond 4 dims the double-buffered quads spill
   for (int d = 0; d < L.numDims; d++) all4 = all4 && L.width[d] == 4;
-  // a layout whose partition-grouped result a later FUSED batch can start from (narrow slots: the generated merge only)
+  // a layout whose partition-grouped result a later FUSED batch can start from (narrow slots: the generated merge only,
+  // which needs two spare hash bits in its 32-bit table keys: at least four partitions)
   SlotWidths slots;
   const bool describable = slot_widths(inputKeys.NumDimsPerDimWidth, &slots);
-  const int partBits = part_bits_for(length);
+  const int partBits = std::max(part_bits_for(length), (describable && !all4) ? 2 : 0);
   const int numParts = 1 << partBits;
   // the output vectors are about to be rewritten: whatever was known about them is void
   grouped_note_write(device, outputKeys.DimValues, static_cast<size_t>(L.rowBytes) * capacity);
@@ -429,7 +430,7 @@ int hash_reduce_lds(int device, const DimensionVector &inputKeys, const uint8_t 
 // The fused pipeline for an already built plan (shared by the extension entry point and by the
 // in-ABI fusion of pending transforms into HashReduce, transform.hip).  Returns the number of groups
 // or -1 when a region overflowed.
-void fused_note_first_batch(size_t shape, int groups) {
+static void fused_note_first_batch(size_t shape, int groups) {
   if (!shape || groups < 0) return;
   std::lock_guard<std::mutex> lock(g_shapeMutex);
   if (g_firstBatchGroups.size() > 4096) g_firstBatchGroups.clear();
@@ -438,8 +439,7 @@ void fused_note_first_batch(size_t shape, int groups) {
 
 int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, const DimensionVector &prevKeys,
                           const uint8_t *prevValues, int prevSize, const DimensionVector &outKeys, uint8_t *outValues,
-                          const AggSpec &a, hipStream_t stream, size_t *pendingShape) {
-  if (pendingShape) *pendingShape = 0;
+                          const AggSpec &a, hipStream_t stream) {
   SlotWidths slots;
   if (!slot_widths(outKeys.NumDimsPerDimWidth, &slots)) return kFusedUnavailable;
   const int nd = slots.nd;
@@ -451,7 +451,7 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
   const int mw = plan.measureWidth;
   const int64_t length = static_cast<int64_t>(batchRows) + prevSize;
   if (length == 0) return 0;
-  const int partBits = part_bits_for(length);
+  const int partBits = std::max(part_bits_for(length), narrow ? 2 : 0);  // (the generated merge needs >= 4 partitions)
   const int numParts = 1 << partBits;
   const size_t prevCapacity = static_cast<size_t>(prevKeys.VectorCapacity);
   const size_t outCapacity = static_cast<size_t>(outKeys.VectorCapacity);
@@ -460,7 +460,7 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
   GroupedState prev;
   bool grouped = prevSize > 0 && grouped_lookup(device, prevKeys.DimValues, prevValues, prevCapacity, slots, mw, &prev) &&
                  prev.partBits == partBits && prev.size == prevSize;
-  if (narrow && (!(batchRows > 0 && rtc_scan_available()) || (prevSize > 0 && !grouped))) return kFusedUnavailable;
+  if (narrow && !(batchRows > 0 && rtc_scan_available())) return kFusedUnavailable;
   const std::shared_ptr<uint32_t> outRangesRef = grouped_enabled() ? take_ranges(device) : nullptr;
   uint32_t *outRanges = outRangesRef.get();
   MergeResult res{0, 0, 0, 0};
@@ -495,26 +495,27 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
   SlowScope slowWhole("fused_hash_reduce_run");
   // (ARES_LEAN_MIN_GROUPS=0 — tests — sends every batch, known shape or not, to the DIRECT kernels)
   const bool wantLean = rtc && expected >= lean_min_groups() && (known || lean_min_groups() <= 0);
-  const bool wantTable = rtc && !wantLean && known;
-  if (narrow && !wantLean && !wantTable) {
-    // a shape nobody has seen: nothing says which scan suits it and there is no generic kernel to find out with.  Both
-    // pairs are requested (background), the unfused sequence runs this batch and reports its groups (pendingShape).
-    (void)rtc_scan_lookup(device, plan, nd, partBits, compact);
-    (void)rtc_merge_lookup(device, plan, nd, partBits, a, widen, compact);
-    (void)rtc_table_scan_lookup(device, plan, nd, partBits, a, widen);
-    (void)rtc_merge_lookup(device, plan, nd, partBits, a, widen, false, false, /*regionA=*/true);
-    if (pendingShape) *pendingShape = shape;
-    return kFusedUnavailable;
-  }
+  // (a narrow shape nobody has seen has no adaptive generic kernel to find its cardinality out with: the TABLE scan takes
+  // it — right for any number of groups, rows that find the table full travel alone — and the next first batch knows)
+  const bool wantTable = rtc && !wantLean && (known || narrow);
   if (wantLean) lean = rtc_scan_lookup(device, plan, nd, partBits, compact);
   else if (wantTable) table = rtc_table_scan_lookup(device, plan, nd, partBits, a, widen);
-  if (narrow) {
-    if (wantLean) narrowMerge = rtc_merge_lookup(device, plan, nd, partBits, a, widen, compact);
-    else tableMerge = rtc_merge_lookup(device, plan, nd, partBits, a, widen, false, false, /*regionA=*/true);
-    if (wantLean ? !(lean && narrowMerge) : !(table && tableMerge)) return kFusedUnavailable;  // still being compiled
+  if (narrow) {  // (both kernels are asked for before the call is declined: one round of background compilation, not two)
+    narrowMerge = rtc_merge_lookup(device, plan, nd, partBits, a, widen, wantLean && compact, false,
+                                   /*regionA=*/wantTable || (prevSize > 0 && !grouped));
+    if (!(wantLean ? lean : table) || !narrowMerge) return kFusedUnavailable;  // still being compiled (or a shape the generator declines)
   }
+  bool launched = false;
   for (;;) {
-    if (narrow && prevSize > 0 && !grouped) return -1;  // (the grouped previous result turned out stale: the long way)
+    // narrow plans: the generated merge, which also takes region A — what the TABLE scan emits, and previous groups that are
+    // not grouped by partition (re-partitioned below by the layout-generic kernel)
+    const bool prevToA = narrow && prevSize > 0 && !grouped;
+    if (narrow) {
+      narrowMerge = rtc_merge_lookup(device, plan, nd, partBits, a, widen, lean && compact, false, /*regionA=*/table || prevToA);
+      if (!narrowMerge) return launched ? -1 : kFusedUnavailable;
+      if (table) tableMerge = narrowMerge;
+    }
+    launched = true;
     const int streams = batchRows > 0 ? (lean ? rtc_scan_grid(batchRows) : table ? 0 : grid_for(batchRows)) : 0;
     Regions r;
     {
@@ -534,12 +535,18 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
     Workspace wsPrev = ws;  // previous groups that are not grouped by partition: TABLE-mode pass into region A
     wsPrev.streams = 0;
     // the specialised merge reads region B and grouped previous results only
-    RtcKernel leanMerge = narrow ? narrowMerge : (lean && (prevSize == 0 || grouped)) ? rtc_merge_lookup(device, plan, nd, partBits, a, widen, compact) : nullptr;
+    RtcKernel leanMerge = narrow ? (lean ? narrowMerge : nullptr) : (lean && (prevSize == 0 || grouped)) ? rtc_merge_lookup(device, plan, nd, partBits, a, widen, compact) : nullptr;
+    if (prevToA) {
+      const DimLayoutD prevLayout = make_dim_layout(prevKeys.NumDimsPerDimWidth);
+      const int64_t tiles = (static_cast<int64_t>(prevSize) + kTileRows - 1) / kTileRows;
+      ARES_LAUNCH("hr_partition_kernel", hr_partition_kernel, static_cast<int>(tiles < 256 ? tiles : 256), kThreads, stream,
+                  prevKeys.DimValues, prevLayout, prevCapacity, prevValues, a, prevSize, wsPrev);
+    }
     // (the specialised merge writes every partition's range entry itself)
     if (outRanges && !leanMerge && !tableMerge) hip_check(hipMemsetAsync(outRanges, 0, kRangesBytes, stream), "hipMemsetAsync");
 #define ARES_FUSED_CASE(ND)                                                                                            \
   case ND:                                                                                                             \
-    if (prevSize > 0 && !grouped) {                                                                                    \
+    if (prevSize > 0 && !grouped && !narrow) {                                                                         \
       if (mw == 8)                                                                                                     \
         ARES_LAUNCH("hr_partition4_kernel", (hr_partition4_kernel<ND, 8>), grid_for(prevSize), kThreads, stream,        \
                     prevKeys.DimValues, prevCapacity, prevValues, 0u, a, prevSize, wsPrev, 0);                         \

@@ -63,12 +63,10 @@ inline bool fused_plan_narrow(const FusedPlanD &p, int nd) {
 // Returns the number of groups; -1: a partition region overflowed (or a partition needs the generic multi-round merge and
 // the plan is narrow) — outputs may be partly written; kFusedUnavailable: declined before anything was launched (narrow
 // plan whose generated kernels are not loaded yet, previous results not grouped ...).  Either way the caller runs the
-// unfused sequence.  pendingShape (may be null): set when the call was declined because nothing is known about the shape's
-// cardinality — the caller reports the groups the unfused sequence found with fused_note_first_batch.
+// unfused sequence.
 constexpr int kFusedUnavailable = -2;
 int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, const DimensionVector &prevKeys,
                           const uint8_t *prevValues, int prevSize, const DimensionVector &outKeys, uint8_t *outValues,
-                          const AggSpec &a, hipStream_t stream, size_t *pendingShape = nullptr);
-void fused_note_first_batch(size_t shape, int groups);
+                          const AggSpec &a, hipStream_t stream);
 
 }  // namespace ares

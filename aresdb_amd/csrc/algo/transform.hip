@@ -3168,8 +3168,7 @@ void launch_pending_writers(int device, const void *ptr, size_t bytes) {
 // ordinary path (whatever was pending has been launched, in stream order).
 bool fuse_pending_into_hash_reduce(int device, hipStream_t stream, const DimensionVector &in, const uint8_t *inValues,
                                    const DimensionVector &out, uint8_t *outValues, int valueBytes, int length, int aggFunc,
-                                   int *groups, size_t *pendingShape) {
-  if (pendingShape) *pendingShape = 0;
+                                   int *groups) {
   if (!fuse_available()) return false;
   const bool forcedGlobal = global_table_forced();
   PendingQueue q;
@@ -3271,7 +3270,7 @@ bool fuse_pending_into_hash_reduce(int device, hipStream_t stream, const Dimensi
             if (plan.cols[c].vals == f.vals && plan.cols[c].nulls == f.nulls && plan.cols[c].bitOff == f.bitOff &&
                 plan.cols[c].step == static_cast<uint32_t>(f.step ? f.step : 4))
               col = c;
-          if (col < 0 && plan.numCols < nd + 2) {
+          if (col < 0 && plan.numCols < kFusedCols) {
             col = plan.numCols++;
             plan.cols[col] = column_of(f);
           }
@@ -3282,6 +3281,8 @@ bool fuse_pending_into_hash_reduce(int device, hipStream_t stream, const Dimensi
         }
         plan.numFilters = static_cast<int>(journal->filters.size());
       }
+      // the precompiled generic scan holds nd + 2 column slots; a narrow plan only ever runs on generated kernels (kFusedCols)
+      ok = ok && (plan.numCols <= nd + 2 || fused_plan_narrow(plan, nd));
     }
     if (!ok) {  // the ordinary path: the pending work runs now, ahead of this call on the same stream
       launch_queue(stream, pq, /*inOrder=*/true);
@@ -3296,7 +3297,7 @@ bool fuse_pending_into_hash_reduce(int device, hipStream_t stream, const Dimensi
     if (q.idx) t_state->journals.erase(q.idx);
   }
   DimensionVector prevKeys = in;
-  const int result = fused_hash_reduce_run(device, plan, n0, prevKeys, inValues, prev, out, outValues, a, stream, pendingShape);
+  const int result = fused_hash_reduce_run(device, plan, n0, prevKeys, inValues, prev, out, outValues, a, stream);
   DeferLock lock(device);
   if (result < 0) {  // a partition region overflowed, or the call was declined: materialise the inputs after all
     launch_queue(stream, q, /*inOrder=*/true);

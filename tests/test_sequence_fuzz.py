@@ -39,8 +39,13 @@ def _d2h(be, ptr, nbytes, stream):
 class Program:
     """One seeded program.  run(be) executes it and returns the list of observations."""
 
-    def __init__(self, seed):
+    def __init__(self, seed, profile=()):
+        """profile: "narrow" — the columns u, i, d are Uint16, Int16 / Int8, Uint8 columns (the same values: 1- / 2-byte
+        columns through the fast kernels and the fused scan); "drift" — the upper time-filter constant moves with every batch,
+        so the filter pair predicted from the stream's previous batch is never the one that arrives.  Neither draws from the
+        program's random stream: a seed is the same program in every profile."""
         self.seed = seed
+        self.profile = tuple(profile)
 
     def run(self, be, streams=None, expect=None):
         """expect: the observations of a reference run; with ARES_FUZZ_DUMP=<directory> set, the first filter count that
@@ -110,13 +115,17 @@ class Program:
                    "i": rng.integers(-6, 7, n).astype(np.int32), "d": rng.integers(0, 3, n).astype(np.uint32),
                    "f": (rng.integers(-200, 200, n) / 4).astype(np.float32)}
             types = {"ts": abi.Uint32, "u": abi.Uint32, "i": abi.Int32, "d": abi.Uint32, "f": abi.Float32}
+            if "narrow" in self.profile:
+                types.update({"u": abi.Uint16, "i": abi.Int16 if self.seed % 2 else abi.Int8, "d": abi.Uint8})
+                raw["u"], raw["d"] = raw["u"].astype(np.uint16), raw["d"].astype(np.uint8)
+                raw["i"] = raw["i"].astype(np.int16 if self.seed % 2 else np.int8)
             valid = {k: (rng.random(n) > 0.05) if nulls and rng.random() < 0.8 else None for k in raw}
             cols = {k: H.Column(be, types[k], raw[k], valid=valid[k]) for k in raw}
             idx, pred = H.Buf(be, nbytes=4 * n), H.Buf(be, nbytes=n)
             be.call("InitIndexVector", idx.ptr, 0, n, stream, 0)
             size = n
             if time_filters:
-                for op, const in ((abi.GreaterThanOrEqual, t_from), (abi.LessThan, t_to)):
+                for op, const in ((abi.GreaterThanOrEqual, t_from), (abi.LessThan, t_to + (977 * b if "drift" in self.profile else 0))):
                     size = be.call("BinaryFilter", cols["ts"].input(), H.const_int(const), idx.ptr, pred.ptr, size, None, 0, None, 0,
                                    op, stream, 0)
                     obs.append(("filter", b, size))
@@ -147,7 +156,7 @@ class Program:
             if size and rng.random() < 0.3:
                 obs.append(("index", b, _d2h(be, idx.ptr, 4 * size, stream).tobytes()))
             if size and rng.random() < 0.06:  # a column changes under the query between filter and projection
-                fresh = rng.integers(0, 12, n).astype(np.uint32)
+                fresh = rng.integers(0, 12, n).astype(raw["u"].dtype)
                 vp = cols["u"].vp
                 H.upload(be, vp.BasePtr + vp.ValuesOffset, fresh, stream)
             # result buffers: capacity for resultSize + size (+ 12.5 %), previous results carried over
@@ -261,14 +270,15 @@ def _same(a, b, seed):
 
 
 SEEDS = list(range(1000, 1160))
+PROFILES = [(), ("narrow",), ("drift",), ("narrow", "drift")]
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("chunk", range(8))
 def test_random_programs_match_the_oracle(chunk):
     hip, oracle = H.hip_backend(), H.oracle_backend()
-    for seed in SEEDS[chunk::8]:
-        p = Program(seed)
+    for k, seed in enumerate(SEEDS[chunk::8]):
+        p = Program(seed, PROFILES[k % len(PROFILES)])
         want = p.run(oracle)
         _same(p.run(hip, expect=want), want, seed)
 
@@ -278,8 +288,8 @@ def test_random_programs_reference_build_matches_the_oracle():
     if not H.have_ref():
         pytest.skip("reference HOST build absent")
     ref, oracle = H.ref_backend(), H.oracle_backend()
-    for seed in SEEDS[:24]:
-        p = Program(seed)
+    for k, seed in enumerate(SEEDS[:48]):
+        p = Program(seed, PROFILES[k % len(PROFILES)])
         _same(p.run(ref), p.run(oracle), seed)
 
 
@@ -304,3 +314,21 @@ def test_random_programs_from_four_host_threads():
         assert not errs, errs
         for t in range(4):
             _same(got[t], want[t], seeds[t])
+
+
+@pytest.mark.gpu
+def test_soak_four_threads_stream_churn_clean_blocks():
+    """The soak the deferral state machine's coverage used to live in, inside the suite the driver runs: 512 programs from
+    four host threads in ONE process (every program creates and destroys its own streams: stream churn with fences, error
+    watches and lazy work outstanding), all four profiles — narrow columns, time-filter pairs whose prediction fails every
+    batch —, ARES_MEM_VERIFY_CLEAN=1 (every block handed out as cleared is checked on the device: a writer that does not
+    report what it wrote aborts the process).  No mismatch, no error, no abort."""
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(H.ROOT, "tools", "stress_fuzz.py"), "--iters", "128", "--threads", "4", "--seeds", "96",
+                        "--profiles", "--tag", "soak"], cwd=H.ROOT, env={**os.environ, "ARES_MEM_VERIFY_CLEAN": "1"},
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+    rep = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rep["programs"] >= 500 and rep["mismatches"] == 0 and rep["errors"] == 0, rep

@@ -453,3 +453,95 @@ def test_single_rank_merge_rccl(use_hash):
     res = q.get(timeout=300)
     p.join(timeout=60)
     assert res[0] == "ok" and res[1] > 0, res
+
+
+# ---- RCCL with more than one rank: one process per GPU, the contract's launch shape --------------------------------------
+def _rccl_worker(rank, world, port, use_hash, q):
+    """Rank `rank` on GPU `rank`: its shard through the HIP library, then the three merges of libaresdriver.so over RCCL —
+    all-gather + re-reduce, hash-partitioned all-to-all (ncclSend / ncclRecv), and the union check across ranks — against
+    one oracle process reducing every shard (shards are generated on the CPU so that every rank and the oracle see the
+    same rows)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    try:
+        import harness as H
+        from aresdb_amd import workload
+        from aresdb_amd.driver import NativeComm, NativeQuery
+        from aresdb_amd.queries import c3_plan
+        os.environ["NCCL_DEBUG"] = "WARN"
+        torch.cuda.set_device(rank)
+        dev = torch.device(f"cuda:{rank}")
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, device_id=dev)
+        be = H.hip_backend()
+        stream = be.call("CreateCudaStream", rank)
+        plan = c3_plan(use_hash_reduction=use_hash)
+        names = [n for n, _ in workload.C3_COLUMNS]
+        rows = [60000 + 7000 * r for r in range(world)]
+        shards = [workload.c3_shard(rows[r], 1 << 15, seed=21 + r, device="cpu") for r in range(world)]
+        mine = [{k: workload.ResidentColumn(rc.blob.to(dev), rc.values_off, rc.data_type, rc.length, rc.has_nulls) for k, rc in b.items()}
+                for b in shards[rank]]
+
+        def bcast(raw):
+            t = torch.tensor(list(raw), dtype=torch.uint8, device=dev)
+            dist.broadcast(t, 0)
+            return bytes(t.cpu().tolist())
+
+        def run_shard():
+            ctx = NativeQuery(be, plan, names, device=rank, stream=stream)
+            for b in mine:
+                ctx.run({k: rc.vp for k, rc in b.items()}, next(iter(b.values())).length)
+            return ctx
+
+        def table(ctx):
+            n = ctx.result_size
+            if not n:
+                return {}
+            dims, valids, meas = ctx.fetch()
+            m = meas.view(np.float64)
+            return {tuple((bytes(d[r * len(d) // n:(r + 1) * len(d) // n]), int(v[r])) for d, v in zip(dims, valids)): m[r] for r in range(n)}
+
+        want = _single_process_result(H.oracle_backend(), plan, [b for s in shards for b in s])
+        comm = NativeComm.rccl(rank, world, rank, bcast)
+        ctx = run_shard()
+        ctx.merge_shards(comm)  # ncclAllGather on the query's stream + re-reduce: every rank ends with the whole table
+        got = table(ctx)
+        assert got.keys() == want.keys(), (len(got), len(want))
+        assert all(abs(got[k] - v) <= 1e-9 * max(1.0, abs(v)) for k, v in want.items())
+        ctx.release()
+        ctx = run_shard()
+        total = ctx.merge_shards_partitioned(comm)  # ncclSend / ncclRecv pairs: disjoint shares whose union is the table
+        part = table(ctx)
+        everyone = [None] * world
+        dist.all_gather_object(everyone, part)
+        union = {}
+        for p in everyone:
+            assert not (union.keys() & p.keys()), "two ranks hold the same group"
+            union.update(p)
+        assert total == len(want) == len(union), (total, len(want), len(union))
+        assert all(abs(union[k] - v) <= 1e-9 * max(1.0, abs(v)) for k, v in want.items())
+        ctx.release()
+        comm.destroy()
+        dist.destroy_process_group()
+        q.put((rank, "ok", len(got)))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, f"{type(e).__name__}: {e}", 0))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 2, 4], ids=["1_rank", "2_ranks", "4_ranks"])
+@pytest.mark.parametrize("use_hash", [True, False], ids=["hash_reduce", "sort_reduce"])
+def test_shard_merges_over_rccl(use_hash, world):
+    """Skipped where the box has fewer GPUs than ranks (the 1-rank case always runs: same code path, RCCL talking to itself)."""
+    if torch.cuda.device_count() < world:
+        pytest.skip(f"needs {world} GPUs (RCCL over xGMI), this box has {torch.cuda.device_count()}")
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, world, port, use_hash, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(r[1] == "ok" for r in results), results
+    assert len({r[2] for r in results}) == 1 and results[0][2] > 0

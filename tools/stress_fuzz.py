@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 os.environ.setdefault("ARES_RTC_ASYNC", "0")
 
 import harness as H  # noqa: E402
-from test_sequence_fuzz import Program  # noqa: E402
+from test_sequence_fuzz import PROFILES, Program  # noqa: E402
 
 
 def first_diff(a, b):
@@ -44,21 +44,26 @@ def main():
     ap.add_argument("--threads", type=int, default=4)
     ap.add_argument("--tag", default="run")
     ap.add_argument("--seeds", type=int, default=48)
+    ap.add_argument("--profiles", action="store_true", help="cycle the fuzzer's profiles (narrow columns, drifting time filters) over the seeds")
+    ap.add_argument("--budget-s", type=float, default=0.0, help="stop starting new rounds after this many seconds (0: run every round)")
     a = ap.parse_args()
+    prof = (lambda s: PROFILES[s % len(PROFILES)]) if a.profiles else (lambda s: ())
     hip, oracle = (H.oracle_backend() if os.environ.get("STRESS_ON_ORACLE") else H.hip_backend()), H.oracle_backend()
     want = {}
     t0 = time.time()
     bad, errs, programs = [], [], 0
     for it in range(a.iters):
+        if a.budget_s and time.time() - t0 > a.budget_s:
+            break
         seeds = [2000 + (it * a.threads + t) % a.seeds for t in range(a.threads)]
         for s in seeds:
             if s not in want:
-                want[s] = Program(s).run(oracle)
+                want[s] = Program(s, prof(s)).run(oracle)
         got = [None] * a.threads
 
         def work(t):
             try:
-                got[t] = Program(seeds[t]).run(hip, expect=want[seeds[t]])
+                got[t] = Program(seeds[t], prof(seeds[t])).run(hip, expect=want[seeds[t]])
             except Exception as e:  # noqa: BLE001
                 errs.append((it, seeds[t], repr(e)[:200]))
         ths = [threading.Thread(target=work, args=(t,)) for t in range(a.threads)]

@@ -172,8 +172,8 @@ extern "C" CGoCallResHandle HashReduce(DimensionVector inputKeys, uint8_t *input
     resHandle.res = int_result(groups);
   } else if (length > 0) {
     const DimLayoutD L = make_dim_layout(inputKeys.NumDimsPerDimWidth);
-    grouped_note_write(device, outputKeys.DimValues, static_cast<size_t>(L.rowBytes) * inputKeys.VectorCapacity);
     grouped_note_write(device, outputValues, static_cast<size_t>(a.width) * length);
+    grouped_note_write(device, outputKeys.DimValues, static_cast<size_t>(L.rowBytes) * inputKeys.VectorCapacity);
     uint64_t tableSize = 1024;
     while (tableSize < 2ull * static_cast<uint64_t>(length)) tableSize <<= 1;
     StreamBuffer keyBuf(tableSize * 8, stream), valBuf(tableSize * a.width, stream), counter(16, stream);

@@ -1,7 +1,9 @@
 // HashReduce, partitioned: kernels and host side (device code: hr_kernels.hpp).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <functional>
+#include <map>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -115,8 +117,14 @@ struct GroupedState {
   int valueBytes, size, partBits;
   // kMaxPartitions x kRangeWords words of device memory.  Shared: a call that looked the state up keeps the buffer
   // alive while its merge reads it, whatever another thread's eviction or overwrite does to the table meanwhile; the
-  // buffer goes back to the free list with the last reference.
+  // buffer goes back to the free list with the last reference.  Null: the rows are not grouped by partition (results of
+  // image-mode merges are in order of first appearance).
   std::shared_ptr<uint32_t> ranges;
+  // ---- table image (see "table images" below): the partitions' LDS tables as the merge that produced these vectors
+  // left them — what the query's next HashReduce starts from instead of re-hashing and re-inserting every group
+  std::shared_ptr<uint8_t> image;
+  uint64_t lineage = 0;     // the query (chain of HashReduce calls) the image belongs to
+  bool lazyValues = false;  // rows [0, size) of `values` are NOT written: they are what the image's value plane holds
 };
 std::mutex g_groupedMutex;
 std::vector<GroupedState> g_grouped;
@@ -150,6 +158,104 @@ std::shared_ptr<uint32_t> take_ranges(int device) {
   });
 }
 
+// ---- table images ------------------------------------------------------------------------------------------------
+// What a live batch (2 Mi rows against a result of millions of groups) used to pay per HashReduce: every partition re-hashed
+// and re-inserted its ~4.5 k previous groups from the previous output vectors and wrote all of them out again — twice the
+// work of the batch's own records.  Now the merge of a DIRECT-mode batch leaves each partition's LDS table in HBM (keys,
+// the output position of every group, values: kSlots x 16 B per partition, 64 MB for 512 partitions, coalesced) and the
+// next call's merge starts from it (hr_rtc.hip generate_merge image = 2): previous groups cost one coalesced load, only
+// groups the batch sees for the first time are emitted — appended, so a group keeps its position for the life of the query
+// — and the measure vector is not written at all: it is DEFINED by the image's value plane ("lazy values") and written by
+// hr_image_values_kernel when somebody reads it (a copy, an entry point that is handed the vector, an overwrite that leaves
+// part of it) — at the latest when the host fetches the result.  Both result buffers of a query (the Go host ping-pongs
+// them) carry their own image: a merge reads the input buffer's and writes the output buffer's, so either buffer can be
+// materialised at any time.  The dimension rows of the output buffer are kept complete: the merge copies over the rows
+// the output buffer has not seen (those added while it was the input's partner: a handful per batch in steady state).
+// Everything is trusted only while nothing has written to the vectors (grouped_note_write), as the ranges are.
+// ARES_IMAGE=0: off.
+constexpr size_t kImagePartBytes = static_cast<size_t>(kSlots) * 16;
+constexpr size_t kImageCountsOff = kImagePartBytes * kMaxPartitions;
+constexpr size_t kImageBytes = kImageCountsOff + sizeof(uint32_t) * kMaxPartitions;
+std::vector<std::pair<int, uint8_t *>> g_freeImages;  // (guarded by g_rangesMutex)
+std::atomic<uint64_t> g_lineage{0};
+
+bool image_enabled() {
+  static EnvSwitch<bool> on("ARES_IMAGE", [](const char *e) { return !(e && e[0] == '0'); });
+  return on.get() && grouped_enabled();
+}
+
+std::shared_ptr<uint8_t> take_image(int device) {
+  uint8_t *p = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_rangesMutex);
+    for (size_t i = 0; i < g_freeImages.size(); i++)
+      if (g_freeImages[i].first == device) {
+        p = g_freeImages[i].second;
+        g_freeImages[i] = g_freeImages.back();
+        g_freeImages.pop_back();
+        break;
+      }
+  }
+  if (!p) {
+    void *fresh = nullptr;
+    hip_check(hipMalloc(&fresh, kImageBytes), "hipMalloc");
+    p = static_cast<uint8_t *>(fresh);
+  }
+  return std::shared_ptr<uint8_t>(p, [device](uint8_t *q) {
+    std::lock_guard<std::mutex> lock(g_rangesMutex);
+    g_freeImages.emplace_back(device, q);
+  });
+}
+uint32_t *image_counts(uint8_t *image) { return reinterpret_cast<uint32_t *>(image + kImageCountsOff); }
+
+// values[pos] = value for every group of the image: the measure vector an image-mode merge left unwritten
+template <int VW>
+__global__ __launch_bounds__(kThreads) void hr_image_values_kernel(const uint4 *image, uint8_t *values, uint32_t size) {
+  const uint4 *img = image + static_cast<size_t>(blockIdx.x) * kSlots;
+  const uint32_t *keys = reinterpret_cast<const uint32_t *>(img), *pos = keys + kSlots;
+  const uint64_t *vals = reinterpret_cast<const uint64_t *>(img + kSlots / 2);
+  for (int s = threadIdx.x; s < kSlots; s += kThreads) {
+    if (keys[s] == 0u) continue;
+    const uint32_t at = pos[s];
+    if (at >= size) continue;  // (cannot happen: positions are handed out below the result's size)
+    if (VW == 8) reinterpret_cast<uint64_t *>(values)[at] = vals[s];
+    else reinterpret_cast<uint32_t *>(values)[at] = static_cast<uint32_t>(vals[s]);
+  }
+}
+
+hipStream_t image_stream(int device) {  // materialisations run here, synchronously: rare (once per query, at its fetch)
+  static std::mutex mu;
+  static std::map<int, hipStream_t> streams;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = streams.find(device);
+  if (it != streams.end()) return it->second;
+  hipStream_t s = nullptr;
+  hip_check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking), "hipStreamCreate");
+  streams[device] = s;
+  return s;
+}
+
+// caller holds g_groupedMutex (or owns `s` outright).  The image's producer has completed: the HashReduce that wrote it
+// waited for its stream before it returned.
+void materialize_values(GroupedState &s) {
+  if (!s.lazyValues || !s.image) return;
+  int current = 0;
+  const bool have = hipGetDevice(&current) == hipSuccess;
+  if (!have || current != s.device) hip_check(hipSetDevice(s.device), "hipSetDevice");
+  hipStream_t stream = image_stream(s.device);
+  uint8_t *values = const_cast<uint8_t *>(s.values);
+  if (s.valueBytes == 8)
+    ARES_LAUNCH("hr_image_values_kernel", hr_image_values_kernel<8>, 1 << s.partBits, kThreads, stream,
+                reinterpret_cast<const uint4 *>(s.image.get()), values, static_cast<uint32_t>(s.size));
+  else
+    ARES_LAUNCH("hr_image_values_kernel", hr_image_values_kernel<4>, 1 << s.partBits, kThreads, stream,
+                reinterpret_cast<const uint4 *>(s.image.get()), values, static_cast<uint32_t>(s.size));
+  hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+  mem_note_write(s.device, values, static_cast<size_t>(s.valueBytes) * s.size);
+  s.lazyValues = false;
+  if (have && current != s.device) (void)hipSetDevice(current);
+}
+
 bool state_overlaps(const GroupedState &s, const uint8_t *lo, const uint8_t *hi) {
   auto hit = [&](const uint8_t *a, size_t bytes) { return a < hi && lo < a + bytes; };
   for (int d = 0; d < s.slots.nd; d++) {
@@ -174,7 +280,10 @@ bool grouped_lookup(int device, const uint8_t *dims, const uint8_t *values, size
 
 void grouped_register(const GroupedState &s) {
   std::lock_guard<std::mutex> lock(g_groupedMutex);
-  if (g_grouped.size() >= 64) g_grouped.erase(g_grouped.begin());  // a host that never frees: forget the oldest
+  if (g_grouped.size() >= 64) {  // a host that never frees: forget the oldest (its unwritten values are written first)
+    materialize_values(g_grouped.front());
+    g_grouped.erase(g_grouped.begin());
+  }
   g_grouped.push_back(s);
 }
 
@@ -274,11 +383,29 @@ void grouped_note_write(int device, const void *ptr, size_t bytes) {
   const uint8_t *hi = lo + (bytes ? bytes : 1);
   std::lock_guard<std::mutex> lock(g_groupedMutex);
   for (size_t i = 0; i < g_grouped.size();) {
-    if (g_grouped[i].device == device && state_overlaps(g_grouped[i], lo, hi)) {
+    GroupedState &st = g_grouped[i];
+    if (st.device == device && state_overlaps(st, lo, hi)) {
+      // values that were never written are written now — unless the write (or free) takes all of them with it
+      const uint8_t *vlo = st.values, *vhi = st.values + static_cast<size_t>(st.valueBytes) * st.size;
+      if (st.lazyValues && !(lo <= vlo && vhi <= hi)) materialize_values(st);
       g_grouped.erase(g_grouped.begin() + i);
     } else {
       i++;
     }
+  }
+}
+
+// [ptr, ptr + bytes) is about to be read (a copy, an entry point that is handed the vector): measure rows an image-mode
+// merge left unwritten are written first.  The state stays: its rows are still what the merge produced.
+void grouped_materialize_for_read(int device, const void *ptr, size_t bytes) {
+  if (!ptr) return;
+  const uint8_t *lo = static_cast<const uint8_t *>(ptr);
+  const uint8_t *hi = lo + (bytes ? bytes : 1);
+  std::lock_guard<std::mutex> lock(g_groupedMutex);
+  for (GroupedState &st : g_grouped) {
+    if (st.device != device || !st.lazyValues) continue;
+    const uint8_t *vlo = st.values, *vhi = st.values + static_cast<size_t>(st.valueBytes) * st.size;
+    if (vlo < hi && lo < vhi) materialize_values(st);
   }
 }
 
@@ -308,11 +435,11 @@ int hash_reduce_lds(int device, const DimensionVector &inputKeys, const uint8_t 
   const int partBits = std::max(part_bits_for(length), (describable && !all4) ? 2 : 0);
   const int numParts = 1 << partBits;
   // the output vectors are about to be rewritten: whatever was known about them is void
+  grouped_note_write(device, outputValues, static_cast<size_t>(a.width) * capacity);  // (values first: unwritten ones die whole)
   grouped_note_write(device, outputKeys.DimValues, static_cast<size_t>(L.rowBytes) * capacity);
-  grouped_note_write(device, outputValues, static_cast<size_t>(a.width) * capacity);
   GroupedState prev;
   bool grouped = all4 && grouped_lookup(device, inputKeys.DimValues, inputValues, capacity, slots, a.width, &prev) &&
-                 prev.partBits == partBits && prev.size > 0 && prev.size <= length;
+                 prev.ranges && prev.partBits == partBits && prev.size > 0 && prev.size <= length;
   // (the reference goes with this call unless the result is registered below: nothing leaks when a launch throws)
   const std::shared_ptr<uint32_t> outRangesRef = (describable && grouped_enabled()) ? take_ranges(device) : nullptr;
   uint32_t *outRanges = outRangesRef.get();
@@ -455,11 +582,17 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
   const int numParts = 1 << partBits;
   const size_t prevCapacity = static_cast<size_t>(prevKeys.VectorCapacity);
   const size_t outCapacity = static_cast<size_t>(outKeys.VectorCapacity);
+  // what is known about the OUTPUT vectors before this call rewrites them: when they belong to this query (the Go host
+  // ping-pongs two result buffers) their leading dimension rows already hold the query's groups, and their table image is
+  // the one to write into
+  GroupedState outOld;
+  const bool outFound = image_enabled() && grouped_lookup(device, outKeys.DimValues, outValues, outCapacity, slots, mw, &outOld);
+  grouped_note_write(device, outValues, static_cast<size_t>(mw) * outCapacity);  // (values first: unwritten ones die whole)
   grouped_note_write(device, outKeys.DimValues, slots.row_bytes() * outCapacity);
-  grouped_note_write(device, outValues, static_cast<size_t>(mw) * outCapacity);
   GroupedState prev;
-  bool grouped = prevSize > 0 && grouped_lookup(device, prevKeys.DimValues, prevValues, prevCapacity, slots, mw, &prev) &&
-                 prev.partBits == partBits && prev.size == prevSize;
+  const bool found = prevSize > 0 && grouped_lookup(device, prevKeys.DimValues, prevValues, prevCapacity, slots, mw, &prev) &&
+                     prev.partBits == partBits && prev.size == prevSize;
+  bool grouped = found && prev.ranges != nullptr;
   if (narrow && !(batchRows > 0 && rtc_scan_available())) return kFusedUnavailable;
   const std::shared_ptr<uint32_t> outRangesRef = grouped_enabled() ? take_ranges(device) : nullptr;
   uint32_t *outRanges = outRangesRef.get();
@@ -500,17 +633,44 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
   const bool wantTable = rtc && !wantLean && (known || narrow);
   if (wantLean) lean = rtc_scan_lookup(device, plan, nd, partBits, compact);
   else if (wantTable) table = rtc_table_scan_lookup(device, plan, nd, partBits, a, widen);
-  if (narrow) {  // (both kernels are asked for before the call is declined: one round of background compilation, not two)
+  // ---- table image (see "table images" above): 2 = the merge starts from the image the previous call left with the input
+  // vectors; 1 = the ordinary specialised merge, which leaves an image for the next call.  DIRECT-mode batches only.
+  int imageMode = 0;
+  RtcKernel imageMerge;
+  std::shared_ptr<uint8_t> imageOut;
+  uint32_t knownOut = 0;
+  if (image_enabled() && wantLean && lean) {
+    if (found && prev.image) imageMode = 2;
+    else if (prevSize == 0 || grouped) imageMode = 1;
+    if (imageMode) imageMerge = rtc_merge_lookup(device, plan, nd, partBits, a, widen, compact, false, false, imageMode);
+    if (!imageMerge) imageMode = 0;  // (being compiled in the background: the ordinary kernels this time)
+  }
+  if (imageMode == 2) {
+    const bool mine = outFound && outOld.lineage == prev.lineage && outOld.image && outOld.image != prev.image &&
+                      outOld.partBits == partBits && outOld.size <= prevSize;
+    knownOut = mine ? static_cast<uint32_t>(outOld.size) : 0u;
+    imageOut = mine ? outOld.image : take_image(device);
+    // a partition's key and position planes are rewritten unless the output's image already holds this very set (equal
+    // counts within one lineage); an image of unknown content starts with counts no partition can have
+    if (!mine) hip_check(hipMemsetAsync(image_counts(imageOut.get()), 0xFF, sizeof(uint32_t) * kMaxPartitions, stream), "hipMemsetAsync");
+  } else {
+    if (imageMode == 1) imageOut = take_image(device);
+    // the previous result's measure rows are read by everything but an image-mode merge: write them if they are still
+    // only defined by their image
+    if (prevSize > 0) grouped_materialize_for_read(device, prevValues, static_cast<size_t>(mw) * prevSize);
+  }
+  if (narrow && !imageMode) {  // (both kernels are asked for before the call is declined: one round of background compilation, not two)
     narrowMerge = rtc_merge_lookup(device, plan, nd, partBits, a, widen, wantLean && compact, false,
                                    /*regionA=*/wantTable || (prevSize > 0 && !grouped));
-    if (!(wantLean ? lean : table) || !narrowMerge) return kFusedUnavailable;  // still being compiled (or a shape the generator declines)
+    if (!narrowMerge) return kFusedUnavailable;  // still being compiled (or a shape the generator declines)
   }
+  if (narrow && !(wantLean ? lean : table)) return kFusedUnavailable;
   bool launched = false;
   for (;;) {
     // narrow plans: the generated merge, which also takes region A — what the TABLE scan emits, and previous groups that are
     // not grouped by partition (re-partitioned below by the layout-generic kernel)
-    const bool prevToA = narrow && prevSize > 0 && !grouped;
-    if (narrow) {
+    const bool prevToA = narrow && prevSize > 0 && !grouped && imageMode != 2;
+    if (narrow && !imageMode) {
       narrowMerge = rtc_merge_lookup(device, plan, nd, partBits, a, widen, lean && compact, false, /*regionA=*/table || prevToA);
       if (!narrowMerge) return launched ? -1 : kFusedUnavailable;
       if (table) tableMerge = narrowMerge;
@@ -522,7 +682,7 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
       SlowScope slow("make_regions");
       // DIRECT mode writes region A only with previous groups that are not grouped by partition yet; sizing it for
       // the batch as well made the first DIRECT batch of a process allocate (and the driver clear) 2.7 GB more
-      const int64_t rowsA = !lean ? length : (prevSize > 0 && !grouped) ? prevSize : 0;
+      const int64_t rowsA = !lean ? length : (prevSize > 0 && !grouped && imageMode != 2) ? prevSize : 0;
       make_regions(r, partBits, rowsA, batchRows, streams, lean ? 4 : 3, stream,
                    !lean ? 0 : compact ? static_cast<int>(kCompactLineRecords) : 8);
     }
@@ -535,7 +695,20 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
     Workspace wsPrev = ws;  // previous groups that are not grouped by partition: TABLE-mode pass into region A
     wsPrev.streams = 0;
     // the specialised merge reads region B and grouped previous results only
-    RtcKernel leanMerge = narrow ? (lean ? narrowMerge : nullptr) : (lean && (prevSize == 0 || grouped)) ? rtc_merge_lookup(device, plan, nd, partBits, a, widen, compact) : nullptr;
+    RtcKernel leanMerge = imageMode ? imageMerge
+                          : narrow  ? (lean ? narrowMerge : nullptr)
+                          : (lean && (prevSize == 0 || grouped)) ? rtc_merge_lookup(device, plan, nd, partBits, a, widen, compact) : nullptr;
+    RtcImageArgs imageArgs{nullptr, nullptr, nullptr, nullptr, 0u};
+    if (imageMode) {
+      imageArgs.in = imageMode == 2 ? prev.image.get() : nullptr;
+      imageArgs.inCount = imageMode == 2 ? image_counts(prev.image.get()) : nullptr;
+      imageArgs.out = imageOut.get();
+      imageArgs.outCount = image_counts(imageOut.get());
+      imageArgs.knownOut = knownOut;
+      // an image-mode merge appends new groups behind the previous result: the row counter starts there
+      if (imageMode == 2 && prevSize > 0) hip_check(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws.outCount), prevSize, 1, stream), "hipMemsetD32Async");
+    }
+    const RtcImageArgs *imagePtr = imageMode ? &imageArgs : nullptr;
     if (prevToA) {
       const DimLayoutD prevLayout = make_dim_layout(prevKeys.NumDimsPerDimWidth);
       const int64_t tiles = (static_cast<int64_t>(prevSize) + kTileRows - 1) / kTileRows;
@@ -546,7 +719,7 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
     if (outRanges && !leanMerge && !tableMerge) hip_check(hipMemsetAsync(outRanges, 0, kRangesBytes, stream), "hipMemsetAsync");
 #define ARES_FUSED_CASE(ND)                                                                                            \
   case ND:                                                                                                             \
-    if (prevSize > 0 && !grouped && !narrow) {                                                                         \
+    if (prevSize > 0 && !grouped && !narrow && imageMode != 2) {                                                       \
       if (mw == 8)                                                                                                     \
         ARES_LAUNCH("hr_partition4_kernel", (hr_partition4_kernel<ND, 8>), grid_for(prevSize), kThreads, stream,        \
                     prevKeys.DimValues, prevCapacity, prevValues, 0u, a, prevSize, wsPrev, 0);                         \
@@ -563,7 +736,7 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
                   static_cast<uint32_t>(prevSize), a, batchRows, ws);                                                  \
     if (leanMerge || tableMerge)                                                                                       \
       rtc_merge_launch(leanMerge ? leanMerge : tableMerge, plan, prevKeys.DimValues, prevCapacity, prevValues,         \
-                       static_cast<uint32_t>(prevSize), outKeys.DimValues, outCapacity, outValues, ws, stream);        \
+                       static_cast<uint32_t>(prevSize), outKeys.DimValues, outCapacity, outValues, ws, stream, imagePtr); \
     else if (lean)                                                                                                     \
       ARES_LAUNCH("hr_fused_merge_kernel", (hr_fused_merge_kernel<ND, 4>), numParts, kThreads, stream, plan,            \
                   prevKeys.DimValues, prevCapacity, prevValues, static_cast<uint32_t>(prevSize), outKeys.DimValues,    \
@@ -580,12 +753,19 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
       SlowScope slow("read_result");
       res = read_result(ws, stream);
     }
-    mem_note_dim_rows(device, outKeys, 0, res.groups);  // what this attempt emitted
-    mem_note_write(device, outValues, static_cast<size_t>(mw) * res.groups);
-    if (narrow && res.needGeneric) {  // more groups in a partition than one table: only the generic merge takes rounds
+    if (imageMode == 2) {  // new groups' dimension rows and the rows copied over; the measure rows stay unwritten
+      if (res.groups > knownOut) mem_note_dim_rows(device, outKeys, knownOut, res.groups - knownOut);
+    } else {
+      mem_note_dim_rows(device, outKeys, 0, res.groups);  // what this attempt emitted
+      mem_note_write(device, outValues, static_cast<size_t>(mw) * res.groups);
+    }
+    if ((narrow || imageMode == 2) && res.needGeneric) {
+      // more groups in a partition than one table: only the generic merge takes rounds (the caller runs the unfused
+      // sequence, which reads the previous result's vectors: complete, whatever this attempt wrote into the output)
       r.buf->mark_idle();
       return -1;
     }
+    if (imageMode == 1 && res.needGeneric) imageMode = 0;  // (the generic merge below leaves no image)
     if (leanMerge && res.needGeneric && !res.overflow && !(grouped && res.stale)) {
       // a partition holds more groups than one LDS table: the generic multi-round merge over the same records
       hip_check(hipMemsetAsync(ws.outCount, 0, 4 * sizeof(uint32_t), stream), "hipMemsetAsync");
@@ -609,6 +789,7 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
     if (grouped && res.stale) {
       grouped_note_write(device, prevKeys.DimValues, slots.row_bytes() * prevCapacity);
       grouped = false;
+      imageMode = 0;
       continue;
     }
     break;
@@ -628,6 +809,15 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
   }
   if (outRanges) {
     GroupedState s{device, outKeys.DimValues, outValues, outCapacity, slots, mw, static_cast<int>(res.groups), partBits, outRangesRef};
+    if (imageMode == 2) {  // rows in order of first appearance: no ranges; the measure rows are the image's value plane
+      s.ranges = nullptr;
+      s.image = imageOut;
+      s.lineage = prev.lineage;
+      s.lazyValues = true;
+    } else if (imageMode == 1) {
+      s.image = imageOut;
+      s.lineage = ++g_lineage;
+    }
     if (res.groups > 0) grouped_register(s);
   }
   return static_cast<int>(res.groups);

@@ -1111,6 +1111,14 @@ struct RtcMergeArgs {  // mirrors `struct MArgs` of the generated source
   const uint4 *recA;  // region A (read by kernels generated with `regionA` only)
   const uint32_t *cursorsA;
   uint64_t capA;
+  // table images (kernels generated with `image`): kSlots uint4 per partition = [keys u32 x kSlots][positions u32 x kSlots]
+  // [values u64 x kSlots]; one group count per partition; knownOut: leading rows of the output dimension vector that already
+  // hold the query's groups
+  const uint4 *imgIn;
+  uint4 *imgOut;
+  const uint32_t *imgInCount;
+  uint32_t *imgOutCount;
+  uint32_t knownOut, pad2;
 };
 static_assert(sizeof(RtcMergeArgs) % 8 == 0, "MArgs is passed as one buffer");
 
@@ -1120,9 +1128,19 @@ static_assert(sizeof(RtcMergeArgs) % 8 == 0, "MArgs is passed as one buffer");
 // is a row of the input vectors).
 // regionA: the partition's records also come from region A — 16-byte {row, hash, value} records, what the TABLE-mode
 // scan emits (one per group and workgroup) — ahead of the region-B runs.
+// image: the partition's LDS table persists between the HashReduce calls of a query (hash_reduce_lds.hip "table image"):
+//   1  the kernel as above, and at the end it leaves its table in HBM — keys (NEWG cleared), the output position of every
+//      group where the representative row stood, values: 128 KB per partition, coalesced stores;
+//   2  the kernel STARTS from the previous call's image (coalesced loads instead of re-hashing and re-inserting every
+//      previous group), takes the batch's records through it, and emits only what is new: dimension rows of the groups
+//      first seen in this batch, appended behind the previous result (a group keeps its position for the life of the
+//      query), the dimension rows the output vector has not seen yet copied over from the input vector, and the table
+//      image again.  The measure vector is NOT written: it is defined by the image (materialised by
+//      hr_image_values_kernel when somebody reads it).
 std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w, int vectorVW = 0,
-                           bool compact = false, bool regionA = false) {
+                           bool compact = false, bool regionA = false, int image = 0) {
   if (nd < 1 || nd > kFusedDims) return "";
+  if (image && vectorVW) return "";
   if (compact && (vectorVW || partBits < 3)) return "";
   if (partBits < 2) return "";  // the 32-bit table keys need two spare hash bits (small inputs: the generic merge)
   const SlotLayout SL = slot_layout(plan, nd);
@@ -1132,7 +1150,8 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
     << "struct MArgs { const u32 *vals[" << kFusedCols << "]; const u8 *nulls[" << kFusedCols << "]; const u32 *recB; const u32 *countsB;\n"
        "  const u32 *prevRanges; const u8 *prevDims; const u8 *prevValues; u8 *dimOut; u8 *outValues; u32 *outCount; u32 *outRanges;\n"
        "  u64 prevCapacity, outCapacity; u32 bitOff[" << kFusedCols << "]; u32 capB, streams, prevSize, chunkRows; u64 *phases; u32 k[" << kNumConsts << "]; u32 pad;\n"
-       "  const uint4 *recA; const u32 *cursorsA; u64 capA; };\n"
+       "  const uint4 *recA; const u32 *cursorsA; u64 capA;\n"
+       "  const uint4 *imgIn; uint4 *imgOut; const u32 *imgInCount; u32 *imgOutCount; u32 knownOut, pad2; };\n"
        "#define ND " << nd << "\n#define VB " << SL.valueBytes << "\n#define PB " << partBits << "\n#define NP " << (1 << partBits) << "\n"
        "#define SLOTS " << hr::kSlots << "\n#define LIMIT " << hr::kMergeLimit << "u\n#define RANGEWORDS " << hr::kRangeWords
     << "\n#define MAXRANGES " << hr::kMaxRanges << "u\n"
@@ -1287,16 +1306,27 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
   const bool wide = a.width == 8;
   o << "extern \"C\" __global__ void __launch_bounds__(1024) hr_merge_rtc(MArgs a) {\n"
        "  __shared__ __attribute__((aligned(16))) u32 sKeys[SLOTS];\n"
-       "  __shared__ u32 sRows[SLOTS];\n"
-       "  __shared__ u64 sVals[SLOTS];\n"
+       "  __shared__ __attribute__((aligned(16))) u32 sRows[SLOTS];\n"
+       "  __shared__ __attribute__((aligned(16))) u64 sVals[SLOTS];\n"
        "  __shared__ u32 sRunCount[256];\n"
        "  __shared__ u32 sQueue[16u * QCAP * QW];\n"
        "  __shared__ u32 sClaimed, sOverflow, sCount, sBase, sEmit;\n"
        "  const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, p = blockIdx.x;\n"
-       "  STAMP(0)\n"
-       "  for (u32 s = tid; s < SLOTS; s += 1024u) { sKeys[s] = 0u; sRows[s] = 0xFFFFFFFFu; sVals[s] = IDENT; }\n"
-       "  if (tid == 0u) { sClaimed = 0u; sOverflow = 0u; sCount = 0u; sEmit = 0u; }\n"
-       "  const u32 G = a.streams;\n"
+       "  STAMP(0)\n";
+  if (image == 2)  // the table as the query's previous HashReduce left it
+    o << "  {\n"
+         "    const uint4 *img = a.imgIn + (u64)p * SLOTS;\n"
+         "    for (u32 i = tid; i < SLOTS / 4u; i += 1024u) {\n"
+         "      reinterpret_cast<uint4 *>(sKeys)[i] = img[i];\n"
+         "      reinterpret_cast<uint4 *>(sRows)[i] = img[SLOTS / 4u + i];\n"
+         "    }\n"
+         "    for (u32 i = tid; i < SLOTS / 2u; i += 1024u) reinterpret_cast<uint4 *>(sVals)[i] = img[SLOTS / 2u + i];\n"
+         "    if (tid == 0u) { sClaimed = a.imgInCount[p]; sOverflow = 0u; sCount = 0u; sEmit = 0u; }\n"
+         "  }\n";
+  else
+    o << "  for (u32 s = tid; s < SLOTS; s += 1024u) { sKeys[s] = 0u; sRows[s] = 0xFFFFFFFFu; sVals[s] = IDENT; }\n"
+         "  if (tid == 0u) { sClaimed = 0u; sOverflow = 0u; sCount = 0u; sEmit = 0u; }\n";
+  o << "  const u32 G = a.streams;\n"
        "  if (tid < G) sRunCount[tid] = a.countsB[(u64)tid * NP + p];\n"
        "  const u32 *ranges = a.prevRanges ? a.prevRanges + (u64)p * RANGEWORDS : nullptr;\n"
        "  u32 nRanges = ranges ? ranges[0] : 0u;\n"
@@ -1432,8 +1462,82 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
        "  }\n"
        "  __syncthreads();\n"
        "  STAMP(3)\n"
-       "  if (sOverflow) { if (tid == 0u) a.outCount[3] = 1u; return; }\n"  // more groups than one table: the generic merge takes over
-       // emit: count occupied slots, reserve output rows once, then copy (as hr::merge_body)
+       "  if (sOverflow) { if (tid == 0u) a.outCount[3] = 1u; return; }\n";  // more groups than one table: the generic merge takes over
+  // the image's three planes leave (or reach) a partition with 16-byte accesses, consecutive lanes consecutive addresses
+  const char *kStoreKeysPos =
+      "    for (u32 i = tid; i < SLOTS / 4u; i += 1024u) {\n"
+      "      img[i] = reinterpret_cast<const uint4 *>(sKeys)[i];\n"
+      "      img[SLOTS / 4u + i] = reinterpret_cast<const uint4 *>(sRows)[i];\n"
+      "    }\n";
+  const char *kStoreVals = "    for (u32 i = tid; i < SLOTS / 2u; i += 1024u) img[SLOTS / 2u + i] = reinterpret_cast<const uint4 *>(sVals)[i];\n";
+  if (image == 2) {
+    // ---- groups first seen in this batch: their dimension rows, appended behind the previous result -------------------
+    o << "  u32 mineNew = 0u;\n"
+         "#pragma unroll\n"
+         "  for (int k = 0; k < SLOTS / 1024; k++) mineNew += (sKeys[tid + (u32)k * 1024u] & NEWG) != 0u;\n"
+         "  if (mineNew) __hip_atomic_fetch_add(&sCount, mineNew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
+         "  __syncthreads();\n"
+         "  const u32 totalNew = sCount;\n"
+         "  if (tid == 0u) sBase = totalNew ? atomicAdd(a.outCount, totalNew) : 0u;\n"  // (outCount starts at the previous result's size)
+         "  __syncthreads();\n"
+         "  STAMP(4)\n"
+         "  u8 *nullsOut = a.dimOut + (u64)VB * a.outCapacity;\n"
+         "  if (totalNew) {\n"
+         "#pragma unroll\n"
+         "    for (int half = 0; half < 2; half++) {\n"
+         "      u32 dv[4][ND], nv[4][ND], at[4]; bool has[4];\n"
+         "#pragma unroll\n"
+         "      for (int kk = 0; kk < 4; kk++) {\n"
+         "        const u32 s = tid + (u32)(half * 4 + kk) * 1024u;\n"
+         "        has[kk] = (sKeys[s] & NEWG) != 0u;\n"
+         "        const u64 m = __ballot(has[kk]);\n"
+         "        u32 waveBase = 0u;\n"
+         "        if (lane == 0u && m) waveBase = __hip_atomic_fetch_add(&sEmit, (u32)__popcll(m), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
+         "        waveBase = (u32)__builtin_amdgcn_readfirstlane((int)waveBase);\n"
+         "        at[kk] = sBase + waveBase + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));\n"
+         "        if (has[kk]) eval_row(a, sRows[s] - a.prevSize, dv[kk], nv[kk]);\n"  // (a new group's representative is a row of the batch)
+         "      }\n"
+         "#pragma unroll\n"
+         "      for (int kk = 0; kk < 4; kk++) {\n"
+         "        if (!has[kk]) continue;\n"
+         "        const u32 s = tid + (u32)(half * 4 + kk) * 1024u;\n";
+    for (int d = 0; d < nd; d++)
+      o << "        " << slot_store(SL, d, "a.dimOut", "a.outCapacity", "at[kk]", "dv[kk][" + std::to_string(d) + "]") << " nullsOut[(u64)" << d
+        << " * a.outCapacity + at[kk]] = (u8)nv[kk][" << d << "];\n";
+    o << "        sRows[s] = at[kk];\n"       // from now on the slot holds the group's position
+         "        sKeys[s] &= ~NEWG;\n"
+         "      }\n"
+         "    }\n"
+         "  }\n"
+         "  __syncthreads();\n"
+         // ---- the image again: values always; keys and positions unless the output's image already holds this very set
+         // (a partition's count only grows, and both images descend from one table: equal counts = equal key planes)
+         "  {\n"
+         "    uint4 *img = a.imgOut + (u64)p * SLOTS;\n"
+         "    const u32 newCount = a.imgInCount[p] + totalNew;\n"
+         "    if (a.imgOutCount[p] != newCount) {\n"
+      << kStoreKeysPos
+      << "    }\n"
+      << kStoreVals
+      << "    __syncthreads();\n"
+         "    if (tid == 0u) a.imgOutCount[p] = newCount;\n"
+         "  }\n"
+         // ---- dimension rows [knownOut, prevSize) the output vector has not seen yet: this workgroup's share, copied over
+         "  if (a.knownOut < a.prevSize) {\n"
+         "    const u8 *nullsIn = a.prevDims + (u64)VB * a.prevCapacity;\n"
+         "    const u32 n = a.prevSize - a.knownOut, share = (n + NP - 1u) / NP;\n"
+         "    const u32 lo = a.knownOut + p * share, hi = lo + share < a.prevSize ? lo + share : a.prevSize;\n"
+         "    for (u32 r = lo + tid; r < hi; r += 1024u) {\n";
+    for (int d = 0; d < nd; d++)
+      o << "      " << slot_store(SL, d, "a.dimOut", "a.outCapacity", "r", slot_load(SL, d, "a.prevDims", "a.prevCapacity", "r")) << " nullsOut[(u64)" << d
+        << " * a.outCapacity + r] = nullsIn[(u64)" << d << " * a.prevCapacity + r];\n";
+    o << "    }\n"
+         "  }\n"
+         "  STAMP(5)\n"
+         "}\n";
+    return o.str();
+  }
+  o << // emit: count occupied slots, reserve output rows once, then copy (as hr::merge_body)
        "  u32 mineCount = 0u;\n"
        "#pragma unroll\n"
        "  for (int k = 0; k < SLOTS / 1024; k++) mineCount += sKeys[tid + (u32)k * 1024u] != 0u;\n"
@@ -1448,8 +1552,8 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
        "  }\n"
        "  __syncthreads();\n"
        "  STAMP(4)\n"
-       "  if (!total) return;\n"
-       "  const u8 *nullsIn = a.prevDims + (u64)VB * a.prevCapacity;\n"
+    << (image == 1 ? "" : "  if (!total) return;\n")  // (an empty partition leaves an empty image)
+    << "  const u8 *nullsIn = a.prevDims + (u64)VB * a.prevCapacity;\n"
        "  u8 *nullsOut = a.dimOut + (u64)VB * a.outCapacity;\n"
        "#pragma unroll\n"
        "  for (int half = 0; half < 2; half++) {\n"
@@ -1495,8 +1599,17 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
   }
   o << (wide ? "      reinterpret_cast<u64 *>(a.outValues)[at[kk]] = sVals[s];\n"
              : "      reinterpret_cast<u32 *>(a.outValues)[at[kk]] = (u32)sVals[s];\n")
+    << (image == 1 ? "      sRows[s] = at[kk];\n      sKeys[s] &= ~NEWG;\n" : "")  // the image: a group's slot holds its position
     << "    }\n"
-       "  }\n"
+       "  }\n";
+  if (image == 1)
+    o << "  __syncthreads();\n"
+         "  {\n"
+         "    uint4 *img = a.imgOut + (u64)p * SLOTS;\n"
+      << kStoreKeysPos << kStoreVals
+      << "    if (tid == 0u) a.imgOutCount[p] = total;\n"
+         "  }\n";
+  o <<
        "  STAMP(5)\n"
        "}\n";
   return o.str();
@@ -2086,15 +2199,15 @@ std::string rtc_vector_merge_source(int nd, int vw, int partBits, const AggSpec 
 }
 
 RtcKernel rtc_merge_lookup(int device, const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w, bool compact,
-                           bool wait, bool regionA) {
+                           bool wait, bool regionA, int image) {
   if (!rtc_api().ok) return nullptr;
-  return front_lookup(shape_key('m', device, plan, nd, partBits, (compact ? 1 : 0) | (regionA ? 2 : 0), &a, &w), device,
-                      [&] { return generate_merge(plan, nd, partBits, a, w, 0, compact, regionA); }, "hr_merge_rtc", wait);
+  return front_lookup(shape_key('m', device, plan, nd, partBits, (compact ? 1 : 0) | (regionA ? 2 : 0) | (image << 2), &a, &w), device,
+                      [&] { return generate_merge(plan, nd, partBits, a, w, 0, compact, regionA, image); }, "hr_merge_rtc", wait);
 }
 
 void rtc_merge_launch(const RtcKernel &kernel, const FusedPlanD &plan, const uint8_t *prevDims, size_t prevCapacity, const uint8_t *prevValues,
                       uint32_t prevSize, uint8_t *dimOut, size_t outCapacity, uint8_t *outValues, const hr::Workspace &ws,
-                      hipStream_t stream) {
+                      hipStream_t stream, const RtcImageArgs *image) {
   RtcMergeArgs args;
   memset(&args, 0, sizeof(args));
   for (int c = 0; c < plan.numCols; c++) {
@@ -2121,6 +2234,13 @@ void rtc_merge_launch(const RtcKernel &kernel, const FusedPlanD &plan, const uin
   args.streams = static_cast<uint32_t>(ws.streams);
   args.prevSize = prevSize;
   args.chunkRows = ws.chunkRows;
+  if (image) {
+    args.imgIn = reinterpret_cast<const uint4 *>(image->in);
+    args.imgOut = reinterpret_cast<uint4 *>(image->out);
+    args.imgInCount = image->inCount;
+    args.imgOutCount = image->outCount;
+    args.knownOut = image->knownOut;
+  }
   size_t size = sizeof(args);
   void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
   static uint64_t *phases = nullptr;
@@ -2156,8 +2276,9 @@ void rtc_merge_launch(const RtcKernel &kernel, const FusedPlanD &plan, const uin
   }
 }
 
-std::string rtc_merge_source(const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w, bool compact, bool regionA) {
-  return generate_merge(plan, nd, partBits, a, w, 0, compact, regionA);
+std::string rtc_merge_source(const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w, bool compact, bool regionA,
+                             int image) {
+  return generate_merge(plan, nd, partBits, a, w, 0, compact, regionA, image);
 }
 
 // source text of the kernel a plan would get (tests / tools; empty = unsupported shape)

@@ -56,11 +56,21 @@ void rtc_vector_scan_launch(const RtcKernel &kernel, const uint8_t *dimValues, s
 // partition-grouped ranges or none, one round over the whole hash range).  It raises outCount[3] when a
 // partition holds more groups than one LDS table: the caller then runs the generic merge.
 // regionA: the records come from region A as well (TABLE-mode scans) — the merge of narrow plans' low-cardinality batches.
+// image: 0 = none; 1 = the merge also leaves the partition's LDS table in HBM ("table image": keys, each group's output
+// position, values — 128 KB per partition); 2 = the merge STARTS from the previous call's image, emits the dimension rows of
+// new groups only (appended: a group keeps its position) and writes the image again — the measure vector stays unwritten.
 RtcKernel rtc_merge_lookup(int device, const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w, bool compact,
-                           bool wait = false, bool regionA = false);
+                           bool wait = false, bool regionA = false, int image = 0);
+struct RtcImageArgs {  // device pointers: images of hr::kSlots x 16 bytes per partition, one group count per partition
+  const void *in;
+  void *out;
+  const uint32_t *inCount;
+  uint32_t *outCount;
+  uint32_t knownOut;  // leading rows of the output dimension vector that already hold the query's groups (image == 2)
+};
 void rtc_merge_launch(const RtcKernel &kernel, const FusedPlanD &plan, const uint8_t *prevDims, size_t prevCapacity,
                       const uint8_t *prevValues, uint32_t prevSize, uint8_t *dimOut, size_t outCapacity, uint8_t *outValues,
-                      const hr::Workspace &ws, hipStream_t stream);
+                      const hr::Workspace &ws, hipStream_t stream, const RtcImageArgs *image = nullptr);
 // ... and for what the vector-sourced scan produces (launched with rtc_merge_launch and an empty plan: every
 // row, old or new, is a row of the input vectors passed as prevDims / prevValues)
 RtcKernel rtc_vector_merge_lookup(int device, int nd, int vw, int partBits, const AggSpec &a, bool wait = false);
@@ -69,7 +79,7 @@ RtcKernel rtc_vector_merge_lookup(int device, int nd, int vw, int partBits, cons
 std::string rtc_scan_source(const FusedPlanD &plan, int nd, int partBits, bool compact = false);
 std::string rtc_table_scan_source(const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w);
 std::string rtc_merge_source(const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w, bool compact = false,
-                             bool regionA = false);
+                             bool regionA = false, int image = 0);
 std::string rtc_vector_scan_source(int nd, int vw, int partBits);
 std::string rtc_vector_merge_source(int nd, int vw, int partBits, const AggSpec &a);
 

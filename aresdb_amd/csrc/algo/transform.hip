@@ -1922,6 +1922,9 @@ void materialize_index_vector(int device, const uint32_t *indexVector) {
 // exempt: the index vector whose pending filters the caller is about to extend (a filter call of the hot shape): its
 // compaction stays pending
 static void flush_deferred_impl(int device, const ByteRange *limboA, const ByteRange *limboB, const uint32_t *exempt = nullptr) {
+  // (before the deferral lock: measure rows a table image defines are written by hash_reduce_lds.hip under its own lock)
+  if (limboA) grouped_materialize_for_read(device, limboA->lo, static_cast<size_t>(limboA->hi - limboA->lo));
+  if (limboB) grouped_materialize_for_read(device, limboB->lo, static_cast<size_t>(limboB->hi - limboB->lo));
   DeferLock lock(device);
   poll_error_words(device);
   // lazy fills (like work a HashReduce skipped, below) are only written for byte ranges the caller reads: they live in
@@ -2565,6 +2568,19 @@ int run_filter_rows(int device, hipStream_t stream, FastOperands f, uint32_t *in
   {
     DeferLock lock(device);
     auto ins = t_state->compactions.find(indexVector);
+    {
+      // The eligibility the caller established (row_space_eligible) is re-established HERE, under the lock that books the
+      // filter: between the caller's check and this point another thread's flush may have applied this vector's pending
+      // filters (replay + compaction) and dropped the entry — the vector is then no longer "iota with filters pending",
+      // and counting this filter over the batch's first n rows would count the wrong rows (found by the soak test: one
+      // count in 512 four-thread programs).  The journal already holds this filter (journal_filter ran first).
+      auto jr = t_state->journals.find(indexVector);
+      const size_t journalled = (jr != t_state->journals.end() && jr->second.valid) ? jr->second.filters.size() : 0;
+      const bool first = ins == t_state->compactions.end() && journalled == 1 && jr->second.n0 == n;
+      const bool next = ins != t_state->compactions.end() && !ins->second.todo.empty() && ins->second.stream == stream &&
+                        ins->second.applied + ins->second.todo.size() + 1 == journalled && ins->second.lastCount == n;
+      if (!first && !next) return -1;
+    }
     if (ins == t_state->compactions.end()) {  // the batch's first filter: the vector is iota(0 .. n)
       PendingCompact fresh{};
       fresh.device = device;
@@ -2726,9 +2742,12 @@ static int run_filter(const InputVector *ins, int arity, uint32_t *indexVector, 
     journal_filter(device, indexVector, &f, p.a.length, n);
   else
     journal_filter(device, indexVector, nullptr, 0, 0);
-  if (rowSpace && fast && journal_is_valid(device, indexVector))
-    return run_filter_rows(device, stream, f, indexVector, pred, n, p.a.length, virtualIdx);
-  if (rowSpace) {  // (cannot happen: eligibility implies all of the above) the predicate vector is written after all
+  if (rowSpace && fast && journal_is_valid(device, indexVector)) {
+    const int counted = run_filter_rows(device, stream, f, indexVector, pred, n, p.a.length, virtualIdx);
+    if (counted >= 0) return counted;
+    // (-1: somebody's flush applied the vector's pending filters since the eligibility check: the ordinary filter below)
+  }
+  if (rowSpace) {  // the predicate vector is written after all
     mem_note_write(device, pred, static_cast<size_t>(n));
     DeferLock lock(device);
     run_compaction(indexVector);
@@ -3042,6 +3061,7 @@ void hook_on_access(int device, const void *ptr, size_t bytes) {
   ReleaseSet released;
   try {
     DeviceGuard guard(device);
+    grouped_materialize_for_read(device, ptr, bytes);  // (measure rows a table image defines)
     DeferLock lock(device);
     for (auto it = t_state->iotas.begin(); it != t_state->iotas.end();) {
       const ByteRange v = range_of(it->first, 4ull * it->second.n);
@@ -3148,6 +3168,7 @@ void hook_on_stream_destroy(int device, void *streamPtr) {
 // launch, the blocks held for it are fenced behind it).
 void launch_pending_writers(int device, const void *ptr, size_t bytes) {
   if (!ptr || bytes == 0 || !defer_available()) return;
+  grouped_materialize_for_read(device, ptr, bytes);
   const ByteRange r = range_of(ptr, bytes);
   ReleaseSet released;
   {

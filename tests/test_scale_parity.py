@@ -41,6 +41,11 @@ C3_VARIANTS = [
     ("eager", {"ARES_DEFER": "0"}, MID),
     ("ungrouped", {"ARES_GROUPED": "0"}, MID),
     ("live_batches", {}, LIVE + ["--streams", "2"]),
+    # table images (the default for DIRECT-mode batches): the same run with every block that is handed out as cleared checked
+    # on the device (an image-mode merge leaves the measure vector unwritten and must not report it written), and with the
+    # images switched off (the merge re-inserts the previous groups from their partition-grouped ranges, as round 4 did)
+    ("live_batches_verify_clean", {"ARES_MEM_VERIFY_CLEAN": "1"}, LIVE + ["--streams", "2"]),
+    ("live_batches_no_image", {"ARES_IMAGE": "0"}, LIVE + ["--streams", "2"]),
     # the query shape the Go host really issues: ts >= from, ts < to in front of the query's own filter — counted in row
     # space, the second one predicted from the stream's previous batch (five batches per stream); and the same with the
     # filters taking the predicate-vector path of rounds 1-3

@@ -70,6 +70,10 @@ int main(int argc, char **argv) {
   if (int rc = build(rtc_scan_source(p, 4, 9, true), "_compact", "compact scan")) return rc;
   if (int rc = build(rtc_merge_source(p, 4, 9, agg, w, true), "_cmerge", "compact merge")) return rc;
   if (int rc = build(rtc_table_scan_source(p, 4, 9, agg, w), "_table", "table scan")) return rc;
+  // table images (hash_reduce_lds.hip): the merge that leaves its table in HBM, and the one that starts from it
+  if (int rc = build(rtc_merge_source(p, 4, 9, agg, w, true, false, 1), "_cmerge_img1", "compact merge + image out")) return rc;
+  if (int rc = build(rtc_merge_source(p, 4, 9, agg, w, true, false, 2), "_cmerge_img2", "compact merge from image")) return rc;
+  if (int rc = build(rtc_merge_source(p, 4, 9, agg, w, false, false, 2), "_merge_img2", "merge from image")) return rc;
   {  // another shape: two dimensions, int32 measure summed into 4 bytes, no nulls, 8 partitions
     FusedPlanD q = p;
     q.numCols = 3;
@@ -103,6 +107,7 @@ int main(int argc, char **argv) {
     if (int rc = build(rtc_merge_source(t, 2, 9, agg, w, false), "_nmerge", "narrow merge")) return rc;
     if (int rc = build(rtc_table_scan_source(t, 2, 9, agg, w), "_ntable", "narrow table scan")) return rc;
     if (int rc = build(rtc_merge_source(t, 2, 9, agg, w, false, true), "_namerge", "narrow region-A merge")) return rc;
+    if (int rc = build(rtc_merge_source(t, 2, 9, agg, w, true, false, 2), "_ncmerge_img2", "narrow compact merge from image")) return rc;
     // signed narrow columns and a 1-byte slot: dimensions [Int16 column -> 2-byte slot, Int8 column -> 1-byte slot], no nulls
     FusedPlanD u = t;
     u.numFilters = 0; u.numCols = 3;

@@ -690,7 +690,7 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
     ws.widen = widen;
     ws.chunkRows = static_cast<uint32_t>(chunkTiles) * 4096u;
     ws.rowBase = static_cast<uint32_t>(prevSize);
-    ws.prevRanges = grouped ? prev.ranges.get() : nullptr;
+    ws.prevRanges = (grouped && imageMode != 2) ? prev.ranges.get() : nullptr;  // (an image-mode merge has them in its image)
     ws.outRanges = outRanges;
     Workspace wsPrev = ws;  // previous groups that are not grouped by partition: TABLE-mode pass into region A
     wsPrev.streams = 0;

@@ -725,6 +725,9 @@ def main(argv=None, backend=None, tensor_device=None):
             leg("time_filters_ts_ge_lt_then_d1", {}, big + ["--ts-range", "3600,601200"])
             leg(f"live_batches_{LIVE_BATCH_ROWS}_rows", {}, common + ["--batch-rows", str(LIVE_BATCH_ROWS)])
             # lower-cardinality variants of the same query (same filter and measure; fewer group-by dimensions)
+            # the reference's own example table and queries at 1 B rows (examples/1k_trips: request_at Uint32, city_id Uint16 in
+            # a 2-byte dimension slot, status Uint8): SUM(fare) through HashReduce, COUNT(*) through Sort + Reduce, key-level checked
+            tool_leg("trips_shaped_1B_rows_u16_dim_u8_filter", "trips", 600, 45)
             leg("groups_100_dims_d2_d3", {}, big + ["--dims", "d2,d3"])        # TABLE-mode scan, ~100 groups, 4 columns read
             leg("groups_15k_dims_ts_d1", {}, big + ["--dims", "ts,d1"])        # DIRECT-mode kernels (> 6000 groups)
             tool_leg("c2_100M_rows_filter_count", "c2", 300, 15)
@@ -784,6 +787,7 @@ def main(argv=None, backend=None, tensor_device=None):
             return None
         c2 = legs.get("c2_100M_rows_filter_count")
         c4 = legs.get("c4_spec_1B_rows_50M_keys")
+        tr = legs.get("trips_shaped_1B_rows_u16_dim_u8_filter")
         out["summary"] = {
             "value_rows_per_s": value, "ms_per_step": out["ms_per_step"], "check_groups": report["status"],
             "roofline_frac_dominant_kernel": None if roofline is None else round(roofline["frac"], 4),
@@ -800,6 +804,8 @@ def main(argv=None, backend=None, tensor_device=None):
             "cold_new_constants_ms": _leg("cold_process_warm_disk_cache", "new_constants_query_ms"),
             "c2_ms_per_query": [round(r["ms"], 3) for r in c2] if isinstance(c2, list) else c2,
             "c4_spec_ms": [round(r["ms"], 1) for r in c4] if isinstance(c4, list) else c4,
+            "trips_shaped": [{"query": r["query"], "ms_per_1B_rows": round(r["ms_per_step"], 2), "rows_per_s": round(r["rows_per_s"]),
+                              "check": r["key_level_check"]} for r in tr] if isinstance(tr, list) else tr,
             "host_batches_pcie_inclusive_rows_per_s": (legs.get("host_batches") or {}).get("pcie_inclusive", {}).get("rows_per_sec")
             if isinstance(legs.get("host_batches"), dict) else None,
         }

@@ -705,8 +705,6 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
       imageArgs.out = imageOut.get();
       imageArgs.outCount = image_counts(imageOut.get());
       imageArgs.knownOut = knownOut;
-      // an image-mode merge appends new groups behind the previous result: the row counter starts there
-      if (imageMode == 2 && prevSize > 0) hip_check(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ws.outCount), prevSize, 1, stream), "hipMemsetD32Async");
     }
     const RtcImageArgs *imagePtr = imageMode ? &imageArgs : nullptr;
     if (prevToA) {
@@ -753,6 +751,7 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
       SlowScope slow("read_result");
       res = read_result(ws, stream);
     }
+    if (imageMode == 2) res.groups += static_cast<uint32_t>(prevSize);  // (the kernel counted the groups it appended)
     if (imageMode == 2) {  // new groups' dimension rows and the rows copied over; the measure rows stay unwritten
       if (res.groups > knownOut) mem_note_dim_rows(device, outKeys, knownOut, res.groups - knownOut);
     } else {

@@ -1393,7 +1393,39 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
          "    }\n"
          "  }\n"
          "  __syncthreads();\n";
-  o << // the partition's runs: every wavefront streams whole runs, three register stages
+  // Small batches (live batches: 2 Mi rows, 512 tiles, two per scanning workgroup) leave every partition a few hundred runs
+  // of a dozen or two records — one to three lines each.  Walking them run by run, sixteen per wavefront, is a chain of
+  // dependent loads (20 us of a partition's 33 at 2 Mi rows); when no run is longer than four lines, the first L lines of
+  // EVERY run of the partition are fetched at once instead (L = lines of the longest run): a few 16-byte loads per lane, all
+  // in flight together.
+  o << "  u32 maxRun = 0u;\n"
+       "  for (u32 g = lane; g < G; g += 64u) { const u32 c = sRunCount[g]; maxRun = c > maxRun ? c : maxRun; }\n"
+       "#pragma unroll\n"
+       "  for (int off = 32; off > 0; off >>= 1) { const u32 t = (u32)__shfl_xor((int)maxRun, off); maxRun = t > maxRun ? t : maxRun; }\n"
+       "  const u32 LPR = (maxRun + " << (compact ? "13u) / 14u" : "7u) / 8u") << ";\n"   // lines of the longest run
+       "  if (G > 0u && LPR <= 4u && LPR <= a.capB" << (compact ? "" : " / 8u") << ") {\n"
+       "    u32 qn = 0u;\n"
+       "    u32 *queue = sQueue + wave * (QCAP * QW);\n"
+       "    const u32 units = G * 8u * LPR;\n"
+       "    for (u32 base = 0u; base < units; base += 4096u) {\n"
+       "      Stage s;\n"
+       "#pragma unroll\n"
+       "      for (int k = 0; k < 4; k++) {\n"
+       "        const u32 u = base + (u32)k * 1024u + tid;\n"  // unit u = lane (u & 7) of line (u >> 3) % LPR of stream (u >> 3) / LPR
+       "        const bool in = u < units;\n"
+       "        const u32 ul = in ? u >> 3 : 0u, g = ul / LPR, l = ul - g * LPR, cnt = in ? sRunCount[g] : 0u;\n"
+    << (compact ? "        const u32 here = cnt > l * 14u ? cnt - l * 14u : 0u;\n"   // records of the run in this line and behind it
+                  "        s.r[k] = reinterpret_cast<const uint4 *>(a.recB)[(((u64)g * NP + p) * a.capB + l) * 8u + (u & 7u)];\n"
+                  "        s.n[k] = here ? 64u : 0u; s.rem[k] = (lane >> 3) * 14u + here; s.rb[k] = a.prevSize + g * a.chunkRows;\n"
+                : "        const u32 here = cnt > l * 8u ? cnt - l * 8u : 0u;\n"
+                  "        s.r[k] = reinterpret_cast<const uint4 *>(a.recB)[((u64)g * NP + p) * a.capB + l * 8u + (u & 7u)];\n"
+                  "        s.n[k] = (u & 7u) < here ? 64u : 0u; s.rem[k] = 0u; s.rb[k] = 0u;\n")
+    << "      }\n"
+       "      consume(s, lane, p, sKeys, sRows, sVals, &sClaimed, &sOverflow, queue, qn);\n"
+       "    }\n"
+       "    while (qn) { const u32 take = qn < 64u ? qn : 64u; qn -= take; drain(queue, qn, take, lane, sKeys, sRows, sVals, &sClaimed, &sOverflow); }\n"
+       "  } else\n"
+       // the partition's runs: every wavefront streams whole runs, three register stages
        "  if (G > 0u) {\n"
        "    const uint4 *dummy = reinterpret_cast<const uint4 *>(a.recB);\n"
        "    u32 j = 0u, off = 0u, qn = 0u;\n"
@@ -1478,7 +1510,7 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
          "  if (mineNew) __hip_atomic_fetch_add(&sCount, mineNew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
          "  __syncthreads();\n"
          "  const u32 totalNew = sCount;\n"
-         "  if (tid == 0u) sBase = totalNew ? atomicAdd(a.outCount, totalNew) : 0u;\n"  // (outCount starts at the previous result's size)
+         "  if (tid == 0u) sBase = a.prevSize + (totalNew ? atomicAdd(a.outCount, totalNew) : 0u);\n"  // (outCount counts the NEW groups)
          "  __syncthreads();\n"
          "  STAMP(4)\n"
          "  u8 *nullsOut = a.dimOut + (u64)VB * a.outCapacity;\n"
@@ -2059,9 +2091,19 @@ void launch_scan(const RtcKernel &kernel, RtcArgs &args, int grid, int length, h
 bool rtc_scan_available() { return rtc_api().ok; }
 
 // number of workgroups (= private streams per partition) the specialised kernels want for `rows` rows
+// ARES_SCAN_MIN_TILES (experiments): at least that many tiles per scanning workgroup — fewer, longer runs for the merge of a
+// small batch, a longer scan.  Measured at 2 Mi-row batches (profiles/r5_experiments.md): 2 tiles (what 256 workgroups give)
+// scan 0.024 + merge 0.051 ms, 4: 0.031 + 0.049, 8: 0.049 + 0.052 — the default (1: no constraint) stays.
 int rtc_scan_grid(int64_t rows) {
+  static const int64_t minTiles = [] {
+    const char *e = getenv("ARES_SCAN_MIN_TILES");
+    const long v = e ? atol(e) : 1;
+    return static_cast<int64_t>(v < 1 ? 1 : v);
+  }();
   const int64_t tiles = (rows + 4095) / 4096;
-  return static_cast<int>(tiles < hr::kMaxStreams ? (tiles < 1 ? 1 : tiles) : hr::kMaxStreams);
+  int64_t grid = tiles < hr::kMaxStreams ? (tiles < 1 ? 1 : tiles) : hr::kMaxStreams;
+  if (tiles > 1 && tiles / grid < minTiles) grid = (tiles + minTiles - 1) / minTiles;
+  return static_cast<int>(grid < 1 ? 1 : grid);
 }
 
 // tiles per workgroup of the compact scan, 0 when a chunk would not fit the record's row field
@@ -2160,7 +2202,9 @@ void rtc_table_scan_launch(const RtcKernel &kernel, const FusedPlanD &plan, uint
                            hipStream_t stream) {
   RtcArgs args;
   fill_scan_args(args, plan, rowBase, length, ws);
-  launch_scan(kernel, args, rtc_scan_grid(length), length, stream, "hr_table_scan_rtc");
+  const int64_t tiles = (static_cast<int64_t>(length) + 4095) / 4096;  // (one workgroup per tile up to a full device: a TABLE scan's
+  const int grid = static_cast<int>(tiles < hr::kMaxStreams ? (tiles < 1 ? 1 : tiles) : hr::kMaxStreams);  // records do not grow with it)
+  launch_scan(kernel, args, grid, length, stream, "hr_table_scan_rtc");
 }
 
 RtcKernel rtc_vector_scan_lookup(int device, int nd, int vw, int partBits, bool wait) {

@@ -539,9 +539,14 @@ def main(argv=None, backend=None, tensor_device=None):
     # The scan / merge kernels of this query shape are compiled in the background the first time the shape is seen
     # (a query never waits for hiprtc: it runs the generic kernels meanwhile).  One untimed priming pass, then wait
     # for the compiler — what a server's first query of the shape does for every later one.
-    ctx = run_shard(be, plan, vps, device_index, streams)
-    ctx.release()
-    rtc_state = be.rtc_wait() if on_gpu else None
+    rtc_state, compiles = None, -1
+    for _ in range(4):  # (a query's first batch, its later batches and the merges that start from a table image are different
+        ctx = run_shard(be, plan, vps, device_index, streams)  # kernels, each requested when the query first gets there)
+        ctx.release()
+        rtc_state = be.rtc_wait() if on_gpu else None
+        if rtc_state is None or rtc_state["compiles"] == compiles:
+            break
+        compiles = rtc_state["compiles"]
     # ---- the timed region: W warm-up steps, then exactly K steps between barrier + synchronize ----
     for _ in range(args.warmup):
         ctx = run_shard(be, plan, vps, device_index, streams)

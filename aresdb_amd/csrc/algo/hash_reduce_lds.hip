@@ -353,7 +353,7 @@ void make_regions(Regions &r, int partBits, int64_t rowsA, int64_t rowsB, int st
     }
   }
   bBytes = (bBytes + 255) / 256 * 256;
-  const size_t headBytes = (sizeof(uint32_t) * (numParts + 4) + 255) / 256 * 256;
+  const size_t headBytes = (sizeof(uint32_t) * (numParts + 8) + 255) / 256 * 256;  // cursors, outCount[4], the result ticket
   const size_t countsBytes = (sizeof(uint32_t) * static_cast<size_t>(numParts) * (streams > 0 ? streams : 1) + 255) / 256 * 256;
   const size_t aBytes = (sizeof(uint4) * ws.capA * numParts + 255) / 256 * 256;
   r.buf.reset(new StreamBuffer(headBytes + countsBytes + aBytes + bBytes + 256, stream));
@@ -373,6 +373,17 @@ struct MergeResult {
 MergeResult read_result(const Workspace &ws, hipStream_t stream) {
   uint32_t w[4] = {0, 0, 0, 0};
   read_back_u32(ws.outCount, w, 4, stream);
+  return MergeResult{w[0], w[1], w[2], w[3]};
+}
+// ... when the merge was generated at run time: its last workgroup has written the words into the thread's pinned slot
+// (ARES_RESULT_PINNED=0: the copy command behind the kernel, as before — A/B in profiles/r5_experiments.md)
+uint32_t *result_slot() {
+  static EnvSwitch<bool> on("ARES_RESULT_PINNED", [](const char *e) { return !(e && e[0] == '0'); });
+  return on.get() ? reinterpret_cast<uint32_t *>(pinned_words()) : nullptr;
+}
+MergeResult read_result_pinned(hipStream_t stream) {
+  hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+  const volatile uint32_t *w = result_slot();
   return MergeResult{w[0], w[1], w[2], w[3]};
 }
 
@@ -507,11 +518,11 @@ int hash_reduce_lds(int device, const DimensionVector &inputKeys, const uint8_t 
       FusedPlanD none;
       memset(&none, 0, sizeof(none));
       rtc_merge_launch(leanMerge, none, inputKeys.DimValues, capacity, inputValues, static_cast<uint32_t>(start), outputKeys.DimValues,
-                       capacity, outputValues, ws, stream);
+                       capacity, outputValues, ws, stream, nullptr, result_slot());
     } else {
       generic_merge();
     }
-    res = read_result(ws, stream);
+    res = (leanMerge && result_slot()) ? read_result_pinned(stream) : read_result(ws, stream);
     mem_note_dim_rows(device, outputKeys, 0, res.groups);  // what this attempt emitted
     mem_note_write(device, outputValues, static_cast<size_t>(a.width) * res.groups);
     if (leanMerge && res.needGeneric && !res.overflow && !(grouped && res.stale)) {
@@ -734,7 +745,8 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
                   static_cast<uint32_t>(prevSize), a, batchRows, ws);                                                  \
     if (leanMerge || tableMerge)                                                                                       \
       rtc_merge_launch(leanMerge ? leanMerge : tableMerge, plan, prevKeys.DimValues, prevCapacity, prevValues,         \
-                       static_cast<uint32_t>(prevSize), outKeys.DimValues, outCapacity, outValues, ws, stream, imagePtr); \
+                       static_cast<uint32_t>(prevSize), outKeys.DimValues, outCapacity, outValues, ws, stream, imagePtr, \
+                       result_slot());                                                                                 \
     else if (lean)                                                                                                     \
       ARES_LAUNCH("hr_fused_merge_kernel", (hr_fused_merge_kernel<ND, 4>), numParts, kThreads, stream, plan,            \
                   prevKeys.DimValues, prevCapacity, prevValues, static_cast<uint32_t>(prevSize), outKeys.DimValues,    \
@@ -749,7 +761,7 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
     }
     {
       SlowScope slow("read_result");
-      res = read_result(ws, stream);
+      res = ((leanMerge || tableMerge) && result_slot()) ? read_result_pinned(stream) : read_result(ws, stream);
     }
     if (imageMode == 2) res.groups += static_cast<uint32_t>(prevSize);  // (the kernel counted the groups it appended)
     if (imageMode == 2) {  // new groups' dimension rows and the rows copied over; the measure rows stay unwritten

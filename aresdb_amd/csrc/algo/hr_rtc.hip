@@ -1118,6 +1118,7 @@ struct RtcMergeArgs {  // mirrors `struct MArgs` of the generated source
   uint4 *imgOut;
   const uint32_t *imgInCount;
   uint32_t *imgOutCount;
+  uint32_t *hostOut;  // the calling thread's mapped pinned slot (null: the host copies outCount back)
   uint32_t knownOut, pad2;
 };
 static_assert(sizeof(RtcMergeArgs) % 8 == 0, "MArgs is passed as one buffer");
@@ -1151,7 +1152,13 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
        "  const u32 *prevRanges; const u8 *prevDims; const u8 *prevValues; u8 *dimOut; u8 *outValues; u32 *outCount; u32 *outRanges;\n"
        "  u64 prevCapacity, outCapacity; u32 bitOff[" << kFusedCols << "]; u32 capB, streams, prevSize, chunkRows; u64 *phases; u32 k[" << kNumConsts << "]; u32 pad;\n"
        "  const uint4 *recA; const u32 *cursorsA; u64 capA;\n"
-       "  const uint4 *imgIn; uint4 *imgOut; const u32 *imgInCount; u32 *imgOutCount; u32 knownOut, pad2; };\n"
+       "  const uint4 *imgIn; uint4 *imgOut; const u32 *imgInCount; u32 *imgOutCount; u32 *hostOut; u32 knownOut, pad2; };\n"
+       // The call's result words (groups, region overflow, stale ranges, crowded partition) reach the host without a copy
+       // command behind the kernel: the workgroup that finishes last writes them into the calling thread's mapped pinned slot
+       // (a.hostOut; outCount[4] is the ticket).  The host only waits for the stream.
+       "#define FINISH() { __syncthreads(); if (threadIdx.x == 0u && a.hostOut) { __threadfence(); \\\n"
+       "  if (atomicAdd(a.outCount + 4, 1u) == gridDim.x - 1u) { __threadfence(); const volatile u32 *oc = a.outCount; \\\n"
+       "    a.hostOut[0] = oc[0]; a.hostOut[1] = oc[1]; a.hostOut[2] = oc[2]; a.hostOut[3] = oc[3]; } } }\n"
        "#define ND " << nd << "\n#define VB " << SL.valueBytes << "\n#define PB " << partBits << "\n#define NP " << (1 << partBits) << "\n"
        "#define SLOTS " << hr::kSlots << "\n#define LIMIT " << hr::kMergeLimit << "u\n#define RANGEWORDS " << hr::kRangeWords
     << "\n#define MAXRANGES " << hr::kMaxRanges << "u\n"
@@ -1494,7 +1501,7 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
        "  }\n"
        "  __syncthreads();\n"
        "  STAMP(3)\n"
-       "  if (sOverflow) { if (tid == 0u) a.outCount[3] = 1u; return; }\n";  // more groups than one table: the generic merge takes over
+       "  if (sOverflow) { if (tid == 0u) a.outCount[3] = 1u; FINISH() return; }\n";  // more groups than one table: the generic merge takes over
   // the image's three planes leave (or reach) a partition with 16-byte accesses, consecutive lanes consecutive addresses
   const char *kStoreKeysPos =
       "    for (u32 i = tid; i < SLOTS / 4u; i += 1024u) {\n"
@@ -1566,6 +1573,7 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
     o << "    }\n"
          "  }\n"
          "  STAMP(5)\n"
+         "  FINISH()\n"
          "}\n";
     return o.str();
   }
@@ -1584,7 +1592,7 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
        "  }\n"
        "  __syncthreads();\n"
        "  STAMP(4)\n"
-    << (image == 1 ? "" : "  if (!total) return;\n")  // (an empty partition leaves an empty image)
+    << (image == 1 ? "" : "  if (!total) { FINISH() return; }\n")  // (an empty partition leaves an empty image)
     << "  const u8 *nullsIn = a.prevDims + (u64)VB * a.prevCapacity;\n"
        "  u8 *nullsOut = a.dimOut + (u64)VB * a.outCapacity;\n"
        "#pragma unroll\n"
@@ -1643,6 +1651,7 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
          "  }\n";
   o <<
        "  STAMP(5)\n"
+       "  FINISH()\n"
        "}\n";
   return o.str();
 }
@@ -2251,7 +2260,7 @@ RtcKernel rtc_merge_lookup(int device, const FusedPlanD &plan, int nd, int partB
 
 void rtc_merge_launch(const RtcKernel &kernel, const FusedPlanD &plan, const uint8_t *prevDims, size_t prevCapacity, const uint8_t *prevValues,
                       uint32_t prevSize, uint8_t *dimOut, size_t outCapacity, uint8_t *outValues, const hr::Workspace &ws,
-                      hipStream_t stream, const RtcImageArgs *image) {
+                      hipStream_t stream, const RtcImageArgs *image, uint32_t *hostOut) {
   RtcMergeArgs args;
   memset(&args, 0, sizeof(args));
   for (int c = 0; c < plan.numCols; c++) {
@@ -2285,6 +2294,7 @@ void rtc_merge_launch(const RtcKernel &kernel, const FusedPlanD &plan, const uin
     args.imgOutCount = image->outCount;
     args.knownOut = image->knownOut;
   }
+  args.hostOut = hostOut;
   size_t size = sizeof(args);
   void *config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
   static uint64_t *phases = nullptr;

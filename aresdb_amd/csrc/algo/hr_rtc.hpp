@@ -70,7 +70,9 @@ struct RtcImageArgs {  // device pointers: images of hr::kSlots x 16 bytes per p
 };
 void rtc_merge_launch(const RtcKernel &kernel, const FusedPlanD &plan, const uint8_t *prevDims, size_t prevCapacity,
                       const uint8_t *prevValues, uint32_t prevSize, uint8_t *dimOut, size_t outCapacity, uint8_t *outValues,
-                      const hr::Workspace &ws, hipStream_t stream, const RtcImageArgs *image = nullptr);
+                      const hr::Workspace &ws, hipStream_t stream, const RtcImageArgs *image = nullptr, uint32_t *hostOut = nullptr);
+// hostOut: four words of host memory the device can write (the calling thread's pinned slot): the kernel's last workgroup
+// leaves ws.outCount[0 .. 3] there, so the caller waits for the stream instead of enqueueing a copy (ws.outCount[4] must be 0)
 // ... and for what the vector-sourced scan produces (launched with rtc_merge_launch and an empty plan: every
 // row, old or new, is a row of the input vectors passed as prevDims / prevValues)
 RtcKernel rtc_vector_merge_lookup(int device, int nd, int vw, int partBits, const AggSpec &a, bool wait = false);

@@ -376,9 +376,11 @@ MergeResult read_result(const Workspace &ws, hipStream_t stream) {
   return MergeResult{w[0], w[1], w[2], w[3]};
 }
 // ... when the merge was generated at run time: its last workgroup has written the words into the thread's pinned slot
-// (ARES_RESULT_PINNED=0: the copy command behind the kernel, as before — A/B in profiles/r5_experiments.md)
+// Off by default: measured SLOWER than the 16-byte copy command behind the kernel (live-batch leg 69.8 / 69.3 ms with it,
+// 63.2 / 63.6 ms without, alternating runs on one box: profiles/r5_evidence_ab.txt — the ticket, the two fences and the
+// system-scope stores at the tail of a 512-workgroup kernel cost more than the copy they replace).  ARES_RESULT_PINNED=1: on.
 uint32_t *result_slot() {
-  static EnvSwitch<bool> on("ARES_RESULT_PINNED", [](const char *e) { return !(e && e[0] == '0'); });
+  static EnvSwitch<bool> on("ARES_RESULT_PINNED", [](const char *e) { return e && e[0] == '1'; });
   return on.get() ? reinterpret_cast<uint32_t *>(pinned_words()) : nullptr;
 }
 MergeResult read_result_pinned(hipStream_t stream) {

@@ -318,10 +318,6 @@ int grid_for(int64_t rows) {
 
 // compact lines (8-byte records, hr::Workspace::lineRecords == 14) for the plan-sourced DIRECT scan; ARES_COMPACT=0:
 // 16-byte records everywhere
-int pmajor_max_tiles() {
-  static EnvSwitch<int> v("ARES_HR_PMAJOR_TILES", [](const char *e) { return e ? atoi(e) : 0; });
-  return v.get();
-}
 bool compact_enabled() {
   static EnvSwitch<bool> on("ARES_COMPACT", [](const char *e) { return !(e && e[0] == '0'); });
   return on.get();
@@ -662,18 +658,6 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
     if (imageMode) imageMerge = rtc_merge_lookup(device, plan, nd, partBits, a, widen, compact, false, false, imageMode);
     if (!imageMerge) imageMode = 0;  // (being compiled in the background: the ordinary kernels this time)
   }
-  // Small batches in image mode: the scan writes PARTITION-major streams (hr_rtc.hip kernel_body_compact `pmajor`), so that
-  // the merge finds a partition's few lines per scanning workgroup side by side.  Only with both generated kernels loaded
-  // (the generic merge reads workgroup-major streams).  ARES_HR_PMAJOR_TILES: up to that many tiles per scanning workgroup.
-  bool pmajor = false;
-  if (imageMode && compact && chunkTiles <= pmajor_max_tiles()) {
-    RtcKernel s2 = rtc_scan_lookup(device, plan, nd, partBits, 2), m2 = rtc_merge_lookup(device, plan, nd, partBits, a, widen, 2, false, false, imageMode);
-    if (s2 && m2) {
-      lean = s2;
-      imageMerge = m2;
-      pmajor = true;
-    }
-  }
   if (imageMode == 2) {
     const bool mine = outFound && outOld.lineage == prev.lineage && outOld.image && outOld.image != prev.image &&
                       outOld.partBits == partBits && outOld.size <= prevSize;
@@ -788,7 +772,7 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
       mem_note_dim_rows(device, outKeys, 0, res.groups);  // what this attempt emitted
       mem_note_write(device, outValues, static_cast<size_t>(mw) * res.groups);
     }
-    if ((narrow || imageMode == 2 || pmajor) && res.needGeneric) {
+    if ((narrow || imageMode == 2) && res.needGeneric) {
       // more groups in a partition than one table: only the generic merge takes rounds (the caller runs the unfused
       // sequence, which reads the previous result's vectors: complete, whatever this attempt wrote into the output)
       r.buf->mark_idle();
@@ -819,7 +803,6 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
       grouped_note_write(device, prevKeys.DimValues, slots.row_bytes() * prevCapacity);
       grouped = false;
       imageMode = 0;
-      if (pmajor) return -1;  // (the scan in hand writes a layout only the image-mode merges read)
       continue;
     }
     break;

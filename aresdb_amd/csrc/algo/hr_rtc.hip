@@ -468,13 +468,8 @@ static void kernel_body_lines16(std::ostringstream &o, const char *fourth) {
 // LDS: records as 8-byte units + a 2-byte array of low row bits; a line is written by 16 adjacent lanes (8 bytes
 // each: lanes 0 and 8 the headers), LPL lines per lane in flight; the header of a half-line is the OR of its
 // seven lanes' shifted row bits (three DPP steps inside the 8-lane group).
-// pmajor: the workgroups' streams of ONE partition lie side by side ([partition][workgroup][capB lines]) instead of a
-// workgroup's streams ([workgroup][partition][capB lines]).  For small batches — a line or two per stream — the merge then
-// reads a partition's records from one neighbourhood instead of from 256 places half a megabyte apart (the scan's stores are
-// the scattered side then, and they are posted).
-static void kernel_body_compact(std::ostringstream &o, bool pmajor) {
+static void kernel_body_compact(std::ostringstream &o) {
   phase_macros(o);
-  o << (pmajor ? "#define STREAM(p) ((u64)(p) * gridDim.x + blockIdx.x)\n" : "#define STREAM(p) ((u64)blockIdx.x * NP + (p))\n");
   const bool direct = scan_opt() & 1u;
   o << (nt_stores_enabled() ? "#define STORE_LINE(p, v) __builtin_nontemporal_store((u64)(v), (p))\n" : "#define STORE_LINE(p, v) (*(p) = (v))\n");
   o << "#define T 4096u\n#define LR 14u\n#define LEFT 13u\n#define LPL 5u\n"
@@ -509,7 +504,7 @@ static void kernel_body_compact(std::ostringstream &o, bool pmajor) {
        "  for (u32 p = tid; p < NP; p += 1024u) { sCount[0][p] = 0u; sCount[1][p] = 0u; }\n"
        "  u32 myLeftN = 0u, myCursor = 0u;\n"    // thread p < NP keeps partition p's leftover count and stream cursor in registers
        "  __syncthreads();\n"
-       "  u64 *myB = reinterpret_cast<u64 *>(a.recB);\n"  // (capB: lines per stream)
+       "  u64 *myB = reinterpret_cast<u64 *>(a.recB) + (u64)blockIdx.x * NP * a.capB * 16u;\n"  // capB: lines per stream
        "  const u32 numTiles = ((u32)a.length + T - 1u) / T;\n"
        "  const u32 firstTile = blockIdx.x * a.chunkTiles;\n"
        "  const u32 endTile = firstTile + a.chunkTiles < numTiles ? firstTile + a.chunkTiles : numTiles;\n"
@@ -587,7 +582,7 @@ static void kernel_body_compact(std::ostringstream &o, bool pmajor) {
        "        const u64 mine = r8 ? (u64)lo[j] << sh : 0ull;\n"
        "        const u64 hdr = ((u64)or8((u32)(mine >> 32)) << 32) | or8((u32)mine);\n"
        "        const u32 p = e[j] & 511u, line = cu[j] + (e[j] >> 9);\n"
-       "        if (L0 + j * 64u < totalLines && line < a.capB) STORE_LINE(&myB[(STREAM(p) * a.capB + line) * 16u + q], r8 ? rec[j] : hdr);\n"
+       "        if (L0 + j * 64u < totalLines && line < a.capB) STORE_LINE(&myB[((u64)p * a.capB + line) * 16u + q], r8 ? rec[j] : hdr);\n"
        "      }\n"
        "    }\n"
        "    __syncthreads();\n"
@@ -634,7 +629,7 @@ static void kernel_body_compact(std::ostringstream &o, bool pmajor) {
        "    const u64 rec = has ? sRec[T + p * LEFT + kk] : 0ull;\n"
        "    const u64 mine = has ? (u64)sLo[T + p * LEFT + kk] << sh : 0ull;\n"
        "    const u64 hdr = ((u64)or8((u32)(mine >> 32)) << 32) | or8((u32)mine);\n"
-       "    if (left && fits) STORE_LINE(&myB[(STREAM(p) * a.capB + cur) * 16u + q], r8 ? rec : hdr);\n"
+       "    if (left && fits) STORE_LINE(&myB[((u64)p * a.capB + cur) * 16u + q], r8 ? rec : hdr);\n"
        "    if (left && !fits) *a.overflow = 1u;\n"
        "    if (q == 0u) a.countsB[(u64)blockIdx.x * NP + p] = cur * LR + ((left && fits) ? left : 0u);\n"
        "  }\n"
@@ -791,7 +786,7 @@ static void kernel_body_table(std::ostringstream &o) {
        "}\n";
 }
 
-enum ScanKind { SCAN_LINES16 = 0, SCAN_COMPACT = 1, SCAN_TABLE = 2, SCAN_COMPACT_PMAJOR = 3 };
+enum ScanKind { SCAN_LINES16 = 0, SCAN_COMPACT = 1, SCAN_TABLE = 2 };
 
 // ---- dimension slots of 1, 2 or 4 bytes -------------------------------------------------------------------
 // The dimension vector holds, for each dimension in descending width order, capacity x width value bytes, then one
@@ -870,7 +865,7 @@ bool column_signed(const FusedPlanD &plan, int nd, int c) {
 std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t nullMask, ScanKind kind, const AggSpec *agg = nullptr,
                      const hr::Widen *widen = nullptr) {
   if (nd < 1 || nd > kFusedDims || plan.numCols > kFusedCols) return "";
-  if ((kind == SCAN_COMPACT || kind == SCAN_COMPACT_PMAJOR) && partBits < 3) return "";
+  if (kind == SCAN_COMPACT && partBits < 3) return "";
   const SlotLayout SL = slot_layout(plan, nd);
   if (!SL.ok) return "";
   for (int c = 0; c < plan.numCols; c++) {
@@ -1012,8 +1007,8 @@ std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t null
   if (kind == SCAN_TABLE) {
     if (!agg || !widen || !gen_widen(o, *widen) || !gen_agg(o, *agg)) return "";
     kernel_body_table(o);
-  } else if (kind == SCAN_COMPACT || kind == SCAN_COMPACT_PMAJOR) {
-    kernel_body_compact(o, kind == SCAN_COMPACT_PMAJOR);
+  } else if (kind == SCAN_COMPACT) {
+    kernel_body_compact(o);
   } else {
     kernel_body_lines16(o, "0u");
   }
@@ -1144,8 +1139,7 @@ static_assert(sizeof(RtcMergeArgs) % 8 == 0, "MArgs is passed as one buffer");
 //      image again.  The measure vector is NOT written: it is defined by the image (materialised by
 //      hr_image_values_kernel when somebody reads it).
 std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w, int vectorVW = 0,
-                           int compactKind = 0, bool regionA = false, int image = 0) {
-  const bool compact = compactKind != 0, pmajor = compactKind == 2;  // (2: the scan wrote partition-major streams)
+                           bool compact = false, bool regionA = false, int image = 0) {
   if (nd < 1 || nd > kFusedDims) return "";
   if (image && vectorVW) return "";
   if (compact && (vectorVW || partBits < 3)) return "";
@@ -1173,8 +1167,7 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
        // an empty slot is 0, "key matches" is one masked compare) and NEWG (the group was first seen in THIS call's
        // records: only then can a record lower the group's representative row — groups that come from the previous
        // result have rows below every row of the batch).  Four keys = one 16-byte LDS read per probe.
-       "#define HMASK ((1u << (32 - PB)) - 1u)\n#define OCC 0x40000000u\n#define NEWG 0x80000000u\n"
-    << (pmajor ? "#define STREAM(g, p) ((u64)(p) * a.streams + (g))\n" : "#define STREAM(g, p) ((u64)(g) * NP + (p))\n");
+       "#define HMASK ((1u << (32 - PB)) - 1u)\n#define OCC 0x40000000u\n#define NEWG 0x80000000u\n";
   gen_widen(o, w);
   if (!gen_agg(o, a)) return "";
   if (phases_enabled())
@@ -1429,7 +1422,7 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
        "        const bool in = u < units;\n"
        "        const u32 ul = in ? u >> 3 : 0u, g = ul / LPR, l = ul - g * LPR, cnt = in ? sRunCount[g] : 0u;\n"
     << (compact ? "        const u32 here = cnt > l * 14u ? cnt - l * 14u : 0u;\n"   // records of the run in this line and behind it
-                  "        s.r[k] = reinterpret_cast<const uint4 *>(a.recB)[(STREAM(g, p) * a.capB + l) * 8u + (u & 7u)];\n"
+                  "        s.r[k] = reinterpret_cast<const uint4 *>(a.recB)[(((u64)g * NP + p) * a.capB + l) * 8u + (u & 7u)];\n"
                   "        s.n[k] = here ? 64u : 0u; s.rem[k] = (lane >> 3) * 14u + here; s.rb[k] = a.prevSize + g * a.chunkRows;\n"
                 : "        const u32 here = cnt > l * 8u ? cnt - l * 8u : 0u;\n"
                   "        s.r[k] = reinterpret_cast<const uint4 *>(a.recB)[((u64)g * NP + p) * a.capB + l * 8u + (u & 7u)];\n"
@@ -1455,7 +1448,7 @@ std::string generate_merge(const FusedPlanD &plan, int nd, int partBits, const A
          "        const u32 cnt = (u32)__builtin_amdgcn_readlane((int)myCnt, (int)j);\n"
          "        const u32 units = ((cnt + 13u) / 14u) * 8u;\n"         // whole lines, eight 16-byte units each
          "        if (off < units) {\n"
-         "          c.ptr = reinterpret_cast<const uint4 *>(a.recB) + STREAM(wave + 16u * j, p) * a.capB * 8u + off;\n"
+         "          c.ptr = reinterpret_cast<const uint4 *>(a.recB) + ((u64)(wave + 16u * j) * NP + p) * a.capB * 8u + off;\n"
          "          c.n = units - off < 64u ? units - off : 64u;\n"
          "          c.rem = cnt - (off >> 3) * 14u;\n"
          "          c.rb = a.prevSize + (wave + 16u * j) * a.chunkRows;\n"
@@ -2194,11 +2187,10 @@ RtcKernel front_lookup(const std::string &key, int device, Gen &&source, const c
 
 }  // namespace
 
-RtcKernel rtc_scan_lookup(int device, const FusedPlanD &plan, int nd, int partBits, int compact, bool wait) {
+RtcKernel rtc_scan_lookup(int device, const FusedPlanD &plan, int nd, int partBits, bool compact, bool wait) {
   if (!rtc_api().ok) return nullptr;
-  const ScanKind kind = compact == 2 ? SCAN_COMPACT_PMAJOR : compact ? SCAN_COMPACT : SCAN_LINES16;
-  return front_lookup(shape_key('s', device, plan, nd, partBits, compact, nullptr, nullptr), device,
-                      [&] { return generate(plan, nd, partBits, null_mask(plan), kind); }, "hr_scan_rtc", wait);
+  return front_lookup(shape_key('s', device, plan, nd, partBits, compact ? 1 : 0, nullptr, nullptr), device,
+                      [&] { return generate(plan, nd, partBits, null_mask(plan), compact ? SCAN_COMPACT : SCAN_LINES16); }, "hr_scan_rtc", wait);
 }
 
 void rtc_scan_launch(const RtcKernel &kernel, const FusedPlanD &plan, uint32_t rowBase, int length, const hr::Workspace &ws,
@@ -2259,10 +2251,10 @@ std::string rtc_vector_merge_source(int nd, int vw, int partBits, const AggSpec 
   return generate_merge(none, nd, partBits, a, hr::Widen{0, 0, 0}, vw);
 }
 
-RtcKernel rtc_merge_lookup(int device, const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w, int compact,
+RtcKernel rtc_merge_lookup(int device, const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w, bool compact,
                            bool wait, bool regionA, int image) {
   if (!rtc_api().ok) return nullptr;
-  return front_lookup(shape_key('m', device, plan, nd, partBits, compact | (regionA ? 4 : 0) | (image << 3), &a, &w), device,
+  return front_lookup(shape_key('m', device, plan, nd, partBits, (compact ? 1 : 0) | (regionA ? 2 : 0) | (image << 2), &a, &w), device,
                       [&] { return generate_merge(plan, nd, partBits, a, w, 0, compact, regionA, image); }, "hr_merge_rtc", wait);
 }
 
@@ -2338,14 +2330,14 @@ void rtc_merge_launch(const RtcKernel &kernel, const FusedPlanD &plan, const uin
   }
 }
 
-std::string rtc_merge_source(const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w, int compact, bool regionA,
+std::string rtc_merge_source(const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w, bool compact, bool regionA,
                              int image) {
   return generate_merge(plan, nd, partBits, a, w, 0, compact, regionA, image);
 }
 
 // source text of the kernel a plan would get (tests / tools; empty = unsupported shape)
-std::string rtc_scan_source(const FusedPlanD &plan, int nd, int partBits, int compact) {
-  return generate(plan, nd, partBits, null_mask(plan), compact == 2 ? SCAN_COMPACT_PMAJOR : compact ? SCAN_COMPACT : SCAN_LINES16);
+std::string rtc_scan_source(const FusedPlanD &plan, int nd, int partBits, bool compact) {
+  return generate(plan, nd, partBits, null_mask(plan), compact ? SCAN_COMPACT : SCAN_LINES16);
 }
 
 std::string rtc_table_scan_source(const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w) {

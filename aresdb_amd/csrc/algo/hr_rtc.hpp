@@ -38,8 +38,7 @@ int rtc_compact_chunk_tiles(int64_t rows, int partBits);
 // DIRECT-mode scan of `plan` (every surviving row becomes a record in the workgroup's private stream of its
 // partition): `compact` = 8-byte records in compact lines (hr::Workspace::lineRecords == 14, ws.chunkRows set),
 // otherwise 16-byte records in lines of 8.
-// (compact: 0 = 16-byte records, 1 = compact lines, 2 = compact lines in partition-major streams — small batches)
-RtcKernel rtc_scan_lookup(int device, const FusedPlanD &plan, int nd, int partBits, int compact, bool wait = false);
+RtcKernel rtc_scan_lookup(int device, const FusedPlanD &plan, int nd, int partBits, bool compact, bool wait = false);
 void rtc_scan_launch(const RtcKernel &kernel, const FusedPlanD &plan, uint32_t rowBase, int length, const hr::Workspace &ws,
                      hipStream_t stream);
 // TABLE-mode scan of `plan` (low cardinality): LDS aggregation per workgroup, one record per group into region A
@@ -60,7 +59,7 @@ void rtc_vector_scan_launch(const RtcKernel &kernel, const uint8_t *dimValues, s
 // image: 0 = none; 1 = the merge also leaves the partition's LDS table in HBM ("table image": keys, each group's output
 // position, values — 128 KB per partition); 2 = the merge STARTS from the previous call's image, emits the dimension rows of
 // new groups only (appended: a group keeps its position) and writes the image again — the measure vector stays unwritten.
-RtcKernel rtc_merge_lookup(int device, const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w, int compact,
+RtcKernel rtc_merge_lookup(int device, const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w, bool compact,
                            bool wait = false, bool regionA = false, int image = 0);
 struct RtcImageArgs {  // device pointers: images of hr::kSlots x 16 bytes per partition, one group count per partition
   const void *in;
@@ -79,9 +78,9 @@ void rtc_merge_launch(const RtcKernel &kernel, const FusedPlanD &plan, const uin
 RtcKernel rtc_vector_merge_lookup(int device, int nd, int vw, int partBits, const AggSpec &a, bool wait = false);
 
 // the generated sources (empty = unsupported shape); for tools and tests
-std::string rtc_scan_source(const FusedPlanD &plan, int nd, int partBits, int compact = 0);
+std::string rtc_scan_source(const FusedPlanD &plan, int nd, int partBits, bool compact = false);
 std::string rtc_table_scan_source(const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w);
-std::string rtc_merge_source(const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w, int compact = 0,
+std::string rtc_merge_source(const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w, bool compact = false,
                              bool regionA = false, int image = 0);
 std::string rtc_vector_scan_source(int nd, int vw, int partBits);
 std::string rtc_vector_merge_source(int nd, int vw, int partBits, const AggSpec &a);

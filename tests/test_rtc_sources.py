@@ -26,7 +26,7 @@ def test_generated_kernels_compile_for_gfx950(tmp_path):
                  "compact merge (2 dims)", "table scan (2 dims, 1 partition)", "narrow compact scan", "narrow compact merge",
                  "narrow scan", "narrow merge", "narrow table scan", "narrow region-A merge", "signed narrow compact scan",
                  "signed narrow compact merge", "compact merge + image out", "compact merge from image", "merge from image",
-                 "narrow compact merge from image", "compact scan, partition-major", "compact merge from image, partition-major"):
+                 "narrow compact merge from image"):
         assert f"{what} compile rc 0" in out.stdout, what
     for nd in (1, 4):
         for vw in (4, 8):

@@ -74,9 +74,6 @@ int main(int argc, char **argv) {
   if (int rc = build(rtc_merge_source(p, 4, 9, agg, w, true, false, 1), "_cmerge_img1", "compact merge + image out")) return rc;
   if (int rc = build(rtc_merge_source(p, 4, 9, agg, w, true, false, 2), "_cmerge_img2", "compact merge from image")) return rc;
   if (int rc = build(rtc_merge_source(p, 4, 9, agg, w, false, false, 2), "_merge_img2", "merge from image")) return rc;
-  // partition-major streams (small batches in image mode)
-  if (int rc = build(rtc_scan_source(p, 4, 9, 2), "_compact_pm", "compact scan, partition-major")) return rc;
-  if (int rc = build(rtc_merge_source(p, 4, 9, agg, w, 2, false, 2), "_cmerge_pm_img2", "compact merge from image, partition-major")) return rc;
   {  // another shape: two dimensions, int32 measure summed into 4 bytes, no nulls, 8 partitions
     FusedPlanD q = p;
     q.numCols = 3;

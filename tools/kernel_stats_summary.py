@@ -1,0 +1,34 @@
+"""profiles/r5_kernel_stats_summary.md from the rocprofv3 `--kernel-trace --stats` CSVs that tools/gpu_r5_evidence.sh leaves
+(copied to profiles/r5_<tag>_kernel_stats_rocprofv3.csv):  python tools/kernel_stats_summary.py"""
+import csv
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(n):
+    n = n.strip('"').replace("(anonymous namespace)::", "").replace("void ", "")
+    return n.split("(")[0].split("ares::")[-1].split("<")[0]
+
+
+HEAD = ["# Round 5 — rocprofv3 `--kernel-trace --stats` summaries (tools/gpu_r5_evidence.sh; one MI355X box per call)", "",
+        "Durations in microseconds per launch; `share` = of all kernel time of the traced command.  Commands: C3 = `bench.py --steps 5 --warmup 2 --no-legs`",
+        "(1 B rows per step, 15 batches of 64 Mi rows; the priming passes on the generic kernels included); live = the same shard as 477 batches of 2 Mi rows;",
+        "trips = `tools/bench_configs.py trips` at 1 B rows (both queries); C2 = `tools/bench_configs.py c2` (100 M rows, three selectivities, one and four batches);",
+        "C4 = `tools/bench_configs.py c4spec` (1 B rows, 50 M-key cuckoo join, Sort + Reduce).  The C3 / live / trips / C2 traces were taken with the merges'",
+        "result words going through the pinned slot (`ARES_RESULT_PINNED=1`, since made opt-in: it costs the live leg 6 ms — `r5_evidence_ab.txt`).", ""]
+SECTIONS = (("c3", "C3 headline"), ("live", "C3 as 2 Mi-row live batches"),
+            ("trips", "trips-shaped leg (SUM(fare) via HashReduce + COUNT(*) via Sort + Reduce)"), ("c2", "C2"), ("c4", "C4 at its stated size"))
+out = list(HEAD)
+for tag, title in SECTIONS:
+    f = os.path.join(ROOT, "profiles", f"r5_{tag}_kernel_stats_rocprofv3.csv")
+    if not os.path.exists(f):
+        continue
+    out += [f"## {title}", "", "| kernel | launches | avg | min | max | share % |", "|---|---|---|---|---|---|"]
+    for r in csv.DictReader(open(f)):
+        if not any(k in r["Name"] for k in ("ares::", "_rtc")) or float(r["Percentage"]) < 0.3:
+            continue
+        out.append(f"| {short(r['Name'])} | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['MinNs']) / 1e3:.1f} | "
+                   f"{float(r['MaxNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |")
+    out.append("")
+open(os.path.join(ROOT, "profiles", "r5_kernel_stats_summary.md"), "w").write("\n".join(out))

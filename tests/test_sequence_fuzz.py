@@ -318,7 +318,7 @@ def test_random_programs_from_four_host_threads():
 
 @pytest.mark.gpu
 def test_soak_four_threads_stream_churn_clean_blocks():
-    """The soak the deferral state machine's coverage used to live in, inside the suite the driver runs: 512 programs from
+    """The soak the deferral state machine's coverage used to live in, inside the suite the driver runs: 1024 programs from
     four host threads in ONE process (every program creates and destroys its own streams: stream churn with fences, error
     watches and lazy work outstanding), all four profiles — narrow columns, time-filter pairs whose prediction fails every
     batch —, ARES_MEM_VERIFY_CLEAN=1 (every block handed out as cleared is checked on the device: a writer that does not
@@ -326,12 +326,12 @@ def test_soak_four_threads_stream_churn_clean_blocks():
     import json
     import subprocess
     import sys
-    r = subprocess.run([sys.executable, os.path.join(H.ROOT, "tools", "stress_fuzz.py"), "--iters", "128", "--threads", "4", "--seeds", "96",
+    r = subprocess.run([sys.executable, os.path.join(H.ROOT, "tools", "stress_fuzz.py"), "--iters", "256", "--threads", "4", "--seeds", "128",
                         "--profiles", "--tag", "soak"], cwd=H.ROOT, env={**os.environ, "ARES_MEM_VERIFY_CLEAN": "1"},
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
     rep = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert rep["programs"] >= 500 and rep["mismatches"] == 0 and rep["errors"] == 0, rep
+    assert rep["programs"] >= 1000 and rep["mismatches"] == 0 and rep["errors"] == 0, rep
 
 
 @pytest.mark.gpu

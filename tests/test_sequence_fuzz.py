@@ -339,14 +339,16 @@ def test_random_programs_on_the_direct_kernels_with_table_images():
     """ARES_LEAN_MIN_GROUPS=0 sends every fusable batch of the (small) fuzz programs to the DIRECT-mode kernels, hence through
     the table images: merges that start from the previous call's image, measure vectors that are only defined until the
     program copies them back (it does, at random points and at the end), result buffers that are reallocated and copied
-    mid-query, all four profiles — six programs, four threads, every block checked clean.  (Few programs: each has its own
-    plan shape, and a shape's kernels are compiled inline here.)"""
+    mid-query, all four profiles — 32 programs twice, four threads, every block checked clean."""
     import json
     import subprocess
     import sys
-    r = subprocess.run([sys.executable, os.path.join(H.ROOT, "tools", "stress_fuzz.py"), "--iters", "6", "--threads", "4", "--seeds", "8",
-                        "--profiles", "--tag", "images"], cwd=H.ROOT,
+    r = subprocess.run([sys.executable, os.path.join(H.ROOT, "tools", "stress_fuzz.py"), "--iters", "16", "--threads", "4", "--seeds", "32",
+                        "--profiles", "--kernels", "--tag", "images"], cwd=H.ROOT,
                        env={**os.environ, "ARES_MEM_VERIFY_CLEAN": "1", "ARES_LEAN_MIN_GROUPS": "0"}, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
     rep = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert rep["programs"] == 24 and rep["mismatches"] == 0 and rep["errors"] == 0, rep
+    assert rep["programs"] == 64 and rep["mismatches"] == 0 and rep["errors"] == 0, rep
+    k = rep["kernels"] or {}
+    # the programs did go where this test means them to: generated scans and merges, images written back when a program reads
+    assert k.get("hr_scan_rtc", 0) > 20 and k.get("hr_merge_rtc", 0) > 20 and k.get("hr_image_values_kernel", 0) > 0, k

@@ -45,11 +45,14 @@ def main():
     ap.add_argument("--tag", default="run")
     ap.add_argument("--seeds", type=int, default=48)
     ap.add_argument("--profiles", action="store_true", help="cycle the fuzzer's profiles (narrow columns, drifting time filters) over the seeds")
+    ap.add_argument("--kernels", action="store_true", help="report the launches per kernel (the library's profiler: HIP events around every launch)")
     ap.add_argument("--budget-s", type=float, default=0.0, help="stop starting new rounds after this many seconds (0: run every round)")
     a = ap.parse_args()
     prof = (lambda s: PROFILES[s % len(PROFILES)]) if a.profiles else (lambda s: ())
     hip, oracle = (H.oracle_backend() if os.environ.get("STRESS_ON_ORACLE") else H.hip_backend()), H.oracle_backend()
     want = {}
+    if a.kernels and getattr(hip, "has_profiler", False):
+        hip.profiler_enable(True)
     t0 = time.time()
     bad, errs, programs = [], [], 0
     for it in range(a.iters):
@@ -77,7 +80,12 @@ def main():
                 d = first_diff(got[t], want[seeds[t]])
                 if d:
                     bad.append((it, seeds[t], d))
-    print(json.dumps({"tag": a.tag, "iters": a.iters, "programs": programs, "mismatches": len(bad), "errors": len(errs),
+    kernels = None
+    if a.kernels and getattr(hip, "has_profiler", False):
+        hip.wait()
+        kernels = {k: v[0] for k, v in hip.profiler_report().items()}
+        hip.profiler_enable(False)
+    print(json.dumps({"kernels": kernels, "tag": a.tag, "iters": a.iters, "programs": programs, "mismatches": len(bad), "errors": len(errs),
                       "seconds": round(time.time() - t0, 1), "first": [list(map(str, b)) for b in bad[:6]], "errs": errs[:4]}))
 
 

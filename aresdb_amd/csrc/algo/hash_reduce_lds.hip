@@ -306,7 +306,10 @@ std::mutex g_shapeMutex;
 std::unordered_map<size_t, int> g_firstBatchGroups;
 
 int part_bits_for(int64_t length) {
-  int partBits = 0;
+  // ARES_MIN_PART_BITS (tests): at least that many partition bits — with 2, inputs of a few thousand rows take the generated
+  // merges (whose 32-bit table keys need two spare hash bits), hence the table images, like production-sized ones
+  static EnvSwitch<int> minBits("ARES_MIN_PART_BITS", [](const char *e) { return e ? atoi(e) : 0; });
+  int partBits = minBits.get() > 0 ? (minBits.get() < 9 ? minBits.get() : 9) : 0;
   while ((8192ll << partBits) < length && (1 << partBits) < kMaxPartitions) partBits++;
   return partBits;
 }
@@ -671,6 +674,15 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
     // the previous result's measure rows are read by everything but an image-mode merge: write them if they are still
     // only defined by their image
     if (prevSize > 0) grouped_materialize_for_read(device, prevValues, static_cast<size_t>(mw) * prevSize);
+  }
+  {
+    static const bool trace = getenv("ARES_HR_TRACE") != nullptr;  // diagnostics
+    if (trace)
+      fprintf(stderr, "fused_hash_reduce_run: batch %d prev %d partBits %d | found %d (state: size %d partBits %d ranges %d image %d lazy %d) grouped %d "
+                      "| lean %d table %d compact %d narrow %d -> image mode %d knownOut %u\n",
+              batchRows, prevSize, partBits, found ? 1 : 0, found ? prev.size : -1, found ? prev.partBits : -1, found && prev.ranges ? 1 : 0,
+              found && prev.image ? 1 : 0, found && prev.lazyValues ? 1 : 0, grouped ? 1 : 0, lean ? 1 : 0, table ? 1 : 0, compact ? 1 : 0,
+              narrow ? 1 : 0, imageMode, knownOut);
   }
   if (narrow && !imageMode) {  // (both kernels are asked for before the call is declined: one round of background compilation, not two)
     narrowMerge = rtc_merge_lookup(device, plan, nd, partBits, a, widen, wantLean && compact, false,

@@ -35,6 +35,8 @@ for w in $WHAT; do
     c3)
       trace c3 python $R/bench.py --steps 5 --warmup 2 --no-legs --no-cpu-baseline --no-pmc
       pmc c3 67108864 python $R/tools/pmc_driver.py 67108864 3 ;;
+    c3t) trace c3 python $R/bench.py --steps 5 --warmup 2 --no-legs --no-cpu-baseline --no-pmc ;;   # (traces only: no counter passes)
+    livet) trace live $LIVE --rows 1e9 ;;
     live)
       trace live $LIVE --rows 1e9
       pmc live 2097152 $LIVE --rows 2e8 ;;

@@ -15,8 +15,9 @@ HEAD = ["# Round 5 — rocprofv3 `--kernel-trace --stats` summaries (tools/gpu_r
         "Durations in microseconds per launch; `share` = of all kernel time of the traced command.  Commands: C3 = `bench.py --steps 5 --warmup 2 --no-legs`",
         "(1 B rows per step, 15 batches of 64 Mi rows; the priming passes on the generic kernels included); live = the same shard as 477 batches of 2 Mi rows;",
         "trips = `tools/bench_configs.py trips` at 1 B rows (both queries); C2 = `tools/bench_configs.py c2` (100 M rows, three selectivities, one and four batches);",
-        "C4 = `tools/bench_configs.py c4spec` (1 B rows, 50 M-key cuckoo join, Sort + Reduce).  The C3 / live / trips / C2 traces were taken with the merges'",
-        "result words going through the pinned slot (`ARES_RESULT_PINNED=1`, since made opt-in: it costs the live leg 6 ms — `r5_evidence_ab.txt`).", ""]
+        "C4 = `tools/bench_configs.py c4spec` (1 B rows, 50 M-key cuckoo join, Sort + Reduce).  C3 and live: the library as committed at the end of the",
+        "round; the trips and C2 traces were taken while the merges' result words still went through the pinned slot by default (`ARES_RESULT_PINNED=1`,",
+        "since made opt-in: it cost the live leg 6 ms — `r5_evidence_ab.txt`; it adds a few microseconds to `hr_merge_rtc`, nothing to the other kernels).", ""]
 SECTIONS = (("c3", "C3 headline"), ("live", "C3 as 2 Mi-row live batches"),
             ("trips", "trips-shaped leg (SUM(fare) via HashReduce + COUNT(*) via Sort + Reduce)"), ("c2", "C2"), ("c4", "C4 at its stated size"))
 out = list(HEAD)

@@ -77,6 +77,8 @@ void grouped_note_write(int device, const DimensionVector &v);  // the whole vec
 // [ptr, ptr + bytes) is about to be read: measure rows that an image-mode HashReduce left unwritten (they are defined by
 // the query's table image) are written first (hash_reduce_lds.hip)
 void grouped_materialize_for_read(int device, const void *ptr, size_t bytes);
+// out of memory elsewhere: the idle range buffers and table images of the device go back to the driver
+void grouped_trim(int device);
 void flush_deferred_for_inputs(int device, const void *a, size_t aBytes, const void *b, size_t bBytes);
 // the same for an entry point that reads a whole dimension vector and a value vector
 void flush_deferred_for_vector(int device, const DimensionVector &v, const void *values, size_t valueBytes);

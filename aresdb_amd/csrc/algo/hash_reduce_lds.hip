@@ -425,6 +425,30 @@ void grouped_materialize_for_read(int device, const void *ptr, size_t bytes) {
   }
 }
 
+void grouped_trim(int device) {
+  std::vector<void *> idle;
+  {
+    std::lock_guard<std::mutex> lock(g_rangesMutex);
+    for (size_t i = 0; i < g_freeRanges.size();)
+      if (g_freeRanges[i].first == device) {
+        idle.push_back(g_freeRanges[i].second);
+        g_freeRanges[i] = g_freeRanges.back();
+        g_freeRanges.pop_back();
+      } else {
+        i++;
+      }
+    for (size_t i = 0; i < g_freeImages.size();)
+      if (g_freeImages[i].first == device) {
+        idle.push_back(g_freeImages[i].second);
+        g_freeImages[i] = g_freeImages.back();
+        g_freeImages.pop_back();
+      } else {
+        i++;
+      }
+  }
+  for (void *p : idle) (void)hipFree(p);  // (a buffer is on a free list only after the last call that used it has waited for its stream)
+}
+
 void grouped_note_write(int device, const DimensionVector &v) {
   size_t rowBytes = 0;
   for (int w = 0; w < NUM_DIM_WIDTH; w++) rowBytes += static_cast<size_t>(v.NumDimsPerDimWidth[w]) * ((1u << (NUM_DIM_WIDTH - 1 - w)) + 1);

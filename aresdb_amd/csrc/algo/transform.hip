@@ -1958,6 +1958,7 @@ void hook_trim(int device) {
   try {
     DeviceGuard guard(device);
     stream_cache_trim(device);
+    grouped_trim(device);
   } catch (std::exception &) {
   }
 }

@@ -786,7 +786,11 @@ static void kernel_body_table(std::ostringstream &o) {
        "}\n";
 }
 
-enum ScanKind { SCAN_LINES16 = 0, SCAN_COMPACT = 1, SCAN_TABLE = 2 };
+// SCAN_SORT64: the Sort + Reduce path (sort_reduce_fused.hip) — 16-byte line records {row, hash64 >> 32, carried measure, (u32)hash64}
+// keyed by murmur3_x64_128 of the packed row (what Sort hashes: query/sort_reduce.cu:118-133), partitioned by the TOP bits of the
+// 64-bit hash so that a partition is a contiguous range of the sorted order; plan.measure.col < 0: a constant measure
+// (COUNT(*) is SUM over the literal 1) — no measure column is read, records carry Args::k's measure slot
+enum ScanKind { SCAN_LINES16 = 0, SCAN_COMPACT = 1, SCAN_TABLE = 2, SCAN_SORT64 = 3 };
 
 // ---- dimension slots of 1, 2 or 4 bytes -------------------------------------------------------------------
 // The dimension vector holds, for each dimension in descending width order, capacity x width value bytes, then one
@@ -833,6 +837,45 @@ void gen_row_hash(std::ostringstream &o, const SlotLayout &L, const std::functio
   o << indent << "  g ^= " << total << "u; g ^= g >> 16; g *= 0x85ebca6bu; g ^= g >> 13; g *= 0xc2b2ae35u; g ^= g >> 16;\n"
     << indent << "  " << out << " = g;\n" << indent << "}\n";
 }
+// lo64(murmur3_x64_128) (seed 0) of the packed row — Murmur128Stream of dim_layout.hpp, query/utils.cu:157-241 — with the
+// same naming of values and validity bits as gen_row_hash; writes the statements that leave the hash in the u64 `out`
+void gen_row_hash64(std::ostringstream &o, const SlotLayout &L, const std::function<std::string(int)> &val,
+                    const std::function<std::string(int)> &okb, const std::string &out, const char *indent) {
+  const int total = L.valueBytes + L.nd, words = (total + 3) / 4;
+  std::vector<std::string> w(static_cast<size_t>(words));
+  auto add = [&](int byteOff, const std::string &e) {
+    std::string &x = w[static_cast<size_t>(byteOff / 4)];
+    const int sh = 8 * (byteOff % 4);
+    const std::string term = sh ? "(" + e + " << " + std::to_string(sh) + ")" : e;
+    x = x.empty() ? term : x + " | " + term;
+  };
+  for (int d = 0; d < L.nd; d++) add(L.off[d], val(d));
+  for (int d = 0; d < L.nd; d++) add(L.valueBytes + d, okb(d));
+  auto lane64 = [&](int firstWord) {  // 8 row bytes from 32-bit word `firstWord` on, as a u64 expression ("" = none left)
+    if (firstWord >= words) return std::string();
+    std::string e = "(u64)(" + w[static_cast<size_t>(firstWord)] + ")";
+    if (firstWord + 1 < words) e += " | ((u64)(" + w[static_cast<size_t>(firstWord + 1)] + ") << 32)";
+    return e;
+  };
+  const std::string in = indent;
+  o << in << "{\n" << in << "  u64 g1 = 0ull, g2 = 0ull, q1, q2;\n";
+  const int blocks = total / 16;
+  for (int b = 0; b < blocks; b++) {
+    o << in << "  q1 = " << lane64(4 * b) << "; q2 = " << lane64(4 * b + 2) << ";\n"
+      << in << "  q1 *= MC1; q1 = rotl64(q1, 31); q1 *= MC2; g1 ^= q1; g1 = rotl64(g1, 27); g1 += g2; g1 = g1 * 5ull + 0x52dce729ull;\n"
+      << in << "  q2 *= MC2; q2 = rotl64(q2, 33); q2 *= MC1; g2 ^= q2; g2 = rotl64(g2, 31); g2 += g1; g2 = g2 * 5ull + 0x38495ab5ull;\n";
+  }
+  const int tail = total % 16;
+  if (tail > 8) o << in << "  q2 = " << lane64(4 * blocks + 2) << "; q2 *= MC2; q2 = rotl64(q2, 33); q2 *= MC1; g2 ^= q2;\n";
+  if (tail > 0) o << in << "  q1 = " << lane64(4 * blocks) << "; q1 *= MC1; q1 = rotl64(q1, 31); q1 *= MC2; g1 ^= q1;\n";
+  o << in << "  g1 ^= " << total << "ull; g2 ^= " << total << "ull; g1 += g2; g2 += g1;\n"
+    << in << "  g1 = fmix64(g1); g2 = fmix64(g2); g1 += g2;\n"
+    << in << "  " << out << " = g1;\n" << in << "}\n";
+}
+const char *kPrelude64 =
+    "#define MC1 0x87c37b91114253d5ull\n#define MC2 0x4cf5ad432745937full\n"
+    "__device__ __forceinline__ u64 rotl64(u64 x, int r) { return (x << r) | (x >> (64 - r)); }\n"
+    "__device__ __forceinline__ u64 fmix64(u64 k) { k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33; return k; }\n";
 // mask that truncates a 32-bit value to a slot's width
 const char *width_mask(int w) { return w == 4 ? "" : w == 2 ? " & 0xFFFFu" : " & 0xFFu"; }
 // dimension d of row `row` of a dimension vector at `base` (capacity `cap`), zero-extended; and its validity byte
@@ -874,7 +917,11 @@ std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t null
   }
   std::ostringstream o;
   const int nc = plan.numCols;
-  o << times5_text() << kPrelude << args_text()
+  const bool sort64 = kind == SCAN_SORT64;
+  const bool constMeasure = sort64 && plan.measure.col < 0;  // the records carry Args::k's measure slot as it is
+  if (plan.measure.col < 0 && !sort64) return "";
+  const int firstFilterCol = constMeasure ? nd : nd + 1;  // column slots: dimension d -> d, measure -> nd (if any), then the filters' own
+  o << times5_text() << kPrelude << (sort64 ? kPrelude64 : "") << args_text()
     << "#define NC " << nc << "\n#define ND " << nd << "\n#define PB " << partBits << "\n#define NP " << (1 << partBits) << "\n"
        "struct Raw { u32 v[NC][4]; u32 win[NC]; };\n";
   // ---- loads, one column at a time.  Always the full 16 bytes + the 16-bit validity window, from a row index clamped
@@ -949,8 +996,10 @@ std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t null
       o << "    }\n";
     }
     o << "    alive[j] = keep;\n  }\n";
-    for (int c = nd + 1; c < nc; c++) prefetch(c);  // columns only the filters read
-    {  // measure: fused_carry
+    for (int c = firstFilterCol; c < nc; c++) prefetch(c);  // columns only the filters read
+    if (constMeasure) {
+      o << "  cv[0] = cv[1] = cv[2] = cv[3] = " << const_name(const_slot_measure()) << ";\n";
+    } else {  // measure: fused_carry
       const FusedExpr &e = plan.measure;
       if (e.col != nd) return "";
       o << "#pragma unroll\n  for (int j = 0; j < 4; j++) {\n"
@@ -967,7 +1016,7 @@ std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t null
       o << "  }\n";
       prefetch(nd);
     }
-    if (SL.all4) {
+    if (SL.all4 && !sort64) {
     o << "  u32 h[4] = {0u, 0u, 0u, 0u}, okbytes[4] = {0u, 0u, 0u, 0u};\n";
     for (int d = 0; d < nd; d++) {
       const FusedExpr &e = plan.dims[d];
@@ -999,8 +1048,15 @@ std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t null
         prefetch(d);
       }
       o << "#pragma unroll\n  for (int j = 0; j < 4; j++) {\n";
-      gen_row_hash(o, SL, [](int d) { return "xv" + std::to_string(d) + "[j]"; }, [](int d) { return "xo" + std::to_string(d) + "[j]"; },
-                   "hh[j]", "    ");
+      if (sort64) {  // the record's second word holds the hash's upper half (its top bits choose the partition), the fourth the lower
+        o << "    u64 h64;\n";
+        gen_row_hash64(o, SL, [](int d) { return "xv" + std::to_string(d) + "[j]"; }, [](int d) { return "xo" + std::to_string(d) + "[j]"; },
+                       "h64", "    ");
+        o << "    hh[j] = (u32)(h64 >> 32); cw[j] = (u32)h64;\n";
+      } else {
+        gen_row_hash(o, SL, [](int d) { return "xv" + std::to_string(d) + "[j]"; }, [](int d) { return "xo" + std::to_string(d) + "[j]"; },
+                     "hh[j]", "    ");
+      }
       o << "  }\n}\n";
     }
   }
@@ -1010,7 +1066,7 @@ std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t null
   } else if (kind == SCAN_COMPACT) {
     kernel_body_compact(o);
   } else {
-    kernel_body_lines16(o, "0u");
+    kernel_body_lines16(o, sort64 ? "cw[j]" : "0u");
   }
   return o.str();
 }
@@ -2199,6 +2255,23 @@ void rtc_scan_launch(const RtcKernel &kernel, const FusedPlanD &plan, uint32_t r
   fill_scan_args(args, plan, rowBase, length, ws);
   if (ws.lineRecords == static_cast<int>(hr::kCompactLineRecords)) args.chunkTiles = ws.chunkRows / 4096u;
   launch_scan(kernel, args, ws.streams, length, stream, "hr_scan_rtc");
+}
+
+RtcKernel rtc_sort_scan_lookup(int device, const FusedPlanD &plan, int nd, int partBits, bool wait) {
+  if (!rtc_api().ok) return nullptr;
+  return front_lookup(shape_key('o', device, plan, nd, partBits, 0, nullptr, nullptr), device,
+                      [&] { return generate(plan, nd, partBits, null_mask(plan), SCAN_SORT64); }, "hr_scan_rtc", wait);
+}
+
+void rtc_sort_scan_launch(const RtcKernel &kernel, const FusedPlanD &plan, uint32_t rowBase, int length, const hr::Workspace &ws,
+                          hipStream_t stream) {
+  RtcArgs args;
+  fill_scan_args(args, plan, rowBase, length, ws);
+  launch_scan(kernel, args, ws.streams, length, stream, "sr_scan_rtc");
+}
+
+std::string rtc_sort_scan_source(const FusedPlanD &plan, int nd, int partBits) {
+  return generate(plan, nd, partBits, null_mask(plan), SCAN_SORT64);
 }
 
 RtcKernel rtc_table_scan_lookup(int device, const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w, bool wait) {

@@ -41,6 +41,13 @@ int rtc_compact_chunk_tiles(int64_t rows, int partBits);
 RtcKernel rtc_scan_lookup(int device, const FusedPlanD &plan, int nd, int partBits, bool compact, bool wait = false);
 void rtc_scan_launch(const RtcKernel &kernel, const FusedPlanD &plan, uint32_t rowBase, int length, const hr::Workspace &ws,
                      hipStream_t stream);
+// The scan of the fused Sort + Reduce path (sort_reduce_fused.hip): like the DIRECT scan with 16-byte line records, but keyed
+// by lo64(murmur3_x64_128) of the packed row — records {row, hash >> 32, carried measure, (u32)hash}, partition = top bits of
+// the 64-bit hash.  plan.measure.col < 0: constant measure (the records carry plan.measure.f.bbits).
+RtcKernel rtc_sort_scan_lookup(int device, const FusedPlanD &plan, int nd, int partBits, bool wait = false);
+void rtc_sort_scan_launch(const RtcKernel &kernel, const FusedPlanD &plan, uint32_t rowBase, int length, const hr::Workspace &ws,
+                          hipStream_t stream);
+std::string rtc_sort_scan_source(const FusedPlanD &plan, int nd, int partBits);
 // TABLE-mode scan of `plan` (low cardinality): LDS aggregation per workgroup, one record per group into region A
 // (what hr::flush_table writes), rtc_scan_grid(length) workgroups; the generic merge reads it.
 RtcKernel rtc_table_scan_lookup(int device, const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w,

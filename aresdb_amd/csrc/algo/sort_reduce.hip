@@ -19,6 +19,7 @@
 #include "device_model.hpp"
 #include "dim_layout.hpp"
 #include "lookback.hpp"
+#include "sort_reduce_fused.hpp"
 
 namespace ares {
 
@@ -506,6 +507,15 @@ static void sort_impl(const DimensionVector &keys, int length, hipStream_t strea
             keys.IndexVector, nullptr, keys.HashValues, keys.IndexVector, false, length, stream);
 }
 
+void sort_keys_now(const DimensionVector &keys, int length, hipStream_t stream) {
+  if (length > 0) {
+    const int device = current_device();
+    mem_note_write(device, keys.HashValues, 8ull * static_cast<size_t>(length));
+    mem_note_write(device, keys.IndexVector, 4ull * static_cast<size_t>(length));
+  }
+  sort_impl(keys, length, stream);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Reduce
 // ---------------------------------------------------------------------------------------------
@@ -710,6 +720,17 @@ static int reduce_impl(const DimensionVector &in, uint8_t *inputValues, const Di
   read_back_u32(p.total, result, 2, stream);
   if (result[1]) throw AlgorithmError("ERROR: Reduce: inter-tile scan timed out");
   return static_cast<int>(result[0]);
+}
+
+int reduce_now(const DimensionVector &in, uint8_t *inputValues, const DimensionVector &out, uint8_t *outputValues, int valueBytes,
+               int length, int aggFunc, hipStream_t stream) {
+  if (length > 0) {
+    const int device = current_device();
+    mem_note_dim_rows(device, out, 0, static_cast<size_t>(length));
+    mem_note_write(device, out.IndexVector, 4ull * static_cast<size_t>(length));
+    mem_note_write(device, outputValues, static_cast<size_t>(valueBytes) * static_cast<size_t>(length));
+  }
+  return reduce_impl(in, inputValues, out, outputValues, valueBytes, length, aggFunc, stream);
 }
 
 int hll_reduce_sorted(const uint64_t *keys, const uint32_t *positions, const uint32_t *indexSrc,
@@ -971,6 +992,9 @@ CGoCallResHandle Sort(DimensionVector keys, int length, void *cudaStream, int de
       virtual_iota_peek(device, keys.IndexVector, length) &&
       defer_fill(device, reinterpret_cast<hipStream_t>(cudaStream), keys.HashValues, 8ull * static_cast<size_t>(length), empty_row_hash(), 8))
     return resHandle;
+  // dimensions whose transforms are still pending on this stream: Sort is DEFINED — Reduce aggregates by the 64-bit row hash
+  // without sorting rows (sort_reduce_fused.hip); anybody else who looks at the hash or index vector makes it run
+  if (define_lazy_sort(device, reinterpret_cast<hipStream_t>(cudaStream), keys, length)) return resHandle;
   flush_deferred(device);
   settle_dimension_vector(device, keys);
   flush_deferred_for_vector(device, keys, nullptr, 0);  // rows a HashReduce skipped, should a host sort them after all
@@ -990,6 +1014,14 @@ CGoCallResHandle Reduce(DimensionVector inputKeys, uint8_t *inputValues, Dimensi
     int groups = 0;
     if (reduce_without_dimensions(device, inputKeys, inputValues, outputKeys, outputValues, valueBytes, length, aggFunc,
                                   reinterpret_cast<hipStream_t>(cudaStream), &groups)) {
+      resHandle.res = int_result(groups);
+      return resHandle;
+    }
+  }
+  {
+    int groups = 0;
+    if (length > 0 && fuse_pending_into_sort_reduce(device, reinterpret_cast<hipStream_t>(cudaStream), inputKeys, inputValues, outputKeys,
+                                                    outputValues, valueBytes, length, aggFunc, &groups)) {
       resHandle.res = int_result(groups);
       return resHandle;
     }

@@ -1,0 +1,478 @@
+// Sort + Reduce, hash-keyed: the group-by of the reference's DEFAULT aggregation path without sorting rows.
+//
+// Reference: query/sort_reduce.cu:118-133 (hash every row of the dimension vector with murmur3_x64_128, stable sort of the
+// index vector by the 64-bit hash), :135-249 (reduce_by_key over runs of equal hashes; the representative of a run is its
+// first index; dimensions of the representatives gathered into the output vector) — what the Go host runs for every
+// aggregate but SUM_SIGNED / SUM_FLOAT, and for those too unless enable_hash_reduction is set
+// (query/aql_context.go:426-434, config/ares.yaml:11).  COUNT(*) — SUM over the literal 1 — always goes this way.
+//
+// What a caller can observe of Sort + Reduce over rows [0, prev) (the previous result) + [prev, prev + n) (the batch):
+//   * the output groups in ASCENDING order of the 64-bit row hash, one group per distinct hash;
+//   * each group's dimension row = that of its lowest-indexed row (stable sort of an iota index vector);
+//   * each group's value = op over its rows' values (integer aggregates: independent of the order).
+// Sorting 40-60 M surviving ROWS per batch to find 70 k - 2 M groups is what made this path 6-7 x slower than HashReduce
+// (4 radix passes + hash + reduce + compaction + materialised dimension rows: 4.4 ms per 64 Mi-row batch).  Here the
+// GROUPS are ordered instead:
+//   1. sr_prev_kernel      hashes the previous result's rows (region A records, one cursor per partition);
+//   2. sr_scan_rtc         (hr_rtc.hip, SCAN_SORT64) the fused scan over the batch's source columns — filters replayed from
+//                          the journal, dimensions and measure evaluated on the fly — writes one 16-byte record
+//                          {row, hash >> 32, carried measure, (u32)hash} per surviving row into the stream of the partition
+//                          the TOP bits of the hash select: a partition is a contiguous range of the sorted order;
+//   3. sr_merge_kernel     one workgroup per partition aggregates its records in an LDS table keyed by the 64-bit hash whose
+//                          home slots are MONOTONE in the key (home = the key's bits below the partition's, scaled to the
+//                          table) with linear probing and no wrap-around: every cluster (run of occupied slots) holds
+//                          exactly the keys whose homes lie in it, all clusters before it hold smaller keys.  Ranking an
+//                          entry = occupied slots before its cluster + keys of the cluster below its own — no sort pass;
+//   4. sr_emit_kernel      prefix over the partitions' group counts, dimension rows of the representatives gathered (previous
+//                          result) or re-evaluated from the source columns (batch rows), values stored: ascending hash order.
+// Float sums keep the real sort (their order of additions is observable), as does anything this path declines: more
+// groups than the partitions' tables hold, a skewed partition stream, a record whose hash equals the table's "empty" word.
+#include <hip/hip_runtime.h>
+
+#include <memory>
+
+#include "aggregate.hpp"
+#include "common.hpp"
+#include "device_model.hpp"
+#include "dim_layout.hpp"
+#include "fast_eval.hpp"
+#include "hash_reduce_lds.hpp"
+#include "hr_kernels.hpp"
+#include "hr_rtc.hpp"
+#include "sort_reduce_fused.hpp"
+
+namespace ares {
+
+namespace {
+using hr::kMaxPartitions;
+using hr::kMaxStreams;
+using hr::kThreads;
+
+constexpr uint64_t kEmptyKey = ~0ull;
+constexpr uint32_t kNoRow = 0xFFFFFFFFu;
+// table slots per partition: 16 bytes per slot with 4-byte values (128 KB), 20 with 8-byte values (140 KB).  The last
+// kTail slots are overflow room for the clusters at the table's end (no wrap-around: order is position)
+template <int VW>
+struct Table {
+  static constexpr int kSlots = VW == 4 ? 8192 : 7168;
+  static constexpr int kTail = 512;
+  static constexpr int kHomes = kSlots - kTail;
+  static constexpr int kPerLane = kSlots / kThreads;
+  static constexpr int kMaxGroups = kHomes * 13 / 16;  // beyond ~0.8 the clusters (and the ranking walks) grow quickly
+};
+
+struct SrArgs {
+  // records
+  const uint4 *recA;
+  uint32_t *cursorsA;
+  uint64_t capA;
+  const uint4 *recB;
+  const uint32_t *countsB;
+  uint32_t capB;
+  int streams, partBits;
+  // previous result + batch
+  const uint8_t *dimIn;
+  const uint8_t *inValues;
+  size_t inCapacity;
+  uint32_t prevSize;
+  // how a batch record's carried 4 bytes become the value: widen (hr::Widen) or the constant
+  hr::Widen widen;
+  int constMeasure;
+  uint64_t constBits;
+  AggSpec agg;
+  // staging: per partition Table::kSlots entries {row, value lo, value hi, 0}, ordered; group count per partition
+  uint4 *staging;
+  uint32_t *partCount;
+  uint32_t *flags;  // [0] groups (emit), [1] a stream / region / table overflowed, [2] a hash equals the empty word
+  uint32_t maxGroups;  // groups a partition's table takes (Table::kMaxGroups; ARES_SR_MAX_GROUPS lowers it: tests)
+  // emission
+  uint8_t *dimOut;
+  uint8_t *outValues;
+};
+
+__device__ __forceinline__ uint32_t sr_partition(uint64_t key, int pb) { return pb ? static_cast<uint32_t>(key >> (64 - pb)) : 0u; }
+
+// ---- 1. previous result -> region A ---------------------------------------------------------------------------------
+// The rows are (in the Go host's flow) the previous Reduce's output, ascending by hash: consecutive lanes mostly share a
+// partition, so each wavefront reserves once per distinct partition it holds.
+__global__ __launch_bounds__(256) void sr_prev_kernel(SrArgs m, DimLayoutD L, uint4 *recA) {
+  const int lane = threadIdx.x & 63;
+  const int64_t n = m.prevSize;
+  for (int64_t base = static_cast<int64_t>(blockIdx.x) * 256; base < n; base += static_cast<int64_t>(gridDim.x) * 256) {
+    const int64_t i = base + threadIdx.x;
+    const bool have = i < n;
+    uint64_t key = 0;
+    if (have) {
+      Murmur128Stream ms(0);
+      hash_dim_row(ms, m.dimIn, L, m.inCapacity, static_cast<uint32_t>(i));
+      key = ms.finish();
+    }
+    const uint32_t p = sr_partition(key, m.partBits);
+    uint64_t todo = __ballot(have);
+    uint32_t at = 0;
+    while (todo) {
+      const int leader = __builtin_ctzll(todo);
+      const uint32_t lp = __shfl(p, leader);
+      const uint64_t same = __ballot(have && p == lp) & todo;
+      uint32_t start = 0;
+      if (lane == leader) start = atomicAdd(m.cursorsA + lp, static_cast<uint32_t>(__popcll(same)));
+      start = __shfl(start, leader);
+      if ((same >> lane) & 1ull) at = start + static_cast<uint32_t>(__popcll(same & ((1ull << lane) - 1)));
+      todo &= ~same;
+    }
+    if (have) {
+      if (at < m.capA) recA[static_cast<uint64_t>(p) * m.capA + at] = make_uint4(static_cast<uint32_t>(i), static_cast<uint32_t>(key >> 32), 0u, static_cast<uint32_t>(key));
+      else m.flags[1] = 1u;
+      if (key == kEmptyKey) m.flags[2] = 1u;
+    }
+  }
+}
+
+// ---- 3. per-partition aggregation + ordering ------------------------------------------------------------------------
+template <int VW>
+struct Slots {
+  using V = typename std::conditional<VW == 4, uint32_t, uint64_t>::type;
+};
+
+template <int VW>
+__device__ __forceinline__ void sr_aggregate(typename Slots<VW>::V *slot, uint64_t bits, const AggSpec &a) {
+  if constexpr (VW == 8) {
+    __hip_atomic_fetch_add(reinterpret_cast<unsigned long long *>(slot), static_cast<unsigned long long>(bits), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_WORKGROUP);
+  } else {
+    if (a.vtype == V_U32) {
+      const uint32_t x = static_cast<uint32_t>(bits);
+      if (a.op == OP_SUM) __hip_atomic_fetch_add(slot, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      else if (a.op == OP_MIN) __hip_atomic_fetch_min(slot, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      else __hip_atomic_fetch_max(slot, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+      int32_t *ps = reinterpret_cast<int32_t *>(slot);
+      const int32_t x = static_cast<int32_t>(static_cast<uint32_t>(bits));
+      if (a.op == OP_SUM) __hip_atomic_fetch_add(ps, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      else if (a.op == OP_MIN) __hip_atomic_fetch_min(ps, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      else __hip_atomic_fetch_max(ps, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+}
+
+template <int VW>
+__global__ __launch_bounds__(kThreads) void sr_merge_kernel(SrArgs m) {
+  using T = Table<VW>;
+  using V = typename Slots<VW>::V;
+  __shared__ uint64_t sKeys[T::kSlots];
+  __shared__ uint32_t sRows[T::kSlots];
+  __shared__ V sVals[T::kSlots];
+  __shared__ uint32_t sRun[kMaxStreams];
+  __shared__ uint32_t sWave[kThreads / 64];
+  __shared__ uint32_t sClaims, sBad;
+  const int p = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int pb = m.partBits;
+  const int numParts = 1 << pb;
+  const AggSpec a = m.agg;
+  for (int s = tid; s < T::kSlots; s += kThreads) {
+    sKeys[s] = kEmptyKey;
+    sRows[s] = kNoRow;
+    sVals[s] = static_cast<V>(a.identity);
+  }
+  if (tid < m.streams) sRun[tid] = m.countsB[static_cast<uint64_t>(tid) * numParts + p];
+  if (tid == 0) { sClaims = 0; sBad = 0; }
+  __syncthreads();
+
+  auto insert = [&](uint32_t row, uint32_t hi, uint32_t lo, uint64_t value) {
+    const uint64_t key = (static_cast<uint64_t>(hi) << 32) | lo;
+    if (key == kEmptyKey) {  // cannot live in this table: the caller takes the real sort
+      m.flags[2] = 1u;
+      return;
+    }
+    // the 32 key bits right below the partition's, scaled to the home slots: monotone in the key
+    const uint32_t x = pb ? ((hi << pb) | (lo >> (32 - pb))) : hi;
+    uint32_t slot = __umulhi(x, static_cast<uint32_t>(T::kHomes));
+    for (;;) {
+      uint64_t cur = sKeys[slot];
+      if (cur == kEmptyKey) {
+        unsigned long long expected = kEmptyKey;
+        if (__hip_atomic_compare_exchange_strong(reinterpret_cast<unsigned long long *>(sKeys + slot), &expected,
+                                                 static_cast<unsigned long long>(key), __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_WORKGROUP)) {
+          if (__hip_atomic_fetch_add(&sClaims, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= m.maxGroups)
+            __hip_atomic_store(&sBad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          break;
+        }
+        cur = expected;
+      }
+      if (cur == key) break;
+      if (++slot >= static_cast<uint32_t>(T::kSlots)) {  // ran off the tail: more groups than the table orders
+        __hip_atomic_store(&sBad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return;
+      }
+    }
+    __hip_atomic_fetch_min(sRows + slot, row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    sr_aggregate<VW>(sVals + slot, value, a);
+  };
+
+  // ---- previous groups (region A): the value is read from the previous result's measure vector
+  {
+    const uint32_t cursor = m.cursorsA[p];
+    const uint32_t nA = cursor < m.capA ? cursor : static_cast<uint32_t>(m.capA);
+    const uint4 *recA = m.recA + static_cast<uint64_t>(p) * m.capA;
+    for (uint32_t i = tid; i < nA; i += kThreads) {
+      const uint4 r = recA[i];
+      insert(r.x, r.y, r.w, load_value_bits(m.inValues, a, r.x));
+    }
+  }
+  // ---- the batch's records (region B): every wavefront streams whole runs, four records per lane in flight
+  {
+    const uint4 *pad = m.recB;  // (any readable address: lanes past a run's end load it and ignore it)
+    for (int g = wave; g < m.streams; g += kThreads / 64) {
+      const uint32_t cnt = sRun[g];
+      const uint4 *run = m.recB + (static_cast<uint64_t>(g) * numParts + p) * m.capB;
+      for (uint32_t off = 0; off < cnt; off += 256u) {
+        if (__hip_atomic_load(&sBad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+        uint4 r[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const uint32_t i = off + static_cast<uint32_t>(k) * 64u + lane;
+          r[k] = *(i < cnt ? run + i : pad);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const uint32_t i = off + static_cast<uint32_t>(k) * 64u + lane;
+          if (i >= cnt || r[k].x == kNoRow) continue;  // (row ~0: the padding of a stream's last line)
+          const uint64_t v = m.constMeasure ? m.constBits : hr::widen_value(m.widen, r[k].z);
+          insert(r[k].x, r[k].y, r[k].w, v);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (sBad) {  // (uniform)
+    if (tid == 0) {
+      m.flags[1] = 1u;
+      m.partCount[p] = 0u;
+    }
+    return;
+  }
+  // ---- order: lane t owns slots [t * kPerLane, (t + 1) * kPerLane)
+  const int first = tid * T::kPerLane;
+  uint32_t mine = 0;
+#pragma unroll
+  for (int k = 0; k < T::kPerLane; k++) mine += sKeys[first + k] != kEmptyKey;
+  uint32_t incl = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(incl, off);
+    if (lane >= off) incl += t;
+  }
+  if (lane == 63) sWave[wave] = incl;
+  __syncthreads();
+  uint32_t before = incl - mine;
+  for (int w = 0; w < wave; w++) before += sWave[w];
+  uint4 *stage = m.staging + static_cast<uint64_t>(p) * T::kSlots;
+  uint32_t seen = 0;  // occupied slots of this lane before the current one
+#pragma unroll
+  for (int k = 0; k < T::kPerLane; k++) {
+    const int s = first + k;
+    const uint64_t key = sKeys[s];
+    if (key == kEmptyKey) continue;
+    uint32_t smaller = 0;
+    int b = s - 1;
+    while (b >= 0) {
+      const uint64_t kb = sKeys[b];
+      if (kb == kEmptyKey) break;
+      smaller += kb < key;
+      b--;
+    }
+    for (int f = s + 1; f < T::kSlots; f++) {
+      const uint64_t kf = sKeys[f];
+      if (kf == kEmptyKey) break;
+      smaller += kf < key;
+    }
+    // occupied slots before the cluster's first = occupied slots before s - (s - first slot of the cluster)
+    const uint32_t rank = before + seen - static_cast<uint32_t>(s - (b + 1)) + smaller;
+    const uint64_t v = static_cast<uint64_t>(sVals[s]);
+    stage[rank] = make_uint4(sRows[s], static_cast<uint32_t>(v), static_cast<uint32_t>(v >> 32), 0u);
+    seen++;
+  }
+  if (tid == kThreads - 1) m.partCount[p] = before + mine;
+}
+
+// ---- 4. emission in partition order ---------------------------------------------------------------------------------
+// dimension d of batch row r, as the transform would have stored it in the dimension vector (fused_eval_row of
+// hr_kernels.hpp for columns of 1 / 2 / 4 bytes)
+__device__ __forceinline__ void sr_eval_dim(const FusedPlanD &plan, int d, uint32_t r, uint32_t *bits, uint32_t *ok) {
+  const FusedExpr &e = plan.dims[d];
+  const FusedColumn col = plan.cols[e.col];
+  const int step = col.step ? static_cast<int>(col.step) : 4;
+  const uint8_t *base = reinterpret_cast<const uint8_t *>(col.vals);
+  const bool sgn = e.f.akind == K_I32;
+  uint32_t raw;
+  if (step == 4) raw = col.vals[r];
+  else if (step == 2) raw = sgn ? static_cast<uint32_t>(static_cast<int32_t>(reinterpret_cast<const int16_t *>(base)[r])) : reinterpret_cast<const uint16_t *>(base)[r];
+  else raw = sgn ? static_cast<uint32_t>(static_cast<int32_t>(reinterpret_cast<const int8_t *>(base)[r])) : base[r];
+  const uint32_t rok = col.nulls ? get_bit(col.nulls, r + col.bitOff) : 1u;
+  const hr::FusedConst c = hr::fused_const(e.f);
+  const DVal x = eval_fast(e.f, raw, rok, c.y, c.fd);
+  *bits = cvt32(x, e.f.rk, e.outKind).bits;
+  *ok = x.ok ? 1u : 0u;
+}
+
+template <int VW>
+__global__ __launch_bounds__(kThreads) void sr_emit_kernel(SrArgs m, FusedPlanD plan, DimLayoutD L) {
+  using T = Table<VW>;
+  __shared__ uint32_t sBase;
+  const int p = blockIdx.x, tid = threadIdx.x;
+  if (tid == 0) sBase = 0;
+  __syncthreads();
+  if (tid < p) {
+    const uint32_t c = m.partCount[tid];
+    if (c) atomicAdd(&sBase, c);
+  }
+  __syncthreads();
+  const uint32_t base = sBase, count = m.partCount[p];
+  if (p == (1 << m.partBits) - 1 && tid == 0) m.flags[0] = base + count;
+  const uint4 *stage = m.staging + static_cast<uint64_t>(p) * T::kSlots;
+  const size_t cap = m.inCapacity;  // (the reference strides BOTH vectors by inputKeys.VectorCapacity: sort_reduce.cu:234-239)
+  uint8_t *nullsOut = m.dimOut + static_cast<size_t>(L.valueBytes) * cap;
+  for (uint32_t i = tid; i < count; i += kThreads) {
+    const uint4 e = stage[i];
+    const uint32_t at = base + i;
+    if (e.x < m.prevSize) {
+      copy_dim_row(m.dimIn, cap, m.dimOut, cap, L, e.x, at);
+    } else {
+      const uint32_t r = e.x - m.prevSize;
+      for (int d = 0; d < L.numDims; d++) {
+        uint32_t bits, ok;
+        sr_eval_dim(plan, d, r, &bits, &ok);
+        uint8_t *q = m.dimOut + static_cast<size_t>(L.valueOff[d]) * cap + static_cast<size_t>(L.width[d]) * at;
+        if (L.width[d] == 4) *reinterpret_cast<uint32_t *>(q) = bits;
+        else if (L.width[d] == 2) *reinterpret_cast<uint16_t *>(q) = static_cast<uint16_t>(bits);
+        else *q = static_cast<uint8_t>(bits);
+        nullsOut[static_cast<size_t>(d) * cap + at] = static_cast<uint8_t>(ok);
+      }
+    }
+    if (VW == 8) reinterpret_cast<uint64_t *>(m.outValues)[at] = (static_cast<uint64_t>(e.z) << 32) | e.y;
+    else reinterpret_cast<uint32_t *>(m.outValues)[at] = e.y;
+  }
+}
+
+int sr_part_bits(int64_t length) {
+  // ARES_MIN_PART_BITS (tests): small inputs take several partitions like production-sized ones
+  static EnvSwitch<int> minBits("ARES_MIN_PART_BITS", [](const char *e) { return e ? atoi(e) : 0; });
+  int partBits = minBits.get() > 0 ? (minBits.get() < 9 ? minBits.get() : 9) : 0;
+  while ((4096ll << partBits) < length && (1 << partBits) < kMaxPartitions) partBits++;
+  return partBits;
+}
+
+}  // namespace
+
+bool fused_sort_reduce_enabled() {
+  static EnvSwitch<bool> on("ARES_SORT_FUSE", [](const char *e) { return !(e && e[0] == '0'); });
+  return on.get() && rtc_scan_available();
+}
+
+bool fused_sort_reduce_supported(const AggSpec &a) {
+  if (a.vtype == V_U32 || a.vtype == V_I32) return a.op == OP_SUM || a.op == OP_MIN || a.op == OP_MAX;
+  return (a.vtype == V_U64 || a.vtype == V_I64) && a.op == OP_SUM;
+}
+
+int fused_sort_reduce_run(int device, const FusedPlanD &plan, int nd, bool constMeasure, uint64_t constBits, int batchRows,
+                          const DimensionVector &in, const uint8_t *inValues, int prevSize, const DimensionVector &out,
+                          uint8_t *outValues, const AggSpec &a, hipStream_t stream) {
+  if (!fused_sort_reduce_enabled() || !fused_sort_reduce_supported(a) || batchRows <= 0 || prevSize < 0) return kFusedUnavailable;
+  const int vw = a.width;
+  static EnvSwitch<int> maxGroups("ARES_SR_MAX_GROUPS", [](const char *e) { return e ? atoi(e) : 0; });
+  int tableGroups = vw == 4 ? Table<4>::kMaxGroups : Table<8>::kMaxGroups;
+  if (maxGroups.get() > 0 && maxGroups.get() < tableGroups) tableGroups = maxGroups.get();
+  const int64_t length = static_cast<int64_t>(batchRows) + prevSize;
+  const int partBits = sr_part_bits(length);
+  const int numParts = 1 << partBits;
+  // the previous result alone must sit comfortably in the tables (3/4 of what a table orders): beyond, the real sort
+  if (static_cast<int64_t>(prevSize) > static_cast<int64_t>(numParts) * tableGroups * 3 / 4) return kFusedUnavailable;
+  const DimLayoutD L = make_dim_layout(in.NumDimsPerDimWidth);
+  if (L.numDims != nd) return kFusedUnavailable;
+  RtcKernel scan = rtc_sort_scan_lookup(device, plan, nd, partBits);
+  if (!scan) return kFusedUnavailable;  // being compiled in the background (or a shape the generator declines)
+
+  // ---- workspace: [cursors A | flags][counts B][partition counts][region A][region B][staging]
+  const int streams = rtc_scan_grid(batchRows);
+  const uint64_t mean = static_cast<uint64_t>(batchRows) / (static_cast<uint64_t>(numParts) * streams);
+  const uint32_t capB = static_cast<uint32_t>(((2 * mean + 64 + 7) / 8 * 8) | 8ull);  // whole lines of 8; odd line count per stream
+  const uint64_t capA = ((2ull * (static_cast<uint64_t>(prevSize) / numParts) + 1024) | 63ull) + 18;
+  const size_t stageSlots = static_cast<size_t>(vw == 4 ? Table<4>::kSlots : Table<8>::kSlots);
+  auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+  const size_t headBytes = up(sizeof(uint32_t) * (numParts + 16));
+  const size_t countsBytes = up(sizeof(uint32_t) * static_cast<size_t>(numParts) * streams);
+  const size_t partBytes = up(sizeof(uint32_t) * numParts);
+  const size_t aBytes = up(sizeof(uint4) * capA * numParts);
+  const size_t bBytes = up(sizeof(uint4) * static_cast<size_t>(capB) * numParts * streams);
+  const size_t stageBytes = up(sizeof(uint4) * stageSlots * numParts);
+  StreamBuffer buf(headBytes + countsBytes + partBytes + aBytes + bBytes + stageBytes + 256, stream);
+  uint8_t *base = buf.as<uint8_t>();
+  hip_check(hipMemsetAsync(base, 0, headBytes, stream), "hipMemsetAsync");
+  hr::Workspace ws;
+  memset(&ws, 0, sizeof(ws));
+  ws.cursorsA = reinterpret_cast<uint32_t *>(base);
+  ws.outCount = ws.cursorsA + numParts;  // [0] groups, [1] overflow, [2] empty-key hash
+  ws.countsB = reinterpret_cast<uint32_t *>(base + headBytes);
+  uint32_t *partCount = reinterpret_cast<uint32_t *>(base + headBytes + countsBytes);
+  ws.recA = reinterpret_cast<uint4 *>(base + headBytes + countsBytes + partBytes);
+  ws.capA = capA;
+  ws.recB = reinterpret_cast<uint32_t *>(base + headBytes + countsBytes + partBytes + aBytes);
+  ws.capB = capB;
+  ws.streams = streams;
+  ws.partBits = partBits;
+  ws.lineRecords = 8;
+  ws.rowBase = static_cast<uint32_t>(prevSize);
+
+  SrArgs m;
+  memset(&m, 0, sizeof(m));
+  m.recA = ws.recA;
+  m.cursorsA = ws.cursorsA;
+  m.capA = capA;
+  m.recB = reinterpret_cast<const uint4 *>(ws.recB);
+  m.countsB = ws.countsB;
+  m.capB = capB;
+  m.streams = streams;
+  m.partBits = partBits;
+  m.dimIn = in.DimValues;
+  m.inValues = inValues;
+  m.inCapacity = static_cast<size_t>(in.VectorCapacity);
+  m.prevSize = static_cast<uint32_t>(prevSize);
+  m.widen.mode = vw == 8 ? 1 : 0;
+  m.widen.rk = plan.measure.f.rk;
+  m.widen.dtype = plan.measureDtype;
+  m.constMeasure = constMeasure ? 1 : 0;
+  m.constBits = constBits;
+  m.agg = a;
+  m.staging = reinterpret_cast<uint4 *>(base + headBytes + countsBytes + partBytes + aBytes + bBytes);
+  m.partCount = partCount;
+  m.flags = ws.outCount;
+  m.maxGroups = static_cast<uint32_t>(tableGroups);
+  m.dimOut = out.DimValues;
+  m.outValues = outValues;
+
+  if (prevSize > 0) {
+    const int grid = static_cast<int>(std::min<int64_t>((static_cast<int64_t>(prevSize) + 255) / 256, 256 * 8));
+    ARES_LAUNCH("sr_prev_kernel", sr_prev_kernel, grid, 256, stream, m, L, ws.recA);
+  }
+  rtc_sort_scan_launch(scan, plan, static_cast<uint32_t>(prevSize), batchRows, ws, stream);
+  if (vw == 8) {
+    ARES_LAUNCH("sr_merge_kernel", sr_merge_kernel<8>, numParts, kThreads, stream, m);
+    ARES_LAUNCH("sr_emit_kernel", sr_emit_kernel<8>, numParts, kThreads, stream, m, plan, L);
+  } else {
+    ARES_LAUNCH("sr_merge_kernel", sr_merge_kernel<4>, numParts, kThreads, stream, m);
+    ARES_LAUNCH("sr_emit_kernel", sr_emit_kernel<4>, numParts, kThreads, stream, m, plan, L);
+  }
+  uint32_t w[3] = {0, 0, 0};
+  read_back_u32(ws.outCount, w, 3, stream);
+  buf.mark_idle();
+  static const bool trace = getenv("ARES_HR_TRACE") != nullptr;  // diagnostics
+  if (trace)
+    fprintf(stderr, "fused_sort_reduce_run: batch %d prev %d partBits %d streams %d capA %llu capB %u vw %d const %d -> groups %u overflow %u emptykey %u\n",
+            batchRows, prevSize, partBits, streams, static_cast<unsigned long long>(capA), capB, vw, constMeasure ? 1 : 0, w[0], w[1], w[2]);
+  if (w[1] || w[2]) return -1;  // the outputs may be partly written: the caller runs the real Sort + Reduce over them
+  return static_cast<int>(w[0]);
+}
+
+}  // namespace ares

@@ -16,7 +16,13 @@
 //   * iotas[index vector]         InitIndexVector recorded, not written ("virtual iota");
 //   * fills[first byte]           a buffer defined as a repeated 4- / 8-byte pattern (constant measures, the hash vector
 //                                 of a query without dimensions);
-//   * (hash_reduce_lds.hip)       measure rows defined by a table image ("lazy values").
+//   * (hash_reduce_lds.hip)       measure rows defined by a table image ("lazy values");
+//   * sorts[index vector]         Sort over rows whose transforms are still pending: the hash vector (a marker entry of
+//                                 `fills`) and the index vector (its `iotas` entry, marked `sorted`) are defined as "what
+//                                 Sort would leave"; Reduce consumes the definition with the pending transforms
+//                                 (sort_reduce_fused.hip) and leaves its own (`reduced`: the input's hash and index vector
+//                                 and the output's index vector are what a replay — skipped transforms, Sort, Reduce —
+//                                 would write: materialize_sort).
 // Invariants (each one is what a reader of device memory relies on; the sequence fuzzer reads every buffer at random
 // points and the soak test does so from four threads):
 //   I1  Before ANY byte of device memory is read by something other than the consumer a definition was made for — a copy
@@ -60,6 +66,7 @@
 #include "fast_eval.hpp"
 #include "hash_reduce_lds.hpp"
 #include "lookback.hpp"
+#include "sort_reduce_fused.hpp"
 
 #include "transform_kernels.hpp"
 
@@ -76,6 +83,9 @@ namespace ares {
 // vector and length; a job whose buffers overlap a queued job's (read-after-write or
 // write-after-anything) forces the queue out first, so the fused launch never reorders dependent
 // work.
+// lazily defined sorts (below, after the fills): run for real / forgotten.  Caller holds the device's DeferLock.
+static void materialize_sort(const uint32_t *indexVector);
+static void drop_sort(const uint32_t *indexVector);
 namespace {
 struct ByteRange {
   const uint8_t *lo, *hi;
@@ -91,6 +101,8 @@ struct PendingQueue {
   // include/ares_extensions.h): a late launch from outside the stream's own call order must
   // restore "the stream is idle" before anybody looks
   bool overWait = false;
+  // (limbo only) the queue was consumed by a fused Sort + Reduce: whoever launches it replays the whole sequence
+  const uint32_t *sortIdx = nullptr;
 };
 struct DeferState;
 DeferState &state_of(int device);
@@ -235,6 +247,8 @@ struct PendingIota {
   // A consumer has already used the vector as what it is defined to be (Reduce over zero dimensions): only somebody
   // who is handed THIS vector, copies it or frees it still cares — unrelated flush points and stream waits leave it.
   bool consumed = false;
+  // Sort has been DEFINED over this vector (DeferState::sorts): what it is defined to hold is the sorted order, not the iota
+  bool sorted = false;
 };
 
 // Buffers that a call has defined as "`unit`-byte pattern, repeated" but that nobody has written yet ("lazy fill"):
@@ -249,6 +263,26 @@ struct PendingFill {
   uint64_t pattern;
   int unit;  // 4 or 8
   bool streamGone = false;  // the defining stream was destroyed: written on the stream of whoever asks for it
+  // not a pattern at all: a buffer a lazily defined Sort (+ Reduce) would write — the hash vector, the output's index vector.
+  // Reading it runs the sort (materialize_sort), a free or a whole overwrite drops the definition (drop_sort)
+  const uint32_t *sortIdx = nullptr;
+};
+
+// Sort over a dimension vector whose batch rows are still pending transforms (define_lazy_sort), and — once `reduced` —
+// the Reduce that consumed it together with them (fuse_pending_into_sort_reduce)
+struct PendingSort {
+  int device;
+  hipStream_t stream;
+  DimensionVector keys;
+  int length;
+  bool reduced = false;
+  // what a replay of the reduced state needs
+  DimensionVector outKeys;
+  uint8_t *inValues = nullptr, *outValues = nullptr;
+  int valueBytes = 0, aggFunc = 0, groups = 0;
+  bool constMeasure = false;  // the batch's measure rows were a lazy fill the Reduce consumed: `fill` at `fillAt`
+  uint8_t *fillAt = nullptr;
+  PendingFill fill;
 };
 
 void hook_on_wait(int device, void *stream);
@@ -329,6 +363,7 @@ struct DeferState {
   uint64_t filterGeneration = 0;
   std::map<uint32_t *, PendingIota> iotas;
   std::map<uint8_t *, PendingFill> fills;  // by first byte; ranges never overlap
+  std::map<const uint32_t *, PendingSort> sorts;  // by index vector
   std::vector<ErrorCheck> errorChecks;
   std::vector<uint32_t *> errorSlots;  // recycled pinned words
   bool errorSeen = false;              // a check that was settled outside an entry point failed: the next poll reports it
@@ -578,7 +613,11 @@ bool materialize_limbo(int device, const ByteRange *range, ReleaseSet *released)
       hit = false;
       for (const ByteRange &w : it->second.writes) hit = hit || w.overlaps(*range);
     }
-    if (hit) {
+    if (hit && it->second.sortIdx) {  // consumed by a fused Sort + Reduce: the whole sequence is replayed (the entry goes with it)
+      materialize_sort(it->second.sortIdx);
+      it = t_state->limbo.begin();
+      any = true;
+    } else if (hit) {
       it->second.overWait = true;  // the host believes this work is long done
       launch_queue(it->first.second, it->second);
       if (released) released->add(it->first.second);
@@ -612,7 +651,7 @@ __global__ __launch_bounds__(kBlock) void fill_pattern_kernel(uint8_t *dst, size
 
 // caller holds the device's DeferLock and has selected the device
 static void launch_fill(uint8_t *dst, const PendingFill &f) {
-  if (f.bytes == 0) return;
+  if (f.bytes == 0 || f.sortIdx) return;  // (a sort's marker is not a pattern: materialize_sort)
   mem_note_write(f.device, dst, f.bytes);
   const size_t units = f.bytes / static_cast<size_t>(f.unit);
   // a fill whose defining stream is gone is written on the caller's stream (or, from a libmem.so hook, on the null stream)
@@ -627,7 +666,16 @@ static void launch_fill(uint8_t *dst, const PendingFill &f) {
 static void materialize_fills(int device, const ByteRange *r, std::vector<hipStream_t> *touched = nullptr) {
   for (auto it = t_state->fills.begin(); it != t_state->fills.end();) {
     const ByteRange v{it->first, it->first + it->second.bytes};
-    if (it->second.device == device && (!r || v.overlaps(*r))) {
+    if (it->second.device == device && it->second.sortIdx) {
+      // a buffer a lazily defined Sort (+ Reduce) would write: only for somebody who looks at these very bytes
+      if (r && v.overlaps(*r)) {
+        if (touched) touched->push_back(it->second.stream);
+        materialize_sort(it->second.sortIdx);  // (erases the marker)
+        it = t_state->fills.begin();
+      } else {
+        ++it;
+      }
+    } else if (it->second.device == device && (!r || v.overlaps(*r))) {
       launch_fill(it->first, it->second);
       if (touched) touched->push_back(it->second.stream);
       it = t_state->fills.erase(it);
@@ -649,6 +697,12 @@ static void retire_fills(int device, const ByteRange &r, bool gone) {
       ++it;
       continue;
     }
+    if (f.sortIdx) {  // freed, or overwritten whole: the definition dies; cut: what the sort would leave is written first
+      if (gone || (r.lo <= lo && hi <= r.hi)) drop_sort(f.sortIdx);
+      else materialize_sort(f.sortIdx);
+      it = t_state->fills.begin();
+      continue;
+    }
     it = t_state->fills.erase(it);
     if (gone || (r.lo <= lo && hi <= r.hi)) continue;
     const bool headCut = r.lo <= lo, tailCut = hi <= r.hi;  // (not both: handled above)
@@ -665,6 +719,79 @@ static void retire_fills(int device, const ByteRange &r, bool gone) {
       it = t_state->fills.upper_bound(lo);
     }
   }
+}
+
+// ---- lazily defined sorts ---------------------------------------------------------------------------------------------
+// every buffer a lazily defined Sort (+ Reduce) reads or would write
+static bool sort_touches(const PendingSort &s, const ByteRange &r) {
+  auto hit = [&](const void *p, size_t bytes) {
+    const uint8_t *lo = static_cast<const uint8_t *>(p);
+    return p && bytes && lo < r.hi && r.lo < lo + bytes;
+  };
+  auto vector_bytes = [](const DimensionVector &v) {
+    size_t rowBytes = 0;
+    for (int w = 0; w < NUM_DIM_WIDTH; w++) rowBytes += static_cast<size_t>(v.NumDimsPerDimWidth[w]) * ((1u << (NUM_DIM_WIDTH - 1 - w)) + 1);
+    return rowBytes * static_cast<size_t>(v.VectorCapacity > 0 ? v.VectorCapacity : 0);
+  };
+  const size_t n = static_cast<size_t>(s.length > 0 ? s.length : 0);
+  bool any = hit(s.keys.DimValues, vector_bytes(s.keys)) || hit(s.keys.HashValues, 8 * n) || hit(s.keys.IndexVector, 4 * n);
+  if (s.reduced)
+    any = any || hit(s.outKeys.DimValues, vector_bytes(s.outKeys)) || hit(s.outKeys.IndexVector, 4 * n) ||
+          hit(s.inValues, static_cast<size_t>(s.valueBytes) * n) || hit(s.outValues, static_cast<size_t>(s.valueBytes) * n);
+  return any;
+}
+
+// caller holds the device's DeferLock.  The definition is forgotten: its buffers are freed, redefined or overwritten whole,
+// or the work a replay needs is gone.  The marker entries go with it; the index vector's iota entry too (nobody may take
+// the vector for an iota any more).
+static void drop_sort(const uint32_t *indexVector) {
+  auto it = t_state->sorts.find(indexVector);
+  if (it == t_state->sorts.end()) return;
+  t_state->sorts.erase(it);
+  auto io = t_state->iotas.find(const_cast<uint32_t *>(indexVector));
+  if (io != t_state->iotas.end() && io->second.sorted) t_state->iotas.erase(io);
+  for (auto f = t_state->fills.begin(); f != t_state->fills.end();) f = (f->second.sortIdx == indexVector) ? t_state->fills.erase(f) : std::next(f);
+  for (auto &kv : t_state->limbo)
+    if (kv.second.sortIdx == indexVector) kv.second.sortIdx = nullptr;  // (plain skipped work from now on)
+}
+
+// caller holds the device's DeferLock and has selected the device.  Somebody reads (or partly overwrites) what a lazily
+// defined Sort — and, once `reduced`, the Reduce that consumed it — would have written: the sequence runs for real, on the
+// stream it was defined on: the batch's transforms (pending, or in limbo), the constant measure rows the Reduce consumed,
+// InitIndexVector, Sort, Reduce.  Integer aggregates only are ever consumed, so the replayed Reduce rewrites the output's
+// dimension and measure rows with the bytes they already hold.  (Rare: the Go host never looks at these vectors.  The sort
+// synchronises its stream while the lock is held.)
+static void materialize_sort(const uint32_t *indexVector) {
+  auto it = t_state->sorts.find(indexVector);
+  if (it == t_state->sorts.end()) return;
+  const PendingSort s = it->second;
+  drop_sort(indexVector);  // (the entries go first: nothing below finds them again)
+  ReleaseSet released;
+  if (s.reduced) {
+    auto lim = t_state->limbo.find({s.device, s.stream});
+    if (lim != t_state->limbo.end()) {
+      lim->second.overWait = true;  // the host believes this work is long done
+      launch_queue(s.stream, lim->second);
+      released.add(s.stream);
+      t_state->limbo.erase(lim);
+    }
+    if (s.constMeasure) {
+      PendingFill f = s.fill;
+      f.sortIdx = nullptr;
+      launch_fill(s.fillAt, f);
+    }
+  } else {
+    auto pq = t_state->pending.find({s.device, s.stream});
+    if (pq != t_state->pending.end() && pq->second.jobs.count) {
+      if (pq->second.overWait) released.add(s.stream);
+      launch_queue(s.stream, pq->second);
+    }
+  }
+  launch_init_index(const_cast<uint32_t *>(indexVector), 0, s.length, s.stream);
+  sort_keys_now(s.keys, s.length, s.stream);
+  if (s.reduced) (void)reduce_now(s.keys, s.inValues, s.outKeys, s.outValues, s.valueBytes, s.length, s.aggFunc, s.stream);
+  order_before_caller(s.stream);
+  released.run(s.device);
 }
 
 // [dst, dst + bytes) is defined as `pattern` (unit = 4 or 8 bytes) repeated; false = deferral is off, the caller writes
@@ -692,7 +819,7 @@ bool pending_fill_exact(int device, const void *dst, size_t bytes, uint64_t *pat
   if (!defer_available()) return false;
   DeferLock lock(device);
   auto it = t_state->fills.find(const_cast<uint8_t *>(static_cast<const uint8_t *>(dst)));
-  if (it == t_state->fills.end() || it->second.device != device || it->second.bytes != bytes) return false;
+  if (it == t_state->fills.end() || it->second.device != device || it->second.bytes != bytes || it->second.sortIdx) return false;
   if (pattern) *pattern = it->second.pattern;
   if (unit) *unit = it->second.unit;
   return true;
@@ -704,7 +831,7 @@ bool pending_fill_tail(int device, const void *base, int width, int length, int 
   DeferLock lock(device);
   const uint8_t *b = static_cast<const uint8_t *>(base), *end = b + static_cast<size_t>(width) * length;
   auto it = t_state->fills.lower_bound(const_cast<uint8_t *>(b));
-  if (it == t_state->fills.end() || it->second.device != device || it->second.unit != width) return false;
+  if (it == t_state->fills.end() || it->second.device != device || it->second.unit != width || it->second.sortIdx) return false;
   if (it->first >= end || it->first + it->second.bytes != end || static_cast<size_t>(it->first - b) % static_cast<size_t>(width)) return false;
   *prev = static_cast<int>(static_cast<size_t>(it->first - b) / static_cast<size_t>(width));
   *pattern = it->second.pattern;
@@ -736,7 +863,7 @@ bool virtual_iota_peek(int device, const uint32_t *indexVector, int n, bool cons
   if (!defer_available()) return false;
   DeferLock lock(device);
   auto it = t_state->iotas.find(const_cast<uint32_t *>(indexVector));
-  if (it == t_state->iotas.end() || it->second.device != device || it->second.start != 0 || it->second.n != n) return false;
+  if (it == t_state->iotas.end() || it->second.device != device || it->second.start != 0 || it->second.n != n || it->second.sorted) return false;
   if (consume) it->second.consumed = true;
   return true;
 }
@@ -761,6 +888,10 @@ void materialize_index_vector(int device, const uint32_t *indexVector) {
   DeferLock lock(device);
   auto it = t_state->iotas.find(const_cast<uint32_t *>(indexVector));
   if (it == t_state->iotas.end() || it->second.device != device || !it->second.consumed) return;
+  if (it->second.sorted) {  // defined as what Sort leaves: run it
+    materialize_sort(indexVector);
+    return;
+  }
   launch_init_index(it->first, it->second.start, it->second.n, it->second.stream);
   t_state->iotas.erase(it);
 }
@@ -782,7 +913,10 @@ static void flush_deferred_impl(int device, const ByteRange *limboA, const ByteR
   for (auto it = t_state->iotas.begin(); it != t_state->iotas.end();) {
     const ByteRange v{reinterpret_cast<const uint8_t *>(it->first), reinterpret_cast<const uint8_t *>(it->first) + 4ull * it->second.n};
     const bool wanted = !it->second.consumed || (limboA && v.overlaps(*limboA)) || (limboB && v.overlaps(*limboB));
-    if (it->second.device == device && wanted) {
+    if (it->second.device == device && wanted && it->second.sorted) {
+      materialize_sort(it->first);
+      it = t_state->iotas.begin();
+    } else if (it->second.device == device && wanted) {
       launch_init_index(it->first, it->second.start, it->second.n, it->second.stream);
       it = t_state->iotas.erase(it);
     } else {
@@ -845,7 +979,9 @@ void drop_skipped_outputs(int device, const void *a, size_t aBytes, const void *
       if (hit) {
         if (it->second.idx) t_state->compactions.erase(it->second.idx);
         released.add(it->first.second);
+        const uint32_t *sortIdx = it->second.sortIdx;
         it = t_state->limbo.erase(it);
+        if (sortIdx) drop_sort(sortIdx);  // (what its Reduce left defined cannot be replayed any more)
       } else {
         ++it;
       }
@@ -871,10 +1007,13 @@ static void begin_batch(int device, hipStream_t stream, const uint32_t *indexVec
     auto lim = t_state->limbo.find({device, stream});
     if (lim != t_state->limbo.end()) {  // the skipped work of the previous batch dies, and with it the compaction it would need
       if (lim->second.idx) t_state->compactions.erase(lim->second.idx);
+      const uint32_t *sortIdx = lim->second.sortIdx;
       t_state->limbo.erase(lim);
+      if (sortIdx) drop_sort(sortIdx);
       release = true;
     }
     t_state->compactions.erase(indexVector);  // the vector is redefined
+    drop_sort(indexVector);                   // ... and so is whatever a lazily defined Sort meant it to hold
     {  // the stream's filters of the batch that just ended are what the new batch's are predicted from
       FilterHistory &h = t_state->filterHistory[{device, stream}];
       if (!h.current.empty()) {  // (the Sort path opens a second index vector per batch: no filters there, nothing to learn)
@@ -940,6 +1079,7 @@ static bool journal_is_valid(int device, const uint32_t *indexVector) {
 static bool defer_iota(int device, hipStream_t stream, uint32_t *indexVector, uint32_t start, int n) {
   if (!defer_available() || n <= 0) return false;
   DeferLock lock(device);
+  drop_sort(indexVector);
   t_state->iotas[indexVector] = PendingIota{device, stream, start, n};
   return true;
 }
@@ -949,7 +1089,7 @@ static bool defer_iota(int device, hipStream_t stream, uint32_t *indexVector, ui
 static bool virtual_iota(int device, uint32_t *indexVector, int n, bool take) {
   DeferLock lock(device);
   auto it = t_state->iotas.find(indexVector);
-  if (it == t_state->iotas.end() || it->second.device != device || it->second.start != 0 || it->second.n != n) return false;
+  if (it == t_state->iotas.end() || it->second.device != device || it->second.start != 0 || it->second.n != n || it->second.sorted) return false;
   if (take) t_state->iotas.erase(it);
   return true;
 }
@@ -1827,6 +1967,14 @@ uintptr_t hook_on_free(int device, void *ptr, size_t bytes) {
   try {
     DeviceGuard guard(device);
     DeferLock lock(device);
+    for (auto it = t_state->sorts.begin(); it != t_state->sorts.end();) {  // a buffer a lazily defined Sort (+ Reduce) works on goes
+      if (it->second.device == device && sort_touches(it->second, r)) {
+        drop_sort(it->first);
+        it = t_state->sorts.begin();
+      } else {
+        ++it;
+      }
+    }
     for (auto it = t_state->iotas.begin(); it != t_state->iotas.end();) {  // an index vector nobody has read yet
       const ByteRange v = range_of(it->first, 4ull * it->second.n);
       it = (it->second.device == device && v.overlaps(r)) ? t_state->iotas.erase(it) : std::next(it);
@@ -1890,7 +2038,9 @@ uintptr_t hook_on_free(int device, void *ptr, size_t bytes) {
       if (it->first.first == device && touches(it->second.writes, r)) {  // the skipped outputs die unseen
         if (it->second.idx) t_state->compactions.erase(it->second.idx);
         released.add(it->first.second);
+        const uint32_t *sortIdx = it->second.sortIdx;
         it = t_state->limbo.erase(it);
+        if (sortIdx) drop_sort(sortIdx);
       } else {
         if (it->first.first == device && touches(it->second.reads, r)) hold = hold_tag(it->first.second);
         ++it;
@@ -1913,7 +2063,11 @@ void hook_on_access(int device, const void *ptr, size_t bytes) {
     DeferLock lock(device);
     for (auto it = t_state->iotas.begin(); it != t_state->iotas.end();) {
       const ByteRange v = range_of(it->first, 4ull * it->second.n);
-      if (it->second.device == device && v.overlaps(r)) {
+      if (it->second.device == device && v.overlaps(r) && it->second.sorted) {
+        t_syncAfterUnlock.push_back(it->second.stream);
+        materialize_sort(it->first);
+        it = t_state->iotas.begin();
+      } else if (it->second.device == device && v.overlaps(r)) {
         launch_init_index(it->first, it->second.start, it->second.n, it->second.stream);
         t_syncAfterUnlock.push_back(it->second.stream);
         it = t_state->iotas.erase(it);
@@ -1971,6 +2125,14 @@ void hook_on_stream_destroy(int device, void *streamPtr) {
     DeviceGuard guard(device);
     {
       DeferLock lock(device);
+      for (auto it = t_state->sorts.begin(); it != t_state->sorts.end();) {
+        if (it->second.device == device && it->second.stream == stream) {
+          drop_sort(it->first);
+          it = t_state->sorts.begin();
+        } else {
+          ++it;
+        }
+      }
       t_state->pending.erase({device, stream});
       auto lim = t_state->limbo.find({device, stream});
       if (lim != t_state->limbo.end()) {
@@ -2176,6 +2338,301 @@ bool fuse_pending_into_hash_reduce(int device, hipStream_t stream, const Dimensi
     return false;
   }
   t_state->limbo[{device, stream}] = q;  // launchable until the next batch begins (begin_batch)
+  *groups = result;
+  return true;
+}
+
+// ---- Sort + Reduce over pending transforms (sort_reduce_fused.hip) ---------------------------------------------------------
+namespace {
+// The queue `pq` is "the dimension columns [and the measure] of rows [prev, prev + pq.n) of `in`": which job writes which
+// dimension, which one the measure (-1: none queued).  Caller holds the device's DeferLock.
+bool match_sort_jobs(const PendingQueue &pq, const DimensionVector &in, const DimLayoutD &L, int prev, int (&dimJob)[kFusedDims], int *measureJob) {
+  const int nd = L.numDims;
+  const size_t cap = static_cast<size_t>(in.VectorCapacity);
+  if (nd < 1 || nd > kFusedDims || in.NumDimsPerDimWidth[0] || in.NumDimsPerDimWidth[1]) return false;
+  if (pq.jobs.count != nd && pq.jobs.count != nd + 1) return false;
+  for (int c = 0; c < kFusedDims; c++) dimJob[c] = -1;
+  *measureJob = -1;
+  for (int k = 0; k < pq.jobs.count; k++) {
+    const SinkD &s = pq.jobs.s[k];
+    if (s.type == SINK_MEASURE) {
+      if (*measureJob >= 0 || s.baseCounts) return false;
+      *measureJob = k;
+      continue;
+    }
+    int d = -1;
+    for (int c = 0; c < nd; c++)
+      if (s.values == in.DimValues + static_cast<size_t>(L.valueOff[c]) * cap + static_cast<size_t>(L.width[c]) * prev &&
+          s.nulls == in.DimValues + static_cast<size_t>(L.valueBytes) * cap + cap * c + prev && s.width == L.width[c])
+        d = c;
+    if (s.type != SINK_DIM || d < 0 || dimJob[d] >= 0) return false;
+    dimJob[d] = k;
+  }
+  for (int c = 0; c < nd; c++)
+    if (dimJob[c] < 0) return false;
+  return true;
+}
+bool same_vector(const DimensionVector &a, const DimensionVector &b) {
+  return a.DimValues == b.DimValues && a.HashValues == b.HashValues && a.IndexVector == b.IndexVector && a.VectorCapacity == b.VectorCapacity &&
+         memcmp(a.NumDimsPerDimWidth, b.NumDimsPerDimWidth, sizeof(a.NumDimsPerDimWidth)) == 0;
+}
+}  // namespace
+
+// Sort(keys, length) when the rows [length - n, length) of `keys` are what this stream's pending transforms would write and
+// the index vector is still the iota InitIndexVector defined: nothing is hashed or sorted — the hash vector (a marker among
+// the lazy fills) and the index vector (its iota entry, `sorted`) are DEFINED as what Sort leaves.  Reduce consumes the
+// definition (below); every other reader runs it (materialize_sort).
+bool define_lazy_sort(int device, hipStream_t stream, const DimensionVector &keys, int length) {
+  if (!fuse_available() || !fused_sort_reduce_enabled() || length <= 0 || !keys.DimValues || !keys.HashValues || !keys.IndexVector ||
+      keys.VectorCapacity < length)
+    return false;
+  DimLayoutD L;
+  try {
+    L = make_dim_layout(keys.NumDimsPerDimWidth);
+  } catch (std::exception &) {
+    return false;
+  }
+  DeferLock lock(device);
+  auto io = t_state->iotas.find(keys.IndexVector);
+  if (io == t_state->iotas.end() || io->second.device != device || io->second.start != 0 || io->second.n != length || io->second.consumed ||
+      io->second.sorted)
+    return false;
+  auto it = t_state->pending.find({device, stream});
+  if (it == t_state->pending.end() || it->second.jobs.count == 0) return false;
+  const PendingQueue &pq = it->second;
+  const int prev = length - pq.n;
+  int dimJob[kFusedDims], measureJob = -1;
+  if (pq.n <= 0 || prev < 0 || !match_sort_jobs(pq, keys, L, prev, dimJob, &measureJob)) return false;
+  if (pq.idx) {  // the survivors must be re-derivable from the filter journal
+    auto j = t_state->journals.find(pq.idx);
+    if (j == t_state->journals.end() || !j->second.valid || j->second.start != 0 || j->second.device != device) return false;
+  }
+  uint8_t *hv = reinterpret_cast<uint8_t *>(keys.HashValues);
+  retire_fills(device, ByteRange{hv, hv + 8ull * static_cast<size_t>(length)}, false);
+  PendingSort ps{};
+  ps.device = device;
+  ps.stream = stream;
+  ps.keys = keys;
+  ps.length = length;
+  t_state->sorts[keys.IndexVector] = ps;
+  io->second.consumed = true;
+  io->second.sorted = true;
+  PendingFill marker{device, stream, 8ull * static_cast<size_t>(length), 0, 8, false};
+  marker.sortIdx = keys.IndexVector;
+  t_state->fills[hv] = marker;
+  return true;
+}
+
+bool fuse_pending_into_sort_reduce(int device, hipStream_t stream, const DimensionVector &in, uint8_t *inValues, const DimensionVector &out,
+                                   uint8_t *outValues, int valueBytes, int length, int aggFunc, int *groups) {
+  if (!fuse_available() || !in.IndexVector) return false;
+  PendingQueue q;
+  FusedPlanD plan;
+  memset(&plan, 0, sizeof(plan));
+  PendingSort ps{};
+  AggSpec a{};
+  int nd = 0, prev = 0, n0 = 0;
+  bool constMeasure = false;
+  uint64_t constBits = 0;
+  PendingFill fill{};
+  uint8_t *fillAt = nullptr;
+  {
+    DeferLock lock(device);
+    auto st = t_state->sorts.find(in.IndexVector);
+    if (st == t_state->sorts.end()) return false;  // nothing lazy about this Sort
+    ps = st->second;
+    bool ok = !ps.reduced && ps.device == device && ps.stream == stream && ps.length == length && same_vector(ps.keys, in) && inValues &&
+              out.DimValues && out.IndexVector && outValues && out.VectorCapacity >= length &&
+              memcmp(out.NumDimsPerDimWidth, in.NumDimsPerDimWidth, sizeof(in.NumDimsPerDimWidth)) == 0;
+    DimLayoutD L;
+    memset(&L, 0, sizeof(L));
+    if (ok) L = make_dim_layout(in.NumDimsPerDimWidth);
+    nd = L.numDims;
+    auto it = t_state->pending.find({device, stream});
+    ok = ok && it != t_state->pending.end() && it->second.jobs.count > 0;
+    int dimJob[kFusedDims], measureJob = -1;
+    if (ok) {
+      prev = length - it->second.n;
+      ok = it->second.n > 0 && prev >= 0 && match_sort_jobs(it->second, in, L, prev, dimJob, &measureJob);
+    }
+    if (ok) {
+      try {
+        a = make_agg_spec(aggFunc, valueBytes);
+        ok = fused_sort_reduce_supported(a);
+      } catch (std::exception &) {
+        ok = false;
+      }
+    }
+    const FilterJournal *journal = nullptr;
+    if (ok) {
+      const PendingQueue &pq = it->second;
+      n0 = pq.n;
+      if (pq.idx) {
+        auto j = t_state->journals.find(pq.idx);
+        ok = j != t_state->journals.end() && j->second.valid && j->second.start == 0 && j->second.device == device;
+        if (ok) {
+          journal = &j->second;
+          n0 = journal->n0;
+        }
+      }
+    }
+    if (ok) {
+      const PendingQueue &pq = it->second;
+      for (int k = 0; ok && k < pq.jobs.count; k++) ok = pq.colRows[k] >= static_cast<uint32_t>(n0);
+      uint8_t *measureRows = inValues + static_cast<size_t>(valueBytes) * prev;
+      if (ok && measureJob >= 0) {
+        const SinkD &sm = pq.jobs.s[measureJob];
+        ok = sm.values == measureRows && sm.width == valueBytes && sm.agg == aggFunc && !(valueBytes == 8 && sm.identity != 0);
+      } else if (ok) {  // a constant measure (COUNT(*)): the rows are a lazy fill
+        auto f = t_state->fills.find(measureRows);
+        ok = f != t_state->fills.end() && f->second.device == device && !f->second.sortIdx && f->second.unit == valueBytes &&
+             f->second.bytes == static_cast<size_t>(valueBytes) * pq.n;
+        if (ok) {
+          constMeasure = true;
+          fill = f->second;
+          fillAt = f->first;
+          constBits = fill.pattern;
+        }
+      }
+    }
+    if (ok) {
+      const PendingQueue &pq = it->second;
+      auto column_of = [](const FastOperands &f) { return FusedColumn{f.vals, f.nulls, f.bitOff, static_cast<uint32_t>(f.step ? f.step : 4)}; };
+      auto strip = [](FastOperands f) {
+        f.vals = nullptr;
+        f.nulls = nullptr;
+        f.idx = nullptr;
+        f.pad = 0;
+        return f;
+      };
+      auto kind_of = [](int dtype) { return (dtype == Int32 || dtype == Int16 || dtype == Int8) ? K_I32 : (dtype == Uint32 || dtype == Uint16 || dtype == Uint8) ? K_U32 : K_F32; };
+      for (int c = 0; c < nd; c++) {
+        const int k = dimJob[c];
+        plan.cols[c] = column_of(pq.jobs.f[k]);
+        plan.dims[c].f = strip(pq.jobs.f[k]);
+        plan.dims[c].col = c;
+        plan.dims[c].outKind = kind_of(pq.jobs.s[k].dtype);
+        plan.dimWidth[c] = L.width[c];
+      }
+      plan.numCols = nd;
+      plan.measureWidth = valueBytes;
+      if (measureJob >= 0) {
+        plan.cols[nd] = column_of(pq.jobs.f[measureJob]);
+        plan.measure.f = strip(pq.jobs.f[measureJob]);
+        plan.measure.col = nd;
+        plan.measure.outKind = kind_of(pq.jobs.s[measureJob].dtype);
+        plan.measureDtype = pq.jobs.s[measureJob].dtype;
+        plan.identity = pq.jobs.s[measureJob].identity;
+        plan.numCols = nd + 1;
+      } else {
+        plan.measure.col = -1;
+        plan.measure.f.bbits = static_cast<uint32_t>(constBits);  // (what the scan's records carry; the merge takes constBits)
+        plan.measureDtype = valueBytes == 8 ? Int64 : (a.vtype == V_I32 ? Int32 : Uint32);
+      }
+      if (journal) {
+        ok = journal->filters.size() <= static_cast<size_t>(kFusedFilters);
+        for (size_t k = 0; ok && k < journal->filters.size(); k++) {
+          const FastOperands &f = journal->filters[k];
+          ok = journal->colRows[k] >= static_cast<uint32_t>(n0);
+          int col = -1;
+          for (int c = 0; c < plan.numCols; c++)
+            if (plan.cols[c].vals == f.vals && plan.cols[c].nulls == f.nulls && plan.cols[c].bitOff == f.bitOff &&
+                plan.cols[c].step == static_cast<uint32_t>(f.step ? f.step : 4))
+              col = c;
+          if (col < 0 && plan.numCols < kFusedCols) {
+            col = plan.numCols++;
+            plan.cols[col] = column_of(f);
+          }
+          ok = ok && col >= 0;
+          plan.filters[k].f = strip(f);
+          plan.filters[k].col = col;
+          plan.filters[k].outKind = K_BOOL;
+        }
+        plan.numFilters = static_cast<int>(journal->filters.size());
+      }
+    }
+    if (!ok) {  // not this case after all: Sort runs (and the ordinary Reduce follows)
+      materialize_sort(in.IndexVector);
+      return false;
+    }
+    PendingQueue &pq = it->second;
+    q = pq;  // taken out of the queue: nobody else launches it
+    pq.jobs.count = 0;
+    pq.reads.clear();
+    pq.writes.clear();
+    pq.overWait = false;
+    if (q.idx) t_state->journals.erase(q.idx);
+    if (constMeasure) t_state->fills.erase(fillAt);
+    drop_sort(in.IndexVector);  // (while the kernels run nothing is defined; the reduced state is entered below)
+  }
+  // the outputs are about to be rewritten, the previous result is read by kernels of this call
+  retire_fills_for_write(device, outValues, static_cast<size_t>(valueBytes) * length);
+  retire_fills_for_write(device, out.IndexVector, 4ull * static_cast<size_t>(length));
+  grouped_note_write(device, out);
+  grouped_note_write(device, outValues, static_cast<size_t>(valueBytes) * length);
+  {
+    size_t rowBytes = 0;
+    for (int w = 0; w < NUM_DIM_WIDTH; w++) rowBytes += static_cast<size_t>(out.NumDimsPerDimWidth[w]) * ((1u << (NUM_DIM_WIDTH - 1 - w)) + 1);
+    drop_skipped_outputs(device, out.DimValues, rowBytes * static_cast<size_t>(in.VectorCapacity), outValues, static_cast<size_t>(valueBytes) * length);
+    if (prev > 0) {  // rows [0, prev) are read by this call's kernels: whatever still only defines them is written (no flush:
+                     // this batch's own lazy compaction must stay lazy)
+      launch_pending_writers(device, in.DimValues, rowBytes * static_cast<size_t>(in.VectorCapacity));
+      launch_pending_writers(device, inValues, static_cast<size_t>(valueBytes) * prev);
+      materialize_fills_for_read(device, in.DimValues, rowBytes * static_cast<size_t>(in.VectorCapacity));
+      materialize_fills_for_read(device, inValues, static_cast<size_t>(valueBytes) * prev);
+    }
+  }
+  int result;
+  try {
+    result = fused_sort_reduce_run(device, plan, nd, constMeasure, constBits, n0, in, inValues, prev, out, outValues, a, stream);
+  } catch (...) {
+    result = -1;
+  }
+  if (result < 0) {  // declined, or a partition overflowed: the real thing — transforms, the constant rows, InitIndexVector, Sort
+    {
+      DeferLock lock(device);
+      launch_queue(stream, q, /*inOrder=*/true);
+      if (constMeasure) launch_fill(fillAt, fill);
+      launch_init_index(in.IndexVector, 0, length, stream);
+    }
+    g_releaseHeld(device, hold_tag(stream));
+    sort_keys_now(in, length, stream);
+    return false;
+  }
+  mem_note_dim_rows(device, out, 0, static_cast<size_t>(result));
+  mem_note_write(device, outValues, static_cast<size_t>(valueBytes) * static_cast<size_t>(result));
+  DeferLock lock(device);
+  q.sortIdx = in.IndexVector;
+  t_state->limbo[{device, stream}] = q;  // launchable until the next batch begins (begin_batch)
+  ps.reduced = true;
+  ps.outKeys = out;
+  ps.inValues = inValues;
+  ps.outValues = outValues;
+  ps.valueBytes = valueBytes;
+  ps.aggFunc = aggFunc;
+  ps.groups = result;
+  ps.constMeasure = constMeasure;
+  ps.fill = fill;
+  ps.fillAt = fillAt;
+  t_state->sorts[in.IndexVector] = ps;
+  PendingIota io{device, stream, 0, length};
+  io.consumed = true;
+  io.sorted = true;
+  t_state->iotas[in.IndexVector] = io;
+  {
+    uint8_t *hv = reinterpret_cast<uint8_t *>(in.HashValues);
+    retire_fills(device, ByteRange{hv, hv + 8ull * static_cast<size_t>(length)}, false);
+    PendingFill marker{device, stream, 8ull * static_cast<size_t>(length), 0, 8, false};
+    marker.sortIdx = in.IndexVector;
+    t_state->fills[hv] = marker;
+    if (result > 0) {
+      uint8_t *oi = reinterpret_cast<uint8_t *>(out.IndexVector);
+      retire_fills(device, ByteRange{oi, oi + 4ull * static_cast<size_t>(result)}, false);
+      PendingFill om{device, stream, 4ull * static_cast<size_t>(result), 0, 4, false};
+      om.sortIdx = in.IndexVector;
+      t_state->fills[oi] = om;
+    }
+  }
   *groups = result;
   return true;
 }

@@ -1,0 +1,248 @@
+"""Sort + Reduce without sorting rows (aresdb_amd/csrc/algo/sort_reduce_fused.hip): the Go host's call sequence of the
+reference's DEFAULT aggregation path (query/aql_batchexecutor.go:236-251: InitIndexVector over previous result + batch,
+Sort, Reduce — every aggregate but SUM_SIGNED / SUM_FLOAT, and those too unless enable_hash_reduction is set) replayed at
+the ABI, batch after batch with the result buffers ping-ponged as query/aql_processor.go:718-724 does.  The HIP library
+DEFINES Sort's outputs while the batch's transforms are still pending and Reduce aggregates by the 64-bit row hash; what a
+host can observe must be what the oracle (and the reference build) leave: the groups in ascending hash order, bit for bit
+— and, for a host that does look, the hash and index vectors between and after the two calls (materialised on demand)."""
+import os
+
+import numpy as np
+import pytest
+
+import harness as H
+from aresdb_amd import abi
+
+pytestmark = pytest.mark.gpu
+
+U32 = (0, 0, 1, 0, 0)
+
+
+def _kernels_of(hip, fn):
+    hip.profiler_enable(True)
+    try:
+        res = fn()
+        hip.wait()
+        return res, hip.profiler_report()
+    finally:
+        hip.profiler_enable(False)
+
+
+def _fusion_on():
+    return all(os.environ.get(k, "1") != "0" for k in ("ARES_FUSE", "ARES_DEFER", "ARES_SORT_FUSE", "ARES_RTC"))
+
+
+class Shape:
+    """One query shape: columns, filters (column, functor, constant), dimensions (column, functor or None, constant, output
+    type), measure (None = COUNT(*): the literal 1; else a column), aggregate, value bytes."""
+
+    def __init__(self, name, cols, filters, dims, measure, agg, value_type, ndw):
+        self.name, self.cols, self.filters, self.dims, self.measure, self.agg, self.value_type, self.ndw = \
+            name, cols, filters, dims, measure, agg, value_type, ndw
+        self.value_bytes = abi.DATA_TYPE_BYTES[value_type]
+
+
+def make_batch(rng, shape, n, null_fraction=0.03):
+    cols = {}
+    for name, (dtype, hi) in shape.cols.items():
+        np_t = {abi.Uint32: np.uint32, abi.Int32: np.int32, abi.Uint16: np.uint16, abi.Uint8: np.uint8, abi.Int16: np.int16}[dtype]
+        lo = -hi if dtype in (abi.Int32, abi.Int16) else 0
+        vals = rng.integers(lo, hi, n).astype(np_t)
+        valid = (rng.random(n) >= null_fraction) if null_fraction > 0 else None
+        cols[name] = (dtype, vals, valid)
+    return cols
+
+
+SHAPES = [
+    # C3's dimensions, COUNT(*) — the shape of the reference's first example query (examples/1k_trips/queries/total_trips.aql)
+    Shape("count_c3", {"ts": (abi.Uint32, 86400 * 7), "d1": (abi.Uint32, 100), "d2": (abi.Uint32, 50), "d3": (abi.Uint32, 2)},
+          [("d1", abi.LessThan, 90)],
+          [("ts", abi.Floor, 3600, abi.Uint32), ("d1", None, 0, abi.Uint32), ("d2", None, 0, abi.Uint32), ("d3", None, 0, abi.Uint32)],
+          None, abi.AGGR_SUM_UNSIGNED, abi.Uint32, (0, 0, 4, 0, 0)),
+    # enable_hash_reduction = false: SUM over an unsigned column goes through Sort + Reduce into 8 bytes (Int64 output type)
+    Shape("sum8_two_dims", {"ts": (abi.Uint32, 86400), "d1": (abi.Uint32, 40), "m": (abi.Uint32, 1000)},
+          [("ts", abi.GreaterThanOrEqual, 3600), ("ts", abi.LessThan, 80000)],
+          [("ts", abi.Floor, 600, abi.Uint32), ("d1", None, 0, abi.Uint32)],
+          "m", abi.AGGR_SUM_UNSIGNED, abi.Int64, (0, 0, 2, 0, 0)),
+    # the trips schema: city_id Uint16 in a 2-byte slot, status Uint8 filter (examples/1k_trips/schema/trips.json), COUNT(*)
+    Shape("count_trips", {"request_at": (abi.Uint32, 86400 * 3), "city_id": (abi.Uint16, 300), "status": (abi.Uint8, 4)},
+          [("request_at", abi.GreaterThanOrEqual, 1000), ("request_at", abi.LessThan, 200000), ("status", abi.Equal, 2)],
+          [("request_at", abi.Floor, 3600, abi.Uint32), ("city_id", None, 0, abi.Uint16)],
+          None, abi.AGGR_SUM_UNSIGNED, abi.Uint32, (0, 0, 1, 1, 0)),
+    # MIN / MAX of a signed column, one dimension, no filter at all
+    Shape("min_signed", {"d1": (abi.Uint32, 3000), "m": (abi.Int32, 100000)}, [],
+          [("d1", None, 0, abi.Uint32)], "m", abi.AGGR_MIN_SIGNED, abi.Int32, (0, 0, 1, 0, 0)),
+    Shape("max_unsigned", {"d1": (abi.Uint32, 7), "d2": (abi.Uint32, 9), "m": (abi.Uint32, 1 << 30)}, [("d2", abi.NotEqual, 3)],
+          [("d1", abi.Plus, 5, abi.Uint32), ("d2", None, 0, abi.Uint32)], "m", abi.AGGR_MAX_UNSIGNED, abi.Uint32, (0, 0, 2, 0, 0)),
+]
+
+
+def run_sequence(b, shape, batches, read=frozenset(), cap_slack=10):
+    """The Go host's per-batch sequence; returns every observable the test compares.  read: any of "iota" (the index
+    vector between InitIndexVector and Sort), "sorted" (hash + index vector between Sort and Reduce), "after" (input hash /
+    index vector and output index vector after Reduce), "inputs" (input dimension and measure rows after Reduce)."""
+    cap = sum(len(next(iter(bt.values()))[1]) for bt in batches) + cap_slack
+    vb = shape.value_bytes
+    dv = [H.DimVector(b, cap, shape.ndw, True, False) for _ in range(2)]   # dimension + hash vector pairs: swapped per batch
+    iv = [H.Buf(b, nbytes=4 * cap) for _ in range(2)]                      # dimIndexVectorD: NOT swapped
+    vv = [H.Buf(b, nbytes=vb * cap) for _ in range(2)]
+    res = 0
+    log = []
+    vtype = {abi.Uint32: np.uint32, abi.Int32: np.int32, abi.Int64: np.int64}[shape.value_type]
+
+    def vec(i, index):
+        s = dv[i].struct()
+        s.IndexVector = index.ptr
+        return s
+
+    for bt in batches:
+        n = len(next(iter(bt.values()))[1])
+        cols = {k: H.Column(b, t, v, valid=ok) for k, (t, v, ok) in bt.items()}
+        idx, pred = H.Buf(b, nbytes=4 * n), H.Buf(b, nbytes=n)
+        b.call("InitIndexVector", idx.ptr, 0, n, None, 0)
+        kept = n
+        for col, ft, k in shape.filters:
+            kept = b.call("BinaryFilter", cols[col].input(), H.const_int(k), idx.ptr, pred.ptr, kept, None, 0, None, 0, ft, None, 0)
+        offs = dv[0].dim_offsets()
+        # dimensions in vector (descending width) order = the order of shape.dims here
+        for d, (col, ft, k, otype) in enumerate(shape.dims):
+            out = H.dimension_output(dv[0].values.ptr + offs[d][0] + offs[d][2] * res, dv[0].values.ptr + offs[d][1] + res, otype)
+            if kept <= 0:
+                continue
+            if ft is None:
+                b.call("UnaryTransform", cols[col].input(), out, idx.ptr, kept, None, 0, abi.Noop, None, 0)
+            else:
+                b.call("BinaryTransform", cols[col].input(), H.const_int(k), out, idx.ptr, kept, None, 0, ft, None, 0)
+        if kept > 0:
+            mout = H.measure_output(vv[0].ptr + vb * res, shape.value_type, shape.agg)
+            if shape.measure is None:
+                b.call("UnaryTransform", H.const_int(1), mout, idx.ptr, kept, None, 0, abi.Noop, None, 0)
+            else:
+                b.call("UnaryTransform", cols[shape.measure].input(), mout, idx.ptr, kept, None, 0, abi.Noop, None, 0)
+        b.wait()
+        for c in cols.values():  # cleanupBeforeAggregation
+            c.free()
+        idx.free(), pred.free()
+        length = res + kept
+        entry = {"kept": kept}
+        b.call("InitIndexVector", iv[0].ptr, 0, length, None, 0)
+        if "iota" in read:
+            entry["iota"] = iv[0].read(np.uint32, length)
+        kin, kout = vec(0, iv[0]), vec(1, iv[1])
+        b.call("Sort", kin, length, None, 0)
+        if "sorted" in read:
+            entry["hash"] = dv[0].hash.read(np.uint64, length)
+            entry["index"] = iv[0].read(np.uint32, length)
+        groups = b.call("Reduce", kin, vv[0].ptr, kout, vv[1].ptr, vb, length, shape.agg, None, 0)
+        b.wait()
+        entry["groups"] = groups
+        if "after" in read:
+            entry["hash_after"] = dv[0].hash.read(np.uint64, length)
+            entry["index_after"] = iv[0].read(np.uint32, length)
+            entry["out_index"] = iv[1].read(np.uint32, groups)
+        if "inputs" in read:
+            entry["in_rows"] = dv[0].rows(length)
+            entry["in_values"] = vv[0].read(vtype, length)
+        entry["rows"] = dv[1].rows(groups)
+        entry["values"] = vv[1].read(vtype, groups)
+        log.append(entry)
+        res = groups
+        dv[0], dv[1] = dv[1], dv[0]
+        vv[0], vv[1] = vv[1], vv[0]
+    for x in dv + iv + vv:
+        x.free()
+    return log
+
+
+def assert_same(got, want, what):
+    assert len(got) == len(want)
+    for k, (g, w) in enumerate(zip(got, want)):
+        assert set(g) == set(w), (what, k)
+        for key in w:
+            if isinstance(w[key], np.ndarray):
+                assert np.array_equal(g[key], w[key]), (what, "batch", k, key, g[key][:8], w[key][:8])
+            else:
+                assert g[key] == w[key], (what, "batch", k, key)
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=[s.name for s in SHAPES])
+def test_sort_reduce_consumes_pending_transforms(shape):
+    """Four batches (one of them a single row, one large enough for several partitions); the output rows IN ORDER, their
+    values and the group counts are the oracle's; on the HIP side nothing is sorted and no transform is launched."""
+    hip, oracle = H.hip_backend(), H.oracle_backend()
+    rng = np.random.default_rng(sum(map(ord, shape.name)))
+    batches = [make_batch(rng, shape, n) for n in (5000, 1, 40000, 700)]
+    got, kernels = _kernels_of(hip, lambda: run_sequence(hip, shape, batches))
+    want = run_sequence(oracle, shape, batches)
+    assert_same(got, want, shape.name)
+    if _fusion_on():
+        assert any(k.startswith("sr_scan_rtc") for k in kernels) and any(k.startswith("sr_merge_kernel") for k in kernels), sorted(kernels)
+        assert not any(k.startswith(("radix_pass_kernel", "transform_", "reduce_kernel", "filter_pred")) for k in kernels), sorted(kernels)
+
+
+@pytest.mark.parametrize("read", [("iota",), ("sorted",), ("after",), ("inputs",), ("sorted", "after"), ("iota", "sorted", "after", "inputs")],
+                         ids=lambda r: "+".join(r))
+@pytest.mark.parametrize("shape", [SHAPES[0], SHAPES[2], SHAPES[1]], ids=lambda s: s.name)
+def test_lazily_defined_sort_materialises_for_a_host_that_looks(shape, read):
+    """A host that reads the index vector before Sort, the hash / index vector between Sort and Reduce, or — after Reduce — the
+    input's hash / index vector, the output's index vector (the groups' representatives) or the input's dimension and measure
+    rows, sees what the reference leaves there: the definition is run (or replayed) on demand."""
+    hip, oracle = H.hip_backend(), H.oracle_backend()
+    rng = np.random.default_rng(99 + len(read))
+    batches = [make_batch(rng, shape, n) for n in (3000, 9000, 50)]
+    got = run_sequence(hip, shape, batches, read=frozenset(read))
+    want = run_sequence(oracle, shape, batches, read=frozenset(read))
+    assert_same(got, want, (shape.name, read))
+
+
+def test_many_groups_per_partition_fall_back_to_the_real_sort(monkeypatch):
+    """More groups than a partition's table orders (ARES_SR_MAX_GROUPS lowers the limit to 100 here): the first batch overflows
+    inside the merge, the second is declined up front (the previous result alone is too large) — either way the ordinary
+    Sort + Reduce runs over the same buffers and the result is the oracle's."""
+    hip, oracle = H.hip_backend(), H.oracle_backend()
+    shape = Shape("distinct", {"d1": (abi.Uint32, 1 << 30)}, [], [("d1", None, 0, abi.Uint32)], None, abi.AGGR_SUM_UNSIGNED, abi.Uint32, U32)
+    rng = np.random.default_rng(5)
+    batches = [make_batch(rng, shape, n, null_fraction=0) for n in (30000, 30000)]
+    monkeypatch.setenv("ARES_SR_MAX_GROUPS", "100")
+    hip.reload_env()
+    try:
+        got, kernels = _kernels_of(hip, lambda: run_sequence(hip, shape, batches, read=frozenset(("after",))))
+    finally:
+        monkeypatch.delenv("ARES_SR_MAX_GROUPS")
+        hip.reload_env()
+    want = run_sequence(oracle, shape, batches, read=frozenset(("after",)))
+    assert_same(got, want, "distinct")
+    assert any(k.startswith("radix_pass_kernel") for k in kernels), sorted(kernels)
+
+
+def test_float_sums_keep_the_real_sort():
+    """SUM over a float measure depends on the order of additions (ascending hash, then row): never consumed."""
+    hip, oracle = H.hip_backend(), H.oracle_backend()
+    rng = np.random.default_rng(8)
+    n = 6000
+    d1 = rng.integers(0, 50, n).astype(np.uint32)
+    m = (rng.integers(0, 400, n) / 4).astype(np.float32)
+
+    def seq(b):
+        cap = n + 10
+        cols = {"d1": H.Column(b, abi.Uint32, d1), "m": H.Column(b, abi.Float32, m)}
+        idx = H.Buf(b, nbytes=4 * n)
+        din, dout = H.DimVector(b, cap, U32), H.DimVector(b, cap, U32)
+        vin, vout = H.Buf(b, nbytes=8 * cap), H.Buf(b, nbytes=8 * cap)
+        b.call("InitIndexVector", idx.ptr, 0, n, None, 0)
+        offs = din.dim_offsets()
+        b.call("UnaryTransform", cols["d1"].input(), H.dimension_output(din.values.ptr + offs[0][0], din.values.ptr + offs[0][1], abi.Uint32),
+               idx.ptr, n, None, 0, abi.Noop, None, 0)
+        b.call("UnaryTransform", cols["m"].input(), H.measure_output(vin.ptr, abi.Float64, abi.AGGR_SUM_FLOAT), idx.ptr, n, None, 0, abi.Noop, None, 0)
+        b.wait()
+        b.call("InitIndexVector", din.index.ptr, 0, n, None, 0)
+        b.call("Sort", din.struct(), n, None, 0)
+        g = b.call("Reduce", din.struct(), vin.ptr, dout.struct(), vout.ptr, 8, n, abi.AGGR_SUM_FLOAT, None, 0)
+        b.wait()
+        out = (g, dout.rows(g), vout.read(np.float64, g))
+        for x in list(cols.values()) + [idx, din, dout, vin, vout]:
+            x.free()
+        return out
+
+    got, want = seq(hip), seq(oracle)
+    assert got[0] == want[0] and got[1] == want[1] and np.array_equal(got[2], want[2])

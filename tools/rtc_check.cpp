@@ -119,6 +119,32 @@ int main(int argc, char **argv) {
     if (int rc = build(rtc_scan_source(u, 2, 9, true), "_scompact", "signed narrow compact scan")) return rc;
     if (int rc = build(rtc_merge_source(u, 2, 9, agg, w, true), "_scmerge", "signed narrow compact merge")) return rc;
   }
+  {  // the Sort + Reduce path (sort_reduce_fused.hip): records keyed by lo64(murmur3_x64_128), constant measure (COUNT(*)) and a
+     // column measure summed into 8 bytes, the C3 dimensions and the narrow trips shape
+    FusedPlanD c = p;
+    c.numCols = 4;  // no measure column: the filter's d1 is dimension 1's column
+    c.measure.col = -1; c.measure.f = col(K_U32); c.measure.f.bbits = 1; c.measureDtype = Uint32; c.measureWidth = 4; c.identity = 0;
+    if (int rc = build(rtc_sort_scan_source(c, 4, 9), "_sort_count", "sort scan (COUNT)")) return rc;
+    {
+      FusedPlanD c2 = c;
+      c2.measure.f.bbits = 7;
+      if (rtc_sort_scan_source(c2, 4, 9) != rtc_sort_scan_source(c, 4, 9)) { puts("the constant measure leaks into the source"); return 22; }
+    }
+    FusedPlanD m8 = p;
+    m8.measure.f = col(K_U32); m8.measure.outKind = K_I32; m8.measureDtype = Int64; m8.measureWidth = 8;
+    if (int rc = build(rtc_sort_scan_source(m8, 4, 9), "_sort_sum8", "sort scan (SUM into 8 bytes)")) return rc;
+    FusedPlanD t = p;  // trips: dims [Floor(request_at, 3600) Uint32, city_id Uint16 -> 2-byte slot], COUNT(*), three filters
+    t.numCols = 3;
+    t.cols[0].step = 4; t.cols[1].step = 2; t.cols[2].step = 1;
+    t.dims[1] = p.dims[1]; t.dims[1].col = 1;
+    t.dimWidth[0] = 4; t.dimWidth[1] = 2;
+    t.measure = c.measure; t.measureDtype = Uint32; t.measureWidth = 4;
+    t.numFilters = 3;
+    t.filters[0] = p.filters[0]; t.filters[0].f.functor = GreaterThanOrEqual; t.filters[0].col = 0;
+    t.filters[1] = p.filters[0]; t.filters[1].f.functor = LessThan; t.filters[1].col = 0;
+    t.filters[2] = p.filters[0]; t.filters[2].f.functor = Equal; t.filters[2].col = 2;
+    if (int rc = build(rtc_sort_scan_source(t, 2, 9), "_sort_trips", "narrow sort scan (COUNT)")) return rc;
+  }
   // the vector-sourced scan (HashReduce on materialised dimension / measure vectors)
   for (int vw = 4; vw <= 8; vw += 4)
     for (int nd = 1; nd <= 4; nd += 3) {

@@ -60,7 +60,61 @@ def murmur3_32_rows(values, valids):
     return h
 
 
-def _codes_of_batch(b, limit=None, dims=ALL_DIMS, d1_below=90, ts_range=None):
+def murmur3_128_lo64_rows(rows):
+    """lo64(murmur3_x64_128) (seed 0) of every row of a uint8 matrix [n, row bytes] — the key Sort orders by
+    (query/utils.cu:157-241, query/iterator.hpp:934-1025: the packed row is [dimension values, widest first][one validity
+    byte per dimension])."""
+    rows = np.ascontiguousarray(rows, dtype=np.uint8)
+    n, nbytes = rows.shape
+    c1, c2 = np.uint64(0x87c37b91114253d5), np.uint64(0x4cf5ad432745937f)
+    padded = np.zeros((n, (nbytes + 15) // 16 * 16), np.uint8)
+    padded[:, :nbytes] = rows
+    lanes = padded.view("<u8")  # [n, 2 * blocks]
+
+    def rotl(x, r):
+        return (x << np.uint64(r)) | (x >> np.uint64(64 - r))
+
+    def fmix(k):
+        k ^= k >> np.uint64(33)
+        k = k * np.uint64(0xff51afd7ed558ccd)
+        k ^= k >> np.uint64(33)
+        k = k * np.uint64(0xc4ceb9fe1a85ec53)
+        k ^= k >> np.uint64(33)
+        return k
+
+    h1 = np.zeros(n, np.uint64)
+    h2 = np.zeros(n, np.uint64)
+    with np.errstate(over="ignore"):
+        for b in range(nbytes // 16):
+            k1, k2 = lanes[:, 2 * b].copy(), lanes[:, 2 * b + 1].copy()
+            k1 = rotl(k1 * c1, 31) * c2
+            h1 ^= k1
+            h1 = (rotl(h1, 27) + h2) * np.uint64(5) + np.uint64(0x52dce729)
+            k2 = rotl(k2 * c2, 33) * c1
+            h2 ^= k2
+            h2 = (rotl(h2, 31) + h1) * np.uint64(5) + np.uint64(0x38495ab5)
+        tail = nbytes % 16
+        if tail:
+            b = nbytes // 16
+            if tail > 8:
+                h2 ^= rotl(lanes[:, 2 * b + 1] * c2, 33) * c1
+            h1 ^= rotl(lanes[:, 2 * b] * c1, 31) * c2
+        h1 ^= np.uint64(nbytes)
+        h2 ^= np.uint64(nbytes)
+        h1 = h1 + h2
+        h2 = h2 + h1
+        h1, h2 = fmix(h1), fmix(h2)
+        return h1 + h2
+
+
+def row_hashes_of_fetched(dims_, valids):
+    """64-bit row hashes of a fetched result (NativeQuery.fetch: per-dimension value bytes in vector order, validity bytes)."""
+    n = len(valids[0]) if valids else 0
+    parts = [np.frombuffer(d, np.uint8).reshape(n, -1) for d in dims_] + [np.frombuffer(v, np.uint8).reshape(n, 1) for v in valids]
+    return murmur3_128_lo64_rows(np.concatenate(parts, axis=1)) if n else np.zeros(0, np.uint64)
+
+
+def _codes_of_batch(b, limit=None, dims=ALL_DIMS, d1_below=90, ts_range=None, measure="m"):
     """dense key code, keep mask and float64 measure of every row of one C3 batch (torch, on the
     batch's device) for the group-by dimensions `dims` (a subset of ts-bucket, d1, d2, d3; the filter d1 < 90 and the
     measure stay); a null dimension is its own key slot, a null measure contributes 0."""
@@ -90,15 +144,19 @@ def _codes_of_batch(b, limit=None, dims=ALL_DIMS, d1_below=90, ts_range=None):
             v = torch.div(v, 3600, rounding_mode="floor")
         k = code(v, ok, _RADIX[name] - 1)
         c = k if c is None else c * _RADIX[name] + k
+    if measure != "m":  # an integer column summed (null -> 0): "count" takes the row counts instead
+        m, mv = col(measure if measure != "count" else "d1")
     mm = m.to(torch.float64)
     if mv is not None:
         mm = torch.where(mv, mm, torch.zeros_like(mm))
     return c, keep, mm
 
 
-def exact_groups(batches, limit_first_batch=None, dims=ALL_DIMS, d1_below=90, ts_range=None):
+def exact_groups(batches, limit_first_batch=None, dims=ALL_DIMS, d1_below=90, ts_range=None, measure="m"):
     """Exact group-by of the C3 query (group-by dimensions `dims`) over `batches` (all rows, or the first
-    `limit_first_batch` rows of the first batch only).  Returns numpy arrays (code, sum, first_row, rows) of the groups."""
+    `limit_first_batch` rows of the first batch only).  Returns numpy arrays (code, sum, first_row, rows) of the groups.
+    measure: "m" (SUM of the float measure), another column's name (SUM of that integer column, nulls as 0) or "count"
+    (COUNT(*): the sums are the row counts)."""
     dev = batches[0]["m"].blob.device
     space = key_space(dims)
     # A small key space is spread over `salt` sub-slots per key (row mod salt) and folded at the end: index_add_ /
@@ -110,7 +168,7 @@ def exact_groups(batches, limit_first_batch=None, dims=ALL_DIMS, d1_below=90, ts
     first = torch.full((space * salt,), torch.iinfo(torch.int64).max, dtype=torch.int64, device=dev)
     offset = 0
     for b in (batches[:1] if limit_first_batch is not None else batches):
-        c, keep, mm = _codes_of_batch(b, limit_first_batch, dims, d1_below, ts_range)
+        c, keep, mm = _codes_of_batch(b, limit_first_batch, dims, d1_below, ts_range, measure)
         rows = torch.arange(offset, offset + c.numel(), dtype=torch.int64, device=dev)[keep]
         idx = c[keep]
         if salt > 1:
@@ -125,6 +183,8 @@ def exact_groups(batches, limit_first_batch=None, dims=ALL_DIMS, d1_below=90, ts
         cnt = cnt.view(space, salt).sum(dim=1)
         first = first.view(space, salt).amin(dim=1)
     live = torch.nonzero(cnt > 0).reshape(-1)
+    if measure == "count":
+        acc = cnt.to(torch.float64)
     return (live.cpu().numpy(), acc[live].cpu().numpy(), first[live].cpu().numpy(), cnt[live].cpu().numpy())
 
 
@@ -189,20 +249,26 @@ def compare_tables(got_code, got_sum, want_code, want_sum, rel=0.0):
     return None
 
 
-def compare_result(fetched, expected, hash_identity=True, rel=0.0, dims=ALL_DIMS):
+def compare_result(fetched, expected, hash_identity=True, rel=0.0, dims=ALL_DIMS, measure_dtype=np.float64, ordered=False):
     """fetched = (dims, valids, measures) of NativeQuery.fetch(); expected = exact_groups(...).
     hash_identity: the result comes from HashReduce (groups are hashes); False: Sort+Reduce on the
-    64-bit hash (exact groups at these cardinalities).  Returns a report dict."""
+    64-bit hash (exact groups at these cardinalities).  measure_dtype: how the fetched measure bytes read (float64 sums,
+    uint32 counts, int64 integer sums).  ordered: the rows must come in strictly ascending order of their 64-bit row hash
+    (what Sort + Reduce leaves: query/sort_reduce.cu:118-249).  Returns a report dict."""
     dims_, valids, meas = fetched
     code, sums, first_row, _ = expected
     got_code = encode_rows([np.frombuffer(d, np.uint32) for d in dims_], [np.frombuffer(v, np.uint8) for v in valids], dims)
-    got_sum = np.frombuffer(meas, np.float64)
+    got_sum = np.frombuffer(meas, measure_dtype).astype(np.float64)
     merged = 0
     if hash_identity:
         want_code, want_sum, merged = predict_hash_merges(code, sums, first_row, dims)
     else:
         want_code, want_sum = code, sums
     why = compare_tables(got_code, got_sum, want_code, want_sum, rel)
+    if why is None and ordered and len(got_code) > 1:
+        h = row_hashes_of_fetched(dims_, valids)
+        if not (h[1:] > h[:-1]).all():
+            why = f"rows are not in ascending order of their 64-bit hash (first descent at row {int(np.nonzero(h[1:] <= h[:-1])[0][0]) + 1})"
     return {"status": "ok" if why is None else "MISMATCH: " + why, "groups": int(len(got_code)),
             "expected_groups": int(len(want_code)), "distinct_dimension_rows": int(len(code)),
             "merged_by_32bit_hash": merged}

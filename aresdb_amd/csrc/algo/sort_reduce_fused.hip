@@ -30,6 +30,7 @@
 #include <hip/hip_runtime.h>
 
 #include <memory>
+#include <vector>
 
 #include "aggregate.hpp"
 #include "common.hpp"
@@ -50,14 +51,16 @@ using hr::kThreads;
 
 constexpr uint64_t kEmptyKey = ~0ull;
 constexpr uint32_t kNoRow = 0xFFFFFFFFu;
-// table slots per partition: 16 bytes per slot with 4-byte values (128 KB), 20 with 8-byte values (140 KB).  The last
-// kTail slots are overflow room for the clusters at the table's end (no wrap-around: order is position)
+// table slots per partition: 16 bytes per slot with 4-byte values (128 KB), 20 with 8-byte values (135 KB) — what a
+// workgroup's 160 KB of LDS leave beside the per-wavefront queues of records that miss their home bucket.  The last kTail
+// slots are overflow room for the clusters at the table's end (no wrap-around: order is position)
+constexpr uint32_t kQueueCap = 80, kQueueDrain = 16;  // per wavefront: drained from kQueueDrain entries on (a push adds <= 64)
 template <int VW>
 struct Table {
-  static constexpr int kSlots = VW == 4 ? 8192 : 7168;
-  static constexpr int kTail = 512;
+  static constexpr int kSlots = VW == 4 ? 8192 : 6912;
+  static constexpr int kTail = 256;
   static constexpr int kHomes = kSlots - kTail;
-  static constexpr int kPerLane = kSlots / kThreads;
+  static constexpr int kPerLane = (kSlots + kThreads - 1) / kThreads;
   static constexpr int kMaxGroups = kHomes * 13 / 16;  // beyond ~0.8 the clusters (and the ranking walks) grow quickly
 };
 
@@ -88,6 +91,7 @@ struct SrArgs {
   // emission
   uint8_t *dimOut;
   uint8_t *outValues;
+  uint64_t *phases;  // ARES_HR_PHASES=1 (diagnostics): six time stamps per partition (100 MHz clock), else null
 };
 
 __device__ __forceinline__ uint32_t sr_partition(uint64_t key, int pb) { return pb ? static_cast<uint32_t>(key >> (64 - pb)) : 0u; }
@@ -159,10 +163,11 @@ template <int VW>
 __global__ __launch_bounds__(kThreads) void sr_merge_kernel(SrArgs m) {
   using T = Table<VW>;
   using V = typename Slots<VW>::V;
-  __shared__ uint64_t sKeys[T::kSlots];
-  __shared__ uint32_t sRows[T::kSlots];
-  __shared__ V sVals[T::kSlots];
+  __shared__ __attribute__((aligned(16))) uint64_t sKeys[T::kSlots];
+  __shared__ uint32_t sRows[T::kSlots + 1];  // (+ 1: the spare slot records that miss their home bucket aim their atomics at)
+  __shared__ V sVals[T::kSlots + 1];
   __shared__ uint32_t sRun[kMaxStreams];
+  __shared__ uint4 sQueue[kThreads / 64][kQueueCap];
   __shared__ uint32_t sWave[kThreads / 64];
   __shared__ uint32_t sClaims, sBad;
   const int p = blockIdx.x;
@@ -175,40 +180,66 @@ __global__ __launch_bounds__(kThreads) void sr_merge_kernel(SrArgs m) {
     sRows[s] = kNoRow;
     sVals[s] = static_cast<V>(a.identity);
   }
+  if (tid == 0) {
+    sRows[T::kSlots] = kNoRow;
+    sVals[T::kSlots] = static_cast<V>(a.identity);
+  }
   if (tid < m.streams) sRun[tid] = m.countsB[static_cast<uint64_t>(tid) * numParts + p];
   if (tid == 0) { sClaims = 0; sBad = 0; }
+  auto stamp = [&](int k) {
+    if (m.phases && tid == 0) m.phases[static_cast<size_t>(p) * 8 + k] = wall_clock64();
+  };
+  stamp(0);
   __syncthreads();
+  stamp(1);
 
-  auto insert = [&](uint32_t row, uint32_t hi, uint32_t lo, uint64_t value) {
-    const uint64_t key = (static_cast<uint64_t>(hi) << 32) | lo;
-    if (key == kEmptyKey) {  // cannot live in this table: the caller takes the real sort
+  // The table is probed by BUCKETS of four keys (32 bytes: two 16-byte LDS reads): home bucket = the 32 key bits right below
+  // the partition's, scaled to the home buckets — monotone in the key; a key sits in the first free slot at or behind its
+  // home bucket's first (claims only ever turn the LOWEST empty slot of a bucket into a key, buckets are walked upwards, no
+  // wrap-around), so every slot between a key's home and its place is occupied: what the ordering below goes by.
+  // With one key per probe the longest probe sequence among 64 lanes paced every wavefront (253 of a partition's 300 us at
+  // 4.5 k groups); a record meets its group in its home bucket ~93 % of the time.
+  constexpr uint32_t kHomeBuckets = T::kHomes / 4, kBuckets = T::kSlots / 4;
+  auto home_bucket = [&](uint32_t hi, uint32_t lo) { return __umulhi(pb ? ((hi << pb) | (lo >> (32 - pb))) : hi, kHomeBuckets); };
+  // One probe of bucket b for key (hi, lo): returns the key's slot, or -1 (the caller looks at bucket `b` again — it may have
+  // been advanced, or a claim was lost to another lane, maybe for this very key), or -2 (ran off the table / table full).
+  auto probe = [&](uint32_t &b, uint32_t hi, uint32_t lo) -> int {
+    const uint4 *bk = reinterpret_cast<const uint4 *>(sKeys + 4u * b);
+    const uint4 u = bk[0], v = bk[1];
+    const bool m0 = u.x == lo && u.y == hi, m1 = u.z == lo && u.w == hi, m2 = v.x == lo && v.y == hi, m3 = v.z == lo && v.w == hi;
+    if (m0 || m1 || m2 || m3) return static_cast<int>(4u * b + (m0 ? 0u : m1 ? 1u : m2 ? 2u : 3u));
+    const bool e0 = (u.x & u.y) == 0xFFFFFFFFu, e1 = (u.z & u.w) == 0xFFFFFFFFu, e2 = (v.x & v.y) == 0xFFFFFFFFu, e3 = (v.z & v.w) == 0xFFFFFFFFu;
+    if (e0 || e1 || e2 || e3) {  // a group that is new in this partition: rare once the groups exist
+      const uint32_t slot = 4u * b + (e0 ? 0u : e1 ? 1u : e2 ? 2u : 3u);
+      unsigned long long expected = kEmptyKey;
+      if (__hip_atomic_compare_exchange_strong(reinterpret_cast<unsigned long long *>(sKeys + slot), &expected,
+                                               (static_cast<unsigned long long>(hi) << 32) | lo, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP)) {
+        if (__hip_atomic_fetch_add(&sClaims, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= m.maxGroups)
+          __hip_atomic_store(&sBad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return static_cast<int>(slot);
+      }
+      return -1;  // lost the slot: the same bucket again (the winner may be this very key)
+    }
+    if (++b >= kBuckets) {  // ran off the tail: more groups than the table orders
+      __hip_atomic_store(&sBad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      return -2;
+    }
+    return -1;
+  };
+  auto settle = [&](int slot, uint32_t row, uint64_t value) {
+    __hip_atomic_fetch_min(sRows + slot, row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    sr_aggregate<VW>(sVals + slot, value, a);
+  };
+  auto insert = [&](uint32_t row, uint32_t hi, uint32_t lo, uint64_t value) {  // the general loop, one record
+    if ((hi & lo) == 0xFFFFFFFFu) {  // the table's empty word: the caller takes the real sort
       m.flags[2] = 1u;
       return;
     }
-    // the 32 key bits right below the partition's, scaled to the home slots: monotone in the key
-    const uint32_t x = pb ? ((hi << pb) | (lo >> (32 - pb))) : hi;
-    uint32_t slot = __umulhi(x, static_cast<uint32_t>(T::kHomes));
-    for (;;) {
-      uint64_t cur = sKeys[slot];
-      if (cur == kEmptyKey) {
-        unsigned long long expected = kEmptyKey;
-        if (__hip_atomic_compare_exchange_strong(reinterpret_cast<unsigned long long *>(sKeys + slot), &expected,
-                                                 static_cast<unsigned long long>(key), __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_WORKGROUP)) {
-          if (__hip_atomic_fetch_add(&sClaims, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= m.maxGroups)
-            __hip_atomic_store(&sBad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          break;
-        }
-        cur = expected;
-      }
-      if (cur == key) break;
-      if (++slot >= static_cast<uint32_t>(T::kSlots)) {  // ran off the tail: more groups than the table orders
-        __hip_atomic_store(&sBad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        return;
-      }
-    }
-    __hip_atomic_fetch_min(sRows + slot, row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    sr_aggregate<VW>(sVals + slot, value, a);
+    uint32_t b = home_bucket(hi, lo);
+    int slot = -1;
+    while (slot == -1) slot = probe(b, hi, lo);
+    if (slot >= 0) settle(slot, row, value);
   };
 
   // ---- previous groups (region A): the value is read from the previous result's measure vector
@@ -221,31 +252,117 @@ __global__ __launch_bounds__(kThreads) void sr_merge_kernel(SrArgs m) {
       insert(r.x, r.y, r.w, load_value_bits(m.inValues, a, r.x));
     }
   }
-  // ---- the batch's records (region B): every wavefront streams whole runs, four records per lane in flight
+  if (m.phases) __syncthreads();
+  stamp(2);
+  // ---- the batch's records (region B): every wavefront streams whole runs, four records per lane in flight.  Round one
+  // looks at every record's home bucket with straight-line code (no claim, no advance); what is left — the group lives
+  // further on, or is new: a few lanes per segment — goes through the probe loop.
   {
-    const uint4 *pad = m.recB;  // (any readable address: lanes past a run's end load it and ignore it)
-    for (int g = wave; g < m.streams; g += kThreads / 64) {
-      const uint32_t cnt = sRun[g];
-      const uint4 *run = m.recB + (static_cast<uint64_t>(g) * numParts + p) * m.capB;
-      for (uint32_t off = 0; off < cnt; off += 256u) {
-        if (__hip_atomic_load(&sBad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
-        uint4 r[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const uint32_t i = off + static_cast<uint32_t>(k) * 64u + lane;
-          r[k] = *(i < cnt ? run + i : pad);
+    const uint4 *pad = m.recB;  // (any readable address: lanes past a chunk's end load it and ignore it)
+    struct Chunk {
+      const uint4 *ptr;
+      uint32_t n;  // records (0: no chunk left)
+    };
+    int g = wave;
+    uint32_t off = 0;
+    auto next = [&]() -> Chunk {
+      while (g < m.streams) {
+        const uint32_t cnt = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(sRun[g])));
+        if (off < cnt) {
+          Chunk c{m.recB + (static_cast<uint64_t>(g) * numParts + p) * m.capB + off, cnt - off < 256u ? cnt - off : 256u};
+          off += 256u;
+          return c;
         }
+        g += kThreads / 64;
+        off = 0;
+      }
+      return Chunk{pad, 0u};
+    };
+    auto load = [&](uint4(&r)[4], const Chunk &c) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const uint32_t i = off + static_cast<uint32_t>(k) * 64u + lane;
-          if (i >= cnt || r[k].x == kNoRow) continue;  // (row ~0: the padding of a stream's last line)
-          const uint64_t v = m.constMeasure ? m.constBits : hr::widen_value(m.widen, r[k].z);
-          insert(r[k].x, r[k].y, r[k].w, v);
+      for (int k = 0; k < 4; k++) {
+        const uint32_t i = static_cast<uint32_t>(k) * 64u + lane;
+        r[k] = *(i < c.n ? c.ptr + i : pad);
+      }
+    };
+    uint4 *queue = sQueue[wave];
+    uint32_t qn = 0;  // (wave-uniform)
+    auto drain = [&](uint32_t first, uint32_t count) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (static_cast<uint32_t>(lane) < count) {
+        const uint4 q = queue[first + lane];
+        insert(q.x, q.y, q.w, m.constMeasure ? m.constBits : hr::widen_value(m.widen, q.z));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    auto consume = [&](uint4(&r)[4], const Chunk &c) {
+      uint32_t pend = 0, bkt[4];
+      // all four home buckets are read before the first compare (eight independent 16-byte LDS reads in flight), and the
+      // atomics are issued unconditionally — a record that does not meet its group at home aims them at a spare slot behind
+      // the table (identity / no-row operands: the slot's contents never matter) — so that no branch separates the four
+      // records' LDS round trips: the waves were parked on them half of the time
+      uint4 u[4], v[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        bkt[k] = home_bucket(r[k].y, r[k].w);
+        const uint4 *bk = reinterpret_cast<const uint4 *>(sKeys + 4u * bkt[k]);
+        u[k] = bk[0];
+        v[k] = bk[1];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t i = static_cast<uint32_t>(k) * 64u + lane;
+        const bool valid = i < c.n && r[k].x != kNoRow;  // (row ~0: the padding of a stream's last line)
+        const uint32_t hi = r[k].y, lo = r[k].w;
+        const bool m0 = u[k].x == lo && u[k].y == hi, m1 = u[k].z == lo && u[k].w == hi, m2 = v[k].x == lo && v[k].y == hi, m3 = v[k].z == lo && v[k].w == hi;
+        const bool hit = valid && (m0 || m1 || m2 || m3) && (hi & lo) != 0xFFFFFFFFu;
+        const uint32_t slot = hit ? 4u * bkt[k] + (m0 ? 0u : m1 ? 1u : m2 ? 2u : 3u) : static_cast<uint32_t>(T::kSlots);
+        const uint64_t value = m.constMeasure ? m.constBits : hr::widen_value(m.widen, r[k].z);
+        __hip_atomic_fetch_min(sRows + slot, hit ? r[k].x : kNoRow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        sr_aggregate<VW>(sVals + slot, hit ? value : a.identity, a);
+        pend |= (valid && !hit ? 1u : 0u) << k;
+      }
+      // Records that did not meet their group at home (it lives further on, or is new: a few lanes per segment) are queued
+      // per wavefront in LDS and taken through the general probe loop up to 64 at a time, every lane busy: run where they
+      // occur, that loop executed for a handful of lanes after nearly every segment — two thirds of the kernel's vector
+      // instructions (the kernel is bound by their issue: 181 per 64 records, measured with SQ_INSTS_VALU).
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const bool pk = (pend >> k) & 1u;
+        const uint64_t pm = __ballot(pk);
+        if (pm) {
+          if (pk) queue[qn + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(pm >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(pm), 0u))] = r[k];
+          qn += static_cast<uint32_t>(__popcll(pm));
+          if (qn >= kQueueDrain) {
+            const uint32_t take = qn < 64u ? qn : 64u;
+            qn -= take;
+            drain(qn, take);
+          }
         }
       }
+    };
+    // two register stages: the next chunk's loads are in flight while the current one goes through the table
+    uint4 ra[4], rb[4];
+    Chunk ca = next();
+    load(ra, ca);
+    while (ca.n) {
+      Chunk cb = next();
+      load(rb, cb);
+      consume(ra, ca);
+      if (!cb.n || __hip_atomic_load(&sBad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+      ca = next();
+      load(ra, ca);
+      consume(rb, cb);
+      if (__hip_atomic_load(&sBad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+    }
+    while (qn) {
+      const uint32_t take = qn < 64u ? qn : 64u;
+      qn -= take;
+      drain(qn, take);
     }
   }
   __syncthreads();
+  stamp(3);
   if (sBad) {  // (uniform)
     if (tid == 0) {
       m.flags[1] = 1u;
@@ -257,7 +374,7 @@ __global__ __launch_bounds__(kThreads) void sr_merge_kernel(SrArgs m) {
   const int first = tid * T::kPerLane;
   uint32_t mine = 0;
 #pragma unroll
-  for (int k = 0; k < T::kPerLane; k++) mine += sKeys[first + k] != kEmptyKey;
+  for (int k = 0; k < T::kPerLane; k++) mine += first + k < T::kSlots && sKeys[first + k] != kEmptyKey;
   uint32_t incl = mine;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
@@ -273,6 +390,7 @@ __global__ __launch_bounds__(kThreads) void sr_merge_kernel(SrArgs m) {
 #pragma unroll
   for (int k = 0; k < T::kPerLane; k++) {
     const int s = first + k;
+    if (s >= T::kSlots) break;
     const uint64_t key = sKeys[s];
     if (key == kEmptyKey) continue;
     uint32_t smaller = 0;
@@ -295,6 +413,8 @@ __global__ __launch_bounds__(kThreads) void sr_merge_kernel(SrArgs m) {
     seen++;
   }
   if (tid == kThreads - 1) m.partCount[p] = before + mine;
+  if (m.phases) __syncthreads();
+  stamp(4);
 }
 
 // ---- 4. emission in partition order ---------------------------------------------------------------------------------
@@ -387,8 +507,9 @@ int fused_sort_reduce_run(int device, const FusedPlanD &plan, int nd, bool const
   const int64_t length = static_cast<int64_t>(batchRows) + prevSize;
   const int partBits = sr_part_bits(length);
   const int numParts = 1 << partBits;
-  // the previous result alone must sit comfortably in the tables (3/4 of what a table orders): beyond, the real sort
-  if (static_cast<int64_t>(prevSize) > static_cast<int64_t>(numParts) * tableGroups * 3 / 4) return kFusedUnavailable;
+  // the previous result alone must fit the tables with room for a partition's share to vary (hashes spread evenly: the
+  // largest of 512 partitions of a 2.5 M-group result holds ~5 % more than the mean): beyond, the real sort
+  if (static_cast<int64_t>(prevSize) > static_cast<int64_t>(numParts) * tableGroups * 9 / 10) return kFusedUnavailable;
   const DimLayoutD L = make_dim_layout(in.NumDimsPerDimWidth);
   if (L.numDims != nd) return kFusedUnavailable;
   RtcKernel scan = rtc_sort_scan_lookup(device, plan, nd, partBits);
@@ -457,6 +578,16 @@ int fused_sort_reduce_run(int device, const FusedPlanD &plan, int nd, bool const
     ARES_LAUNCH("sr_prev_kernel", sr_prev_kernel, grid, 256, stream, m, L, ws.recA);
   }
   rtc_sort_scan_launch(scan, plan, static_cast<uint32_t>(prevSize), batchRows, ws, stream);
+  static const bool phasesOn = [] {
+    const char *e = getenv("ARES_HR_PHASES");
+    return e && e[0] == '1';
+  }();
+  static uint64_t *phases = nullptr;
+  if (phasesOn) {
+    if (!phases) hip_check(hipMalloc(reinterpret_cast<void **>(&phases), sizeof(uint64_t) * 8 * kMaxPartitions), "hipMalloc");
+    hip_check(hipMemsetAsync(phases, 0, sizeof(uint64_t) * 8 * kMaxPartitions, stream), "hipMemsetAsync");
+    m.phases = phases;
+  }
   if (vw == 8) {
     ARES_LAUNCH("sr_merge_kernel", sr_merge_kernel<8>, numParts, kThreads, stream, m);
     ARES_LAUNCH("sr_emit_kernel", sr_emit_kernel<8>, numParts, kThreads, stream, m, plan, L);
@@ -466,6 +597,23 @@ int fused_sort_reduce_run(int device, const FusedPlanD &plan, int nd, bool const
   }
   uint32_t w[3] = {0, 0, 0};
   read_back_u32(ws.outCount, w, 3, stream);
+  if (phasesOn) {  // diagnostics: where a partition's time goes
+    static int launches = 0;
+    std::vector<uint64_t> h(static_cast<size_t>(8) * numParts);
+    hip_check(hipMemcpy(h.data(), phases, sizeof(uint64_t) * h.size(), hipMemcpyDeviceToHost), "hipMemcpy");
+    if (++launches <= 4 || launches % 16 == 0) {
+      double sum[4] = {0, 0, 0, 0};
+      uint64_t first = ~0ull, last = 0;
+      for (int p = 0; p < numParts; p++) {
+        const uint64_t *t = &h[static_cast<size_t>(8) * p];
+        if (t[0] < first) first = t[0];
+        if (t[4] > last) last = t[4];
+        for (int k = 0; k < 4; k++) sum[k] += static_cast<double>(t[k + 1] - t[k]) * 0.01;
+      }
+      fprintf(stderr, "sr_merge_kernel phases (launch %d, %d partitions, prev %d, batch %d): span %.1f us; per partition avg: init %.1f + previous groups %.1f + records %.1f + order %.1f us\n",
+              launches, numParts, prevSize, batchRows, static_cast<double>(last - first) * 0.01, sum[0] / numParts, sum[1] / numParts, sum[2] / numParts, sum[3] / numParts);
+    }
+  }
   buf.mark_idle();
   static const bool trace = getenv("ARES_HR_TRACE") != nullptr;  // diagnostics
   if (trace)

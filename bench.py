@@ -453,6 +453,9 @@ def main(argv=None, backend=None, tensor_device=None):
     ap.add_argument("--d1-below", type=int, default=90, help="constant of the filter d1 < K")
     ap.add_argument("--ts-range", default="", help="from,to: the Go host's two time filters (ts >= from, ts < to) in front of the "
                                                    "query's own filter — the shape every fact-table query has (secondary leg)")
+    ap.add_argument("--sort-path", default="", choices=["", "count", "sum"],
+                    help="the same group-by through the reference's DEFAULT aggregation path, Sort + Reduce (config/ares.yaml:11 "
+                         "enable_hash_reduction: false): count = COUNT(*), sum = SUM(d2) as AGGR_SUM_UNSIGNED into 8 bytes (secondary legs)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes that measure roofline.traffic")
     ap.add_argument("--single-process", action="store_true",
                     help="N shards on N GPUs as N threads of THIS process (the reference's process model, "
@@ -530,10 +533,23 @@ def main(argv=None, backend=None, tensor_device=None):
     dims = tuple(d for d in args.dims.split(",") if d)
     assert dims and all(d in check.ALL_DIMS for d in dims), args.dims
     ts_range = tuple(int(x) for x in args.ts_range.split(",")) if args.ts_range else None
-    plan = c3_plan(use_hash_reduction=True, dims=dims, d1_below=args.d1_below, ts_range=ts_range)
+    sort_measure = {"": None, "count": "count", "sum": "d2"}[args.sort_path]
+    plan = c3_plan(use_hash_reduction=True, dims=dims, d1_below=args.d1_below, ts_range=ts_range, sort_measure=sort_measure)
     plan.use_fused_extension = bool(args.fused_extension)
     # columns the plan reads (dimensions + measure + the filter's d1 [+ ts of the time filters]): the algorithmic bytes per row
-    plan_columns = sorted(set(dims) | {"m", "d1"} | ({"ts"} if ts_range else set()))
+    measure_columns = {"": {"m"}, "count": set(), "sum": {"d2"}}[args.sort_path]
+    plan_columns = sorted(set(dims) | measure_columns | {"d1"} | ({"ts"} if ts_range else set()))
+
+    # the independent group-by a result is compared with, and the comparison: HashReduce identifies groups by their 32-bit
+    # hash; Sort + Reduce by the 64-bit one (exact groups at these cardinalities) and leaves them in ascending hash order
+    def expected_groups(bs, d1_below=args.d1_below, **kw):
+        return check.exact_groups(bs, dims=dims, d1_below=d1_below, ts_range=ts_range, measure=(sort_measure or "m"), **kw)
+
+    def compare_fetched(fetched, expected):
+        if not args.sort_path:
+            return check.compare_result(fetched, expected, hash_identity=True, dims=dims)
+        return check.compare_result(fetched, expected, hash_identity=False, dims=dims, ordered=True,
+                                    measure_dtype={"count": "<u4", "sum": "<i8"}[args.sort_path])
 
     def sync():
         if on_gpu:
@@ -594,7 +610,7 @@ def main(argv=None, backend=None, tensor_device=None):
         ctx, cold["cold_first_query_batch_ms"] = run_timed(plan)
         sync()
         cold["cold_first_query_ms"] = (time.perf_counter() - t0) * 1e3
-        rep = check.compare_result(ctx.fetch(), check.exact_groups(batches, dims=dims, d1_below=args.d1_below, ts_range=ts_range), hash_identity=True, dims=dims)
+        rep = compare_fetched(ctx.fetch(), expected_groups(batches))
         cold["cold_check_groups"] = rep["status"]
         ctx.release()
         cold["rtc_after_cold_query"] = be.rtc_wait()  # (waits for the kernels the first query asked for)
@@ -700,11 +716,10 @@ def main(argv=None, backend=None, tensor_device=None):
             every = []
             for r in range(world):
                 every += workload.c3_shard(rows, batch_rows, seed=1 + r, device=tdev, null_fraction=args.null_fraction)
-            merged_check = check.compare_result(ctx.fetch(), check.exact_groups(every, dims=dims, d1_below=args.d1_below, ts_range=ts_range),
-                                                hash_identity=True, dims=dims)
+            merged_check = compare_fetched(ctx.fetch(), expected_groups(every))
         ctx.release()
         ctx = run_shard(be, plan, vps, device_index, streams)
-    report = check.compare_result(ctx.fetch(), check.exact_groups(batches, dims=dims, d1_below=args.d1_below, ts_range=ts_range), hash_identity=True, dims=dims)
+    report = compare_fetched(ctx.fetch(), expected_groups(batches))
     groups = ctx.result_size
     ok = report["status"] == "ok" and report["groups"] == groups
     if merged_check is not None:
@@ -812,6 +827,10 @@ def main(argv=None, backend=None, tensor_device=None):
             # in the order of what the round's review asks about first; the two long ones last
             # the query shape the Go host really issues: ts >= from, ts < to in front of the query's own filter
             leg("time_filters_ts_ge_lt_then_d1", {}, big + ["--ts-range", "3600,601200"])
+            # the reference's DEFAULT aggregation path (enable_hash_reduction: false, and COUNT(*) always): Sort + Reduce over the
+            # same four dimensions — hash-keyed inside the ABI (sort_reduce_fused.hip), rows in ascending 64-bit hash order
+            leg("c3_sort_path_count", {}, big + ["--sort-path", "count"])
+            leg("c3_sort_path_sum_unsigned", {}, big + ["--sort-path", "sum"])
             leg(f"live_batches_{LIVE_BATCH_ROWS}_rows", {}, common + ["--batch-rows", str(LIVE_BATCH_ROWS)])
             # lower-cardinality variants of the same query (same filter and measure; fewer group-by dimensions)
             # the reference's own example table and queries at 1 B rows (examples/1k_trips: request_at Uint32, city_id Uint16 in

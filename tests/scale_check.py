@@ -33,6 +33,9 @@ def main():
     ap.add_argument("--fused-extension", action="store_true")
     ap.add_argument("--streams", type=int, default=1, help="2: alternate two streams per batch like the Go host")
     ap.add_argument("--ts-range", default="", help="from,to: the Go host's two time filters in front of the query's own")
+    ap.add_argument("--sort-path", default="", choices=["", "count", "sum"],
+                    help="the reference's default aggregation path, Sort + Reduce: COUNT(*) / SUM(d2) as AGGR_SUM_UNSIGNED into 8 bytes; "
+                         "the result must also come in ascending order of the 64-bit row hash")
     args = ap.parse_args()
     ts_range = tuple(int(x) for x in args.ts_range.split(",")) if args.ts_range else None
     dev = torch.device("cuda:0")
@@ -42,15 +45,24 @@ def main():
     batches = workload.c3_shard(int(args.rows), int(args.batch_rows), seed=args.seed, device=dev,
                                 null_fraction=args.null_fraction)
     torch.cuda.synchronize()
-    plan = c3_plan(use_hash_reduction=True, ts_range=ts_range)
+    sort_measure = {"": None, "count": "count", "sum": "d2"}[args.sort_path]
+    plan = c3_plan(use_hash_reduction=True, ts_range=ts_range, sort_measure=sort_measure)
     plan.use_fused_extension = args.fused_extension
     ctx = NativeQuery(be, plan, NAMES, device=0, stream=streams[0], streams=streams)
     sizes = []
+    be.profiler_enable(True)
     for b in batches:
         ctx.run({k: rc.vp for k, rc in b.items()}, next(iter(b.values())).length)
         sizes.append(ctx.result_size)
+    kernels = sorted(be.profiler_report())
+    be.profiler_enable(False)
     fetched = ctx.fetch()
-    report = check.compare_result(fetched, check.exact_groups(batches, ts_range=ts_range), hash_identity=True)
+    if args.sort_path:
+        report = check.compare_result(fetched, check.exact_groups(batches, ts_range=ts_range, measure=sort_measure), hash_identity=False,
+                                      ordered=True, measure_dtype={"count": "<u4", "sum": "<i8"}[args.sort_path])
+    else:
+        report = check.compare_result(fetched, check.exact_groups(batches, ts_range=ts_range), hash_identity=True)
+    report["kernels"] = kernels
     report.update({"rows": int(args.rows), "batch_rows": int(args.batch_rows), "result_sizes": sizes,
                    "fused_batches": ctx.fused_batches,
                    "env": {k: v for k, v in os.environ.items() if k.startswith("ARES_")}})

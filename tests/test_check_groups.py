@@ -37,3 +37,27 @@ def test_exact_groups_against_a_dictionary(dims):
     assert set(got) == set(want) and len(want) > (50 if len(dims) > 1 else 20)
     for k, (s, f, r) in got.items():
         assert abs(s - want[k][0]) <= 1e-9 * max(1.0, abs(want[k][0])) and f == want[k][1] and r == want[k][2], k
+
+
+def test_row_hash_of_the_checker_matches_the_reference_known_answers():
+    """The 64-bit row hash the ordered comparison goes by (check.murmur3_128_lo64_rows) against the four hashes of
+    SortAndReduceTest.CheckHash (query/algorithm_unittest.cu:1160-1217: one 1-byte dimension, rows {value, validity = 1};
+    SURVEY.md 8c) and against the oracle's Sort over random rows of 5, 16, 20, 25 and 33 bytes (tail and multi-block paths)."""
+    rows = np.array([[2, 1], [0, 1], [3, 1], [1, 1]], np.uint8)
+    assert [int(h) for h in check.murmur3_128_lo64_rows(rows)] == [0x60e187b4814392c4, 0x7cb3f5c58dab264c, 0xb73e42bb654cee53, 0xca410abc0a9d4c6b]
+    import harness as H
+    from aresdb_amd import abi
+    be = H.oracle_backend()
+    rng = np.random.default_rng(4)
+    for ndw in ((0, 0, 1, 0, 0), (0, 0, 3, 1, 0), (0, 0, 4, 0, 0), (0, 1, 2, 2, 1), (1, 1, 1, 0, 0)):
+        n = 300
+        dv = H.DimVector(be, n, ndw)
+        blob = rng.integers(0, 256, dv.nbytes).astype(np.uint8)
+        dv.values.write(blob)
+        be.call("InitIndexVector", dv.index.ptr, 0, n, None, 0)
+        be.call("Sort", dv.struct(), n, None, 0)
+        got = np.sort(dv.hash.read(np.uint64, n))
+        packed = np.concatenate([blob[vo:vo + w * n].reshape(n, w) for vo, _, w in dv.dim_offsets()] +
+                                [blob[no:no + n].reshape(n, 1) for _, no, _ in dv.dim_offsets()], axis=1)
+        assert np.array_equal(np.sort(check.murmur3_128_lo64_rows(packed)), got), ndw
+        dv.free()

@@ -52,6 +52,14 @@ C3_VARIANTS = [
     ("time_filters", {}, ["--rows", str(40 << 20), "--batch-rows", str(4 << 20), "--streams", "2", "--ts-range", "40000,560000"]),
     ("time_filters_pred_vectors", {"ARES_FILTER_ROWSPACE": "0"},
      ["--rows", str(40 << 20), "--batch-rows", str(8 << 20), "--streams", "2", "--ts-range", "40000,560000"]),
+    # the reference's DEFAULT aggregation path, Sort + Reduce (COUNT(*) always goes there; every SUM too unless
+    # enable_hash_reduction is set): hash-keyed inside the ABI (sort_reduce_fused.hip) — every key -> count / sum exact AND the
+    # rows in ascending order of the 64-bit row hash; the same with the path switched off (rows are sorted for real)
+    ("sort_path_count", {}, BIG + ["--streams", "2", "--sort-path", "count"]),
+    ("sort_path_sum_time_filters", {}, ["--rows", str(40 << 20), "--batch-rows", str(8 << 20), "--streams", "2", "--ts-range", "40000,560000",
+                                        "--sort-path", "sum"]),
+    ("sort_path_count_live_batches", {}, LIVE + ["--streams", "2", "--sort-path", "count"]),
+    ("sort_path_count_real_sort", {"ARES_SORT_FUSE": "0"}, MID + ["--sort-path", "count"]),
 ]
 
 
@@ -69,6 +77,10 @@ def test_c3_key_level_parity_at_scale(name, env, args):
         assert report["fused_batches"] == 0  # (the extension counter: these go through the plain ABI)
     if name == "extension":
         assert report["fused_batches"] == len(report["result_sizes"])
+    if name.startswith("sort_path"):  # which path ran
+        fused = any(k.startswith("sr_merge_kernel") for k in report["kernels"])
+        sorted_rows = any(k.startswith("radix_pass_kernel") for k in report["kernels"])
+        assert (fused, sorted_rows) == ((False, True) if name.endswith("real_sort") else (True, False)), report["kernels"]
 
 
 def test_c2_filter_count_at_spec_size():

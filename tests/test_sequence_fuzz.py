@@ -44,8 +44,12 @@ class Program:
         columns through the fast kernels and the fused scan); "drift" — the upper time-filter constant moves with every batch,
         so the filter pair predicted from the stream's previous batch is never the one that arrives; "prealloc" — the result
         buffers are sized once for the whole program, so consecutive batches find the previous call's state (partition-grouped
-        ranges, table images) instead of freshly copied vectors.  None draws from the program's random stream: a seed is the
-        same program in every profile."""
+        ranges, table images) instead of freshly copied vectors; "sort" — every program takes the reference's default
+        aggregation path, Sort + Reduce, and the host LOOKS at what only a sort leaves behind: the hash / index vector between
+        Sort and Reduce, the input's hash / index vector and the output's index vector after Reduce, and the output rows in
+        their order (ascending 64-bit hash) — a Sort that was only defined (sort_reduce_fused.hip) has to materialise, a
+        Reduce that consumed it has to be replayed.  None draws from the program's random stream: a seed is the same program
+        in every profile."""
         self.seed = seed
         self.profile = tuple(profile)
 
@@ -71,8 +75,9 @@ class Program:
         # MIN over positive values yields 0 there, while its DEVICE build (cudf map initialised with the
         # identity) and this library yield the minimum.  Such programs take the Sort + Reduce path, where
         # all three agree.
-        if agg == abi.AGGR_MIN_SIGNED:
+        if agg == abi.AGGR_MIN_SIGNED or "sort" in self.profile:
             use_hash = False
+        peeks = "sort" in self.profile
         # dimension expressions, fixed for the whole program: (column, functor or None, constant)
         dim_exprs = []
         for d in range(nd):
@@ -209,8 +214,22 @@ class Program:
                 else:
                     be.call("InitIndexVector", dimidx[0].ptr, 0, length, stream, 0)
                     be.call("Sort", dimvec(dims[0].ptr, cap, hashes[0], dimidx[0]), length, stream, 0)
+                    peek = (self.seed + 3 * b) % 5 if peeks else 0  # (no draw from rng: see __init__)
+                    if peek in (1, 3):
+                        obs.append(("sorted_hashes", b, _d2h(be, hashes[0].ptr, 8 * length, stream).tobytes()))
+                        if peek == 3:
+                            obs.append(("sorted_index", b, _d2h(be, dimidx[0].ptr, 4 * length, stream).tobytes()))
                     result_size = be.call("Reduce", dimvec(dims[0].ptr, cap, hashes[0], dimidx[0]), meas[0].ptr,
                                           dimvec(dims[1].ptr, cap, hashes[1], dimidx[1]), meas[1].ptr, mb, length, agg, stream, 0)
+                    if peek in (2, 3) and result_size:
+                        obs.append(("representatives", b, _d2h(be, dimidx[1].ptr, 4 * result_size, stream).tobytes()))
+                    if peek == 2:
+                        obs.append(("index_after", b, _d2h(be, dimidx[0].ptr, 4 * length, stream).tobytes()))
+                        obs.append(("hashes_after", b, _d2h(be, hashes[0].ptr, 8 * length, stream).tobytes()))
+                    if peeks and result_size and mnp != np.float64:  # the output rows in their order (dimension 0 and the values)
+                        vo, no, w = offsets(cap)[0]
+                        obs.append(("ordered_rows", b, _d2h(be, dims[1].ptr + vo, w * result_size, stream).tobytes()))
+                        obs.append(("ordered_values", b, _d2h(be, meas[1].ptr, mb * result_size, stream).tobytes()))
             obs.append(("groups", b, result_size))
             if size and rng.random() < 0.12:  # ... and after it (work the reduction skipped must materialise)
                 vo, no, w = offsets(cap)[nd - 1]
@@ -274,7 +293,8 @@ def _same(a, b, seed):
 
 
 SEEDS = list(range(1000, 1160))
-PROFILES = [(), ("narrow",), ("drift",), ("narrow", "drift"), ("prealloc",), ("prealloc", "narrow"), ("prealloc", "drift")]
+PROFILES = [(), ("narrow",), ("drift",), ("narrow", "drift"), ("prealloc",), ("prealloc", "narrow"), ("prealloc", "drift"),
+            ("sort",), ("sort", "narrow"), ("sort", "prealloc"), ("sort", "drift")]
 
 
 @pytest.mark.gpu

@@ -124,6 +124,10 @@ struct GroupedState {
   // left them — what the query's next HashReduce starts from instead of re-hashing and re-inserting every group
   std::shared_ptr<uint8_t> image;
   uint64_t lineage = 0;     // the query (chain of HashReduce calls) the image belongs to
+  // Ancestry inside a lineage: every image-mode result gets a generation; a result that STARTED from an image records the
+  // generation of the state it started from.  Only a state's parent holds, in its leading rows, exactly the groups the
+  // state began with — same lineage alone does not say that (two results forked from one input share it).
+  uint64_t gen = 0, parentGen = 0;
   bool lazyValues = false;  // rows [0, size) of `values` are NOT written: they are what the image's value plane holds
 };
 std::mutex g_groupedMutex;
@@ -178,6 +182,7 @@ constexpr size_t kImageCountsOff = kImagePartBytes * kMaxPartitions;
 constexpr size_t kImageBytes = kImageCountsOff + sizeof(uint32_t) * kMaxPartitions;
 std::vector<std::pair<int, uint8_t *>> g_freeImages;  // (guarded by g_rangesMutex)
 std::atomic<uint64_t> g_lineage{0};
+std::atomic<uint64_t> g_generation{0};
 
 bool image_enabled() {
   static EnvSwitch<bool> on("ARES_IMAGE", [](const char *e) { return !(e && e[0] == '0'); });
@@ -196,9 +201,18 @@ std::shared_ptr<uint8_t> take_image(int device) {
         break;
       }
   }
-  if (!p) {
+  if (!p) {  // images are an optimisation: out of memory means "no image this time" (null), not a failed HashReduce
     void *fresh = nullptr;
-    hip_check(hipMalloc(&fresh, kImageBytes), "hipMalloc");
+    if (hipMalloc(&fresh, kImageBytes) != hipSuccess) {
+      (void)hipGetLastError();
+      grouped_trim(device);
+      if (g_memTrimCache) g_memTrimCache(device);
+      fresh = nullptr;
+      if (hipMalloc(&fresh, kImageBytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+      }
+    }
     p = static_cast<uint8_t *>(fresh);
   }
   return std::shared_ptr<uint8_t>(p, [device](uint8_t *q) {
@@ -625,6 +639,8 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
   // what is known about the OUTPUT vectors before this call rewrites them: when they belong to this query (the Go host
   // ping-pongs two result buffers) their leading dimension rows already hold the query's groups, and their table image is
   // the one to write into
+  // (declined before anything is touched: what is known about the output vectors stays known)
+  if (narrow && !(batchRows > 0 && rtc_scan_available())) return kFusedUnavailable;
   GroupedState outOld;
   const bool outFound = image_enabled() && grouped_lookup(device, outKeys.DimValues, outValues, outCapacity, slots, mw, &outOld);
   grouped_note_write(device, outValues, static_cast<size_t>(mw) * outCapacity);  // (values first: unwritten ones die whole)
@@ -633,7 +649,6 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
   const bool found = prevSize > 0 && grouped_lookup(device, prevKeys.DimValues, prevValues, prevCapacity, slots, mw, &prev) &&
                      prev.partBits == partBits && prev.size == prevSize;
   bool grouped = found && prev.ranges != nullptr;
-  if (narrow && !(batchRows > 0 && rtc_scan_available())) return kFusedUnavailable;
   const std::shared_ptr<uint32_t> outRangesRef = grouped_enabled() ? take_ranges(device) : nullptr;
   uint32_t *outRanges = outRangesRef.get();
   MergeResult res{0, 0, 0, 0};
@@ -686,17 +701,26 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
     if (!imageMerge) imageMode = 0;  // (being compiled in the background: the ordinary kernels this time)
   }
   if (imageMode == 2) {
+    // The output buffer's leading rows are trusted as "the first outOld.size groups of prev" only when the state found there
+    // is the very state prev was derived from (the Go host's ping-pong: the call before last wrote this buffer).  A state of
+    // the same lineage that is NOT prev's parent — two results forked from one input, then one reduced into the other's
+    // buffer — holds other groups behind the common prefix.
     const bool mine = outFound && outOld.lineage == prev.lineage && outOld.image && outOld.image != prev.image &&
-                      outOld.partBits == partBits && outOld.size <= prevSize;
+                      outOld.partBits == partBits && outOld.size <= prevSize && prev.parentGen != 0 && outOld.gen == prev.parentGen;
     knownOut = mine ? static_cast<uint32_t>(outOld.size) : 0u;
     imageOut = mine ? outOld.image : take_image(device);
     // a partition's key and position planes are rewritten unless the output's image already holds this very set (equal
     // counts within one lineage); an image of unknown content starts with counts no partition can have
-    if (!mine) hip_check(hipMemsetAsync(image_counts(imageOut.get()), 0xFF, sizeof(uint32_t) * kMaxPartitions, stream), "hipMemsetAsync");
+    if (imageOut && !mine) hip_check(hipMemsetAsync(image_counts(imageOut.get()), 0xFF, sizeof(uint32_t) * kMaxPartitions, stream), "hipMemsetAsync");
   } else {
     if (imageMode == 1) imageOut = take_image(device);
     // the previous result's measure rows are read by everything but an image-mode merge: write them if they are still
     // only defined by their image
+    if (prevSize > 0) grouped_materialize_for_read(device, prevValues, static_cast<size_t>(mw) * prevSize);
+  }
+  if (imageMode && !imageOut) {  // no memory for an image: the ordinary merge (which reads the previous result's measure rows)
+    imageMode = 0;
+    knownOut = 0;
     if (prevSize > 0) grouped_materialize_for_read(device, prevValues, static_cast<size_t>(mw) * prevSize);
   }
   {
@@ -862,10 +886,13 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
       s.ranges = nullptr;
       s.image = imageOut;
       s.lineage = prev.lineage;
+      s.gen = ++g_generation;
+      s.parentGen = prev.gen;
       s.lazyValues = true;
     } else if (imageMode == 1) {
       s.image = imageOut;
       s.lineage = ++g_lineage;
+      s.gen = ++g_generation;
     }
     if (res.groups > 0) grouped_register(s);
   }
@@ -952,6 +979,9 @@ int fused_filter_hash_reduce(int device, const AresFusedQuery &q, int batchRows,
   if (mw == 8 && plan.identity != 0) throw NotFusable("8-byte aggregate with a non-zero identity");
 
   const int groups = fused_hash_reduce_run(device, plan, batchRows, prevKeys, prevValues, prevSize, outKeys, outValues, a, stream);
+  if (groups == kFusedUnavailable)
+    throw NotFusable("the kernels generated for this plan's shape are not loaded yet (compiled in the background), or the shape is outside what they cover; "
+                     "run the unfused sequence for this batch");
   if (groups < 0) throw NotFusable("a hash partition overflowed (skewed hashes); run the unfused sequence");
   return groups;
 }

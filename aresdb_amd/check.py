@@ -114,16 +114,16 @@ def row_hashes_of_fetched(dims_, valids):
     return murmur3_128_lo64_rows(np.concatenate(parts, axis=1)) if n else np.zeros(0, np.uint64)
 
 
-def _codes_of_batch(b, limit=None, dims=ALL_DIMS, d1_below=90, ts_range=None, measure="m"):
+def _codes_of_batch(b, limit=None, dims=ALL_DIMS, d1_below=90, ts_range=None, measure="m", lo=0):
     """dense key code, keep mask and float64 measure of every row of one C3 batch (torch, on the
     batch's device) for the group-by dimensions `dims` (a subset of ts-bucket, d1, d2, d3; the filter d1 < 90 and the
     measure stay); a null dimension is its own key slot, a null measure contributes 0."""
     def col(name):
         rc = b[name]
-        n = rc.length if limit is None else min(limit, rc.length)
-        v = rc.values()[:n]
+        n = rc.length if limit is None else min(lo + limit, rc.length)
+        v = rc.values()[lo:n]
         ok = rc.valid()
-        return v, (None if ok is None else ok[:n])
+        return v, (None if ok is None else ok[lo:n])
     d1, d1v = col("d1")
     m, mv = col("m")
     keep = d1 < d1_below
@@ -152,11 +152,12 @@ def _codes_of_batch(b, limit=None, dims=ALL_DIMS, d1_below=90, ts_range=None, me
     return c, keep, mm
 
 
-def exact_groups(batches, limit_first_batch=None, dims=ALL_DIMS, d1_below=90, ts_range=None, measure="m"):
+def exact_groups(batches, limit_first_batch=None, dims=ALL_DIMS, d1_below=90, ts_range=None, measure="m", slices=None):
     """Exact group-by of the C3 query (group-by dimensions `dims`) over `batches` (all rows, or the first
     `limit_first_batch` rows of the first batch only).  Returns numpy arrays (code, sum, first_row, rows) of the groups.
     measure: "m" (SUM of the float measure), another column's name (SUM of that integer column, nulls as 0) or "count"
-    (COUNT(*): the sums are the row counts)."""
+    (COUNT(*): the sums are the row counts).  slices: instead of whole batches, the row ranges [(batch index, first row,
+    rows), ...] in that order (a sample spread over the shard)."""
     dev = batches[0]["m"].blob.device
     space = key_space(dims)
     # A small key space is spread over `salt` sub-slots per key (row mod salt) and folded at the end: index_add_ /
@@ -167,8 +168,12 @@ def exact_groups(batches, limit_first_batch=None, dims=ALL_DIMS, d1_below=90, ts
     cnt = torch.zeros(space * salt, dtype=torch.int64, device=dev)
     first = torch.full((space * salt,), torch.iinfo(torch.int64).max, dtype=torch.int64, device=dev)
     offset = 0
-    for b in (batches[:1] if limit_first_batch is not None else batches):
-        c, keep, mm = _codes_of_batch(b, limit_first_batch, dims, d1_below, ts_range, measure)
+    if slices is not None:
+        work = [(batches[bi], lo, n) for bi, lo, n in slices]
+    else:
+        work = [(b, 0, limit_first_batch) for b in (batches[:1] if limit_first_batch is not None else batches)]
+    for b, lo, limit in work:
+        c, keep, mm = _codes_of_batch(b, limit, dims, d1_below, ts_range, measure, lo)
         rows = torch.arange(offset, offset + c.numel(), dtype=torch.int64, device=dev)[keep]
         idx = c[keep]
         if salt > 1:

@@ -115,13 +115,13 @@ def c3_shard(rows, batch_rows, seed, device, null_fraction=0.01) -> List[Dict[st
     return batches
 
 
-def batch_to_host(batch: Dict[str, ResidentColumn], limit=None):
-    """numpy copies of a batch (values, validity) — what the CPU baseline leg uploads."""
+def batch_to_host(batch: Dict[str, ResidentColumn], limit=None, lo=0):
+    """numpy copies of rows [lo, lo + limit) of a batch (values, validity) — what the CPU baseline leg uploads."""
     cols, valid = {}, {}
     for name, rc in batch.items():
-        n = rc.length if limit is None else min(limit, rc.length)
-        v = rc.values()[:n].cpu().numpy()
+        n = rc.length if limit is None else min(lo + limit, rc.length)
+        v = rc.values()[lo:n].cpu().numpy()
         cols[name] = (rc.data_type, v.view(np.uint32) if rc.data_type != abi.Float32 else v)
         m = rc.valid()
-        valid[name] = None if m is None else m[:n].cpu().numpy()
+        valid[name] = None if m is None else m[lo:n].cpu().numpy()
     return cols, valid

@@ -59,12 +59,14 @@ def run_shard(be, plan, vps, device, streams):
 _PACKED = {}
 
 
-def cpu_baseline(batch, plan_factory, budget_s=15.0):
+def cpu_baseline(batches, plan_factory, budget_s=15.0, max_chunks=32):
     """The reference's own sources in QUERY_MODE=HOST (oracle/_ref, kind "reference") or, when that
     build is absent, the C restatement (kind "port"), single-threaded like thrust::host
-    (query/utils.hpp:236-241), on a bounded sample of the same workload.  HOST HashReduce's
+    (query/utils.hpp:236-241), on a bounded sample of the same workload: live-batch-sized chunks taken round-robin from
+    EVERY batch of the shard (chunk j comes from batch j mod #batches), so the sample — and the key-level comparison of the
+    reference's result with the independent group-by — covers the whole shard, not its first batch.  HOST HashReduce's
     extraction is O(groups^2) (query/concurrent_unordered_map.hpp:154-159), so the sample goes
-    through the HOST Sort+Reduce path.  Returns (report, fetched result, rows)."""
+    through the HOST Sort+Reduce path.  Returns (report, fetched result, slices)."""
     from aresdb_amd.columns import DeviceColumn
     ref_algo = os.path.join(ROOT, "oracle", "_ref", "libalgorithm.so")
     ref_mem = os.path.join(ROOT, "oracle", "_ref", "libmem.so")
@@ -74,33 +76,36 @@ def cpu_baseline(batch, plan_factory, budget_s=15.0):
     elif os.path.exists(port):
         be, kind = abi.Backend("oracle", port, port, device_memory=False), "port"
     else:
-        return None, None, 0
+        return None, None, []
     chunk = LIVE_BATCH_ROWS
-    cols, valid = workload.batch_to_host(batch, limit=32 * chunk)
-    total_rows = len(next(iter(cols.values()))[1])
+    nb = len(batches)
     plan = plan_factory(use_hash_reduction=False)
     ctx = NativeQuery(be, plan, COLUMN_NAMES)
-    spent, rows, nb = 0.0, 0, 0
-    for start in range(0, total_rows, chunk):
-        n = min(chunk, total_rows - start)
-        dev = {k: DeviceColumn(be, t, v[start:start + n], valid=None if valid[k] is None else valid[k][start:start + n])
-               for k, (t, v) in cols.items()}
+    spent, rows, slices = 0.0, 0, []
+    for j in range(max_chunks):
+        bi, lo = j % nb, (j // nb) * chunk
+        length = next(iter(batches[bi].values())).length
+        if lo >= length:
+            continue
+        cols, valid = workload.batch_to_host(batches[bi], limit=chunk, lo=lo)
+        n = len(next(iter(cols.values()))[1])
+        dev = {k: DeviceColumn(be, t, v, valid=valid[k]) for k, (t, v) in cols.items()}
         t0 = time.perf_counter()
         ctx.run({k: d.vp for k, d in dev.items()}, n)
         spent += time.perf_counter() - t0
         for d in dev.values():
             d.free()
         rows += n
-        nb += 1
+        slices.append((bi, lo, n))
         if spent > budget_s:
             break
     groups = ctx.result_size
     fetched = ctx.fetch()
     ctx.release()
     report = {"value": rows / spent, "unit": "rows/s", "cores": 1, "kind": kind,
-              "sample": f"{rows} rows of the same C3 shard as {nb} live batches of {chunk} rows, "
-                        f"QUERY_MODE=HOST filter+transforms+Sort+Reduce, {groups} groups, {spent:.1f} s"}
-    return report, fetched, rows
+              "sample": f"{rows} rows of the same C3 shard: {len(slices)} live batches of {chunk} rows taken round-robin from all "
+                        f"{nb} batches, QUERY_MODE=HOST filter+transforms+Sort+Reduce, {groups} groups, {spent:.1f} s"}
+    return report, fetched, slices
 
 
 def host_batch_leg(be, plan, batches, device, streams, max_batches=4):
@@ -357,7 +362,7 @@ def _round_floats(x, digits=6):
 def _brief_check(rep):
     if not isinstance(rep, dict):
         return rep
-    return {k: rep[k] for k in ("status", "groups", "rows") if k in rep}
+    return {k: rep[k] for k in ("status", "groups", "rows", "batches_sampled") if k in rep}
 
 
 def headline(out):
@@ -777,11 +782,11 @@ def main(argv=None, backend=None, tensor_device=None):
     legs = {}
     if rank == 0 and world == 1 and on_gpu:
         if not args.no_cpu_baseline:
-            cpu, ref_fetched, ref_rows = cpu_baseline(batches[0], c3_plan, args.cpu_budget)
+            cpu, ref_fetched, ref_slices = cpu_baseline(batches, c3_plan, args.cpu_budget)
             if cpu is not None:  # the reference's HOST result of the sample, key by key against the same group-by
-                ref_check = check.compare_result(ref_fetched, check.exact_groups(batches, limit_first_batch=ref_rows),
-                                                 hash_identity=False)
-                ref_check["rows"] = ref_rows
+                ref_check = check.compare_result(ref_fetched, check.exact_groups(batches, slices=ref_slices), hash_identity=False)
+                ref_check["rows"] = sum(n for _, _, n in ref_slices)
+                ref_check["batches_sampled"] = len({bi for bi, _, _ in ref_slices})
                 ok = ok and ref_check["status"] == "ok"
         if not args.no_legs:
             common = ["--rows", str(rows), "--null-fraction", str(args.null_fraction), "--steps", "3", "--warmup", "1"]

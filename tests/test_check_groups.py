@@ -61,3 +61,19 @@ def test_row_hash_of_the_checker_matches_the_reference_known_answers():
                                 [blob[no:no + n].reshape(n, 1) for _, no, _ in dv.dim_offsets()], axis=1)
         assert np.array_equal(np.sort(check.murmur3_128_lo64_rows(packed)), got), ndw
         dv.free()
+
+
+def test_exact_groups_over_slices_equals_whole_batches():
+    """bench.py compares the reference's HOST result of a SAMPLE spread over the whole shard (chunks taken round-robin from
+    every batch) with exact_groups(slices=...): slices that tile the batches must give the whole shard's groups."""
+    batches = workload.c3_shard(30000, 8000, seed=5, device=torch.device("cpu"), null_fraction=0.02)
+    whole = check.exact_groups(batches)
+    slices = []
+    for bi, b in enumerate(batches):
+        n = next(iter(b.values())).length
+        slices += [(bi, 0, 3000), (bi, 3000, n - 3000)]
+    tiled = check.exact_groups(batches, slices=slices)
+    assert np.array_equal(whole[0], tiled[0]) and np.array_equal(whole[1], tiled[1]) and np.array_equal(whole[3], tiled[3])
+    part = check.exact_groups(batches, slices=[(1, 100, 500), (3, 0, 200)])
+    assert int(part[3].sum()) == int(check.exact_groups(batches[1:2], limit_first_batch=600)[3].sum()) - \
+        int(check.exact_groups(batches[1:2], limit_first_batch=100)[3].sum()) + int(check.exact_groups(batches[3:4], limit_first_batch=200)[3].sum())

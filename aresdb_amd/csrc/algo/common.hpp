@@ -56,8 +56,18 @@ inline void hip_check_timed(F &&call, const char *what) {
 }
 #define hip_check(expr, what) hip_check_timed([&]() -> hipError_t { return (expr); }, what)
 
+// The sibling libmem.so shares the fence events of a free with the frees that follow it while nothing was submitted to the
+// device in between (mem/memory.hip "shared fences"): every entry point and every kernel launch of this library — launches
+// happen inside libmem's hooks too — says so (AresMemNoteActivity; null: no such libmem, nothing is shared).
+extern void (*g_memNoteActivity)();
+inline void mem_note_activity() {
+  if (g_memNoteActivity) g_memNoteActivity();
+}
 // Checks the launch that was just enqueued (reference CheckCUDAError, utils.cu:44-59).
-inline void check_launch(const char *what) { hip_check(hipGetLastError(), what); }
+inline void check_launch(const char *what) {
+  mem_note_activity();
+  hip_check(hipGetLastError(), what);
+}
 
 // launches the transforms held back for cross-call fusion on `device` (transform.hip)
 void flush_deferred(int device);
@@ -133,6 +143,7 @@ class CallStreamScope {
   try {                                                \
     ares::hip_check(hipSetDevice(device), "hipSetDevice");  \
     ares::CallStreamScope callStreamScope_(cudaStream, __func__);  \
+    ares::mem_note_activity();                                      \
     (void)ares::deferral_hooks_active(); /* write tracking is on before this entry point's first kernel */
 
 #define ARES_ABI_BEGIN(device)     \

@@ -283,6 +283,7 @@ __global__ __launch_bounds__(kThreads) void sr_merge_kernel(SrArgs m) {
       for (int k = 0; k < 4; k++) {
         const uint32_t i = static_cast<uint32_t>(k) * 64u + lane;
         r[k] = *(i < c.n ? c.ptr + i : pad);
+        r[k].x = i < c.n ? r[k].x : kNoRow;  // (past the chunk's end: no record)
       }
     };
     uint4 *queue = sQueue[wave];
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(kThreads) void sr_merge_kernel(SrArgs m) {
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
-    auto consume = [&](uint4(&r)[4], const Chunk &c) {
+    auto consume = [&](uint4(&r)[4]) {
       uint32_t pend = 0, bkt[4];
       // all four home buckets are read before the first compare (eight independent 16-byte LDS reads in flight), and the
       // atomics are issued unconditionally — a record that does not meet its group at home aims them at a spare slot behind
@@ -311,8 +312,7 @@ __global__ __launch_bounds__(kThreads) void sr_merge_kernel(SrArgs m) {
       }
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        const uint32_t i = static_cast<uint32_t>(k) * 64u + lane;
-        const bool valid = i < c.n && r[k].x != kNoRow;  // (row ~0: the padding of a stream's last line)
+        const bool valid = r[k].x != kNoRow;  // (row ~0: the padding of a stream's last line, or no record at all)
         const uint32_t hi = r[k].y, lo = r[k].w;
         const bool m0 = u[k].x == lo && u[k].y == hi, m1 = u[k].z == lo && u[k].w == hi, m2 = v[k].x == lo && v[k].y == hi, m3 = v[k].z == lo && v[k].w == hi;
         const bool hit = valid && (m0 || m1 || m2 || m3) && (hi & lo) != 0xFFFFFFFFu;
@@ -341,19 +341,47 @@ __global__ __launch_bounds__(kThreads) void sr_merge_kernel(SrArgs m) {
         }
       }
     };
-    // two register stages: the next chunk's loads are in flight while the current one goes through the table
+    // Small batches (live batches: 2 Mi rows = 512 tiles, two per scanning workgroup) leave every partition a few hundred
+    // runs of a dozen records — one or two lines each.  Walked run by run, sixteen runs per wavefront, that is a chain of
+    // dependent loads (113 us of a partition's 155 at 2 Mi rows): when no run is longer than four lines, the first L lines of
+    // EVERY run are fetched at once instead (L = lines of the longest run), four 16-byte loads per lane in flight.
+    uint32_t maxRun = 0;
+    for (int gg = lane; gg < m.streams; gg += 64) maxRun = sRun[gg] > maxRun ? sRun[gg] : maxRun;
+#pragma unroll
+    for (int off2 = 32; off2 > 0; off2 >>= 1) {
+      const uint32_t t = static_cast<uint32_t>(__shfl_xor(static_cast<int>(maxRun), off2));
+      maxRun = t > maxRun ? t : maxRun;
+    }
+    const uint32_t lpr = (maxRun + 7u) / 8u;  // lines of the longest run
     uint4 ra[4], rb[4];
-    Chunk ca = next();
-    load(ra, ca);
-    while (ca.n) {
-      Chunk cb = next();
-      load(rb, cb);
-      consume(ra, ca);
-      if (!cb.n || __hip_atomic_load(&sBad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
-      ca = next();
+    if (m.streams > 0 && lpr >= 1u && lpr <= 4u) {
+      const uint32_t units = static_cast<uint32_t>(m.streams) * 8u * lpr;
+      for (uint32_t base = 0; base < units; base += 4u * kThreads) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const uint32_t unit = base + static_cast<uint32_t>(k) * kThreads + tid;  // lane (unit & 7) of line (unit >> 3) % lpr of run (unit >> 3) / lpr
+          const uint32_t ul = unit < units ? unit >> 3 : 0u, gg = ul / lpr, idx = (ul - gg * lpr) * 8u + (unit & 7u);
+          const bool in = unit < units && idx < sRun[gg];
+          ra[k] = *(in ? m.recB + (static_cast<uint64_t>(gg) * numParts + p) * m.capB + idx : pad);
+          ra[k].x = in ? ra[k].x : kNoRow;
+        }
+        consume(ra);
+        if (__hip_atomic_load(&sBad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+      }
+    } else {
+      // two register stages: the next chunk's loads are in flight while the current one goes through the table
+      Chunk ca = next();
       load(ra, ca);
-      consume(rb, cb);
-      if (__hip_atomic_load(&sBad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+      while (ca.n) {
+        Chunk cb = next();
+        load(rb, cb);
+        consume(ra);
+        if (!cb.n || __hip_atomic_load(&sBad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+        ca = next();
+        load(ra, ca);
+        consume(rb);
+        if (__hip_atomic_load(&sBad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+      }
     }
     while (qn) {
       const uint32_t take = qn < 64u ? qn : 64u;

@@ -327,6 +327,10 @@ bool defer_available() {
     auto track = reinterpret_cast<void (*)()>(dlsym(h, "AresMemEnableWriteTracking"));
     if (g_memNoteWrite && track) track();  // from here on every kernel output is reported
     else g_memNoteWrite = nullptr;
+    g_memNoteActivity = reinterpret_cast<void (*)()>(dlsym(h, "AresMemNoteActivity"));
+    auto share = reinterpret_cast<void (*)()>(dlsym(h, "AresMemEnableActivityTracking"));
+    if (g_memNoteActivity && share) share();  // from here on every entry point and every launch is reported: frees may share fences
+    else g_memNoteActivity = nullptr;
     return true;
   }();
   return ok;

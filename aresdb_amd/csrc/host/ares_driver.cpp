@@ -71,8 +71,12 @@ struct AbiLibrary {
   // optional (include/ares_extensions.h): libmem.so clears a freed block only where something wrote, so
   // whatever writes DeviceAllocate memory behind its back — a collective receiving into it — says so
   void (*NoteWrite)(int, const void *, size_t) = nullptr;
+  // ... and whoever submits work to the query's streams behind its back says that too: frees that follow one another with
+  // nothing submitted in between share their fence events (a collective is such a submission)
+  void (*NoteActivity)() = nullptr;
   void noteWrite(int device, const void *p, size_t bytes) const {
     if (NoteWrite) NoteWrite(device, p, bytes);
+    if (NoteActivity) NoteActivity();
   }
 
   template <typename F>
@@ -106,6 +110,7 @@ struct AbiLibrary {
     bind(memHandle, "AsyncCopyDeviceToHost", AsyncCopyDeviceToHost);
     bind(memHandle, "AsyncCopyHostToDevice", AsyncCopyHostToDevice);
     NoteWrite = reinterpret_cast<decltype(NoteWrite)>(dlsym(memHandle, "AresMemNoteWrite"));
+    NoteActivity = reinterpret_cast<decltype(NoteActivity)>(dlsym(memHandle, "AresMemNoteActivity"));
   }
   ~AbiLibrary() {
     if (algoHandle) dlclose(algoHandle);

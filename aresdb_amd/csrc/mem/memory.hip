@@ -116,8 +116,10 @@ inline void notify_wait(int device, void *stream) {
   const AresDeferralHooks *h = g_hooks.load(std::memory_order_acquire);
   if (h && h->on_wait) h->on_wait(device, stream); else flush_pending(device);
 }
-// a copy is about to read or write [ptr, ptr + bytes)
+// a copy is about to read or write [ptr, ptr + bytes) (and about to be submitted: fences recorded before do not cover it)
+extern std::atomic<uint64_t> g_activity;
 inline void notify_access(int device, const void *ptr, size_t bytes) {
+  g_activity.fetch_add(1, std::memory_order_acq_rel);
   const AresDeferralHooks *h = g_hooks.load(std::memory_order_acquire);
   if (h && h->on_access) h->on_access(device, ptr, bytes); else flush_pending(device);
 }
@@ -210,6 +212,12 @@ struct LiveBlock {
   std::vector<std::pair<size_t, size_t>> dirty;  // [lo, hi) byte ranges, disjoint, sorted
 };
 std::atomic<bool> g_writeTracking{false};
+// Fence sharing (below: DeviceState::lastFence) is only sound when everything that submits work to the device's streams
+// says so: libalgorithm.so switches it on (AresMemEnableActivityTracking) once it reports its entry points and launches.
+std::atomic<bool> g_activityTracking{false};
+// Counts everything that may have submitted work to any stream (process-wide: a finer count would only share more).
+std::atomic<uint64_t> g_activity{1};
+inline void note_activity() { g_activity.fetch_add(1, std::memory_order_acq_rel); }
 
 struct DeviceState {
   std::once_flag once;
@@ -232,6 +240,20 @@ struct DeviceState {
   // stream's events
   int waiters = 0;
   std::condition_variable waitersCv;
+  // ---- shared fences.  A fence is one event per stream, recorded at a free.  The Go host frees in bursts (a batch's columns,
+  // index and predicate vector: query/aql_processor.go:695-714) with nothing submitted in between: the events of the first
+  // free of a burst fence the others just as well — recording them again cost 1.6 us per event and free, and the first
+  // hipEventQuery of every new event 3.5 us at the allocation that meets it (tools/ubench_libmem.cpp, ubench_events.py).
+  // g_activity counts everything that may have submitted work since: entry points and kernel launches of libalgorithm.so
+  // (AresMemNoteActivity), this library's own copies and fills, stream creation; a free that finds it unchanged since
+  // `lastFence` was recorded shares those events (reference counts in `events`; an event seen complete is not queried again).
+  uint64_t lastFenceActivity = 0;
+  std::vector<FenceEvent> lastFence;  // holds one reference on each of its events
+  struct EventInfo {
+    int refs = 0;
+    bool done = false;
+  };
+  std::map<hipEvent_t, EventInfo> events;
 };
 DeviceState g_devices[kMaxDevices];
 
@@ -274,25 +296,42 @@ size_t bin_size(size_t bytes) {
   return (bytes + step - 1) / step * step;
 }
 
-bool fence_done(const ParkedBlock &b) {
-  for (const FenceEvent &f : b.fence)
+// caller holds st->mu
+bool fence_done(DeviceState *st, const ParkedBlock &b) {
+  for (const FenceEvent &f : b.fence) {
+    DeviceState::EventInfo &info = st->events[f.event];
+    if (info.done) continue;  // (seen complete through another block that shares it)
     if (hipEventQuery(f.event) != hipSuccess) {
       (void)hipGetLastError();
       return false;
     }
+    info.done = true;
+  }
   return true;
+}
+
+// caller holds st->mu: one reference on `f` goes; the last one recycles the event (while the stream of its last record
+// exists: see FenceEvent) or destroys it
+void release_event(DeviceState *st, const FenceEvent &f) {
+  auto it = st->events.find(f.event);
+  if (it != st->events.end() && --it->second.refs > 0) return;
+  if (it != st->events.end()) st->events.erase(it);
+  bool alive = f.stream == nullptr || f.stream == st->allocStream || f.stream == st->freshStream;
+  for (size_t i = 0; !alive && i < st->streams.size(); i++) alive = st->streams[i] == f.stream;
+  if (alive) st->freeEvents.push_back(f);
+  else (void)hipEventDestroy(f.event);
 }
 
 // caller holds st->mu.  An event is only kept for reuse while the stream of its last record exists (see FenceEvent):
 // one whose stream has gone meanwhile is destroyed here, never recorded again.
 void recycle_events(DeviceState *st, ParkedBlock &b) {
-  for (const FenceEvent &f : b.fence) {
-    bool alive = f.stream == nullptr || f.stream == st->allocStream || f.stream == st->freshStream;
-    for (size_t i = 0; !alive && i < st->streams.size(); i++) alive = st->streams[i] == f.stream;
-    if (alive) st->freeEvents.push_back(f);
-    else (void)hipEventDestroy(f.event);
-  }
+  for (const FenceEvent &f : b.fence) release_event(st, f);
   b.fence.clear();
+}
+void drop_last_fence(DeviceState *st) {
+  for (const FenceEvent &f : st->lastFence) release_event(st, f);
+  st->lastFence.clear();
+  st->lastFenceActivity = 0;
 }
 
 // Releases parked blocks (oldest bins first) until `need` more bytes fit under the cap or nothing
@@ -402,7 +441,7 @@ hipError_t pool_alloc(DeviceState *st, void **p, size_t bytes, bool zero) {
     if (it != st->bins.end()) {
       auto &vec = it->second;
       for (size_t i = 0; i < vec.size(); i++) {
-        if (fence_done(vec[i])) {
+        if (fence_done(st, vec[i])) {
           ptr = vec[i].ptr;
           cleared = vec[i].zeroed;
           recycle_events(st, vec[i]);
@@ -555,11 +594,30 @@ hipError_t pool_free(DeviceState *st, void *p) {
     }
     hipError_t err = hipEventRecord(e, s);
     b.fence.push_back(FenceEvent{e, s});
+    st->events[e] = DeviceState::EventInfo{1, false};
     return err;
   };
-  hipError_t err = fence_on(nullptr);
-  for (hipStream_t s : st->streams)
-    if (err == hipSuccess) err = fence_on(s);
+  hipError_t err = hipSuccess;
+  const uint64_t activityNow = g_activity.load(std::memory_order_acquire);
+  if (g_activityTracking.load(std::memory_order_acquire) && !st->lastFence.empty() && st->lastFenceActivity == activityNow) {
+    // nothing was submitted since the last fence was recorded: it fences this block as well
+    for (const FenceEvent &f : st->lastFence) {
+      st->events[f.event].refs++;
+      b.fence.push_back(f);
+    }
+  } else {
+    err = fence_on(nullptr);
+    for (hipStream_t s : st->streams)
+      if (err == hipSuccess) err = fence_on(s);
+    if (err == hipSuccess && g_activityTracking.load(std::memory_order_acquire)) {
+      drop_last_fence(st);
+      for (const FenceEvent &f : b.fence) {
+        st->events[f.event].refs++;
+        st->lastFence.push_back(f);
+      }
+      st->lastFenceActivity = activityNow;
+    }
+  }
   if (err != hipSuccess) {  // cannot fence: fall back to the synchronising free of the reference
     (void)hipGetLastError();
     recycle_events(st, b);
@@ -645,6 +703,10 @@ void AresMemSetAuxHooks(const AresMemAuxHooks *hooks) { g_aux.store(hooks, std::
 // library receiving into it, say) reports it the same way.
 void AresMemNoteWrite(int device, const void *ptr, size_t bytes) { note_write(device, ptr, bytes); }
 void AresMemEnableWriteTracking(void) { g_writeTracking.store(true, std::memory_order_release); }
+// Something may have been submitted to a stream of `device` (an entry point of libalgorithm.so was called, a kernel was
+// launched from one of its hooks, RCCL was handed the query's stream): fences recorded before do not cover it.
+void AresMemNoteActivity(void) { note_activity(); }
+void AresMemEnableActivityTracking(void) { g_activityTracking.store(true, std::memory_order_release); }
 
 // What the host currently owns on `device` (the Go host keeps the same books itself and asserts they
 // return to zero after every query, query/aql_processor_test.go:230-231): bytes of live DeviceAllocate /
@@ -693,12 +755,16 @@ size_t AresMemStreamEvents(int device, void *stream) {
   if (device < 0 || device >= kMaxDevices) return 0;
   DeviceState *st = &g_devices[device];
   std::lock_guard<std::mutex> lock(st->mu);
-  size_t n = 0;
+  std::map<hipEvent_t, int> seen;  // (blocks may share an event)
   for (auto &bin : st->bins)
     for (const ParkedBlock &b : bin.second)
-      for (const FenceEvent &f : b.fence) n += f.stream == reinterpret_cast<hipStream_t>(stream);
-  for (const FenceEvent &f : st->freeEvents) n += f.stream == reinterpret_cast<hipStream_t>(stream);
-  return n;
+      for (const FenceEvent &f : b.fence)
+        if (f.stream == reinterpret_cast<hipStream_t>(stream)) seen[f.event] = 1;
+  for (const FenceEvent &f : st->lastFence)
+    if (f.stream == reinterpret_cast<hipStream_t>(stream)) seen[f.event] = 1;
+  for (const FenceEvent &f : st->freeEvents)
+    if (f.stream == reinterpret_cast<hipStream_t>(stream)) seen[f.event] = 1;
+  return seen.size();
 }
 
 void AresMemTrimCache(int device) {
@@ -775,6 +841,7 @@ CGoCallResHandle CreateCudaStream(int device) {
   {
     std::lock_guard<std::mutex> lock(st->mu);
     st->streams.push_back(s);  // frees are fenced against every stream the host works on
+    drop_last_fence(st);       // (a fence shared from now on names this stream too)
   }
   return ok(reinterpret_cast<void *>(s));
 }
@@ -813,11 +880,16 @@ CGoCallResHandle DestroyCudaStream(void *s, int device) {
       // hands its events to freeEvents, where the sweep below finds them.
       std::unique_lock<std::mutex> lock(st->mu);
       st->waitersCv.wait(lock, [&] { return st->waiters == 0; });
+      drop_last_fence(st);  // (its events of this stream go to freeEvents unless a parked block shares them: swept either way)
       for (auto &bin : st->bins)
         for (ParkedBlock &b : bin.second)
           for (size_t i = 0; i < b.fence.size();)
             if (b.fence[i].stream == reinterpret_cast<hipStream_t>(s)) {
-              (void)hipEventDestroy(b.fence[i].event);
+              auto info = st->events.find(b.fence[i].event);
+              if (info == st->events.end() || --info->second.refs <= 0) {  // the last block that names it
+                if (info != st->events.end()) st->events.erase(info);
+                (void)hipEventDestroy(b.fence[i].event);
+              }
               b.fence[i] = b.fence.back();
               b.fence.pop_back();
             } else {

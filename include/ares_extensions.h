@@ -107,6 +107,15 @@ void AresMemTrimCache(int device);                     /* exported by libmem.so 
 void AresMemNoteWrite(int device, const void *ptr, size_t bytes);
 void AresMemEnableWriteTracking(void);
 
+/* Shared fences.  DeviceFree fences a block with one event per stream; frees that follow one another with NOTHING submitted
+ * to the device in between (the Go host frees a batch's columns, index and predicate vector in a row) share the events of
+ * the first.  "Nothing submitted" must be known: libalgorithm.so reports every entry point and every kernel launch with
+ * AresMemNoteActivity and switches sharing on with AresMemEnableActivityTracking (never called: every free records its
+ * own events).  A host component that submits work to the query's streams itself (the driver's RCCL calls) reports it
+ * the same way. */
+void AresMemNoteActivity(void);
+void AresMemEnableActivityTracking(void);
+
 /* Books of libmem.so for one device: bytes / number of blocks the host holds (DeviceAllocate, deviceMalloc;
  * held blocks were freed by the host but are kept aside for deferred work and are NOT counted as live),
  * blocks kept aside, bytes parked in the cache.  Any pointer may be NULL. */

@@ -114,6 +114,45 @@ def row_hashes_of_fetched(dims_, valids):
     return murmur3_128_lo64_rows(np.concatenate(parts, axis=1)) if n else np.zeros(0, np.uint64)
 
 
+def murmur3_32_bytes(rows):
+    """murmur3_x86_32 (seed 0) of every row of a uint8 matrix [n, row bytes] (query/utils.cu:113-155): any row width."""
+    rows = np.ascontiguousarray(rows, dtype=np.uint8)
+    n, nbytes = rows.shape
+    padded = np.zeros((n, (nbytes + 3) // 4 * 4), np.uint8)
+    padded[:, :nbytes] = rows
+    words = padded.view("<u4")
+    c1, c2 = np.uint32(0xcc9e2d51), np.uint32(0x1b873593)
+    h = np.zeros(n, np.uint32)
+    with np.errstate(over="ignore"):
+        for b in range(nbytes // 4):
+            k = (words[:, b] * c1).astype(np.uint32)
+            k = (_rotl(k, 15) * c2).astype(np.uint32)
+            h ^= k
+            h = (_rotl(h, 13) * np.uint32(5) + np.uint32(0xe6546b64)).astype(np.uint32)
+        if nbytes % 4:
+            k = (words[:, nbytes // 4] * c1).astype(np.uint32)
+            k = (_rotl(k, 15) * c2).astype(np.uint32)
+            h ^= k
+        h ^= np.uint32(nbytes)
+        h ^= h >> np.uint32(16)
+        h = (h * np.uint32(0x85ebca6b)).astype(np.uint32)
+        h ^= h >> np.uint32(13)
+        h = (h * np.uint32(0xc2b2ae35)).astype(np.uint32)
+        h ^= h >> np.uint32(16)
+    return h
+
+
+def derive_eight(values, valids):
+    """The four derived dimensions of queries.c3_plan(eight_dims=True) from the four base ones (ts bucket, d1, d2, d3): d1 + 5,
+    d2 * 3, d3 + 1, d2 mod 7 — a null operand of a binary functor yields value 0, validity 0 (query/functor.hpp:660-697)."""
+    _, d1, d2, d3 = [np.asarray(v).astype(np.uint32) for v in values]
+    _, o1, o2, o3 = [np.asarray(v).astype(np.uint8) for v in valids]
+    with np.errstate(over="ignore"):
+        extra = [np.where(o1 != 0, d1 + np.uint32(5), 0), np.where(o2 != 0, d2 * np.uint32(3), 0), np.where(o3 != 0, d3 + np.uint32(1), 0),
+                 np.where(o2 != 0, d2 % np.uint32(7), 0)]
+    return [e.astype(np.uint32) for e in extra], [o1, o2, o3, o2]
+
+
 def _codes_of_batch(b, limit=None, dims=ALL_DIMS, d1_below=90, ts_range=None, measure="m", lo=0):
     """dense key code, keep mask and float64 measure of every row of one C3 batch (torch, on the
     batch's device) for the group-by dimensions `dims` (a subset of ts-bucket, d1, d2, d3; the filter d1 < 90 and the
@@ -219,11 +258,17 @@ def encode_rows(values, valids, dims=ALL_DIMS):
     return c
 
 
-def predict_hash_merges(code, sums, first_row, dims=ALL_DIMS):
+def predict_hash_merges(code, sums, first_row, dims=ALL_DIMS, eight=False):
     """Groups as HashReduce forms them: one per distinct 32-bit hash; representative = the member
-    whose first row comes first; value = sum over the members."""
+    whose first row comes first; value = sum over the members.  eight: the rows carry derive_eight's four dimensions too."""
     values, valids = decode_codes(code, dims)
-    h = murmur3_32_rows(values, valids)
+    if eight:
+        ev, eo = derive_eight(values, valids)
+        values, valids = values + ev, valids + eo
+        h = murmur3_32_bytes(np.concatenate([v.astype("<u4").view(np.uint8).reshape(-1, 4) for v in values] +
+                                            [o.astype(np.uint8).reshape(-1, 1) for o in valids], axis=1))
+    else:
+        h = murmur3_32_rows(values, valids)
     order = np.lexsort((first_row, h))
     hs = h[order]
     head = np.ones(len(hs), bool)
@@ -254,7 +299,7 @@ def compare_tables(got_code, got_sum, want_code, want_sum, rel=0.0):
     return None
 
 
-def compare_result(fetched, expected, hash_identity=True, rel=0.0, dims=ALL_DIMS, measure_dtype=np.float64, ordered=False):
+def compare_result(fetched, expected, hash_identity=True, rel=0.0, dims=ALL_DIMS, measure_dtype=np.float64, ordered=False, eight=False):
     """fetched = (dims, valids, measures) of NativeQuery.fetch(); expected = exact_groups(...).
     hash_identity: the result comes from HashReduce (groups are hashes); False: Sort+Reduce on the
     64-bit hash (exact groups at these cardinalities).  measure_dtype: how the fetched measure bytes read (float64 sums,
@@ -265,8 +310,16 @@ def compare_result(fetched, expected, hash_identity=True, rel=0.0, dims=ALL_DIMS
     got_code = encode_rows([np.frombuffer(d, np.uint32) for d in dims_], [np.frombuffer(v, np.uint8) for v in valids], dims)
     got_sum = np.frombuffer(meas, measure_dtype).astype(np.float64)
     merged = 0
+    if eight:  # the four derived dimensions are functions of the first four
+        base_v = [np.frombuffer(d, np.uint32) for d in dims_[:4]]
+        base_o = [np.frombuffer(v, np.uint8) for v in valids[:4]]
+        ev, eo = derive_eight(base_v, base_o)
+        for k in range(4):
+            if not (np.array_equal(np.frombuffer(dims_[4 + k], np.uint32), ev[k]) and np.array_equal(np.frombuffer(valids[4 + k], np.uint8) != 0, eo[k] != 0)):
+                return {"status": f"MISMATCH: derived dimension {4 + k} is not the function of its base dimension", "groups": int(len(got_code)),
+                        "expected_groups": int(len(code)), "distinct_dimension_rows": int(len(code)), "merged_by_32bit_hash": 0}
     if hash_identity:
-        want_code, want_sum, merged = predict_hash_merges(code, sums, first_row, dims)
+        want_code, want_sum, merged = predict_hash_merges(code, sums, first_row, dims, eight)
     else:
         want_code, want_sum = code, sums
     why = compare_tables(got_code, got_sum, want_code, want_sum, rel)

@@ -89,7 +89,7 @@ std::vector<std::pair<int, uint32_t *>> g_freeRanges;
 // 4, 2 or 1 bytes (dim_layout.hpp: descending width order)
 struct SlotWidths {
   int nd = 0, dimBytes = 0;  // dimBytes: value bytes of one row
-  uint8_t width[kFusedDims] = {0, 0, 0, 0}, off[kFusedDims] = {0, 0, 0, 0};
+  uint8_t width[kFusedDims] = {}, off[kFusedDims] = {};
   bool same(const SlotWidths &o) const { return nd == o.nd && memcmp(width, o.width, sizeof(width)) == 0; }
   size_t row_bytes() const { return static_cast<size_t>(dimBytes + nd); }
 };
@@ -820,6 +820,12 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
     break;
     switch (nd) {
       ARES_FUSED_CASE(1) ARES_FUSED_CASE(2) ARES_FUSED_CASE(3) ARES_FUSED_CASE(4)
+      default:  // five to eight dimensions: the generated kernels only (the plan counts as narrow: both were looked up above)
+        if (batchRows > 0 && lean) rtc_scan_launch(lean, plan, static_cast<uint32_t>(prevSize), batchRows, ws, stream);
+        else if (batchRows > 0 && table) rtc_table_scan_launch(table, plan, static_cast<uint32_t>(prevSize), batchRows, ws, stream);
+        rtc_merge_launch(leanMerge ? leanMerge : tableMerge, plan, prevKeys.DimValues, prevCapacity, prevValues, static_cast<uint32_t>(prevSize),
+                         outKeys.DimValues, outCapacity, outValues, ws, stream, imagePtr, result_slot());
+        break;
     }
     {
       SlowScope slow("read_result");
@@ -947,7 +953,7 @@ void fused_expr(const AresFusedExpr &e, bool compareOnly, int batchRows, hipStre
 int fused_filter_hash_reduce(int device, const AresFusedQuery &q, int batchRows, const DimensionVector &prevKeys,
                              uint8_t *prevValues, int prevSize, const DimensionVector &outKeys, uint8_t *outValues,
                              hipStream_t stream) {
-  if (q.numDims < 1 || q.numDims > kFusedDims) throw NotFusable("1..4 dimensions");
+  if (q.numDims < 1 || q.numDims > kGenericFusedDims) throw NotFusable("1..4 dimensions");
   if (q.numFilters < 0 || q.numFilters > kExtensionFilters) throw NotFusable("at most 4 filters");
   const int nd = q.numDims;
   for (int k = 0; k < NUM_DIM_WIDTH; k++)

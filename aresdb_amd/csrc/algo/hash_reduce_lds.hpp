@@ -21,7 +21,11 @@ int hash_reduce_lds(int device, const DimensionVector &inputKeys, const uint8_t 
 
 // ---- fused scan: filter + projection evaluated from the source columns ------------------------------
 // (kFusedFilters: the Go host's two time filters, a cutoff filter on live batches and three of the query's own)
-constexpr int kFusedCols = 6, kFusedFilters = 6, kFusedDims = 4;
+// kFusedDims / kFusedCols (round 6): what the ABI allows — MAX_DIMENSIONS = 8 (query/time_series_aggregate.h:36-37) — in slots
+// of 4, 2 or 1 bytes; eight dimensions + measure + a filter column = ten column slots.  More than four dimensions run on the
+// kernels generated for the plan's shape only (the precompiled generic kernels are instantiated for one to four).
+constexpr int kFusedCols = 10, kFusedFilters = 6, kFusedDims = 8;
+constexpr int kGenericFusedDims = 4;
 constexpr int kExtensionFilters = 4;  // AresFusedQuery::filters (include/ares_extensions.h)
 struct FusedColumn {
   const uint32_t *vals;
@@ -51,6 +55,7 @@ struct FusedPlanD {
 inline int fused_dim_width(const FusedPlanD &p, int d) { return p.dimWidth[d] ? p.dimWidth[d] : 4; }
 inline int fused_col_step(const FusedPlanD &p, int c) { return p.cols[c].step ? static_cast<int>(p.cols[c].step) : 4; }
 inline bool fused_plan_narrow(const FusedPlanD &p, int nd) {
+  if (nd > kGenericFusedDims) return true;  // (generated kernels only, like a plan with narrow slots)
   for (int d = 0; d < nd; d++)
     if (fused_dim_width(p, d) != 4) return true;
   for (int c = 0; c < p.numCols; c++)

@@ -799,7 +799,7 @@ enum ScanKind { SCAN_LINES16 = 0, SCAN_COMPACT = 1, SCAN_TABLE = 2, SCAN_SORT64 
 // each the OR of the fields that fall into it.
 struct SlotLayout {
   int nd = 0, valueBytes = 0;
-  int width[kFusedDims] = {4, 4, 4, 4}, off[kFusedDims] = {0, 0, 0, 0};
+  int width[kFusedDims] = {4, 4, 4, 4, 4, 4, 4, 4}, off[kFusedDims] = {};
   bool all4 = true, ok = true;
 };
 SlotLayout slot_layout(const FusedPlanD &plan, int nd) {
@@ -815,6 +815,8 @@ SlotLayout slot_layout(const FusedPlanD &plan, int nd) {
     L.valueBytes += w;
     L.all4 = L.all4 && w == 4;
   }
+  // (the all-4-byte shortcuts pack the validity bytes of up to four dimensions into one word: beyond, the general word list)
+  L.all4 = L.all4 && nd <= 4;
   return L;
 }
 // murmur3_x86_32 (seed 0) of the packed row: `val(d)` names the dimension's value (already truncated to its width),

@@ -2249,7 +2249,8 @@ bool fuse_pending_into_hash_reduce(int device, hipStream_t stream, const Dimensi
     }
     // every dimension column and the measure of rows [prev, prev + n) must be a pending sink
     const size_t cap = static_cast<size_t>(in.VectorCapacity);
-    int dimJob[kFusedDims] = {-1, -1, -1, -1}, measureJob = -1;
+    int dimJob[kFusedDims], measureJob = -1;
+    for (int c = 0; c < kFusedDims; c++) dimJob[c] = -1;
     for (int k = 0; ok && k < pq.jobs.count; k++) {
       const SinkD &s = pq.jobs.s[k];
       ok = pq.colRows[k] >= static_cast<uint32_t>(n0);

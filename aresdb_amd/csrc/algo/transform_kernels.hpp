@@ -734,7 +734,7 @@ __global__ __launch_bounds__(kBlock) void transform_fast_kernel(FastOperands f, 
 // column and writes its own sink.  The quad grid is unshifted (pad 0): validity bytes use
 // byte-aligned dword stores.  (Measured: running the jobs one after the other per tile, 16 rows per
 // lane each, beats issuing every job's loads up front — 4.4 vs 3.2 TB/s on BASELINE config C3.)
-constexpr int kMaxMultiJobs = 8;
+constexpr int kMaxMultiJobs = 10;  // eight dimensions (MAX_DIMENSIONS) + the measure + one to spare
 struct MultiJobs {
   int count;
   FastOperands f[kMaxMultiJobs];

@@ -461,6 +461,8 @@ def main(argv=None, backend=None, tensor_device=None):
     ap.add_argument("--sort-path", default="", choices=["", "count", "sum"],
                     help="the same group-by through the reference's DEFAULT aggregation path, Sort + Reduce (config/ares.yaml:11 "
                          "enable_hash_reduction: false): count = COUNT(*), sum = SUM(d2) as AGGR_SUM_UNSIGNED into 8 bytes (secondary legs)")
+    ap.add_argument("--eight-dims", action="store_true",
+                    help="MAX_DIMENSIONS: four more dimensions (functions of the first four: the same groups) — the fused path at the ABI's limit (secondary leg)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes that measure roofline.traffic")
     ap.add_argument("--single-process", action="store_true",
                     help="N shards on N GPUs as N threads of THIS process (the reference's process model, "
@@ -539,7 +541,8 @@ def main(argv=None, backend=None, tensor_device=None):
     assert dims and all(d in check.ALL_DIMS for d in dims), args.dims
     ts_range = tuple(int(x) for x in args.ts_range.split(",")) if args.ts_range else None
     sort_measure = {"": None, "count": "count", "sum": "d2"}[args.sort_path]
-    plan = c3_plan(use_hash_reduction=True, dims=dims, d1_below=args.d1_below, ts_range=ts_range, sort_measure=sort_measure)
+    plan = c3_plan(use_hash_reduction=True, dims=dims, d1_below=args.d1_below, ts_range=ts_range, sort_measure=sort_measure,
+                   eight_dims=args.eight_dims)
     plan.use_fused_extension = bool(args.fused_extension)
     # columns the plan reads (dimensions + measure + the filter's d1 [+ ts of the time filters]): the algorithmic bytes per row
     measure_columns = {"": {"m"}, "count": set(), "sum": {"d2"}}[args.sort_path]
@@ -552,8 +555,8 @@ def main(argv=None, backend=None, tensor_device=None):
 
     def compare_fetched(fetched, expected):
         if not args.sort_path:
-            return check.compare_result(fetched, expected, hash_identity=True, dims=dims)
-        return check.compare_result(fetched, expected, hash_identity=False, dims=dims, ordered=True,
+            return check.compare_result(fetched, expected, hash_identity=True, dims=dims, eight=args.eight_dims)
+        return check.compare_result(fetched, expected, hash_identity=False, dims=dims, ordered=True, eight=args.eight_dims,
                                     measure_dtype={"count": "<u4", "sum": "<i8"}[args.sort_path])
 
     def sync():
@@ -836,6 +839,8 @@ def main(argv=None, backend=None, tensor_device=None):
             # same four dimensions — hash-keyed inside the ABI (sort_reduce_fused.hip), rows in ascending 64-bit hash order
             leg("c3_sort_path_count", {}, big + ["--sort-path", "count"])
             leg("c3_sort_path_sum_unsigned", {}, big + ["--sort-path", "sum"])
+            # the ABI's limit of dimensions (MAX_DIMENSIONS = 8) on the fused path: generated kernels only
+            leg("c3_eight_dimensions", {}, big + ["--eight-dims"])
             leg(f"live_batches_{LIVE_BATCH_ROWS}_rows", {}, common + ["--batch-rows", str(LIVE_BATCH_ROWS)])
             # lower-cardinality variants of the same query (same filter and measure; fewer group-by dimensions)
             # the reference's own example table and queries at 1 B rows (examples/1k_trips: request_at Uint32, city_id Uint16 in

@@ -77,7 +77,7 @@ SHAPES = [
 ]
 
 
-def run_sequence(b, shape, batches, read=frozenset(), cap_slack=10):
+def run_sequence(b, shape, batches, read=frozenset(), cap_slack=10, hash_reduce=False):
     """The Go host's per-batch sequence; returns every observable the test compares.  read: any of "iota" (the index
     vector between InitIndexVector and Sort), "sorted" (hash + index vector between Sort and Reduce), "after" (input hash /
     index vector and output index vector after Reduce), "inputs" (input dimension and measure rows after Reduce)."""
@@ -125,10 +125,20 @@ def run_sequence(b, shape, batches, read=frozenset(), cap_slack=10):
         idx.free(), pred.free()
         length = res + kept
         entry = {"kept": kept}
+        kin, kout = vec(0, iv[0]), vec(1, iv[1])
+        if hash_reduce:  # (enable_hash_reduction: the same buffers through HashReduce; the order of its output is arbitrary)
+            groups = b.call("HashReduce", kin, vv[0].ptr, kout, vv[1].ptr, vb, length, shape.agg, None, 0)
+            b.wait()
+            entry["groups"] = groups
+            entry["table"] = dict(zip(dv[1].rows(groups), (int(x) for x in vv[1].read(vtype, groups))))
+            log.append(entry)
+            res = groups
+            dv[0], dv[1] = dv[1], dv[0]
+            vv[0], vv[1] = vv[1], vv[0]
+            continue
         b.call("InitIndexVector", iv[0].ptr, 0, length, None, 0)
         if "iota" in read:
             entry["iota"] = iv[0].read(np.uint32, length)
-        kin, kout = vec(0, iv[0]), vec(1, iv[1])
         b.call("Sort", kin, length, None, 0)
         if "sorted" in read:
             entry["hash"] = dv[0].hash.read(np.uint64, length)
@@ -194,6 +204,60 @@ def test_lazily_defined_sort_materialises_for_a_host_that_looks(shape, read):
     got = run_sequence(hip, shape, batches, read=frozenset(read))
     want = run_sequence(oracle, shape, batches, read=frozenset(read))
     assert_same(got, want, (shape.name, read))
+
+
+# MAX_DIMENSIONS = 8 (query/time_series_aggregate.h:36-37): six 4-byte slots, a 2-byte and a 1-byte one, in vector order
+# (widest first: query/aql_compiler.go:1341-1362), every column with nulls, a filter on a column no dimension reads
+_EIGHT_COLS = {**{c: (abi.Uint32, 3) for c in "abcdef"}, "g": (abi.Uint16, 3), "h": (abi.Uint8, 2), "m": (abi.Uint32, 1000), "k": (abi.Uint32, 10)}
+_EIGHT_DIMS = [("a", abi.Floor, 2, abi.Uint32)] + [(c, None, 0, abi.Uint32) for c in "bcdef"] + [("g", None, 0, abi.Uint16), ("h", None, 0, abi.Uint8)]
+EIGHT_SUM = Shape("eight_dims_sum", _EIGHT_COLS, [("k", abi.LessThan, 8)], _EIGHT_DIMS, "m", abi.AGGR_SUM_UNSIGNED, abi.Uint32, (0, 0, 6, 1, 1))
+EIGHT_COUNT = Shape("eight_dims_count", _EIGHT_COLS, [("k", abi.LessThan, 8)], _EIGHT_DIMS, None, abi.AGGR_SUM_UNSIGNED, abi.Uint32, (0, 0, 6, 1, 1))
+
+
+def test_eight_dimensions_through_sort_reduce():
+    """The ABI's limit of dimensions on the fused Sort + Reduce path: ordered output, bit for bit."""
+    hip, oracle = H.hip_backend(), H.oracle_backend()
+    rng = np.random.default_rng(88)
+    batches = [make_batch(rng, EIGHT_COUNT, n) for n in (20000, 30000, 900)]
+    for shape in (EIGHT_COUNT, EIGHT_SUM):
+        got, kernels = _kernels_of(hip, lambda: run_sequence(hip, shape, batches, read=frozenset(("after",))))
+        want = run_sequence(oracle, shape, batches, read=frozenset(("after",)))
+        assert_same(got, want, shape.name)
+        got, kernels = _kernels_of(hip, lambda: run_sequence(hip, shape, batches))
+        if _fusion_on():
+            assert any(k.startswith("sr_scan_rtc") for k in kernels) and not any(k.startswith(("radix_pass", "transform_")) for k in kernels), sorted(kernels)
+
+
+# ... and eight 4-byte slots (the all-4-byte shortcuts of the generators pack four validity bytes into a word: not beyond four)
+_ALL4_COLS = {**{c: (abi.Uint32, 3) for c in "abcdefgh"}, "m": (abi.Uint32, 1000), "k": (abi.Uint32, 10)}
+EIGHT_ALL4 = Shape("eight_u32_dims_sum", _ALL4_COLS, [("k", abi.LessThan, 8)], [(c, None, 0, abi.Uint32) for c in "abcdefgh"], "m",
+                   abi.AGGR_SUM_UNSIGNED, abi.Uint32, (0, 0, 8, 0, 0))
+
+
+@pytest.mark.parametrize("shape8", [EIGHT_SUM, EIGHT_ALL4], ids=lambda s: s.name)
+@pytest.mark.parametrize("lean", [False, True], ids=["table_scan", "direct_scan"])
+def test_eight_dimensions_through_hash_reduce(lean, shape8, monkeypatch):
+    """... and on the fused HashReduce path (kFusedDims 8, kFusedCols 10: round 6): more than four dimensions run on the
+    kernels generated for the plan's shape only — the kernel log proves that nothing was materialised."""
+    hip, oracle = H.hip_backend(), H.oracle_backend()
+    rng = np.random.default_rng(89)
+    batches = [make_batch(rng, shape8, n) for n in (20000, 30000, 900, 25000)]
+    want = run_sequence(oracle, shape8, batches, hash_reduce=True)
+    if lean:
+        monkeypatch.setenv("ARES_LEAN_MIN_GROUPS", "0")
+        monkeypatch.setenv("ARES_MIN_PART_BITS", "2")
+    hip.reload_env()
+    try:
+        for attempt in range(2):  # (the first pass of a shape may meet kernels that are still to be generated)
+            got, kernels = _kernels_of(hip, lambda: run_sequence(hip, shape8, batches, hash_reduce=True))
+            assert_same(got, want, "eight_dims_hash")
+    finally:
+        monkeypatch.undo()
+        hip.reload_env()
+    if _fusion_on():
+        assert any(k.startswith(("hr_scan_rtc", "hr_table_scan_rtc")) for k in kernels) and any(k.startswith("hr_merge_rtc") for k in kernels), sorted(kernels)
+        # (hr_partition_kernel — layout-generic — only re-partitions PREVIOUS groups that are not grouped by partition yet)
+        assert not any(k.startswith(("transform_", "hr_partition4", "hr_fused")) for k in kernels), sorted(kernels)
 
 
 def test_many_groups_per_partition_fall_back_to_the_real_sort(monkeypatch):

@@ -145,6 +145,27 @@ int main(int argc, char **argv) {
     t.filters[2] = p.filters[0]; t.filters[2].f.functor = Equal; t.filters[2].col = 2;
     if (int rc = build(rtc_sort_scan_source(t, 2, 9), "_sort_trips", "narrow sort scan (COUNT)")) return rc;
   }
+  {  // eight dimensions (MAX_DIMENSIONS, query/time_series_aggregate.h:36-37): six 4-byte slots, a 2-byte and a 1-byte one, the
+     // measure and a filter on a column of its own — ten column slots
+    FusedPlanD e = p;
+    e.numCols = 10;
+    for (int c = 0; c < 10; c++) { e.cols[c].vals = reinterpret_cast<const uint32_t *>(0x1000); e.cols[c].nulls = c % 3 ? reinterpret_cast<const uint8_t *>(0x2000) : nullptr; e.cols[c].step = 4; }
+    e.cols[6].step = 2; e.cols[7].step = 1;
+    for (int d = 0; d < 8; d++) { e.dims[d].f = col(K_U32); e.dims[d].col = d; e.dims[d].outKind = K_U32; e.dimWidth[d] = 4; }
+    e.dims[0] = p.dims[0];
+    e.dimWidth[6] = 2; e.dimWidth[7] = 1;
+    e.measure.f = col(K_F32); e.measure.col = 8; e.measure.outKind = K_F32;
+    e.numFilters = 1; e.filters[0] = p.filters[0]; e.filters[0].col = 9;
+    if (int rc = build(rtc_scan_source(e, 8, 9, true), "_8compact", "8-dimension compact scan")) return rc;
+    if (int rc = build(rtc_merge_source(e, 8, 9, agg, w, true), "_8cmerge", "8-dimension compact merge")) return rc;
+    if (int rc = build(rtc_merge_source(e, 8, 9, agg, w, true, false, 2), "_8cmerge_img2", "8-dimension compact merge from image")) return rc;
+    if (int rc = build(rtc_table_scan_source(e, 8, 9, agg, w), "_8table", "8-dimension table scan")) return rc;
+    if (int rc = build(rtc_merge_source(e, 8, 9, agg, w, false, true), "_8amerge", "8-dimension region-A merge")) return rc;
+    FusedPlanD ec = e;
+    ec.numCols = 9; ec.cols[8] = e.cols[9]; ec.filters[0].col = 8;
+    ec.measure.col = -1; ec.measure.f = col(K_U32); ec.measure.f.bbits = 1; ec.measureDtype = Uint32; ec.measureWidth = 4;
+    if (int rc = build(rtc_sort_scan_source(ec, 8, 9), "_8sort", "8-dimension sort scan (COUNT)")) return rc;
+  }
   // the vector-sourced scan (HashReduce on materialised dimension / measure vectors)
   for (int vw = 4; vw <= 8; vw += 4)
     for (int nd = 1; nd <= 4; nd += 3) {

@@ -282,7 +282,9 @@ void *take_cached(StreamCache &c, size_t rounded, bool larger) {
     if (!larger || rounded < kFitAnyFrom) return nullptr;
     it = c.bins.upper_bound(rounded);
     while (it != c.bins.end() && it->second.empty()) ++it;
-    if (it == c.bins.end()) return nullptr;
+    // ... up to twice the request: a 260 MB temporary (a decoded run-length column) that sits on a 4 GB workspace block for
+    // a whole batch makes the workspace's next user go to the driver (archive batches: 4.3 + 1.5 GB of hipMalloc per batch)
+    if (it == c.bins.end() || it->first > 2 * rounded) return nullptr;
   }
   void *p = it->second.back();
   it->second.pop_back();

@@ -357,7 +357,7 @@ void make_regions(Regions &r, int partBits, int64_t rowsA, int64_t rowsB, int st
   ws.lineRecords = lineRecords;
   size_t bBytes = 0;
   if (streams > 0) {
-    const uint64_t mean = static_cast<uint64_t>(rowsB) / (static_cast<uint64_t>(numParts) * streams);
+    const uint64_t mean = (static_cast<uint64_t>(rowsB) / (static_cast<uint64_t>(numParts) * streams)) << record_stream_slack();
     if (lineRecords == static_cast<int>(kCompactLineRecords)) {  // whole 128-byte lines of 14 records; an odd number of lines per stream
       ws.capB = static_cast<uint32_t>(((2 * mean + 64) / kCompactLineRecords + 2) | 1ull);
       bBytes = 128ull * ws.capB * numParts * streams;
@@ -467,6 +467,17 @@ void grouped_note_write(int device, const DimensionVector &v) {
   size_t rowBytes = 0;
   for (int w = 0; w < NUM_DIM_WIDTH; w++) rowBytes += static_cast<size_t>(v.NumDimsPerDimWidth[w]) * ((1u << (NUM_DIM_WIDTH - 1 - w)) + 1);
   if (v.DimValues && v.VectorCapacity > 0) grouped_note_write(device, v.DimValues, rowBytes * static_cast<size_t>(v.VectorCapacity));
+}
+
+namespace {
+std::atomic<int> g_recordStreamSlack{0};
+}
+int record_stream_slack() { return g_recordStreamSlack.load(std::memory_order_relaxed); }
+bool grow_record_stream_slack() {
+  int s = g_recordStreamSlack.load(std::memory_order_relaxed);
+  while (s < 2)
+    if (g_recordStreamSlack.compare_exchange_weak(s, s + 1)) return true;
+  return false;
 }
 
 bool hash_reduce_lds_supported(const AggSpec &a) {
@@ -871,6 +882,8 @@ int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, con
       imageMode = 0;
       continue;
     }
+    // a record stream overflowed (rows that arrive sorted fill the partitions of a workgroup's chunk unevenly): more room, again
+    if (res.overflow && lean && grow_record_stream_slack()) continue;
     break;
   }
   if (res.overflow) {

@@ -70,6 +70,12 @@ inline bool fused_plan_narrow(const FusedPlanD &p, int nd) {
 // plan whose generated kernels are not loaded yet, previous results not grouped ...).  Either way the caller runs the
 // unfused sequence.
 constexpr int kFusedUnavailable = -2;
+// Room of a scanning workgroup's private record stream of one partition: (2 << slack) x the mean + 64.  Batches whose rows
+// arrive SORTED (archive batches: a workgroup's contiguous chunk holds two or three time buckets, hence few distinct groups
+// and unevenly filled partitions) overflow the default (slack 0: twice the mean); the call that sees the overflow flag grows
+// the slack — it stays grown for the process — and runs again instead of leaving the fast path.
+int record_stream_slack();
+bool grow_record_stream_slack();  // false: already at its limit (8 x the mean)
 int fused_hash_reduce_run(int device, const FusedPlanD &plan, int batchRows, const DimensionVector &prevKeys,
                           const uint8_t *prevValues, int prevSize, const DimensionVector &outKeys, uint8_t *outValues,
                           const AggSpec &a, hipStream_t stream);

@@ -545,7 +545,7 @@ int fused_sort_reduce_run(int device, const FusedPlanD &plan, int nd, bool const
 
   // ---- workspace: [cursors A | flags][counts B][partition counts][region A][region B][staging]
   const int streams = rtc_scan_grid(batchRows);
-  const uint64_t mean = static_cast<uint64_t>(batchRows) / (static_cast<uint64_t>(numParts) * streams);
+  const uint64_t mean = (static_cast<uint64_t>(batchRows) / (static_cast<uint64_t>(numParts) * streams)) << record_stream_slack();
   const uint32_t capB = static_cast<uint32_t>(((2 * mean + 64 + 7) / 8 * 8) | 8ull);  // whole lines of 8; odd line count per stream
   const uint64_t capA = ((2ull * (static_cast<uint64_t>(prevSize) / numParts) + 1024) | 63ull) + 18;
   const size_t stageSlots = static_cast<size_t>(vw == 4 ? Table<4>::kSlots : Table<8>::kSlots);
@@ -647,6 +647,9 @@ int fused_sort_reduce_run(int device, const FusedPlanD &plan, int nd, bool const
   if (trace)
     fprintf(stderr, "fused_sort_reduce_run: batch %d prev %d partBits %d streams %d capA %llu capB %u vw %d const %d -> groups %u overflow %u emptykey %u\n",
             batchRows, prevSize, partBits, streams, static_cast<unsigned long long>(capA), capB, vw, constMeasure ? 1 : 0, w[0], w[1], w[2]);
+  // a record stream may have overflowed (sorted rows fill a chunk's partitions unevenly): more room — kept for the process — and again
+  if (w[1] && !w[2] && grow_record_stream_slack())
+    return fused_sort_reduce_run(device, plan, nd, constMeasure, constBits, batchRows, in, inValues, prevSize, out, outValues, a, stream);
   if (w[1] || w[2]) return -1;  // the outputs may be partly written: the caller runs the real Sort + Reduce over them
   return static_cast<int>(w[0]);
 }

@@ -17,6 +17,11 @@
 //   * fills[first byte]           a buffer defined as a repeated 4- / 8-byte pattern (constant measures, the hash vector
 //                                 of a query without dimensions);
 //   * (hash_reduce_lds.hip)       measure rows defined by a table image ("lazy values");
+//   * expansions[(device, stream)] run-length encoded (mode-3) columns of an archive batch, decoded ONCE per batch into a
+//                                 stream temporary laid out like a mode-2 column; the hot-shape machinery below (row-space
+//                                 filters, queued transforms, the fused scans) then reads the copy.  Every definition that
+//                                 reads a copy keeps it alive (`keep`); the per-batch cache dies at the stream's next
+//                                 InitIndexVector and whenever the source column is written or freed;
 //   * sorts[index vector]         Sort over rows whose transforms are still pending: the hash vector (a marker entry of
 //                                 `fills`) and the index vector (its `iotas` entry, marked `sorted`) are defined as "what
 //                                 Sort would leave"; Reduce consumes the definition with the pending transforms
@@ -101,6 +106,7 @@ struct PendingQueue {
   // include/ares_extensions.h): a late launch from outside the stream's own call order must
   // restore "the stream is idle" before anybody looks
   bool overWait = false;
+  std::vector<std::shared_ptr<StreamBuffer>> keep;  // decoded copies of run-length columns the jobs read
   // (limbo only) the queue was consumed by a fused Sort + Reduce: whoever launches it replays the whole sequence
   const uint32_t *sortIdx = nullptr;
 };
@@ -162,6 +168,7 @@ struct FilterJournal {
   bool valid;
   std::vector<FastOperands> filters;
   std::vector<uint32_t> colRows;
+  std::vector<std::shared_ptr<StreamBuffer>> keep;  // decoded copies of run-length columns the filters read
   int lastCount = -1;  // survivors of the last journalled filter (-1: not known), what the next one must be called with
 };
 
@@ -192,6 +199,15 @@ struct LazyFilter {
   uint32_t colRows;   // rows of the column
   uint8_t *pred;      // the predicate vector the host passed with the call
   int rowsBefore;     // length of the index vector before this filter (= the previous filter's count)
+  std::shared_ptr<StreamBuffer> keep;  // the decoded copy of a run-length column the filter reads (or null)
+};
+// A run-length encoded column decoded for the stream's current batch (expand_runs_kernel): what it was made from, and the copy
+struct RunExpansion {
+  const uint8_t *base;
+  uint32_t nullsOff, valuesOff, length, bitOff, step, startCount;
+  int rows;
+  std::shared_ptr<StreamBuffer> copy;
+  size_t valuesAt;  // byte offset of the values behind the validity bitmap
 };
 // What the next filter call of the stream is expected to be (the previous batch of the stream had the same filter on the
 // same column right behind this one): evaluated in the same pass, handed out without a kernel when the call arrives.
@@ -368,6 +384,7 @@ struct DeferState {
   std::map<uint32_t *, PendingIota> iotas;
   std::map<uint8_t *, PendingFill> fills;  // by first byte; ranges never overlap
   std::map<const uint32_t *, PendingSort> sorts;  // by index vector
+  std::map<std::pair<int, hipStream_t>, std::vector<RunExpansion>> expansions;  // decoded run-length columns of the stream's batch
   std::vector<ErrorCheck> errorChecks;
   std::vector<uint32_t *> errorSlots;  // recycled pinned words
   bool errorSeen = false;              // a check that was settled outside an entry point failed: the next poll reports it
@@ -604,6 +621,7 @@ void launch_queue(hipStream_t stream, PendingQueue &q, bool inOrder = false) {
   q.jobs.count = 0;
   q.reads.clear();
   q.writes.clear();
+  q.keep.clear();  // (released in stream order, behind the kernel that read them)
   if (syncAfter) t_syncAfterUnlock.push_back(stream);  // (DeferLock: after the mutex is released)
 }
 
@@ -1017,6 +1035,7 @@ static void begin_batch(int device, hipStream_t stream, const uint32_t *indexVec
       release = true;
     }
     t_state->compactions.erase(indexVector);  // the vector is redefined
+    t_state->expansions.erase({device, stream});  // (what still reads a decoded column keeps it alive itself)
     drop_sort(indexVector);                   // ... and so is whatever a lazily defined Sort meant it to hold
     {  // the stream's filters of the batch that just ended are what the new batch's are predicted from
       FilterHistory &h = t_state->filterHistory[{device, stream}];
@@ -1037,7 +1056,8 @@ static void begin_batch(int device, hipStream_t stream, const uint32_t *indexVec
 }
 
 // a fast filter has compacted `indexVector` (f == nullptr: something else has — forget the journal)
-static void journal_filter(int device, const uint32_t *indexVector, const FastOperands *f, uint32_t colRows, int rowsBefore) {
+static void journal_filter(int device, const uint32_t *indexVector, const FastOperands *f, uint32_t colRows, int rowsBefore,
+                           std::shared_ptr<StreamBuffer> keep = nullptr) {
   if (!fuse_available()) return;
   DeferLock lock(device);
   auto it = t_state->journals.find(indexVector);
@@ -1055,6 +1075,7 @@ static void journal_filter(int device, const uint32_t *indexVector, const FastOp
   copy.pad = 0;
   j.filters.push_back(copy);
   j.colRows.push_back(colRows);
+  if (keep) j.keep.push_back(std::move(keep));
 }
 
 void invalidate_filter_journal(int device, const uint32_t *indexVector) { journal_filter(device, indexVector, nullptr, 0, 0); }
@@ -1099,7 +1120,8 @@ static bool virtual_iota(int device, uint32_t *indexVector, int n, bool take) {
 }
 
 // Queues one fast-path transform; returns false when deferral is unavailable (the caller launches it).
-static bool defer_transform(int device, hipStream_t stream, const FastOperands &f, const SinkD &s, int n, uint32_t colRows) {
+static bool defer_transform(int device, hipStream_t stream, const FastOperands &f, const SinkD &s, int n, uint32_t colRows,
+                            std::shared_ptr<StreamBuffer> keep = nullptr) {
   if (!defer_available()) return false;
   DeferLock lock(device);
   // everything pending on OTHER streams of the device is unrelated; only this stream's queue matters
@@ -1126,7 +1148,129 @@ static bool defer_transform(int device, hipStream_t stream, const FastOperands &
   if (f.idx) q.reads.push_back(ri);
   q.writes.push_back(wv);
   if (s.nulls) q.writes.push_back(wn);
+  if (keep) q.keep.push_back(std::move(keep));
   return true;
+}
+
+// ---- run-length encoded columns (archive batches) -------------------------------------------------------------------------
+// rows [0, n) of a mode-3 column — [counts u32 x (runs + 1)][validity bit per run][value per run], row r lives in the run that
+// holds startCount + r (query/iterator.hpp:199-278; locate() of device_model.hpp) — written as [validity bit per row][value
+// per row].  A lane decodes 32 consecutive rows: one binary search, then a walk along the counts; one validity word.
+__global__ __launch_bounds__(kBlock) void expand_runs_kernel(const uint32_t *counts, int numRuns, const uint8_t *nulls, uint32_t bitOff,
+                                                             const uint8_t *values, int step, uint32_t startCount, int n, uint32_t *outNulls,
+                                                             uint8_t *outValues) {
+  // A wavefront decodes 2048 consecutive rows: lane l walks rows [32 l, 32 l + 32) of the tile (values into LDS, row r at word
+  // r + r / 32: the lanes' columns fall into different banks), then the tile leaves the CU as whole lines — lane l stores rows
+  // l, l + 64, ... (the first version stored each lane's 128 bytes where the lane walked: 64 scattered 4-byte stores per
+  // instruction, 0.90 ms per 64 Mi rows instead of 0.1).
+  __shared__ uint32_t sTile[kBlock / 64][2048 + 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t *tile = sTile[wave];
+  const int64_t tiles = (static_cast<int64_t>(n) + 2047) / 2048;
+  for (int64_t t = static_cast<int64_t>(blockIdx.x) * (kBlock / 64) + wave; t < tiles; t += static_cast<int64_t>(gridDim.x) * (kBlock / 64)) {
+    const int64_t w = t * 64 + lane;  // this lane's validity word = its 32 rows
+    const int64_t r0 = w * 32;
+    uint32_t okWord = 0;
+    if (r0 < n) {
+      const uint32_t x0 = startCount + static_cast<uint32_t>(r0);
+      uint32_t first = 0, last = static_cast<uint32_t>(numRuns);
+      while (first < last) {
+        const uint32_t mid = first + ((last - first) >> 1);
+        if (counts[mid] > x0) last = mid; else first = mid + 1;
+      }
+      uint32_t run = first ? first - 1 : 0u, next = run + 1 < static_cast<uint32_t>(numRuns) ? counts[run + 1] : 0xFFFFFFFFu;
+      uint32_t v = step == 4 ? reinterpret_cast<const uint32_t *>(values)[run] : step == 2 ? reinterpret_cast<const uint16_t *>(values)[run] : values[run];
+      uint32_t ok = nulls ? get_bit(nulls, run + bitOff) : 1u;
+      for (int j = 0; j < 32; j++) {
+        const uint32_t x = x0 + static_cast<uint32_t>(j);
+        if (x >= next) {
+          while (run + 1 < static_cast<uint32_t>(numRuns) && counts[run + 1] <= x) run++;
+          next = run + 1 < static_cast<uint32_t>(numRuns) ? counts[run + 1] : 0xFFFFFFFFu;
+          v = step == 4 ? reinterpret_cast<const uint32_t *>(values)[run] : step == 2 ? reinterpret_cast<const uint16_t *>(values)[run] : values[run];
+          ok = nulls ? get_bit(nulls, run + bitOff) : 1u;
+        }
+        okWord |= ok << j;
+        tile[33 * lane + j] = v;
+      }
+      if (r0 + 32 > n) okWord &= (1u << static_cast<uint32_t>(n - r0)) - 1u;  // (rows past the end: no bits)
+      outNulls[w] = okWord;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int64_t base = t * 2048;
+#pragma unroll 4
+    for (int k = 0; k < 32; k++) {
+      const int rr = k * 64 + lane;
+      const int64_t r = base + rr;
+      if (r < n) {
+        const uint32_t v = tile[rr + (rr >> 5)];
+        if (step == 4) reinterpret_cast<uint32_t *>(outValues)[r] = v;
+        else if (step == 2) reinterpret_cast<uint16_t *>(outValues)[r] = static_cast<uint16_t>(v);
+        else outValues[r] = static_cast<uint8_t>(v);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// A call's first operand is a run-length encoded column of a 32-bit kind and rows are raw rows (no base counts): the operand
+// is re-bound to the column's decoded copy for the stream's batch — made now, on the call's stream, or found in the batch's
+// cache.  Returns the copy (to be kept alive by whatever is defined over it), or null when the operand stays as it is.
+// The copy is a SNAPSHOT: definitions made over it (journalled filters, queued transforms) see the column as it was when
+// their call came, whatever the host writes into the column afterwards — like the call's own kernel would have.
+static std::shared_ptr<StreamBuffer> decode_run_length_operand(int device, hipStream_t stream, OperandD &a, const uint32_t *indexVector,
+                                                              const uint32_t *baseCounts, uint32_t startCount) {
+  static EnvSwitch<bool> on("ARES_EXPAND_RLE", [](const char *e) { return !(e && e[0] == '0'); });
+  if (a.type != OP_COLUMN || a.mode != 3 || baseCounts != nullptr || indexVector == nullptr || !on.get() || !fuse_available()) return nullptr;
+  if (!(a.kind == K_I32 || a.kind == K_U32 || a.kind == K_F32) || a.length == 0) return nullptr;
+  DeferLock lock(device);
+  auto j = t_state->journals.find(indexVector);  // the batch's rows: what InitIndexVector was called with
+  if (j == t_state->journals.end() || j->second.device != device || j->second.stream != stream || j->second.start != 0 || j->second.n0 <= 0)
+    return nullptr;
+  const int rows = j->second.n0;
+  std::vector<RunExpansion> &cache = t_state->expansions[{device, stream}];
+  const RunExpansion *hit = nullptr;
+  for (const RunExpansion &e : cache)
+    if (e.base == a.base && e.nullsOff == a.nullsOff && e.valuesOff == a.valuesOff && e.length == a.length && e.bitOff == a.bitOff &&
+        e.step == a.step && e.startCount == startCount && e.rows == rows)
+      hit = &e;
+  RunExpansion fresh;
+  if (!hit) {
+    const size_t nullBytes = ((static_cast<size_t>(rows) + 31) / 32 * 4 + 63) / 64 * 64;
+    fresh = RunExpansion{a.base, a.nullsOff, a.valuesOff, a.length, a.bitOff, a.step, startCount, rows,
+                         std::make_shared<StreamBuffer>(nullBytes + static_cast<size_t>(a.step) * rows + 64, stream), nullBytes};
+    uint8_t *out = fresh.copy->as<uint8_t>();
+    const int64_t tiles = (static_cast<int64_t>(rows) + 2047) / 2048;
+    ARES_LAUNCH("expand_runs_kernel", expand_runs_kernel, capped_grid((tiles + kBlock / 64 - 1) / (kBlock / 64), 256 * 8), kBlock, stream,
+                reinterpret_cast<const uint32_t *>(a.base), static_cast<int>(a.length), a.base + a.nullsOff, static_cast<uint32_t>(a.bitOff),
+                a.base + a.valuesOff, static_cast<int>(a.step), startCount, rows, reinterpret_cast<uint32_t *>(out), out + nullBytes);
+    cache.push_back(fresh);
+    hit = &cache.back();
+  }
+  a.base = hit->copy->as<uint8_t>();
+  a.mode = 2;
+  a.nullsOff = 0;
+  a.valuesOff = static_cast<uint32_t>(hit->valuesAt);
+  a.bitOff = 0;
+  a.length = static_cast<uint32_t>(rows);
+  return hit->copy;
+}
+
+// the host writes into (or frees) [r.lo, r.hi): decoded copies of run-length columns that lie in there are no longer what a
+// NEW call would read.  Caller holds the device's DeferLock.
+static void forget_run_expansions(int device, const ByteRange &r) {
+  for (auto &kv : t_state->expansions) {
+    if (kv.first.first != device) continue;
+    auto &v = kv.second;
+    for (size_t i = 0; i < v.size();) {
+      const ByteRange src{v[i].base, v[i].base + v[i].valuesOff + static_cast<size_t>(v[i].step) * v[i].length};
+      if (src.overlaps(r)) {
+        v[i] = v.back();
+        v.pop_back();
+      } else {
+        i++;
+      }
+    }
+  }
 }
 
 static bool fast_sink(const SinkD &s) {
@@ -1279,6 +1423,8 @@ static int run_transform(const InputVector *ins, int arity, const OutputVector &
   SinkD s;
   CallTemps temps;
   build_params(ins, arity, stream, indexVector, baseCounts, startCount, functor, p, temps);
+  // (archive batches: a run-length encoded column is read through its decoded copy — every fast path below applies)
+  const std::shared_ptr<StreamBuffer> decoded = decode_run_length_operand(device, stream, p.a, indexVector, baseCounts, startCount);
   bind_sink(output, baseCounts, s);
   if (s.type == SINK_MEASURE && s.baseCounts && indexVector) p.needRow = 1;
   if (s.type == SINK_DIM || s.type == SINK_MEASURE) {  // rows of a result vector are (about to be) rewritten
@@ -1300,7 +1446,7 @@ static int run_transform(const InputVector *ins, int arity, const OutputVector &
   if (fast && s.type == SINK_DIM && s.width < 4 && !(f.rk == K_I32 || f.rk == K_U32)) fast = false;  // float -> narrow integer: generic kernel
   if (fast && f.idx && virtual_iota(device, indexVector, n, false)) f.idx = nullptr;  // rows = position
   // root outputs of the hot shape are held back and fused with their siblings (same index vector)
-  if (fast && (s.type == SINK_DIM || s.type == SINK_MEASURE) && defer_transform(device, stream, f, s, n, p.a.length)) return n;
+  if (fast && (s.type == SINK_DIM || s.type == SINK_MEASURE) && defer_transform(device, stream, f, s, n, p.a.length, decoded)) return n;
   flush_deferred(device);
   materialize_index_vector(device, indexVector);
   note_sink(device, s, n);
@@ -1544,7 +1690,7 @@ bool row_space_eligible(int device, hipStream_t stream, const uint32_t *indexVec
 
 // The call itself.  f: the filter (idx and pad are ignored: rows = positions).  Returns the survivor count.
 int run_filter_rows(int device, hipStream_t stream, FastOperands f, uint32_t *indexVector, uint8_t *pred, int n, uint32_t colRows,
-                    bool virtualIdx) {
+                    bool virtualIdx, const std::shared_ptr<StreamBuffer> &keep = nullptr) {
   f.idx = nullptr;
   f.pad = 0;
   // streaming (non-temporal) column loads: the column is read once by this kernel — 0.060 -> 0.054 ms per 64 Mi rows
@@ -1591,7 +1737,7 @@ int run_filter_rows(int device, hipStream_t stream, FastOperands f, uint32_t *in
     h.current.push_back(shape);
     if (c.predicted.valid && same_filter(c.predicted.g, f)) {  // counted together with the previous filter: no kernel
       const int count = c.predicted.count;
-      c.todo.push_back(LazyFilter{f, colRows, pred, n});
+      c.todo.push_back(LazyFilter{f, colRows, pred, n, keep});
       c.bits = c.predicted.bits;
       c.lastCount = count;
       c.predicted = PredictedFilter{};
@@ -1643,7 +1789,7 @@ int run_filter_rows(int device, hipStream_t stream, FastOperands f, uint32_t *in
                 two ? bits2->as<uint16_t>() : static_cast<uint16_t *>(nullptr), c.n0, tiles, hostPartials);
     // booked before the count is known: a flush from another thread that applies the pending filters meanwhile
     // applies this one too
-    c.todo.push_back(LazyFilter{f, colRows, pred, n});
+    c.todo.push_back(LazyFilter{f, colRows, pred, n, keep});
     c.bits = bits1;
     c.lastCount = -1;
     generation = ++t_state->filterGeneration;
@@ -1687,12 +1833,14 @@ static int run_filter(const InputVector *ins, int arity, uint32_t *indexVector, 
   CallTemps temps;
   const bool isArray = ins[0].Type == ArrayVectorPartyInput;
   ArrayD arr;
+  std::shared_ptr<StreamBuffer> decoded;  // the decoded copy of a run-length encoded column (archive batches), or null
   if (isArray) {
     bind_array(ins, arity, functor, Bool, arr);
     memset(&p, 0, sizeof(p));
     p.a.kind = K_UUID;  // routed like a wide operand: predicate first, then compaction by predicate
   } else {
     build_params(ins, arity, stream, indexVector, baseCounts, startCount, functor, p, temps);
+    decoded = decode_run_length_operand(device, stream, p.a, indexVector, baseCounts, startCount);
   }
   p.needRow = 1;
   static const bool onePass = [] {
@@ -1731,11 +1879,11 @@ static int run_filter(const InputVector *ins, int arity, uint32_t *indexVector, 
   FastOperands f;
   const bool fast = !is_wide(p.a.kind) && indexVector != nullptr && fast_operands(p, f, true);
   if (fast && !onePass && numForeignTables == 0 && baseCounts == nullptr)
-    journal_filter(device, indexVector, &f, p.a.length, n);
+    journal_filter(device, indexVector, &f, p.a.length, n, decoded);
   else
     journal_filter(device, indexVector, nullptr, 0, 0);
   if (rowSpace && fast && journal_is_valid(device, indexVector)) {
-    const int counted = run_filter_rows(device, stream, f, indexVector, pred, n, p.a.length, virtualIdx);
+    const int counted = run_filter_rows(device, stream, f, indexVector, pred, n, p.a.length, virtualIdx, decoded);
     if (counted >= 0) return counted;
     // (-1: somebody's flush applied the vector's pending filters since the eligibility check: the ordinary filter below)
   }
@@ -1984,6 +2132,7 @@ uintptr_t hook_on_free(int device, void *ptr, size_t bytes) {
       it = (it->second.device == device && v.overlaps(r)) ? t_state->iotas.erase(it) : std::next(it);
     }
     retire_fills(device, r, true);  // lazy fills of the block die unwritten
+    forget_run_expansions(device, r);
     for (auto it = t_state->journals.begin(); it != t_state->journals.end();) {
       // a journal dies with its index vector or with a column its filters read — unless a queue the
       // host has already waited for still refers to it (then the block is held below, contents intact)
@@ -2086,6 +2235,7 @@ void hook_on_access(int device, const void *ptr, size_t bytes) {
         launch_queue(kv.first.second, kv.second);
       }
     }
+    forget_run_expansions(device, r);  // (a copy INTO a run-length column: later calls decode it again)
     materialize_fills(device, &r, &t_syncAfterUnlock);  // (the copy may run on another stream: wait for the fill)
     materialize_limbo(device, &r, &released);
     for (auto it = t_state->compactions.begin(); it != t_state->compactions.end();) {
@@ -2138,6 +2288,7 @@ void hook_on_stream_destroy(int device, void *streamPtr) {
         }
       }
       t_state->pending.erase({device, stream});
+      t_state->expansions.erase({device, stream});
       auto lim = t_state->limbo.find({device, stream});
       if (lim != t_state->limbo.end()) {
         if (lim->second.idx) t_state->compactions.erase(lim->second.idx);
@@ -2331,7 +2482,11 @@ bool fuse_pending_into_hash_reduce(int device, hipStream_t stream, const Dimensi
     pq.reads.clear();
     pq.writes.clear();
     pq.overWait = false;
-    if (q.idx) t_state->journals.erase(q.idx);
+    if (q.idx) {  // (decoded columns only the filters read live as long as the consumed queue does: the scan is launched below)
+      auto jk = t_state->journals.find(q.idx);
+      if (jk != t_state->journals.end()) q.keep.insert(q.keep.end(), jk->second.keep.begin(), jk->second.keep.end());
+      t_state->journals.erase(q.idx);
+    }
   }
   DimensionVector prevKeys = in;
   const int result = fused_hash_reduce_run(device, plan, n0, prevKeys, inValues, prev, out, outValues, a, stream);
@@ -2566,7 +2721,11 @@ bool fuse_pending_into_sort_reduce(int device, hipStream_t stream, const Dimensi
     pq.reads.clear();
     pq.writes.clear();
     pq.overWait = false;
-    if (q.idx) t_state->journals.erase(q.idx);
+    if (q.idx) {  // (decoded columns only the filters read live as long as the consumed queue does: the scan is launched below)
+      auto jk = t_state->journals.find(q.idx);
+      if (jk != t_state->journals.end()) q.keep.insert(q.keep.end(), jk->second.keep.begin(), jk->second.keep.end());
+      t_state->journals.erase(q.idx);
+    }
     if (constMeasure) t_state->fills.erase(fillAt);
     drop_sort(in.IndexVector);  // (while the kernels run nothing is defined; the reduced state is entered below)
   }

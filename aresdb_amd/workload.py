@@ -75,6 +75,55 @@ def _pack_column(values: torch.Tensor, valid: Optional[torch.Tensor], data_type:
     return ResidentColumn(blob, off, data_type, n, True)
 
 
+@dataclass
+class RunLengthColumn(ResidentColumn):
+    """A sort column of an ARCHIVE batch, resident in HBM as the Go host uploads it (query/aql_processor.go:1415-1429, mode 3 of
+    query/iterator.hpp:117-126): [counts u32 x (runs + 1)][validity bit per run][value per run].  `length` stays the batch's
+    ROW count (what the verification and the drivers size the batch by); the per-row values and validity are kept beside the
+    encoded blob for the independent group-by of aresdb_amd/check.py only — the libraries get the encoded column."""
+    runs: int = 0
+    nulls_off: int = 0
+    row_values: Optional[torch.Tensor] = None
+    row_valid: Optional[torch.Tensor] = None
+
+    @property
+    def vp(self) -> abi.VectorPartySlice:
+        vp = abi.VectorPartySlice()
+        vp.BasePtr, vp.NullsOffset, vp.ValuesOffset = self.blob.data_ptr(), self.nulls_off, self.values_off
+        vp.DataType, vp.Length, vp.StartingIndex = self.data_type, self.runs, 0
+        return vp
+
+    def values(self, np_dtype=None) -> torch.Tensor:
+        return self.row_values
+
+    def valid(self) -> Optional[torch.Tensor]:
+        return self.row_valid
+
+
+def _pack_run_length(values: torch.Tensor, valid: Optional[torch.Tensor], data_type: int) -> RunLengthColumn:
+    n = values.numel()
+    ok = torch.ones(n, dtype=torch.bool, device=values.device) if valid is None else valid
+    head = torch.ones(n, dtype=torch.bool, device=values.device)
+    head[1:] = (values[1:] != values[:-1]) | (ok[1:] != ok[:-1])
+    starts = torch.nonzero(head).reshape(-1).to(torch.int32)
+    runs = starts.numel()
+    counts = torch.cat([starts, torch.tensor([n], dtype=torch.int32, device=values.device)])
+    run_ok = ok[starts.long()].to(torch.uint8)
+    nb = (runs + 7) // 8
+    pad = nb * 8 - runs
+    if pad:
+        run_ok = torch.cat([run_ok, torch.zeros(pad, dtype=torch.uint8, device=values.device)])
+    weights = (1 << torch.arange(8, device=values.device, dtype=torch.int32)).to(torch.uint8)
+    bitmap = (run_ok.view(nb, 8) * weights).sum(dim=1, dtype=torch.int32).to(torch.uint8)
+    nulls_off = _align64(4 * (runs + 1))
+    values_off = nulls_off + _align64(nb)
+    blob = torch.zeros(values_off + _align64(4 * runs), dtype=torch.uint8, device=values.device)
+    blob[:4 * (runs + 1)] = counts.view(torch.uint8)
+    blob[nulls_off:nulls_off + nb] = bitmap
+    blob[values_off:values_off + 4 * runs] = values[starts.long()].contiguous().view(torch.uint8)
+    return RunLengthColumn(blob, values_off, data_type, n, True, runs, nulls_off, values, valid)
+
+
 def _zipf_cdf(alpha, k, device):
     w = 1.0 / torch.arange(1, k + 1, dtype=torch.float64, device=device) ** alpha
     return (torch.cumsum(w, 0) / w.sum()).to(torch.float32)
@@ -103,14 +152,40 @@ def c3_batch(n, gen: torch.Generator, device, null_fraction=0.01) -> Dict[str, R
     return out
 
 
-def c3_shard(rows, batch_rows, seed, device, null_fraction=0.01) -> List[Dict[str, ResidentColumn]]:
+def c3_archive_batch(n, gen: torch.Generator, device, null_fraction=0.01) -> Dict[str, ResidentColumn]:
+    """The same batch as an ARCHIVE batch: rows sorted by (ts, d3) — the table's archiving sort order — with both sort
+    columns run-length encoded (mode 3); nulls of a sort column sort first and form runs of their own.  The other columns
+    stay as they are (mode 2).  Column order: an uncompressed column first (the batch's rows are its rows: firstColumn of
+    query/aql_processor.go:571-625 carries no count vector)."""
+    plain = c3_batch(n, gen, device, null_fraction)
+    def col(name):
+        rc = plain[name]
+        return rc.values().clone(), (None if rc.valid() is None else rc.valid().clone())
+    ts, tsv = col("ts")
+    d3, d3v = col("d3")
+    key = ts.to(torch.int64) * 8 + d3.to(torch.int64) * 2
+    if tsv is not None:
+        key = torch.where(tsv, key + (1 << 40), key)   # null ts first
+    if d3v is not None:
+        key = key + d3v.to(torch.int64)                # null d3 first inside a ts run
+    order = torch.argsort(key, stable=True)
+    out = {}
+    for name, dt in (("d1", abi.Uint32), ("d2", abi.Uint32), ("m", abi.Float32), ("ts", abi.Uint32), ("d3", abi.Uint32)):
+        v, ok = col(name)
+        v = v[order].contiguous()
+        ok = None if ok is None else ok[order].contiguous()
+        out[name] = _pack_run_length(v, ok, dt) if name in ("ts", "d3") else _pack_column(v, ok, dt)
+    return out
+
+
+def c3_shard(rows, batch_rows, seed, device, null_fraction=0.01, archive=False) -> List[Dict[str, ResidentColumn]]:
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
     batches = []
     done = 0
     while done < rows:
         n = min(batch_rows, rows - done)
-        batches.append(c3_batch(n, gen, device, null_fraction))
+        batches.append((c3_archive_batch if archive else c3_batch)(n, gen, device, null_fraction))
         done += n
     return batches
 

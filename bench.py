@@ -463,6 +463,9 @@ def main(argv=None, backend=None, tensor_device=None):
                          "enable_hash_reduction: false): count = COUNT(*), sum = SUM(d2) as AGGR_SUM_UNSIGNED into 8 bytes (secondary legs)")
     ap.add_argument("--eight-dims", action="store_true",
                     help="MAX_DIMENSIONS: four more dimensions (functions of the first four: the same groups) — the fused path at the ABI's limit (secondary leg)")
+    ap.add_argument("--archive", action="store_true",
+                    help="archive batches: rows sorted by (ts, d3), both run-length encoded (mode 3) — decoded once per batch inside the "
+                         "ABI, everything else on the same fast path (secondary leg)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc passes that measure roofline.traffic")
     ap.add_argument("--single-process", action="store_true",
                     help="N shards on N GPUs as N threads of THIS process (the reference's process model, "
@@ -535,7 +538,7 @@ def main(argv=None, backend=None, tensor_device=None):
     streams = [be.call("CreateCudaStream", device_index) for _ in range(n_streams)]
 
     rows, batch_rows = int(args.rows), int(args.batch_rows)
-    batches = workload.c3_shard(rows, batch_rows, seed=1 + rank, device=tdev, null_fraction=args.null_fraction)
+    batches = workload.c3_shard(rows, batch_rows, seed=1 + rank, device=tdev, null_fraction=args.null_fraction, archive=args.archive)
     vps = [({k: rc.vp for k, rc in b.items()}, next(iter(b.values())).length) for b in batches]
     dims = tuple(d for d in args.dims.split(",") if d)
     assert dims and all(d in check.ALL_DIMS for d in dims), args.dims
@@ -841,6 +844,8 @@ def main(argv=None, backend=None, tensor_device=None):
             leg("c3_sort_path_sum_unsigned", {}, big + ["--sort-path", "sum"])
             # the ABI's limit of dimensions (MAX_DIMENSIONS = 8) on the fused path: generated kernels only
             leg("c3_eight_dimensions", {}, big + ["--eight-dims"])
+            # archive batches (mode-3 run-length sort columns ts and d3): decoded once per batch, then the headline's path
+            leg("archive_batches_rle_ts_d3", {}, big + ["--archive", "--ts-range", "3600,601200"])
             leg(f"live_batches_{LIVE_BATCH_ROWS}_rows", {}, common + ["--batch-rows", str(LIVE_BATCH_ROWS)])
             # lower-cardinality variants of the same query (same filter and measure; fewer group-by dimensions)
             # the reference's own example table and queries at 1 B rows (examples/1k_trips: request_at Uint32, city_id Uint16 in

@@ -53,6 +53,18 @@ def make_batch(rng, shape, n, null_fraction=0.03):
     return cols
 
 
+def _column(b, dtype, vals, valid, rle=False):
+    """A batch column on backend b: plain (mode 1 / 2) or — rle — run-length encoded (mode 3: counts, one validity bit and one
+    value per run; query/iterator.hpp:117-126), the way an archive batch stores a sorted column."""
+    if not rle:
+        return H.Column(b, dtype, vals, valid=valid)
+    ok = np.ones(len(vals), bool) if valid is None else valid
+    cut = np.flatnonzero((vals[1:] != vals[:-1]) | (ok[1:] != ok[:-1])) + 1
+    starts = np.concatenate([[0], cut])
+    counts = np.concatenate([starts, [len(vals)]]).astype(np.uint32)
+    return H.Column(b, dtype, vals[starts], valid=ok[starts], counts=counts)
+
+
 SHAPES = [
     # C3's dimensions, COUNT(*) — the shape of the reference's first example query (examples/1k_trips/queries/total_trips.aql)
     Shape("count_c3", {"ts": (abi.Uint32, 86400 * 7), "d1": (abi.Uint32, 100), "d2": (abi.Uint32, 50), "d3": (abi.Uint32, 2)},
@@ -97,7 +109,7 @@ def run_sequence(b, shape, batches, read=frozenset(), cap_slack=10, hash_reduce=
 
     for bt in batches:
         n = len(next(iter(bt.values()))[1])
-        cols = {k: H.Column(b, t, v, valid=ok) for k, (t, v, ok) in bt.items()}
+        cols = {k: _column(b, *spec) for k, spec in bt.items()}
         idx, pred = H.Buf(b, nbytes=4 * n), H.Buf(b, nbytes=n)
         b.call("InitIndexVector", idx.ptr, 0, n, None, 0)
         kept = n
@@ -204,6 +216,49 @@ def test_lazily_defined_sort_materialises_for_a_host_that_looks(shape, read):
     got = run_sequence(hip, shape, batches, read=frozenset(read))
     want = run_sequence(oracle, shape, batches, read=frozenset(read))
     assert_same(got, want, (shape.name, read))
+
+
+def make_archive_batch(rng, n):
+    """An archive batch sorted by (ts, d3): both run-length encoded (ts in runs of ~40 rows, nulls in runs too), the other
+    columns plain."""
+    ts = np.sort(rng.integers(0, 86400 * 2, max(1, n // 40)).astype(np.uint32))[rng.integers(0, max(1, n // 40), n)]
+    ts.sort()
+    d3 = ((np.arange(n) // 23) % 3).astype(np.uint32)
+    ok_ts = np.repeat(rng.random((n + 99) // 100) >= 0.04, 100)[:n]
+    ok_d3 = np.repeat(rng.random((n + 22) // 23) >= 0.03, 23)[:n]
+    ts = np.where(ok_ts, ts, 0).astype(np.uint32)
+    plain = lambda hi: (rng.integers(0, hi, n).astype(np.uint32), rng.random(n) >= 0.03)
+    d1, o1 = plain(100)
+    d2, o2 = plain(50)
+    m, om = plain(1000)
+    return {"ts": (abi.Uint32, ts, ok_ts, True), "d3": (abi.Uint32, d3, ok_d3, True), "d1": (abi.Uint32, d1, o1), "d2": (abi.Uint32, d2, o2),
+            "m": (abi.Uint32, m, om)}
+
+
+_ARCHIVE_FILTERS = [("ts", abi.GreaterThanOrEqual, 3600), ("ts", abi.LessThan, 150000), ("d1", abi.LessThan, 90)]
+_ARCHIVE_DIMS = [("ts", abi.Floor, 3600, abi.Uint32), ("d1", None, 0, abi.Uint32), ("d2", None, 0, abi.Uint32), ("d3", None, 0, abi.Uint32)]
+ARCHIVE_SUM = Shape("archive_sum", {}, _ARCHIVE_FILTERS, _ARCHIVE_DIMS, "m", abi.AGGR_SUM_UNSIGNED, abi.Uint32, (0, 0, 4, 0, 0))
+ARCHIVE_COUNT = Shape("archive_count", {}, _ARCHIVE_FILTERS, _ARCHIVE_DIMS, None, abi.AGGR_SUM_UNSIGNED, abi.Uint32, (0, 0, 4, 0, 0))
+
+
+@pytest.mark.parametrize("hash_reduce", [True, False], ids=["hash_reduce", "sort_reduce"])
+def test_archive_batches_decode_run_length_columns_once_and_stay_on_the_fast_path(hash_reduce):
+    """Archive batches (query/aql_processor.go:571-625): the sort columns arrive run-length encoded (mode 3).  The time
+    filters and a dimension read ts, another dimension reads d3: each is decoded ONCE per batch into a stream temporary
+    (expand_runs_kernel) and the row-space filters, the queued transforms and the fused scan read the copy — nothing is
+    materialised, the result is the oracle's (ordered, on the Sort + Reduce path)."""
+    hip, oracle = H.hip_backend(), H.oracle_backend()
+    rng = np.random.default_rng(71)
+    batches = [make_archive_batch(rng, n) for n in (30000, 45000, 1200)]
+    shape = ARCHIVE_SUM if hash_reduce else ARCHIVE_COUNT
+    want = run_sequence(oracle, shape, batches, hash_reduce=hash_reduce)
+    for attempt in range(2):
+        got, kernels = _kernels_of(hip, lambda: run_sequence(hip, shape, batches, hash_reduce=hash_reduce))
+        assert_same(got, want, shape.name)
+    if _fusion_on():
+        assert kernels["expand_runs_kernel"][0] == 2 * len(batches), kernels.get("expand_runs_kernel")  # ts and d3, once per batch
+        assert any(k.startswith(("hr_scan_rtc", "hr_table_scan_rtc", "sr_scan_rtc", "hr_fused_scan")) for k in kernels), sorted(kernels)
+        assert not any(k.startswith(("transform", "filter_pred", "filter_kernel", "radix_pass")) for k in kernels), sorted(kernels)
 
 
 # MAX_DIMENSIONS = 8 (query/time_series_aggregate.h:36-37): six 4-byte slots, a 2-byte and a 1-byte one, in vector order

@@ -21,6 +21,7 @@
 #include "hash_reduce_lds.hpp"
 #include "hr_kernels.hpp"
 #include "hr_rtc.hpp"
+#include "sort_reduce_fused.hpp"
 
 namespace ares {
 
@@ -409,6 +410,7 @@ MergeResult read_result_pinned(hipStream_t stream) {
 }  // namespace
 
 void grouped_note_write(int device, const void *ptr, size_t bytes) {
+  sorted_state_note_write(device, ptr, bytes);  // (sort_reduce_fused.hip: the row hashes kept beside a Sort + Reduce result)
   const uint8_t *lo = static_cast<const uint8_t *>(ptr);
   const uint8_t *hi = lo + (bytes ? bytes : 1);
   std::lock_guard<std::mutex> lock(g_groupedMutex);

@@ -30,6 +30,7 @@
 #include <hip/hip_runtime.h>
 
 #include <memory>
+#include <mutex>
 #include <vector>
 
 #include "aggregate.hpp"
@@ -91,6 +92,11 @@ struct SrArgs {
   // emission
   uint8_t *dimOut;
   uint8_t *outValues;
+  // the groups' keys: stageKeys [partition][Table::kSlots] in the merge's order; keysOut [group] as emitted (what the next
+  // call of the query reads as prevKeys: the previous result's row hashes, ascending — null: not known, sr_prev_kernel)
+  uint64_t *stageKeys;
+  uint64_t *keysOut;
+  const uint64_t *prevKeys;
   uint64_t *phases;  // ARES_HR_PHASES=1 (diagnostics): six time stamps per partition (100 MHz clock), else null
 };
 
@@ -242,7 +248,25 @@ __global__ __launch_bounds__(kThreads) void sr_merge_kernel(SrArgs m) {
     if (slot >= 0) settle(slot, row, value);
   };
 
-  // ---- previous groups (region A): the value is read from the previous result's measure vector
+  // ---- previous groups.  Their row hashes are known (the query's previous Reduce left them, ascending, beside its result):
+  // the partition's rows are the range of hashes that start with its bits — two binary searches, no hashing, no region A
+  if (m.prevKeys) {
+    auto lower = [&](uint64_t bound) {
+      uint32_t lo = 0, hi = m.prevSize;
+      while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (m.prevKeys[mid] < bound) lo = mid + 1; else hi = mid;
+      }
+      return lo;
+    };
+    const uint32_t from = pb ? lower(static_cast<uint64_t>(p) << (64 - pb)) : 0u;
+    const uint32_t to = (pb && p + 1 < numParts) ? lower(static_cast<uint64_t>(p + 1) << (64 - pb)) : m.prevSize;
+    for (uint32_t i = from + tid; i < to; i += kThreads) {
+      const uint64_t key = m.prevKeys[i];
+      insert(i, static_cast<uint32_t>(key >> 32), static_cast<uint32_t>(key), load_value_bits(m.inValues, a, i));
+    }
+  } else
+  // ---- ... or not (region A, written by sr_prev_kernel): the value is read from the previous result's measure vector
   {
     const uint32_t cursor = m.cursorsA[p];
     const uint32_t nA = cursor < m.capA ? cursor : static_cast<uint32_t>(m.capA);
@@ -438,6 +462,7 @@ __global__ __launch_bounds__(kThreads) void sr_merge_kernel(SrArgs m) {
     const uint32_t rank = before + seen - static_cast<uint32_t>(s - (b + 1)) + smaller;
     const uint64_t v = static_cast<uint64_t>(sVals[s]);
     stage[rank] = make_uint4(sRows[s], static_cast<uint32_t>(v), static_cast<uint32_t>(v >> 32), 0u);
+    m.stageKeys[static_cast<uint64_t>(p) * T::kSlots + rank] = key;
     seen++;
   }
   if (tid == kThreads - 1) m.partCount[p] = before + mine;
@@ -485,6 +510,7 @@ __global__ __launch_bounds__(kThreads) void sr_emit_kernel(SrArgs m, FusedPlanD 
   for (uint32_t i = tid; i < count; i += kThreads) {
     const uint4 e = stage[i];
     const uint32_t at = base + i;
+    m.keysOut[at] = m.stageKeys[static_cast<uint64_t>(p) * T::kSlots + i];
     if (e.x < m.prevSize) {
       copy_dim_row(m.dimIn, cap, m.dimOut, cap, L, e.x, at);
     } else {
@@ -504,6 +530,68 @@ __global__ __launch_bounds__(kThreads) void sr_emit_kernel(SrArgs m, FusedPlanD 
   }
 }
 
+// ---- the row hashes of a result, kept beside it ---------------------------------------------------------------------------
+// A fused Sort + Reduce leaves, in a block of its own, the 64-bit row hash of every group it emitted — ascending, like the
+// groups.  When the host feeds those vectors back as the first rows of the query's next Reduce (query/aql_processor.go:718-724),
+// the merge reads each partition's previous groups as a RANGE of that array: sr_prev_kernel (hashing 2.3 M rows and scattering
+// them into region A: 0.085 ms per batch) is not run.  The array is trusted only while nothing has written to the vectors
+// (every writer of a result vector reports to grouped_note_write, which calls sorted_state_note_write) — the contract the
+// partition-grouped ranges and table images of HashReduce live by.  ARES_SORT_STATE=0: off.
+struct SortedState {
+  int device;
+  const uint8_t *dims;
+  const uint8_t *values;
+  size_t capacity;
+  uint8_t ndw[NUM_DIM_WIDTH];
+  int valueBytes, size;
+  std::shared_ptr<uint64_t> keys;  // (a caller that looked the state up keeps the block alive while its kernels read it)
+};
+std::mutex g_sortedMutex;
+std::vector<SortedState> g_sorted;
+
+bool sorted_state_enabled() {
+  static EnvSwitch<bool> on("ARES_SORT_STATE", [](const char *e) { return !(e && e[0] == '0'); });
+  return on.get() && deferral_hooks_active();
+}
+
+// a block of the temporaries' cache that outlives the call: released as idle memory (its last user has been waited for)
+std::shared_ptr<uint64_t> take_key_block(int device, size_t groups, hipStream_t stream) {
+  void *p = stream_alloc(sizeof(uint64_t) * (groups ? groups : 1), stream);
+  return std::shared_ptr<uint64_t>(static_cast<uint64_t *>(p), [device](uint64_t *q) {
+    int current = 0;
+    const bool have = hipGetDevice(&current) == hipSuccess;
+    if (have && current != device) (void)hipSetDevice(device);
+    stream_release_idle(q);
+    if (have && current != device) (void)hipSetDevice(current);
+  });
+}
+
+size_t dim_row_bytes(const uint8_t ndw[NUM_DIM_WIDTH]) {
+  size_t rowBytes = 0;
+  for (int w = 0; w < NUM_DIM_WIDTH; w++) rowBytes += static_cast<size_t>(ndw[w]) * ((1u << (NUM_DIM_WIDTH - 1 - w)) + 1);
+  return rowBytes;
+}
+
+std::shared_ptr<uint64_t> sorted_state_lookup(int device, const DimensionVector &v, const uint8_t *values, int valueBytes, int size) {
+  if (!sorted_state_enabled() || size <= 0) return nullptr;
+  std::lock_guard<std::mutex> lock(g_sortedMutex);
+  for (const SortedState &st : g_sorted)
+    if (st.device == device && st.dims == v.DimValues && st.values == values && st.capacity == static_cast<size_t>(v.VectorCapacity) &&
+        memcmp(st.ndw, v.NumDimsPerDimWidth, sizeof(st.ndw)) == 0 && st.valueBytes == valueBytes && st.size == size)
+      return st.keys;
+  return nullptr;
+}
+
+void sorted_state_register(int device, const DimensionVector &v, const uint8_t *values, size_t capacity, int valueBytes, int size,
+                           std::shared_ptr<uint64_t> keys) {
+  if (!sorted_state_enabled() || size <= 0) return;
+  SortedState st{device, v.DimValues, values, capacity, {}, valueBytes, size, std::move(keys)};
+  memcpy(st.ndw, v.NumDimsPerDimWidth, sizeof(st.ndw));
+  std::lock_guard<std::mutex> lock(g_sortedMutex);
+  if (g_sorted.size() >= 64) g_sorted.erase(g_sorted.begin());  // (a host that never frees: forget the oldest)
+  g_sorted.push_back(std::move(st));
+}
+
 int sr_part_bits(int64_t length) {
   // ARES_MIN_PART_BITS (tests): small inputs take several partitions like production-sized ones
   static EnvSwitch<int> minBits("ARES_MIN_PART_BITS", [](const char *e) { return e ? atoi(e) : 0; });
@@ -513,6 +601,35 @@ int sr_part_bits(int64_t length) {
 }
 
 }  // namespace
+
+// something writes (or frees) [ptr, ptr + bytes): what is known about result vectors in there is void (hash_reduce_lds.hip:
+// grouped_note_write passes every report on)
+void sorted_state_note_write(int device, const void *ptr, size_t bytes) {
+  const uint8_t *lo = static_cast<const uint8_t *>(ptr), *hi = lo + (bytes ? bytes : 1);
+  std::lock_guard<std::mutex> lock(g_sortedMutex);
+  for (size_t i = 0; i < g_sorted.size();) {
+    const SortedState &st = g_sorted[i];
+    // the rows the state describes: [0, size) of every dimension's values and validity bytes, and of the measure vector (the
+    // next batch's transforms write rows BEHIND them into the same vectors)
+    auto hit = [&](const uint8_t *a, size_t n) { return a < hi && lo < a + n; };
+    bool touched = st.device == device && hit(st.values, static_cast<size_t>(st.valueBytes) * st.size);
+    if (st.device == device && !touched) {
+      size_t off = 0, valueBytes = 0;
+      int nd = 0;
+      for (int w = 0; w < NUM_DIM_WIDTH; w++) valueBytes += static_cast<size_t>(st.ndw[w]) << (NUM_DIM_WIDTH - 1 - w);
+      for (int w = 0; w < NUM_DIM_WIDTH && !touched; w++) {
+        const size_t width = static_cast<size_t>(1) << (NUM_DIM_WIDTH - 1 - w);
+        for (int k = 0; k < st.ndw[w] && !touched; k++) {
+          touched = hit(st.dims + off * st.capacity, width * st.size) || hit(st.dims + valueBytes * st.capacity + static_cast<size_t>(nd) * st.capacity, st.size);
+          off += width;
+          nd++;
+        }
+      }
+    }
+    if (touched) g_sorted.erase(g_sorted.begin() + i);
+    else i++;
+  }
+}
 
 bool fused_sort_reduce_enabled() {
   static EnvSwitch<bool> on("ARES_SORT_FUSE", [](const char *e) { return !(e && e[0] == '0'); });
@@ -555,8 +672,8 @@ int fused_sort_reduce_run(int device, const FusedPlanD &plan, int nd, bool const
   const size_t partBytes = up(sizeof(uint32_t) * numParts);
   const size_t aBytes = up(sizeof(uint4) * capA * numParts);
   const size_t bBytes = up(sizeof(uint4) * static_cast<size_t>(capB) * numParts * streams);
-  const size_t stageBytes = up(sizeof(uint4) * stageSlots * numParts);
-  StreamBuffer buf(headBytes + countsBytes + partBytes + aBytes + bBytes + stageBytes + 256, stream);
+  const size_t stageBytes = up(sizeof(uint4) * stageSlots * numParts), stageKeyBytes = up(sizeof(uint64_t) * stageSlots * numParts);
+  StreamBuffer buf(headBytes + countsBytes + partBytes + aBytes + bBytes + stageBytes + stageKeyBytes + 256, stream);
   uint8_t *base = buf.as<uint8_t>();
   hip_check(hipMemsetAsync(base, 0, headBytes, stream), "hipMemsetAsync");
   hr::Workspace ws;
@@ -595,13 +712,19 @@ int fused_sort_reduce_run(int device, const FusedPlanD &plan, int nd, bool const
   m.constBits = constBits;
   m.agg = a;
   m.staging = reinterpret_cast<uint4 *>(base + headBytes + countsBytes + partBytes + aBytes + bBytes);
+  m.stageKeys = reinterpret_cast<uint64_t *>(base + headBytes + countsBytes + partBytes + aBytes + bBytes + stageBytes);
   m.partCount = partCount;
   m.flags = ws.outCount;
   m.maxGroups = static_cast<uint32_t>(tableGroups);
   m.dimOut = out.DimValues;
   m.outValues = outValues;
 
-  if (prevSize > 0) {
+  // the previous result's row hashes, if the query's previous Reduce left them (and nothing has written to the vectors since)
+  const std::shared_ptr<uint64_t> prevKeys = prevSize > 0 ? sorted_state_lookup(device, in, inValues, vw, prevSize) : nullptr;
+  const std::shared_ptr<uint64_t> keysOut = take_key_block(device, static_cast<size_t>(length), stream);
+  m.prevKeys = prevKeys.get();
+  m.keysOut = keysOut.get();
+  if (prevSize > 0 && !prevKeys) {
     const int grid = static_cast<int>(std::min<int64_t>((static_cast<int64_t>(prevSize) + 255) / 256, 256 * 8));
     ARES_LAUNCH("sr_prev_kernel", sr_prev_kernel, grid, 256, stream, m, L, ws.recA);
   }
@@ -651,6 +774,8 @@ int fused_sort_reduce_run(int device, const FusedPlanD &plan, int nd, bool const
   if (w[1] && !w[2] && grow_record_stream_slack())
     return fused_sort_reduce_run(device, plan, nd, constMeasure, constBits, batchRows, in, inValues, prevSize, out, outValues, a, stream);
   if (w[1] || w[2]) return -1;  // the outputs may be partly written: the caller runs the real Sort + Reduce over them
+  // (the caller reported the output vectors as rewritten before this call: what is registered now describes the new rows)
+  sorted_state_register(device, out, outValues, static_cast<size_t>(in.VectorCapacity), vw, static_cast<int>(w[0]), keysOut);
   return static_cast<int>(w[0]);
 }
 

@@ -27,6 +27,10 @@ int fused_sort_reduce_run(int device, const FusedPlanD &plan, int nd, bool const
                           const DimensionVector &in, const uint8_t *inValues, int prevSize, const DimensionVector &out,
                           uint8_t *outValues, const AggSpec &a, hipStream_t stream);
 
+// something writes [ptr, ptr + bytes): row hashes a fused Reduce kept beside a result in there are forgotten (called by
+// grouped_note_write, which every writer of a result vector reports to)
+void sorted_state_note_write(int device, const void *ptr, size_t bytes);
+
 // sort_reduce.hip: the real thing, for a lazily defined Sort (+ Reduce) that somebody reads after all
 void sort_keys_now(const DimensionVector &keys, int length, hipStream_t stream);
 int reduce_now(const DimensionVector &in, uint8_t *inputValues, const DimensionVector &out, uint8_t *outputValues, int valueBytes,

@@ -342,7 +342,8 @@ __global__ __launch_bounds__(kThreads) void sr_merge_kernel(SrArgs m) {
         const bool hit = valid && (m0 || m1 || m2 || m3) && (hi & lo) != 0xFFFFFFFFu;
         const uint32_t slot = hit ? 4u * bkt[k] + (m0 ? 0u : m1 ? 1u : m2 ? 2u : 3u) : static_cast<uint32_t>(T::kSlots);
         const uint64_t value = m.constMeasure ? m.constBits : hr::widen_value(m.widen, r[k].z);
-        __hip_atomic_fetch_min(sRows + slot, hit ? r[k].x : kNoRow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // (the group's lowest row is settled after its first few records: a plain read tells the rest they need no atomic)
+        if (hit && r[k].x < sRows[slot]) __hip_atomic_fetch_min(sRows + slot, r[k].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         sr_aggregate<VW>(sVals + slot, hit ? value : a.identity, a);
         pend |= (valid && !hit ? 1u : 0u) << k;
       }

@@ -111,7 +111,7 @@ bool virtual_iota_peek(int device, const uint32_t *indexVector, int n, bool cons
 // the caller was handed `indexVector` and reads it with a kernel: a lazy iota a consumer left behind is written now
 void materialize_index_vector(int device, const uint32_t *indexVector);
 // ... and the same for every buffer of a dimension vector (dimension rows, hash vector, index vector), lazy fills included
-void settle_dimension_vector(int device, const DimensionVector &v);
+void settle_dimension_vector(int device, const DimensionVector &v, bool rowsOnly = false);
 
 // The stream of the entry point the calling thread is executing.  Work that was DEFINED on another stream (a lazy
 // fill, a lazy iota, a lazy compaction) and is written on that stream at one of this call's flush points is waited for

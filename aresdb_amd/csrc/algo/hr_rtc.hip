@@ -338,11 +338,11 @@ bool gen_agg(std::ostringstream &o, const AggSpec &a) {
 // Records are counting-sorted by partition in LDS and ONLY whole lines of 8 records leave the CU, each written
 // by 8 adjacent lanes with one store; the < 8 records a partition has left over stay in LDS and go first in
 // the next tile's lines.  Streams are private to the workgroup: no global atomics.
-static void kernel_body_lines16(std::ostringstream &o, const char *fourth) {
+static void kernel_body_lines16(std::ostringstream &o, const char *fourth, const char *entry = "hr_scan_rtc") {
   phase_macros(o);
   o << "#define T 4096u\n"
        "__device__ __forceinline__ u32 lane_up(u32 v, u32 lane, u32 off) { return (u32)__builtin_amdgcn_ds_bpermute((int)((lane - off) << 2), (int)v); }\n"
-       "extern \"C\" __global__ void __launch_bounds__(1024) hr_scan_rtc(Args a) {\n"
+       "extern \"C\" __global__ void __launch_bounds__(1024) " << entry << "(Args a) {\n"
        "  __shared__ uint4 sRec[T];\n"            // the tile's records, sorted by partition
        "  __shared__ uint4 sLeft[NP * 7u];\n"     // up to 7 records per partition waiting for a full line
        "  __shared__ u32 sCount[2][NP];\n"
@@ -1068,7 +1068,7 @@ std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t null
   } else if (kind == SCAN_COMPACT) {
     kernel_body_compact(o);
   } else {
-    kernel_body_lines16(o, sort64 ? "cw[j]" : "0u");
+    kernel_body_lines16(o, sort64 ? "cw[j]" : "0u", sort64 ? "sr_scan_rtc" : "hr_scan_rtc");
   }
   return o.str();
 }
@@ -1078,11 +1078,13 @@ std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t null
 // values — what HashReduce is handed when the batch's transforms were launched (ARES_FUSE=0, plans the
 // fused scan does not cover).  Args: vals[d] / nulls[d] = dimension d's values / validity bytes at
 // rowBase, vals[nd] = the measures at rowBase.  Records carry the whole value: {row, hash, lo, hi}.
-std::string generate_vector(int nd, int vw, int partBits) {
-  if (nd < 1 || nd > kFusedDims || (vw != 4 && vw != 8)) return "";
+// sort64: the Sort + Reduce path over materialised vectors (sort_reduce_fused.hip): records {row, hash64 >> 32, the 4-byte value,
+// (u32)hash64} keyed by lo64(murmur3_x64_128) of the packed row, partition = top bits of the 64-bit hash; up to eight dimensions.
+std::string generate_vector(int nd, int vw, int partBits, bool sort64 = false) {
+  if (nd < 1 || nd > (sort64 ? kFusedDims : kGenericFusedDims) || (vw != 4 && vw != 8) || (sort64 && vw != 4)) return "";
   std::ostringstream o;
   const int mq = vw / 4;
-  o << times5_text() << kPrelude << args_text()
+  o << times5_text() << kPrelude << (sort64 ? kPrelude64 : "") << args_text()
     << "#define ND " << nd << "\n#define MQ " << mq << "\n#define PB " << partBits << "\n#define NP " << (1 << partBits) << "\n"
        "struct Raw { u32 v[ND][4]; u32 ok[ND]; u32 m[MQ * 4]; };\n"
        "__device__ __forceinline__ void load_full(Raw &r, const Args &a, u32 i0) {\n"
@@ -1116,8 +1118,25 @@ std::string generate_vector(int nd, int vw, int partBits) {
        "__device__ __forceinline__ void eval4(const Raw &r, const Args &a, u32 i0, u32 (&hh)[4], u32 (&cv)[4], u32 (&cw)[4], u32 (&alive)[4]) {\n"
        "#pragma unroll\n"
        "  for (int j = 0; j < 4; j++) {\n"
-       "    alive[j] = (int)(i0 + j) < a.length ? 1u : 0u;\n"
-       "    u32 h = 0u, okbytes = 0u;\n"
+       "    alive[j] = (int)(i0 + j) < a.length ? 1u : 0u;\n";
+  if (sort64) {
+    SlotLayout SL;
+    SL.nd = nd;
+    for (int d = 0; d < nd; d++) {
+      SL.width[d] = 4;
+      SL.off[d] = 4 * d;
+    }
+    SL.valueBytes = 4 * nd;
+    o << "    u64 h64;\n";
+    gen_row_hash64(o, SL, [](int d) { return "r.v[" + std::to_string(d) + "][j]"; },
+                   [](int d) { return "((r.ok[" + std::to_string(d) + "] >> (8 * j)) & 0xFFu)"; }, "h64", "    ");
+    o << "    hh[j] = (u32)(h64 >> 32);\n"
+         "    cv[j] = r.m[j];\n"
+         "    cw[j] = (u32)h64;\n"
+         "  }\n"
+         "}\n";
+  } else {
+  o << "    u32 h = 0u, okbytes = 0u;\n"
        "#pragma unroll\n"
        "    for (int d = 0; d < ND; d++) { h = mix(h, r.v[d][j]); okbytes |= ((r.ok[d] >> (8 * j)) & 0xFFu) << (8 * d); }\n";
   if (nd == 4) o << "    h = mix(h, okbytes);\n";
@@ -1128,12 +1147,13 @@ std::string generate_vector(int nd, int vw, int partBits) {
        "    cw[j] = MQ == 2 ? r.m[j * MQ + MQ - 1] : 0u;\n"
        "  }\n"
        "}\n";
+  }
   o << "__device__ __forceinline__ void load_tile(Raw &r, const Args &a, u32 i0) { if ((int)(i0 + 3u) < a.length) load_full(r, a, i0); else if ((int)i0 < a.length) load_tail(r, a, i0); }\n"
        "__device__ __forceinline__ void eval4p(Raw &r, const Args &a, u32 &i0, u32 (&hh)[4], u32 (&cv)[4], u32 (&cw)[4], u32 (&alive)[4], u32 i0n) {\n"
        "  eval4(r, a, i0, hh, cv, cw, alive);\n"
        "  load_tile(r, a, i0n);\n"
        "}\n";
-  kernel_body_lines16(o, "cw[j]");
+  kernel_body_lines16(o, "cw[j]", sort64 ? "sr_scan_rtc" : "hr_scan_rtc");
   return o.str();
 }
 
@@ -2262,7 +2282,7 @@ void rtc_scan_launch(const RtcKernel &kernel, const FusedPlanD &plan, uint32_t r
 RtcKernel rtc_sort_scan_lookup(int device, const FusedPlanD &plan, int nd, int partBits, bool wait) {
   if (!rtc_api().ok) return nullptr;
   return front_lookup(shape_key('o', device, plan, nd, partBits, 0, nullptr, nullptr), device,
-                      [&] { return generate(plan, nd, partBits, null_mask(plan), SCAN_SORT64); }, "hr_scan_rtc", wait);
+                      [&] { return generate(plan, nd, partBits, null_mask(plan), SCAN_SORT64); }, "sr_scan_rtc", wait);
 }
 
 void rtc_sort_scan_launch(const RtcKernel &kernel, const FusedPlanD &plan, uint32_t rowBase, int length, const hr::Workspace &ws,
@@ -2312,6 +2332,26 @@ void rtc_vector_scan_launch(const RtcKernel &kernel, const uint8_t *dimValues, s
 }
 
 std::string rtc_vector_scan_source(int nd, int vw, int partBits) { return generate_vector(nd, vw, partBits); }
+
+RtcKernel rtc_sort_vector_scan_lookup(int device, int nd, int partBits, bool wait) {
+  if (!rtc_api().ok) return nullptr;
+  return compiled_kernel(device, generate_vector(nd, 4, partBits, true), "sr_scan_rtc", wait);
+}
+void rtc_sort_vector_scan_launch(const RtcKernel &kernel, const uint8_t *dimValues, size_t capacity, const uint8_t *values, int nd,
+                                 uint32_t rowBase, int length, const hr::Workspace &ws, hipStream_t stream) {
+  FusedPlanD plan;
+  memset(&plan, 0, sizeof(plan));
+  plan.numCols = nd + 1;
+  for (int d = 0; d < nd; d++) {
+    plan.cols[d].vals = reinterpret_cast<const uint32_t *>(dimValues + 4ull * d * capacity) + rowBase;
+    plan.cols[d].nulls = dimValues + 4ull * nd * capacity + static_cast<size_t>(d) * capacity + rowBase;
+  }
+  plan.cols[nd].vals = reinterpret_cast<const uint32_t *>(values) + rowBase;
+  RtcArgs args;
+  fill_scan_args(args, plan, rowBase, length, ws);
+  launch_scan(kernel, args, ws.streams, length, stream, "sr_vector_scan_rtc");
+}
+std::string rtc_sort_vector_scan_source(int nd, int partBits) { return generate_vector(nd, 4, partBits, true); }
 
 RtcKernel rtc_vector_merge_lookup(int device, int nd, int vw, int partBits, const AggSpec &a, bool wait) {
   if (!rtc_api().ok) return nullptr;

@@ -995,9 +995,12 @@ CGoCallResHandle Sort(DimensionVector keys, int length, void *cudaStream, int de
   // dimensions whose transforms are still pending on this stream: Sort is DEFINED — Reduce aggregates by the 64-bit row hash
   // without sorting rows (sort_reduce_fused.hip); anybody else who looks at the hash or index vector makes it run
   if (define_lazy_sort(device, reinterpret_cast<hipStream_t>(cudaStream), keys, length)) return resHandle;
+  const bool lazyVectors = lazy_vector_sort_candidate(device, keys, length);
   flush_deferred(device);
-  settle_dimension_vector(device, keys);
+  settle_dimension_vector(device, keys, /*rowsOnly=*/lazyVectors);
   flush_deferred_for_vector(device, keys, nullptr, 0);  // rows a HashReduce skipped, should a host sort them after all
+  // the rows exist now: Sort is DEFINED all the same — Reduce orders the groups by row hash (fused_sort_reduce_vectors)
+  if (lazyVectors && define_lazy_sort_vectors(device, reinterpret_cast<hipStream_t>(cudaStream), keys, length)) return resHandle;
   if (length > 0) {
     mem_note_write(device, keys.HashValues, 8ull * static_cast<size_t>(length));
     mem_note_write(device, keys.IndexVector, 4ull * static_cast<size_t>(length));

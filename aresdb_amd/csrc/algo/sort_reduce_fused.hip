@@ -29,6 +29,7 @@
 // groups than the partitions' tables hold, a skewed partition stream, a record whose hash equals the table's "empty" word.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <memory>
 #include <mutex>
 #include <vector>
@@ -56,14 +57,20 @@ constexpr uint32_t kNoRow = 0xFFFFFFFFu;
 // workgroup's 160 KB of LDS leave beside the per-wavefront queues of records that miss their home bucket.  The last kTail
 // slots are overflow room for the clusters at the table's end (no wrap-around: order is position)
 constexpr uint32_t kQueueCap = 80, kQueueDrain = 16;  // per wavefront: drained from kQueueDrain entries on (a push adds <= 64)
-template <int VW>
+// WIDE (Sort + Reduce over materialised vectors, fused_sort_reduce_vectors below: results of tens of millions of groups):
+// many small partitions instead — 2048 slots (37 KB with the queues: four workgroups per CU), what a partition's fixed
+// costs (clearing the table, the ordering pass over its slots) are proportional to
+template <int VW, bool WIDE = false>
 struct Table {
-  static constexpr int kSlots = VW == 4 ? 8192 : 6912;
-  static constexpr int kTail = 256;
+  static constexpr int kSlots = WIDE ? 2048 : (VW == 4 ? 8192 : 6912);
+  static constexpr int kTail = WIDE ? 128 : 256;
   static constexpr int kHomes = kSlots - kTail;
-  static constexpr int kPerLane = (kSlots + kThreads - 1) / kThreads;
+  static constexpr int kLanes = WIDE ? 256 : kThreads;  // workgroup size (wide: four wavefronts, so that a CU holds four workgroups)
+  static constexpr int kPerLane = (kSlots + kLanes - 1) / kLanes;
   static constexpr int kMaxGroups = kHomes * 13 / 16;  // beyond ~0.8 the clusters (and the ranking walks) grow quickly
+  static constexpr int kStage = WIDE ? (kMaxGroups + 7) / 8 * 8 : kSlots;  // staging entries per partition
 };
+constexpr int kWideMaxPartBits = 17, kWideEntries = 1024;  // partitions of the wide layout: entries / 1024 (up to 2^17)
 
 struct SrArgs {
   // records
@@ -97,6 +104,13 @@ struct SrArgs {
   uint64_t *stageKeys;
   uint64_t *keysOut;
   const uint64_t *prevKeys;
+  // wide layout (fused_sort_reduce_vectors): region B holds ONE run per partition (recB + offsetsB[p], countsB[p] records,
+  // written by sr_split_kernel); prevBounds[p .. p + 1] = the partition's range of prevKeys; partBase[p] = groups before
+  // partition p (sr_prefix_kernel); copyAll: every representative's dimension row is copied from dimIn (no plan)
+  const uint32_t *prevBounds;
+  const uint32_t *offsetsB;
+  const uint32_t *partBase;
+  int copyAll;
   uint64_t *phases;  // ARES_HR_PHASES=1 (diagnostics): six time stamps per partition (100 MHz clock), else null
 };
 
@@ -165,23 +179,24 @@ __device__ __forceinline__ void sr_aggregate(typename Slots<VW>::V *slot, uint64
   }
 }
 
-template <int VW>
-__global__ __launch_bounds__(kThreads) void sr_merge_kernel(SrArgs m) {
-  using T = Table<VW>;
+template <int VW, bool WIDE>
+__global__ __launch_bounds__((Table<VW, WIDE>::kLanes)) void sr_merge_kernel(SrArgs m) {
+  using T = Table<VW, WIDE>;
   using V = typename Slots<VW>::V;
   __shared__ __attribute__((aligned(16))) uint64_t sKeys[T::kSlots];
   __shared__ uint32_t sRows[T::kSlots + 1];  // (+ 1: the spare slot records that miss their home bucket aim their atomics at)
   __shared__ V sVals[T::kSlots + 1];
-  __shared__ uint32_t sRun[kMaxStreams];
-  __shared__ uint4 sQueue[kThreads / 64][kQueueCap];
-  __shared__ uint32_t sWave[kThreads / 64];
+  __shared__ uint32_t sRun[WIDE ? 1 : kMaxStreams];
+  __shared__ uint4 sQueue[T::kLanes / 64][kQueueCap];
+  __shared__ uint32_t sWave[T::kLanes / 64];
   __shared__ uint32_t sClaims, sBad;
   const int p = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int pb = m.partBits;
   const int numParts = 1 << pb;
   const AggSpec a = m.agg;
-  for (int s = tid; s < T::kSlots; s += kThreads) {
+  if (m.phases && tid == 0) m.phases[static_cast<size_t>(p) * 8 + 5] = wall_clock64();
+  for (int s = tid; s < T::kSlots; s += T::kLanes) {
     sKeys[s] = kEmptyKey;
     sRows[s] = kNoRow;
     sVals[s] = static_cast<V>(a.identity);
@@ -190,7 +205,9 @@ __global__ __launch_bounds__(kThreads) void sr_merge_kernel(SrArgs m) {
     sRows[T::kSlots] = kNoRow;
     sVals[T::kSlots] = static_cast<V>(a.identity);
   }
-  if (tid < m.streams) sRun[tid] = m.countsB[static_cast<uint64_t>(tid) * numParts + p];
+  if constexpr (!WIDE) {
+    if (tid < m.streams) sRun[tid] = m.countsB[static_cast<uint64_t>(tid) * numParts + p];
+  }
   if (tid == 0) { sClaims = 0; sBad = 0; }
   auto stamp = [&](int k) {
     if (m.phases && tid == 0) m.phases[static_cast<size_t>(p) * 8 + k] = wall_clock64();
@@ -259,19 +276,20 @@ __global__ __launch_bounds__(kThreads) void sr_merge_kernel(SrArgs m) {
       }
       return lo;
     };
-    const uint32_t from = pb ? lower(static_cast<uint64_t>(p) << (64 - pb)) : 0u;
-    const uint32_t to = (pb && p + 1 < numParts) ? lower(static_cast<uint64_t>(p + 1) << (64 - pb)) : m.prevSize;
-    for (uint32_t i = from + tid; i < to; i += kThreads) {
+    // (wide layout: 2^17 partitions would each walk the array with two chains of dependent loads — sr_bounds_kernel did)
+    const uint32_t from = m.prevBounds ? m.prevBounds[p] : pb ? lower(static_cast<uint64_t>(p) << (64 - pb)) : 0u;
+    const uint32_t to = m.prevBounds ? m.prevBounds[p + 1] : (pb && p + 1 < numParts) ? lower(static_cast<uint64_t>(p + 1) << (64 - pb)) : m.prevSize;
+    for (uint32_t i = from + tid; i < to; i += T::kLanes) {
       const uint64_t key = m.prevKeys[i];
       insert(i, static_cast<uint32_t>(key >> 32), static_cast<uint32_t>(key), load_value_bits(m.inValues, a, i));
     }
-  } else
+  } else if (m.recA)
   // ---- ... or not (region A, written by sr_prev_kernel): the value is read from the previous result's measure vector
   {
     const uint32_t cursor = m.cursorsA[p];
     const uint32_t nA = cursor < m.capA ? cursor : static_cast<uint32_t>(m.capA);
     const uint4 *recA = m.recA + static_cast<uint64_t>(p) * m.capA;
-    for (uint32_t i = tid; i < nA; i += kThreads) {
+    for (uint32_t i = tid; i < nA; i += T::kLanes) {
       const uint4 r = recA[i];
       insert(r.x, r.y, r.w, load_value_bits(m.inValues, a, r.x));
     }
@@ -290,6 +308,7 @@ __global__ __launch_bounds__(kThreads) void sr_merge_kernel(SrArgs m) {
     int g = wave;
     uint32_t off = 0;
     auto next = [&]() -> Chunk {
+      if constexpr (WIDE) return Chunk{pad, 0u};
       while (g < m.streams) {
         const uint32_t cnt = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(sRun[g])));
         if (off < cnt) {
@@ -297,7 +316,7 @@ __global__ __launch_bounds__(kThreads) void sr_merge_kernel(SrArgs m) {
           off += 256u;
           return c;
         }
-        g += kThreads / 64;
+        g += T::kLanes / 64;
         off = 0;
       }
       return Chunk{pad, 0u};
@@ -371,7 +390,7 @@ __global__ __launch_bounds__(kThreads) void sr_merge_kernel(SrArgs m) {
     // dependent loads (113 us of a partition's 155 at 2 Mi rows): when no run is longer than four lines, the first L lines of
     // EVERY run are fetched at once instead (L = lines of the longest run), four 16-byte loads per lane in flight.
     uint32_t maxRun = 0;
-    for (int gg = lane; gg < m.streams; gg += 64) maxRun = sRun[gg] > maxRun ? sRun[gg] : maxRun;
+    for (int gg = lane; !WIDE && gg < m.streams; gg += 64) maxRun = sRun[gg] > maxRun ? sRun[gg] : maxRun;
 #pragma unroll
     for (int off2 = 32; off2 > 0; off2 >>= 1) {
       const uint32_t t = static_cast<uint32_t>(__shfl_xor(static_cast<int>(maxRun), off2));
@@ -379,12 +398,21 @@ __global__ __launch_bounds__(kThreads) void sr_merge_kernel(SrArgs m) {
     }
     const uint32_t lpr = (maxRun + 7u) / 8u;  // lines of the longest run
     uint4 ra[4], rb[4];
-    if (m.streams > 0 && lpr >= 1u && lpr <= 4u) {
+    if constexpr (WIDE) {  // one run of a thousand records: chunks of 256 dealt to the four wavefronts (the CU's other workgroups cover the loads)
+      const uint32_t cnt = m.countsB[p];
+      const uint4 *run = m.recB + m.offsetsB[p];
+      for (uint32_t c = static_cast<uint32_t>(wave) * 256u; c < cnt; c += T::kLanes / 64 * 256u) {
+        const Chunk ch{run + c, cnt - c < 256u ? cnt - c : 256u};
+        load(ra, ch);
+        consume(ra);
+        if (__hip_atomic_load(&sBad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+      }
+    } else if (m.streams > 0 && lpr >= 1u && lpr <= 4u) {
       const uint32_t units = static_cast<uint32_t>(m.streams) * 8u * lpr;
-      for (uint32_t base = 0; base < units; base += 4u * kThreads) {
+      for (uint32_t base = 0; base < units; base += 4u * T::kLanes) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-          const uint32_t unit = base + static_cast<uint32_t>(k) * kThreads + tid;  // lane (unit & 7) of line (unit >> 3) % lpr of run (unit >> 3) / lpr
+          const uint32_t unit = base + static_cast<uint32_t>(k) * T::kLanes + tid;  // lane (unit & 7) of line (unit >> 3) % lpr of run (unit >> 3) / lpr
           const uint32_t ul = unit < units ? unit >> 3 : 0u, gg = ul / lpr, idx = (ul - gg * lpr) * 8u + (unit & 7u);
           const bool in = unit < units && idx < sRun[gg];
           ra[k] = *(in ? m.recB + (static_cast<uint64_t>(gg) * numParts + p) * m.capB + idx : pad);
@@ -418,7 +446,7 @@ __global__ __launch_bounds__(kThreads) void sr_merge_kernel(SrArgs m) {
   stamp(3);
   if (sBad) {  // (uniform)
     if (tid == 0) {
-      m.flags[1] = 1u;
+      m.flags[WIDE ? 3 : 1] = 1u;  // (wide: told apart from a record stream's overflow — more room for records would not help)
       m.partCount[p] = 0u;
     }
     return;
@@ -438,7 +466,9 @@ __global__ __launch_bounds__(kThreads) void sr_merge_kernel(SrArgs m) {
   __syncthreads();
   uint32_t before = incl - mine;
   for (int w = 0; w < wave; w++) before += sWave[w];
-  uint4 *stage = m.staging + static_cast<uint64_t>(p) * T::kSlots;
+  // (wide: packed — a partition emits at most its entries: records + previous groups, whose prefixes are at hand)
+  const uint64_t stageAt = WIDE ? static_cast<uint64_t>(m.offsetsB[p]) + (m.prevBounds ? m.prevBounds[p] : 0u) : static_cast<uint64_t>(p) * T::kStage;
+  uint4 *stage = m.staging + stageAt;
   uint32_t seen = 0;  // occupied slots of this lane before the current one
 #pragma unroll
   for (int k = 0; k < T::kPerLane; k++) {
@@ -463,10 +493,10 @@ __global__ __launch_bounds__(kThreads) void sr_merge_kernel(SrArgs m) {
     const uint32_t rank = before + seen - static_cast<uint32_t>(s - (b + 1)) + smaller;
     const uint64_t v = static_cast<uint64_t>(sVals[s]);
     stage[rank] = make_uint4(sRows[s], static_cast<uint32_t>(v), static_cast<uint32_t>(v >> 32), 0u);
-    m.stageKeys[static_cast<uint64_t>(p) * T::kSlots + rank] = key;
+    m.stageKeys[stageAt + rank] = key;
     seen++;
   }
-  if (tid == kThreads - 1) m.partCount[p] = before + mine;
+  if (tid == T::kLanes - 1) m.partCount[p] = before + mine;
   if (m.phases) __syncthreads();
   stamp(4);
 }
@@ -491,28 +521,32 @@ __device__ __forceinline__ void sr_eval_dim(const FusedPlanD &plan, int d, uint3
   *ok = x.ok ? 1u : 0u;
 }
 
-template <int VW>
-__global__ __launch_bounds__(kThreads) void sr_emit_kernel(SrArgs m, FusedPlanD plan, DimLayoutD L) {
-  using T = Table<VW>;
+template <int VW, bool WIDE>
+__global__ __launch_bounds__((Table<VW, WIDE>::kLanes)) void sr_emit_kernel(SrArgs m, FusedPlanD plan, DimLayoutD L) {
+  using T = Table<VW, WIDE>;
   __shared__ uint32_t sBase;
   const int p = blockIdx.x, tid = threadIdx.x;
-  if (tid == 0) sBase = 0;
-  __syncthreads();
-  if (tid < p) {
-    const uint32_t c = m.partCount[tid];
-    if (c) atomicAdd(&sBase, c);
+  if constexpr (!WIDE) {
+    if (tid == 0) sBase = 0;
+    __syncthreads();
+    if (tid < p) {
+      const uint32_t c = m.partCount[tid];
+      if (c) atomicAdd(&sBase, c);
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  const uint32_t base = sBase, count = m.partCount[p];
-  if (p == (1 << m.partBits) - 1 && tid == 0) m.flags[0] = base + count;
-  const uint4 *stage = m.staging + static_cast<uint64_t>(p) * T::kSlots;
+  const uint32_t count = m.partCount[p];
+  const uint32_t base = WIDE ? m.partBase[p] : sBase;
+  if (!WIDE && p == (1 << m.partBits) - 1 && tid == 0) m.flags[0] = base + count;  // (wide: sr_prefix_kernel)
+  const uint64_t stageAt = WIDE ? static_cast<uint64_t>(m.offsetsB[p]) + (m.prevBounds ? m.prevBounds[p] : 0u) : static_cast<uint64_t>(p) * T::kStage;
+  const uint4 *stage = m.staging + stageAt;
   const size_t cap = m.inCapacity;  // (the reference strides BOTH vectors by inputKeys.VectorCapacity: sort_reduce.cu:234-239)
   uint8_t *nullsOut = m.dimOut + static_cast<size_t>(L.valueBytes) * cap;
-  for (uint32_t i = tid; i < count; i += kThreads) {
+  for (uint32_t i = tid; i < count; i += T::kLanes) {
     const uint4 e = stage[i];
     const uint32_t at = base + i;
-    m.keysOut[at] = m.stageKeys[static_cast<uint64_t>(p) * T::kSlots + i];
-    if (e.x < m.prevSize) {
+    m.keysOut[at] = m.stageKeys[stageAt + i];
+    if (m.copyAll || e.x < m.prevSize) {
       copy_dim_row(m.dimIn, cap, m.dimOut, cap, L, e.x, at);
     } else {
       const uint32_t r = e.x - m.prevSize;
@@ -529,6 +563,124 @@ __global__ __launch_bounds__(kThreads) void sr_emit_kernel(SrArgs m, FusedPlanD 
     if (VW == 8) reinterpret_cast<uint64_t *>(m.outValues)[at] = (static_cast<uint64_t>(e.z) << 32) | e.y;
     else reinterpret_cast<uint32_t *>(m.outValues)[at] = e.y;
   }
+}
+
+// ---- the wide layout's extra steps ------------------------------------------------------------------------------------------
+// where each partition's range of the previous result's (ascending) row hashes begins: bounds[p] = first index whose key's
+// top bits are >= p; bounds[numParts] = prevSize
+__global__ __launch_bounds__(256) void sr_bounds_kernel(const uint64_t *prevKeys, uint32_t prevSize, int pb, uint32_t *bounds) {
+  const uint32_t p = blockIdx.x * 256u + threadIdx.x, numParts = 1u << pb;
+  if (p > numParts) return;
+  uint32_t lo = 0, hi = prevSize;
+  if (p == numParts || pb == 0) {
+    lo = p == 0 ? 0u : prevSize;
+  } else {
+    const uint64_t bound = static_cast<uint64_t>(p) << (64 - pb);
+    while (lo < hi) {
+      const uint32_t mid = lo + ((hi - lo) >> 1);
+      if (prevKeys[mid] < bound) lo = mid + 1; else hi = mid;
+    }
+  }
+  bounds[p] = lo;
+}
+
+// The scan's records lie in [workgroup][level-1 partition] streams (up to 512 partitions: what the scan's line staging
+// holds); each level-1 partition is dealt out to its 2^(pb - pb1) partitions by the hash's next bits, into runs of EXACTLY
+// the partition's size (a key that a million rows share fills one partition: no capacity to guess).  One workgroup per
+// (level-1 partition, group of streams), twice: COUNT adds its records per partition (LDS histogram, one global atomic per
+// partition it meets); after the prefix over the counts the second launch reserves its share of each run with one atomic
+// per partition and writes the records there.  Order within a partition does not matter to the merge (lowest row by atomic
+// min, integer aggregates).
+struct SplitArgs {
+  const uint4 *rec1;
+  const uint32_t *counts1;
+  uint32_t cap1;
+  int streams, group, pb1, pb;
+  uint4 *rec2;
+  uint32_t *counts2;         // COUNT: records per partition
+  const uint32_t *offsets2;  // their exclusive prefix
+  uint32_t *cursors2;        // records placed so far
+};
+template <bool COUNT>
+__global__ __launch_bounds__(256) void sr_split_kernel(SplitArgs s) {
+  __shared__ uint32_t sHist[256], sBase[256];
+  const int tid = threadIdx.x;
+  const int units = (s.streams + s.group - 1) / s.group;
+  const int p1 = blockIdx.x / units, unit = blockIdx.x - p1 * units;
+  const int numParts1 = 1 << s.pb1, sb = s.pb - s.pb1, fan = 1 << sb;
+  const int g0 = unit * s.group, g1 = g0 + s.group < s.streams ? g0 + s.group : s.streams;
+  // partition of a record within its level-1 partition: the hash bits right below the level-1 bits (pb <= 17: all in the high word)
+  auto sub_of = [&](const uint4 &r) { return sb ? (r.y << s.pb1) >> (32 - sb) : 0u; };
+  sHist[tid] = 0;
+  __syncthreads();
+  for (int g = g0; g < g1; g++) {
+    const uint32_t stored = s.counts1[static_cast<uint64_t>(g) * numParts1 + p1], cnt = stored < s.cap1 ? stored : s.cap1;
+    const uint4 *run = s.rec1 + (static_cast<uint64_t>(g) * numParts1 + p1) * s.cap1;
+    for (uint32_t i = tid; i < cnt; i += 256) {
+      const uint4 r = run[i];
+      if (r.x != kNoRow) __hip_atomic_fetch_add(sHist + sub_of(r), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+  __syncthreads();
+  const uint32_t first = static_cast<uint32_t>(p1) << sb;
+  if (tid < fan) {
+    const uint32_t c = sHist[tid];
+    if (COUNT) {
+      if (c) atomicAdd(s.counts2 + first + tid, c);
+    } else {
+      sBase[tid] = s.offsets2[first + tid] + (c ? atomicAdd(s.cursors2 + first + tid, c) : 0u);
+      sHist[tid] = 0;
+    }
+  }
+  if (COUNT) return;
+  __syncthreads();
+  for (int g = g0; g < g1; g++) {
+    const uint32_t stored = s.counts1[static_cast<uint64_t>(g) * numParts1 + p1], cnt = stored < s.cap1 ? stored : s.cap1;
+    const uint4 *run = s.rec1 + (static_cast<uint64_t>(g) * numParts1 + p1) * s.cap1;
+    for (uint32_t i = tid; i < cnt; i += 256) {
+      const uint4 r = run[i];
+      if (r.x == kNoRow) continue;
+      const uint32_t sub = sub_of(r);
+      s.rec2[sBase[sub] + __hip_atomic_fetch_add(sHist + sub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = r;
+    }
+  }
+}
+
+// exclusive prefix of a per-partition count (one workgroup of 1024 lanes walks tiles of 4096 counts; numParts <= 2^17):
+// records / groups before each partition, the total to *total
+__global__ __launch_bounds__(1024) void sr_prefix_kernel(const uint32_t *partCount, int numParts, uint32_t *partBase, uint32_t *total) {
+  __shared__ uint32_t sWave[2][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint32_t carry = 0;
+  int flip = 0;
+  for (int base = 0; base < numParts; base += 4096, flip ^= 1) {
+    const int i = base + 4 * tid;
+    uint32_t c[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) c[k] = i + k < numParts ? partCount[i + k] : 0u;
+    const uint32_t mine = c[0] + c[1] + c[2] + c[3];
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(incl, off);
+      if (lane >= off) incl += t;
+    }
+    if (lane == 63) sWave[flip][wave] = incl;
+    __syncthreads();
+    uint32_t before = carry + incl - mine, all = 0;
+    for (int w = 0; w < 16; w++) {
+      const uint32_t t = sWave[flip][w];
+      before += w < wave ? t : 0u;
+      all += t;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (i + k < numParts) partBase[i + k] = before;
+      before += c[k];
+    }
+    carry += all;
+  }
+  if (tid == 0) *total = carry;
 }
 
 // ---- the row hashes of a result, kept beside it ---------------------------------------------------------------------------
@@ -580,6 +732,20 @@ std::shared_ptr<uint64_t> sorted_state_lookup(int device, const DimensionVector 
     if (st.device == device && st.dims == v.DimValues && st.values == values && st.capacity == static_cast<size_t>(v.VectorCapacity) &&
         memcmp(st.ndw, v.NumDimsPerDimWidth, sizeof(st.ndw)) == 0 && st.valueBytes == valueBytes && st.size == size)
       return st.keys;
+  return nullptr;
+}
+
+// ... whatever its size (a Reduce over materialised vectors is not told where the previous result ends): the state whose rows
+// are the first *size <= maxSize rows of these vectors
+std::shared_ptr<uint64_t> sorted_state_find(int device, const DimensionVector &v, const uint8_t *values, int valueBytes, int maxSize, int *size) {
+  if (!sorted_state_enabled() || maxSize <= 0) return nullptr;
+  std::lock_guard<std::mutex> lock(g_sortedMutex);
+  for (const SortedState &st : g_sorted)
+    if (st.device == device && st.dims == v.DimValues && st.values == values && st.capacity == static_cast<size_t>(v.VectorCapacity) &&
+        memcmp(st.ndw, v.NumDimsPerDimWidth, sizeof(st.ndw)) == 0 && st.valueBytes == valueBytes && st.size <= maxSize) {
+      *size = st.size;
+      return st.keys;
+    }
   return nullptr;
 }
 
@@ -741,11 +907,11 @@ int fused_sort_reduce_run(int device, const FusedPlanD &plan, int nd, bool const
     m.phases = phases;
   }
   if (vw == 8) {
-    ARES_LAUNCH("sr_merge_kernel", sr_merge_kernel<8>, numParts, kThreads, stream, m);
-    ARES_LAUNCH("sr_emit_kernel", sr_emit_kernel<8>, numParts, kThreads, stream, m, plan, L);
+    ARES_LAUNCH("sr_merge_kernel", (sr_merge_kernel<8, false>), numParts, kThreads, stream, m);
+    ARES_LAUNCH("sr_emit_kernel", (sr_emit_kernel<8, false>), numParts, kThreads, stream, m, plan, L);
   } else {
-    ARES_LAUNCH("sr_merge_kernel", sr_merge_kernel<4>, numParts, kThreads, stream, m);
-    ARES_LAUNCH("sr_emit_kernel", sr_emit_kernel<4>, numParts, kThreads, stream, m, plan, L);
+    ARES_LAUNCH("sr_merge_kernel", (sr_merge_kernel<4, false>), numParts, kThreads, stream, m);
+    ARES_LAUNCH("sr_emit_kernel", (sr_emit_kernel<4, false>), numParts, kThreads, stream, m, plan, L);
   }
   uint32_t w[3] = {0, 0, 0};
   read_back_u32(ws.outCount, w, 3, stream);
@@ -778,6 +944,217 @@ int fused_sort_reduce_run(int device, const FusedPlanD &plan, int nd, bool const
   // (the caller reported the output vectors as rewritten before this call: what is registered now describes the new rows)
   sorted_state_register(device, out, outValues, static_cast<size_t>(in.VectorCapacity), vw, static_cast<int>(w[0]), keysOut);
   return static_cast<int>(w[0]);
+}
+
+// Sort + Reduce over MATERIALISED vectors (rows [0, length) of `in` and `inValues` exist: the batch's dimensions came from a
+// join, a generic expression — anything the fused scans do not evaluate): the same aggregation by 64-bit row hash, in the
+// wide layout — the previous result is tens of millions of groups when this matters (50 M keys, 64 Mi rows per batch: four
+// radix passes over 114 M entries + the hashing pass + a reduce that gathers every entry's dimension row, 10 ms):
+//   sr_bounds_kernel   (previous result's row hashes known) each partition's range of them;
+//   sr_scan_rtc        (hr_rtc.hip: generate_vector, sort64) hashes rows [prev, length) — all rows when the previous result's
+//                      hashes are not known — into <= 512 level-1 partitions x streams;
+//   sr_split_kernel    deals each level-1 partition's records out to its partitions (2^pb <= 2^17 in all, ~1 k entries each);
+//   sr_merge_kernel    <WIDE>: 2048-slot tables, one run per partition;
+//   sr_prefix_kernel   groups before each partition;
+//   sr_emit_kernel     <WIDE>: the representatives' dimension rows copied from `in` (ascending: the previous result's rows come
+//                      out in the order they lie in).
+// 4-byte dimensions (up to eight) and 4-byte integer aggregates; returns like fused_sort_reduce_run.
+static int sort_reduce_vectors_run(int device, int length, const DimensionVector &in, const uint8_t *inValues, const DimensionVector &out,
+                                   uint8_t *outValues, const AggSpec &a, hipStream_t stream, int slack) {
+  static const bool trace = getenv("ARES_HR_TRACE") != nullptr;  // diagnostics
+  auto decline = [&](const char *why) {
+    if (trace) fprintf(stderr, "fused_sort_reduce_vectors: rows %d declined: %s\n", length, why);
+    return kFusedUnavailable;
+  };
+  if (!fused_sort_reduce_enabled() || !fused_sort_reduce_supported(a) || a.width != 4 || length <= 0) return decline("aggregate");
+  const DimLayoutD L = make_dim_layout(in.NumDimsPerDimWidth);
+  const int nd = L.numDims;
+  if (nd < 1 || nd > kFusedDims || in.NumDimsPerDimWidth[2] != nd) return decline("layout");
+  using T = Table<4, true>;
+  static EnvSwitch<int> maxGroups("ARES_SR_MAX_GROUPS", [](const char *e) { return e ? atoi(e) : 0; });
+  int tableGroups = T::kMaxGroups;
+  if (maxGroups.get() > 0 && maxGroups.get() < tableGroups) tableGroups = maxGroups.get();
+  // ARES_SRV_PART_BITS (tests): small inputs take the partition counts of production-sized ones
+  static EnvSwitch<int> forceBits("ARES_SRV_PART_BITS", [](const char *e) { return e ? atoi(e) : -1; });
+  int partBits = 0;
+  while ((static_cast<int64_t>(kWideEntries) << partBits) < length && partBits < kWideMaxPartBits) partBits++;
+  if (forceBits.get() >= 0) partBits = forceBits.get() < kWideMaxPartBits ? forceBits.get() : kWideMaxPartBits;
+  const int numParts = 1 << partBits;
+  if (static_cast<int64_t>(length) > static_cast<int64_t>(numParts) * tableGroups * 7 / 10) return decline("more rows than the tables take");  // (all rows may be groups)
+  const int pb1 = partBits < 9 ? partBits : 9, numParts1 = 1 << pb1;
+  RtcKernel scan = rtc_sort_vector_scan_lookup(device, nd, pb1);
+  if (!scan) return decline("scan kernel not available (yet)");  // being compiled in the background
+
+  int prevSize = 0;
+  const std::shared_ptr<uint64_t> prevKeys = sorted_state_find(device, in, inValues, 4, length, &prevSize);
+  if (!prevKeys) prevSize = 0;  // every row is hashed
+  const int batchRows = length - prevSize;
+
+  // ---- workspace: [head: flags][level-1 counts][cursors][partition counts][partition bases][bounds][level 1][level 2][staging][keys]
+  const int streams = batchRows > 0 ? rtc_scan_grid(batchRows) : 1;
+  // (`slack`: more room per level-1 stream after an overflow — for this call only: what overflows here is a previous result
+  // whose row hashes are not known, hashed again in the ascending order it lies in)
+  const uint64_t mean1 = (static_cast<uint64_t>(batchRows) / (static_cast<uint64_t>(numParts1) * streams)) << slack;
+  const uint32_t cap1 = static_cast<uint32_t>(((2 * mean1 + 64 + 7) / 8 * 8) | 8ull);
+  auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+  const size_t headBytes = up(sizeof(uint32_t) * 16);
+  const size_t counts1Bytes = up(sizeof(uint32_t) * static_cast<size_t>(numParts1) * streams);
+  const size_t cursorBytes = up(sizeof(uint32_t) * numParts);  // (twice: counts, cursors)
+  const size_t partBytes = up(sizeof(uint32_t) * (numParts + 1));
+  const size_t l1Bytes = up(sizeof(uint4) * static_cast<size_t>(cap1) * numParts1 * streams);
+  const size_t l2Bytes = up(sizeof(uint4) * (static_cast<size_t>(batchRows) + 16));
+  // staging (packed: one entry per row at most) shares the level-1 region: the split has read it before the merge stages anything
+  const size_t stageBytes = up(sizeof(uint4) * (static_cast<size_t>(length) + 16)), stageKeyBytes = up(sizeof(uint64_t) * (static_cast<size_t>(length) + 16));
+  const size_t sharedBytes = l1Bytes > stageBytes + stageKeyBytes ? l1Bytes : stageBytes + stageKeyBytes;
+  StreamBuffer buf(headBytes + counts1Bytes + 2 * cursorBytes + 4 * partBytes + sharedBytes + l2Bytes + 256, stream);
+  uint8_t *at = buf.as<uint8_t>();
+  auto take = [&](size_t bytes) {
+    uint8_t *p = at;
+    at += bytes;
+    return p;
+  };
+  uint32_t *flags = reinterpret_cast<uint32_t *>(take(headBytes));
+  uint32_t *counts1 = reinterpret_cast<uint32_t *>(take(counts1Bytes));
+  uint32_t *counts2 = reinterpret_cast<uint32_t *>(take(cursorBytes));
+  uint32_t *cursors2 = reinterpret_cast<uint32_t *>(take(cursorBytes));
+  hip_check(hipMemsetAsync(flags, 0, headBytes + counts1Bytes + 2 * cursorBytes, stream), "hipMemsetAsync");
+  uint32_t *offsets2 = reinterpret_cast<uint32_t *>(take(partBytes));
+  uint32_t *partCount = reinterpret_cast<uint32_t *>(take(partBytes));
+  uint32_t *partBase = reinterpret_cast<uint32_t *>(take(partBytes));
+  uint32_t *bounds = reinterpret_cast<uint32_t *>(take(partBytes));
+  uint8_t *shared = take(sharedBytes);
+  uint4 *rec1 = reinterpret_cast<uint4 *>(shared);
+  uint4 *rec2 = reinterpret_cast<uint4 *>(take(l2Bytes));
+
+  SrArgs m;
+  memset(&m, 0, sizeof(m));
+  m.recB = rec2;
+  m.countsB = counts2;
+  m.offsetsB = offsets2;
+  m.capB = 0;
+  m.streams = 1;
+  m.partBits = partBits;
+  m.dimIn = in.DimValues;
+  m.inValues = inValues;
+  m.inCapacity = static_cast<size_t>(in.VectorCapacity);
+  m.prevSize = static_cast<uint32_t>(prevSize);
+  m.widen.mode = 0;
+  m.widen.rk = a.vtype == V_I32 ? K_I32 : K_U32;
+  m.widen.dtype = a.vtype == V_I32 ? Int32 : Uint32;
+  m.agg = a;
+  m.staging = reinterpret_cast<uint4 *>(shared);
+  m.stageKeys = reinterpret_cast<uint64_t *>(shared + stageBytes);
+  m.partCount = partCount;
+  m.flags = flags;
+  m.maxGroups = static_cast<uint32_t>(tableGroups);
+  m.dimOut = out.DimValues;
+  m.outValues = outValues;
+  m.prevKeys = prevSize > 0 ? prevKeys.get() : nullptr;
+  m.prevBounds = prevSize > 0 ? bounds : nullptr;
+  m.partBase = partBase;
+  m.copyAll = 1;
+  const std::shared_ptr<uint64_t> keysOut = take_key_block(device, static_cast<size_t>(length), stream);
+  m.keysOut = keysOut.get();
+
+  if (prevSize > 0)
+    ARES_LAUNCH("sr_bounds_kernel", sr_bounds_kernel, (numParts + 1 + 255) / 256, 256, stream, prevKeys.get(), static_cast<uint32_t>(prevSize), partBits, bounds);
+  if (batchRows > 0) {
+    hr::Workspace ws;
+    memset(&ws, 0, sizeof(ws));
+    ws.outCount = flags;  // [0] groups, [1] overflow, [2] empty-key hash
+    ws.countsB = counts1;
+    ws.recB = reinterpret_cast<uint32_t *>(rec1);
+    ws.capB = cap1;
+    ws.streams = streams;
+    ws.partBits = pb1;
+    ws.lineRecords = 8;
+    ws.rowBase = static_cast<uint32_t>(prevSize);
+    rtc_sort_vector_scan_launch(scan, in.DimValues, static_cast<size_t>(in.VectorCapacity), inValues, nd, static_cast<uint32_t>(prevSize), batchRows, ws, stream);
+    SplitArgs sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.rec1 = rec1;
+    sp.counts1 = counts1;
+    sp.cap1 = cap1;
+    sp.streams = streams;
+    // ~4096 records per workgroup
+    const uint64_t run = static_cast<uint64_t>(batchRows) / (static_cast<uint64_t>(numParts1) * streams) + 1;
+    sp.group = static_cast<int>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(streams), 4096 / run)));
+    sp.pb1 = pb1;
+    sp.pb = partBits;
+    sp.rec2 = rec2;
+    sp.counts2 = counts2;
+    sp.offsets2 = offsets2;
+    sp.cursors2 = cursors2;
+    const int units = (streams + sp.group - 1) / sp.group;
+    ARES_LAUNCH("sr_count_kernel", sr_split_kernel<true>, numParts1 * units, 256, stream, sp);
+    ARES_LAUNCH("sr_prefix_kernel", sr_prefix_kernel, 1, 1024, stream, counts2, numParts, offsets2, flags + 4);
+    ARES_LAUNCH("sr_split_kernel", sr_split_kernel<false>, numParts1 * units, 256, stream, sp);
+  } else {
+    hip_check(hipMemsetAsync(offsets2, 0, partBytes, stream), "hipMemsetAsync");
+  }
+  static const bool phasesOn = [] {
+    const char *e = getenv("ARES_HR_PHASES");
+    return e && e[0] == '1';
+  }();
+  static uint64_t *phases = nullptr;
+  if (phasesOn) {
+    if (!phases) hip_check(hipMalloc(reinterpret_cast<void **>(&phases), sizeof(uint64_t) * 8 << kWideMaxPartBits), "hipMalloc");
+    hip_check(hipMemsetAsync(phases, 0, sizeof(uint64_t) * 8 * numParts, stream), "hipMemsetAsync");
+    m.phases = phases;
+  }
+  FusedPlanD noPlan;
+  memset(&noPlan, 0, sizeof(noPlan));
+  ARES_LAUNCH("sr_merge_kernel", (sr_merge_kernel<4, true>), numParts, T::kLanes, stream, m);
+  ARES_LAUNCH("sr_prefix_kernel", sr_prefix_kernel, 1, 1024, stream, partCount, numParts, partBase, flags);  // (flags[0]: groups)
+  ARES_LAUNCH("sr_emit_kernel", (sr_emit_kernel<4, true>), numParts, T::kLanes, stream, m, noPlan, L);
+  uint32_t w[4] = {0, 0, 0, 0};
+  read_back_u32(flags, w, 4, stream);
+  if (phasesOn) {  // diagnostics: where a partition's time goes
+    static int launches = 0;
+    std::vector<uint64_t> h(static_cast<size_t>(8) * numParts);
+    hip_check(hipMemcpy(h.data(), phases, sizeof(uint64_t) * h.size(), hipMemcpyDeviceToHost), "hipMemcpy");
+    if (++launches <= 6 || launches % 16 == 0) {
+      double sum[4] = {0, 0, 0, 0}, resident = 0;
+      uint64_t first = ~0ull, last = 0;
+      for (int p = 0; p < numParts; p++) {
+        const uint64_t *t = &h[static_cast<size_t>(8) * p];
+        if (t[5] < first) first = t[5];
+        if (t[4] > last) last = t[4];
+        for (int k = 0; k < 4; k++) sum[k] += static_cast<double>(t[k + 1] - t[k]) * 0.01;
+        resident += static_cast<double>(t[4] - t[5]) * 0.01;
+      }
+      const double span = static_cast<double>(last - first) * 0.01;
+      {
+        std::vector<double> ends, lives;
+        for (int p = 0; p < numParts; p++) {
+          ends.push_back(static_cast<double>(h[static_cast<size_t>(8) * p + 4] - first) * 0.01);
+          lives.push_back(static_cast<double>(h[static_cast<size_t>(8) * p + 4] - h[static_cast<size_t>(8) * p + 5]) * 0.01);
+        }
+        std::sort(ends.begin(), ends.end());
+        std::sort(lives.begin(), lives.end());
+        auto q = [&](const std::vector<double> &v, double f) { return v[static_cast<size_t>(f * (v.size() - 1))]; };
+        fprintf(stderr, "  workgroups done by: 50%% %.0f us, 90%% %.0f, 99%% %.0f, 100%% %.0f; lifetimes: median %.1f us, 90%% %.1f, 99%% %.1f, max %.1f; first starts spread %.0f us\n",
+                q(ends, 0.5), q(ends, 0.9), q(ends, 0.99), q(ends, 1.0), q(lives, 0.5), q(lives, 0.9), q(lives, 0.99), q(lives, 1.0),
+                static_cast<double>(h[5 + 8 * static_cast<size_t>(numParts - 1)] - first) * 0.01);
+      }
+      fprintf(stderr, "sr_merge_kernel<wide> phases (launch %d, %d partitions, prev %d, batch %d): span %.1f us, %.0f workgroups resident on average; per partition avg: clear %.1f + init %.1f + previous groups %.1f + records %.1f + order %.1f us\n",
+              launches, numParts, prevSize, batchRows, span, resident / span, resident / numParts - (sum[0] + sum[1] + sum[2] + sum[3]) / numParts, sum[0] / numParts,
+              sum[1] / numParts, sum[2] / numParts, sum[3] / numParts);
+    }
+  }
+  buf.mark_idle();
+  if (trace)
+    fprintf(stderr, "fused_sort_reduce_vectors: rows %d prev %d (hashes %s) partBits %d/%d streams %d cap1 %u -> groups %u stream overflow %u table overflow %u emptykey %u\n",
+            length, prevSize, prevKeys ? "known" : "unknown", pb1, partBits, streams, cap1, w[0], w[1], w[3], w[2]);
+  if (w[1] && !w[2] && !w[3] && slack < 3) return sort_reduce_vectors_run(device, length, in, inValues, out, outValues, a, stream, slack + 1);
+  if (w[1] || w[2] || w[3]) return -1;  // the outputs may be partly written: the caller runs the real Sort + Reduce over them
+  sorted_state_register(device, out, outValues, static_cast<size_t>(in.VectorCapacity), 4, static_cast<int>(w[0]), keysOut);
+  return static_cast<int>(w[0]);
+}
+
+int fused_sort_reduce_vectors(int device, int length, const DimensionVector &in, const uint8_t *inValues, const DimensionVector &out,
+                              uint8_t *outValues, const AggSpec &a, hipStream_t stream) {
+  return sort_reduce_vectors_run(device, length, in, inValues, out, outValues, a, stream, record_stream_slack());
 }
 
 }  // namespace ares

@@ -27,6 +27,11 @@ int fused_sort_reduce_run(int device, const FusedPlanD &plan, int nd, bool const
                           const DimensionVector &in, const uint8_t *inValues, int prevSize, const DimensionVector &out,
                           uint8_t *outValues, const AggSpec &a, hipStream_t stream);
 
+// The same over MATERIALISED vectors: rows [0, length) of `in` / `inValues` exist (4-byte dimensions, a 4-byte integer
+// aggregate); rows a previous fused Reduce left there are recognised by the row hashes kept beside them.  Returns alike.
+int fused_sort_reduce_vectors(int device, int length, const DimensionVector &in, const uint8_t *inValues, const DimensionVector &out,
+                              uint8_t *outValues, const AggSpec &a, hipStream_t stream);
+
 // something writes [ptr, ptr + bytes): row hashes a fused Reduce kept beside a result in there are forgotten (called by
 // grouped_note_write, which every writer of a result vector reports to)
 void sorted_state_note_write(int device, const void *ptr, size_t bytes);
@@ -37,6 +42,10 @@ int reduce_now(const DimensionVector &in, uint8_t *inputValues, const DimensionV
                int length, int aggFunc, hipStream_t stream);
 // transform.hip: Sort over rows whose transforms are still pending is DEFINED, not run (true = nothing left to do) ...
 bool define_lazy_sort(int device, hipStream_t stream, const DimensionVector &keys, int length);
+// ... or, when the rows exist (written by kernels): asked BEFORE Sort's flush (the index vector's lazy iota is kept from being
+// written), defined AFTER it (false: the index vector has been written, the caller sorts)
+bool lazy_vector_sort_candidate(int device, const DimensionVector &keys, int length);
+bool define_lazy_sort_vectors(int device, hipStream_t stream, const DimensionVector &keys, int length);
 // ... and Reduce consumes it together with the pending transforms (true = *groups is the result); false: whatever was lazy
 // about the inputs has been written, the caller runs the ordinary Reduce
 bool fuse_pending_into_sort_reduce(int device, hipStream_t stream, const DimensionVector &in, uint8_t *inValues,

@@ -292,6 +292,7 @@ struct PendingSort {
   DimensionVector keys;
   int length;
   bool reduced = false;
+  bool fromVectors = false;  // every row of `keys` exists (define_lazy_sort_vectors): no queue, no limbo — a replay is Sort [+ Reduce]
   // what a replay of the reduced state needs
   DimensionVector outKeys;
   uint8_t *inValues = nullptr, *outValues = nullptr;
@@ -789,7 +790,9 @@ static void materialize_sort(const uint32_t *indexVector) {
   const PendingSort s = it->second;
   drop_sort(indexVector);  // (the entries go first: nothing below finds them again)
   ReleaseSet released;
-  if (s.reduced) {
+  if (s.reduced && s.fromVectors) {
+    // (the rows exist: nothing to launch first)
+  } else if (s.reduced) {
     auto lim = t_state->limbo.find({s.device, s.stream});
     if (lim != t_state->limbo.end()) {
       lim->second.overWait = true;  // the host believes this work is long done
@@ -892,12 +895,13 @@ bool virtual_iota_peek(int device, const uint32_t *indexVector, int n, bool cons
 
 // an entry point reads (or rewrites) the buffers of a dimension vector with kernels: lazy fills inside them are written
 // first, and so is a lazy iota that a consumer has left behind
-void settle_dimension_vector(int device, const DimensionVector &v) {
+void settle_dimension_vector(int device, const DimensionVector &v, bool rowsOnly) {
   if (!defer_available()) return;
   const size_t cap = v.VectorCapacity > 0 ? static_cast<size_t>(v.VectorCapacity) : 0;
   size_t rowBytes = 0;
   for (int w = 0; w < NUM_DIM_WIDTH; w++) rowBytes += static_cast<size_t>(v.NumDimsPerDimWidth[w]) * ((1u << (NUM_DIM_WIDTH - 1 - w)) + 1);
   materialize_fills_for_read(device, v.DimValues, rowBytes * cap);
+  if (rowsOnly) return;  // (the caller is about to DEFINE the hash and index vector: define_lazy_sort_vectors)
   materialize_fills_for_read(device, v.HashValues, 8 * cap);
   materialize_fills_for_read(device, v.IndexVector, 4 * cap);
   materialize_index_vector(device, v.IndexVector);
@@ -2538,6 +2542,37 @@ bool same_vector(const DimensionVector &a, const DimensionVector &b) {
 }
 }  // namespace
 
+// caller holds the device's DeferLock.  A lazily defined Sort has been consumed by a Reduce whose kernels wrote `result` groups:
+// the hash vector, the input's index vector and the output's index vector stay DEFINED (what Sort and Reduce would have left
+// there); whoever reads them replays the sequence (materialize_sort)
+static void enter_reduced_sort(int device, hipStream_t stream, PendingSort ps, const DimensionVector &in, uint8_t *inValues,
+                               const DimensionVector &out, uint8_t *outValues, int valueBytes, int length, int aggFunc, int result) {
+  ps.reduced = true;
+  ps.outKeys = out;
+  ps.inValues = inValues;
+  ps.outValues = outValues;
+  ps.valueBytes = valueBytes;
+  ps.aggFunc = aggFunc;
+  ps.groups = result;
+  t_state->sorts[in.IndexVector] = ps;
+  PendingIota io{device, stream, 0, length};
+  io.consumed = true;
+  io.sorted = true;
+  t_state->iotas[in.IndexVector] = io;
+  uint8_t *hv = reinterpret_cast<uint8_t *>(in.HashValues);
+  retire_fills(device, ByteRange{hv, hv + 8ull * static_cast<size_t>(length)}, false);
+  PendingFill marker{device, stream, 8ull * static_cast<size_t>(length), 0, 8, false};
+  marker.sortIdx = in.IndexVector;
+  t_state->fills[hv] = marker;
+  if (result > 0) {
+    uint8_t *oi = reinterpret_cast<uint8_t *>(out.IndexVector);
+    retire_fills(device, ByteRange{oi, oi + 4ull * static_cast<size_t>(result)}, false);
+    PendingFill om{device, stream, 4ull * static_cast<size_t>(result), 0, 4, false};
+    om.sortIdx = in.IndexVector;
+    t_state->fills[oi] = om;
+  }
+}
+
 // Sort(keys, length) when the rows [length - n, length) of `keys` are what this stream's pending transforms would write and
 // the index vector is still the iota InitIndexVector defined: nothing is hashed or sorted — the hash vector (a marker among
 // the lazy fills) and the index vector (its iota entry, `sorted`) are DEFINED as what Sort leaves.  Reduce consumes the
@@ -2583,9 +2618,141 @@ bool define_lazy_sort(int device, hipStream_t stream, const DimensionVector &key
   return true;
 }
 
+// ---- Sort + Reduce over materialised vectors -----------------------------------------------------------------------------
+// The batch's dimension rows were written by kernels (a joined column, a generic expression, an eager host): Sort still need
+// not order ROWS for Reduce to order GROUPS (fused_sort_reduce_vectors).  Sort asks before its flush (the index vector's lazy
+// iota is marked consumed: the flush does not write it) ...
+namespace {
+bool vector_sort_enabled() {
+  static EnvSwitch<bool> on("ARES_SORT_VECTORS", [](const char *e) { return !(e && e[0] == '0'); });
+  return on.get();
+}
+bool vector_sort_layout(const DimensionVector &keys) {
+  int nd = 0;
+  for (int w = 0; w < NUM_DIM_WIDTH; w++) nd += keys.NumDimsPerDimWidth[w];
+  return nd >= 1 && nd <= kFusedDims && keys.NumDimsPerDimWidth[2] == nd;  // 4-byte dimensions only
+}
+}  // namespace
+
+bool lazy_vector_sort_candidate(int device, const DimensionVector &keys, int length) {
+  static const bool trace = getenv("ARES_HR_TRACE") != nullptr;  // diagnostics
+  if (trace)
+    fprintf(stderr, "lazy_vector_sort_candidate: rows %d fuse %d enabled %d switch %d layout %d capacity %d\n", length, fuse_available() ? 1 : 0,
+            fused_sort_reduce_enabled() ? 1 : 0, vector_sort_enabled() ? 1 : 0, vector_sort_layout(keys) ? 1 : 0, keys.VectorCapacity);
+  if (!fuse_available() || !fused_sort_reduce_enabled() || !vector_sort_enabled() || length <= 0 || !keys.DimValues || !keys.HashValues ||
+      !keys.IndexVector || keys.VectorCapacity < length || !vector_sort_layout(keys))
+    return false;
+  DeferLock lock(device);
+  auto io = t_state->iotas.find(keys.IndexVector);
+  if (io == t_state->iotas.end() || io->second.device != device || io->second.start != 0 || io->second.n != length || io->second.consumed ||
+      io->second.sorted) {
+    if (trace) fprintf(stderr, "lazy_vector_sort_candidate: index vector is %s\n", io == t_state->iotas.end() ? "not a lazy iota" : "a lazy iota of another kind");
+    return false;
+  }
+  io->second.consumed = true;
+  return true;
+}
+
+// ... and defines itself after it (every pending writer of the rows has been launched).  false: the index vector is written,
+// the caller sorts.
+bool define_lazy_sort_vectors(int device, hipStream_t stream, const DimensionVector &keys, int length) {
+  {
+    DeferLock lock(device);
+    auto io = t_state->iotas.find(keys.IndexVector);
+    if (io != t_state->iotas.end() && io->second.device == device && io->second.start == 0 && io->second.n == length && io->second.consumed &&
+        !io->second.sorted) {
+      uint8_t *hv = reinterpret_cast<uint8_t *>(keys.HashValues);
+      retire_fills(device, ByteRange{hv, hv + 8ull * static_cast<size_t>(length)}, false);
+      PendingSort ps{};
+      ps.device = device;
+      ps.stream = stream;
+      ps.keys = keys;
+      ps.length = length;
+      ps.fromVectors = true;
+      t_state->sorts[keys.IndexVector] = ps;
+      io->second.sorted = true;
+      PendingFill marker{device, stream, 8ull * static_cast<size_t>(length), 0, 8, false};
+      marker.sortIdx = keys.IndexVector;
+      t_state->fills[hv] = marker;
+      return true;
+    }
+  }
+  materialize_index_vector(device, keys.IndexVector);
+  return false;
+}
+
+// Reduce over a Sort defined that way.  Caller: fuse_pending_into_sort_reduce.
+static bool reduce_lazy_vector_sort(int device, hipStream_t stream, const DimensionVector &in, uint8_t *inValues, const DimensionVector &out,
+                                    uint8_t *outValues, int valueBytes, int length, int aggFunc, int *groups) {
+  PendingSort ps{};
+  AggSpec a{};
+  {
+    DeferLock lock(device);
+    auto st = t_state->sorts.find(in.IndexVector);
+    if (st == t_state->sorts.end()) return false;
+    ps = st->second;
+    bool ok = !ps.reduced && ps.fromVectors && ps.device == device && ps.stream == stream && ps.length == length && same_vector(ps.keys, in) &&
+              inValues && out.DimValues && out.IndexVector && outValues && out.VectorCapacity >= length && in.VectorCapacity >= length &&
+              memcmp(out.NumDimsPerDimWidth, in.NumDimsPerDimWidth, sizeof(in.NumDimsPerDimWidth)) == 0 && valueBytes == 4;
+    if (ok) {
+      try {
+        a = make_agg_spec(aggFunc, valueBytes);
+        ok = fused_sort_reduce_supported(a);
+      } catch (std::exception &) {
+        ok = false;
+      }
+    }
+    if (!ok) {
+      materialize_sort(in.IndexVector);
+      return false;
+    }
+    drop_sort(in.IndexVector);  // (while the kernels run nothing is defined; the reduced state is entered below)
+  }
+  const size_t rowBytes = static_cast<size_t>(5) * in.NumDimsPerDimWidth[2];
+  retire_fills_for_write(device, outValues, static_cast<size_t>(valueBytes) * length);
+  retire_fills_for_write(device, out.IndexVector, 4ull * static_cast<size_t>(length));
+  grouped_note_write(device, out);
+  grouped_note_write(device, outValues, static_cast<size_t>(valueBytes) * length);
+  drop_skipped_outputs(device, out.DimValues, rowBytes * static_cast<size_t>(in.VectorCapacity), outValues, static_cast<size_t>(valueBytes) * length);
+  // every row is read by this call's kernels: whatever still only defines one is written
+  launch_pending_writers(device, in.DimValues, rowBytes * static_cast<size_t>(in.VectorCapacity));
+  launch_pending_writers(device, inValues, static_cast<size_t>(valueBytes) * length);
+  materialize_fills_for_read(device, in.DimValues, rowBytes * static_cast<size_t>(in.VectorCapacity));
+  materialize_fills_for_read(device, inValues, static_cast<size_t>(valueBytes) * length);
+  int result;
+  try {
+    result = fused_sort_reduce_vectors(device, length, in, inValues, out, outValues, a, stream);
+  } catch (...) {
+    result = -1;
+  }
+  if (result < 0) {  // declined (a kernel still being compiled, too many rows), or a table overflowed: the real thing
+    {
+      DeferLock lock(device);
+      launch_init_index(in.IndexVector, 0, length, stream);
+    }
+    sort_keys_now(in, length, stream);
+    return false;
+  }
+  mem_note_dim_rows(device, out, 0, static_cast<size_t>(result));
+  mem_note_write(device, outValues, static_cast<size_t>(valueBytes) * static_cast<size_t>(result));
+  DeferLock lock(device);
+  enter_reduced_sort(device, stream, ps, in, inValues, out, outValues, valueBytes, length, aggFunc, result);
+  *groups = result;
+  return true;
+}
+
 bool fuse_pending_into_sort_reduce(int device, hipStream_t stream, const DimensionVector &in, uint8_t *inValues, const DimensionVector &out,
                                    uint8_t *outValues, int valueBytes, int length, int aggFunc, int *groups) {
   if (!fuse_available() || !in.IndexVector) return false;
+  {
+    bool vectors = false;
+    {
+      DeferLock lock(device);
+      auto st = t_state->sorts.find(in.IndexVector);
+      vectors = st != t_state->sorts.end() && st->second.fromVectors && !st->second.reduced;
+    }
+    if (vectors) return reduce_lazy_vector_sort(device, stream, in, inValues, out, outValues, valueBytes, length, aggFunc, groups);
+  }
   PendingQueue q;
   FusedPlanD plan;
   memset(&plan, 0, sizeof(plan));
@@ -2768,35 +2935,10 @@ bool fuse_pending_into_sort_reduce(int device, hipStream_t stream, const Dimensi
   DeferLock lock(device);
   q.sortIdx = in.IndexVector;
   t_state->limbo[{device, stream}] = q;  // launchable until the next batch begins (begin_batch)
-  ps.reduced = true;
-  ps.outKeys = out;
-  ps.inValues = inValues;
-  ps.outValues = outValues;
-  ps.valueBytes = valueBytes;
-  ps.aggFunc = aggFunc;
-  ps.groups = result;
   ps.constMeasure = constMeasure;
   ps.fill = fill;
   ps.fillAt = fillAt;
-  t_state->sorts[in.IndexVector] = ps;
-  PendingIota io{device, stream, 0, length};
-  io.consumed = true;
-  io.sorted = true;
-  t_state->iotas[in.IndexVector] = io;
-  {
-    uint8_t *hv = reinterpret_cast<uint8_t *>(in.HashValues);
-    retire_fills(device, ByteRange{hv, hv + 8ull * static_cast<size_t>(length)}, false);
-    PendingFill marker{device, stream, 8ull * static_cast<size_t>(length), 0, 8, false};
-    marker.sortIdx = in.IndexVector;
-    t_state->fills[hv] = marker;
-    if (result > 0) {
-      uint8_t *oi = reinterpret_cast<uint8_t *>(out.IndexVector);
-      retire_fills(device, ByteRange{oi, oi + 4ull * static_cast<size_t>(result)}, false);
-      PendingFill om{device, stream, 4ull * static_cast<size_t>(result), 0, 4, false};
-      om.sortIdx = in.IndexVector;
-      t_state->fills[oi] = om;
-    }
-  }
+  enter_reduced_sort(device, stream, ps, in, inValues, out, outValues, valueBytes, length, aggFunc, result);
   *groups = result;
   return true;
 }

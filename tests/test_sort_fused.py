@@ -89,10 +89,12 @@ SHAPES = [
 ]
 
 
-def run_sequence(b, shape, batches, read=frozenset(), cap_slack=10, hash_reduce=False):
+def run_sequence(b, shape, batches, read=frozenset(), cap_slack=10, hash_reduce=False, eager=False):
     """The Go host's per-batch sequence; returns every observable the test compares.  read: any of "iota" (the index
     vector between InitIndexVector and Sort), "sorted" (hash + index vector between Sort and Reduce), "after" (input hash /
-    index vector and output index vector after Reduce), "inputs" (input dimension and measure rows after Reduce)."""
+    index vector and output index vector after Reduce), "inputs" (input dimension and measure rows after Reduce).
+    eager: the host looks at the batch's dimension and measure rows before it sorts (so they are written: what a joined column
+    or a generic expression leads to as well)."""
     cap = sum(len(next(iter(bt.values()))[1]) for bt in batches) + cap_slack
     vb = shape.value_bytes
     dv = [H.DimVector(b, cap, shape.ndw, True, False) for _ in range(2)]   # dimension + hash vector pairs: swapped per batch
@@ -132,6 +134,8 @@ def run_sequence(b, shape, batches, read=frozenset(), cap_slack=10, hash_reduce=
             else:
                 b.call("UnaryTransform", cols[shape.measure].input(), mout, idx.ptr, kept, None, 0, abi.Noop, None, 0)
         b.wait()
+        if eager and kept > 0:
+            dv[0].rows(res + kept), vv[0].read(vtype, res + kept)
         for c in cols.values():  # cleanupBeforeAggregation
             c.free()
         idx.free(), pred.free()
@@ -366,3 +370,68 @@ def test_float_sums_keep_the_real_sort():
 
     got, want = seq(hip), seq(oracle)
     assert got[0] == want[0] and got[1] == want[1] and np.array_equal(got[2], want[2])
+
+
+# ---- Sort + Reduce over rows that exist (fused_sort_reduce_vectors: the wide layout) -----------------------------------------
+_VECTOR_SHAPES = [SHAPES[0], SHAPES[3], SHAPES[4],
+                  Shape("eight_u32_dims_count", _ALL4_COLS, [("k", abi.LessThan, 8)], [(c, None, 0, abi.Uint32) for c in "abcdefgh"], None,
+                        abi.AGGR_SUM_UNSIGNED, abi.Uint32, (0, 0, 8, 0, 0))]
+
+
+@pytest.mark.parametrize("part_bits", [None, 7, 12], ids=["default_bits", "128_partitions", "4096_partitions"])
+@pytest.mark.parametrize("shape", _VECTOR_SHAPES, ids=[s.name for s in _VECTOR_SHAPES])
+def test_sort_reduce_over_materialised_rows_orders_groups_not_rows(shape, part_bits, monkeypatch):
+    """The batch's rows were written before Sort (an eager host; a joined column): Sort is defined all the same and Reduce
+    aggregates by row hash in the wide layout — level-1 scan, split into 2^bits partitions (forced here: one level, and two
+    levels with a fan-out of 8), small tables, the previous result taken from the row hashes kept beside it.  Ordered output,
+    bit for bit; no radix pass, no reduce kernel."""
+    hip, oracle = H.hip_backend(), H.oracle_backend()
+    rng = np.random.default_rng(sum(map(ord, shape.name)) + 7)
+    batches = [make_batch(rng, shape, n) for n in (5000, 1, 40000, 700)]
+    want = run_sequence(oracle, shape, batches, eager=True)
+    if part_bits is not None:
+        monkeypatch.setenv("ARES_SRV_PART_BITS", str(part_bits))
+    hip.reload_env()
+    try:
+        got, kernels = _kernels_of(hip, lambda: run_sequence(hip, shape, batches, eager=True))
+    finally:
+        monkeypatch.undo()
+        hip.reload_env()
+    assert_same(got, want, shape.name)
+    if _fusion_on() and os.environ.get("ARES_SORT_VECTORS", "1") != "0":
+        assert any(k.startswith("sr_split_kernel") for k in kernels) and any(k.startswith("sr_merge_kernel") for k in kernels), sorted(kernels)
+        assert any(k.startswith("sr_bounds_kernel") for k in kernels), sorted(kernels)  # (the previous result was recognised)
+        # (63 groups over 512 forced level-1 partitions: a few streams take everything and overflow — that batch is sorted for real)
+        if not (shape.name == "max_unsigned" and part_bits == 12):
+            assert not any(k.startswith(("radix_pass_kernel", "reduce_kernel")) for k in kernels), sorted(kernels)
+
+
+@pytest.mark.parametrize("read", [("sorted",), ("after",), ("inputs",), ("iota", "sorted", "after", "inputs")], ids=lambda r: "+".join(r))
+def test_sort_over_materialised_rows_materialises_for_a_host_that_looks(read):
+    hip, oracle = H.hip_backend(), H.oracle_backend()
+    shape = SHAPES[0]
+    rng = np.random.default_rng(199 + len(read))
+    batches = [make_batch(rng, shape, n) for n in (3000, 9000, 50)]
+    got = run_sequence(hip, shape, batches, read=frozenset(read), eager=True)
+    want = run_sequence(oracle, shape, batches, read=frozenset(read), eager=True)
+    assert_same(got, want, (shape.name, read))
+
+
+def test_materialised_rows_with_too_many_groups_fall_back_to_the_real_sort(monkeypatch):
+    """A partition's table overflows (ARES_SR_MAX_GROUPS = 20, one partition forced): the ordinary Sort + Reduce runs over the
+    same buffers."""
+    hip, oracle = H.hip_backend(), H.oracle_backend()
+    shape = Shape("distinct", {"d1": (abi.Uint32, 1 << 30)}, [], [("d1", None, 0, abi.Uint32)], None, abi.AGGR_SUM_UNSIGNED, abi.Uint32, U32)
+    rng = np.random.default_rng(6)
+    batches = [make_batch(rng, shape, n, null_fraction=0) for n in (600, 500)]
+    want = run_sequence(oracle, shape, batches, read=frozenset(("after",)), eager=True)
+    monkeypatch.setenv("ARES_SR_MAX_GROUPS", "20")
+    monkeypatch.setenv("ARES_SRV_PART_BITS", "1")
+    hip.reload_env()
+    try:
+        got, kernels = _kernels_of(hip, lambda: run_sequence(hip, shape, batches, read=frozenset(("after",)), eager=True))
+    finally:
+        monkeypatch.undo()
+        hip.reload_env()
+    assert_same(got, want, "fallback")
+    assert any(k.startswith("radix_pass_kernel") or k.startswith("sort_") for k in kernels), sorted(kernels)

@@ -166,6 +166,10 @@ int main(int argc, char **argv) {
     ec.measure.col = -1; ec.measure.f = col(K_U32); ec.measure.f.bbits = 1; ec.measureDtype = Uint32; ec.measureWidth = 4;
     if (int rc = build(rtc_sort_scan_source(ec, 8, 9), "_8sort", "8-dimension sort scan (COUNT)")) return rc;
   }
+  // the vector-sourced sort scans (Sort + Reduce over materialised vectors: 64-bit row hash, up to eight 4-byte dimensions)
+  if (int rc = build(rtc_sort_vector_scan_source(2, 9), "_vsort2", "vector sort scan nd 2")) return rc;
+  if (int rc = build(rtc_sort_vector_scan_source(8, 9), "_vsort8", "vector sort scan nd 8")) return rc;
+  if (int rc = build(rtc_sort_vector_scan_source(1, 0), "_vsort1", "vector sort scan nd 1, one partition")) return rc;
   // the vector-sourced scan (HashReduce on materialised dimension / measure vectors)
   for (int vw = 4; vw <= 8; vw += 4)
     for (int nd = 1; nd <= 4; nd += 3) {

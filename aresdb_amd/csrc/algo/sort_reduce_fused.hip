@@ -196,6 +196,35 @@ __global__ __launch_bounds__((Table<VW, WIDE>::kLanes)) void sr_merge_kernel(SrA
   const int numParts = 1 << pb;
   const AggSpec a = m.agg;
   if (m.phases && tid == 0) m.phases[static_cast<size_t>(p) * 8 + 5] = wall_clock64();
+  // wide layout: a partition is a thousand entries — its life is a chain of memory latencies (bounds -> hashes and values of
+  // the previous groups; count and offset -> records).  Everything a lane needs first is requested here, before the table is
+  // cleared: two previous groups per lane, the wavefront's first chunk of records.
+  uint32_t wFrom = 0, wTo = 0, wCnt = 0;
+  const uint4 *wRun = m.recB;
+  uint64_t wKey[2] = {0, 0}, wVal[2] = {0, 0};
+  uint4 wRec[4];
+  if constexpr (WIDE) {
+    if (m.prevBounds) {
+      wFrom = m.prevBounds[p];
+      wTo = m.prevBounds[p + 1];
+    }
+    wCnt = m.countsB[p];
+    wRun = m.recB + m.offsetsB[p];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const uint32_t i = wFrom + static_cast<uint32_t>(k) * T::kLanes + tid;
+      if (i < wTo) {
+        wKey[k] = m.prevKeys[i];
+        wVal[k] = load_value_bits(m.inValues, a, i);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t i = static_cast<uint32_t>(wave) * 256u + static_cast<uint32_t>(k) * 64u + lane;
+      wRec[k] = *(i < wCnt ? wRun + i : m.recB);
+      wRec[k].x = i < wCnt ? wRec[k].x : kNoRow;
+    }
+  }
   for (int s = tid; s < T::kSlots; s += T::kLanes) {
     sKeys[s] = kEmptyKey;
     sRows[s] = kNoRow;
@@ -267,7 +296,17 @@ __global__ __launch_bounds__((Table<VW, WIDE>::kLanes)) void sr_merge_kernel(SrA
 
   // ---- previous groups.  Their row hashes are known (the query's previous Reduce left them, ascending, beside its result):
   // the partition's rows are the range of hashes that start with its bits — two binary searches, no hashing, no region A
-  if (m.prevKeys) {
+  if (WIDE) {
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const uint32_t i = wFrom + static_cast<uint32_t>(k) * T::kLanes + tid;
+      if (i < wTo) insert(i, static_cast<uint32_t>(wKey[k] >> 32), static_cast<uint32_t>(wKey[k]), wVal[k]);
+    }
+    for (uint32_t i = wFrom + 2u * T::kLanes + tid; i < wTo; i += T::kLanes) {
+      const uint64_t key = m.prevKeys[i];
+      insert(i, static_cast<uint32_t>(key >> 32), static_cast<uint32_t>(key), load_value_bits(m.inValues, a, i));
+    }
+  } else if (m.prevKeys) {
     auto lower = [&](uint64_t bound) {
       uint32_t lo = 0, hi = m.prevSize;
       while (lo < hi) {
@@ -399,13 +438,12 @@ __global__ __launch_bounds__((Table<VW, WIDE>::kLanes)) void sr_merge_kernel(SrA
     const uint32_t lpr = (maxRun + 7u) / 8u;  // lines of the longest run
     uint4 ra[4], rb[4];
     if constexpr (WIDE) {  // one run of a thousand records: chunks of 256 dealt to the four wavefronts (the CU's other workgroups cover the loads)
-      const uint32_t cnt = m.countsB[p];
-      const uint4 *run = m.recB + m.offsetsB[p];
-      for (uint32_t c = static_cast<uint32_t>(wave) * 256u; c < cnt; c += T::kLanes / 64 * 256u) {
-        const Chunk ch{run + c, cnt - c < 256u ? cnt - c : 256u};
+      if (static_cast<uint32_t>(wave) * 256u < wCnt) consume(wRec);  // (requested at the kernel's start)
+      for (uint32_t c = static_cast<uint32_t>(wave) * 256u + T::kLanes / 64 * 256u; c < wCnt; c += T::kLanes / 64 * 256u) {
+        if (__hip_atomic_load(&sBad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+        const Chunk ch{wRun + c, wCnt - c < 256u ? wCnt - c : 256u};
         load(ra, ch);
         consume(ra);
-        if (__hip_atomic_load(&sBad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
       }
     } else if (m.streams > 0 && lpr >= 1u && lpr <= 4u) {
       const uint32_t units = static_cast<uint32_t>(m.streams) * 8u * lpr;
@@ -587,9 +625,9 @@ __global__ __launch_bounds__(256) void sr_bounds_kernel(const uint64_t *prevKeys
 // The scan's records lie in [workgroup][level-1 partition] streams (up to 512 partitions: what the scan's line staging
 // holds); each level-1 partition is dealt out to its 2^(pb - pb1) partitions by the hash's next bits, into runs of EXACTLY
 // the partition's size (a key that a million rows share fills one partition: no capacity to guess).  One workgroup per
-// (level-1 partition, group of streams), twice: COUNT adds its records per partition (LDS histogram, one global atomic per
-// partition it meets); after the prefix over the counts the second launch reserves its share of each run with one atomic
-// per partition and writes the records there.  Order within a partition does not matter to the merge (lowest row by atomic
+// (level-1 partition, group of streams), twice: sr_count_kernel adds its records per partition (LDS histogram, one global
+// atomic per partition it meets); after the prefix over the counts sr_split_kernel reserves its share of each run with one
+// atomic per partition and writes the records there.  Order within a partition does not matter to the merge (lowest row by atomic
 // min, integer aggregates).
 struct SplitArgs {
   const uint4 *rec1;
@@ -597,13 +635,12 @@ struct SplitArgs {
   uint32_t cap1;
   int streams, group, pb1, pb;
   uint4 *rec2;
-  uint32_t *counts2;         // COUNT: records per partition
+  uint32_t *counts2;         // records per partition (sr_count_kernel)
   const uint32_t *offsets2;  // their exclusive prefix
   uint32_t *cursors2;        // records placed so far
 };
-template <bool COUNT>
-__global__ __launch_bounds__(256) void sr_split_kernel(SplitArgs s) {
-  __shared__ uint32_t sHist[256], sBase[256];
+__global__ __launch_bounds__(256) void sr_count_kernel(SplitArgs s) {
+  __shared__ uint32_t sHist[256];
   const int tid = threadIdx.x;
   const int units = (s.streams + s.group - 1) / s.group;
   const int p1 = blockIdx.x / units, unit = blockIdx.x - p1 * units;
@@ -622,27 +659,95 @@ __global__ __launch_bounds__(256) void sr_split_kernel(SplitArgs s) {
     }
   }
   __syncthreads();
+  if (tid < fan && sHist[tid]) atomicAdd(s.counts2 + (static_cast<uint32_t>(p1) << sb) + tid, sHist[tid]);
+}
+
+// ... the second launch: tiles of 2048 records (the unit's runs taken as one sequence) are ordered by partition in LDS —
+// histogram, prefix, one reservation per partition met — and written out in that order: a partition's share of the tile is
+// one contiguous piece (written record by record in arrival order, 16 bytes here and 16 there, the same data took twice as long)
+constexpr int kSplitTile = 2048, kSplitPerLane = kSplitTile / 256;
+__global__ __launch_bounds__(256) void sr_split_kernel(SplitArgs s) {
+  __shared__ uint4 sTile[kSplitTile];
+  __shared__ uint32_t sHist[256], sStart[256], sBase[256], sRunStart[257], sWaveSum[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int units = (s.streams + s.group - 1) / s.group;
+  const int p1 = blockIdx.x / units, unit = blockIdx.x - p1 * units;
+  const int numParts1 = 1 << s.pb1, sb = s.pb - s.pb1;
+  const int g0 = unit * s.group, g1 = g0 + s.group < s.streams ? g0 + s.group : s.streams, runs = g1 - g0;
+  auto sub_of = [&](const uint4 &r) { return sb ? (r.y << s.pb1) >> (32 - sb) : 0u; };
   const uint32_t first = static_cast<uint32_t>(p1) << sb;
-  if (tid < fan) {
-    const uint32_t c = sHist[tid];
-    if (COUNT) {
-      if (c) atomicAdd(s.counts2 + first + tid, c);
-    } else {
-      sBase[tid] = s.offsets2[first + tid] + (c ? atomicAdd(s.cursors2 + first + tid, c) : 0u);
-      sHist[tid] = 0;
+  // the unit's runs as one sequence: sRunStart[k] = records before run k (runs <= 256: one per lane, scanned by the workgroup)
+  {
+    uint32_t c = 0;
+    if (tid < runs) {
+      const uint32_t stored = s.counts1[static_cast<uint64_t>(g0 + tid) * numParts1 + p1];
+      c = stored < s.cap1 ? stored : s.cap1;
     }
+    uint32_t incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(incl, off);
+      if (lane >= off) incl += t;
+    }
+    if (lane == 63) sWaveSum[wave] = incl;
+    __syncthreads();
+    uint32_t before = incl - c;
+    for (int w = 0; w < wave; w++) before += sWaveSum[w];
+    sRunStart[tid] = before;
+    if (tid == 255) sRunStart[256] = before + c;
+    __syncthreads();
   }
-  if (COUNT) return;
-  __syncthreads();
-  for (int g = g0; g < g1; g++) {
-    const uint32_t stored = s.counts1[static_cast<uint64_t>(g) * numParts1 + p1], cnt = stored < s.cap1 ? stored : s.cap1;
-    const uint4 *run = s.rec1 + (static_cast<uint64_t>(g) * numParts1 + p1) * s.cap1;
-    for (uint32_t i = tid; i < cnt; i += 256) {
-      const uint4 r = run[i];
-      if (r.x == kNoRow) continue;
-      const uint32_t sub = sub_of(r);
-      s.rec2[sBase[sub] + __hip_atomic_fetch_add(sHist + sub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)] = r;
+  const uint32_t total = sRunStart[runs < 256 ? runs : 256];
+  for (uint32_t tile = 0; tile < total; tile += kSplitTile) {
+    sHist[tid] = 0;
+    __syncthreads();
+    uint4 r[kSplitPerLane];
+    uint32_t rank[kSplitPerLane];
+#pragma unroll
+    for (int k = 0; k < kSplitPerLane; k++) {
+      const uint32_t j = tile + static_cast<uint32_t>(k) * 256u + tid;
+      r[k].x = kNoRow;
+      if (j < total) {
+        int lo = 0, hi = runs - 1;  // the run that holds record j: last k with sRunStart[k] <= j
+        while (lo < hi) {
+          const int mid = (lo + hi + 1) >> 1;
+          if (sRunStart[mid] <= j) lo = mid; else hi = mid - 1;
+        }
+        r[k] = s.rec1[(static_cast<uint64_t>(g0 + lo) * numParts1 + p1) * s.cap1 + (j - sRunStart[lo])];
+      }
     }
+#pragma unroll
+    for (int k = 0; k < kSplitPerLane; k++)
+      rank[k] = r[k].x != kNoRow ? __hip_atomic_fetch_add(sHist + sub_of(r[k]), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+    __syncthreads();
+    {  // where each partition's piece starts in the tile, and in the partition's run
+      const uint32_t c = sHist[tid];
+      uint32_t incl = c;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+      }
+      if (lane == 63) sWaveSum[wave] = incl;
+      __syncthreads();
+      uint32_t before = incl - c;
+      for (int w = 0; w < wave; w++) before += sWaveSum[w];
+      sStart[tid] = before;
+      sBase[tid] = c ? s.offsets2[first + tid] + atomicAdd(s.cursors2 + first + tid, c) : 0u;
+    }
+    __syncthreads();
+    uint32_t kept = 0;
+#pragma unroll
+    for (int k = 0; k < kSplitPerLane; k++)
+      if (r[k].x != kNoRow) sTile[sStart[sub_of(r[k])] + rank[k]] = r[k];
+    kept = sStart[255] + sHist[255];
+    __syncthreads();
+    for (uint32_t j = tid; j < kept; j += 256) {
+      const uint4 q = sTile[j];
+      const uint32_t sub = sub_of(q);
+      s.rec2[sBase[sub] + (j - sStart[sub])] = q;
+    }
+    __syncthreads();
   }
 }
 
@@ -1086,9 +1191,9 @@ static int sort_reduce_vectors_run(int device, int length, const DimensionVector
     sp.offsets2 = offsets2;
     sp.cursors2 = cursors2;
     const int units = (streams + sp.group - 1) / sp.group;
-    ARES_LAUNCH("sr_count_kernel", sr_split_kernel<true>, numParts1 * units, 256, stream, sp);
+    ARES_LAUNCH("sr_count_kernel", sr_count_kernel, numParts1 * units, 256, stream, sp);
     ARES_LAUNCH("sr_prefix_kernel", sr_prefix_kernel, 1, 1024, stream, counts2, numParts, offsets2, flags + 4);
-    ARES_LAUNCH("sr_split_kernel", sr_split_kernel<false>, numParts1 * units, 256, stream, sp);
+    ARES_LAUNCH("sr_split_kernel", sr_split_kernel, numParts1 * units, 256, stream, sp);
   } else {
     hip_check(hipMemsetAsync(offsets2, 0, partBytes, stream), "hipMemsetAsync");
   }

@@ -1402,6 +1402,11 @@ static bool constant_measure_bits(const EvalParams &p, const SinkD &s, uint64_t 
   }
 }
 
+static bool foreign_gather_enabled() {
+  static EnvSwitch<bool> on("ARES_FOREIGN_GATHER", [](const char *e) { return !(e && e[0] == '0'); });
+  return on.get();
+}
+
 static int run_transform(const InputVector *ins, int arity, const OutputVector &output, uint32_t *indexVector,
                          int n, uint32_t *baseCounts, uint32_t startCount, int functor, hipStream_t stream, int device) {
   if (n <= 0) {
@@ -1463,6 +1468,11 @@ static int run_transform(const InputVector *ins, int arity, const OutputVector &
   } else if (is_wide(p.a.kind)) {
     const int grid = capped_grid((static_cast<int64_t>(n) + kBlock - 1) / kBlock);
     ARES_LAUNCH("transform_wide_kernel", transform_wide_kernel, grid, kBlock, stream, p, s, n);
+  } else if (foreign_gather_enabled() && p.arity == 1 && functor == Noop && p.a.type == OP_FOREIGN && !p.a.tz && !p.needRow && !s.baseCounts) {
+    // a joined column into a dimension / measure vector: the join's transform on its own kernel
+    constexpr int ITEMS = 8;
+    const int grid = capped_grid((static_cast<int64_t>(n) + kBlock * ITEMS - 1) / (kBlock * ITEMS), 256 * 16);
+    ARES_LAUNCH("transform_foreign_kernel", transform_foreign_kernel<ITEMS>, grid, kBlock, stream, p, s, n);
   } else {
     constexpr int ITEMS = 4;
     const int grid = capped_grid((static_cast<int64_t>(n) + kBlock * ITEMS - 1) / (kBlock * ITEMS), 256 * 16);

@@ -124,8 +124,12 @@ def c4_spec(be, dev, rows, nkeys, batch_rows=1 << 26):
     nbatches = (rows + batch_rows - 1) // batch_rows
     q = NativeQuery(be, plan, ["fk", "amount"])
     kernels, busy = {}, 0.0
+    model = {}  # algorithmic bytes per kernel over the whole leg (the C4 table)
+    def account(name, nbytes):
+        model[name] = model.get(name, 0) + nbytes
     for b in range(nbatches):
         n = min(batch_rows, rows - b * batch_rows)
+        prev_groups = q.result_size if b else 0
         # the first batches walk the keys in order so that every key occurs; the rest draw at random
         pick = (torch.arange(b * batch_rows, b * batch_rows + n, device=dev) % len(usable)) if (b + 1) * batch_rows <= len(usable) + batch_rows \
             else torch.randint(0, len(usable), (n,), device=dev, generator=g)
@@ -140,6 +144,17 @@ def c4_spec(be, dev, rows, nkeys, batch_rows=1 << 26):
             c0, m0 = kernels.get(name, (0, 0.0)); kernels[name] = (c0 + c, m0 + ms)
         be.profiler_enable(False)
         del cf, ca
+        ng = q.result_size
+        nd = 2
+        account("hash_lookup_kernel", n * (128 + 4 + 8))             # one 104-byte bucket (two sectors pairs) + key + RecordID out
+        account("transform_foreign_kernel", n * (8 + 32 + 4 + 1))   # RecordID + the value's sector + dimension slot + validity byte
+        account("transform32_kernel", n * (8 + 32 + 4 + 1))         # (the same work when ARES_FOREIGN_GATHER=0)
+        account("transform_fast_kernel", n * (4 + 4 + 1) + n * (4 + 4))  # fk -> dimension slot, amount -> measure vector
+        account("sr_vector_scan_rtc", n * (nd * 5 + 4 + 16))        # dimension rows + value read, one 16-byte record written
+        account("sr_count_kernel", n * 16)
+        account("sr_split_kernel", n * (16 + 16))                   # (the second read of a workgroup's records comes from L2)
+        account("sr_merge_kernel", n * 16 + prev_groups * (8 + 4) + ng * 24)  # records + previous hashes / values in, staged groups out
+        account("sr_emit_kernel", ng * (24 + nd * 5 + nd * 5 + 4 + 8))    # staged group + its dimension row in; row, value, hash out
     groups = q.result_size
     dims, valids, meas = q.fetch()
     got_fk, got_attr, got_sum = dims[0].view(np.uint32), dims[1].view(np.uint32), meas.view(np.uint32)
@@ -158,6 +173,10 @@ def c4_spec(be, dev, rows, nkeys, batch_rows=1 << 26):
            "cuckoo_table_MB": len(table) / 1e6, "cuckoo_build_s": build_s, "groups": groups, "key_level_check": "ok" if ok else "MISMATCH",
            "ms": busy * 1e3, "rows_per_s": rows / busy,
            "kernels": {n: {"launches": c, "avg_ms": ms / c, "total_ms": ms} for n, (c, ms) in sorted(kernels.items(), key=lambda kv: -kv[1][1])}}
+    out["kernel_rooflines"] = {
+        name: {"bound": "hbm", "unit": "GB/s", "peak": 8000.0, "algorithmic_GB": model[name] / 1e9,
+               "achieved": model[name] / (kernels[name][1] * 1e-3) / 1e9, "frac": model[name] / (kernels[name][1] * 1e-3) / 1e9 / 8000.0}
+        for name in model if name in kernels and kernels[name][1] > 0}
     if look:
         per_launch_rows = rows / look[0]
         out["hash_lookup_roofline"] = {"bound": "hbm", "unit": "GB/s", "peak": 8000.0, "bytes_per_row": 128 + 4 + 8,

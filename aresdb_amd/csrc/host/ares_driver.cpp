@@ -1533,16 +1533,61 @@ int AresQueryRunHostBatches(AresQuery *q, const AresHostColumn *columns, int num
     if (cache)
       for (uint64_t k : b->pinned) cache->unpin(k);
   };
+  // ONE executor thread for the whole call (a thread per batch pays for its thread-local state in the library — a mapped pinned
+  // result slot from hipHostMalloc among it — on every batch): batches are handed over one at a time
+  struct Executor {
+    std::mutex mu;
+    std::condition_variable cv;
+    Staged *job = nullptr;
+    bool busy = false, quit = false;
+    std::thread thread;
+  } ex;
+  auto submit = [&](Staged *b) {
+    std::lock_guard<std::mutex> lock(ex.mu);
+    ex.job = b;
+    ex.busy = true;
+    ex.cv.notify_all();
+  };
+  auto wait_idle = [&] {
+    std::unique_lock<std::mutex> lock(ex.mu);
+    ex.cv.wait(lock, [&] { return !ex.busy; });
+  };
+  auto stop = [&] {
+    {
+      std::lock_guard<std::mutex> lock(ex.mu);
+      ex.quit = true;
+      ex.cv.notify_all();
+    }
+    if (ex.thread.joinable()) ex.thread.join();
+  };
   try {
     Staged prev, cur;
     bool havePrev = false;
+    if (numBatches > 1)
+      ex.thread = std::thread([&] {
+        for (;;) {
+          Staged *b = nullptr;
+          {
+            std::unique_lock<std::mutex> lock(ex.mu);
+            ex.cv.wait(lock, [&] { return ex.quit || ex.job; });
+            if (!ex.job) return;
+            b = ex.job;
+            ex.job = nullptr;
+          }
+          run_staged(b);
+          {
+            std::lock_guard<std::mutex> lock(ex.mu);
+            ex.busy = false;
+            ex.cv.notify_all();
+          }
+        }
+      });
     for (int k = 0; k < numBatches; k++) {
       // (query/aql_processor.go:850-881) async transfer of batch k ...
       void *xfer = havePrev && q->otherStream ? q->otherStream : q->stream;
       cur = Staged();
       cur.size = batchSizes[k];
-      std::thread worker;
-      if (havePrev) worker = std::thread(run_staged, &prev);  // ... while batch k-1 executes
+      if (havePrev) submit(&prev);  // ... while batch k-1 executes
       try {
         for (int c = 0; c < numColumns; c++) {
           const AresHostColumn &hc = columns[static_cast<size_t>(k) * numColumns + c];
@@ -1564,15 +1609,24 @@ int AresQueryRunHostBatches(AresQuery *q, const AresHostColumn *columns, int num
         }
         check(q->lib->WaitForCudaStream(xfer, q->device));  // wait for the data transfer of the current batch
       } catch (...) {
-        if (worker.joinable()) worker.join();
+        wait_idle();
+        stop();
         throw;
       }
-      if (worker.joinable()) worker.join();
+      wait_idle();
       if (!workerError.empty()) throw AbiError(workerError);
       prev = cur;
       havePrev = true;
     }
-    if (havePrev) run_staged(&prev);
+    if (havePrev) {
+      if (ex.thread.joinable()) {
+        submit(&prev);
+        wait_idle();
+      } else {
+        run_staged(&prev);
+      }
+    }
+    stop();
     if (!workerError.empty()) throw AbiError(workerError);
     if (stats) {
       stats[0] = uploadedBytes;
@@ -1582,6 +1636,7 @@ int AresQueryRunHostBatches(AresQuery *q, const AresHostColumn *columns, int num
     }
     return 0;
   } catch (std::exception &e) {
+    stop();
     set_err(err, errLen, e.what());
     return -1;
   }

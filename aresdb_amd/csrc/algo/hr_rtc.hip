@@ -338,7 +338,9 @@ bool gen_agg(std::ostringstream &o, const AggSpec &a) {
 // Records are counting-sorted by partition in LDS and ONLY whole lines of 8 records leave the CU, each written
 // by 8 adjacent lanes with one store; the < 8 records a partition has left over stay in LDS and go first in
 // the next tile's lines.  Streams are private to the workgroup: no global atomics.
-static void kernel_body_lines16(std::ostringstream &o, const char *fourth, const char *entry = "hr_scan_rtc") {
+// part: the partition of row j's hash (default: its top PB bits)
+static void kernel_body_lines16(std::ostringstream &o, const char *fourth, const char *entry = "hr_scan_rtc",
+                                const char *part = "(PB ? hh[j] >> (32 - (PB ? PB : 1)) : 0u)") {
   phase_macros(o);
   o << "#define T 4096u\n"
        "__device__ __forceinline__ u32 lane_up(u32 v, u32 lane, u32 off) { return (u32)__builtin_amdgcn_ds_bpermute((int)((lane - off) << 2), (int)v); }\n"
@@ -368,7 +370,7 @@ static void kernel_body_lines16(std::ostringstream &o, const char *fourth, const
        "#pragma unroll\n"
        "    for (int j = 0; j < 4; j++) {\n"
        "      rank[j] = 0u;\n"
-       "      if (alive[j]) rank[j] = __hip_atomic_fetch_add(&cnt[PB ? hh[j] >> (32 - (PB ? PB : 1)) : 0u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
+       "      if (alive[j]) rank[j] = __hip_atomic_fetch_add(&cnt[" << part << "], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
        "    }\n"
        "    __syncthreads();\n"
        "    PH(0)\n"
@@ -396,7 +398,7 @@ static void kernel_body_lines16(std::ostringstream &o, const char *fourth, const
        "    PH(1)\n"
        "#pragma unroll\n"
        "    for (int j = 0; j < 4; j++)\n"
-       "      if (alive[j]) sRec[sStart[PB ? hh[j] >> (32 - (PB ? PB : 1)) : 0u] + rank[j]] = make_uint4(a.rowBase + i0 + j, hh[j], cv[j], " << fourth << ");\n"
+       "      if (alive[j]) sRec[sStart[" << part << "] + rank[j]] = make_uint4(a.rowBase + i0 + j, hh[j], cv[j], " << fourth << ");\n"
        "    __syncthreads();\n"
        "    PH(2)\n"
        // whole lines: 8 adjacent lanes write the 8 records of one aligned 128-byte line with one store;
@@ -1153,7 +1155,15 @@ std::string generate_vector(int nd, int vw, int partBits, bool sort64 = false) {
        "  eval4(r, a, i0, hh, cv, cw, alive);\n"
        "  load_tile(r, a, i0n);\n"
        "}\n";
-  kernel_body_lines16(o, "cw[j]", sort64 ? "sr_scan_rtc" : "hr_scan_rtc");
+  // (sort64: the level-1 partition of the wide layout is the hash's top PB bits, or — a.pad set: a previous result whose row
+  // hashes are not known is hashed again, rows in ascending hash order of which every tile falls into ONE such partition —
+  // the LOW PB bits of the top-bits partition index (a.chunkTiles = 32 - total partition bits) XORed with a scramble of its
+  // leading bits: the tiles one workgroup scans lie a multiple of a power of two apart, the plain low bits would repeat)
+  if (sort64)
+    kernel_body_lines16(o, "cw[j]", "sr_scan_rtc",
+                        "(a.pad ? (((hh[j] >> a.chunkTiles) ^ ((((hh[j] >> a.chunkTiles) >> PB) * 0x9E3779B1u) >> 23)) & (NP - 1u)) "
+                        ": (PB ? hh[j] >> (32 - (PB ? PB : 1)) : 0u))");
+  else kernel_body_lines16(o, "cw[j]", "hr_scan_rtc");
   return o.str();
 }
 
@@ -2338,7 +2348,7 @@ RtcKernel rtc_sort_vector_scan_lookup(int device, int nd, int partBits, bool wai
   return compiled_kernel(device, generate_vector(nd, 4, partBits, true), "sr_scan_rtc", wait);
 }
 void rtc_sort_vector_scan_launch(const RtcKernel &kernel, const uint8_t *dimValues, size_t capacity, const uint8_t *values, int nd,
-                                 uint32_t rowBase, int length, const hr::Workspace &ws, hipStream_t stream) {
+                                 uint32_t rowBase, int length, int totalPartBits, bool spread, const hr::Workspace &ws, hipStream_t stream) {
   FusedPlanD plan;
   memset(&plan, 0, sizeof(plan));
   plan.numCols = nd + 1;
@@ -2349,6 +2359,8 @@ void rtc_sort_vector_scan_launch(const RtcKernel &kernel, const uint8_t *dimValu
   plan.cols[nd].vals = reinterpret_cast<const uint32_t *>(values) + rowBase;
   RtcArgs args;
   fill_scan_args(args, plan, rowBase, length, ws);
+  args.chunkTiles = totalPartBits > 0 ? static_cast<uint32_t>(32 - totalPartBits) : 0u;  // (the partition expression's shift)
+  args.pad = spread ? 1u : 0u;
   launch_scan(kernel, args, ws.streams, length, stream, "sr_vector_scan_rtc");
 }
 std::string rtc_sort_vector_scan_source(int nd, int partBits) { return generate_vector(nd, 4, partBits, true); }

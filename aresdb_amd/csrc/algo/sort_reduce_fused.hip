@@ -693,7 +693,7 @@ __global__ __launch_bounds__(256) void sr_bounds_kernel(const uint64_t *prevKeys
 }
 
 // The scan's records lie in [workgroup][level-1 partition] streams (up to 512 partitions: what the scan's line staging
-// holds); each level-1 partition is dealt out to its 2^(pb - pb1) partitions by the hash's next bits, into runs of EXACTLY
+// holds); each level-1 partition is dealt out to its 2^(pb - pb1) partitions by the hash's top bits, into runs of EXACTLY
 // the partition's size (a key that a million rows share fills one partition: no capacity to guess).  One workgroup per
 // (level-1 partition, group of streams), twice: sr_count_kernel adds its records per partition (LDS histogram, one global
 // atomic per partition it meets); after the prefix over the counts sr_split_kernel reserves its share of each run with one
@@ -703,12 +703,23 @@ struct SplitArgs {
   const uint4 *rec1;
   const uint32_t *counts1;
   uint32_t cap1;
-  int streams, group, pb1, pb;
+  int streams, group, pb1, pb, spread;
   uint4 *rec2;
   uint32_t *counts2;         // records per partition (sr_count_kernel)
   const uint32_t *offsets2;  // their exclusive prefix
   uint32_t *cursors2;        // records placed so far
 };
+// the `sub`-th partition of level-1 partition p1.  spread: the scan filed a hash under (low pb1 bits of its partition index) XOR
+// scramble(leading bits) — generate_vector, hr_rtc.hip —, `sub` = the leading bits
+__device__ __forceinline__ uint32_t split_partition(uint32_t sub, uint32_t p1, const SplitArgs &s) {
+  if (!s.spread) return (p1 << (s.pb - s.pb1)) + sub;  // (level 1 = the hash's top bits, `sub` the bits below)
+  const uint32_t mask = (1u << s.pb1) - 1u;
+  return (sub << s.pb1) | ((p1 ^ ((sub * 0x9E3779B1u) >> 23)) & mask);
+}
+__device__ __forceinline__ uint32_t split_sub(const uint4 &r, const SplitArgs &s) {
+  const int sb = s.pb - s.pb1;
+  return !sb ? 0u : s.spread ? r.y >> (32 - sb) : (r.y << s.pb1) >> (32 - sb);
+}
 __global__ __launch_bounds__(256) void sr_count_kernel(SplitArgs s) {
   __shared__ uint32_t sHist[256];
   const int tid = threadIdx.x;
@@ -716,8 +727,7 @@ __global__ __launch_bounds__(256) void sr_count_kernel(SplitArgs s) {
   const int p1 = blockIdx.x / units, unit = blockIdx.x - p1 * units;
   const int numParts1 = 1 << s.pb1, sb = s.pb - s.pb1, fan = 1 << sb;
   const int g0 = unit * s.group, g1 = g0 + s.group < s.streams ? g0 + s.group : s.streams;
-  // partition of a record within its level-1 partition: the hash bits right below the level-1 bits (pb <= 17: all in the high word)
-  auto sub_of = [&](const uint4 &r) { return sb ? (r.y << s.pb1) >> (32 - sb) : 0u; };
+  auto sub_of = [&](const uint4 &r) { return split_sub(r, s); };
   sHist[tid] = 0;
   __syncthreads();
   for (int g = g0; g < g1; g++) {
@@ -729,7 +739,7 @@ __global__ __launch_bounds__(256) void sr_count_kernel(SplitArgs s) {
     }
   }
   __syncthreads();
-  if (tid < fan && sHist[tid]) atomicAdd(s.counts2 + (static_cast<uint32_t>(p1) << sb) + tid, sHist[tid]);
+  if (tid < fan && sHist[tid]) atomicAdd(s.counts2 + split_partition(static_cast<uint32_t>(tid), static_cast<uint32_t>(p1), s), sHist[tid]);
 }
 
 // ... the second launch: tiles of 2048 records (the unit's runs taken as one sequence) are ordered by partition in LDS —
@@ -744,8 +754,7 @@ __global__ __launch_bounds__(256) void sr_split_kernel(SplitArgs s) {
   const int p1 = blockIdx.x / units, unit = blockIdx.x - p1 * units;
   const int numParts1 = 1 << s.pb1, sb = s.pb - s.pb1;
   const int g0 = unit * s.group, g1 = g0 + s.group < s.streams ? g0 + s.group : s.streams, runs = g1 - g0;
-  auto sub_of = [&](const uint4 &r) { return sb ? (r.y << s.pb1) >> (32 - sb) : 0u; };
-  const uint32_t first = static_cast<uint32_t>(p1) << sb;
+  auto sub_of = [&](const uint4 &r) { return split_sub(r, s); };
   // the unit's runs as one sequence: sRunStart[k] = records before run k (runs <= 256: one per lane, scanned by the workgroup)
   {
     uint32_t c = 0;
@@ -803,7 +812,8 @@ __global__ __launch_bounds__(256) void sr_split_kernel(SplitArgs s) {
       uint32_t before = incl - c;
       for (int w = 0; w < wave; w++) before += sWaveSum[w];
       sStart[tid] = before;
-      sBase[tid] = c ? s.offsets2[first + tid] + atomicAdd(s.cursors2 + first + tid, c) : 0u;
+      const uint32_t part = split_partition(static_cast<uint32_t>(tid), static_cast<uint32_t>(p1), s);
+      sBase[tid] = c ? s.offsets2[part] + atomicAdd(s.cursors2 + part, c) : 0u;
     }
     __syncthreads();
     uint32_t kept = 0;
@@ -1135,7 +1145,7 @@ int fused_sort_reduce_run(int device, const FusedPlanD &plan, int nd, bool const
 //                      out in the order they lie in).
 // 4-byte dimensions (up to eight) and 4-byte integer aggregates; returns like fused_sort_reduce_run.
 static int sort_reduce_vectors_run(int device, int length, const DimensionVector &in, const uint8_t *inValues, const DimensionVector &out,
-                                   uint8_t *outValues, const AggSpec &a, hipStream_t stream, int slack) {
+                                   uint8_t *outValues, const AggSpec &a, hipStream_t stream, int slack, bool spread) {
   static const bool trace = getenv("ARES_HR_TRACE") != nullptr;  // diagnostics
   auto decline = [&](const char *why) {
     if (trace) fprintf(stderr, "fused_sort_reduce_vectors: rows %d declined: %s\n", length, why);
@@ -1244,7 +1254,7 @@ static int sort_reduce_vectors_run(int device, int length, const DimensionVector
     ws.partBits = pb1;
     ws.lineRecords = 8;
     ws.rowBase = static_cast<uint32_t>(prevSize);
-    rtc_sort_vector_scan_launch(scan, in.DimValues, static_cast<size_t>(in.VectorCapacity), inValues, nd, static_cast<uint32_t>(prevSize), batchRows, ws, stream);
+    rtc_sort_vector_scan_launch(scan, in.DimValues, static_cast<size_t>(in.VectorCapacity), inValues, nd, static_cast<uint32_t>(prevSize), batchRows, partBits, spread, ws, stream);
     SplitArgs sp;
     memset(&sp, 0, sizeof(sp));
     sp.rec1 = rec1;
@@ -1256,6 +1266,7 @@ static int sort_reduce_vectors_run(int device, int length, const DimensionVector
     sp.group = static_cast<int>(std::max<uint64_t>(1, std::min<uint64_t>(static_cast<uint64_t>(streams), 4096 / run)));
     sp.pb1 = pb1;
     sp.pb = partBits;
+    sp.spread = spread ? 1 : 0;
     sp.rec2 = rec2;
     sp.counts2 = counts2;
     sp.offsets2 = offsets2;
@@ -1319,9 +1330,13 @@ static int sort_reduce_vectors_run(int device, int length, const DimensionVector
   }
   buf.mark_idle();
   if (trace)
-    fprintf(stderr, "fused_sort_reduce_vectors: rows %d prev %d (hashes %s) partBits %d/%d streams %d cap1 %u -> groups %u stream overflow %u table overflow %u emptykey %u\n",
-            length, prevSize, prevKeys ? "known" : "unknown", pb1, partBits, streams, cap1, w[0], w[1], w[3], w[2]);
-  if (w[1] && !w[2] && !w[3] && slack < 3) return sort_reduce_vectors_run(device, length, in, inValues, out, outValues, a, stream, slack + 1);
+    fprintf(stderr, "fused_sort_reduce_vectors: rows %d prev %d (hashes %s) partBits %d/%d%s streams %d cap1 %u -> groups %u stream overflow %u table overflow %u emptykey %u\n",
+            length, prevSize, prevKeys ? "known" : "unknown", pb1, partBits, spread ? " spread" : "", streams, cap1, w[0], w[1], w[3], w[2]);
+  // a level-1 stream overflowed.  Hashes of the previous result unknown: its rows lie in hash order, tile after tile into one
+  // stream each — again with the level-1 partitions spread (and more room: a workgroup's tiles still meet by chance);
+  // otherwise with more room
+  if (w[1] && !w[2] && !w[3] && !prevKeys && !spread) return sort_reduce_vectors_run(device, length, in, inValues, out, outValues, a, stream, slack + 1, true);
+  if (w[1] && !w[2] && !w[3] && slack < 3) return sort_reduce_vectors_run(device, length, in, inValues, out, outValues, a, stream, slack + 1, spread);
   if (w[1] || w[2] || w[3]) return -1;  // the outputs may be partly written: the caller runs the real Sort + Reduce over them
   sorted_state_register(device, out, outValues, static_cast<size_t>(in.VectorCapacity), 4, static_cast<int>(w[0]), keysOut);
   return static_cast<int>(w[0]);
@@ -1329,7 +1344,7 @@ static int sort_reduce_vectors_run(int device, int length, const DimensionVector
 
 int fused_sort_reduce_vectors(int device, int length, const DimensionVector &in, const uint8_t *inValues, const DimensionVector &out,
                               uint8_t *outValues, const AggSpec &a, hipStream_t stream) {
-  return sort_reduce_vectors_run(device, length, in, inValues, out, outValues, a, stream, record_stream_slack());
+  return sort_reduce_vectors_run(device, length, in, inValues, out, outValues, a, stream, record_stream_slack(), false);
 }
 
 }  // namespace ares

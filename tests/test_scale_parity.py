@@ -166,7 +166,10 @@ def build_cuckoo_u32(keys, num_buckets, seeds, per_batch, base_batch_id=1):
 def test_c4_join_sort_reduce_at_16m_groups():
     """C4 towards its stated shape: a 16.7 M-key cuckoo index (348 MB of buckets: every probe is an
     HBM access) joined to the fact table, group by (fk, joined attribute) through Sort + Reduce —
-    one group per key.  Batch 1 holds every key once, batch 2 draws keys at random."""
+    one group per key.  Batch 1 holds every key once, batches 2 and 3 draw keys at random (the result buffers grow before
+    batch 2, so its previous result is hashed again; batch 3 finds the row hashes batch 2 left beside its result).  On the
+    HIP side the reduction orders GROUPS, not rows (fused_sort_reduce_vectors, the wide layout: 2^15 partitions here) — the
+    16.7 M output rows must be in ascending order of their 64-bit row hash, like a sort's."""
     import torch
     be = H.hip_backend()
     rng = np.random.default_rng(6)
@@ -195,15 +198,24 @@ def test_c4_join_sort_reduce_at_16m_groups():
     q = NativeQuery(be, plan, ["fk", "amount"])
     sums = np.zeros(nkeys, np.int64)
     from aresdb_amd.columns import DeviceColumn
-    for batch in range(2):
+    be.profiler_enable(True)
+    for batch in range(3):
         pick = rng.permutation(usable) if batch == 0 else usable[rng.integers(0, len(usable), 1 << 24)]
         amount = rng.integers(0, 100, len(pick)).astype(np.uint32)
         cf, ca = DeviceColumn(be, abi.Uint32, keys[pick]), DeviceColumn(be, abi.Uint32, amount)
         q.run({"fk": cf.vp, "amount": ca.vp}, len(pick))
         cf.free(); ca.free()
         sums += np.bincount(pick, weights=amount, minlength=nkeys).astype(np.int64)
+    be.wait()
+    kernels = be.profiler_report()
+    be.profiler_enable(False)
     dims, valids, meas = q.fetch()
     assert q.result_size == len(usable)
+    from aresdb_amd import check
+    hashes = check.row_hashes_of_fetched(dims, valids)
+    assert (hashes[1:] > hashes[:-1]).all(), "output rows not in ascending order of the row hash"
+    if all(os.environ.get(k, "1") != "0" for k in ("ARES_FUSE", "ARES_DEFER", "ARES_SORT_FUSE", "ARES_RTC", "ARES_SORT_VECTORS")):
+        assert "sr_split_kernel" in kernels and "sr_bounds_kernel" in kernels and "radix_pass_kernel" not in kernels, sorted(kernels)
     got_fk, got_attr, got_sum = dims[0].view(np.uint32), dims[1].view(np.uint32), meas.view(np.uint32)
     assert valids[0].all() and valids[1].all()
     order = np.argsort(got_fk)

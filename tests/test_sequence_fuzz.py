@@ -48,8 +48,10 @@ class Program:
         aggregation path, Sort + Reduce, and the host LOOKS at what only a sort leaves behind: the hash / index vector between
         Sort and Reduce, the input's hash / index vector and the output's index vector after Reduce, and the output rows in
         their order (ascending 64-bit hash) — a Sort that was only defined (sort_reduce_fused.hip) has to materialise, a
-        Reduce that consumed it has to be replayed.  None draws from the program's random stream: a seed is the same program
-        in every profile."""
+        Reduce that consumed it has to be replayed; "eager" — the host looks at the batch's dimension rows before every
+        reduction, so they exist when Sort is called (what a join or a generic expression leads to as well): Sort + Reduce over
+        materialised vectors (fused_sort_reduce_vectors: the wide layout).  None draws from the program's random stream: a
+        seed is the same program in every profile."""
         self.seed = seed
         self.profile = tuple(profile)
 
@@ -203,7 +205,8 @@ class Program:
             if free_before:
                 for x in list(cols.values()) + [idx, pred]:
                     x.free()
-            if size and rng.random() < 0.15:  # the reduction's input rows, observed before the reduction
+            look = rng.random() < 0.15
+            if size and (look or "eager" in self.profile):  # the reduction's input rows, observed before the reduction
                 vo, no, w = offsets(cap)[0]
                 obs.append(("dim_rows_before", b, _d2h(be, dims[0].ptr + vo + w * prev, w * size, stream).tobytes()))
             length = prev + size
@@ -294,7 +297,7 @@ def _same(a, b, seed):
 
 SEEDS = list(range(1000, 1160))
 PROFILES = [(), ("narrow",), ("drift",), ("narrow", "drift"), ("prealloc",), ("prealloc", "narrow"), ("prealloc", "drift"),
-            ("sort",), ("sort", "narrow"), ("sort", "prealloc"), ("sort", "drift")]
+            ("sort",), ("sort", "narrow"), ("sort", "prealloc"), ("sort", "drift"), ("sort", "eager"), ("sort", "eager", "prealloc")]
 
 
 @pytest.mark.gpu
@@ -303,6 +306,18 @@ def test_random_programs_match_the_oracle(chunk):
     hip, oracle = H.hip_backend(), H.oracle_backend()
     for k, seed in enumerate(SEEDS[chunk::8]):
         p = Program(seed, PROFILES[k % len(PROFILES)])
+        want = p.run(oracle)
+        _same(p.run(hip, expect=want), want, seed)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("profile", [("sort", "eager"), ("sort", "eager", "prealloc")], ids=lambda p: "+".join(p))
+def test_random_programs_sorting_rows_that_exist(profile):
+    """48 more programs in the "eager" profiles alone: every reduction is a Sort + Reduce over rows the host has looked at,
+    with the hash / index vectors and the output order observed (fused_sort_reduce_vectors and its replay)."""
+    hip, oracle = H.hip_backend(), H.oracle_backend()
+    for seed in range(3000, 3048):
+        p = Program(seed, profile)
         want = p.run(oracle)
         _same(p.run(hip, expect=want), want, seed)
 

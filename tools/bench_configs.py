@@ -122,6 +122,21 @@ def c4_spec(be, dev, rows, nkeys, batch_rows=1 << 26):
     keys_d = torch.from_numpy(keys[usable].astype(np.int64)).to(dev)
     sums = torch.zeros(len(usable), dtype=torch.float64, device=dev)
     nbatches = (rows + batch_rows - 1) // batch_rows
+    # priming pass, as bench.py's legs do: the shape's run-time kernel (the vector-sourced sort scan: dimension count and level-1
+    # partition bits) is compiled in the background on first use — the batches that arrive before it is loaded take the real sort
+    compiles = -1
+    for _ in range(3):
+        pq = NativeQuery(be, plan, ["fk", "amount"])
+        pn = 1 << 21
+        pick = torch.randint(0, len(usable), (pn,), device=dev, generator=g)
+        pcf = workload._pack_column(keys_d[pick].to(torch.int32), None, abi.Uint32)
+        pca = workload._pack_column(torch.ones(pn, dtype=torch.int32, device=dev), None, abi.Uint32)
+        pq.run({"fk": pcf.vp, "amount": pca.vp}, pn)
+        be.wait(); pq.release(); del pcf, pca, pick
+        state = be.rtc_wait()
+        if state is None or state["compiles"] == compiles:
+            break
+        compiles = state["compiles"]
     q = NativeQuery(be, plan, ["fk", "amount"])
     kernels, busy = {}, 0.0
     model = {}  # algorithmic bytes per kernel over the whole leg (the C4 table)

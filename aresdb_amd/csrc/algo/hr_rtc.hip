@@ -1082,28 +1082,65 @@ std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t null
 // rowBase, vals[nd] = the measures at rowBase.  Records carry the whole value: {row, hash, lo, hi}.
 // sort64: the Sort + Reduce path over materialised vectors (sort_reduce_fused.hip): records {row, hash64 >> 32, the 4-byte value,
 // (u32)hash64} keyed by lo64(murmur3_x64_128) of the packed row, partition = top bits of the 64-bit hash; up to eight dimensions.
-std::string generate_vector(int nd, int vw, int partBits, bool sort64 = false) {
+// widths (sort64 only): the dimension slots' bytes in vector order (4 / 2 / 1, descending); null: all four bytes
+std::string generate_vector(int nd, int vw, int partBits, bool sort64 = false, const int *widths = nullptr) {
   if (nd < 1 || nd > (sort64 ? kFusedDims : kGenericFusedDims) || (vw != 4 && vw != 8) || (sort64 && vw != 4)) return "";
+  int width[kFusedDims] = {4, 4, 4, 4, 4, 4, 4, 4};
+  bool narrow = false;
+  for (int d = 0; widths && d < nd; d++) {
+    if ((widths[d] != 4 && widths[d] != 2 && widths[d] != 1) || (d && widths[d] > widths[d - 1]) || !sort64) return "";
+    width[d] = widths[d];
+    narrow = narrow || widths[d] != 4;
+  }
   std::ostringstream o;
   const int mq = vw / 4;
   o << times5_text() << kPrelude << (sort64 ? kPrelude64 : "") << args_text()
     << "#define ND " << nd << "\n#define MQ " << mq << "\n#define PB " << partBits << "\n#define NP " << (1 << partBits) << "\n"
        "struct Raw { u32 v[ND][4]; u32 ok[ND]; u32 m[MQ * 4]; };\n"
-       "__device__ __forceinline__ void load_full(Raw &r, const Args &a, u32 i0) {\n"
-       "#pragma unroll\n"
+       "__device__ __forceinline__ void load_full(Raw &r, const Args &a, u32 i0) {\n";
+  if (narrow) {  // (slot by slot: a 2-byte slot's four rows are one 8-byte load, a 1-byte slot's one 4-byte load)
+    for (int d = 0; d < nd; d++) {
+      if (width[d] == 4)
+        o << "  { const PU32x4 t = *reinterpret_cast<const PU32x4 *>(a.vals[" << d << "] + i0); r.v[" << d << "][0] = t.v[0]; r.v[" << d
+          << "][1] = t.v[1]; r.v[" << d << "][2] = t.v[2]; r.v[" << d << "][3] = t.v[3]; }\n";
+      else if (width[d] == 2)
+        o << "  { const PU32x2 t = *reinterpret_cast<const PU32x2 *>(reinterpret_cast<const u8 *>(a.vals[" << d << "]) + 2ull * i0); r.v[" << d
+          << "][0] = t.v[0] & 0xFFFFu; r.v[" << d << "][1] = t.v[0] >> 16; r.v[" << d << "][2] = t.v[1] & 0xFFFFu; r.v[" << d << "][3] = t.v[1] >> 16; }\n";
+      else
+        o << "  { const u32 t = reinterpret_cast<const PU32 *>(reinterpret_cast<const u8 *>(a.vals[" << d << "]) + i0)->v; r.v[" << d
+          << "][0] = t & 0xFFu; r.v[" << d << "][1] = (t >> 8) & 0xFFu; r.v[" << d << "][2] = (t >> 16) & 0xFFu; r.v[" << d << "][3] = t >> 24; }\n";
+      o << "  r.ok[" << d << "] = reinterpret_cast<const PU32 *>(a.nulls[" << d << "] + i0)->v;\n";
+    }
+  } else {
+  o << "#pragma unroll\n"
        "  for (int d = 0; d < ND; d++) {\n"
        "    const PU32x4 t = *reinterpret_cast<const PU32x4 *>(a.vals[d] + i0);\n"
        "    r.v[d][0] = t.v[0]; r.v[d][1] = t.v[1]; r.v[d][2] = t.v[2]; r.v[d][3] = t.v[3];\n"
        "    r.ok[d] = reinterpret_cast<const PU32 *>(a.nulls[d] + i0)->v;\n"
-       "  }\n"
+       "  }\n";
+  }
+  o << ""
        "#pragma unroll\n"
        "  for (int q = 0; q < MQ; q++) {\n"
        "    const PU32x4 t = *reinterpret_cast<const PU32x4 *>(a.vals[ND] + (u64)i0 * MQ + 4 * q);\n"
        "    r.m[4 * q] = t.v[0]; r.m[4 * q + 1] = t.v[1]; r.m[4 * q + 2] = t.v[2]; r.m[4 * q + 3] = t.v[3];\n"
        "  }\n"
        "}\n"
-       "__device__ __forceinline__ void load_tail(Raw &r, const Args &a, u32 i0) {\n"
-       "#pragma unroll\n"
+       "__device__ __forceinline__ void load_tail(Raw &r, const Args &a, u32 i0) {\n";
+  if (narrow) {
+    for (int d = 0; d < nd; d++) {
+      const char *elem = width[d] == 4 ? "a.vals[%d][i0 + j]" : width[d] == 2 ? "(u32)reinterpret_cast<const u16 *>(a.vals[%d])[i0 + j]" : "(u32)reinterpret_cast<const u8 *>(a.vals[%d])[i0 + j]";
+      char buf[128];
+      snprintf(buf, sizeof(buf), elem, d);
+      o << "  r.ok[" << d << "] = 0u;\n"
+           "  for (int j = 0; j < 4; j++) {\n"
+           "    const bool in = (int)(i0 + j) < a.length;\n"
+           "    r.v[" << d << "][j] = in ? " << buf << " : 0u;\n"
+           "    r.ok[" << d << "] |= in ? (u32)a.nulls[" << d << "][i0 + j] << (8 * j) : 0u;\n"
+           "  }\n";
+    }
+  } else {
+  o << "#pragma unroll\n"
        "  for (int d = 0; d < ND; d++) {\n"
        "    r.ok[d] = 0u;\n"
        "    for (int j = 0; j < 4; j++) {\n"
@@ -1111,8 +1148,9 @@ std::string generate_vector(int nd, int vw, int partBits, bool sort64 = false) {
        "      r.v[d][j] = in ? a.vals[d][i0 + j] : 0u;\n"
        "      r.ok[d] |= in ? (u32)a.nulls[d][i0 + j] << (8 * j) : 0u;\n"
        "    }\n"
-       "  }\n"
-       "  for (int j = 0; j < 4; j++)\n"
+       "  }\n";
+  }
+  o << "  for (int j = 0; j < 4; j++)\n"
        "    for (int q = 0; q < MQ; q++) r.m[j * MQ + q] = (int)(i0 + j) < a.length ? a.vals[ND][(u64)(i0 + j) * MQ + q] : 0u;\n"
        "}\n"
        // Murmur32Stream over the packed row (dim_layout.hpp): values, then the validity bytes — one more block
@@ -1125,10 +1163,10 @@ std::string generate_vector(int nd, int vw, int partBits, bool sort64 = false) {
     SlotLayout SL;
     SL.nd = nd;
     for (int d = 0; d < nd; d++) {
-      SL.width[d] = 4;
-      SL.off[d] = 4 * d;
+      SL.width[d] = width[d];
+      SL.off[d] = SL.valueBytes;
+      SL.valueBytes += width[d];
     }
-    SL.valueBytes = 4 * nd;
     o << "    u64 h64;\n";
     gen_row_hash64(o, SL, [](int d) { return "r.v[" + std::to_string(d) + "][j]"; },
                    [](int d) { return "((r.ok[" + std::to_string(d) + "] >> (8 * j)) & 0xFFu)"; }, "h64", "    ");
@@ -2343,27 +2381,32 @@ void rtc_vector_scan_launch(const RtcKernel &kernel, const uint8_t *dimValues, s
 
 std::string rtc_vector_scan_source(int nd, int vw, int partBits) { return generate_vector(nd, vw, partBits); }
 
-RtcKernel rtc_sort_vector_scan_lookup(int device, int nd, int partBits, bool wait) {
+RtcKernel rtc_sort_vector_scan_lookup(int device, int nd, const int *widths, int partBits, bool wait) {
   if (!rtc_api().ok) return nullptr;
-  return compiled_kernel(device, generate_vector(nd, 4, partBits, true), "sr_scan_rtc", wait);
+  return compiled_kernel(device, generate_vector(nd, 4, partBits, true, widths), "sr_scan_rtc", wait);
 }
 void rtc_sort_vector_scan_launch(const RtcKernel &kernel, const uint8_t *dimValues, size_t capacity, const uint8_t *values, int nd,
-                                 uint32_t rowBase, int length, int totalPartBits, bool spread, const hr::Workspace &ws, hipStream_t stream) {
+                                 const int *widths, uint32_t rowBase, int length, int totalPartBits, bool spread, const hr::Workspace &ws,
+                                 hipStream_t stream) {
   FusedPlanD plan;
   memset(&plan, 0, sizeof(plan));
   plan.numCols = nd + 1;
+  size_t valueBytes = 0, off = 0;
+  for (int d = 0; d < nd; d++) valueBytes += static_cast<size_t>(widths ? widths[d] : 4);
   for (int d = 0; d < nd; d++) {
-    plan.cols[d].vals = reinterpret_cast<const uint32_t *>(dimValues + 4ull * d * capacity) + rowBase;
-    plan.cols[d].nulls = dimValues + 4ull * nd * capacity + static_cast<size_t>(d) * capacity + rowBase;
+    const size_t w = static_cast<size_t>(widths ? widths[d] : 4);
+    plan.cols[d].vals = reinterpret_cast<const uint32_t *>(dimValues + off * capacity + w * rowBase);
+    plan.cols[d].nulls = dimValues + valueBytes * capacity + static_cast<size_t>(d) * capacity + rowBase;
+    off += w;
   }
-  plan.cols[nd].vals = reinterpret_cast<const uint32_t *>(values) + rowBase;
+  plan.cols[nd].vals = reinterpret_cast<const uint32_t *>(values) + rowBase;  // (8-byte values: read at this stride and ignored)
   RtcArgs args;
   fill_scan_args(args, plan, rowBase, length, ws);
   args.chunkTiles = totalPartBits > 0 ? static_cast<uint32_t>(32 - totalPartBits) : 0u;  // (the partition expression's shift)
   args.pad = spread ? 1u : 0u;
   launch_scan(kernel, args, ws.streams, length, stream, "sr_vector_scan_rtc");
 }
-std::string rtc_sort_vector_scan_source(int nd, int partBits) { return generate_vector(nd, 4, partBits, true); }
+std::string rtc_sort_vector_scan_source(int nd, const int *widths, int partBits) { return generate_vector(nd, 4, partBits, true, widths); }
 
 RtcKernel rtc_vector_merge_lookup(int device, int nd, int vw, int partBits, const AggSpec &a, bool wait) {
   if (!rtc_api().ok) return nullptr;

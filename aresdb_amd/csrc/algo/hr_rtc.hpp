@@ -48,13 +48,15 @@ RtcKernel rtc_sort_scan_lookup(int device, const FusedPlanD &plan, int nd, int p
 void rtc_sort_scan_launch(const RtcKernel &kernel, const FusedPlanD &plan, uint32_t rowBase, int length, const hr::Workspace &ws,
                           hipStream_t stream);
 std::string rtc_sort_scan_source(const FusedPlanD &plan, int nd, int partBits);
-// ... and over rows [rowBase, rowBase + length) of a materialised dimension vector of `nd` 4-byte dimensions and a measure vector of 4-byte values
+// ... and over rows [rowBase, rowBase + length) of a materialised dimension vector of `nd` dimensions (widths: 4 / 2 / 1 bytes in vector
+// order, null = all four bytes) and a measure vector of 4-byte values
 // (Sort + Reduce after joins or generic expressions): the same records, the value carried whole; the level-1 partition is the
 // hash's top partBits bits or — spread — the scrambled low partBits bits of its top totalPartBits bits (sort_reduce_fused.hip)
-RtcKernel rtc_sort_vector_scan_lookup(int device, int nd, int partBits, bool wait = false);
+RtcKernel rtc_sort_vector_scan_lookup(int device, int nd, const int *widths, int partBits, bool wait = false);
 void rtc_sort_vector_scan_launch(const RtcKernel &kernel, const uint8_t *dimValues, size_t capacity, const uint8_t *values, int nd,
-                                 uint32_t rowBase, int length, int totalPartBits, bool spread, const hr::Workspace &ws, hipStream_t stream);
-std::string rtc_sort_vector_scan_source(int nd, int partBits);
+                                 const int *widths, uint32_t rowBase, int length, int totalPartBits, bool spread, const hr::Workspace &ws,
+                                 hipStream_t stream);
+std::string rtc_sort_vector_scan_source(int nd, const int *widths, int partBits);
 // TABLE-mode scan of `plan` (low cardinality): LDS aggregation per workgroup, one record per group into region A
 // (what hr::flush_table writes), rtc_scan_grid(length) workgroups; the generic merge reads it.
 RtcKernel rtc_table_scan_lookup(int device, const FusedPlanD &plan, int nd, int partBits, const AggSpec &a, const hr::Widen &w,

@@ -111,6 +111,7 @@ struct SrArgs {
   const uint32_t *offsetsB;
   const uint32_t *partBase;
   int copyAll;
+  int gatherValues;  // (wide, 8-byte values: a record has no room for one — the merge reads inValues[row])
   uint64_t *phases;  // ARES_HR_PHASES=1 (diagnostics): six time stamps per partition (100 MHz clock), else null
 };
 
@@ -374,7 +375,7 @@ __global__ __launch_bounds__((Table<VW, WIDE>::kLanes)) void sr_merge_kernel(SrA
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (static_cast<uint32_t>(lane) < count) {
         const uint4 q = queue[first + lane];
-        insert(q.x, q.y, q.w, m.constMeasure ? m.constBits : hr::widen_value(m.widen, q.z));
+        insert(q.x, q.y, q.w, m.constMeasure ? m.constBits : m.gatherValues ? load_value_bits(m.inValues, a, q.x) : hr::widen_value(m.widen, q.z));
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
@@ -399,7 +400,7 @@ __global__ __launch_bounds__((Table<VW, WIDE>::kLanes)) void sr_merge_kernel(SrA
         const bool m0 = u[k].x == lo && u[k].y == hi, m1 = u[k].z == lo && u[k].w == hi, m2 = v[k].x == lo && v[k].y == hi, m3 = v[k].z == lo && v[k].w == hi;
         const bool hit = valid && (m0 || m1 || m2 || m3) && (hi & lo) != 0xFFFFFFFFu;
         const uint32_t slot = hit ? 4u * bkt[k] + (m0 ? 0u : m1 ? 1u : m2 ? 2u : 3u) : static_cast<uint32_t>(T::kSlots);
-        const uint64_t value = m.constMeasure ? m.constBits : hr::widen_value(m.widen, r[k].z);
+        const uint64_t value = m.constMeasure ? m.constBits : (WIDE && m.gatherValues) ? (valid ? load_value_bits(m.inValues, a, r[k].x) : 0ull) : hr::widen_value(m.widen, r[k].z);
         // (the group's lowest row is settled after its first few records: a plain read tells the rest they need no atomic)
         if (hit && r[k].x < sRows[slot]) __hip_atomic_fetch_min(sRows + slot, r[k].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         sr_aggregate<VW>(sVals + slot, hit ? value : a.identity, a);
@@ -1151,11 +1152,15 @@ static int sort_reduce_vectors_run(int device, int length, const DimensionVector
     if (trace) fprintf(stderr, "fused_sort_reduce_vectors: rows %d declined: %s\n", length, why);
     return kFusedUnavailable;
   };
-  if (!fused_sort_reduce_enabled() || !fused_sort_reduce_supported(a) || a.width != 4 || length <= 0) return decline("aggregate");
+  if (!fused_sort_reduce_enabled() || !fused_sort_reduce_supported(a) || (a.width != 4 && a.width != 8) || length <= 0) return decline("aggregate");
   const DimLayoutD L = make_dim_layout(in.NumDimsPerDimWidth);
   const int nd = L.numDims;
-  if (nd < 1 || nd > kFusedDims || in.NumDimsPerDimWidth[2] != nd) return decline("layout");
-  using T = Table<4, true>;
+  if (nd < 1 || nd > kFusedDims || in.NumDimsPerDimWidth[0] || in.NumDimsPerDimWidth[1]) return decline("layout");  // (slots of 4 / 2 / 1 bytes)
+  int widths[kFusedDims];
+  for (int d = 0; d < nd; d++) widths[d] = L.width[d];
+  using T = Table<4, true>;  // (the 8-byte tables have the same number of slots)
+  static_assert(Table<8, true>::kSlots == T::kSlots && Table<8, true>::kMaxGroups == T::kMaxGroups, "wide tables differ by value width");
+  const int vw = a.width;
   static EnvSwitch<int> maxGroups("ARES_SR_MAX_GROUPS", [](const char *e) { return e ? atoi(e) : 0; });
   int tableGroups = T::kMaxGroups;
   if (maxGroups.get() > 0 && maxGroups.get() < tableGroups) tableGroups = maxGroups.get();
@@ -1167,11 +1172,11 @@ static int sort_reduce_vectors_run(int device, int length, const DimensionVector
   const int numParts = 1 << partBits;
   if (static_cast<int64_t>(length) > static_cast<int64_t>(numParts) * tableGroups * 7 / 10) return decline("more rows than the tables take");  // (all rows may be groups)
   const int pb1 = partBits < 9 ? partBits : 9, numParts1 = 1 << pb1;
-  RtcKernel scan = rtc_sort_vector_scan_lookup(device, nd, pb1);
+  RtcKernel scan = rtc_sort_vector_scan_lookup(device, nd, widths, pb1);
   if (!scan) return decline("scan kernel not available (yet)");  // being compiled in the background
 
   int prevSize = 0;
-  const std::shared_ptr<uint64_t> prevKeys = sorted_state_find(device, in, inValues, 4, length, &prevSize);
+  const std::shared_ptr<uint64_t> prevKeys = sorted_state_find(device, in, inValues, vw, length, &prevSize);
   if (!prevKeys) prevSize = 0;  // every row is hashed
   const int batchRows = length - prevSize;
 
@@ -1226,6 +1231,7 @@ static int sort_reduce_vectors_run(int device, int length, const DimensionVector
   m.widen.mode = 0;
   m.widen.rk = a.vtype == V_I32 ? K_I32 : K_U32;
   m.widen.dtype = a.vtype == V_I32 ? Int32 : Uint32;
+  m.gatherValues = vw == 8 ? 1 : 0;
   m.agg = a;
   m.staging = reinterpret_cast<uint4 *>(shared);
   m.stageKeys = reinterpret_cast<uint64_t *>(shared + stageBytes);
@@ -1254,7 +1260,7 @@ static int sort_reduce_vectors_run(int device, int length, const DimensionVector
     ws.partBits = pb1;
     ws.lineRecords = 8;
     ws.rowBase = static_cast<uint32_t>(prevSize);
-    rtc_sort_vector_scan_launch(scan, in.DimValues, static_cast<size_t>(in.VectorCapacity), inValues, nd, static_cast<uint32_t>(prevSize), batchRows, partBits, spread, ws, stream);
+    rtc_sort_vector_scan_launch(scan, in.DimValues, static_cast<size_t>(in.VectorCapacity), inValues, nd, widths, static_cast<uint32_t>(prevSize), batchRows, partBits, spread, ws, stream);
     SplitArgs sp;
     memset(&sp, 0, sizeof(sp));
     sp.rec1 = rec1;
@@ -1290,9 +1296,11 @@ static int sort_reduce_vectors_run(int device, int length, const DimensionVector
   }
   FusedPlanD noPlan;
   memset(&noPlan, 0, sizeof(noPlan));
-  ARES_LAUNCH("sr_merge_kernel", (sr_merge_kernel<4, true>), numParts, T::kLanes, stream, m);
+  if (vw == 8) ARES_LAUNCH("sr_merge_kernel", (sr_merge_kernel<8, true>), numParts, T::kLanes, stream, m);
+  else ARES_LAUNCH("sr_merge_kernel", (sr_merge_kernel<4, true>), numParts, T::kLanes, stream, m);
   ARES_LAUNCH("sr_prefix_kernel", sr_prefix_kernel, 1, 1024, stream, partCount, numParts, partBase, flags);  // (flags[0]: groups)
-  ARES_LAUNCH("sr_emit_kernel", (sr_emit_kernel<4, true>), numParts, T::kLanes, stream, m, noPlan, L);
+  if (vw == 8) ARES_LAUNCH("sr_emit_kernel", (sr_emit_kernel<8, true>), numParts, T::kLanes, stream, m, noPlan, L);
+  else ARES_LAUNCH("sr_emit_kernel", (sr_emit_kernel<4, true>), numParts, T::kLanes, stream, m, noPlan, L);
   uint32_t w[4] = {0, 0, 0, 0};
   read_back_u32(flags, w, 4, stream);
   if (phasesOn) {  // diagnostics: where a partition's time goes
@@ -1338,7 +1346,7 @@ static int sort_reduce_vectors_run(int device, int length, const DimensionVector
   if (w[1] && !w[2] && !w[3] && !prevKeys && !spread) return sort_reduce_vectors_run(device, length, in, inValues, out, outValues, a, stream, slack + 1, true);
   if (w[1] && !w[2] && !w[3] && slack < 3) return sort_reduce_vectors_run(device, length, in, inValues, out, outValues, a, stream, slack + 1, spread);
   if (w[1] || w[2] || w[3]) return -1;  // the outputs may be partly written: the caller runs the real Sort + Reduce over them
-  sorted_state_register(device, out, outValues, static_cast<size_t>(in.VectorCapacity), 4, static_cast<int>(w[0]), keysOut);
+  sorted_state_register(device, out, outValues, static_cast<size_t>(in.VectorCapacity), vw, static_cast<int>(w[0]), keysOut);
   return static_cast<int>(w[0]);
 }
 

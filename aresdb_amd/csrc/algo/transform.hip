@@ -2640,7 +2640,7 @@ bool vector_sort_enabled() {
 bool vector_sort_layout(const DimensionVector &keys) {
   int nd = 0;
   for (int w = 0; w < NUM_DIM_WIDTH; w++) nd += keys.NumDimsPerDimWidth[w];
-  return nd >= 1 && nd <= kFusedDims && keys.NumDimsPerDimWidth[2] == nd;  // 4-byte dimensions only
+  return nd >= 1 && nd <= kFusedDims && !keys.NumDimsPerDimWidth[0] && !keys.NumDimsPerDimWidth[1];  // slots of 4 / 2 / 1 bytes
 }
 }  // namespace
 
@@ -2703,7 +2703,7 @@ static bool reduce_lazy_vector_sort(int device, hipStream_t stream, const Dimens
     ps = st->second;
     bool ok = !ps.reduced && ps.fromVectors && ps.device == device && ps.stream == stream && ps.length == length && same_vector(ps.keys, in) &&
               inValues && out.DimValues && out.IndexVector && outValues && out.VectorCapacity >= length && in.VectorCapacity >= length &&
-              memcmp(out.NumDimsPerDimWidth, in.NumDimsPerDimWidth, sizeof(in.NumDimsPerDimWidth)) == 0 && valueBytes == 4;
+              memcmp(out.NumDimsPerDimWidth, in.NumDimsPerDimWidth, sizeof(in.NumDimsPerDimWidth)) == 0 && (valueBytes == 4 || valueBytes == 8);
     if (ok) {
       try {
         a = make_agg_spec(aggFunc, valueBytes);
@@ -2718,7 +2718,8 @@ static bool reduce_lazy_vector_sort(int device, hipStream_t stream, const Dimens
     }
     drop_sort(in.IndexVector);  // (while the kernels run nothing is defined; the reduced state is entered below)
   }
-  const size_t rowBytes = static_cast<size_t>(5) * in.NumDimsPerDimWidth[2];
+  size_t rowBytes = 0;
+  for (int w = 0; w < NUM_DIM_WIDTH; w++) rowBytes += static_cast<size_t>(in.NumDimsPerDimWidth[w]) * ((1u << (NUM_DIM_WIDTH - 1 - w)) + 1);
   retire_fills_for_write(device, outValues, static_cast<size_t>(valueBytes) * length);
   retire_fills_for_write(device, out.IndexVector, 4ull * static_cast<size_t>(length));
   grouped_note_write(device, out);

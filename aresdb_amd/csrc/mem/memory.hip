@@ -238,7 +238,9 @@ struct DeviceState {
   // allocations that took a parked block out of `bins` and are waiting for its fence outside `mu` (pool_alloc): the
   // events they wait on are in nobody's books meanwhile, so DestroyCudaStream lets them finish before it retires a
   // stream's events
-  int waiters = 0;
+  // allocations waiting (outside the lock) for a parked block's fence, per stream their fence events belong to: only those
+  // hold events of a stream outside every list — DestroyCudaStream lets exactly them through, not every waiter of the device
+  std::map<hipStream_t, int> waiters;
   std::condition_variable waitersCv;
   // ---- shared fences.  A fence is one event per stream, recorded at a free.  The Go host frees in bursts (a batch's columns,
   // index and predicate vector: query/aql_processor.go:695-714) with nothing submitted in between: the events of the first
@@ -460,7 +462,7 @@ hipError_t pool_alloc(DeviceState *st, void **p, size_t bytes, bool zero) {
         vec.erase(vec.begin());
         st->parkedBytes -= rounded;
         waitFor = b;
-        st->waiters++;
+        for (const FenceEvent &f : waitFor.fence) st->waiters[f.stream]++;
       }
     }
     if (mem_trace_enabled()) {  // (diagnostics only: nothing is counted when the trace is off)
@@ -475,8 +477,11 @@ hipError_t pool_alloc(DeviceState *st, void **p, size_t bytes, bool zero) {
     cleared = waitFor.zeroed;
     {
       std::lock_guard<std::mutex> lock(st->mu);
+      for (const FenceEvent &f : waitFor.fence) {
+        auto w = st->waiters.find(f.stream);
+        if (w != st->waiters.end() && --w->second <= 0) st->waiters.erase(w);
+      }
       recycle_events(st, waitFor);
-      st->waiters--;
     }
     st->waitersCv.notify_all();
   }
@@ -875,11 +880,12 @@ CGoCallResHandle DestroyCudaStream(void *s, int device) {
     {
       // The stream is idle: whatever its fence events stand for has happened.  They are retired NOW, while the stream
       // exists (see FenceEvent) — destroyed, not recycled: nothing of the runtime's bookkeeping for this stream is kept.
-      // An allocation that is waiting for a parked block's fence holds events of this stream outside every list: it is
-      // let through first (well under a millisecond; no new fence can name this stream, it left `streams` above) and
-      // hands its events to freeEvents, where the sweep below finds them.
+      // An allocation that is waiting for a parked block's fence may hold events of THIS stream outside every list: those
+      // waiters (counted per stream: a waiter parked on other, still busy streams' events is none of this call's business) are
+      // let through first — this stream is idle, its events have fired; no new fence can name it, it left `streams` above —
+      // and hand their events to freeEvents, where the sweep below finds them.
       std::unique_lock<std::mutex> lock(st->mu);
-      st->waitersCv.wait(lock, [&] { return st->waiters == 0; });
+      st->waitersCv.wait(lock, [&] { return st->waiters.find(reinterpret_cast<hipStream_t>(s)) == st->waiters.end(); });
       drop_last_fence(st);  // (its events of this stream go to freeEvents unless a parked block shares them: swept either way)
       for (auto &bin : st->bins)
         for (ParkedBlock &b : bin.second)

@@ -373,7 +373,7 @@ def test_float_sums_keep_the_real_sort():
 
 
 # ---- Sort + Reduce over rows that exist (fused_sort_reduce_vectors: the wide layout) -----------------------------------------
-_VECTOR_SHAPES = [SHAPES[0], SHAPES[3], SHAPES[4],
+_VECTOR_SHAPES = [SHAPES[0], SHAPES[3], SHAPES[4], SHAPES[1], SHAPES[2], EIGHT_COUNT, EIGHT_SUM,  # (8-byte values; 2- and 1-byte slots)
                   Shape("eight_u32_dims_count", _ALL4_COLS, [("k", abi.LessThan, 8)], [(c, None, 0, abi.Uint32) for c in "abcdefgh"], None,
                         abi.AGGR_SUM_UNSIGNED, abi.Uint32, (0, 0, 8, 0, 0))]
 

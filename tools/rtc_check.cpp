@@ -167,9 +167,13 @@ int main(int argc, char **argv) {
     if (int rc = build(rtc_sort_scan_source(ec, 8, 9), "_8sort", "8-dimension sort scan (COUNT)")) return rc;
   }
   // the vector-sourced sort scans (Sort + Reduce over materialised vectors: 64-bit row hash, up to eight 4-byte dimensions)
-  if (int rc = build(rtc_sort_vector_scan_source(2, 9), "_vsort2", "vector sort scan nd 2")) return rc;
-  if (int rc = build(rtc_sort_vector_scan_source(8, 9), "_vsort8", "vector sort scan nd 8")) return rc;
-  if (int rc = build(rtc_sort_vector_scan_source(1, 0), "_vsort1", "vector sort scan nd 1, one partition")) return rc;
+  if (int rc = build(rtc_sort_vector_scan_source(2, nullptr, 9), "_vsort2", "vector sort scan nd 2")) return rc;
+  if (int rc = build(rtc_sort_vector_scan_source(8, nullptr, 9), "_vsort8", "vector sort scan nd 8")) return rc;
+  if (int rc = build(rtc_sort_vector_scan_source(1, nullptr, 0), "_vsort1", "vector sort scan nd 1, one partition")) return rc;
+  {
+    const int narrow[4] = {4, 4, 2, 1};
+    if (int rc = build(rtc_sort_vector_scan_source(4, narrow, 9), "_vsort_narrow", "vector sort scan, slots 4 4 2 1")) return rc;
+  }
   // the vector-sourced scan (HashReduce on materialised dimension / measure vectors)
   for (int vw = 4; vw <= 8; vw += 4)
     for (int nd = 1; nd <= 4; nd += 3) {

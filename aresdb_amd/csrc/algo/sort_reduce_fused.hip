@@ -998,6 +998,9 @@ int fused_sort_reduce_run(int device, const FusedPlanD &plan, int nd, bool const
                           const DimensionVector &in, const uint8_t *inValues, int prevSize, const DimensionVector &out,
                           uint8_t *outValues, const AggSpec &a, hipStream_t stream) {
   if (!fused_sort_reduce_enabled() || !fused_sort_reduce_supported(a) || batchRows <= 0 || prevSize < 0) return kFusedUnavailable;
+  // ARES_SR_SCAN_FED=0 (tests): this path declines everything — its callers go on to the wide layout over materialised rows
+  static EnvSwitch<bool> scanFed("ARES_SR_SCAN_FED", [](const char *e) { return !(e && e[0] == '0'); });
+  if (!scanFed.get()) return kFusedUnavailable;
   const int vw = a.width;
   static EnvSwitch<int> maxGroups("ARES_SR_MAX_GROUPS", [](const char *e) { return e ? atoi(e) : 0; });
   int tableGroups = vw == 4 ? Table<4>::kMaxGroups : Table<8>::kMaxGroups;

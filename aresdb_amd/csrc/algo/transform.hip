@@ -2930,14 +2930,37 @@ bool fuse_pending_into_sort_reduce(int device, hipStream_t stream, const Dimensi
   } catch (...) {
     result = -1;
   }
-  if (result < 0) {  // declined, or a partition overflowed: the real thing — transforms, the constant rows, InitIndexVector, Sort
+  if (result < 0) {  // declined, or a partition overflowed: the batch's rows are written — transforms, the constant rows — ...
     {
       DeferLock lock(device);
       launch_queue(stream, q, /*inOrder=*/true);
       if (constMeasure) launch_fill(fillAt, fill);
-      launch_init_index(in.IndexVector, 0, length, stream);
     }
     g_releaseHeld(device, hold_tag(stream));
+    // ... and the groups are ordered by row hash over the rows that exist now (the wide layout takes results the 512 tables
+    // of the scan-fed path do not: millions of groups per batch) ...
+    int wide = kFusedUnavailable;
+    if (vector_sort_enabled() && vector_sort_layout(in)) {
+      try {
+        wide = fused_sort_reduce_vectors(device, length, in, inValues, out, outValues, a, stream);
+      } catch (...) {
+        wide = -1;
+      }
+    }
+    if (wide >= 0) {
+      mem_note_dim_rows(device, out, 0, static_cast<size_t>(wide));
+      mem_note_write(device, outValues, static_cast<size_t>(valueBytes) * static_cast<size_t>(wide));
+      DeferLock lock(device);
+      ps.fromVectors = true;
+      enter_reduced_sort(device, stream, ps, in, inValues, out, outValues, valueBytes, length, aggFunc, wide);
+      *groups = wide;
+      return true;
+    }
+    // ... or the real thing: InitIndexVector, Sort (the ordinary Reduce follows)
+    {
+      DeferLock lock(device);
+      launch_init_index(in.IndexVector, 0, length, stream);
+    }
     sort_keys_now(in, length, stream);
     return false;
   }

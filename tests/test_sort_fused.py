@@ -435,3 +435,27 @@ def test_materialised_rows_with_too_many_groups_fall_back_to_the_real_sort(monke
         hip.reload_env()
     assert_same(got, want, "fallback")
     assert any(k.startswith("radix_pass_kernel") or k.startswith("sort_") for k in kernels), sorted(kernels)
+
+
+@pytest.mark.parametrize("shape", [SHAPES[0], SHAPES[1], SHAPES[2]], ids=lambda s: s.name)
+def test_scan_fed_path_declining_hands_over_to_the_wide_layout(shape, monkeypatch):
+    """What the scan-fed path declines (ARES_SR_SCAN_FED=0 here; in production: a previous result of more groups than its 512
+    tables order) is not sorted row by row either: the pending transforms are launched and the groups ordered over the rows
+    they wrote.  Ordered output, and — for a host that looks — the hash / index vectors a sort would have left."""
+    hip, oracle = H.hip_backend(), H.oracle_backend()
+    rng = np.random.default_rng(41)
+    batches = [make_batch(rng, shape, n) for n in (6000, 20000, 300)]
+    want = run_sequence(oracle, shape, batches)
+    want_read = run_sequence(oracle, shape, batches, read=frozenset(("sorted", "after")))
+    monkeypatch.setenv("ARES_SR_SCAN_FED", "0")
+    hip.reload_env()
+    try:
+        got, kernels = _kernels_of(hip, lambda: run_sequence(hip, shape, batches))
+        got_read = run_sequence(hip, shape, batches, read=frozenset(("sorted", "after")))
+    finally:
+        monkeypatch.undo()
+        hip.reload_env()
+    assert_same(got, want, shape.name)
+    assert_same(got_read, want_read, shape.name)
+    if _fusion_on() and os.environ.get("ARES_SORT_VECTORS", "1") != "0":
+        assert any(k.startswith("sr_split_kernel") for k in kernels) and not any(k.startswith("radix_pass_kernel") for k in kernels), sorted(kernels)

@@ -759,10 +759,10 @@ def main(argv=None, backend=None, tensor_device=None):
         pmc_note += f" ({time.perf_counter() - t_pmc0:.0f} s)"
     if not pmc_kernels:
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r5_c3_pmc_traffic.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r6_c3_pmc_traffic.json")))
             if pmc.get("rows_per_batch") == batch_rows and pmc.get("libalgorithm_sha256_16") == library_sha() and on_gpu:
                 pmc_kernels = pmc["kernels"]
-                pmc_note += f"; taken from profiles/r5_c3_pmc_traffic.json (build {pmc['libalgorithm_sha256_16']})"
+                pmc_note += f"; taken from profiles/r6_c3_pmc_traffic.json (build {pmc['libalgorithm_sha256_16']})"
         except (OSError, ValueError, KeyError):
             pass
     for name, k in kern_out.items():  # measured traffic rate of every kernel (not the algorithmic roofline)

@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/r6ev
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-WHAT=${*:-c3 sort trips archive live c2 c4}
+WHAT=${*:-c3 sort trips archive live c2 c4 ab}
 trace() {
   tag=$1; shift
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$tag -o t -- "$@" > $OUT/prof_$tag.log 2>&1
@@ -54,13 +54,14 @@ for w in $WHAT; do
     c4)
       trace c4 env C4_ROWS=1e9 python $R/tools/bench_configs.py c4spec
       pmc c4 67108864 env C4_ROWS=268435456 C4_KEYS=5e7 python $R/tools/bench_configs.py c4spec ;;
-    ab)
-      for v in 1 0 1 0; do
-        ARES_RESULT_PINNED=$v $LIVE --rows 1e9 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('live result_pinned=$v', round(d['ms_per_step'],2), d['check_groups'])"
+    ab)   # what round 6 added, switched off and on again (same box, back to back)
+      for v in 1 0; do
+        ARES_SORT_VECTORS=$v python $R/tools/bench_configs.py c4spec 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); d=d[0] if isinstance(d,list) else d; print('c4 1B rows / 50M keys, ARES_SORT_VECTORS=$v:', round(d['ms'],1), 'ms', d['key_level_check'], {k: round(x['avg_ms'],3) for k,x in list(d['kernels'].items())[:6]})"
       done
       for v in 1 0; do
-        ARES_IMAGE=$v $LIVE --rows 1e9 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('live image=$v', round(d['ms_per_step'],2), d['check_groups'], {k: round(x['avg_ms'],4) for k,x in d['kernels'].items()})"
-        ARES_IMAGE=$v python $R/bench.py --steps 5 --warmup 2 --no-pmc --no-cpu-baseline --no-legs --leg 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('c3 image=$v', round(d['ms_per_step'],2), d['check_groups'], {k: round(x['avg_ms'],4) for k,x in d['kernels'].items()})"
+        ARES_SORT_FUSE=$v python $R/bench.py --leg --steps 3 --warmup 1 --rows 1e9 --batch-rows 67108864 --sort-path count 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('c3 COUNT(*) through Sort + Reduce, ARES_SORT_FUSE=$v:', round(d['ms_per_step'],2), 'ms per 1 B rows', d['check_groups'])"
+        ARES_EXPAND_RLE=$v python $R/bench.py --leg --steps 3 --warmup 2 --rows 1e9 --batch-rows 67108864 --archive --ts-range 3600,601200 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('archive batches, ARES_EXPAND_RLE=$v:', round(d['ms_per_step'],2), 'ms per 1 B rows', d['check_groups'])"
+        ARES_SORT_STATE=$v python $R/bench.py --leg --steps 3 --warmup 1 --rows 1e9 --batch-rows 67108864 --sort-path count 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('c3 COUNT(*) through Sort + Reduce, ARES_SORT_STATE=$v:', round(d['ms_per_step'],2), 'ms per 1 B rows', d['check_groups'])"
       done ;;
   esac
 done

@@ -208,6 +208,15 @@ static bool phases_enabled() {
   return on;
 }
 
+// ARES_HR_SCAN_TILES=1|2: tiles of 4096 rows per pass of the compact scan (kernel_body_compact / kernel_body_compact2)
+static int scan_tiles() {
+  static const int n = [] {
+    const char *e = getenv("ARES_HR_SCAN_TILES");
+    return e && e[0] == '2' ? 2 : 1;
+  }();
+  return n;
+}
+
 // ARES_HR_NT: non-temporal loads for the columns (read once; 4 = loads only, the default) and / or non-temporal stores for the
 // record lines (written once, read by another kernel; 2 = stores only, 3 or 1 = both, 0 = neither).  Round 3 measured the
 // pair 4 % SLOWER than neither; round 4 measured them one at a time (profiles/r4_experiments.md): loads only, scan
@@ -652,6 +661,211 @@ static void kernel_body_compact(std::ostringstream &o) {
 // time, every lane busy.  Once the table holds LIMIT groups a row whose group finds no slot is written as a single
 // record straight away (one global cursor reservation): always correct, slow when frequent — the host sends
 // queries with that many groups to the DIRECT kernels.
+// Two tiles per pass (ARES_HR_SCAN_TILES=2): the per-partition work of a pass — the scan over the partitions' counts, the
+// leftover bookkeeping, the barriers — is the same whether 7 or 14 records per partition arrive (4096 rows x 0.9 / 512
+// partitions = 7.2: half a line), so two tiles are evaluated and counted one after the other (the second tile's rows in
+// registers of their own) and sorted, lined up and written out together.  LDS: 161 KB of the 160 KiB.
+static void kernel_body_compact2(std::ostringstream &o) {
+  phase_macros(o);
+  const bool direct = scan_opt() & 1u;
+  o << (nt_stores_enabled() ? "#define STORE_LINE(p, v) __builtin_nontemporal_store((u64)(v), (p))\n" : "#define STORE_LINE(p, v) (*(p) = (v))\n");
+  o << "#define T 4096u\n#define T2 8192u\n#define LR 14u\n#define LEFT 13u\n#define LPL 5u\n"
+       "__device__ __forceinline__ u32 lane_up(u32 v, u32 lane, u32 off) { return (u32)__builtin_amdgcn_ds_bpermute((int)((lane - off) << 2), (int)v); }\n"
+       // OR over the 8 lanes of a half-line: xor 1, xor 2 (quad permutes), then the mirrored quad (row_half_mirror)
+       "__device__ __forceinline__ u32 or8(u32 v) {\n"
+       "  v |= (u32)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);\n"
+       "  v |= (u32)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);\n"
+       "  v |= (u32)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xF, 0xF, true);\n"
+       "  return v;\n"
+       "}\n"
+       // inclusive scan over the wavefront: Hillis-Steele inside each row of 16 (row_shr 1, 2, 4, 8; lanes without a
+       // source keep the 0), then lane 15 of rows 0 / 2 into rows 1 / 3 and lane 31 into rows 2 and 3
+       "__device__ __forceinline__ u32 wave_incl_scan(u32 v) {\n"
+       "  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);\n"
+       "  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);\n"
+       "  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);\n"
+       "  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);\n"
+       "  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);\n"
+       "  v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);\n"
+       "  return v;\n"
+       "}\n"
+       "extern \"C\" __global__ void __launch_bounds__(1024) hr_scan_rtc(Args a) {\n"
+       "  __shared__ u64 sRec[T2 + NP * LEFT];\n"   // the tile's records sorted by partition, then up to 13 records per partition waiting for a full line
+       "  __shared__ u16 sLo[T2 + NP * LEFT];\n"    // their low 9 row bits
+       "  __shared__ u32 sCount[2][NP];\n"
+       "  __shared__ u32 sStart[NP];\n"            // where the tile's records of a partition go
+       "  __shared__ uint2 sLines[(T2 + NP * LEFT) / LR + 2u];\n"   // {partition | line of the tile << 9 | leftovers << 18, first slot | stream cursor << 13}
+       "  __shared__ u32 sWave[16];\n"
+       "  __shared__ u32 sTotalLines;\n"
+       "  const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;\n"
+       "  for (u32 p = tid; p < NP; p += 1024u) { sCount[0][p] = 0u; sCount[1][p] = 0u; }\n"
+       "  u32 myLeftN = 0u, myCursor = 0u;\n"    // thread p < NP keeps partition p's leftover count and stream cursor in registers
+       "  __syncthreads();\n"
+       "  u64 *myB = reinterpret_cast<u64 *>(a.recB) + (u64)blockIdx.x * NP * a.capB * 16u;\n"  // capB: lines per stream
+       "  const u32 numTiles = ((u32)a.length + T - 1u) / T;\n"
+       "  const u32 firstTile = blockIdx.x * a.chunkTiles;\n"
+       "  const u32 endTile = firstTile + a.chunkTiles < numTiles ? firstTile + a.chunkTiles : numTiles;\n"
+       "  u32 tile = firstTile, par = 0u;\n"
+       "  Raw R;\n"
+       "  PH_DECL\n"
+       "  load_tile(R, a, tile * T + tid * 4u);\n"
+       // the lane's place in a line: 16 lanes per line, lanes 0 and 8 carry the two headers
+       "  const u32 q = tid & 15u, r8 = q & 7u;\n"
+       "  const u32 kk = (q >> 3) * 7u + (r8 ? r8 - 1u : 0u);\n"  // record of the line this lane carries
+       "  const u32 sh = r8 ? 9u * (r8 - 1u) : 0u;\n"
+       "  while (tile < endTile) {\n"
+       "    u32 i0 = tile * T + tid * 4u;\n"          // eval4p moves it to the first row the lane's registers hold
+       "    u32 hh[4], cv[4], cw[4], alive[4], rank[4];\n"
+       "    u32 hhB[4], cvB[4], aliveB[4], rankB[4];\n"
+       "    const u32 next = tile + 2u;\n"
+       "    eval4p(R, a, i0, hh, cv, cw, alive, (tile + 1u) * T + tid * 4u);\n"
+       "    const u32 rc0 = i0 - firstTile * T;\n"    // row within the chunk
+       "    u32 *cnt = sCount[par];\n"
+       "#pragma unroll\n"
+       "    for (int j = 0; j < 4; j++) {\n"
+       "      rank[j] = 0u;\n"
+       "      if (alive[j]) rank[j] = __hip_atomic_fetch_add(&cnt[hh[j] >> (32 - PB)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
+       "    }\n"
+       // the pass's second tile (none: the chunk's last pass holds one tile — its rows are the next workgroup's)
+       "    u32 i0B = (tile + 1u) * T + tid * 4u;\n"
+       "    const bool second = tile + 1u < endTile;\n"
+       "    eval4p(R, a, i0B, hhB, cvB, cw, aliveB, next * T + tid * 4u);\n"
+       "    const u32 rc0B = i0B - firstTile * T;\n"
+       "#pragma unroll\n"
+       "    for (int j = 0; j < 4; j++) {\n"
+       "      rankB[j] = 0u;\n"
+       "      aliveB[j] = second ? aliveB[j] : 0u;\n"
+       "      if (aliveB[j]) rankB[j] = __hip_atomic_fetch_add(&cnt[hhB[j] >> (32 - PB)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);\n"
+       "    }\n"
+       "    __syncthreads();\n"
+       "    PH(0)\n"
+       // exclusive scans of (new records, whole lines) per partition, packed in one word
+       "    u32 myCount = 0u, myLeft = 0u;\n"
+       "    if (tid < NP) { myCount = cnt[tid]; myLeft = myLeftN; }\n"
+       "    const u32 myHave = myCount + myLeft, myLines = myHave / LR;\n"
+       "    const u32 packed = (myCount << 16) | myLines;\n"
+       "    const u32 incl = wave_incl_scan(packed);\n"
+       "    if (lane == 63u) sWave[wave] = incl;\n"
+       "    __syncthreads();\n"
+       "    u32 before = 0u;\n"
+       "#pragma unroll\n"
+       "    for (u32 w = 0u; w < (NP + 63u) / 64u; w++) { const u32 t = sWave[w]; before += w < wave ? t : 0u; }\n"
+       "    const u32 excl = before + incl - packed;\n"
+       "    const u32 myStart = excl >> 16, myLineStart = excl & 0xFFFFu;\n"
+       "    if (tid < NP) {\n"
+    // a partition that completes no line in this tile takes its records straight into its remainder
+    << (direct ? "      sStart[tid] = myLines ? myStart : T2 + tid * LEFT + myLeft;\n" : "      sStart[tid] = myStart;\n")
+    << "      for (u32 c = 0u; c < myLines; c++) sLines[myLineStart + c] = make_uint2(tid | (c << 9) | (myLeft << 19), myStart | (myCursor << 13));\n"
+       "      if (tid == NP - 1u) sTotalLines = myLineStart + myLines;\n"
+       "    }\n"
+       "    __syncthreads();\n"
+       "    PH(1)\n"
+       "#pragma unroll\n"
+       "    for (int j = 0; j < 4; j++)\n"
+       "      if (alive[j]) {\n"
+       "        const u32 at = sStart[hh[j] >> (32 - PB)] + rank[j], rc = rc0 + (u32)j;\n"
+       "        sRec[at] = ((u64)((hh[j] << PB) | (rc >> 9)) << 32) | cv[j];\n"
+       "        sLo[at] = (u16)(rc & 511u);\n"
+       "      }\n"
+       "#pragma unroll\n"
+       "    for (int j = 0; j < 4; j++)\n"
+       "      if (aliveB[j]) {\n"
+       "        const u32 at = sStart[hhB[j] >> (32 - PB)] + rankB[j], rc = rc0B + (u32)j;\n"
+       "        sRec[at] = ((u64)((hhB[j] << PB) | (rc >> 9)) << 32) | cvB[j];\n"
+       "        sLo[at] = (u16)(rc & 511u);\n"
+       "      }\n"
+       "    __syncthreads();\n"
+       "    PH(2)\n"
+       "    const u32 totalLines = sTotalLines;\n"
+       "    for (u32 L0 = tid >> 4; L0 < totalLines; L0 += 64u * LPL) {\n"
+       "      u32 e[LPL], lf[LPL], st[LPL], cu[LPL], lo[LPL];\n"
+       "      u64 rec[LPL];\n"
+       "#pragma unroll\n"
+       "      for (u32 j = 0u; j < LPL; j++) {\n"
+       "        const u32 L = L0 + j * 64u;\n"
+       "        const uint2 w = L < totalLines ? sLines[L] : make_uint2(0u, 0u);\n"
+       "        e[j] = w.x & 0x7FFFFu; lf[j] = w.x >> 19; st[j] = w.y & 0x1FFFu; cu[j] = w.y >> 13;\n"
+       "      }\n"
+       "#pragma unroll\n"
+       "      for (u32 j = 0u; j < LPL; j++) {\n"
+       "        const u32 p = e[j] & 511u, idx = (e[j] >> 9) * LR + kk;\n"
+       "        const u32 at = idx < lf[j] ? T2 + p * LEFT + idx : st[j] + idx - lf[j];\n"
+       "        rec[j] = sRec[at];\n"
+       "        lo[j] = sLo[at];\n"
+       "      }\n"
+       "#pragma unroll\n"
+       "      for (u32 j = 0u; j < LPL; j++) {\n"
+       "        const u64 mine = r8 ? (u64)lo[j] << sh : 0ull;\n"
+       "        const u64 hdr = ((u64)or8((u32)(mine >> 32)) << 32) | or8((u32)mine);\n"
+       "        const u32 p = e[j] & 511u, line = cu[j] + (e[j] >> 9);\n"
+       "        if (L0 + j * 64u < totalLines && line < a.capB) STORE_LINE(&myB[((u64)p * a.capB + line) * 16u + q], r8 ? rec[j] : hdr);\n"
+       "      }\n"
+       "    }\n"
+       "    __syncthreads();\n"
+       "    PH(3)\n"
+       // what is left of each partition (< 14 records) moves to its LDS remainder; cursors advance
+       "    if (tid < NP) {\n"
+       "      const u32 rem = myHave - myLines * LR;\n"
+    << (direct ?  // only after a line: the 13 slots behind the last line go to the remainder as they are (those past `rem` are never read)
+                 "      if (myLines) {\n"
+                 "        const u32 from = myStart + myLines * LR - myLeft, to = T2 + tid * LEFT;\n"
+                 "        u64 t[LEFT]; u16 tl[LEFT];\n"
+                 "#pragma unroll\n"
+                 "        for (u32 k = 0u; k < LEFT; k++) { t[k] = sRec[from + k]; tl[k] = sLo[from + k]; }\n"
+                 "#pragma unroll\n"
+                 "        for (u32 k = 0u; k < LEFT; k++) { sRec[to + k] = t[k]; sLo[to + k] = tl[k]; }\n"
+                 "      }\n"
+               : "      const u32 n = myLines ? rem : myCount;\n"
+                 "      const u32 from = myLines ? myStart + myLines * LR - myLeft : myStart;\n"
+                 "      const u32 to = T2 + tid * LEFT + (myLines ? 0u : myLeft);\n"
+                 "      u64 t[LEFT]; u16 tl[LEFT];\n"
+                 "#pragma unroll\n"
+                 "      for (u32 k = 0u; k < LEFT; k++) { const u32 s = from + (k < n ? k : 0u); t[k] = sRec[s]; tl[k] = sLo[s]; }\n"
+                 "#pragma unroll\n"
+                 "      for (u32 k = 0u; k < LEFT; k++) if (k < n) { sRec[to + k] = t[k]; sLo[to + k] = tl[k]; }\n")
+    << "      myLeftN = rem;\n"
+       "      u32 cur = myCursor + myLines;\n"
+       "      if (cur > a.capB) { *a.overflow = 1u; cur = a.capB; }\n"
+       "      myCursor = cur;\n"
+       "      cnt[tid] = 0u;\n"  // this counter set is used again two tiles from now
+       "    }\n"
+       "    par ^= 1u;\n"
+       "    tile = next;\n"
+       "    PH(4)\n"
+       "  }\n"
+       "  __syncthreads();\n"
+       "  if (tid < NP) sLines[tid] = make_uint2(myLeftN, myCursor);\n"
+       "  __syncthreads();\n"
+       "  PH(5)\n"
+       // the remainders go out as one last, partly filled line each; countsB holds the exact number of records
+       "  for (u32 p = tid >> 4; p < NP; p += 64u) {\n"
+       "    const uint2 m = sLines[p];\n"
+       "    const u32 left = m.x, cur = m.y;\n"
+       "    const bool fits = cur < a.capB, has = r8 && kk < left;\n"
+       "    const u64 rec = has ? sRec[T2 + p * LEFT + kk] : 0ull;\n"
+       "    const u64 mine = has ? (u64)sLo[T2 + p * LEFT + kk] << sh : 0ull;\n"
+       "    const u64 hdr = ((u64)or8((u32)(mine >> 32)) << 32) | or8((u32)mine);\n"
+       "    if (left && fits) STORE_LINE(&myB[((u64)p * a.capB + cur) * 16u + q], r8 ? rec : hdr);\n"
+       "    if (left && !fits) *a.overflow = 1u;\n"
+       "    if (q == 0u) a.countsB[(u64)blockIdx.x * NP + p] = cur * LR + ((left && fits) ? left : 0u);\n"
+       "  }\n"
+       "  PH(6)\n"
+       "  PH_OUT\n"
+       "}\n";
+}
+
+// ---- TABLE scan ----------------------------------------------------------------------------------------
+// Low-cardinality queries: every workgroup aggregates its rows in an LDS hash table (key = hash << 32 | lowest
+// row, 8-byte value) and emits one 16-byte record per group {row, hash, value} into region A at the end — the
+// layout hr::flush_table writes and hr::merge_body reads.  No barrier inside the loop: the wavefronts run free,
+// two tiles per wavefront in flight (two register buffers, each refilled column by column while it is evaluated:
+// with two or three columns a single tile per wavefront leaves too few bytes in flight to cover HBM latency).
+// The table is the specialised merge's: buckets of four keys (two 16-byte LDS reads).  A row first looks at its
+// home bucket with straight-line code — it meets its group there nearly always once the groups exist: one LDS
+// atomic more —; rows that do not are queued per wavefront in LDS and taken through the general probe loop 64 at a
+// time, every lane busy.  Once the table holds LIMIT groups a row whose group finds no slot is written as a single
+// record straight away (one global cursor reservation): always correct, slow when frequent — the host sends
+// queries with that many groups to the DIRECT kernels.
 static void kernel_body_table(std::ostringstream &o) {
   // table: 32-bit keys (the hash; 0xFFFFFFFF = empty — a row whose hash IS that value travels alone), the groups'
   // lowest rows and their values in arrays of their own: a probe is one 16-byte LDS read and four 32-bit compares
@@ -1068,7 +1282,9 @@ std::string generate(const FusedPlanD &plan, int nd, int partBits, uint32_t null
     if (!agg || !widen || !gen_widen(o, *widen) || !gen_agg(o, *agg)) return "";
     kernel_body_table(o);
   } else if (kind == SCAN_COMPACT) {
-    kernel_body_compact(o);
+    // (two tiles per pass: the second tile's rows need 16 more registers — four dimensions at most)
+    if (scan_tiles() == 2 && nd <= 4) kernel_body_compact2(o);
+    else kernel_body_compact(o);
   } else {
     kernel_body_lines16(o, sort64 ? "cw[j]" : "0u", sort64 ? "sr_scan_rtc" : "hr_scan_rtc");
   }

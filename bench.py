@@ -842,6 +842,9 @@ def main(argv=None, backend=None, tensor_device=None):
             # same four dimensions — hash-keyed inside the ABI (sort_reduce_fused.hip), rows in ascending 64-bit hash order
             leg("c3_sort_path_count", {}, big + ["--sort-path", "count"])
             leg("c3_sort_path_sum_unsigned", {}, big + ["--sort-path", "sum"])
+            # ... and with the scan-fed path declining everything: the batch's transforms are launched and Reduce orders the groups
+            # over the rows they wrote (the wide layout of sort_reduce_fused.hip — what a join or a generic expression gets)
+            leg("c3_sort_path_count_materialised_rows", {"ARES_SR_SCAN_FED": "0"}, big + ["--sort-path", "count"])
             # the ABI's limit of dimensions (MAX_DIMENSIONS = 8) on the fused path: generated kernels only
             leg("c3_eight_dimensions", {}, big + ["--eight-dims"])
             # archive batches (mode-3 run-length sort columns ts and d3): decoded once per batch, then the headline's path

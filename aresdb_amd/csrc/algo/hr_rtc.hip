@@ -236,6 +236,7 @@ static bool nt_stores_enabled() { return (nt_mode() & 2) != 0; }
 // can be timed against each other in one process tree: tools/gpu_r3_ab.sh, profiles/r3_experiments.md)
 //   1  a partition that completes no line in a tile scatters its records straight into its remainder
 //   2  murmur's h * 5 + c as shift-add + add instead of the v_mad_u64_u32 the compiler picks
+//   4  compact scan: the 13 slots behind a partition's last line are moved to its remainder by two lanes (sixteen wavefronts) instead of one
 static unsigned scan_opt() {
   static const unsigned v = [] {
     const char *e = getenv("ARES_HR_SCAN_OPT");
@@ -482,6 +483,7 @@ static void kernel_body_lines16(std::ostringstream &o, const char *fourth, const
 static void kernel_body_compact(std::ostringstream &o) {
   phase_macros(o);
   const bool direct = scan_opt() & 1u;
+  const bool pairCopy = direct && (scan_opt() & 4u);  // a partition's 13 slots behind its last line are moved by TWO lanes
   o << (nt_stores_enabled() ? "#define STORE_LINE(p, v) __builtin_nontemporal_store((u64)(v), (p))\n" : "#define STORE_LINE(p, v) (*(p) = (v))\n");
   o << "#define T 4096u\n#define LR 14u\n#define LEFT 13u\n#define LPL 5u\n"
        "__device__ __forceinline__ u32 lane_up(u32 v, u32 lane, u32 off) { return (u32)__builtin_amdgcn_ds_bpermute((int)((lane - off) << 2), (int)v); }\n"
@@ -508,6 +510,8 @@ static void kernel_body_compact(std::ostringstream &o) {
        "  __shared__ u16 sLo[T + NP * LEFT];\n"    // their low 9 row bits
        "  __shared__ u32 sCount[2][NP];\n"
        "  __shared__ u32 sStart[NP];\n"            // where the tile's records of a partition go
+    << (pairCopy ? "  __shared__ u32 sMove[NP];\n" : "")  // first of the 13 slots behind a partition's last line of this tile (~0: no line)
+    << ""
        "  __shared__ uint2 sLines[(T + NP * LEFT) / LR + 2u];\n"   // {partition | line of the tile << 9 | leftovers << 18, first slot | stream cursor << 13}
        "  __shared__ u32 sWave[16];\n"
        "  __shared__ u32 sTotalLines;\n"
@@ -557,6 +561,7 @@ static void kernel_body_compact(std::ostringstream &o) {
        "    if (tid < NP) {\n"
     // a partition that completes no line in this tile takes its records straight into its remainder
     << (direct ? "      sStart[tid] = myLines ? myStart : T + tid * LEFT + myLeft;\n" : "      sStart[tid] = myStart;\n")
+    << (pairCopy ? "      sMove[tid] = myLines ? myStart + myLines * LR - myLeft : 0xFFFFFFFFu;\n" : "")
     << "      for (u32 c = 0u; c < myLines; c++) sLines[myLineStart + c] = make_uint2(tid | (c << 9) | (myLeft << 18), myStart | (myCursor << 13));\n"
        "      if (tid == NP - 1u) sTotalLines = myLineStart + myLines;\n"
        "    }\n"
@@ -601,7 +606,8 @@ static void kernel_body_compact(std::ostringstream &o) {
        // what is left of each partition (< 14 records) moves to its LDS remainder; cursors advance
        "    if (tid < NP) {\n"
        "      const u32 rem = myHave - myLines * LR;\n"
-    << (direct ?  // only after a line: the 13 slots behind the last line go to the remainder as they are (those past `rem` are never read)
+    << (pairCopy ? ""  // (moved by all lanes, below)
+       : direct ?  // only after a line: the 13 slots behind the last line go to the remainder as they are (those past `rem` are never read)
                  "      if (myLines) {\n"
                  "        const u32 from = myStart + myLines * LR - myLeft, to = T + tid * LEFT;\n"
                  "        u64 t[LEFT]; u16 tl[LEFT];\n"
@@ -624,7 +630,20 @@ static void kernel_body_compact(std::ostringstream &o) {
        "      myCursor = cur;\n"
        "      cnt[tid] = 0u;\n"  // this counter set is used again two tiles from now
        "    }\n"
-       "    par ^= 1u;\n"
+    << (pairCopy ?  // lanes 2p and 2p + 1 move slots 0..6 and 7..12 of partition p: sixteen wavefronts share what eight did
+                   "    if (tid < 2u * NP) {\n"
+                   "      const u32 p = tid >> 1, k0 = (tid & 1u) * 7u, from = sMove[p];\n"
+                   "      if (from != 0xFFFFFFFFu) {\n"
+                   "        const u32 to = T + p * LEFT;\n"
+                   "        u64 t[7]; u16 tl[7];\n"
+                   "#pragma unroll\n"
+                   "        for (u32 k = 0u; k < 7u; k++) { const u32 kk2 = k0 + k < LEFT ? k0 + k : 0u; t[k] = sRec[from + kk2]; tl[k] = sLo[from + kk2]; }\n"
+                   "#pragma unroll\n"
+                   "        for (u32 k = 0u; k < 7u; k++) if (k0 + k < LEFT) { sRec[to + k0 + k] = t[k]; sLo[to + k0 + k] = tl[k]; }\n"
+                   "      }\n"
+                   "    }\n"
+                 : "")
+    << "    par ^= 1u;\n"
        "    tile = next;\n"
        "    PH(4)\n"
        "  }\n"

@@ -1563,7 +1563,7 @@ int AresQueryRunHostBatches(AresQuery *q, const AresHostColumn *columns, int num
   try {
     Staged prev, cur;
     bool havePrev = false;
-    if (numBatches > 1)
+    auto start_executor = [&] {  // (on the first batch that is handed over: a query whose columns all sit in the cache never starts it)
       ex.thread = std::thread([&] {
         for (;;) {
           Staged *b = nullptr;
@@ -1582,20 +1582,36 @@ int AresQueryRunHostBatches(AresQuery *q, const AresHostColumn *columns, int num
           }
         }
       });
+    };
     for (int k = 0; k < numBatches; k++) {
       // (query/aql_processor.go:850-881) async transfer of batch k ...
       void *xfer = havePrev && q->otherStream ? q->otherStream : q->stream;
       cur = Staged();
       cur.size = batchSizes[k];
-      if (havePrev) submit(&prev);  // ... while batch k-1 executes
+      // columns the cache holds first: a batch that needs no upload has nothing to overlap with — batch k-1 then runs on
+      // THIS thread (handing it to the executor and waking up again costs ~0.1 ms per batch of condition-variable latency)
+      std::vector<void *> devs(static_cast<size_t>(numColumns), nullptr);
+      int misses = 0;
+      for (int c = 0; c < numColumns; c++) {
+        const AresHostColumn &hc = columns[static_cast<size_t>(k) * numColumns + c];
+        devs[c] = (cache && hc.cacheKey) ? cache->find(hc.cacheKey) : nullptr;
+        if (devs[c]) {
+          hits++;
+          cur.pinned.push_back(hc.cacheKey);
+        } else {
+          misses++;
+        }
+      }
+      const bool handOver = havePrev && misses > 0;
+      if (handOver) {
+        if (!ex.thread.joinable()) start_executor();
+        submit(&prev);  // ... while batch k-1 executes
+      }
       try {
         for (int c = 0; c < numColumns; c++) {
           const AresHostColumn &hc = columns[static_cast<size_t>(k) * numColumns + c];
-          void *dev = (cache && hc.cacheKey) ? cache->find(hc.cacheKey) : nullptr;
-          if (dev) {
-            hits++;
-            cur.pinned.push_back(hc.cacheKey);
-          } else {
+          void *dev = devs[c];
+          if (!dev) {
             dev = reinterpret_cast<void *>(check(q->lib->DeviceAllocate(hc.bytes ? hc.bytes : 1, q->device)));
             check(q->lib->AsyncCopyHostToDevice(dev, const_cast<void *>(hc.host), hc.bytes, xfer, q->device));
             uploadedBytes += hc.bytes;
@@ -1607,25 +1623,19 @@ int AresQueryRunHostBatches(AresQuery *q, const AresHostColumn *columns, int num
           vp.BasePtr = static_cast<uint8_t *>(dev) + reinterpret_cast<uintptr_t>(hc.slice.BasePtr);
           cur.slices.push_back(vp);
         }
-        check(q->lib->WaitForCudaStream(xfer, q->device));  // wait for the data transfer of the current batch
+        if (misses > 0) check(q->lib->WaitForCudaStream(xfer, q->device));  // wait for the data transfer of the current batch
       } catch (...) {
-        wait_idle();
+        if (handOver) wait_idle();
         stop();
         throw;
       }
-      wait_idle();
+      if (handOver) wait_idle();
+      else if (havePrev) run_staged(&prev);
       if (!workerError.empty()) throw AbiError(workerError);
       prev = cur;
       havePrev = true;
     }
-    if (havePrev) {
-      if (ex.thread.joinable()) {
-        submit(&prev);
-        wait_idle();
-      } else {
-        run_staged(&prev);
-      }
-    }
+    if (havePrev) run_staged(&prev);  // (nothing left to overlap with)
     stop();
     if (!workerError.empty()) throw AbiError(workerError);
     if (stats) {

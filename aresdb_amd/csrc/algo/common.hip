@@ -1,6 +1,7 @@
 // Host helpers shared by the entry points (see common.hpp).
 #include "common.hpp"
 
+#include <algorithm>
 #include <atomic>
 #include <map>
 #include <mutex>
@@ -114,6 +115,8 @@ std::map<int, StreamCache> g_orphans;
 std::map<void *, size_t> g_blockSize;  // every block handed out or cached -> rounded size
 std::map<void *, bool> g_handedOut;    // invariant check: a block is either in a cache or with exactly one user
 size_t g_cachedBytes = 0;
+std::map<void *, uint64_t> g_releasedAt;  // cached block -> the release count at which it was cached (oldest first out)
+uint64_t g_releases = 0;
 
 void check_take(void *p) {  // caller holds g_cacheMutex
   bool &out = g_handedOut[p];
@@ -157,6 +160,51 @@ void drop_all_cached() {
   g_cachedBytes = 0;
 }
 }  // namespace
+
+// The cache has outgrown its bound: the blocks cached LONGEST go back to the driver until three quarters of the bound are
+// left — what a query in steady state releases and takes again batch after batch stays (dropping everything made a
+// working set near the bound thrash: gigabytes of hipMalloc per batch, 19 -> 275 ms per 1 B rows of archive batches in one
+// run out of four), the leftovers of earlier sizes (a workspace that has grown since) go.  The caller holds g_cacheMutex.
+void evict_oldest_cached(size_t bound) {
+  struct Victim {
+    uint64_t at;
+    void *ptr;
+    size_t size;
+    StreamCache *cache;
+  };
+  std::vector<Victim> all;
+  auto collect = [&](StreamCache &c) {
+    for (auto &bin : c.bins)
+      for (void *p : bin.second) {
+        auto it = g_releasedAt.find(p);
+        all.push_back(Victim{it == g_releasedAt.end() ? 0 : it->second, p, bin.first, &c});
+      }
+  };
+  for (auto &kv : g_caches) collect(kv.second);
+  for (auto &kv : g_orphans) collect(kv.second);
+  std::sort(all.begin(), all.end(), [](const Victim &a, const Victim &b) { return a.at < b.at; });
+  {
+    size_t real = 0;
+    for (const Victim &v : all) real += v.size;
+    char what[160];
+    snprintf(what, sizeof(what), "temporary: cache over its bound: %.1f MB counted, %.1f MB in %zu blocks, bound %.1f MB", g_cachedBytes / 1e6, real / 1e6,
+             all.size(), bound / 1e6);
+    slow_trace(what, 0.0);
+  }
+  for (const Victim &v : all) {
+    if (g_cachedBytes <= bound / 4 * 3) break;
+    std::vector<void *> &bin = v.cache->bins[v.size];
+    auto it = std::find(bin.begin(), bin.end(), v.ptr);
+    if (it == bin.end()) continue;
+    bin.erase(it);
+    v.cache->bytes -= v.size;
+    g_cachedBytes -= v.size;
+    (void)hipFree(v.ptr);
+    g_blockSize.erase(v.ptr);
+    g_handedOut.erase(v.ptr);
+    g_releasedAt.erase(v.ptr);
+  }
+}
 
 void (*g_memNoteActivity)() = nullptr;  // AresMemNoteActivity of the sibling libmem.so (transform.hip resolves it)
 void (*g_memNoteWrite)(int, const void *, size_t) = nullptr;  // AresMemNoteWrite of the sibling libmem.so (transform.hip resolves it)
@@ -290,6 +338,7 @@ void *take_cached(StreamCache &c, size_t rounded, bool larger) {
   it->second.pop_back();
   c.bytes -= it->first;
   g_cachedBytes -= it->first;
+  g_releasedAt.erase(p);
   check_take(p);
   return p;
 }
@@ -354,8 +403,11 @@ void release_block(void *ptr, hipStream_t stream, bool idle) {
   c.bins[rounded].push_back(ptr);
   c.bytes += rounded;
   g_cachedBytes += rounded;
-  // keep the cache below an eighth of the device: drop everything when it outgrows that
+  g_releasedAt[ptr] = ++g_releases;
+  // keep the cache below an eighth of the device: the longest-cached blocks go when it outgrows that
   static const size_t cap = [] {
+    if (const char *e = getenv("ARES_TEMP_CACHE_MB"))  // (tests: a bound small enough for evictions to happen all the time)
+      if (atol(e) > 0) return static_cast<size_t>(atol(e)) << 20;
     size_t freeB = 0, totalB = 0;
     if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) {
       (void)hipGetLastError();
@@ -363,9 +415,21 @@ void release_block(void *ptr, hipStream_t stream, bool idle) {
     }
     return totalB / 8;
   }();
-  if (g_cachedBytes > cap) drop_all_cached();
+  if (g_cachedBytes > cap) evict_oldest_cached(cap);
 }
 }  // namespace
+
+void temp_stats(size_t *handedOut, size_t *cached) {
+  std::lock_guard<std::mutex> lock(g_cacheMutex);
+  size_t out = 0;
+  for (auto &kv : g_handedOut)
+    if (kv.second) {
+      auto it = g_blockSize.find(kv.first);
+      if (it != g_blockSize.end()) out += it->second;
+    }
+  if (handedOut) *handedOut = out;
+  if (cached) *cached = g_cachedBytes;
+}
 
 void stream_release(void *ptr, hipStream_t stream) { release_block(ptr, stream, false); }
 void stream_release_idle(void *ptr) { release_block(ptr, nullptr, true); }

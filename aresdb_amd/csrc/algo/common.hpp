@@ -112,6 +112,8 @@ bool virtual_iota_peek(int device, const uint32_t *indexVector, int n, bool cons
 void materialize_index_vector(int device, const uint32_t *indexVector);
 // ... and the same for every buffer of a dimension vector (dimension rows, hash vector, index vector), lazy fills included
 void settle_dimension_vector(int device, const DimensionVector &v, bool rowsOnly = false);
+// bytes of stream temporaries handed out / cached (AresTempStats)
+void temp_stats(size_t *handedOut, size_t *cached);
 
 // The stream of the entry point the calling thread is executing.  Work that was DEFINED on another stream (a lazy
 // fill, a lazy iota, a lazy compaction) and is written on that stream at one of this call's flush points is waited for

@@ -1040,6 +1040,23 @@ static void begin_batch(int device, hipStream_t stream, const uint32_t *indexVec
     }
     t_state->compactions.erase(indexVector);  // the vector is redefined
     t_state->expansions.erase({device, stream});  // (what still reads a decoded column keeps it alive itself)
+    {  // ARES_RTC_TRACE (diagnostics): who holds decoded run-length columns when a batch begins
+      static int calls = 0;
+      if ((++calls & 15) == 0) {
+        size_t j = 0, jn = 0, c = 0, cn = 0, p = 0, l = 0, e = 0;
+        for (auto &kv : t_state->journals) { jn++; j += kv.second.keep.size(); }
+        for (auto &kv : t_state->compactions) { cn++; for (auto &t : kv.second.todo) c += t.keep ? 1 : 0; }
+        for (auto &kv : t_state->pending) p += kv.second.keep.size();
+        for (auto &kv : t_state->limbo) l += kv.second.keep.size();
+        for (auto &kv : t_state->expansions) e += kv.second.size();
+        if (j + c + p + l + e > 16) {
+          char what[200];
+          snprintf(what, sizeof(what), "decoded columns held at begin_batch: journals %zu (in %zu), compactions %zu (in %zu), pending %zu, limbo %zu, expansions %zu",
+                   j, jn, c, cn, p, l, e);
+          slow_trace(what, 0.0);
+        }
+      }
+    }
     drop_sort(indexVector);                   // ... and so is whatever a lazily defined Sort meant it to hold
     {  // the stream's filters of the batch that just ended are what the new batch's are predicted from
       FilterHistory &h = t_state->filterHistory[{device, stream}];
@@ -2495,6 +2512,8 @@ bool fuse_pending_into_hash_reduce(int device, hipStream_t stream, const Dimensi
     pq.jobs.count = 0;
     pq.reads.clear();
     pq.writes.clear();
+    pq.keep.clear();  // (the copy holds the decoded columns from here on: left in place they piled up, two per batch, for the life
+                      // of the stream — 86 GB after 143 archive batches — and every later copy of the queue took the pile along)
     pq.overWait = false;
     if (q.idx) {  // (decoded columns only the filters read live as long as the consumed queue does: the scan is launched below)
       auto jk = t_state->journals.find(q.idx);
@@ -2898,6 +2917,8 @@ bool fuse_pending_into_sort_reduce(int device, hipStream_t stream, const Dimensi
     pq.jobs.count = 0;
     pq.reads.clear();
     pq.writes.clear();
+    pq.keep.clear();  // (the copy holds the decoded columns from here on: left in place they piled up, two per batch, for the life
+                      // of the stream — 86 GB after 143 archive batches — and every later copy of the queue took the pile along)
     pq.overWait = false;
     if (q.idx) {  // (decoded columns only the filters read live as long as the consumed queue does: the scan is launched below)
       auto jk = t_state->journals.find(q.idx);
@@ -3061,6 +3082,8 @@ size_t AresStreamEvents(int device, void *stream) {
   for (const ErrorCheck &c : t_state->errorChecks) n += c.device == device && c.stream == reinterpret_cast<hipStream_t>(stream);
   return n;
 }
+
+void AresTempStats(size_t *handedOutBytes, size_t *cachedBytes) { temp_stats(handedOutBytes, cachedBytes); }
 
 void AresFlushDeferred(int device) {
   int current = 0;

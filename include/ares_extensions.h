@@ -129,6 +129,10 @@ void AresMemDriverCalls(int device, size_t *mallocs, size_t *frees, size_t *trim
 size_t AresMemStreamEvents(int device, void *stream);
 /* the same for libalgorithm.so: error-word watches of lazily launched compactions and unresolved profiler events */
 size_t AresStreamEvents(int device, void *stream);
+/* libalgorithm.so's stream temporaries (workspaces, decoded run-length columns, row hashes kept beside results): bytes handed
+ * out and not yet released, and bytes sitting in its cache.  A steady workload keeps the first bounded (tests: nothing may
+ * pile up batch after batch).  Either pointer may be NULL. */
+void AresTempStats(size_t *handedOutBytes, size_t *cachedBytes);
 
 /* Fused batch execution: filter -> dimension / measure projection -> hash reduction of ONE batch in
  * a single pass over the source columns, without the index / predicate / dimension vectors the

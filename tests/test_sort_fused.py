@@ -459,3 +459,31 @@ def test_scan_fed_path_declining_hands_over_to_the_wide_layout(shape, monkeypatc
     assert_same(got_read, want_read, shape.name)
     if _fusion_on() and os.environ.get("ARES_SORT_VECTORS", "1") != "0":
         assert any(k.startswith("sr_split_kernel") for k in kernels) and not any(k.startswith("radix_pass_kernel") for k in kernels), sorted(kernels)
+
+
+def _temp_stats(b):
+    import ctypes as C
+    out, cached = C.c_size_t(0), C.c_size_t(0)
+    b._algo.AresTempStats.argtypes, b._algo.AresTempStats.restype = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)], None
+    b._algo.AresTempStats(C.byref(out), C.byref(cached))
+    return out.value, cached.value
+
+
+@pytest.mark.parametrize("hash_reduce", [True, False], ids=["hash_reduce", "sort_reduce"])
+def test_decoded_columns_do_not_pile_up(hash_reduce):
+    """Regression (round 6): a consumed queue kept its list of decoded run-length columns, so every archive batch of a stream's
+    life stayed allocated (two 300 MB buffers per 64 Mi-row batch: 86 GB after 143 batches, and a hipMalloc per decode).  The
+    library's stream temporaries that are handed out must not grow with the number of batches."""
+    hip = H.hip_backend()
+    rng = np.random.default_rng(72)
+    shape = ARCHIVE_SUM if hash_reduce else ARCHIVE_COUNT
+    few = [make_archive_batch(rng, 20000) for _ in range(3)]
+    many = [make_archive_batch(rng, 20000) for _ in range(24)]
+    run_sequence(hip, shape, few, hash_reduce=hash_reduce)
+    hip.wait()
+    base, _ = _temp_stats(hip)
+    run_sequence(hip, shape, many, hash_reduce=hash_reduce)
+    hip.wait()
+    after, _ = _temp_stats(hip)
+    # (a decoded column of 20 000 rows is 80 KB + validity: 24 batches x 2 columns piling up would be ~4 MB)
+    assert after <= base + (1 << 20), (base, after)

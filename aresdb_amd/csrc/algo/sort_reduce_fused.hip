@@ -27,6 +27,12 @@
 //                          result) or re-evaluated from the source columns (batch rows), values stored: ascending hash order.
 // Float sums keep the real sort (their order of additions is observable), as does anything this path declines: more
 // groups than the partitions' tables hold, a skewed partition stream, a record whose hash equals the table's "empty" word.
+//
+// The same over rows that EXIST (a joined column, a generic expression, an eager host — or what the scan-fed path above
+// declined, after its transforms were launched): fused_sort_reduce_vectors at the end of this file, the "wide layout" —
+// sr_vector_scan_rtc into <= 512 level-1 partitions, sr_count_kernel / sr_prefix_kernel / sr_split_kernel into up to 2^17
+// partitions of about a thousand entries in runs of exactly their size, sr_merge_kernel<WIDE> (2048-slot tables, four
+// workgroups of 256 lanes per CU), sr_prefix_kernel, sr_emit_kernel<WIDE>.  50 M groups per call at C4's size.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

@@ -394,3 +394,23 @@ def test_random_programs_on_the_direct_kernels_with_table_images():
     # two consecutive fusable batches on the same result buffers — the "prealloc" profiles; a handful of the 140 programs:
     # tests/test_table_image.py and the scale-parity variants are where that path is exercised batch after batch)
     assert k.get("hr_scan_rtc", 0) > 40 and k.get("hr_merge_rtc", 0) > 40, k
+
+
+@pytest.mark.gpu
+def test_random_programs_on_the_wide_sort_layout_with_two_levels():
+    """ARES_SR_SCAN_FED=0 hands every Sort + Reduce of the "sort" profiles to the wide layout (rows written first), and
+    ARES_SRV_PART_BITS=11 gives the small fuzz batches what production-sized ones get: 512 level-1 partitions dealt out to 2048
+    (sr_count_kernel / sr_split_kernel with a fan-out of four), previous results found by their row hashes or hashed again —
+    130 programs, four threads, every block checked clean, hash / index vectors and output order observed by the profiles."""
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(H.ROOT, "tools", "stress_fuzz.py"), "--iters", "33", "--threads", "4", "--seeds", "130",
+                        "--profiles", "--kernels", "--tag", "wide"], cwd=H.ROOT,
+                       env={**os.environ, "ARES_MEM_VERIFY_CLEAN": "1", "ARES_SR_SCAN_FED": "0", "ARES_SRV_PART_BITS": "11"},
+                       capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+    rep = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rep["mismatches"] == 0 and rep["errors"] == 0 and rep["programs"] >= 130, rep
+    k = rep["kernels"] or {}
+    assert k.get("sr_split_kernel", 0) > 40 and k.get("sr_merge_kernel", 0) > 40, k

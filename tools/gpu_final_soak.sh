@@ -7,3 +7,6 @@ timeout 330 python tools/stress_fuzz.py --iters 1100 --threads 4 --seeds 4400 --
 echo "soak rc $?"; tail -c 1200 gpurun_out/final_soak.json
 ARES_LEAN_MIN_GROUPS=0 ARES_MIN_PART_BITS=2 timeout 200 python tools/stress_fuzz.py --iters 400 --threads 4 --seeds 1600 --profiles --kernels --budget-s 70 --tag final_image_soak > gpurun_out/final_image_soak.json 2> gpurun_out/final_image_soak.err
 echo "image soak rc $?"; tail -c 1500 gpurun_out/final_image_soak.json
+# round 6: every Sort + Reduce of the "sort" profiles through the wide layout with two partition levels, blocks checked clean
+ARES_MEM_VERIFY_CLEAN=1 ARES_SR_SCAN_FED=0 ARES_SRV_PART_BITS=11 timeout 200 python tools/stress_fuzz.py --iters 400 --threads 4 --seeds 1600 --profiles --kernels --budget-s 70 --tag final_wide_soak > gpurun_out/final_wide_soak.json 2> gpurun_out/final_wide_soak.err
+echo "wide soak rc $?"; tail -c 1500 gpurun_out/final_wide_soak.json

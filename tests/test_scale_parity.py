@@ -60,6 +60,10 @@ C3_VARIANTS = [
                                         "--sort-path", "sum"]),
     ("sort_path_count_live_batches", {}, LIVE + ["--streams", "2", "--sort-path", "count"]),
     ("sort_path_count_real_sort", {"ARES_SORT_FUSE": "0"}, MID + ["--sort-path", "count"]),
+    # ... and with the scan-fed path declining everything: the transforms are launched and the groups ordered over the rows they
+    # wrote (the wide layout: two partition levels at this size, ~26 rows per group and batch, the previous result found by
+    # the row hashes kept beside it)
+    ("sort_path_count_materialised_rows", {"ARES_SR_SCAN_FED": "0"}, BIG + ["--streams", "2", "--sort-path", "count"]),
 ]
 
 
@@ -81,6 +85,8 @@ def test_c3_key_level_parity_at_scale(name, env, args):
         fused = any(k.startswith("sr_merge_kernel") for k in report["kernels"])
         sorted_rows = any(k.startswith("radix_pass_kernel") for k in report["kernels"])
         assert (fused, sorted_rows) == ((False, True) if name.endswith("real_sort") else (True, False)), report["kernels"]
+        if name.endswith("materialised_rows"):
+            assert any(k.startswith("sr_split_kernel") for k in report["kernels"]) and not any(k.startswith("sr_scan_rtc") for k in report["kernels"])
 
 
 def test_c2_filter_count_at_spec_size():
